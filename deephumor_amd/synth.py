@@ -116,11 +116,19 @@ def synth_state_dict(reference_sd, seed=1234, logit_std=2.5):
             out[key] = _normal(seed, key, shape, gain * logit_std / (shape[1] ** 0.5))
             continue
         if key.endswith("classifier.bias"):
-            out[key] = _normal(seed, key, shape, 0.5)
+            t = _normal(seed, key, shape, 0.5)
+            # greedy decode (top_k=1) raises in the reference when <unk> (index 1) is the
+            # arg-max, because every logit is then filtered (beam.py:35-36); keep it unlikely
+            t[1] = -30.0
+            out[key] = t
             continue
         if ref.dim() == 2:  # generic Linear
             # trunk features have rms ~5: bring the image embeddings back to O(1)
             gain = 0.2 if key.endswith("encoder.linear.weight") and shape[1] == 2048 else 1.0
+            # post-LN residual stack: damp the sub-layer outputs so token/position/image
+            # information survives 6 layers instead of collapsing onto one repeated token
+            if key.endswith("fc_o.weight") or key.endswith("fc_2.weight"):
+                gain = 0.3
             out[key] = _normal(seed, key, shape, gain / (shape[1] ** 0.5))
             continue
         if ref.dim() == 1:  # generic bias

@@ -1,0 +1,227 @@
+"""Generates ``tests/golden/*`` by running the REAL reference (``/root/reference``) in the build
+container.  TEST INFRASTRUCTURE ONLY; cannot run on the GPU box (no reference there) and is not
+needed there: the fixtures it writes are committed.
+
+    python oracle/make_golden.py            # rewrites tests/golden/
+
+The reference imports torchvision (encoders.py:4), which is absent here, so
+``oracle/_standin`` (our own ResNet-50 definition, torchvision naming) is put on ``sys.path``
+first.  Weights and images come from ``deephumor_amd.synth`` (pure functions of seed + name).
+Fixtures are data only: inputs are regenerated from seeds, expected outputs are stored.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, os.path.join(HERE, "_standin"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+
+from deephumor.models import (CaptioningLSTM, CaptioningLSTMWithLabels, CaptioningTransformer,   # noqa: E402
+                              CaptioningTransformerBase, ImageEncoder, TransformerDecoder)
+from deephumor.models.beam import BeamSearchHelper                                              # noqa: E402
+from deephumor.models.encoders import LabelEncoder                                              # noqa: E402
+from deephumor_amd.synth import load_synthetic, synth_images                                    # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+SEED = 1234
+V_SMALL = 1000
+V_WORD = 36541          # deephumor_demo.ipynb:524
+
+
+class _WithLabelsTransformer(torch.nn.Module):
+    """BASELINE config 5 composition, assembled from reference modules."""
+
+    def __init__(self, num_tokens, hid_dim=512, n_layers=6, n_heads=8, pf_dim=2048, max_len=128):
+        super().__init__()
+        enc = torch.nn.Module()
+        enc.image_encoder = ImageEncoder(hid_dim, 0.3, spatial_features=True)
+        enc.label_encoder = LabelEncoder(num_tokens, hid_dim, 0.3)
+        enc.linear = torch.nn.Linear(2 * hid_dim, hid_dim)
+        self.encoder = enc
+        self.decoder = TransformerDecoder(num_tokens, hid_dim, n_layers, n_heads, pf_dim, 0.1, 0, max_len)
+
+    def _start(self, images, labels):
+        emb, spatial = self.encoder.image_encoder(images)
+        start = self.encoder.linear(torch.cat([emb, self.encoder.label_encoder(labels)], dim=1))
+        return start, spatial
+
+    def forward(self, images, captions, lengths, labels):
+        start, spatial = self._start(images, labels)
+        return self.decoder(captions, enc_out=spatial, start_emb=start)
+
+    def generate(self, image, label, **kw):
+        start, spatial = self._start(image, label)
+        return self.decoder.generate(start, spatial, **kw)
+
+
+def build(kind, v):
+    cls = {"CaptioningLSTM": CaptioningLSTM, "CaptioningLSTMWithLabels": CaptioningLSTMWithLabels,
+           "CaptioningTransformerBase": CaptioningTransformerBase, "CaptioningTransformer": CaptioningTransformer,
+           "CaptioningTransformerWithLabels": _WithLabelsTransformer}[kind]
+    return load_synthetic(cls(v).eval(), seed=SEED)
+
+
+def captions_and_lengths(v):
+    g = np.random.Generator(np.random.Philox(key=[SEED, 77]))
+    cap = torch.from_numpy(g.integers(6, v, size=(4, 31)).astype(np.int64))
+    lengths = torch.tensor([32, 20, 32, 11])          # valid inputs incl. the image slot
+    for r, n in enumerate(lengths.tolist()):
+        cap[r, n - 1:] = 0
+    labels = torch.from_numpy(g.integers(6, v, size=(4, 3)).astype(np.int64))
+    return cap, lengths, labels
+
+
+class _LogitTap:
+    """Captures the classifier output of every decoder call (pre-filter: cloned before
+    BeamSearchHelper.filter_top_k mutates it in place, beam.py:36)."""
+
+    def __init__(self, model):
+        self.rows = []
+        self.handle = model.decoder.classifier.register_forward_hook(lambda m, i, o: self.rows.append(o.detach().clone()))
+
+    def close(self):
+        self.handle.remove()
+
+
+def greedy_with_margins(model, kind, image, label, caption, max_len=32):
+    tap = _LogitTap(model)
+    kw = dict(caption=caption, max_len=max_len, beam_size=1, top_k=1)
+    with torch.no_grad():
+        ids = model.generate(image, label, **kw) if "WithLabels" in kind else model.generate(image, **kw)
+    tap.close()
+    pos0 = 0 if caption is None else caption.size(1)
+    margins, top1 = [], []
+    for step, out in enumerate(tap.rows):
+        row = out[0] if out.dim() == 2 else out[0, pos0 + step]
+        t = torch.topk(row, 2)
+        margins.append(float(t.values[0] - t.values[1]))
+        top1.append(int(t.indices[0]))
+    return ids.reshape(-1).numpy(), np.array(margins, np.float32), np.array(top1, np.int64)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    images = synth_images(4, seed=0)
+    meta = {"seed": SEED, "v_small": V_SMALL, "v_word": V_WORD, "torch": torch.__version__, "models": {}}
+
+    # ---- G1: encoder ------------------------------------------------------------------
+    g1 = {}
+    for e in (256, 512):
+        enc = ImageEncoder(e, 0.3, spatial_features=(e == 512)).eval()
+        holder = torch.nn.Module()
+        holder.encoder = enc
+        load_synthetic(holder, seed=SEED)
+        with torch.no_grad():
+            x = images
+            for i, mod in enumerate(enc.resnet):
+                x = mod(x)
+                if i >= 3:
+                    g1[f"e{e}_stage{i}_mean"] = np.float32(x.mean())
+                    g1[f"e{e}_stage{i}_absmean"] = np.float32(x.abs().mean())
+            g1[f"e{e}_features_slice"] = x[:, :64].numpy().copy()
+            out = enc(images)
+        if e == 512:
+            g1["e512_emb"], g1["e512_spatial"] = out[0].numpy(), out[1].numpy()
+        else:
+            g1["e256_emb"] = out.numpy()
+    np.savez_compressed(os.path.join(OUT, "g1_encoder.npz"), **g1)
+
+    cap, lengths, labels = captions_and_lengths(V_SMALL)
+    prefix = torch.tensor([[17, 230, 45]])
+    for kind in ("CaptioningLSTM", "CaptioningLSTMWithLabels", "CaptioningTransformerBase",
+                 "CaptioningTransformer", "CaptioningTransformerWithLabels"):
+        model = build(kind, V_SMALL)
+        sd = model.state_dict()
+        meta["models"][kind] = {"hp": getattr(model, "_hp", None),
+                                "keys": {k: list(v.shape) for k, v in sd.items()}}
+        rec = {}
+        # ---- G2: teacher-forced forward logits (first two images stored in full) ---------
+        with torch.no_grad():
+            if "WithLabels" in kind:
+                logits = model(images, cap, lengths, labels)
+            else:
+                logits = model(images, cap, lengths)
+        rec["forward_shape"] = np.array(logits.shape)
+        rec["forward_logits01"] = logits[:2].numpy()
+        rec["forward_rowsum"] = logits.sum(-1).numpy()
+        rec["forward_argmax"] = logits.argmax(-1).numpy()
+        # ---- G3: greedy ids + margins -----------------------------------------------------
+        for i in range(4):
+            lab = labels[i:i + 1] if "WithLabels" in kind else None
+            for tag, pre in (("", None), ("_prefix", prefix)):
+                ids, margins, top1 = greedy_with_margins(model, kind, images[i:i + 1], lab, pre)
+                rec[f"greedy{tag}_{i}"], rec[f"greedy{tag}_margin_{i}"], rec[f"greedy{tag}_top1_{i}"] = ids, margins, top1
+        # ---- G5: stochastic beam replay (torch CPU RNG stream) ----------------------------
+        for i in range(2):
+            lab = labels[i:i + 1] if "WithLabels" in kind else None
+            torch.manual_seed(100 + i)
+            kw = dict(max_len=12, beam_size=3, top_k=20, temperature=1.3)
+            with torch.no_grad():
+                ids = model.generate(images[i:i + 1], lab, **kw) if "WithLabels" in kind else model.generate(images[i:i + 1], **kw)
+            rec[f"beam_{i}"] = ids.reshape(-1).numpy()
+        # ---- EOS behaviour: force EOS as the arg-max token ---------------------------------
+        with torch.no_grad():
+            model.decoder.classifier.bias[3] += 100.0
+            lab = labels[:1] if "WithLabels" in kind else None
+            kw = dict(max_len=8, beam_size=1, top_k=1)
+            ids = model.generate(images[:1], lab, **kw) if "WithLabels" in kind else model.generate(images[:1], **kw)
+            rec["forced_eos"] = ids.reshape(-1).numpy()
+            rec["forced_eos_ndim"] = np.array(ids.dim())
+            model.decoder.classifier.bias[3] -= 100.0
+        np.savez_compressed(os.path.join(OUT, f"g2g3_{kind}.npz"), **rec)
+        print(kind, "forward", tuple(logits.shape), "greedy0", rec["greedy_0"][:10],
+              "min margin", min(float(rec[f'greedy_margin_{i}'].min()) for i in range(4)))
+
+    # ---- G3 at the word vocabulary (BASELINE configs C1-C3) -----------------------------
+    for kind in ("CaptioningLSTM", "CaptioningTransformer"):
+        model = build(kind, V_WORD)
+        rec = {}
+        for i in range(4):
+            ids, margins, top1 = greedy_with_margins(model, kind, images[i:i + 1], None, None)
+            rec[f"greedy_{i}"], rec[f"greedy_margin_{i}"], rec[f"greedy_top1_{i}"] = ids, margins, top1
+        np.savez_compressed(os.path.join(OUT, f"g3_word_{kind}.npz"), **rec)
+        print(kind, "V=36541 greedy0", rec["greedy_0"][:10],
+              "min margin", min(float(rec[f'greedy_margin_{i}'].min()) for i in range(4)))
+
+    # ---- G4: BeamSearchHelper unit vectors --------------------------------------------------
+    g4 = {}
+    h = BeamSearchHelper(temperature=1.0, beam_size=3, top_k=4, device="cpu")
+    lg = torch.tensor([[0.5, 9.0, 3.0, 3.0, 2.0, 3.0, -1.0, 2.5],       # unk(1) is the max; tie at the 4th value
+                       [4.0, 0.0, 4.0, 1.0, 4.0, 4.0, 4.0, -2.0],       # 5-way tie at the threshold
+                       [-3.0, -2.0, -1.0, 0.0, 1.0, 2.0, 3.0, 4.0]])
+    g4["filter_in"] = lg.numpy().copy()
+    g4["filter_out"] = h.filter_top_k(lg.clone()).numpy()
+    g = np.random.Generator(np.random.Philox(key=[SEED, 99]))
+    lg = torch.from_numpy(g.standard_normal(size=(3, 40)).astype(np.float32) * 2)
+    lg[2, 3] = 30.0                                  # beam 2 will pick EOS first
+    seqs = torch.tensor([[7, 8], [9, 3], [11, 12]])
+    vals = torch.tensor([-0.5, -1.0, -2.0])
+    h = BeamSearchHelper(temperature=0.7, beam_size=3, top_k=5, device="cpu")
+    h.has_ended = torch.tensor([False, True, False])
+    torch.manual_seed(7)
+    (ps, pv), (ni, nv) = h.process_logits(lg.clone(), seqs, vals)
+    g4.update(pl_logits=lg.numpy(), pl_seqs=seqs.numpy(), pl_vals=vals.numpy(), pl_prev_seqs=ps.numpy(),
+              pl_prev_vals=pv.numpy(), pl_new_ind=ni.numpy(), pl_new_val=nv.numpy(), pl_has_ended=h.has_ended.numpy())
+    # multinomial == top-k of p / Exp(1) noise drawn with the same generator state
+    p = torch.softmax(torch.from_numpy(g.standard_normal(size=(3, 50)).astype(np.float32)), -1)
+    torch.manual_seed(11)
+    picks = torch.multinomial(p, 4)
+    torch.manual_seed(11)
+    q = torch.empty_like(p).exponential_(1)
+    g4.update(mn_p=p.numpy(), mn_picks=picks.numpy(), mn_noise=q.numpy())
+    np.savez_compressed(os.path.join(OUT, "g4_beam_helper.npz"), **g4)
+
+    with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("wrote", OUT)
+
+
+if __name__ == "__main__":
+    main()

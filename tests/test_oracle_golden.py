@@ -1,0 +1,123 @@
+"""Pins the CPU oracle (oracle/ref_path.py) against golden vectors recorded from the REAL
+reference by oracle/make_golden.py.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_path as R
+from helpers import KINDS, PREFIX, captions_and_lengths, golden, synthetic_sd, synth_images
+
+TOL = 1e-5     # same ops in (almost) the same order as the reference
+
+
+@pytest.fixture(scope="module")
+def images():
+    return synth_images(4, seed=0)
+
+
+def test_g1_encoder(images):
+    g = golden("g1_encoder.npz")
+    sd, _ = synthetic_sd("CaptioningLSTM")
+    with torch.no_grad():
+        taps = {}
+        feats = R.resnet50_trunk(sd, "encoder.resnet", images, taps)
+        for idx in (4, 5, 6, 7):
+            assert abs(float(taps[f"stage{idx}"].mean()) - float(g[f"e256_stage{idx}_mean"])) < TOL
+            assert abs(float(taps[f"stage{idx}"].abs().mean()) - float(g[f"e256_stage{idx}_absmean"])) < TOL
+        np.testing.assert_allclose(feats[:, :64].numpy(), g["e256_features_slice"], atol=1e-4, rtol=1e-5)
+        emb = R.image_encoder(sd, "encoder", images, False)
+        np.testing.assert_allclose(emb.numpy(), g["e256_emb"], atol=TOL, rtol=1e-5)
+        # G1 was recorded on a bare ImageEncoder(512, spatial) holder: encoder.* keys only
+        from helpers import shapes_to_sd, synth_state_dict
+        full, _ = shapes_to_sd("CaptioningTransformer")
+        sd = synth_state_dict({k: v for k, v in full.items() if k.startswith("encoder.")}, seed=1234)
+        emb, spatial = R.image_encoder(sd, "encoder", images, True)
+        np.testing.assert_allclose(emb.numpy(), g["e512_emb"], atol=1e-4, rtol=1e-5)
+        np.testing.assert_allclose(spatial.numpy(), g["e512_spatial"], atol=TOL, rtol=1e-5)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_g2_forward_logits(kind, images):
+    g = golden(f"g2g3_{kind}.npz")
+    sd, hp = synthetic_sd(kind)
+    cap, lengths, labels = captions_and_lengths()
+    out = R.model_forward(kind, sd, hp, images, cap, lengths, labels if "WithLabels" in kind else None)
+    assert tuple(out.shape) == tuple(g["forward_shape"])
+    np.testing.assert_allclose(out[:2].numpy(), g["forward_logits01"], atol=2e-4, rtol=1e-5)  # explicit LSTM cell vs mkldnn: 2e-5 on |logit|<=30
+    np.testing.assert_allclose(out.sum(-1).numpy(), g["forward_rowsum"], atol=5e-3, rtol=1e-5)
+    assert (out.argmax(-1).numpy() == g["forward_argmax"]).mean() > 0.999
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_g3_greedy_ids(kind, images):
+    g = golden(f"g2g3_{kind}.npz")
+    sd, hp = synthetic_sd(kind)
+    _, _, labels = captions_and_lengths()
+    for i in range(4):
+        lab = labels[i:i + 1] if "WithLabels" in kind else None
+        for tag, pre in (("", None), ("_prefix", PREFIX)):
+            trace = []
+            ids = R.model_generate(kind, sd, hp, images[i:i + 1], label=lab, caption=pre, max_len=32,
+                                   beam_size=1, top_k=1, trace=trace)
+            assert ids.reshape(-1).tolist() == g[f"greedy{tag}_{i}"].tolist()
+            margins = np.array([float(t["top2_val"][0, 0] - t["top2_val"][0, 1]) for t in trace])
+            np.testing.assert_allclose(margins, g[f"greedy{tag}_margin_{i}"], atol=1e-4)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_g5_beam_rng_replay(kind, images):
+    """Stochastic beam search consumes the global CPU generator in the reference's order."""
+    g = golden(f"g2g3_{kind}.npz")
+    sd, hp = synthetic_sd(kind)
+    _, _, labels = captions_and_lengths()
+    for i in range(2):
+        lab = labels[i:i + 1] if "WithLabels" in kind else None
+        torch.manual_seed(100 + i)
+        ids = R.model_generate(kind, sd, hp, images[i:i + 1], label=lab, max_len=12, beam_size=3, top_k=20,
+                               temperature=1.3)
+        assert ids.reshape(-1).tolist() == g[f"beam_{i}"].tolist()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_forced_eos(kind, images):
+    """LSTM output includes EOS + one trailing 0; Transformer output excludes the terminator and a
+    first-step EOS does not end the beam (SURVEY.md 8(a) G-LSTM step 4 / G-TR steps 1,3)."""
+    g = golden(f"g2g3_{kind}.npz")
+    sd, hp = synthetic_sd(kind)
+    sd["decoder.classifier.bias"] = sd["decoder.classifier.bias"].clone()
+    sd["decoder.classifier.bias"][3] += 100.0
+    _, _, labels = captions_and_lengths()
+    ids = R.model_generate(kind, sd, hp, images[:1], label=labels[:1] if "WithLabels" in kind else None,
+                           max_len=8, beam_size=1, top_k=1)
+    assert ids.dim() == int(g["forced_eos_ndim"])
+    assert ids.reshape(-1).tolist() == g["forced_eos"].tolist()
+
+
+def test_g4_beam_helper():
+    g = golden("g4_beam_helper.npz")
+    book = R.BeamBook(1.0, 3, 4)
+    out = book.keep_top_k(torch.from_numpy(g["filter_in"].copy()))
+    np.testing.assert_array_equal(out.numpy(), g["filter_out"])
+    book = R.BeamBook(0.7, 3, 5)
+    book.ended = torch.tensor([False, True, False])
+    torch.manual_seed(7)
+    ps, pv, ni, nv, parent = book.expand(torch.from_numpy(g["pl_logits"].copy()), torch.from_numpy(g["pl_seqs"]),
+                                         torch.from_numpy(g["pl_vals"]))
+    np.testing.assert_array_equal(ps.numpy(), g["pl_prev_seqs"])
+    np.testing.assert_allclose(pv.numpy(), g["pl_prev_vals"].reshape(-1))
+    np.testing.assert_array_equal(ni.numpy(), g["pl_new_ind"])
+    np.testing.assert_allclose(nv.numpy(), g["pl_new_val"], atol=1e-6)
+    np.testing.assert_array_equal(book.ended.numpy(), g["pl_has_ended"])
+    assert parent.tolist() == [0, 0, 0, 1, 2, 2, 2]
+    # multinomial(p, k) without replacement == top-k of p / Exp(1) noise
+    q = torch.from_numpy(g["mn_p"]) / torch.from_numpy(g["mn_noise"])
+    np.testing.assert_array_equal(torch.topk(q, 4, dim=-1).indices.numpy(), g["mn_picks"])
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_g3_word_vocab(kind, images):
+    g = golden(f"g3_word_{kind}.npz")
+    sd, hp = synthetic_sd(kind, v=36541)
+    for i in range(2):
+        ids = R.model_generate(kind, sd, hp, images[i:i + 1], max_len=32, beam_size=1, top_k=1)
+        assert ids.reshape(-1).tolist() == g[f"greedy_{i}"].tolist()
