@@ -1,0 +1,300 @@
+// Device-side beam-search step (deephumor/models/beam.py), batched over images: no host sync and no
+// torch.multinomial in the token loop.
+//   beam_row_sample : per (image, beam) row -- k-th-largest threshold by 4-pass radix select over the
+//                     logits row (L2-resident after the vocabulary GEMM wrote it), survivor
+//                     compaction into LDS, temperature softmax, Exp(1)-race draw of `beam` tokens
+//                     (== CPU torch.multinomial without replacement), log-softmax over the picks.
+//   beam_select     : per image -- candidate list with ended-beam dedup, second race, in-place
+//                     rewrite of tokens / scores / ended flags / KV-ancestor table / parent rows.
+//   beam_finalize   : per image -- final single draw and output copy.
+#include "common.h"
+
+#define CAP DH_BEAM_MAX_SURVIVORS
+
+// order-preserving float -> uint key (larger float <=> larger key)
+__device__ __forceinline__ uint32_t f2key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ float block_reduce_256(float v, float* red, bool is_max) {
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = is_max ? fmaxf(red[tid], red[tid + s]) : red[tid] + red[tid + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void beam_row_sample_kernel(
+    const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
+    float temperature, int unk, const float* __restrict__ noise, uint64_t seed, int img0, int step,
+    int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
+    __shared__ int hist[4][256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_k, s_cnt;
+    __shared__ int idx_a[CAP], idx_b[CAP];
+    __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
+    __shared__ float red[256];
+    __shared__ int picks[DH_BEAM_MAX_BEAMS];
+
+    const int rc = blockIdx.x, tid = threadIdx.x, wave = tid >> 6;
+    const float* row = logits + (size_t)rc * ldl;
+
+    // ---- k-th largest by MSB-first radix select on the order-preserving key --------------------
+    if (tid == 0) { s_prefix = 0u; s_k = top_k; s_cnt = 0; }
+    uint32_t mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 1024; i += 256) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        for (int i = tid; i < V; i += 256) {
+            const uint32_t key = f2key(row[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int k = s_k, cum = 0, d = 255;
+            for (; d > 0; --d) {
+                const int c = hist[0][d] + hist[1][d] + hist[2][d] + hist[3][d];
+                if (cum + c >= k) break;
+                cum += c;
+            }
+            s_k = k - cum;
+            s_prefix = prefix | ((uint32_t)d << shift);
+        }
+        mask |= 0xFFu << shift;
+        __syncthreads();
+    }
+    const uint32_t thr = s_prefix;
+
+    // ---- survivors: logit >= threshold (ties kept, beam.py:34), unk always dropped (:35) -------
+    for (int i = tid; i < V; i += 256) {
+        const float v = row[i];
+        if (f2key(v) >= thr && i != unk) {
+            const int p = atomicAdd(&s_cnt, 1);
+            if (p < CAP) { idx_a[p] = i; val_a[p] = v; }
+        }
+    }
+    __syncthreads();
+    int n = s_cnt;
+    if (n > CAP) { if (tid == 0) atomicOr(err, DH_BEAM_ERR_OVERFLOW); n = CAP; }
+    if (n == 0) {
+        if (tid == 0) atomicOr(err, DH_BEAM_ERR_ALL_FILTERED);
+        if (tid < beam) { pick_idx[(size_t)rc * beam + tid] = 0; pick_val[(size_t)rc * beam + tid] = 0.f; }
+        return;
+    }
+    // deterministic order: sort by token index (rank sort, n is ~top_k)
+    for (int i = tid; i < n; i += 256) {
+        const int me = idx_a[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (idx_a[j] < me);
+        idx_b[r] = me; val_b[r] = val_a[i];
+    }
+    __syncthreads();
+
+    // ---- p = softmax(filtered / T);  q = p / Exp(1) noise -------------------------------------
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += 256) m = fmaxf(m, val_b[i] / temperature);
+    m = block_reduce_256(m, red, true);
+    float s = 0.f;
+    for (int i = tid; i < n; i += 256) { const float e = expf(val_b[i] / temperature - m); qv[i] = e; s += e; }
+    s = block_reduce_256(s, red, false);
+    const int img = rc / rows_per_img, rin = rc % rows_per_img;
+    for (int i = tid; i < n; i += 256) {
+        const float nz = noise ? noise[(size_t)rc * ldl + idx_b[i]]
+                               : philox_exp1(seed, (uint32_t)(img0 + img), (uint32_t)step, 0u, (uint32_t)rin, (uint32_t)idx_b[i]);
+        qv[i] = (qv[i] / s) / nz;
+    }
+    if (tid < DH_BEAM_MAX_BEAMS) picks[tid] = -1;
+    __syncthreads();
+    // top-`beam` of q, descending; ties -> lower token index first (argmax semantics for beam == 1)
+    for (int i = tid; i < n; i += 256) {
+        const float me = qv[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (qv[j] > me) || (qv[j] == me && j < i);
+        if (r < beam) picks[r] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (n < beam) atomicOr(err, DH_BEAM_ERR_TOO_FEW);
+        // log_softmax over the gathered (un-tempered) logits of the picks (beam.py:79)
+        float mx = -INFINITY;
+        for (int b = 0; b < beam; ++b) if (picks[b] >= 0) mx = fmaxf(mx, val_b[picks[b]]);
+        float se = 0.f;
+        for (int b = 0; b < beam; ++b) if (picks[b] >= 0) se += expf(val_b[picks[b]] - mx);
+        const float lse = logf(se);
+        for (int b = 0; b < beam; ++b) {
+            const int pi = picks[b];
+            pick_idx[(size_t)rc * beam + b] = pi >= 0 ? idx_b[pi] : 0;
+            pick_val[(size_t)rc * beam + b] = pi >= 0 ? (val_b[pi] - mx) - lse : -INFINITY;
+        }
+    }
+}
+
+extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,
+                                  int top_k, float temperature, int unk_index, const float* noise,
+                                  uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
+                                  int32_t* err, void* stream) {
+    DH_REQUIRE(logits && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
+    DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
+    hipLaunchKernelGGL(beam_row_sample_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
+                       rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step, pick_idx,
+                       pick_val, err);
+    DH_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+struct SelectParams {
+    const int32_t* pick_idx; const float* pick_val;
+    int32_t* tokens; int tok_ld; float* vals; uint8_t* ended; int32_t* src; int src_ld;
+    int32_t* parent; int32_t* hparent; uint8_t* done; int32_t* end_step;
+    int beam, first, first_sets_ended, write_pos, t, step_index, eos, img0;
+    float temperature; const float* noise; uint64_t seed;
+};
+
+__global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
+    extern __shared__ int32_t stage[];                  // [beam][tok_ld] tokens, then [beam][t] ancestors
+    __shared__ int ctok[256], cpar[256], keep[DH_BEAM_MAX_BEAMS];
+    __shared__ float cval[256], q[256];
+    __shared__ uint8_t cend[256];
+    __shared__ int s_n;
+    const int img = blockIdx.x, lane = threadIdx.x, B = p.beam, base = img * B;
+    if (p.done[img]) return;
+
+    if (lane == 0) {
+        int c = 0;
+        if (p.first) {
+            for (int j = 0; j < B; ++j, ++c) {
+                const int tok = p.pick_idx[(size_t)img * B + j];
+                ctok[c] = tok; cval[c] = p.pick_val[(size_t)img * B + j]; cpar[c] = 0;
+                cend[c] = (uint8_t)(p.first_sets_ended && tok == p.eos);
+                keep[j] = j;
+            }
+        } else {
+            for (int b = 0; b < B; ++b) {
+                const bool was = p.ended[base + b] != 0;
+                const float v0 = p.vals[base + b];
+                for (int j = 0; j < (was ? 1 : B); ++j, ++c) {
+                    const int tok = was ? 0 : p.pick_idx[(size_t)(base + b) * B + j];
+                    ctok[c] = tok;
+                    cval[c] = v0 + (was ? 0.f : p.pick_val[(size_t)(base + b) * B + j]);
+                    cpar[c] = b;
+                    cend[c] = (uint8_t)(was || tok == p.eos);
+                }
+            }
+        }
+        s_n = c;
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (!p.first) {
+        // draw `beam` candidates without replacement from softmax(cand_val / T)
+        float m = -INFINITY;
+        for (int c = lane; c < n; c += 64) m = fmaxf(m, cval[c] / p.temperature);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < n; c += 64) { const float e = expf(cval[c] / p.temperature - m); q[c] = e; s += e; }
+        s = wave_sum(s);
+        for (int c = lane; c < n; c += 64) {
+            const float nz = p.noise ? p.noise[(size_t)img * B * B + c]
+                                     : philox_exp1(p.seed, (uint32_t)(p.img0 + img), (uint32_t)p.step_index, 1u, 0u, (uint32_t)c);
+            q[c] = (q[c] / s) / nz;
+        }
+        __syncthreads();
+        for (int c = lane; c < n; c += 64) {
+            const float me = q[c];
+            int r = 0;
+            for (int j = 0; j < n; ++j) r += (q[j] > me) || (q[j] == me && j < c);
+            if (r < B) keep[r] = c;
+        }
+    }
+    // stage the image's token rows and ancestor rows, then rewrite them in place
+    int32_t* tokbuf = stage;
+    int32_t* srcbuf = stage + (size_t)B * p.tok_ld;
+    for (int i = lane; i < B * p.tok_ld; i += 64) tokbuf[i] = p.tokens[(size_t)base * p.tok_ld + i];
+    if (p.src)
+        for (int b = 0; b < B; ++b)
+            for (int j = lane; j < p.t; j += 64) srcbuf[b * p.t + j] = p.src[(size_t)(base + b) * p.src_ld + j];
+    __syncthreads();
+    int all_ended = 1;
+    for (int b = 0; b < B; ++b) {
+        const int c = keep[b], par = cpar[c];
+        for (int i = lane; i < p.tok_ld; i += 64)
+            p.tokens[(size_t)(base + b) * p.tok_ld + i] = (i == p.write_pos) ? ctok[c] : tokbuf[par * p.tok_ld + i];
+        if (p.src) {
+            for (int j = lane; j < p.t; j += 64) p.src[(size_t)(base + b) * p.src_ld + j] = srcbuf[par * p.t + j];
+            if (lane == 0) p.src[(size_t)(base + b) * p.src_ld + p.t] = base + par;
+        }
+        if (lane == 0) {
+            p.vals[base + b] = cval[c];
+            p.ended[base + b] = cend[c];
+            p.parent[base + b] = base + par;
+            p.hparent[base + b] = base + c / B;        // rnn_models.py:135-137: dense B*B layout index
+        }
+        all_ended &= cend[c];
+    }
+    if (lane == 0 && all_ended) { p.done[img] = 1; p.end_step[img] = p.step_index; }
+}
+
+extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* tokens, int tok_ld,
+                              float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent,
+                              int32_t* hparent, uint8_t* done, int32_t* end_step, int n_img, int beam,
+                              int first, int first_sets_ended, int write_pos, int t, int step_index,
+                              float temperature, int eos_index, const float* noise, uint64_t seed, int img0,
+                              void* stream) {
+    DH_REQUIRE(pick_idx && pick_val && tokens && vals && ended && parent && hparent && done && end_step);
+    DH_REQUIRE(n_img > 0 && beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && tok_ld > 0 && t >= 0 && temperature > 0.f);
+    DH_REQUIRE(!src || src_ld > t);
+    SelectParams p{pick_idx, pick_val, tokens, tok_ld, vals, ended, src, src_ld, parent, hparent, done, end_step,
+                   beam, first, first_sets_ended, write_pos, t, step_index, eos_index, img0, temperature, noise, seed};
+    const size_t lds = (size_t)beam * (tok_ld + (src ? t : 0)) * sizeof(int32_t);
+    hipLaunchKernelGGL(beam_select_kernel, dim3(n_img), dim3(64), lds, (hipStream_t)stream, p);
+    DH_LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void beam_finalize_kernel(
+    const int32_t* __restrict__ tokens, int tok_ld, const float* __restrict__ vals, const uint8_t* __restrict__ done,
+    const int32_t* __restrict__ end_step, int32_t* __restrict__ out, int out_ld, int32_t* __restrict__ out_len,
+    int beam, int len_bias_done, int full_len, int pad_index, float temperature, const float* __restrict__ noise,
+    uint64_t seed, int img0) {
+    const int img = blockIdx.x, lane = threadIdx.x, base = img * beam;
+    // ind = multinomial(softmax(vals / T), 1) == arg-max of p / Exp(1) (first index on ties)
+    float x = lane < beam ? vals[base + lane] / temperature : -INFINITY;
+    const float m = wave_max(x);
+    float e = lane < beam ? expf(x - m) : 0.f;
+    const float s = wave_sum(e);
+    float qq = -1.f;
+    if (lane < beam) {
+        const float nz = noise ? noise[(size_t)img * beam + lane]
+                               : philox_exp1(seed, (uint32_t)(img0 + img), 0xFFFFFFFFu, 2u, 0u, (uint32_t)lane);
+        qq = (e / s) / nz;
+    }
+    const float best = wave_max(qq);
+    const unsigned long long bal = __ballot(qq == best && lane < beam);
+    const int ind = __ffsll((long long)bal) - 1;
+    int len = done[img] ? end_step[img] + len_bias_done : full_len;
+    len = min(len, min(out_ld, tok_ld));
+    for (int i = lane; i < out_ld; i += 64)
+        out[(size_t)img * out_ld + i] = i < len ? tokens[(size_t)(base + ind) * tok_ld + i] : pad_index;
+    if (lane == 0) out_len[img] = len;
+}
+
+extern "C" int dh_beam_finalize(const int32_t* tokens, int tok_ld, const float* vals, const uint8_t* done,
+                                const int32_t* end_step, int32_t* out, int out_ld, int32_t* out_len,
+                                int n_img, int beam, int len_bias_done, int full_len, int pad_index,
+                                float temperature, const float* noise, uint64_t seed, int img0, void* stream) {
+    DH_REQUIRE(tokens && vals && done && end_step && out && out_len && n_img > 0);
+    DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && temperature > 0.f);
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3(n_img), dim3(64), 0, (hipStream_t)stream, tokens, tok_ld, vals,
+                       done, end_step, out, out_ld, out_len, beam, len_bias_done, full_len, pad_index,
+                       temperature, noise, seed, img0);
+    DH_LAUNCH_CHECK();
+}

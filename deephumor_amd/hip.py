@@ -1,0 +1,258 @@
+"""ctypes binding of ``include/deephumor_hip.h`` (the C-ABI of the gfx950 kernels).
+
+PyTorch is plumbing here: it owns device memory and the stream; every operation on the product
+path goes through ``libdeephumor_hip.so``.  There is NO CPU or eager-torch fallback: if the
+library cannot be loaded, importing a kernel raises ``RuntimeError``.
+"""
+import ctypes
+import os
+
+import torch
+
+from . import _build
+
+F32, BF16 = 0, 1
+ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
+MAX_BEAMS = 16
+
+_c = ctypes
+_P, _I, _F, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64
+
+# name -> argtypes, mirrors include/deephumor_hip.h line by line
+SIGNATURES = {
+    "dh_abi_version": [],
+    "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
+    "dh_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_avgpool_rows": [_P, _P, _I, _I, _I, _P],
+    "dh_nchw_to_rows": [_P, _P, _I, _I, _I, _I, _P],
+    "dh_label_mean": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dh_embed_rows": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "dh_add_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "dh_attn_self_decode": [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "dh_attn_cross_decode": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "dh_enc_key_mask": [_P, _P, _I, _I, _I, _P],
+    "dh_lstm_prepare": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dh_lstm_cell": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _I, _I, _P, _P, _P, _P],
+    "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
+                       _U64, _I, _P],
+    "dh_beam_finalize": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _U64, _I, _P],
+}
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Loads (building first if a compiler is present and sources are newer) the shared library."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path) or (_build.needs_build() and os.path.exists(_build._hipcc())):
+        try:
+            _build.build()
+        except Exception as e:  # pragma: no cover - depends on toolchain presence
+            if not os.path.exists(path):
+                raise RuntimeError(f"deephumor_amd: cannot build {path}: {e}") from e
+    if not os.path.exists(path):
+        raise RuntimeError(f"deephumor_amd: HIP extension missing at {path}; run `python __graft_entry__.py build`. "
+                           "There is no CPU fallback on the product path.")
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)             # AttributeError if the ABI lost a symbol
+        fn.argtypes = argtypes
+        fn.restype = _I
+    lib.dh_error_string.argtypes = [_I]
+    lib.dh_error_string.restype = _c.c_char_p
+    _lib = lib
+    return lib
+
+
+def _check(code, name):
+    if code != 0:
+        raise RuntimeError(f"{name} failed: {load().dh_error_string(code).decode()} (code {code})")
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("deephumor_amd kernels need CUDA(HIP) tensors; there is no CPU path "
+                               "(move the model and inputs to 'cuda')")
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------------------
+# thin tensor-level wrappers (shape checks live here; the library only sees pointers and sizes)
+# ------------------------------------------------------------------------------------------------
+def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad=0, out=None):
+    _dev(x, w, scale, shift, residual)
+    n, cin, h, wd = x.shape
+    cout, cin2, kh, kw = w.shape
+    assert cin == cin2 and x.is_contiguous() and w.is_contiguous()
+    ho, wo = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device)
+    _check(load().dh_conv2d_bn_act(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
+                                   n, cin, h, wd, cout, kh, kw, stride, pad, int(relu), _dt(x), _stream()),
+           "dh_conv2d_bn_act")
+    return out
+
+
+def maxpool3x3s2(x):
+    _dev(x)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=x.dtype, device=x.device)
+    _check(load().dh_maxpool3x3s2(_ptr(x), _ptr(out), n, c, h, w, _dt(x), _stream()), "dh_maxpool3x3s2")
+    return out
+
+
+def avgpool_rows(x):
+    """x [N, C, H, W] -> [N, C]"""
+    _dev(x)
+    n, c, h, w = x.shape
+    out = torch.empty((n, c), dtype=x.dtype, device=x.device)
+    _check(load().dh_avgpool_rows(_ptr(x), _ptr(out), n * c, h * w, _dt(x), _stream()), "dh_avgpool_rows")
+    return out
+
+
+def nchw_to_rows(x):
+    """x [N, C, H, W] -> [N, H*W, C]"""
+    _dev(x)
+    n, c, h, w = x.shape
+    out = torch.empty((n, h * w, c), dtype=x.dtype, device=x.device)
+    _check(load().dh_nchw_to_rows(_ptr(x), _ptr(out), n, c, h * w, _dt(x), _stream()), "dh_nchw_to_rows")
+    return out
+
+
+def label_mean(emb, labels, out):
+    """emb [V, E], labels int64 [N, L] -> out [N, E] view (row stride may exceed E)."""
+    _dev(emb, labels, out)
+    n, l = labels.shape
+    assert labels.dtype == torch.int64 and labels.is_contiguous() and out.stride(1) == 1
+    _check(load().dh_label_mean(_ptr(emb), _ptr(labels), _ptr(out), out.stride(0), n, l, emb.shape[1], _dt(emb),
+                                _stream()), "dh_label_mean")
+    return out
+
+
+def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None):
+    """a [M, K] (row stride may exceed K), w [N, K] -> [M, N]."""
+    _dev(a, w, bias, scale, shift, out)
+    m, k = a.shape
+    n, k2 = w.shape
+    assert k == k2 and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    assert out.shape == (m, n) and out.stride(1) == 1
+    _check(load().dh_linear(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(scale), _ptr(shift),
+                            _ptr(out), out.stride(0), m, n, k, int(relu), _dt(a), _stream()), "dh_linear")
+    return out
+
+
+def embed_rows(tok_emb, pos_emb, start_emb, tokens, x, rows, rows_per_img, row_mult, pos, scale):
+    _dev(tok_emb, pos_emb, start_emb, tokens, x)
+    d = tok_emb.shape[1]
+    _check(load().dh_embed_rows(_ptr(tok_emb), _ptr(pos_emb), _ptr(start_emb), _ptr(tokens),
+                                tokens.stride(0) if tokens is not None else 0, _ptr(x), rows, rows_per_img,
+                                row_mult, pos, d, float(scale), _dt(tok_emb), _stream()), "dh_embed_rows")
+    return x
+
+
+def add_layernorm(x, y, gamma, beta, out=None, eps=1e-5):
+    _dev(x, y, gamma, beta)
+    rows, d = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    _check(load().dh_add_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(out), rows, d, float(eps),
+                                   _dt(x), _stream()), "dh_add_layernorm")
+    return out
+
+
+def attn_self_decode(qkv, kcache, vcache, src, tokens, out, n_img, rows_per_img, row_mult, rows_total, t, d,
+                     n_heads, scale, pad_index):
+    _dev(qkv, kcache, vcache, src, tokens, out)
+    _check(load().dh_attn_self_decode(_ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(src), src.stride(0),
+                                      _ptr(tokens), tokens.stride(0), _ptr(out), n_img, rows_per_img, row_mult,
+                                      rows_total, t, d, n_heads, float(scale), pad_index, _dt(qkv), _stream()),
+           "dh_attn_self_decode")
+    return out
+
+
+def attn_cross_decode(q, kv, keymask, out, n_img, rows_per_img, s, d, n_heads, scale):
+    _dev(q, kv, keymask, out)
+    _check(load().dh_attn_cross_decode(_ptr(q), q.stride(0), _ptr(kv), _ptr(keymask), _ptr(out), n_img,
+                                       rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream()),
+           "dh_attn_cross_decode")
+    return out
+
+
+def enc_key_mask(enc_out):
+    """enc_out [rows, D] -> uint8 [rows]"""
+    _dev(enc_out)
+    rows, d = enc_out.shape
+    out = torch.empty((rows,), dtype=torch.uint8, device=enc_out.device)
+    _check(load().dh_enc_key_mask(_ptr(enc_out), _ptr(out), rows, d, _dt(enc_out), _stream()), "dh_enc_key_mask")
+    return out
+
+
+def lstm_prepare(emb, img_emb, tokens, tok_pos, hparent, h_prev, c_prev, xcat0, xcatl, c_cur, rows, rows_per_img,
+                 row_mult, rows_total, n_layers, e, hh):
+    _dev(emb, img_emb, tokens, hparent, h_prev, c_prev, xcat0, xcatl, c_cur)
+    _check(load().dh_lstm_prepare(_ptr(emb), _ptr(img_emb), _ptr(tokens),
+                                  tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(hparent),
+                                  _ptr(h_prev), _ptr(c_prev), _ptr(xcat0), _ptr(xcatl), _ptr(c_cur), rows,
+                                  rows_per_img, row_mult, rows_total, n_layers, e, hh, _dt(xcat0), _stream()),
+           "dh_lstm_prepare")
+
+
+def lstm_cell(gates, c_cur, h_new, c_new, h_out, ld_out, rows, row_mult, hh):
+    _dev(gates, c_cur, h_new, c_new, h_out)
+    _check(load().dh_lstm_cell(_ptr(gates), _ptr(c_cur), _ptr(h_new), _ptr(c_new), _ptr(h_out), ld_out, rows,
+                               row_mult, hh, _dt(gates), _stream()), "dh_lstm_cell")
+
+
+def beam_row_sample(logits, v, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step,
+                    pick_idx, pick_val, err):
+    _dev(logits, noise, pick_idx, pick_val, err)
+    assert logits.dtype == torch.float32
+    _check(load().dh_beam_row_sample(_ptr(logits), logits.stride(0), v, rows, rows_per_img, beam, top_k,
+                                     float(temperature), unk_index, _ptr(noise), seed, img0, step, _ptr(pick_idx),
+                                     _ptr(pick_val), _ptr(err), _stream()), "dh_beam_row_sample")
+
+
+def beam_select(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, n_img, beam, first,
+                first_sets_ended, write_pos, t, step_index, temperature, eos_index, noise, seed, img0):
+    _dev(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, noise)
+    _check(load().dh_beam_select(_ptr(pick_idx), _ptr(pick_val), _ptr(tokens), tokens.stride(0), _ptr(vals),
+                                 _ptr(ended), _ptr(src), src.stride(0) if src is not None else 0, _ptr(parent),
+                                 _ptr(hparent), _ptr(done), _ptr(end_step), n_img, beam, int(first),
+                                 int(first_sets_ended), write_pos, t, step_index, float(temperature), eos_index,
+                                 _ptr(noise), seed, img0, _stream()), "dh_beam_select")
+
+
+def beam_finalize(tokens, vals, done, end_step, out, out_len, n_img, beam, len_bias_done, full_len, pad_index,
+                  temperature, noise, seed, img0):
+    _dev(tokens, vals, done, end_step, out, out_len, noise)
+    _check(load().dh_beam_finalize(_ptr(tokens), tokens.stride(0), _ptr(vals), _ptr(done), _ptr(end_step),
+                                   _ptr(out), out.stride(0), _ptr(out_len), n_img, beam, len_bias_done, full_len,
+                                   pad_index, float(temperature), _ptr(noise), seed, img0, _stream()),
+           "dh_beam_finalize")

@@ -1,0 +1,103 @@
+"""Batched, device-resident beam-search bookkeeping.
+
+Mirror of ``deephumor.models.beam.BeamSearchHelper`` (reference beam.py:4-112): same constructor
+arguments and the same selection rules, but the state of ALL images of a batch lives in HBM and
+every step is two kernel launches (``dh_beam_row_sample`` + ``dh_beam_select``) with no host
+synchronisation, instead of per-image torch ops and a ``torch.all`` sync per token.
+
+Randomness: the reference draws with ``torch.multinomial`` from the global CPU generator.  On
+CPU that is exactly "top-k of p / Exp(1) noise" (SURVEY.md section 7), so the kernels take the
+noise either from a counter-based Philox stream keyed by ``(seed, global image index, step, row,
+token)`` -- results do not depend on batch composition or rank layout -- or, for RNG-replay parity
+tests, from caller-supplied tensors (``noise_source``).
+"""
+import torch
+
+from .. import hip
+
+
+class BeamSearchHelper:
+    """Beam state for ``n_img`` images x ``beam_size`` beams.
+
+    Reference signature kept: ``BeamSearchHelper(temperature, beam_size, top_k, unk_index,
+    eos_index, device)`` (beam.py:7-8); ``n_img``, ``max_len`` and the rest are new keyword arguments.
+    """
+
+    def __init__(self, temperature=1.0, beam_size=10, top_k=50, unk_index=1, eos_index=3, device='cuda',
+                 n_img=1, max_len=25, src_len=0, seed=0, img0=0, noise_source=None):
+        assert beam_size <= top_k, '`beam_size` should be less than `top_k`'          # beam.py:9
+        if beam_size > hip.MAX_BEAMS:
+            raise ValueError(f"beam_size <= {hip.MAX_BEAMS} supported")
+        self.temperature, self.beam_size, self.top_k = float(temperature), int(beam_size), int(top_k)
+        self.unk_index, self.eos_index, self.device = unk_index, eos_index, device
+        self.n_img, self.max_len = n_img, max_len
+        self.seed, self.img0, self.noise_source = int(seed), int(img0), noise_source
+        r = n_img * beam_size
+        dev = device
+        self.tokens = torch.zeros((r, max_len), dtype=torch.int32, device=dev)
+        self.vals = torch.zeros((r,), dtype=torch.float32, device=dev)
+        self.has_ended = torch.zeros((r,), dtype=torch.uint8, device=dev)
+        self.parent = torch.zeros((r,), dtype=torch.int32, device=dev)
+        self.hparent = torch.zeros((r,), dtype=torch.int32, device=dev)
+        self.done = torch.zeros((n_img,), dtype=torch.uint8, device=dev)
+        self.end_step = torch.zeros((n_img,), dtype=torch.int32, device=dev)
+        self.err = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.pick_idx = torch.empty((r, beam_size), dtype=torch.int32, device=dev)
+        self.pick_val = torch.empty((r, beam_size), dtype=torch.float32, device=dev)
+        # KV-cache ancestor table (Transformer only): src[r, j] = row holding position j of r's history
+        self.src = None
+        if src_len:
+            base = (torch.arange(r, dtype=torch.int32, device=dev) // beam_size) * beam_size
+            self.src = base[:, None].expand(r, src_len).contiguous()
+
+    def set_prefix(self, caption):
+        """caption int64 [n_img, p]: teacher-forced beginning, copied to every beam row."""
+        p = caption.shape[1]
+        self.tokens[:, :p] = caption.to(torch.int32).repeat_interleave(self.beam_size, dim=0)
+
+    def _noise(self, kind, step, shape):
+        if self.noise_source is None:
+            return None
+        t = self.noise_source(kind, step, shape)
+        return None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
+
+    def step(self, logits, first, write_pos, t, step_index, first_sets_ended=False):
+        """One beam step from ``logits`` ([n_img, V] if ``first`` else [n_img*beam, V]):
+        beam.py:55-108 + the caller-side candidate draw (rnn_models.py:116-128, transformers.py:557-569)."""
+        rows = logits.shape[0]
+        rpi = 1 if first else self.beam_size
+        assert rows == self.n_img * rpi
+        v = logits.shape[1]
+        hip.beam_row_sample(logits, v, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
+                            self._noise("row", step_index, (rows, v)), self.seed, self.img0, step_index,
+                            self.pick_idx, self.pick_val, self.err)
+        noise = None if first else self._noise("cand", step_index, (self.n_img, self.beam_size ** 2))
+        hip.beam_select(self.pick_idx, self.pick_val, self.tokens, self.vals, self.has_ended, self.src,
+                        self.parent, self.hparent, self.done, self.end_step, self.n_img, self.beam_size, first,
+                        first_sets_ended, write_pos, t, step_index, self.temperature, self.eos_index, noise,
+                        self.seed, self.img0)
+
+    def finalize(self, len_bias_done, full_len, pad_index=0):
+        """Final draw among the beams and output copy; returns (tokens int64 [n_img, max_len], lengths)."""
+        out = torch.empty((self.n_img, self.max_len), dtype=torch.int32, device=self.device)
+        out_len = torch.empty((self.n_img,), dtype=torch.int32, device=self.device)
+        hip.beam_finalize(self.tokens, self.vals, self.done, self.end_step, out, out_len, self.n_img, self.beam_size,
+                          len_bias_done, full_len, pad_index, self.temperature,
+                          self._noise("final", 0, (self.n_img, self.beam_size)), self.seed, self.img0)
+        self.check()
+        return out.long(), out_len.long()
+
+    def check(self):
+        """Raises like the reference does when every logit of a row was filtered (beam.py:46)."""
+        code = int(self.err.item())
+        if code & hip.ERR_ALL_FILTERED:
+            raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0 "
+                               "(every logit of a row was filtered: <unk> was the only top-k token)")
+        if code & hip.ERR_OVERFLOW:
+            raise RuntimeError("more than 1024 logits tie at the top-k threshold")
+        if code & hip.ERR_TOO_FEW:
+            raise RuntimeError("fewer positive-probability tokens than beams (top_k == beam_size with <unk> in the top-k)")
+
+    def all_ended(self):
+        """Host-visible early-exit test (one sync; callers poll it sparsely, not per token)."""
+        return bool(self.done.cpu().numpy().all())

@@ -1,0 +1,193 @@
+"""Image / label encoders on the gfx950 kernels.
+
+Drop-in for ``deephumor.models.encoders`` (reference encoders.py:7-144): same class names,
+constructor arguments, ``forward`` signatures and state-dict keys.  The modules below are
+parameter containers -- the arithmetic runs in ``libdeephumor_hip.so`` (``deephumor_amd.hip``),
+batched over images.  Inference only: like the reference's ``generate`` callers
+(deephumor_demo.ipynb:1134-1141) the model must be in ``eval()`` mode.
+"""
+import torch
+from torch import nn
+
+from .. import hip
+
+RESNET50_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
+
+
+def _require_eval(module, p):
+    if module.training and p > 0:
+        raise RuntimeError("deephumor_amd implements the inference path (eval mode); "
+                           "call model.eval() -- train-mode dropout is out of scope")
+
+
+class _Bottleneck(nn.Module):
+    """Parameter holder with torchvision's Bottleneck attribute names (conv1..bn3, downsample)."""
+
+    def __init__(self, inplanes, planes, stride, downsample):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        if downsample:
+            self.downsample = nn.Sequential(nn.Conv2d(inplanes, planes * 4, 1, stride=stride, bias=False),
+                                            nn.BatchNorm2d(planes * 4))
+        else:
+            self.downsample = None
+        self.stride = stride
+
+
+def _resnet50_trunk():
+    """Children 0..7 of the reference's ``self.resnet`` (encoders.py:37-38): conv1, bn1, relu,
+    maxpool, layer1..layer4 -- the 318 trunk tensors of the state dict."""
+    mods = [nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False), nn.BatchNorm2d(64),
+            nn.ReLU(inplace=True), nn.MaxPool2d(3, stride=2, padding=1)]
+    inplanes = 64
+    for planes, blocks, stride in RESNET50_STAGES:
+        stage = [_Bottleneck(inplanes, planes, stride, downsample=True)]
+        inplanes = planes * 4
+        stage += [_Bottleneck(inplanes, planes, 1, downsample=False) for _ in range(1, blocks)]
+        mods.append(nn.Sequential(*stage))
+    return nn.Sequential(*mods)
+
+
+def _bn_affine(bn):
+    """Eval-mode BatchNorm as y = x*scale + shift (applied in the kernel epilogue, weights untouched)."""
+    scale = (bn.weight.detach().float() / torch.sqrt(bn.running_var.detach().float() + bn.eps)).contiguous()
+    shift = (bn.bias.detach().float() - bn.running_mean.detach().float() * scale).contiguous()
+    return scale, shift
+
+
+class _Planned:
+    """Lazily derived device-side constants, rebuilt when any parameter/buffer changes."""
+
+    def _plan_key(self):
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def _get_plan(self):
+        key = self._plan_key()
+        if getattr(self, "_plan_cache", None) is None or self._plan_cache[0] != key:
+            object.__setattr__(self, "_plan_cache", (key, self._build_plan()))
+        return self._plan_cache[1]
+
+
+class ImageEncoder(nn.Module, _Planned):
+    """ResNet-50 image encoder (reference encoders.py:7-70).
+
+    ``forward(images[N,3,H,W])`` returns ``emb [N, emb_dim]`` or, with ``spatial_features``,
+    ``(emb, spatial_emb [N, k*k, emb_dim])``; the Linear is shared, BatchNorm1d only on the global
+    branch (encoders.py:61 vs :67).  The reference's ``pretrained=True`` download (encoders.py:34)
+    is not reproduced: weights come from ``load_state_dict`` / ``from_pretrained``.
+    """
+
+    def __init__(self, emb_dim=256, dropout=0.2, spatial_features=False):
+        super().__init__()
+        self.spatial_features = spatial_features
+        self.resnet = _resnet50_trunk()
+        for p in self.resnet.parameters():
+            p.requires_grad = False                       # encoders.py:35-36
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.linear = nn.Linear(2048, emb_dim)
+        self.bn = nn.BatchNorm1d(emb_dim)
+        self.dropout = nn.Dropout(dropout)
+
+    def _build_plan(self):
+        convs = []
+
+        def conv(c, bn, relu, residual=False):
+            s, b = _bn_affine(bn)
+            return dict(w=c.weight.detach().contiguous(), scale=s, shift=b, stride=c.stride[0],
+                        pad=c.padding[0], relu=relu, residual=residual)
+
+        stem = conv(self.resnet[0], self.resnet[1], True)
+        for stage in list(self.resnet)[4:]:
+            for blk in stage:
+                convs.append(dict(
+                    down=conv(blk.downsample[0], blk.downsample[1], False) if blk.downsample is not None else None,
+                    c1=conv(blk.conv1, blk.bn1, True), c2=conv(blk.conv2, blk.bn2, True),
+                    c3=conv(blk.conv3, blk.bn3, True, residual=True)))
+        s, b = _bn_affine(self.bn)
+        return dict(stem=stem, blocks=convs, bn_scale=s, bn_shift=b)
+
+    @staticmethod
+    def _conv(x, c, residual=None):
+        return hip.conv2d_bn_act(x, c["w"], c["scale"], c["shift"], residual=residual, relu=c["relu"],
+                                 stride=c["stride"], pad=c["pad"])
+
+    def features(self, images):
+        """Trunk output ``[N, 2048, H/32, W/32]`` (encoders.py:56)."""
+        plan = self._get_plan()
+        x = hip.maxpool3x3s2(self._conv(images.contiguous(), plan["stem"]))
+        for blk in plan["blocks"]:
+            idt = x if blk["down"] is None else self._conv(x, blk["down"])
+            y = self._conv(self._conv(x, blk["c1"]), blk["c2"])
+            x = self._conv(y, blk["c3"], residual=idt)
+        return x
+
+    def forward(self, images):
+        _require_eval(self, self.dropout.p)
+        plan = self._get_plan()
+        feats = self.features(images)
+        n = feats.shape[0]
+        w, b = self.linear.weight.detach(), self.linear.bias.detach()
+        emb = hip.linear(hip.avgpool_rows(feats), w, b, scale=plan["bn_scale"], shift=plan["bn_shift"])
+        if not self.spatial_features:
+            return emb
+        rows = hip.nchw_to_rows(feats)                                    # [N, k*k, 2048]
+        spatial = hip.linear(rows.view(-1, rows.shape[-1]), w, b).view(n, rows.shape[1], -1)
+        return emb, spatial
+
+
+class LabelEncoder(nn.Module):
+    """Mean label embedding (reference encoders.py:73-106)."""
+
+    def __init__(self, num_tokens, emb_dim=256, dropout=0.2):
+        super().__init__()
+        self.embedding = nn.Embedding(num_tokens, emb_dim)
+        self.dropout = nn.Dropout(dropout)
+
+    def forward(self, labels, out=None):
+        _require_eval(self, self.dropout.p)
+        w = self.embedding.weight.detach()
+        if out is None:
+            out = torch.empty((labels.shape[0], w.shape[1]), dtype=w.dtype, device=w.device)
+        return hip.label_mean(w, labels.contiguous(), out)
+
+
+class ImageLabelEncoder(nn.Module):
+    """Image + label encoder (reference encoders.py:109-144): Linear(cat[image_emb, label_emb])."""
+
+    def __init__(self, num_tokens, emb_dim=256, dropout=0.2):
+        super().__init__()
+        self.image_encoder = ImageEncoder(emb_dim, dropout)
+        self.label_encoder = LabelEncoder(num_tokens, emb_dim, dropout)
+        self.linear = nn.Linear(2 * emb_dim, emb_dim)
+        self.dropout = nn.Dropout(dropout)
+
+    def _combine(self, image_emb, labels):
+        n, e = image_emb.shape
+        both = torch.empty((n, 2 * e), dtype=image_emb.dtype, device=image_emb.device)
+        both[:, :e].copy_(image_emb)
+        self.label_encoder(labels, out=both[:, e:])
+        return hip.linear(both, self.linear.weight.detach(), self.linear.bias.detach())
+
+    def forward(self, images, labels):
+        _require_eval(self, self.dropout.p)
+        return self._combine(self.image_encoder(images), labels)
+
+
+class SpatialImageLabelEncoder(ImageLabelEncoder):
+    """BASELINE config 5 composition (no reference class): the image encoder
+    keeps its spatial branch, the start embedding is Linear(cat[global_emb, label_emb])."""
+
+    def __init__(self, num_tokens, emb_dim=512, dropout=0.2):
+        super().__init__(num_tokens, emb_dim, dropout)
+        self.image_encoder.spatial_features = True
+
+    def forward(self, images, labels):
+        _require_eval(self, self.dropout.p)
+        emb, spatial = self.image_encoder(images)
+        return self._combine(emb, labels), spatial

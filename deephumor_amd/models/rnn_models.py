@@ -1,0 +1,154 @@
+"""LSTM caption decoder on the gfx950 kernels.
+
+Drop-in for ``deephumor.models.rnn_models.LSTMDecoder`` (reference rnn_models.py:8-143): same
+constructor, ``forward(image_emb, captions, lengths)`` and ``generate(image_emb, caption, ...)``;
+``generate_batch`` is the new batched entry point (the reference is strictly one image per call,
+SURVEY.md section 2b).  One time step = ``dh_lstm_prepare`` (state/embedding gather incl. beam
+reorder) + per layer ``dh_linear`` (fused [x|h] gate GEMM on the matrix cores) + ``dh_lstm_cell``.
+"""
+import torch
+from torch import nn
+
+from .. import hip
+from .beam import BeamSearchHelper
+from .encoders import _Planned
+
+
+class LSTMDecoder(nn.Module, _Planned):
+    """LSTM-based decoder (reference rnn_models.py:8-26)."""
+
+    def __init__(self, num_tokens, emb_dim=256, hidden_size=512,
+                 num_layers=3, dropout=0.1, embedding=None):
+        super().__init__()
+        self.num_tokens = num_tokens
+        self.embedding = embedding if embedding is not None else nn.Embedding(num_tokens, emb_dim)
+        self.lstm = nn.LSTM(emb_dim, hidden_size, num_layers, batch_first=True,
+                            dropout=(0 if num_layers == 1 else dropout))
+        self.classifier = nn.Linear(hidden_size, num_tokens)
+
+    # -- derived constants: [W_ih | W_hh] per layer and the summed bias -------------------------
+    def _build_plan(self):
+        layers = []
+        for l in range(self.lstm.num_layers):
+            w = torch.cat([getattr(self.lstm, f"weight_ih_l{l}").detach(),
+                           getattr(self.lstm, f"weight_hh_l{l}").detach()], dim=1).contiguous()
+            b = (getattr(self.lstm, f"bias_ih_l{l}").detach() + getattr(self.lstm, f"bias_hh_l{l}").detach()).contiguous()
+            layers.append((w, b))
+        return dict(layers=layers, emb=self.embedding.weight.detach(),
+                    cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach())
+
+    def _check_mode(self):
+        if self.training and self.lstm.dropout > 0:
+            raise RuntimeError("deephumor_amd implements the inference path; call model.eval()")
+
+    class _State:
+        """Recurrent state of n_img*beam logical rows + per-step scratch (cached per row count)."""
+
+        def __init__(self, dec, n_img, beam, dev):
+            self.nl, self.hh, self.e = dec.lstm.num_layers, dec.lstm.hidden_size, dec.lstm.input_size
+            self.dev = dev
+            r = n_img * beam
+            self.h = torch.zeros((self.nl, r, self.hh), device=dev)
+            self.c = torch.zeros((self.nl, r, self.hh), device=dev)
+            self.started = False
+            self._scratch = {}
+
+        def scratch(self, rows):
+            if rows not in self._scratch:
+                nl, hh, e, dev = self.nl, self.hh, self.e, self.dev
+                self._scratch[rows] = dict(
+                    xcat0=torch.empty((rows, e + hh), device=dev),
+                    xcatl=torch.empty((max(nl - 1, 1), rows, 2 * hh), device=dev),
+                    c_cur=torch.empty((nl, rows, hh), device=dev),
+                    gates=torch.empty((rows, 4 * hh), device=dev),
+                    hout=torch.empty((rows, hh), device=dev))
+            return self._scratch[rows]
+
+    def _step(self, plan, st, rows, rpi, mult, rows_total, img_emb=None, tokens=None, tok_pos=0, hparent=None,
+              hout=None):
+        """One LSTM time step for ``rows`` compact rows; returns the top layer's h ``[rows, Hh]``."""
+        nl, hh, e = st.nl, st.hh, st.e
+        sc = st.scratch(rows)
+        xcat0, xcatl, c_cur, gates = sc["xcat0"], sc["xcatl"], sc["c_cur"], sc["gates"]
+        hip.lstm_prepare(plan["emb"], img_emb, tokens, tok_pos, hparent,
+                         st.h if st.started else None, st.c if st.started else None,
+                         xcat0, xcatl, c_cur, rows, rpi, mult, rows_total, nl, e, hh)
+        hout = sc["hout"] if hout is None else hout
+        for l in range(nl):
+            w, b = plan["layers"][l]
+            hip.linear(xcat0 if l == 0 else xcatl[l - 1], w, b, out=gates)
+            if l + 1 < nl:
+                dst, ld = xcatl[l], 2 * hh
+            else:
+                dst, ld = hout, hout.stride(0)
+            hip.lstm_cell(gates, c_cur[l], st.h[l], st.c[l], dst, ld, rows, mult, hh)
+        st.started = True
+        return hout
+
+    def forward(self, image_emb, captions, lengths=None):
+        """Teacher-forced logits ``[bs, max(lengths), num_tokens]`` (reference rnn_models.py:28-46).
+        Rows past ``lengths[i]`` are the packed-sequence zeros, i.e. the classifier bias."""
+        self._check_mode()
+        plan = self._get_plan()
+        bs, steps = captions.shape[0], captions.shape[1] + 1
+        dev = image_emb.device
+        if lengths is None:
+            lengths = torch.full((bs,), steps, dtype=torch.long)
+        lengths = torch.as_tensor(lengths).cpu()
+        steps_out = int(lengths.max())
+        hh = self.lstm.hidden_size
+        tokens = captions.to(torch.int32).contiguous()
+        st = self._State(self, bs, 1, dev)
+        hs = torch.zeros((bs, steps_out, hh), device=dev)
+        for t in range(steps_out):
+            self._step(plan, st, bs, 1, 1, bs, img_emb=image_emb if t == 0 else None,
+                       tokens=None if t == 0 else tokens, tok_pos=t - 1, hout=hs[:, t, :])
+        valid = (torch.arange(steps_out)[None, :] < lengths[:, None]).to(dev)
+        hs.mul_(valid[..., None])          # pad_packed_sequence zero rows (mask, not arithmetic on valid rows)
+        out = hip.linear(hs.view(bs * steps_out, hh), plan["cls_w"], plan["cls_b"])
+        return out.view(bs, steps_out, -1)
+
+    def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
+                       eos_index=3, seed=0, img0=0, noise_source=None, logits_hook=None):
+        """Batched beam-search sampling for ``image_emb [N, 1, E]`` or ``[N, E]``.
+
+        Returns ``(tokens int64 [N, max_len] zero-padded, lengths int64 [N])``; row ``i`` equals
+        what the reference's ``generate`` returns for image ``i`` under the same random draws
+        (rnn_models.py:48-143, incl. the hidden-state indexing at :135-137)."""
+        self._check_mode()
+        plan = self._get_plan()
+        image_emb = image_emb.reshape(image_emb.shape[0], -1).contiguous()
+        n, b = image_emb.shape[0], beam_size
+        dev = image_emb.device
+        r = n * b
+        helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
+                                  max_len=max_len, seed=seed, img0=img0, noise_source=noise_source)
+        pos = 0
+        if caption is not None:
+            pos = caption.shape[1]
+            helper.set_prefix(caption)
+        st = self._State(self, n, b, dev)
+        logits = torch.empty((r, self.num_tokens), device=dev)
+        # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam
+        hout = self._step(plan, st, n, 1, b, r, img_emb=image_emb)
+        for j in range(pos):
+            hout = self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j)
+        lg = hip.linear(hout, plan["cls_w"], plan["cls_b"], out=logits[:n])
+        if logits_hook is not None:
+            logits_hook(pos, lg)
+        helper.step(lg, first=True, write_pos=pos, t=0, step_index=pos, first_sets_ended=True)
+        for i in range(pos + 1, max_len):
+            hout = self._step(plan, st, r, b, 1, r, tokens=helper.tokens, tok_pos=i - 1, hparent=helper.hparent)
+            hip.linear(hout, plan["cls_w"], plan["cls_b"], out=logits)
+            if logits_hook is not None:
+                logits_hook(i, logits)
+            helper.step(logits, first=False, write_pos=i, t=0, step_index=i)
+        return helper.finalize(len_bias_done=1, full_len=max_len)
+
+    def generate(self, image_emb, caption=None, max_len=25,
+                 temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
+        """Single-image API of the reference (rnn_models.py:48-49): ``image_emb [1, 1, E]`` ->
+        1-D int64 token tensor."""
+        toks, lens = self.generate_batch(image_emb, caption=caption, max_len=max_len, temperature=temperature,
+                                         beam_size=beam_size, top_k=top_k, eos_index=eos_index, **kw)
+        return toks[0, :int(lens[0])].squeeze()

@@ -1,0 +1,289 @@
+"""Transformer caption decoders on the gfx950 kernels.
+
+Drop-in for the decoder half of ``deephumor.models.transformers`` (reference
+transformers.py:43-165, 309-825): same class names, constructor arguments, ``forward`` /
+``generate`` signatures and state-dict keys (including the ``scale`` parameters, which are part
+of the checkpoint format, transformers.py:77-80,424-427).
+
+Design difference (MI355X-first, results-equivalent -- SURVEY.md 8(a) G-TR.4): the reference
+re-runs the whole padded sequence through all layers for every generated token and applies the
+vocabulary classifier to all ``max(max_len+1, 49)`` positions; here every position is decoded
+ONCE against a per-layer KV cache kept in HBM, for all images and beams of a batch at a time, and
+beam reordering is an ancestor-index table, never a cache copy.  ``forward()`` (teacher forcing)
+runs on the same incremental engine, so it and ``generate()`` share every kernel.
+"""
+import torch
+from torch import nn
+
+from .. import hip
+from .beam import BeamSearchHelper
+from .encoders import _Planned
+
+
+class MultiHeadAttentionLayer(nn.Module):
+    """Parameter holder of the reference layer (transformers.py:43-80): fc_q/fc_k/fc_v/fc_o + scale."""
+
+    def __init__(self, hid_dim=512, n_heads=8, dropout=0.):
+        super().__init__()
+        assert hid_dim % n_heads == 0, "hid_dim must be divisible by n_heads"
+        self.hid_dim, self.n_heads, self.head_dim = hid_dim, n_heads, hid_dim // n_heads
+        self.fc_q = nn.Linear(hid_dim, hid_dim)
+        self.fc_k = nn.Linear(hid_dim, hid_dim)
+        self.fc_v = nn.Linear(hid_dim, hid_dim)
+        self.fc_o = nn.Linear(hid_dim, hid_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.scale = nn.Parameter(torch.sqrt(torch.tensor(self.head_dim, dtype=torch.float32)), requires_grad=False)
+
+
+class PositionwiseFeedforwardLayer(nn.Module):
+    """fc_2(relu(fc_1(x))) (transformers.py:132-165)."""
+
+    def __init__(self, hid_dim=512, pf_dim=2048, dropout=0.):
+        super().__init__()
+        self.fc_1 = nn.Linear(hid_dim, pf_dim)
+        self.fc_2 = nn.Linear(pf_dim, hid_dim)
+        self.dropout = nn.Dropout(dropout)
+
+
+class DecoderLayer(nn.Module):
+    """Post-LN decoder layer with encoder attention (transformers.py:309-377)."""
+
+    def __init__(self, hid_dim=512, n_heads=8, pf_dim=2048, dropout=0.):
+        super().__init__()
+        self.self_attn = MultiHeadAttentionLayer(hid_dim, n_heads, dropout)
+        self.self_attn_ln = nn.LayerNorm(hid_dim)
+        self.enc_attn = MultiHeadAttentionLayer(hid_dim, n_heads, dropout)
+        self.enc_attn_ln = nn.LayerNorm(hid_dim)
+        self.pf = PositionwiseFeedforwardLayer(hid_dim, pf_dim, dropout)
+        self.pf_ln = nn.LayerNorm(hid_dim)
+        self.dropout = nn.Dropout(dropout)
+
+
+class SelfAttentionDecoderLayer(nn.Module):
+    """Decoder layer without encoder attention (transformers.py:582-636)."""
+
+    def __init__(self, hid_dim=512, n_heads=8, pf_dim=2048, dropout=0.):
+        super().__init__()
+        self.self_attn = MultiHeadAttentionLayer(hid_dim, n_heads, dropout)
+        self.self_attn_ln = nn.LayerNorm(hid_dim)
+        self.pf = PositionwiseFeedforwardLayer(hid_dim, pf_dim, dropout)
+        self.pf_ln = nn.LayerNorm(hid_dim)
+        self.dropout = nn.Dropout(dropout)
+
+
+class TransformerEncoder(nn.Module):
+    """Exported by the reference (models/__init__.py:6-8) but dead and broken there
+    (``self.padding_index`` AttributeError at transformers.py:298; never instantiated) -- out of the
+    hot-path scope."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("TransformerEncoder is dead code in the reference and not on the caption path")
+
+
+class _IncrementalDecoder(nn.Module, _Planned):
+    """Shared engine of TransformerDecoder / SelfAttentionTransformerDecoder."""
+
+    _layer_cls = None
+    _cross = False
+
+    def __init__(self, num_tokens, hid_dim=512, n_layers=6, n_heads=8,
+                 pf_dim=2048, dropout=0., pad_index=None, max_len=128):
+        super().__init__()
+        self.pad_index = pad_index
+        self.tok_embedding = nn.Embedding(num_tokens, hid_dim)
+        self.pos_embedding = nn.Embedding(max_len, hid_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.layers = nn.ModuleList([self._layer_cls(hid_dim, n_heads, pf_dim, dropout) for _ in range(n_layers)])
+        self.scale = nn.Parameter(torch.sqrt(torch.tensor(hid_dim, dtype=torch.float32)), requires_grad=False)
+        self.classifier = nn.Linear(hid_dim, num_tokens)
+        self.num_tokens, self.hid_dim, self.n_heads = num_tokens, hid_dim, n_heads
+
+    # ---- derived constants: fused QKV / KV weights, scalar scales --------------------------------
+    def _build_plan(self):
+        d = lambda t: t.detach()
+        layers = []
+        for lyr in self.layers:
+            sa = lyr.self_attn
+            ent = dict(
+                wqkv=torch.cat([d(sa.fc_q.weight), d(sa.fc_k.weight), d(sa.fc_v.weight)], 0).contiguous(),
+                bqkv=torch.cat([d(sa.fc_q.bias), d(sa.fc_k.bias), d(sa.fc_v.bias)], 0).contiguous(),
+                wo=d(sa.fc_o.weight), bo=d(sa.fc_o.bias), sa_scale=float(sa.scale),
+                ln1=(d(lyr.self_attn_ln.weight), d(lyr.self_attn_ln.bias), lyr.self_attn_ln.eps),
+                w1=d(lyr.pf.fc_1.weight), b1=d(lyr.pf.fc_1.bias), w2=d(lyr.pf.fc_2.weight), b2=d(lyr.pf.fc_2.bias),
+                ln3=(d(lyr.pf_ln.weight), d(lyr.pf_ln.bias), lyr.pf_ln.eps))
+            if self._cross:
+                ea = lyr.enc_attn
+                ent.update(
+                    wq=d(ea.fc_q.weight), bq=d(ea.fc_q.bias),
+                    wkv=torch.cat([d(ea.fc_k.weight), d(ea.fc_v.weight)], 0).contiguous(),
+                    bkv=torch.cat([d(ea.fc_k.bias), d(ea.fc_v.bias)], 0).contiguous(),
+                    weo=d(ea.fc_o.weight), beo=d(ea.fc_o.bias), ea_scale=float(ea.scale),
+                    ln2=(d(lyr.enc_attn_ln.weight), d(lyr.enc_attn_ln.bias), lyr.enc_attn_ln.eps))
+            layers.append(ent)
+        return dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
+                    scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=d(self.classifier.bias))
+
+    def _check_mode(self):
+        if self.training and self.dropout.p > 0:
+            raise RuntimeError("deephumor_amd implements the inference path; call model.eval()")
+        if self.pad_index is None:
+            raise TypeError("pad_index=None is unusable in the reference too (transformers.py:451); pass an int")
+
+    class _Run:
+        """KV cache + cross-attention operands + scratch for one batch."""
+
+        def __init__(self, dec, plan, n_img, beam, n_pos, enc_out, dev):
+            d, nl = dec.hid_dim, len(dec.layers)
+            self.n_img, self.beam, self.rows_total, self.n_pos = n_img, beam, n_img * beam, n_pos
+            self.kc = torch.empty((nl, n_pos, self.rows_total, d), device=dev)
+            self.vc = torch.empty((nl, n_pos, self.rows_total, d), device=dev)
+            self.kv, self.keymask, self.s = None, None, 0
+            if enc_out is not None:
+                n, s, _ = enc_out.shape
+                flat = enc_out.contiguous().view(n * s, d)
+                self.s = s
+                self.keymask = hip.enc_key_mask(flat)                                   # transformers.py:480-481
+                self.kv = [hip.linear(flat, L["wkv"], L["bkv"]) for L in plan["layers"]]   # once per image
+            self._scratch = {}
+            self.pf = dec.layers[0].pf.fc_1.out_features
+            self.d, self.dev = d, dev
+
+        def scratch(self, rows):
+            if rows not in self._scratch:
+                e = lambda *shape: torch.empty(shape, device=self.dev)
+                self._scratch[rows] = dict(x=e(rows, self.d), qkv=e(rows, 3 * self.d), att=e(rows, self.d),
+                                           o=e(rows, self.d), q=e(rows, self.d), ff=e(rows, self.pf))
+            return self._scratch[rows]
+
+    def _decode_position(self, plan, run, t, rows, rpi, mult, tokens, src, start_emb, x_out=None):
+        """Hidden state of position ``t`` for ``rows`` compact rows (all layers), [rows, D]."""
+        d, h = self.hid_dim, self.n_heads
+        sc = run.scratch(rows)
+        x = sc["x"]
+        hip.embed_rows(plan["tok"], plan["pos"], start_emb, tokens, x, rows, rpi, mult, t, plan["scale"])
+        n_layers = len(plan["layers"])
+        for li, L in enumerate(plan["layers"]):
+            hip.linear(x, L["wqkv"], L["bqkv"], out=sc["qkv"])
+            hip.attn_self_decode(sc["qkv"], run.kc[li], run.vc[li], src, tokens, sc["att"], run.n_img, rpi, mult,
+                                 run.rows_total, t, d, h, L["sa_scale"], self.pad_index)
+            hip.linear(sc["att"], L["wo"], L["bo"], out=sc["o"])
+            hip.add_layernorm(x, sc["o"], L["ln1"][0], L["ln1"][1], out=x, eps=L["ln1"][2])
+            if self._cross:
+                hip.linear(x, L["wq"], L["bq"], out=sc["q"])
+                hip.attn_cross_decode(sc["q"], run.kv[li], run.keymask, sc["att"], run.n_img, rpi, run.s, d, h,
+                                      L["ea_scale"])
+                hip.linear(sc["att"], L["weo"], L["beo"], out=sc["o"])
+                hip.add_layernorm(x, sc["o"], L["ln2"][0], L["ln2"][1], out=x, eps=L["ln2"][2])
+            hip.linear(x, L["w1"], L["b1"], relu=True, out=sc["ff"])
+            hip.linear(sc["ff"], L["w2"], L["b2"], out=sc["o"])
+            last = li == n_layers - 1 and x_out is not None
+            hip.add_layernorm(x, sc["o"], L["ln3"][0], L["ln3"][1], out=x_out if last else x, eps=L["ln3"][2])
+        return x_out if x_out is not None else x
+
+    def _forward(self, x, enc_out, start_emb):
+        self._check_mode()
+        plan = self._get_plan()
+        bs, dec_len = x.shape
+        dev = start_emb.device if start_emb is not None else x.device
+        if start_emb is None:
+            raise NotImplementedError("forward without start_emb is never used by the captioning models")
+        dec_len += 1
+        seq = dec_len if enc_out is None else max(dec_len, enc_out.shape[1])          # transformers.py:450
+        if seq > self.pos_embedding.num_embeddings:
+            raise IndexError("index out of range in self")                            # pos-embedding lookup
+        tokens = torch.full((bs, max(seq - 1, 1)), self.pad_index, dtype=torch.int32, device=dev)
+        tokens[:, :x.shape[1]] = x.to(torch.int32)
+        helper_src = (torch.arange(bs, dtype=torch.int32, device=dev))[:, None].expand(bs, seq).contiguous()
+        run = self._Run(self, plan, bs, 1, seq, enc_out, dev)
+        hs = torch.empty((bs, seq, self.hid_dim), device=dev)
+        xt = torch.empty((bs, self.hid_dim), device=dev)
+        for t in range(seq):
+            self._decode_position(plan, run, t, bs, 1, 1, tokens, helper_src, start_emb.contiguous(), x_out=xt)
+            hs[:, t, :].copy_(xt)
+        out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"])
+        return out.view(bs, seq, -1)
+
+    def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
+                        seed=0, img0=0, noise_source=None, logits_hook=None):
+        self._check_mode()
+        plan = self._get_plan()
+        n, b = start_emb.shape[0], beam_size
+        r = n * b
+        dev = start_emb.device
+        if max_len + 1 > self.pos_embedding.num_embeddings:
+            raise IndexError("index out of range in self")    # reference: pos_embedding lookup, SURVEY.md section 5
+        helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
+                                  max_len=max_len, src_len=max_len + 1, seed=seed, img0=img0,
+                                  noise_source=noise_source)
+        if self.pad_index != 0:
+            helper.tokens.fill_(self.pad_index)
+        pos = 0
+        if caption is not None:
+            pos = caption.shape[1]
+            helper.set_prefix(caption)
+        run = self._Run(self, plan, n, b, max_len + 1, enc_out, dev)
+        start_emb = start_emb.contiguous()
+        logits = torch.empty((r, self.num_tokens), device=dev)
+        # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
+        for t in range(pos + 1):
+            x = self._decode_position(plan, run, t, n, 1, b, helper.tokens, helper.src, start_emb)
+        lg = hip.linear(x, plan["cls_w"], plan["cls_b"], out=logits[:n])
+        if logits_hook is not None:
+            logits_hook(pos, lg)
+        helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False)
+        for i in range(pos + 1, max_len + 1):
+            x = self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, start_emb)
+            hip.linear(x, plan["cls_w"], plan["cls_b"], out=logits)
+            if logits_hook is not None:
+                logits_hook(i, logits)
+            # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn
+            helper.step(logits, first=False, write_pos=i, t=i, step_index=i)
+        return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index)
+
+
+class TransformerDecoder(_IncrementalDecoder):
+    """Multi-layer Transformer decoder with encoder attention (reference transformers.py:380-579)."""
+
+    _layer_cls = DecoderLayer
+    _cross = True
+
+    def forward(self, x, enc_out, start_emb=None):
+        """Teacher-forced logits ``[bs, max(len(x)+1, S), num_tokens]`` (transformers.py:432-490)."""
+        return self._forward(x, enc_out, start_emb)
+
+    def generate_batch(self, start_emb, enc_out, caption=None, max_len=25, temperature=1.0, beam_size=10,
+                       top_k=50, eos_index=3, **kw):
+        """``start_emb [N, D]``, ``enc_out [N, S, D]`` -> ``(tokens [N, max_len], lengths [N])``."""
+        return self._generate_batch(start_emb, enc_out, caption, max_len, temperature, beam_size, top_k,
+                                    eos_index, **kw)
+
+    def generate(self, start_emb, enc_out, caption=None, max_len=25,
+                 temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
+        """Reference single-image API (transformers.py:492-493) -> 1-D (0-D for one token) int64."""
+        toks, lens = self._generate_batch(start_emb, enc_out, caption, max_len, temperature, beam_size, top_k,
+                                          eos_index, **kw)
+        return toks[0, :int(lens[0])].squeeze()
+
+
+class SelfAttentionTransformerDecoder(_IncrementalDecoder):
+    """Transformer decoder without encoder attention (reference transformers.py:639-825)."""
+
+    _layer_cls = SelfAttentionDecoderLayer
+    _cross = False
+
+    def forward(self, x, start_emb):
+        """Teacher-forced logits ``[bs, len(x)+1, num_tokens]`` (transformers.py:694-738)."""
+        return self._forward(x, None, start_emb)
+
+    def generate_batch(self, start_emb, caption=None, max_len=25, temperature=1.0, beam_size=10,
+                       top_k=50, eos_index=3, **kw):
+        return self._generate_batch(start_emb, None, caption, max_len, temperature, beam_size, top_k,
+                                    eos_index, **kw)
+
+    def generate(self, start_emb, caption=None, max_len=25,
+                 temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
+        """Reference single-image API (transformers.py:740-741)."""
+        toks, lens = self._generate_batch(start_emb, None, caption, max_len, temperature, beam_size, top_k,
+                                          eos_index, **kw)
+        return toks[0, :int(lens[0])].squeeze()

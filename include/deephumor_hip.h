@@ -1,0 +1,196 @@
+/*
+ * deephumor_hip.h -- C-ABI of the MI355X (gfx950) image->caption hot path.
+ *
+ * The reference (ilya16/deephumor) is pure Python on torch ops; it has no FFI of its own.  Each
+ * entry point below replaces the torch call sites named in its comment (file:line under the
+ * reference tree) and is what a maintainer would bind from the modules under deephumor/models through ctypes
+ * (see INTEGRATION.md).  Conventions, all entry points:
+ *   - plain device pointers + explicit sizes; no torch types; no allocation, no host sync and no
+ *     stream sync inside; workspace is supplied by the caller; re-entrant across streams;
+ *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
+ *   - returns DH_OK (0) or a DH_ERR_* code; dh_error_string() names it;
+ *   - `dtype` is the storage/compute type of activations and weights (DH_F32 today; DH_BF16 entry
+ *     points return DH_ERR_UNSUPPORTED until their kernels land); accumulation is always fp32.
+ *   - row-major everywhere; images NCHW; "rows" are (image, beam) pairs, image-major.
+ */
+#ifndef DEEPHUMOR_HIP_H
+#define DEEPHUMOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DH_ABI_VERSION 1
+
+enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
+enum { DH_F32 = 0, DH_BF16 = 1 };
+
+/* device-side error bits OR-ed into the `err` word of the beam kernels */
+enum { DH_BEAM_ERR_ALL_FILTERED = 1,   /* every logit filtered (-inf): reference raises RuntimeError, beam.py:46 */
+       DH_BEAM_ERR_OVERFLOW = 2,       /* more than DH_BEAM_MAX_SURVIVORS logits tie at the top-k threshold */
+       DH_BEAM_ERR_TOO_FEW = 4 };      /* fewer positive-probability tokens than beams */
+#define DH_BEAM_MAX_SURVIVORS 1024
+#define DH_BEAM_MAX_BEAMS 16
+
+int dh_abi_version(void);
+const char* dh_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder (deephumor/models/encoders.py:46-70, torchvision resnet50 trunk at :34-38,56)
+ * ------------------------------------------------------------------------------------------- */
+
+/* y = act( conv2d(x, w) * scale[co] + shift[co] (+ residual) ).  Replaces Conv2d(bias=False) +
+ * eval-mode BatchNorm2d (+ residual add) (+ ReLU) of one trunk layer.  scale = gamma/sqrt(var+eps),
+ * shift = beta - mean*scale, precomputed by the caller.  x [N,Cin,H,W], w [Cout,Cin,KH,KW],
+ * residual/y [N,Cout,Ho,Wo], Ho = (H+2*pad-KH)/stride+1.  KH==KW in {1,3,7}. residual may be NULL. */
+int dh_conv2d_bn_act(const void* x, const void* w, const float* scale, const float* shift,
+                     const void* residual, void* y, int N, int Cin, int H, int W, int Cout,
+                     int KH, int KW, int stride, int pad, int relu, int dtype, void* stream);
+
+/* MaxPool2d(kernel 3, stride 2, padding 1) -- trunk index 3.  x [N,C,H,W] -> y [N,C,Ho,Wo]. */
+int dh_maxpool3x3s2(const void* x, void* y, int N, int C, int H, int W, int dtype, void* stream);
+
+/* AdaptiveAvgPool2d(1): x [rows, HW] -> y [rows] (rows = N*C).  encoders.py:60. */
+int dh_avgpool_rows(const void* x, void* y, int rows, int HW, int dtype, void* stream);
+
+/* features.reshape(bs, C, HW).transpose(2, 1): x [N,C,HW] -> y [N,HW,C].  encoders.py:65-66. */
+int dh_nchw_to_rows(const void* x, void* y, int N, int C, int HW, int dtype, void* stream);
+
+/* LabelEncoder: out[n, 0..E) = mean over the L label positions of emb[labels[n,j], :] (pads
+ * included, encoders.py:104).  labels int64 [N, L]; out row stride ld_out (>= E). */
+int dh_label_mean(const void* emb, const int64_t* labels, void* out, int ld_out, int N, int L, int E,
+                  int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense layers: nn.Linear call sites (encoders.py:61,67,142; rnn_models.py:44,81,109 classifier;
+ * nn.LSTM gate products; transformers.py:97,127,162-163,488)
+ * ------------------------------------------------------------------------------------------- */
+
+/* C[m,n] = act( (sum_k A[m,k]*W[n,k] + bias[n]) * scale[n] + shift[n] ), fp32 accumulate on the
+ * matrix cores.  A [M,K] lda, W [N,K] ldw (nn.Linear layout), C [M,N] ldc.  bias/scale/shift may be
+ * NULL (scale/shift: eval-mode BatchNorm1d folded behind the Linear, encoders.py:61).  K % 4 == 0. */
+int dh_linear(const void* A, int lda, const void* W, int ldw, const float* bias,
+              const float* scale, const float* shift, void* C, int ldc,
+              int M, int N, int K, int relu, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row addressing shared by the decoder kernels.  A decode step works on `rows` compact rows
+ * rc = img*rows_per_img + w.  Persistent per-row state (tokens, KV cache, LSTM state) lives at
+ * "logical" row rl = rc*row_mult of buffers sized for n_img*beam rows: before the first draw
+ * every image has ONE row (rows_per_img=1, row_mult=beam), afterwards `beam` rows (row_mult=1).
+ * ------------------------------------------------------------------------------------------- */
+
+/* x[rc,:] = (pos==0 && start_emb ? start_emb[img,:] : tok_emb[token,:]) / scale + pos_emb[pos,:]
+ * with token = tokens[rl*tok_ld + pos - (start_emb?1:0)].  transformers.py:455-469 / 697-718. */
+int dh_embed_rows(const void* tok_emb, const void* pos_emb, const void* start_emb,
+                  const int32_t* tokens, int tok_ld, void* x, int rows, int rows_per_img,
+                  int row_mult, int pos, int D, float scale, int dtype, void* stream);
+
+/* out = LayerNorm(x + y) * gamma + beta, eps as given (nn.LayerNorm default 1e-5), rows of D.
+ * transformers.py:360,368,375.  out may alias x.  D % 4 == 0, D <= 4096. */
+int dh_add_layernorm(const void* x, const void* y, const float* gamma, const float* beta,
+                     void* out, int rows, int D, float eps, int dtype, void* stream);
+
+/* Single-position masked multi-head self-attention over a KV cache (transformers.py:356 -> 97-127,
+ * in the KV-cached form SURVEY.md 8(a) G-TR.4 shows equivalent).
+ *   qkv   [rows, 3*D]  this position's q | k | v for every compact row (output of dh_linear)
+ *   kcache/vcache [(pos_cap) * rows_total * D]  position-major cache of ONE layer; position t of
+ *         logical row rl is written here by this call
+ *   src   [rows_total, src_ld] int32: src[rl, j] = logical row whose cache slot holds position j of
+ *         row rl's history (beam reordering is this indirection, never a copy), j < t
+ *   tokens[rows_total, tok_ld]: key position j>=1 is masked iff tokens[rl, j-1] == pad_index
+ *         (transformers.py:474-477); position 0 (image slot) never is.  pad_index < 0: no masking.
+ *   out   [rows, D]
+ * t = index of the current position (keys 0..t).  dynamic LDS = rows_per_img*(t+1+64)*4 bytes. */
+int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
+                        const int32_t* tokens, int tok_ld, void* out, int n_img, int rows_per_img,
+                        int row_mult, int rows_total, int t, int D, int n_heads, float scale,
+                        int pad_index, int dtype, void* stream);
+
+/* Single-position multi-head attention over the S image patches (transformers.py:364 -> 97-127).
+ *   q [rows, ldq] (first D columns used), kv [n_img*S, 2*D] = fc_k | fc_v of enc_out (computed once
+ *   per image), keymask [n_img*S] uint8 (1 = masked: some element of that enc_out row == 0,
+ *   transformers.py:480-481), out [rows, D]. */
+int dh_attn_cross_decode(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out,
+                         int n_img, int rows_per_img, int S, int D, int n_heads, float scale,
+                         int dtype, void* stream);
+
+/* keymask[r] = any(enc_out[r, :] == 0)  (transformers.py:480-481).  enc_out [rows, D]. */
+int dh_enc_key_mask(const void* enc_out, uint8_t* keymask, int rows, int D, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * LSTM cell (nn.LSTM single time step; rnn_models.py:80,108)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Gathers one step's inputs.  For every compact row rc (logical rl = rc*row_mult):
+ *   xcat0[rc] = [ x_in , h_prev[0][hp] ],  xcatl[l-1][rc][Hh:2Hh] = h_prev[l][hp] (l>=1),
+ *   c_cur[l][rc] = c_prev[l][hp]
+ * where x_in = emb[tokens[rl*tok_ld + tok_pos]] if tokens != NULL else img_emb[img], and
+ * hp = hparent ? hparent[rl] : rl; hp < 0 or h_prev == NULL means zero state.
+ * h_prev/c_prev [n_layers, rows_total, Hh]; xcat0 [rows, E+Hh]; xcatl [n_layers-1, rows, 2*Hh];
+ * c_cur [n_layers, rows, Hh]. */
+int dh_lstm_prepare(const void* emb, const void* img_emb, const int32_t* tokens, int tok_ld, int tok_pos,
+                    const int32_t* hparent, const void* h_prev, const void* c_prev,
+                    void* xcat0, void* xcatl, void* c_cur, int rows, int rows_per_img, int row_mult,
+                    int rows_total, int n_layers, int E, int Hh, int dtype, void* stream);
+
+/* gates [rows, 4*Hh] in PyTorch order i,f,g,o (biases already added by dh_linear):
+ *   c' = sigmoid(f)*c_cur + sigmoid(i)*tanh(g);  h' = sigmoid(o)*tanh(c')
+ * writes h_new[rl], c_new[rl] (state at logical rows) and h_out[rc*ld_out + 0..Hh) (next layer's
+ * input slot or the classifier input). */
+int dh_lstm_cell(const void* gates, const void* c_cur, void* h_new, void* c_new, void* h_out,
+                 int ld_out, int rows, int row_mult, int Hh, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Beam-search step (deephumor/models/beam.py:32-108; rnn_models.py:87-103,111-137;
+ * transformers.py:532-545,552-573,576-577)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Per row: top-k filter (threshold = k-th largest, strict '<', ties kept, unk always dropped),
+ * p = softmax(filtered / temperature), draw `beam` tokens without replacement as the top-`beam`
+ * of p / Exp(1)-noise (== torch.multinomial on CPU), gather, log_softmax over the picks.
+ *   logits [rows, ldl] fp32 (read only); pick_idx/pick_val [rows, beam]
+ *   noise: NULL -> counter-based Philox noise keyed by (seed, img0+img, step, row, token);
+ *          else [rows, ldl] fp32 Exp(1) samples supplied by the caller (RNG-replay parity tests)
+ *   err: int32 word, DH_BEAM_ERR_* bits are OR-ed in. */
+int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,
+                       int top_k, float temperature, int unk_index, const float* noise,
+                       uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
+                       int32_t* err, void* stream);
+
+/* Per image: builds the candidate list (a live beam contributes `beam` candidates, an ended beam one
+ * with token 0 / score +0), draws `beam` of them without replacement from softmax(cand_val/T),
+ * and rewrites the image's beam state IN PLACE.
+ *   first != 0: the image has one source row (its picks are row img of pick_*): every new beam's
+ *               parent is beam 0; `ended` is set from eos only if first_sets_ended (LSTM yes,
+ *               Transformer no -- transformers.py:540-545 never updates has_ended there).
+ *   tokens [R, tok_ld]: the picked token is written at column write_pos if write_pos < tok_ld
+ *               (the Transformer's last step writes nothing, transformers.py:557).
+ *   vals [R], ended [R] uint8, src [R, src_ld] (NULL for LSTM): src[r', 0..t) follow the parent,
+ *               src[r', t] = parent row;  parent [R] / hparent [R]: logical parent rows for the
+ *               sequence and for the LSTM state (rnn_models.py:135-137 quirk: candidate index / beam).
+ *   done [n_img] uint8, end_step [n_img] int32: set to 1 / `step_index` when every beam of the image
+ *               has ended (break at rnn_models.py:131 / transformers.py:572); done images are frozen.
+ *   noise: NULL -> Philox; else [n_img, beam*beam] Exp(1) samples. */
+int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* tokens, int tok_ld,
+                   float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent,
+                   int32_t* hparent, uint8_t* done, int32_t* end_step, int n_img, int beam,
+                   int first, int first_sets_ended, int write_pos, int t, int step_index,
+                   float temperature, int eos_index, const float* noise, uint64_t seed, int img0,
+                   void* stream);
+
+/* Per image: final draw ind ~ softmax(vals/T) (k=1 -> arg-max of p/noise), copies
+ * tokens[img*beam+ind, 0..len) to out[img, :] (rest = pad) and writes len, where
+ * len = (done ? end_step + len_bias_done : full_len).  rnn_models.py:140-141; transformers.py:576-577.
+ *   noise: NULL -> Philox; else [n_img, beam]. */
+int dh_beam_finalize(const int32_t* tokens, int tok_ld, const float* vals, const uint8_t* done,
+                     const int32_t* end_step, int32_t* out, int out_ld, int32_t* out_len,
+                     int n_img, int beam, int len_bias_done, int full_len, int pad_index,
+                     float temperature, const float* noise, uint64_t seed, int img0, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEEPHUMOR_HIP_H */

@@ -1,0 +1,53 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+exactly the entry points include/deephumor_hip.h declares, with matching arity (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _prototypes():
+    text = open(os.path.join(ROOT, "include", "deephumor_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(dh_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = m.group(2).strip()
+        protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return protos
+
+
+def test_header_declares_the_path():
+    protos = _prototypes()
+    for name in ("dh_conv2d_bn_act", "dh_maxpool3x3s2", "dh_linear", "dh_embed_rows", "dh_add_layernorm",
+                 "dh_attn_self_decode", "dh_attn_cross_decode", "dh_lstm_cell", "dh_beam_row_sample",
+                 "dh_beam_select", "dh_beam_finalize"):
+        assert name in protos
+
+
+def test_library_builds_loads_and_exports_every_symbol():
+    from deephumor_amd import _build, hip
+    path = _build.build()
+    assert os.path.exists(path)
+    lib = ctypes.CDLL(path)
+    protos = _prototypes()
+    for name, nargs in protos.items():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+        if name in hip.SIGNATURES:
+            assert len(hip.SIGNATURES[name]) == nargs, f"{name}: binding has {len(hip.SIGNATURES[name])} args, header {nargs}"
+    for name in hip.SIGNATURES:
+        assert name in protos, f"{name} bound but not declared in include/deephumor_hip.h"
+    lib.dh_abi_version.restype = ctypes.c_int
+    assert lib.dh_abi_version() == 1
+    lib.dh_error_string.restype = ctypes.c_char_p
+    assert lib.dh_error_string(1).startswith(b"bad argument")
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation happens before any HIP call, so it is testable on CPU."""
+    from deephumor_amd import hip
+    lib = hip.load()
+    assert lib.dh_linear(None, 0, None, 0, None, None, None, None, 0, 4, 4, 4, 0, hip.F32, None) == 1
+    assert lib.dh_linear(None, 0, None, 0, None, None, None, None, 0, 4, 4, 4, 0, hip.BF16, None) == 2
+    assert lib.dh_conv2d_bn_act(None, None, None, None, None, None, 1, 3, 8, 8, 8, 5, 5, 1, 0, 1, hip.F32, None) == 1
+    assert lib.dh_beam_row_sample(None, 0, 10, 1, 1, 3, 2, 1.0, 1, None, 0, 0, 0, None, None, None, None) == 1

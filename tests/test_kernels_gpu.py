@@ -1,0 +1,282 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry point against a plain fp32 torch-CPU
+statement of the same operation (floating-point kernels -> torch fp32 reference, tolerance in
+each test), beam kernels against the oracle's BeamBook / the reference's golden vectors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import golden  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from deephumor_amd import hip as h
+    h.load()
+    assert torch.cuda.is_available()
+    return h
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(a, b, atol, rtol=1e-4):
+    np.testing.assert_allclose(a.detach().cpu().numpy(), b.detach().cpu().numpy(), atol=atol, rtol=rtol)
+
+
+@pytest.mark.parametrize("m,n,k", [(4, 1000, 512), (1280, 512, 512), (300, 36541 // 8, 768), (77, 130, 2048),
+                                   (256, 2048, 512), (1, 64, 4), (129, 129, 36)])
+def test_linear(hip, m, n, k):
+    a, w, b = rnd(m, k, seed=1), rnd(n, k, seed=2) / k ** 0.5, rnd(n, seed=3)
+    out = hip.linear(a.cuda(), w.cuda(), b.cuda())
+    close(out, F.linear(a, w, b), atol=2e-5 * max(1.0, k ** 0.5 / 8))
+    sc, sh = rnd(n, seed=4).abs() + 0.5, rnd(n, seed=5)
+    out = hip.linear(a.cuda(), w.cuda(), b.cuda(), scale=sc.cuda(), shift=sh.cuda(), relu=True)
+    close(out, torch.relu(F.linear(a, w, b) * sc + sh), atol=5e-5 * max(1.0, k ** 0.5 / 8))
+
+
+def test_linear_strided(hip):
+    """lda > K (LSTM [x|h] operand slices) and ldc > N (writing into a wider buffer)."""
+    a_full, w = rnd(50, 96, seed=7), rnd(40, 64, seed=8)
+    a = a_full.cuda()[:, 32:96]
+    out_full = torch.zeros(50, 100, device="cuda")
+    hip.linear(a, w.cuda(), None, out=out_full[:, 20:60])
+    close(out_full[:, 20:60], F.linear(a_full[:, 32:96], w), atol=5e-5)
+    assert float(out_full[:, :20].abs().max()) == 0 and float(out_full[:, 60:].abs().max()) == 0
+
+
+@pytest.mark.parametrize("cin,cout,hw,ks,stride,pad,n", [
+    (3, 64, 32, 7, 2, 3, 3), (64, 64, 14, 1, 1, 0, 2), (64, 256, 14, 1, 1, 0, 2), (256, 128, 14, 1, 2, 0, 2),
+    (128, 128, 14, 3, 2, 1, 3), (64, 64, 9, 3, 1, 1, 2), (512, 2048, 7, 1, 1, 0, 3), (512, 512, 7, 3, 1, 1, 3),
+    (1024, 2048, 14, 1, 2, 0, 2)])
+def test_conv_bn_act(hip, cin, cout, hw, ks, stride, pad, n):
+    x, w = rnd(n, cin, hw, hw, seed=1), rnd(cout, cin, ks, ks, seed=2) * (2.0 / (cin * ks * ks)) ** 0.5
+    sc, sh = rnd(cout, seed=3).abs() + 0.5, rnd(cout, seed=4)
+    ref = F.conv2d(x, w, stride=stride, padding=pad) * sc[None, :, None, None] + sh[None, :, None, None]
+    out = hip.conv2d_bn_act(x.cuda(), w.cuda(), sc.cuda(), sh.cuda(), relu=False, stride=stride, pad=pad)
+    close(out, ref, atol=1e-4)
+    res = rnd(*ref.shape, seed=5)
+    out = hip.conv2d_bn_act(x.cuda(), w.cuda(), sc.cuda(), sh.cuda(), residual=res.cuda(), relu=True,
+                            stride=stride, pad=pad)
+    close(out, torch.relu(ref + res), atol=1e-4)
+
+
+def test_pools_and_layout(hip):
+    x = rnd(3, 64, 30, 30)
+    close(hip.maxpool3x3s2(x.cuda()), F.max_pool2d(x, 3, 2, 1), atol=0)
+    x = rnd(2, 16, 15, 15)
+    close(hip.maxpool3x3s2(x.cuda()), F.max_pool2d(x, 3, 2, 1), atol=0)
+    f = rnd(5, 2048, 7, 7)
+    close(hip.avgpool_rows(f.cuda()), f.mean(dim=(2, 3)), atol=1e-6)
+    close(hip.nchw_to_rows(f.cuda()), f.reshape(5, 2048, 49).transpose(2, 1), atol=0)
+    emb = rnd(100, 256)
+    labels = torch.randint(0, 100, (7, 3))
+    out = torch.zeros(7, 512, device="cuda")
+    hip.label_mean(emb.cuda(), labels.cuda(), out[:, 256:])
+    close(out[:, 256:], emb[labels].mean(dim=1), atol=1e-6)
+
+
+@pytest.mark.parametrize("d", [512, 256, 1024])
+def test_add_layernorm_embed_mask(hip, d):
+    x, y, g, b = rnd(37, d, seed=1), rnd(37, d, seed=2), rnd(d, seed=3), rnd(d, seed=4)
+    close(hip.add_layernorm(x.cuda(), y.cuda(), g.cuda(), b.cuda()), F.layer_norm(x + y, (d,), g, b, 1e-5), atol=5e-6)
+    xin = x.cuda()
+    hip.add_layernorm(xin, y.cuda(), g.cuda(), b.cuda(), out=xin)            # in place
+    close(xin, F.layer_norm(x + y, (d,), g, b, 1e-5), atol=5e-6)
+    # embedding rows: 3 images x 2 beams, logical rows = compact rows (row_mult 1)
+    tok, pos, start = rnd(50, d, seed=5), rnd(20, d, seed=6), rnd(3, d, seed=7)
+    tokens = torch.randint(0, 50, (6, 8), dtype=torch.int32)
+    out = torch.empty(6, d, device="cuda")
+    scale = float(d) ** 0.5
+    hip.embed_rows(tok.cuda(), pos.cuda(), start.cuda(), tokens.cuda(), out, 6, 2, 1, 4, scale)
+    close(out, tok[tokens[:, 3].long()] / scale + pos[4], atol=1e-6)
+    hip.embed_rows(tok.cuda(), pos.cuda(), start.cuda(), tokens.cuda(), out, 6, 2, 1, 0, scale)
+    close(out, start.repeat_interleave(2, 0) / scale + pos[0], atol=1e-6)
+    out3 = torch.empty(3, d, device="cuda")                                   # one row per image, row_mult = beam
+    hip.embed_rows(tok.cuda(), pos.cuda(), start.cuda(), tokens.cuda(), out3, 3, 1, 2, 2, scale)
+    close(out3, tok[tokens[::2, 1].long()] / scale + pos[2], atol=1e-6)
+    e = rnd(10, d, seed=8)
+    e[3, 5] = 0.0
+    e[7] = 0.0
+    assert hip.enc_key_mask(e.cuda()).cpu().tolist() == [0, 0, 0, 1, 0, 0, 0, 1, 0, 0]
+
+
+def _attn_ref(q, keys, vals, masked, scale):
+    """q [H,dh]; keys/vals [L,H,dh]; masked [L] bool -> [H*dh] following transformers.py:106-120."""
+    energy = torch.einsum("hd,lhd->hl", q, keys) / scale
+    energy = energy.masked_fill(masked[None, :], -1e8)
+    return torch.einsum("hl,lhd->hd", torch.softmax(energy, -1), vals).reshape(-1)
+
+
+@pytest.mark.parametrize("t", [0, 1, 5, 32, 100])
+def test_attn_self_decode(hip, t):
+    n_img, beam, d, h, tmax = 3, 4, 512, 8, 128
+    r = n_img * beam
+    dh = d // h
+    qkv = rnd(r, 3 * d, seed=t)
+    kc, vc = rnd(tmax + 1, r, d, seed=1), rnd(tmax + 1, r, d, seed=2)
+    g = torch.Generator().manual_seed(t)
+    src = (torch.arange(r)[:, None] // beam * beam + torch.randint(0, beam, (r, tmax + 1), generator=g)).int()
+    tokens = torch.randint(0, 5, (r, tmax), generator=g, dtype=torch.int32)   # plenty of pad (0) keys
+    out = torch.empty(r, d, device="cuda")
+    kcd, vcd = kc.cuda(), vc.cuda()
+    hip.attn_self_decode(qkv.cuda(), kcd, vcd, src.cuda(), tokens.cuda(), out, n_img, beam, 1, r, t, d, h, 8.0, 0)
+    ref = torch.empty(r, d)
+    for row in range(r):
+        keys = torch.stack([kc[j, src[row, j]] for j in range(t)] + [qkv[row, d:2 * d]]).view(t + 1, h, dh)
+        vals = torch.stack([vc[j, src[row, j]] for j in range(t)] + [qkv[row, 2 * d:]]).view(t + 1, h, dh)
+        masked = torch.tensor([False] + [bool(tokens[row, j - 1] == 0) for j in range(1, t + 1)])
+        ref[row] = _attn_ref(qkv[row, :d].view(h, dh), keys, vals, masked, 8.0)
+    close(out, ref, atol=2e-5)
+    close(kcd[t], qkv[:, d:2 * d], atol=0)       # this position appended at each row's own slot
+    close(vcd[t], qkv[:, 2 * d:], atol=0)
+    # one row per image (before the first draw): compact row i <-> logical row i*beam
+    out1 = torch.empty(n_img, d, device="cuda")
+    kcd, vcd = kc.cuda(), vc.cuda()
+    hip.attn_self_decode(qkv[:n_img].cuda(), kcd, vcd, src.cuda(), tokens.cuda(), out1, n_img, 1, beam, r, t, d, h,
+                         8.0, 0)
+    for i in range(n_img):
+        rl = i * beam
+        keys = torch.stack([kc[j, src[rl, j]] for j in range(t)] + [qkv[i, d:2 * d]]).view(t + 1, h, dh)
+        vals = torch.stack([vc[j, src[rl, j]] for j in range(t)] + [qkv[i, 2 * d:]]).view(t + 1, h, dh)
+        masked = torch.tensor([False] + [bool(tokens[rl, j - 1] == 0) for j in range(1, t + 1)])
+        close(out1[i], _attn_ref(qkv[i, :d].view(h, dh), keys, vals, masked, 8.0), atol=2e-5)
+        close(kcd[t, rl], qkv[i, d:2 * d], atol=0)
+
+
+@pytest.mark.parametrize("s", [49, 64, 100])
+def test_attn_cross_decode(hip, s):
+    n_img, beam, d, h = 3, 5, 512, 8
+    r, dh = n_img * beam, 512 // 8
+    q, kv = rnd(r, d, seed=1), rnd(n_img * s, 2 * d, seed=2)
+    mask = torch.zeros(n_img * s, dtype=torch.uint8)
+    mask[3] = 1
+    mask[s:2 * s] = 1                      # image 1: every key masked -> uniform attention (softmax of equal -1e8)
+    out = torch.empty(r, d, device="cuda")
+    hip.attn_cross_decode(q.cuda(), kv.cuda(), mask.cuda(), out, n_img, beam, s, d, h, 8.0)
+    for row in range(r):
+        i = row // beam
+        keys = kv[i * s:(i + 1) * s, :d].reshape(s, h, dh)
+        vals = kv[i * s:(i + 1) * s, d:].reshape(s, h, dh)
+        close(out[row], _attn_ref(q[row].view(h, dh), keys, vals, mask[i * s:(i + 1) * s].bool(), 8.0), atol=2e-5)
+
+
+def test_lstm_step(hip):
+    n_img, beam, e, hh, nl, v = 3, 2, 256, 512, 2, 40
+    r = n_img * beam
+    emb, img = rnd(v, e, seed=1), rnd(n_img, e, seed=2)
+    h_prev, c_prev = rnd(nl, r, hh, seed=3), rnd(nl, r, hh, seed=4)
+    tokens = torch.randint(0, v, (r, 6), dtype=torch.int32)
+    hpar = torch.tensor([1, 0, 3, 3, 4, 5], dtype=torch.int32)
+    xcat0, xcatl = torch.zeros(r, e + hh, device="cuda"), torch.zeros(nl - 1, r, 2 * hh, device="cuda")
+    c_cur = torch.zeros(nl, r, hh, device="cuda")
+    hip.lstm_prepare(emb.cuda(), None, tokens.cuda(), 2, hpar.cuda(), h_prev.cuda(), c_prev.cuda(), xcat0, xcatl,
+                     c_cur, r, beam, 1, r, nl, e, hh)
+    close(xcat0[:, :e], emb[tokens[:, 2].long()], atol=0)
+    close(xcat0[:, e:], h_prev[0][hpar.long()], atol=0)
+    close(xcatl[0][:, hh:], h_prev[1][hpar.long()], atol=0)
+    close(c_cur, c_prev[:, hpar.long()], atol=0)
+    # image step, zero state, one row per image stored at logical row img*beam
+    x0 = torch.full((n_img, e + hh), 7.0, device="cuda")
+    xl, cc = torch.full((1, n_img, 2 * hh), 7.0, device="cuda"), torch.full((nl, n_img, hh), 7.0, device="cuda")
+    hip.lstm_prepare(None, img.cuda(), None, 0, None, None, None, x0, xl, cc, n_img, 1, beam, r, nl, e, hh)
+    close(x0[:, :e], img, atol=0)
+    assert float(x0[:, e:].abs().max()) == 0 and float(cc.abs().max()) == 0 and float(xl[0][:, hh:].abs().max()) == 0
+    gates, c0 = rnd(n_img, 4 * hh, seed=5) * 2, rnd(n_img, hh, seed=6)
+    h_new, c_new = torch.zeros(r, hh, device="cuda"), torch.zeros(r, hh, device="cuda")
+    h_out = torch.zeros(n_img, 2 * hh, device="cuda")
+    hip.lstm_cell(gates.cuda(), c0.cuda(), h_new, c_new, h_out, 2 * hh, n_img, beam, hh)
+    gi, gf, gg, go = gates.chunk(4, 1)
+    c1 = torch.sigmoid(gf) * c0 + torch.sigmoid(gi) * torch.tanh(gg)
+    h1 = torch.sigmoid(go) * torch.tanh(c1)
+    close(c_new[::beam], c1, atol=2e-6)
+    close(h_new[::beam], h1, atol=2e-6)
+    close(h_out[:, :hh], h1, atol=2e-6)
+    assert float(h_new[1::beam].abs().max()) == 0
+
+
+def _race(p, noise, k):
+    return torch.topk(p / noise, k, dim=-1).indices
+
+
+@pytest.mark.parametrize("v,beam,top_k,temp", [(1000, 3, 20, 1.3), (36541, 5, 50, 1.0), (71, 7, 50, 1.1), (500, 1, 1, 1.0)])
+def test_beam_row_sample(hip, v, beam, top_k, temp):
+    """beam.py:32-48,78-79 with caller-supplied Exp(1) noise == torch.multinomial's race."""
+    from oracle.ref_path import BeamBook
+    rows = 6
+    logits = rnd(rows, v, seed=v) * 2.5
+    if top_k > 2:
+        logits[0, 1] = 50.0                              # <unk> is the arg-max of row 0: always dropped
+        logits[2, 10:10 + top_k + 3] = 30.0              # ties straddling the threshold are all kept
+    noise = torch.empty(rows, v).exponential_(1, generator=torch.Generator().manual_seed(3))
+    book = BeamBook(temp, beam, top_k)
+    filt = book.keep_top_k(logits.clone())
+    picks = _race(torch.softmax(filt / temp, -1), noise, beam)
+    vals = torch.gather(filt, 1, picks).log_softmax(-1)
+    pi = torch.empty(rows, beam, dtype=torch.int32, device="cuda")
+    pv = torch.empty(rows, beam, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.beam_row_sample(logits.cuda(), v, rows, 3, beam, top_k, temp, 1, noise.cuda(), 0, 0, 0, pi, pv, err)
+    assert int(err.item()) == 0
+    assert pi.cpu().tolist() == picks.tolist()
+    close(pv, vals, atol=2e-6)
+    # Philox mode: picks are survivors, distinct, deterministic and depend on the seed
+    a, b = torch.empty_like(pi), torch.empty_like(pi)
+    hip.beam_row_sample(logits.cuda(), v, rows, 3, beam, top_k, temp, 1, None, 11, 5, 2, a, pv, err)
+    hip.beam_row_sample(logits.cuda(), v, rows, 3, beam, top_k, temp, 1, None, 11, 5, 2, b, pv, err)
+    assert a.cpu().tolist() == b.cpu().tolist()
+    for row in range(rows):
+        ids = a[row].cpu().tolist()
+        assert len(set(ids)) == beam and all(torch.isfinite(filt[row, i]) for i in ids)
+
+
+def test_beam_row_sample_all_filtered(hip):
+    """top_k=1 with <unk> as arg-max: the reference raises (beam.py:46); the kernel sets the error bit."""
+    logits = rnd(2, 100)
+    logits[1, 1] = 99.0
+    pi = torch.empty(2, 1, dtype=torch.int32, device="cuda")
+    pv = torch.empty(2, 1, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.beam_row_sample(logits.cuda(), 100, 2, 1, 1, 1, 1.0, 1, None, 0, 0, 0, pi, pv, err)
+    assert int(err.item()) & hip.ERR_ALL_FILTERED
+    assert int(pi[0, 0]) == int(logits[0].argmax())
+
+
+def test_beam_select_matches_reference_process_logits(hip):
+    """G4 golden: BeamSearchHelper.process_logits recorded from the real reference (torch.manual_seed(7)),
+    replayed through both kernels with the same Exp(1) noise."""
+    g = golden("g4_beam_helper.npz")
+    logits = torch.from_numpy(g["pl_logits"])
+    b, v = 3, logits.shape[1]
+    torch.manual_seed(7)
+    noise_row = torch.empty(b, v).exponential_(1)        # what multinomial consumed inside process_logits
+    pi = torch.empty(b, b, dtype=torch.int32, device="cuda")
+    pv = torch.empty(b, b, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.beam_row_sample(logits.cuda(), v, b, b, b, 5, 0.7, 1, noise_row.cuda(), 0, 0, 0, pi, pv, err)
+    tokens = torch.zeros(b, 4, dtype=torch.int32)
+    tokens[:, :2] = torch.from_numpy(g["pl_seqs"]).int()
+    tokens, vals = tokens.cuda(), torch.from_numpy(g["pl_vals"]).cuda()
+    ended = torch.tensor([0, 1, 0], dtype=torch.uint8).cuda()
+    parent, hparent = torch.zeros(b, dtype=torch.int32).cuda(), torch.zeros(b, dtype=torch.int32).cuda()
+    done, end_step = torch.zeros(1, dtype=torch.uint8).cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    # candidate order of the reference: [b0 x3, b1 x1, b2 x3]; give candidates 4, 3, 0 the smallest noise
+    n_cand = len(g["pl_new_ind"])
+    cand_val = torch.from_numpy(g["pl_prev_vals"].reshape(-1) + g["pl_new_val"])
+    noise_c = torch.ones(1, b * b)
+    noise_c[0, :n_cand] = torch.tensor([1.0, 50.0, 60.0, 0.5, 0.1, 70.0, 80.0])
+    keep = _race(torch.softmax(cand_val / 0.7, -1), noise_c[0, :n_cand], b)
+    hip.beam_select(pi, pv, tokens, vals, ended, None, parent, hparent, done, end_step, 1, b, False, False, 2, 0, 2,
+                    0.7, 3, noise_c.cuda(), 0, 0)
+    exp_seq = torch.cat([torch.from_numpy(g["pl_prev_seqs"]), torch.from_numpy(g["pl_new_ind"])[:, None]], 1)[keep]
+    assert tokens[:, :3].cpu().tolist() == exp_seq.tolist()
+    close(vals, cand_val[keep], atol=2e-6)
+    assert ended.cpu().bool().tolist() == torch.from_numpy(g["pl_has_ended"])[keep].tolist()
+    cand_parent = torch.tensor([0, 0, 0, 1, 2, 2, 2])
+    assert parent.cpu().tolist() == cand_parent[keep].tolist()
+    assert hparent.cpu().tolist() == (keep // b).tolist()       # rnn_models.py:135-137 dense-layout quirk
+    assert int(done.item()) == int(bool(torch.from_numpy(g["pl_has_ended"])[keep].all()))
