@@ -240,7 +240,8 @@ __global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
         }
         all_ended &= cend[c];
     }
-    if (lane == 0 && all_ended) { p.done[img] = 1; p.end_step[img] = p.step_index; }
+    // the reference only tests all_ended() inside the token loop (rnn_models.py:131), never after the first draw
+    if (lane == 0 && all_ended && !p.first) { p.done[img] = 1; p.end_step[img] = p.step_index; }
 }
 
 extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* tokens, int tok_ld,

@@ -25,7 +25,8 @@ def shapes_to_sd(kind, m=None):
     fixed ``scale`` parameters filled in as the reference constructs them."""
     m = m or meta()
     rec = m["models"][kind]
-    hp = rec["hp"] or {"hid_dim": 512, "n_heads": 8, "pad_index": 0}
+    hp = rec["hp"] or {"num_tokens": 1000, "hid_dim": 512, "n_layers": 6, "n_heads": 8, "pf_dim": 2048,
+                       "enc_dropout": 0.3, "dec_dropout": 0.1, "pad_index": 0, "max_len": 128}
     sd = {}
     for k, shp in rec["keys"].items():
         if k.endswith("num_batches_tracked"):
