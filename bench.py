@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Benchmark of the image -> caption hot path on MI355X (contract: see the task brief / DESIGN.md).
+
+    python bench.py --gpus 1 --steps K --warmup W                 # one rank
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic images that are already resident
+in HBM: ResNet-50 encoder -> decoder -> beam-search generate (beam=5, top_k=50, 32 tokens) for
+``--batch`` images per rank, followed -- when N > 1 -- by the single all_gather of token ids.
+``value`` = captions finished by all ranks / wall time (max over ranks), weak scaling (256 images
+per GPU).  Workloads (BASELINE.json configs): ``c2`` = CaptioningLSTM (default, configs[1]);
+``c3`` = CaptioningTransformer 6-layer/8-head.  The default run reports c2 as the contract line and
+attaches a short c3 measurement (with the decoder self-attention roofline) under ``"c3"``.
+
+Only the ``cpu_baseline`` leg and the greedy parity check import ``oracle/`` (the CPU restatement of
+the reference); the measured path is the HIP library only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+V_WORD = 36541          # deephumor_demo.ipynb:524
+MAX_LEN = 32            # deephumor_demo.ipynb:1127
+BEAM, TOP_K, TEMP = 5, 50, 1.0
+PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
+
+
+def build_model(workload, dev):
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import synth_state_dict
+    cls = M.CaptioningLSTM if workload == "c2" else M.CaptioningTransformer
+    model = cls(V_WORD).eval()
+    sd = synth_state_dict(model.state_dict(), seed=1234)
+    model.load_state_dict(sd)
+    return model.to(dev), sd, model._hp
+
+
+def one_step(model, images, img0, n_total, seed):
+    from deephumor_amd.dist import gather_captions
+    toks, lens = model.generate_batch(images, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP,
+                                      seed=seed, img0=img0)
+    return gather_captions(toks, lens, n_total)
+
+
+def kind_of(workload):
+    return "CaptioningLSTM" if workload == "c2" else "CaptioningTransformer"
+
+
+def cpu_baseline(workload, sd, hp, n_sample):
+    """The oracle (CPU restatement of the reference: per-image generate, full re-forward per token,
+    fp32, torch CPU threads) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle import ref_path as R
+    from deephumor_amd.synth import synth_images
+    imgs = synth_images(n_sample, seed=0)
+    torch.manual_seed(0)
+    R.model_generate(kind_of(workload), sd, hp, imgs[:1], max_len=4, beam_size=BEAM, top_k=TOP_K)   # warm-up
+    t0 = time.perf_counter()
+    n_tok = 0
+    for i in range(n_sample):
+        ids = R.model_generate(kind_of(workload), sd, hp, imgs[i:i + 1], max_len=MAX_LEN, temperature=TEMP,
+                               beam_size=BEAM, top_k=TOP_K)
+        n_tok += ids.numel()
+    dt = time.perf_counter() - t0
+    return {"value": n_sample / dt, "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "host_cpus": os.cpu_count(),
+            "sample": f"{n_sample} images, {kind_of(workload)} V={V_WORD}, beam={BEAM}, top_k={TOP_K}, "
+                      f"max_len={MAX_LEN}, per-image generate with full re-forward per token (reference algorithm), "
+                      f"{dt:.1f} s, mean length {n_tok / n_sample:.1f}"}
+
+
+def greedy_match(workload, model, sd, hp, n_check):
+    """Greedy decode (beam_size=1, top_k=1) token match of the HIP path vs the CPU oracle."""
+    from oracle import ref_path as R
+    from deephumor_amd.synth import synth_images
+    imgs = synth_images(n_check, seed=0)
+    with torch.no_grad():
+        toks, lens = model.generate_batch(imgs.to(next(model.parameters()).device), max_len=MAX_LEN, beam_size=1, top_k=1)
+    same = total = 0
+    for i in range(n_check):
+        want = R.model_generate(kind_of(workload), sd, hp, imgs[i:i + 1], max_len=MAX_LEN, beam_size=1, top_k=1).reshape(-1).tolist()
+        got = toks[i, :int(lens[i])].cpu().tolist()
+        total += max(len(want), len(got))
+        same += sum(int(a == b) for a, b in zip(want, got))
+    return same / max(total, 1)
+
+
+def roofline_from(summary, prefer=None):
+    """Picks the dominant kernel (by measured time) -- or ``prefer`` -- and prices it against its roofline."""
+    if not summary:
+        return None
+    key = prefer if prefer in summary else max(summary, key=lambda k: summary[k]["ms"])
+    d = summary[key]
+    sec = d["ms"] / 1e3 / max(d["calls"], 1)
+    if key.startswith("dh_attn"):
+        ach = d["bytes"] / d["calls"] / sec / 1e9
+        return {"kernel": key, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
+                "algorithmic_bytes_per_launch": d["bytes"] / d["calls"]}
+    ach = d["flops"] / d["calls"] / sec / 1e12
+    return {"kernel": key, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+            "frac": ach / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
+            "algorithmic_flops_per_launch": d["flops"] / d["calls"]}
+
+
+def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu):
+    import torch.distributed as dist
+    from deephumor_amd import hip
+    from deephumor_amd.synth import synth_images
+    model, sd, hp = build_model(workload, dev)
+    n_local, n_total = args.batch, args.batch * world
+    images = synth_images(n_local, seed=0, first=rank * n_local).to(dev)     # resident in HBM before timing
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lens = None
+    with torch.no_grad():
+        for w in range(warmup):
+            _, lens = one_step(model, images, rank * n_local, n_total, seed=w)
+        barrier()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            _, lens = one_step(model, images, rank * n_local, n_total, seed=100 + s)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        # per-kernel breakdown with HIP events on the launch stream (one extra, untimed-for-`value` step)
+        with hip.profile() as prof:
+            one_step(model, images, rank * n_local, n_total, seed=999)
+        summary = prof.summary()
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    res = {"value": n_total * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "mean_caption_len": float(lens.float().mean()) if lens is not None else None}
+    total_ms = sum(d["ms"] for d in summary.values())
+    res["kernel_breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["ms"])}
+    res["kernel_ms_sum"] = round(total_ms, 3)
+    res["roofline"] = roofline_from(summary)
+    if workload == "c3":
+        res["roofline_self_attention"] = roofline_from(summary, prefer="dh_attn_self_decode")
+        res["roofline_cross_attention"] = roofline_from(summary, prefer="dh_attn_cross_decode")
+    if rank == 0 and with_cpu:
+        res["greedy_token_match_vs_cpu_ref"] = greedy_match(workload, model, sd, hp, 2)
+        res["cpu_baseline"] = cpu_baseline(workload, sd, hp, args.cpu_sample if workload == "c2" else max(2, args.cpu_sample // 4))
+        res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+    del model
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE configs: 256)")
+    ap.add_argument("--workload", choices=["c2", "c3", "both"], default="both")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="images for the CPU baseline leg (rank 0, N=1 only)")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    main_wl = "c2" if args.workload in ("c2", "both") else "c3"
+    with_cpu = (world == 1) and not args.no_cpu
+    res = run_workload(main_wl, args, rank, world, dev, args.steps, args.warmup, with_cpu)
+    line = {
+        "metric": "captions/sec (224x224, 32-tok, beam=5)", "value": res["value"], "unit": "captions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": ("C2 CaptioningLSTM + ImageEncoder (emb 256, hidden 512, 2 layers)" if main_wl == "c2" else
+                                "C3 CaptioningTransformer 6-layer/8-head (spatial feats)"),
+                   "images_per_gpu": args.batch, "global_batch": args.batch * world, "vocab": V_WORD,
+                   "max_len": MAX_LEN, "beam_size": BEAM, "top_k": TOP_K, "temperature": TEMP,
+                   "parallelism": f"image-sharded x{world}, one all_gather of token ids per batch",
+                   "weights": "synthetic name-keyed (seed 1234)", "encoder_in_timed_region": True},
+        "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"),
+        "greedy_token_match_vs_cpu_ref": res.get("greedy_token_match_vs_cpu_ref"),
+        "speedup_vs_cpu": res.get("speedup_vs_cpu"), "mean_caption_len": res["mean_caption_len"],
+        "kernel_breakdown_ms_per_step": res["kernel_breakdown_ms_per_step"],
+    }
+    if args.workload == "both":
+        r3 = run_workload("c3", args, rank, world, dev, max(1, args.steps // 2), 1, with_cpu)
+        line["c3"] = {"workload": "C3 CaptioningTransformer 6-layer/8-head (spatial feats), same batch/beam settings",
+                      "value": r3["value"], "unit": "captions/s", "ms_per_step": r3["ms_per_step"],
+                      "roofline": r3["roofline"], "roofline_self_attention": r3.get("roofline_self_attention"),
+                      "roofline_cross_attention": r3.get("roofline_cross_attention"),
+                      "cpu_baseline": r3.get("cpu_baseline"), "speedup_vs_cpu": r3.get("speedup_vs_cpu"),
+                      "greedy_token_match_vs_cpu_ref": r3.get("greedy_token_match_vs_cpu_ref"),
+                      "kernel_breakdown_ms_per_step": r3["kernel_breakdown_ms_per_step"]}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

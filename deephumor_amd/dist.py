@@ -1,0 +1,54 @@
+"""Image-sharded captioning over the GPUs of one node (one process per GPU, RCCL over xGMI).
+
+Every image's caption depends only on that image and the replicated weights (the reference's
+``generate`` is batch-1, so independence holds by construction -- SURVEY.md section 8e).  The image
+batch is therefore split into contiguous shards, each rank decodes its shard with NO data-path
+collective, and the results are exchanged ONCE per batch with a single ``all_gather`` of the padded
+token ids and lengths (64 KB per rank at 256 x 32) -- never per decode step.  The Philox noise of
+stochastic beam search is keyed by the GLOBAL image index (``img0``), so captions do not depend on
+the world size.
+"""
+import torch
+import torch.distributed as dist
+
+__all__ = ["shard_range", "gather_captions", "generate_sharded"]
+
+
+def shard_range(n_total, rank, world_size):
+    """Contiguous shard ``[lo, hi)`` of ``n_total`` images for ``rank``; the first ``n_total %
+    world_size`` ranks get one extra image (300 images / 8 ranks -> 38,38,38,38,37,37,37,37)."""
+    base, extra = divmod(n_total, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def gather_captions(tokens, lengths, n_total, group=None):
+    """``tokens [n_local, T]`` int64, ``lengths [n_local]`` -> the full ``[n_total, T]`` / ``[n_total]``
+    on every rank, in global image order.  One ``all_gather_into_tensor`` on shards padded to the
+    largest shard (uneven shards differ by at most one image)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tokens, lengths
+    world = dist.get_world_size(group)
+    t = tokens.shape[1]
+    cap = -(-n_total // world)
+    packed = torch.zeros((cap, t + 1), dtype=torch.int64, device=tokens.device)
+    packed[:tokens.shape[0], :t] = tokens
+    packed[:tokens.shape[0], t] = lengths
+    out = torch.empty((world * cap, t + 1), dtype=torch.int64, device=tokens.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        rows.append(out[r * cap:r * cap + (hi - lo)])
+    full = torch.cat(rows, 0)
+    return full[:, :t].contiguous(), full[:, t].contiguous()
+
+
+def generate_sharded(generate_fn, n_total, group=None):
+    """Runs ``generate_fn(lo, hi) -> (tokens, lengths)`` on this rank's shard (``lo`` is the global
+    index of its first image: pass it as ``img0``) and gathers the whole batch on every rank."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = shard_range(n_total, rank, world)
+    tokens, lengths = generate_fn(lo, hi)
+    return gather_captions(tokens, lengths, n_total, group)

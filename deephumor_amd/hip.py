@@ -78,6 +78,62 @@ def _check(code, name):
         raise RuntimeError(f"{name} failed: {load().dh_error_string(code).decode()} (code {code})")
 
 
+class Profiler:
+    """Per-entry-point HIP-event timing on the stream the kernels are launched on (torch's current
+    stream).  ``with hip.profile(watch={...}) as prof`` brackets every watched C-ABI call with an
+    event pair; ``prof.summary()`` gives calls, total/avg ms and the algorithmic flops/bytes the
+    wrappers attach.  Used by bench.py for the roofline line; off (zero overhead) otherwise."""
+
+    def __init__(self, watch=None):
+        self.watch = None if watch is None else set(watch)
+        self.events = []
+
+    def wants(self, name):
+        return self.watch is None or name in self.watch
+
+    def __enter__(self):
+        global _prof
+        self._prev, _prof = _prof, self
+        return self
+
+    def __exit__(self, *exc):
+        global _prof
+        _prof = self._prev
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, tag, e0, e1, flops, nbytes in self.events:
+            key = name if tag is None else f"{name}[{tag}]"
+            d = out.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+_prof = None
+
+
+def profile(watch=None):
+    return Profiler(watch)
+
+
+def _launch(name, *args, flops=0.0, nbytes=0.0, tag=None):
+    fn = getattr(load(), name)
+    p = _prof
+    if p is not None and p.wants(name):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        code = fn(*args)
+        e1.record()
+        p.events.append((name, tag, e0, e1, flops, nbytes))
+    else:
+        code = fn(*args)
+    _check(code, name)
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
@@ -112,9 +168,11 @@ def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad=0,
     ho, wo = (h + 2 * pad - kh) // stride + 1, (wd + 2 * pad - kw) // stride + 1
     if out is None:
         out = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device)
-    _check(load().dh_conv2d_bn_act(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
-                                   n, cin, h, wd, cout, kh, kw, stride, pad, int(relu), _dt(x), _stream()),
-           "dh_conv2d_bn_act")
+    _launch("dh_conv2d_bn_act", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
+                                   n, cin, h, wd, cout, kh, kw, stride, pad, int(relu), _dt(x), _stream(),
+            flops=2.0 * n * ho * wo * cout * cin * kh * kw,
+            nbytes=4.0 * (x.numel() + w.numel() + out.numel() * (2 if residual is not None else 1)),
+            tag=f"{kh}x{kw}")
     return out
 
 
@@ -122,7 +180,7 @@ def maxpool3x3s2(x):
     _dev(x)
     n, c, h, w = x.shape
     out = torch.empty((n, c, (h - 1) // 2 + 1, (w - 1) // 2 + 1), dtype=x.dtype, device=x.device)
-    _check(load().dh_maxpool3x3s2(_ptr(x), _ptr(out), n, c, h, w, _dt(x), _stream()), "dh_maxpool3x3s2")
+    _launch("dh_maxpool3x3s2", _ptr(x), _ptr(out), n, c, h, w, _dt(x), _stream())
     return out
 
 
@@ -131,7 +189,7 @@ def avgpool_rows(x):
     _dev(x)
     n, c, h, w = x.shape
     out = torch.empty((n, c), dtype=x.dtype, device=x.device)
-    _check(load().dh_avgpool_rows(_ptr(x), _ptr(out), n * c, h * w, _dt(x), _stream()), "dh_avgpool_rows")
+    _launch("dh_avgpool_rows", _ptr(x), _ptr(out), n * c, h * w, _dt(x), _stream())
     return out
 
 
@@ -140,7 +198,7 @@ def nchw_to_rows(x):
     _dev(x)
     n, c, h, w = x.shape
     out = torch.empty((n, h * w, c), dtype=x.dtype, device=x.device)
-    _check(load().dh_nchw_to_rows(_ptr(x), _ptr(out), n, c, h * w, _dt(x), _stream()), "dh_nchw_to_rows")
+    _launch("dh_nchw_to_rows", _ptr(x), _ptr(out), n, c, h * w, _dt(x), _stream())
     return out
 
 
@@ -149,12 +207,12 @@ def label_mean(emb, labels, out):
     _dev(emb, labels, out)
     n, l = labels.shape
     assert labels.dtype == torch.int64 and labels.is_contiguous() and out.stride(1) == 1
-    _check(load().dh_label_mean(_ptr(emb), _ptr(labels), _ptr(out), out.stride(0), n, l, emb.shape[1], _dt(emb),
-                                _stream()), "dh_label_mean")
+    _launch("dh_label_mean", _ptr(emb), _ptr(labels), _ptr(out), out.stride(0), n, l, emb.shape[1], _dt(emb),
+                                _stream())
     return out
 
 
-def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None):
+def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=None):
     """a [M, K] (row stride may exceed K), w [N, K] -> [M, N]."""
     _dev(a, w, bias, scale, shift, out)
     m, k = a.shape
@@ -163,17 +221,18 @@ def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None):
     if out is None:
         out = torch.empty((m, n), dtype=a.dtype, device=a.device)
     assert out.shape == (m, n) and out.stride(1) == 1
-    _check(load().dh_linear(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(scale), _ptr(shift),
-                            _ptr(out), out.stride(0), m, n, k, int(relu), _dt(a), _stream()), "dh_linear")
+    _launch("dh_linear", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(scale), _ptr(shift),
+                            _ptr(out), out.stride(0), m, n, k, int(relu), _dt(a), _stream(),
+            flops=2.0 * m * n * k, nbytes=4.0 * (m * k + n * k + m * n), tag=tag)
     return out
 
 
 def embed_rows(tok_emb, pos_emb, start_emb, tokens, x, rows, rows_per_img, row_mult, pos, scale):
     _dev(tok_emb, pos_emb, start_emb, tokens, x)
     d = tok_emb.shape[1]
-    _check(load().dh_embed_rows(_ptr(tok_emb), _ptr(pos_emb), _ptr(start_emb), _ptr(tokens),
+    _launch("dh_embed_rows", _ptr(tok_emb), _ptr(pos_emb), _ptr(start_emb), _ptr(tokens),
                                 tokens.stride(0) if tokens is not None else 0, _ptr(x), rows, rows_per_img,
-                                row_mult, pos, d, float(scale), _dt(tok_emb), _stream()), "dh_embed_rows")
+                                row_mult, pos, d, float(scale), _dt(tok_emb), _stream())
     return x
 
 
@@ -182,26 +241,27 @@ def add_layernorm(x, y, gamma, beta, out=None, eps=1e-5):
     rows, d = x.shape
     if out is None:
         out = torch.empty_like(x)
-    _check(load().dh_add_layernorm(_ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(out), rows, d, float(eps),
-                                   _dt(x), _stream()), "dh_add_layernorm")
+    _launch("dh_add_layernorm", _ptr(x), _ptr(y), _ptr(gamma), _ptr(beta), _ptr(out), rows, d, float(eps),
+                                   _dt(x), _stream())
     return out
 
 
 def attn_self_decode(qkv, kcache, vcache, src, tokens, out, n_img, rows_per_img, row_mult, rows_total, t, d,
                      n_heads, scale, pad_index):
     _dev(qkv, kcache, vcache, src, tokens, out)
-    _check(load().dh_attn_self_decode(_ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(src), src.stride(0),
+    _launch("dh_attn_self_decode", _ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(src), src.stride(0),
                                       _ptr(tokens), tokens.stride(0), _ptr(out), n_img, rows_per_img, row_mult,
-                                      rows_total, t, d, n_heads, float(scale), pad_index, _dt(qkv), _stream()),
-           "dh_attn_self_decode")
+                                      rows_total, t, d, n_heads, float(scale), pad_index, _dt(qkv), _stream(),
+            nbytes=4.0 * n_img * rows_per_img * ((t + 1) * 2 * d + 2 * d),
+            flops=4.0 * n_img * rows_per_img * (t + 1) * d)
     return out
 
 
 def attn_cross_decode(q, kv, keymask, out, n_img, rows_per_img, s, d, n_heads, scale):
     _dev(q, kv, keymask, out)
-    _check(load().dh_attn_cross_decode(_ptr(q), q.stride(0), _ptr(kv), _ptr(keymask), _ptr(out), n_img,
-                                       rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream()),
-           "dh_attn_cross_decode")
+    _launch("dh_attn_cross_decode", _ptr(q), q.stride(0), _ptr(kv), _ptr(keymask), _ptr(out), n_img,
+                                       rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream(),
+            nbytes=4.0 * n_img * (s * 2 * d + rows_per_img * 2 * d), flops=4.0 * n_img * rows_per_img * s * d)
     return out
 
 
@@ -210,49 +270,47 @@ def enc_key_mask(enc_out):
     _dev(enc_out)
     rows, d = enc_out.shape
     out = torch.empty((rows,), dtype=torch.uint8, device=enc_out.device)
-    _check(load().dh_enc_key_mask(_ptr(enc_out), _ptr(out), rows, d, _dt(enc_out), _stream()), "dh_enc_key_mask")
+    _launch("dh_enc_key_mask", _ptr(enc_out), _ptr(out), rows, d, _dt(enc_out), _stream())
     return out
 
 
 def lstm_prepare(emb, img_emb, tokens, tok_pos, hparent, h_prev, c_prev, xcat0, xcatl, c_cur, rows, rows_per_img,
                  row_mult, rows_total, n_layers, e, hh):
     _dev(emb, img_emb, tokens, hparent, h_prev, c_prev, xcat0, xcatl, c_cur)
-    _check(load().dh_lstm_prepare(_ptr(emb), _ptr(img_emb), _ptr(tokens),
+    _launch("dh_lstm_prepare", _ptr(emb), _ptr(img_emb), _ptr(tokens),
                                   tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(hparent),
                                   _ptr(h_prev), _ptr(c_prev), _ptr(xcat0), _ptr(xcatl), _ptr(c_cur), rows,
-                                  rows_per_img, row_mult, rows_total, n_layers, e, hh, _dt(xcat0), _stream()),
-           "dh_lstm_prepare")
+                                  rows_per_img, row_mult, rows_total, n_layers, e, hh, _dt(xcat0), _stream())
 
 
 def lstm_cell(gates, c_cur, h_new, c_new, h_out, ld_out, rows, row_mult, hh):
     _dev(gates, c_cur, h_new, c_new, h_out)
-    _check(load().dh_lstm_cell(_ptr(gates), _ptr(c_cur), _ptr(h_new), _ptr(c_new), _ptr(h_out), ld_out, rows,
-                               row_mult, hh, _dt(gates), _stream()), "dh_lstm_cell")
+    _launch("dh_lstm_cell", _ptr(gates), _ptr(c_cur), _ptr(h_new), _ptr(c_new), _ptr(h_out), ld_out, rows,
+                               row_mult, hh, _dt(gates), _stream())
 
 
 def beam_row_sample(logits, v, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step,
                     pick_idx, pick_val, err):
     _dev(logits, noise, pick_idx, pick_val, err)
     assert logits.dtype == torch.float32
-    _check(load().dh_beam_row_sample(_ptr(logits), logits.stride(0), v, rows, rows_per_img, beam, top_k,
+    _launch("dh_beam_row_sample", _ptr(logits), logits.stride(0), v, rows, rows_per_img, beam, top_k,
                                      float(temperature), unk_index, _ptr(noise), seed, img0, step, _ptr(pick_idx),
-                                     _ptr(pick_val), _ptr(err), _stream()), "dh_beam_row_sample")
+                                     _ptr(pick_val), _ptr(err), _stream())
 
 
 def beam_select(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, n_img, beam, first,
                 first_sets_ended, write_pos, t, step_index, temperature, eos_index, noise, seed, img0):
     _dev(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, noise)
-    _check(load().dh_beam_select(_ptr(pick_idx), _ptr(pick_val), _ptr(tokens), tokens.stride(0), _ptr(vals),
+    _launch("dh_beam_select", _ptr(pick_idx), _ptr(pick_val), _ptr(tokens), tokens.stride(0), _ptr(vals),
                                  _ptr(ended), _ptr(src), src.stride(0) if src is not None else 0, _ptr(parent),
                                  _ptr(hparent), _ptr(done), _ptr(end_step), n_img, beam, int(first),
                                  int(first_sets_ended), write_pos, t, step_index, float(temperature), eos_index,
-                                 _ptr(noise), seed, img0, _stream()), "dh_beam_select")
+                                 _ptr(noise), seed, img0, _stream())
 
 
 def beam_finalize(tokens, vals, done, end_step, out, out_len, n_img, beam, len_bias_done, full_len, pad_index,
                   temperature, noise, seed, img0):
     _dev(tokens, vals, done, end_step, out, out_len, noise)
-    _check(load().dh_beam_finalize(_ptr(tokens), tokens.stride(0), _ptr(vals), _ptr(done), _ptr(end_step),
+    _launch("dh_beam_finalize", _ptr(tokens), tokens.stride(0), _ptr(vals), _ptr(done), _ptr(end_step),
                                    _ptr(out), out.stride(0), _ptr(out_len), n_img, beam, len_bias_done, full_len,
-                                   pad_index, float(temperature), _ptr(noise), seed, img0, _stream()),
-           "dh_beam_finalize")
+                                   pad_index, float(temperature), _ptr(noise), seed, img0, _stream())

@@ -76,7 +76,7 @@ class LSTMDecoder(nn.Module, _Planned):
         hout = sc["hout"] if hout is None else hout
         for l in range(nl):
             w, b = plan["layers"][l]
-            hip.linear(xcat0 if l == 0 else xcatl[l - 1], w, b, out=gates)
+            hip.linear(xcat0 if l == 0 else xcatl[l - 1], w, b, out=gates, tag="gates")
             if l + 1 < nl:
                 dst, ld = xcatl[l], 2 * hh
             else:
@@ -133,13 +133,13 @@ class LSTMDecoder(nn.Module, _Planned):
         hout = self._step(plan, st, n, 1, b, r, img_emb=image_emb)
         for j in range(pos):
             hout = self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j)
-        lg = hip.linear(hout, plan["cls_w"], plan["cls_b"], out=logits[:n])
+        lg = hip.linear(hout, plan["cls_w"], plan["cls_b"], out=logits[:n], tag="vocab")
         if logits_hook is not None:
             logits_hook(pos, lg)
         helper.step(lg, first=True, write_pos=pos, t=0, step_index=pos, first_sets_ended=True)
         for i in range(pos + 1, max_len):
             hout = self._step(plan, st, r, b, 1, r, tokens=helper.tokens, tok_pos=i - 1, hparent=helper.hparent)
-            hip.linear(hout, plan["cls_w"], plan["cls_b"], out=logits)
+            hip.linear(hout, plan["cls_w"], plan["cls_b"], out=logits, tag="vocab")
             if logits_hook is not None:
                 logits_hook(i, logits)
             helper.step(logits, first=False, write_pos=i, t=0, step_index=i)

@@ -144,7 +144,7 @@ class _IncrementalDecoder(nn.Module, _Planned):
                 flat = enc_out.contiguous().view(n * s, d)
                 self.s = s
                 self.keymask = hip.enc_key_mask(flat)                                   # transformers.py:480-481
-                self.kv = [hip.linear(flat, L["wkv"], L["bkv"]) for L in plan["layers"]]   # once per image
+                self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv") for L in plan["layers"]]   # once per image
             self._scratch = {}
             self.pf = dec.layers[0].pf.fc_1.out_features
             self.d, self.dev = d, dev
@@ -164,19 +164,19 @@ class _IncrementalDecoder(nn.Module, _Planned):
         hip.embed_rows(plan["tok"], plan["pos"], start_emb, tokens, x, rows, rpi, mult, t, plan["scale"])
         n_layers = len(plan["layers"])
         for li, L in enumerate(plan["layers"]):
-            hip.linear(x, L["wqkv"], L["bqkv"], out=sc["qkv"])
+            hip.linear(x, L["wqkv"], L["bqkv"], out=sc["qkv"], tag="qkv")
             hip.attn_self_decode(sc["qkv"], run.kc[li], run.vc[li], src, tokens, sc["att"], run.n_img, rpi, mult,
                                  run.rows_total, t, d, h, L["sa_scale"], self.pad_index)
-            hip.linear(sc["att"], L["wo"], L["bo"], out=sc["o"])
+            hip.linear(sc["att"], L["wo"], L["bo"], out=sc["o"], tag="proj")
             hip.add_layernorm(x, sc["o"], L["ln1"][0], L["ln1"][1], out=x, eps=L["ln1"][2])
             if self._cross:
-                hip.linear(x, L["wq"], L["bq"], out=sc["q"])
+                hip.linear(x, L["wq"], L["bq"], out=sc["q"], tag="proj")
                 hip.attn_cross_decode(sc["q"], run.kv[li], run.keymask, sc["att"], run.n_img, rpi, run.s, d, h,
                                       L["ea_scale"])
-                hip.linear(sc["att"], L["weo"], L["beo"], out=sc["o"])
+                hip.linear(sc["att"], L["weo"], L["beo"], out=sc["o"], tag="proj")
                 hip.add_layernorm(x, sc["o"], L["ln2"][0], L["ln2"][1], out=x, eps=L["ln2"][2])
-            hip.linear(x, L["w1"], L["b1"], relu=True, out=sc["ff"])
-            hip.linear(sc["ff"], L["w2"], L["b2"], out=sc["o"])
+            hip.linear(x, L["w1"], L["b1"], relu=True, out=sc["ff"], tag="ffn")
+            hip.linear(sc["ff"], L["w2"], L["b2"], out=sc["o"], tag="ffn")
             last = li == n_layers - 1 and x_out is not None
             hip.add_layernorm(x, sc["o"], L["ln3"][0], L["ln3"][1], out=x_out if last else x, eps=L["ln3"][2])
         return x_out if x_out is not None else x
@@ -228,13 +228,13 @@ class _IncrementalDecoder(nn.Module, _Planned):
         # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
         for t in range(pos + 1):
             x = self._decode_position(plan, run, t, n, 1, b, helper.tokens, helper.src, start_emb)
-        lg = hip.linear(x, plan["cls_w"], plan["cls_b"], out=logits[:n])
+        lg = hip.linear(x, plan["cls_w"], plan["cls_b"], out=logits[:n], tag="vocab")
         if logits_hook is not None:
             logits_hook(pos, lg)
         helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False)
         for i in range(pos + 1, max_len + 1):
             x = self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, start_emb)
-            hip.linear(x, plan["cls_w"], plan["cls_b"], out=logits)
+            hip.linear(x, plan["cls_w"], plan["cls_b"], out=logits, tag="vocab")
             if logits_hook is not None:
                 logits_hook(i, logits)
             # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn

@@ -1,0 +1,47 @@
+"""world_size-2 gloo test of the image-sharding path (no GPU): shard arithmetic and the single
+all_gather of results reproduce the unsharded order, including uneven shards."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from deephumor_amd.dist import generate_sharded, shard_range
+
+
+def test_shard_range_covers_everything():
+    for n, w in [(300, 8), (2048, 8), (5, 2), (3, 4), (256, 1)]:
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert [hi - lo for lo, hi in (shard_range(300, r, 8) for r in range(8))] == [38] * 4 + [37] * 4
+
+
+def _fake_generate(lo, hi, t=6):
+    """Stands in for model.generate_batch: captions are a pure function of the GLOBAL image index."""
+    idx = torch.arange(lo, hi)
+    toks = (idx[:, None] * 10 + torch.arange(t)[None, :]) % 97
+    lens = (idx % t) + 1
+    return toks, lens
+
+
+def _worker(rank, world, port, n_total, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    toks, lens = generate_sharded(_fake_generate, n_total)
+    ret[rank] = (toks.clone(), lens.clone())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gather_in_global_order():
+    for n_total in (8, 7):
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_worker, args=(2, 29500 + n_total, n_total, ret), nprocs=2, join=True)
+            want_t, want_l = _fake_generate(0, n_total)
+            for r in range(2):
+                toks, lens = ret[r]
+                assert torch.equal(toks, want_t) and torch.equal(lens, want_l)
