@@ -17,6 +17,35 @@ __device__ __forceinline__ uint32_t f2key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+
+// Picks the radix digit holding the k-th largest key: the digit d with (#keys in digits > d) < k <= (... >= d).
+// Parallel suffix sum over the 256 bins (wave shuffles + 4 wave totals) instead of a serial scan whose
+// dependent LDS reads cost ~10 us per pass.  Must be called by all threads of the block; threads
+// 0..255 own one bin each.  `bins` may be 1 or 4 histograms of 256 (summed).
+__device__ __forceinline__ void radix_pick_digit(const int* hist, int n_hist, int shift, uint32_t prefix,
+                                                 uint32_t* s_prefix, int* s_k, int* wtot) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = *s_k;
+    int c = 0, suf = 0;
+    if (tid < 256) {
+        for (int h = 0; h < n_hist; ++h) c += hist[h * 256 + tid];
+        suf = c;                                   // inclusive suffix sum inside the wave (towards higher lanes)
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_down(suf, o, 64);
+            if (lane + o < 64) suf += t;
+        }
+        if (lane == 0) wtot[wave] = suf;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        int above = suf - c;                       // bins above me inside my wave
+        for (int w = wave + 1; w < 4; ++w) above += wtot[w];
+        if (above < k && k <= above + c) { *s_prefix = prefix | ((uint32_t)tid << shift); *s_k = k - above; }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ float block_reduce_256(float v, float* red, bool is_max) {
     const int tid = threadIdx.x;
     red[tid] = v;
@@ -37,7 +66,7 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
     __shared__ int hist[4][256];
     __shared__ uint32_t s_prefix;
-    __shared__ int s_k, s_cnt;
+    __shared__ int s_k, s_cnt, wtot[4];
     __shared__ int idx_a[CAP], idx_b[CAP];
     __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
     __shared__ float red[256];
@@ -59,18 +88,8 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
             if ((key & mask) == prefix) atomicAdd(&hist[wave][(key >> shift) & 255u], 1);
         }
         __syncthreads();
-        if (tid == 0) {
-            int k = s_k, cum = 0, d = 255;
-            for (; d > 0; --d) {
-                const int c = hist[0][d] + hist[1][d] + hist[2][d] + hist[3][d];
-                if (cum + c >= k) break;
-                cum += c;
-            }
-            s_k = k - cum;
-            s_prefix = prefix | ((uint32_t)d << shift);
-        }
+        radix_pick_digit(&hist[0][0], 4, shift, prefix, &s_prefix, &s_k, wtot);
         mask |= 0xFFu << shift;
-        __syncthreads();
     }
     const uint32_t thr = s_prefix;
 
@@ -138,15 +157,163 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     }
 }
 
+
+// ---- single-pass variant --------------------------------------------------------------------------
+// The logits row is read from HBM exactly ONCE, straight into registers (512 threads x EPT values,
+// every load issued up front).  A valid lower bound of the k-th largest value is the k-th largest of
+// the 512 per-thread maxima (k <= 512): at least k elements are >= it.  Everything >= that bound
+// (about top_k..2*top_k values on real logits) is compacted into LDS and the exact threshold,
+// the survivors and the draws are computed there.  Falls back to the 4-pass radix kernel
+// (beam_row_sample_kernel) only through DH_BEAM_ERR_OVERFLOW if > CAP values pass the bound.
+template <int EPT>
+__global__ __launch_bounds__(512) void beam_row_sample_fast_kernel(
+    const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
+    float temperature, int unk, const float* __restrict__ noise, uint64_t seed, int img0, int step,
+    int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
+    constexpr int NT = 512;
+    __shared__ uint32_t lmax[NT];
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_k, s_cnt, wtot[4];
+    __shared__ int idx_a[CAP], idx_b[CAP];
+    __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
+    __shared__ float red[NT];
+    __shared__ int picks[DH_BEAM_MAX_BEAMS];
+    __shared__ uint32_t s_thr;
+
+    const int rc = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (size_t)rc * ldl;
+    float v[EPT];
+    uint32_t best = 0u;                          // key 0 < key of every real float
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * NT;
+        v[e] = i < V ? row[i] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * NT;
+        if (i < V) best = max(best, f2key(v[e]));
+    }
+    lmax[tid] = best;
+    if (tid == 0) { s_prefix = 0u; s_k = top_k; s_cnt = 0; }
+    // k-th largest of the 512 thread maxima (one key per thread: cheap LDS radix select)
+    uint32_t mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        if ((best & mask) == prefix) atomicAdd(&hist[(best >> shift) & 255u], 1);
+        __syncthreads();
+        radix_pick_digit(hist, 1, shift, prefix, &s_prefix, &s_k, wtot);
+        mask |= 0xFFu << shift;
+    }
+    const uint32_t bound = s_prefix;             // <= key of the row's k-th largest value
+    // compact every value >= bound
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * NT;
+        if (i < V && f2key(v[e]) >= bound) {
+            const int p = atomicAdd(&s_cnt, 1);
+            if (p < CAP) { idx_a[p] = i; val_a[p] = v[e]; }
+        }
+    }
+    __syncthreads();
+    int n0 = s_cnt;
+    if (n0 > CAP) { if (tid == 0) atomicOr(err, DH_BEAM_ERR_OVERFLOW); n0 = CAP; }
+    // exact k-th largest among the candidates: the value whose "strictly greater" count is < k <= "greater or equal"
+    for (int i = tid; i < n0; i += NT) {
+        const uint32_t me = f2key(val_a[i]);
+        int gt = 0, ge = 0;
+        for (int j = 0; j < n0; ++j) { const uint32_t o = f2key(val_a[j]); gt += (o > me); ge += (o >= me); }
+        if (gt < top_k && top_k <= ge) s_thr = me;      // all writers agree on the value
+    }
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const uint32_t thr = s_thr;
+    // survivors: >= threshold (ties kept), unk dropped
+    for (int i = tid; i < n0; i += NT) {
+        if (f2key(val_a[i]) >= thr && idx_a[i] != unk) {
+            const int p = atomicAdd(&s_cnt, 1);
+            idx_b[p] = idx_a[i]; val_b[p] = val_a[i];
+        }
+    }
+    __syncthreads();
+    const int n = s_cnt;
+    if (n == 0) {
+        if (tid == 0) atomicOr(err, DH_BEAM_ERR_ALL_FILTERED);
+        if (tid < beam) { pick_idx[(size_t)rc * beam + tid] = 0; pick_val[(size_t)rc * beam + tid] = 0.f; }
+        return;
+    }
+    // deterministic order: sort survivors by token index
+    for (int i = tid; i < n; i += NT) {
+        const int me = idx_b[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (idx_b[j] < me);
+        idx_a[r] = me; val_a[r] = val_b[i];
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int i = tid; i < n; i += NT) m = fmaxf(m, val_a[i] / temperature);
+    red[tid] = m;
+    __syncthreads();
+    for (int s2 = NT / 2; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] = fmaxf(red[tid], red[tid + s2]); __syncthreads(); }
+    m = red[0];
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < n; i += NT) { const float e = expf(val_a[i] / temperature - m); qv[i] = e; s += e; }
+    red[tid] = s;
+    __syncthreads();
+    for (int s2 = NT / 2; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] = red[tid] + red[tid + s2]; __syncthreads(); }
+    s = red[0];
+    const int img = rc / rows_per_img, rin = rc % rows_per_img;
+    for (int i = tid; i < n; i += NT) {
+        const float nz = noise ? noise[(size_t)rc * ldl + idx_a[i]]
+                               : philox_exp1(seed, (uint32_t)(img0 + img), (uint32_t)step, 0u, (uint32_t)rin, (uint32_t)idx_a[i]);
+        qv[i] = (qv[i] / s) / nz;
+    }
+    if (tid < DH_BEAM_MAX_BEAMS) picks[tid] = -1;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        const float me = qv[i];
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += (qv[j] > me) || (qv[j] == me && j < i);
+        if (r < beam) picks[r] = i;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (n < beam) atomicOr(err, DH_BEAM_ERR_TOO_FEW);
+        float mx = -INFINITY;
+        for (int b = 0; b < beam; ++b) if (picks[b] >= 0) mx = fmaxf(mx, val_a[picks[b]]);
+        float se = 0.f;
+        for (int b = 0; b < beam; ++b) if (picks[b] >= 0) se += expf(val_a[picks[b]] - mx);
+        const float lse = logf(se);
+        for (int b = 0; b < beam; ++b) {
+            const int pi = picks[b];
+            pick_idx[(size_t)rc * beam + b] = pi >= 0 ? idx_a[pi] : 0;
+            pick_val[(size_t)rc * beam + b] = pi >= 0 ? (val_a[pi] - mx) - lse : -INFINITY;
+        }
+    }
+}
+
 extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,
                                   int top_k, float temperature, int unk_index, const float* noise,
                                   uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
                                   int32_t* err, void* stream) {
     DH_REQUIRE(logits && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
     DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
-    hipLaunchKernelGGL(beam_row_sample_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
-                       rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step, pick_idx,
-                       pick_val, err);
+#define DH_FAST(EPT) hipLaunchKernelGGL((beam_row_sample_fast_kernel<EPT>), dim3(rows), dim3(512), 0, \
+        (hipStream_t)stream, logits, ldl, V, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, \
+        step, pick_idx, pick_val, err)
+    if (top_k <= 256 && V <= 512 * 8) DH_FAST(8);
+    else if (top_k <= 256 && V <= 512 * 32) DH_FAST(32);
+    else if (top_k <= 256 && V <= 512 * 72) DH_FAST(72);
+    else
+        hipLaunchKernelGGL(beam_row_sample_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
+                           rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step, pick_idx,
+                           pick_val, err);
+#undef DH_FAST
     DH_LAUNCH_CHECK();
 }
 
