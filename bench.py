@@ -31,16 +31,25 @@ MAX_LEN = 32            # deephumor_demo.ipynb:1127
 BEAM, TOP_K, TEMP = 5, 50, 1.0
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
 
 
-def build_model(workload, dev):
+_SD_CACHE = {}
+
+
+def build_model(workload, dev, dtype="bf16"):
     import deephumor_amd.models as M
     from deephumor_amd.synth import synth_state_dict
     cls = M.CaptioningLSTM if workload == "c2" else M.CaptioningTransformer
     model = cls(V_WORD).eval()
-    sd = synth_state_dict(model.state_dict(), seed=1234)
+    if workload not in _SD_CACHE:
+        _SD_CACHE[workload] = synth_state_dict(model.state_dict(), seed=1234)
+    sd = _SD_CACHE[workload]
     model.load_state_dict(sd)
-    return model.to(dev), sd, model._hp
+    model = model.to(dev)
+    if dtype == "bf16":
+        model = model.bfloat16()
+    return model, sd, model._hp
 
 
 def one_step(model, images, img0, n_total, seed):
@@ -92,7 +101,7 @@ def greedy_match(workload, model, sd, hp, n_check):
     return same / max(total, 1)
 
 
-def roofline_from(summary, prefer=None):
+def roofline_from(summary, prefer=None, dtype="bf16"):
     """Picks the dominant kernel (by measured time) -- or ``prefer`` -- and prices it against its roofline."""
     if not summary:
         return None
@@ -105,16 +114,17 @@ def roofline_from(summary, prefer=None):
                 "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
                 "algorithmic_bytes_per_launch": d["bytes"] / d["calls"]}
     ach = d["flops"] / d["calls"] / sec / 1e12
-    return {"kernel": key, "bound": "mfma", "achieved": ach, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-            "frac": ach / PEAK_F32_TFLOPS, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
+    peak = PEAK_F32_TFLOPS if (dtype == "f32" or key.startswith("dh_stem")) else PEAK_BF16_TFLOPS
+    return {"kernel": key, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+            "frac": ach / peak, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
             "algorithmic_flops_per_launch": d["flops"] / d["calls"]}
 
 
-def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu):
+def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtype="bf16"):
     import torch.distributed as dist
     from deephumor_amd import hip
     from deephumor_amd.synth import synth_images
-    model, sd, hp = build_model(workload, dev)
+    model, sd, hp = build_model(workload, dev, dtype)
     n_local, n_total = args.batch, args.batch * world
     images = synth_images(n_local, seed=0, first=rank * n_local).to(dev)     # resident in HBM before timing
     torch.cuda.synchronize()
@@ -148,12 +158,17 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu):
     total_ms = sum(d["ms"] for d in summary.values())
     res["kernel_breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(summary.items(), key=lambda kv: -kv[1]["ms"])}
     res["kernel_ms_sum"] = round(total_ms, 3)
-    res["roofline"] = roofline_from(summary)
+    res["roofline"] = roofline_from(summary, dtype=dtype)
     if workload == "c3":
-        res["roofline_self_attention"] = roofline_from(summary, prefer="dh_attn_self_decode")
-        res["roofline_cross_attention"] = roofline_from(summary, prefer="dh_attn_cross_decode")
+        res["roofline_self_attention"] = roofline_from(summary, prefer="dh_attn_self_decode", dtype=dtype)
+        res["roofline_cross_attention"] = roofline_from(summary, prefer="dh_attn_cross_decode", dtype=dtype)
     if rank == 0 and with_cpu:
-        res["greedy_token_match_vs_cpu_ref"] = greedy_match(workload, model, sd, hp, 2)
+        # the parity gate is the fp32 path: bit-exact greedy ids vs the CPU reference path
+        m32 = model if dtype == "f32" else build_model(workload, dev, "f32")[0]
+        res["greedy_token_match_vs_cpu_ref"] = greedy_match(workload, m32, sd, hp, 2)
+        if dtype != "f32":
+            res["greedy_token_match_bf16_vs_cpu_ref"] = greedy_match(workload, model, sd, hp, 2)
+            del m32
         res["cpu_baseline"] = cpu_baseline(workload, sd, hp, args.cpu_sample if workload == "c2" else max(2, args.cpu_sample // 4))
         res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
     del model
@@ -170,6 +185,8 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3", "both"], default="both")
     ap.add_argument("--cpu-sample", type=int, default=16, help="images for the CPU baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
+                    help="storage/MFMA operand type of the measured path (BASELINE configs C2/C3: bf16)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -187,11 +204,11 @@ def main():
 
     main_wl = "c2" if args.workload in ("c2", "both") else "c3"
     with_cpu = (world == 1) and not args.no_cpu
-    res = run_workload(main_wl, args, rank, world, dev, args.steps, args.warmup, with_cpu)
+    res = run_workload(main_wl, args, rank, world, dev, args.steps, args.warmup, with_cpu, args.dtype)
     line = {
         "metric": "captions/sec (224x224, 32-tok, beam=5)", "value": res["value"], "unit": "captions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": ("C2 CaptioningLSTM + ImageEncoder (emb 256, hidden 512, 2 layers)" if main_wl == "c2" else
                                 "C3 CaptioningTransformer 6-layer/8-head (spatial feats)"),
                    "images_per_gpu": args.batch, "global_batch": args.batch * world, "vocab": V_WORD,
@@ -200,11 +217,12 @@ def main():
                    "weights": "synthetic name-keyed (seed 1234)", "encoder_in_timed_region": True},
         "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"),
         "greedy_token_match_vs_cpu_ref": res.get("greedy_token_match_vs_cpu_ref"),
+        "greedy_token_match_bf16_vs_cpu_ref": res.get("greedy_token_match_bf16_vs_cpu_ref"),
         "speedup_vs_cpu": res.get("speedup_vs_cpu"), "mean_caption_len": res["mean_caption_len"],
         "kernel_breakdown_ms_per_step": res["kernel_breakdown_ms_per_step"],
     }
     if args.workload == "both":
-        r3 = run_workload("c3", args, rank, world, dev, max(1, args.steps // 2), 1, with_cpu)
+        r3 = run_workload("c3", args, rank, world, dev, max(1, args.steps // 2), 1, with_cpu, args.dtype)
         line["c3"] = {"workload": "C3 CaptioningTransformer 6-layer/8-head (spatial feats), same batch/beam settings",
                       "value": r3["value"], "unit": "captions/s", "ms_per_step": r3["ms_per_step"],
                       "roofline": r3["roofline"], "roofline_self_attention": r3.get("roofline_self_attention"),

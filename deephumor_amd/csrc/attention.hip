@@ -11,20 +11,22 @@
 // Phase 2: lane = head dim d: out[d] = sum_j p_j * v_j[d], coalesced 256-B value rows.
 #include "common.h"
 
+template <typename T>
 struct AttnParams {
-    const float* q; int ldq;              // query rows (compact)
-    const float* knew; const float* vnew; int ldnew;   // self: this position's k/v (compact rows)
-    float* kc; float* vc;                 // self: cache of one layer [pos][rows_total][D]
+    const T* q; int ldq;                  // query rows (compact)
+    const T* knew; const T* vnew; int ldnew;   // self: this position's k/v (compact rows)
+    T* kc; T* vc;                         // self: cache of one layer [pos][rows_total][D]
     const int32_t* src; int src_ld;       // self: ancestor row per position
     const int32_t* tokens; int tok_ld;    // self: pad masking
-    const float* kv; const uint8_t* keymask;   // cross: [n_img*S][2D], [n_img*S]
-    float* out;
+    const T* kv; const uint8_t* keymask;  // cross: [n_img*S][2D], [n_img*S]
+    T* out;
     int rows_per_img, row_mult, rows_total, L, D, dh, lcap, pad_index;
     float scale;
 };
 
-template <bool CROSS>
-__global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams p) {
+template <typename T, bool CROSS>
+__global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams<T> p) {
+    constexpr int VN = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rc = img * p.rows_per_img + w, rl = rc * p.row_mult;
@@ -33,12 +35,12 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams p) {
     float* sc = qs + dh;
     int* ph = reinterpret_cast<int*>(sc + p.lcap);
 
-    for (int d = lane; d < dh; d += 64) qs[d] = p.q[(size_t)rc * p.ldq + h * dh + d];
+    for (int d = lane; d < dh; d += 64) qs[d] = ldf(p.q + (size_t)rc * p.ldq + h * dh + d);
     __syncthreads();
 
     float mx = -INFINITY;
     for (int j = lane; j < L; j += 64) {
-        const float* kp;
+        const T* kp;
         bool masked;
         if (CROSS) {
             kp = p.kv + (size_t)(img * L + j) * (2 * D) + h * dh;
@@ -57,11 +59,15 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams p) {
         float e = -1e8f;
         if (!masked) {
             float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int d = 0; d < dh; d += 4) {
-                const float4 kk = *reinterpret_cast<const float4*>(kp + d);
-                const float4 qq = *reinterpret_cast<const float4*>(qs + d);
-                a0 = fmaf(kk.x, qq.x, a0); a1 = fmaf(kk.y, qq.y, a1);
-                a2 = fmaf(kk.z, qq.z, a2); a3 = fmaf(kk.w, qq.w, a3);
+            for (int d = 0; d < dh; d += VN) {
+                float kk[VN];
+                load16(kp + d, kk);
+#pragma unroll
+                for (int u = 0; u < VN; u += 4) {
+                    const float4 qq = *reinterpret_cast<const float4*>(qs + d + u);
+                    a0 = fmaf(kk[u], qq.x, a0); a1 = fmaf(kk[u + 1], qq.y, a1);
+                    a2 = fmaf(kk[u + 2], qq.z, a2); a3 = fmaf(kk[u + 3], qq.w, a3);
+                }
             }
             e = ((a0 + a1) + (a2 + a3)) / p.scale;
         }
@@ -84,13 +90,13 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams p) {
         for (int j = 0; j < L; ++j) {
             const float pj = sc[j];
             if (pj == 0.f) continue;              // masked keys underflow to exactly 0 in fp32
-            const float* vp;
+            const T* vp;
             if (CROSS) vp = p.kv + (size_t)(img * L + j) * (2 * D) + D + h * dh;
             else if (j < t) vp = p.vc + ((size_t)j * p.rows_total + ph[j]) * D + h * dh;
             else vp = p.vnew + (size_t)rc * p.ldnew + h * dh;
-            acc = fmaf(pj, vp[d], acc);
+            acc = fmaf(pj, ldf(vp + d), acc);
         }
-        p.out[(size_t)rc * D + h * dh + d] = acc;
+        stf(p.out + (size_t)rc * D + h * dh + d, acc);
         if (!CROSS) {   // append this position to the cache at the row's own logical slot
             p.kc[((size_t)t * p.rows_total + rl) * D + h * dh + d] = p.knew[(size_t)rc * p.ldnew + h * dh + d];
             p.vc[((size_t)t * p.rows_total + rl) * D + h * dh + d] = p.vnew[(size_t)rc * p.ldnew + h * dh + d];
@@ -98,39 +104,50 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams p) {
     }
 }
 
+template <typename T>
+static void launch_self(const void* qkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
+                        const int32_t* tokens, int tok_ld, void* out, int n_img, int rows_per_img, int row_mult,
+                        int rows_total, int t, int D, int n_heads, float scale, int pad_index, hipStream_t s) {
+    AttnParams<T> p{};
+    p.q = (const T*)qkv; p.ldq = 3 * D;
+    p.knew = (const T*)qkv + D; p.vnew = (const T*)qkv + 2 * D; p.ldnew = 3 * D;
+    p.kc = (T*)kcache; p.vc = (T*)vcache; p.src = src; p.src_ld = src_ld;
+    p.tokens = tokens; p.tok_ld = tok_ld; p.out = (T*)out;
+    p.rows_per_img = rows_per_img; p.row_mult = row_mult; p.rows_total = rows_total;
+    p.L = t + 1; p.D = D; p.dh = D / n_heads; p.lcap = (t + 1 + 3) & ~3; p.pad_index = pad_index; p.scale = scale;
+    const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
+    hipLaunchKernelGGL((attn_decode_kernel<T, false>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds, s, p);
+}
+
 extern "C" int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
                                    const int32_t* tokens, int tok_ld, void* out, int n_img, int rows_per_img,
                                    int row_mult, int rows_total, int t, int D, int n_heads, float scale,
                                    int pad_index, int dtype, void* stream) {
-    if (dtype != DH_F32) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(qkv && kcache && vcache && out && n_img > 0 && rows_per_img > 0 && rows_per_img <= DH_BEAM_MAX_BEAMS);
-    DH_REQUIRE(t >= 0 && n_heads > 0 && D % n_heads == 0 && ((D / n_heads) % 4) == 0);
+    DH_REQUIRE(t >= 0 && n_heads > 0 && D % n_heads == 0 && ((D / n_heads) % 8) == 0);
     DH_REQUIRE((t == 0 || src) && (t == 0 || pad_index < 0 || tokens));
-    AttnParams p{};
-    p.q = (const float*)qkv; p.ldq = 3 * D;
-    p.knew = (const float*)qkv + D; p.vnew = (const float*)qkv + 2 * D; p.ldnew = 3 * D;
-    p.kc = (float*)kcache; p.vc = (float*)vcache; p.src = src; p.src_ld = src_ld;
-    p.tokens = tokens; p.tok_ld = tok_ld; p.out = (float*)out;
-    p.rows_per_img = rows_per_img; p.row_mult = row_mult; p.rows_total = rows_total;
-    p.L = t + 1; p.D = D; p.dh = D / n_heads; p.lcap = (t + 1 + 3) & ~3; p.pad_index = pad_index; p.scale = scale;
-    const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
-    hipLaunchKernelGGL((attn_decode_kernel<false>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds,
-                       (hipStream_t)stream, p);
+    DH_DISPATCH_T(dtype, launch_self<T>(qkv, kcache, vcache, src, src_ld, tokens, tok_ld, out, n_img, rows_per_img,
+                                        row_mult, rows_total, t, D, n_heads, scale, pad_index, (hipStream_t)stream));
     DH_LAUNCH_CHECK();
+}
+
+template <typename T>
+static void launch_cross(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out, int n_img,
+                         int rows_per_img, int S, int D, int n_heads, float scale, hipStream_t s) {
+    AttnParams<T> p{};
+    p.q = (const T*)q; p.ldq = ldq; p.kv = (const T*)kv; p.keymask = keymask; p.out = (T*)out;
+    p.rows_per_img = rows_per_img; p.row_mult = 1; p.rows_total = 0;
+    p.L = S; p.D = D; p.dh = D / n_heads; p.lcap = (S + 3) & ~3; p.pad_index = -1; p.scale = scale;
+    const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
+    hipLaunchKernelGGL((attn_decode_kernel<T, true>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds, s, p);
 }
 
 extern "C" int dh_attn_cross_decode(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out,
                                     int n_img, int rows_per_img, int S, int D, int n_heads, float scale,
                                     int dtype, void* stream) {
-    if (dtype != DH_F32) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(q && kv && keymask && out && n_img > 0 && rows_per_img > 0 && rows_per_img <= DH_BEAM_MAX_BEAMS);
-    DH_REQUIRE(S > 0 && n_heads > 0 && D % n_heads == 0 && ((D / n_heads) % 4) == 0 && ldq >= D);
-    AttnParams p{};
-    p.q = (const float*)q; p.ldq = ldq; p.kv = (const float*)kv; p.keymask = keymask; p.out = (float*)out;
-    p.rows_per_img = rows_per_img; p.row_mult = 1; p.rows_total = 0;
-    p.L = S; p.D = D; p.dh = D / n_heads; p.lcap = (S + 3) & ~3; p.pad_index = -1; p.scale = scale;
-    const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
-    hipLaunchKernelGGL((attn_decode_kernel<true>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds,
-                       (hipStream_t)stream, p);
+    DH_REQUIRE(S > 0 && n_heads > 0 && D % n_heads == 0 && ((D / n_heads) % 8) == 0 && ldq >= D);
+    DH_DISPATCH_T(dtype, launch_cross<T>(q, ldq, kv, keymask, out, n_img, rows_per_img, S, D, n_heads, scale,
+                                         (hipStream_t)stream));
     DH_LAUNCH_CHECK();
 }

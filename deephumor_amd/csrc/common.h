@@ -50,3 +50,45 @@ __device__ __forceinline__ float philox_exp1(uint64_t seed, uint32_t img, uint32
     float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
     return -logf(u);
 }
+
+// ---- storage-type helpers: T = float (parity path) or __bf16 (throughput path); math is fp32 ---------
+typedef __bf16 bf16_t;
+template <typename T> struct Vec16;                 // elements per 16-byte access
+template <> struct Vec16<float> { static constexpr int N = 4; };
+template <> struct Vec16<bf16_t> { static constexpr int N = 8; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (bf16_t)f); }
+
+// 16-byte vector load of Vec16<T>::N elements into fp32 registers
+__device__ __forceinline__ void load16(const float* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+__device__ __forceinline__ void load16(const bf16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xFFFF0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xFFFF0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xFFFF0000u);
+}
+__device__ __forceinline__ void store16(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store16(bf16_t* p, const float (&v)[8]) {
+    uint4 t;
+    t.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    t.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    t.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = t;
+}
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+#define DH_DISPATCH_T(dtype, ...)                                             \
+    if ((dtype) == DH_F32) { using T = float; __VA_ARGS__; }                  \
+    else if ((dtype) == DH_BF16) { using T = bf16_t; __VA_ARGS__; }           \
+    else return DH_ERR_UNSUPPORTED;

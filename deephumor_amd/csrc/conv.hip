@@ -27,7 +27,7 @@ struct ConvParams {
     int N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, K, P;   // K = Cin*KS*KS, P = N*Ho*Wo
 };
 
-template <int TM, int KS>
+template <int TM, int KS, bool NHWC_BF16_OUT>
 __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
     constexpr int TN = 128, BK = 16, LDA = TM + 4;
     constexpr int CO_T = TM / 16;            // output channels per thread (8 or 4)
@@ -106,6 +106,34 @@ __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
     }
 
     // ---- epilogue: y = act(acc*scale + shift (+ residual)) --------------------------------------
+    if (NHWC_BF16_OUT) {
+        // stem of the bf16 path: NCHW fp32 image in, channels-last bf16 out (4 consecutive channels per store)
+        bf16_t* yo = reinterpret_cast<bf16_t*>(p.y);
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pj = p0 + g * 64 + tx * 4 + j;
+                if (pj >= p.P) continue;
+#pragma unroll
+                for (int ig = 0; ig < CO_T / 4; ++ig) {
+                    const int cb = co0 + ig * 64 + ty * 4;
+                    if (cb >= p.Cout) continue;
+                    uint16_t h[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        float v = acc[ig * 4 + c][g * 4 + j] * p.scale[cb + c] + p.shift[cb + c];
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        h[c] = f32_to_bf16(v);
+                    }
+                    uint2 pk;
+                    pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                    pk.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+                    *reinterpret_cast<uint2*>(yo + (size_t)pj * p.Cout + cb) = pk;
+                }
+            }
+        return;
+    }
     const bool vec = (HoWo % 4) == 0;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -145,9 +173,10 @@ __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
     }
 }
 
-template <int TM, int KS>
+template <int TM, int KS, bool NHWC_BF16_OUT = false>
 static void launch_conv(const ConvParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((conv_bn_act_kernel<TM, KS>), dim3(dh_cdiv(p.P, 128), dh_cdiv(p.Cout, TM)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_bn_act_kernel<TM, KS, NHWC_BF16_OUT>), dim3(dh_cdiv(p.P, 128), dh_cdiv(p.Cout, TM)),
+                       dim3(256), 0, s, p);
 }
 
 extern "C" int dh_conv2d_bn_act(const void* x, const void* w, const float* scale, const float* shift,
@@ -166,6 +195,93 @@ extern "C" int dh_conv2d_bn_act(const void* x, const void* w, const float* scale
     if (KH == 1) { if (big) launch_conv<128, 1>(p, s); else launch_conv<64, 1>(p, s); }
     else if (KH == 3) { if (big) launch_conv<128, 3>(p, s); else launch_conv<64, 3>(p, s); }
     else { if (big) launch_conv<128, 7>(p, s); else launch_conv<64, 7>(p, s); }
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const float* shift, void* y,
+                                 int N, int Cin, int H, int W, int Cout, int KS, int stride, int pad, int relu,
+                                 void* stream) {
+    DH_REQUIRE(x && w && scale && shift && y && N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && (Cout % 4) == 0);
+    DH_REQUIRE((KS == 7 || KS == 3) && stride >= 1 && pad >= 0);
+    ConvParams p{x, w, scale, shift, nullptr, (float*)y, N, Cin, H, W, Cout, (H + 2 * pad - KS) / stride + 1,
+                 (W + 2 * pad - KS) / stride + 1, stride, pad, relu, Cin * KS * KS, 0};
+    DH_REQUIRE(p.Ho > 0 && p.Wo > 0 && (long long)N * p.Ho * p.Wo < (1ll << 31));
+    p.P = N * p.Ho * p.Wo;
+    hipStream_t s = (hipStream_t)stream;
+    if (KS == 7) { if (Cout >= 128) launch_conv<128, 7, true>(p, s); else launch_conv<64, 7, true>(p, s); }
+    else { if (Cout >= 128) launch_conv<128, 3, true>(p, s); else launch_conv<64, 3, true>(p, s); }
+    DH_LAUNCH_CHECK();
+}
+
+// ---- channels-last bf16 pools (bf16 path) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                                 int N, int H, int W, int C, int Ho, int Wo) {
+    const int c8 = C / 8;
+    const size_t total = (size_t)N * Ho * Wo * c8;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
+        const int cc = (int)(i % c8);
+        size_t r = i / c8;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = -INFINITY;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                float v[8];
+                load16(x + (((size_t)n * H + ih) * W + iw) * C + cc * 8, v);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) m[u] = fmaxf(m[u], v[u]);
+            }
+        }
+        store16(y + (((size_t)n * Ho + oh) * Wo + ow) * C + cc * 8, m);
+    }
+}
+
+extern "C" int dh_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
+    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && (C % 8) == 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       (bf16_t*)y, N, H, W, C, Ho, Wo);
+    DH_LAUNCH_CHECK();
+}
+
+// x [N, HW, C] -> y [N, C]: mean over the HW positions, fp32 accumulation
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                            int N, int HW, int C) {
+    const int c8 = C / 8;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * c8) return;
+    const int n = i / c8, cc = i - n * c8;
+    float s[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] = 0.f;
+    for (int j = 0; j < HW; ++j) {
+        float v[8];
+        load16(x + ((size_t)n * HW + j) * C + cc * 8, v);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s[u] += v[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u] /= (float)HW;
+    store16(y + (size_t)n * C + cc * 8, s);
+}
+
+extern "C" int dh_avgpool_nhwc(const void* x, void* y, int N, int HW, int C, int dtype, void* stream) {
+    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && (C % 8) == 0);
+    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(dh_cdiv((long long)N * (C / 8), 256)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, HW, C);
     DH_LAUNCH_CHECK();
 }
 

@@ -16,6 +16,7 @@ template <int BM, int BN>
 __global__ __launch_bounds__(256) void linear_f32_kernel(
     const float* __restrict__ A, int lda, const float* __restrict__ W, int ldw,
     const float* __restrict__ bias, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ res, int ldres,
     float* __restrict__ C, int ldc, int M, int N, int K, int relu, int tiles_m, int tiles_n) {
     constexpr int BK = 32, LD = BK + 1;
     constexpr int TM = BM / 64, TN = BN / 64;          // 32x32 tiles per wave in each direction
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(
                 if (m >= M) continue;
                 float v = acc[i][j][r] + bv;
                 if (scale) v = v * sc + sh;
+                if (res) v += res[(size_t)m * ldres + n];
                 if (relu) v = fmaxf(v, 0.f);
                 C[(size_t)m * ldc + n] = v;
             }
@@ -119,26 +121,34 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(
     }
 }
 
+int dh_linear_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const float* scale,
+                        const float* shift, const void* residual, int ldres, void* C, int ldc, int M, int N, int K,
+                        int relu, int out_f32, hipStream_t s);
+
 extern "C" int dh_linear(const void* A, int lda, const void* W, int ldw, const float* bias,
-                         const float* scale, const float* shift, void* C, int ldc,
-                         int M, int N, int K, int relu, int dtype, void* stream) {
-    if (dtype != DH_F32) return DH_ERR_UNSUPPORTED;
+                         const float* scale, const float* shift, const void* residual, int ldres,
+                         void* C, int ldc, int M, int N, int K, int relu, int dtype, void* stream) {
     DH_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0);
+    DH_REQUIRE((scale == nullptr) == (shift == nullptr));
+    DH_REQUIRE(!residual || ldres >= N);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DH_BF16 || dtype == DH_BF16_OUT_F32)
+        return dh_linear_bf16_impl(A, lda, W, ldw, bias, scale, shift, residual, ldres, C, ldc, M, N, K, relu,
+                                   dtype == DH_BF16_OUT_F32, s);
+    if (dtype != DH_F32) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE((K % 4) == 0 && (lda % 4) == 0 && (ldw % 4) == 0 && lda >= K && ldw >= K && ldc >= N);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
-    DH_REQUIRE((scale == nullptr) == (shift == nullptr));
-    hipStream_t s = (hipStream_t)stream;
     const long long big_tiles = (long long)dh_cdiv(M, 128) * dh_cdiv(N, 128);
     if (big_tiles >= 192 && M >= 96) {
         const int tm = dh_cdiv(M, 128), tn = dh_cdiv(N, 128);
         hipLaunchKernelGGL((linear_f32_kernel<128, 128>), dim3(tm * tn), dim3(256), 0, s,
-                           (const float*)A, lda, (const float*)W, ldw, bias, scale, shift, (float*)C, ldc,
-                           M, N, K, relu, tm, tn);
+                           (const float*)A, lda, (const float*)W, ldw, bias, scale, shift, (const float*)residual, ldres,
+                           (float*)C, ldc, M, N, K, relu, tm, tn);
     } else {
         const int tm = dh_cdiv(M, 64), tn = dh_cdiv(N, 64);
         hipLaunchKernelGGL((linear_f32_kernel<64, 64>), dim3(tm * tn), dim3(256), 0, s,
-                           (const float*)A, lda, (const float*)W, ldw, bias, scale, shift, (float*)C, ldc,
-                           M, N, K, relu, tm, tn);
+                           (const float*)A, lda, (const float*)W, ldw, bias, scale, shift, (const float*)residual, ldres,
+                           (float*)C, ldc, M, N, K, relu, tm, tn);
     }
     DH_LAUNCH_CHECK();
 }

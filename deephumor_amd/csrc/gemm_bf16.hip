@@ -1,0 +1,291 @@
+// bf16 matrix-core engine: C[M,N] = act((A[M,K] * W[N,K]^T + bias) * scale + shift (+ residual)),
+// bf16 operands, fp32 accumulation in v_mfma_f32_16x16x32_bf16, bf16 or fp32 output.
+//
+// One kernel, two A-operand loaders:
+//   dense  : A is a row-major [M, lda] matrix (every nn.Linear / LSTM gate / vocabulary product);
+//   conv   : A is the implicit im2col of a channels-last (NHWC) activation: row m = output pixel
+//            (n, oh, ow), column k = (kh, kw, ci) with ci fastest, so every 16-byte chunk of 8
+//            consecutive k is 8 consecutive channels of ONE input pixel (Cin % 8 == 0).  The weight
+//            operand is [Cout][kh][kw][ci] (repacked once when the model is planned).  Output rows are
+//            pixels, i.e. the result is NHWC again.
+//
+// Structure (MI355X_MICROARCH / cdna_hip_programming guide, "minimum 2-phase" + glds):
+//   * both operand slabs ([rows][64 k] bf16 = 128-B rows) go HBM/L2 -> LDS with global_load_lds_dwordx4
+//     (no staging VGPRs); a wave instruction fills 8 consecutive rows (1 KiB, lane-linear), and the
+//     bank-conflict swizzle chunk' = chunk ^ (row & 7) is applied on the per-lane SOURCE address;
+//     rows beyond M/N, chunks beyond K and the convolution halo read a 16-byte zero page instead;
+//   * two LDS slabs: the loads of slab t+1 are in flight while slab t feeds the MFMAs, one barrier per slab;
+//   * the weight rows are the MFMA "A" operand and the activation rows the "B" operand, so an
+//     accumulator register quad is 4 consecutive output columns n of one row m;
+//   * the bf16 epilogue stages the fp32 tile through LDS (XOR-swizzled 16-B slots) and finishes with
+//     16-byte row-contiguous residual loads / stores -- one rounding, at the very end; fp32 output
+//     (logits, odd leading dimension) is stored straight from registers.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ uint4 dh_zero_page[4];        // zero-initialised: source of padding chunks
+
+struct GemmBf16Params {
+    const uint16_t* A; int lda;
+    const uint16_t* W; int ldw;
+    const float* bias; const float* scale; const float* shift;
+    const uint16_t* res; int ldres;
+    void* C; int ldc;
+    int M, N, K, relu, out_f32;
+    int conv, H, Wd, Cin, Ho, Wo, KS, stride, pad;     // conv loader: A = NHWC input
+    int tiles_m, tiles_n;
+};
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
+    constexpr int BK = 64;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SLAB = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / 2;              // per-wave sub-tile (2x2 waves)
+    constexpr int TM = WM / 16, TN = WN / 16;            // 16x16 MFMA tiles per wave
+    constexpr int IA = BM / 32, IB = BN / 32;            // glds instructions per wave per slab
+    constexpr int LDS_BYTES = 2 * SLAB;                  // the fp32 epilogue tile (BM*BN*4 B) fits exactly
+    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: consecutive tile ids (sharing a W panel) stay on one XCD's L2
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
+    const int lr = lane >> 3, lpos = lane & 7;           // loader: row within the 8-row group, LDS chunk slot
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(dh_zero_page);
+
+    // ---- per-lane source rows (fixed over the reduction) ----------------------------------------
+    const uint16_t* a_base[IA];
+    int a_ih0[IA], a_iw0[IA], a_swz[IA];
+    bool a_ok[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int row = (wave * IA + i) * 8 + lr, m = m0 + row;
+        a_ok[i] = m < p.M;
+        a_swz[i] = lpos ^ (row & 7);                     // global chunk landing in this lane's LDS slot
+        a_ih0[i] = a_iw0[i] = 0;
+        if (CONV) {
+            const int mm = a_ok[i] ? m : 0;
+            const int hw = p.Ho * p.Wo, n = mm / hw, r = mm - n * hw, oh = r / p.Wo, ow = r - oh * p.Wo;
+            a_ih0[i] = oh * p.stride - p.pad; a_iw0[i] = ow * p.stride - p.pad;
+            a_base[i] = p.A + (size_t)n * p.H * p.Wd * p.Cin;
+        } else {
+            a_base[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.lda;
+        }
+    }
+    const uint16_t* b_base[IB];
+    int b_swz[IB];
+    bool b_ok[IB];
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        const int row = (wave * IB + i) * 8 + lr, n = n0 + row;
+        b_ok[i] = n < p.N;
+        b_swz[i] = lpos ^ (row & 7);
+        b_base[i] = p.W + (size_t)(b_ok[i] ? n : 0) * p.ldw;
+    }
+
+    auto stage = [&](int buf, int k0) {
+        unsigned char* slab = lds + buf * SLAB;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int k = k0 + a_swz[i] * 8;
+            const void* src = zero;
+            if (a_ok[i] && k < p.K) {
+                if (CONV) {
+                    const int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.KS, kw = tap - kh * p.KS;
+                    const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
+                        src = a_base[i] + ((size_t)ih * p.Wd + iw) * p.Cin + ci;
+                } else {
+                    src = a_base[i] + k;
+                }
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int k = k0 + b_swz[i] * 8;
+            const void* src = (b_ok[i] && k < p.K) ? (const void*)(b_base[i] + k) : (const void*)zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int nslab = (p.K + BK - 1) / BK;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA landed (this wave's part) ...
+    __syncthreads();                                      // ... and everybody else's
+    for (int t = 0; t < nslab; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nslab) stage(cur ^ 1, (t + 1) * BK);
+        const unsigned char* sa = lds + cur * SLAB;
+        const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int g = kk * 4 + lq;                    // logical 16-B chunk holding k = kk*32 + 8*lq .. +7
+            bf16x8 fa[TM], fw[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm0 + i * 16 + l15;
+                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + r * 128 + ((g ^ (r & 7)) << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn0 + j * 16 + l15;
+                fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + r * 128 + ((g ^ (r & 7)) << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                  // next slab landed and this one is free to be refilled
+    }
+
+    // ---- epilogue: acc[j][i][r] = C[m = m0+wm0+16i+(lane&15)][n = n0+wn0+16j+4*(lane>>4)+r] --------------
+    float bv[TN][4], sc[TN][4], sh[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wn0 + 16 * j + 4 * lq + r;
+            const bool ok = n < p.N;
+            bv[j][r] = (ok && p.bias) ? p.bias[n] : 0.f;
+            sc[j][r] = (ok && p.scale) ? p.scale[n] : 1.f;
+            sh[j][r] = (ok && p.scale) ? p.shift[n] : 0.f;
+        }
+    if (p.out_f32) {
+        float* C = reinterpret_cast<float*>(p.C);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + wm0 + 16 * i + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = n0 + wn0 + 16 * j + 4 * lq + r;
+                    if (n >= p.N) continue;
+                    float v = (acc[j][i][r] + bv[j][r]) * sc[j][r] + sh[j][r];
+                    if (p.res) v += bf16_to_f32(p.res[(size_t)m * p.ldres + n]);
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    C[(size_t)m * p.ldc + n] = v;
+                }
+        }
+        return;
+    }
+    // bf16 output: stage the fp32 tile in LDS, then finish rows with 16-byte accesses.  Slot s of row m
+    // (16 B = 4 fp32) is stored at slot s ^ (m & (SLOTS-1)): the 16 lanes of a store hit 16 distinct slots.
+    constexpr int SLOTS = BN / 4;
+    float* ep = reinterpret_cast<float*>(lds);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int row = wm0 + 16 * i + l15, slot = (wn0 + 16 * j) / 4 + lq;
+            float4 v;
+            v.x = (acc[j][i][0] + bv[j][0]) * sc[j][0] + sh[j][0];
+            v.y = (acc[j][i][1] + bv[j][1]) * sc[j][1] + sh[j][1];
+            v.z = (acc[j][i][2] + bv[j][2]) * sc[j][2] + sh[j][2];
+            v.w = (acc[j][i][3] + bv[j][3]) * sc[j][3] + sh[j][3];
+            *reinterpret_cast<float4*>(ep + row * BN + ((slot ^ (row & (SLOTS - 1))) << 2)) = v;
+        }
+    __syncthreads();
+    constexpr int CHUNKS = BN / 8;                        // 16-byte bf16 chunks per tile row
+    uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+    const bool fast = ((p.ldc & 7) == 0) && (!p.res || (p.ldres & 7) == 0);
+    for (int c = tid; c < BM * CHUNKS; c += 256) {
+        const int row = c / CHUNKS, ch = c - row * CHUNKS;
+        const int m = m0 + row, n = n0 + ch * 8;
+        if (m >= p.M || n >= p.N) continue;
+        const int sw = row & (SLOTS - 1);
+        const float4 lo = *reinterpret_cast<const float4*>(ep + row * BN + (((2 * ch) ^ sw) << 2));
+        const float4 hi = *reinterpret_cast<const float4*>(ep + row * BN + (((2 * ch + 1) ^ sw) << 2));
+        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        if (fast && n + 8 <= p.N) {
+            if (p.res) {
+                float q[8];
+                load16(reinterpret_cast<const bf16_t*>(p.res + (size_t)m * p.ldres + n), q);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] += q[u];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = fmaxf(v[u], 0.f);
+            }
+            store16(reinterpret_cast<bf16_t*>(C + (size_t)m * p.ldc + n), v);
+        } else {
+            for (int u = 0; u < 8 && n + u < p.N; ++u) {
+                float x = v[u];
+                if (p.res) x += bf16_to_f32(p.res[(size_t)m * p.ldres + n + u]);
+                if (p.relu) x = fmaxf(x, 0.f);
+                C[(size_t)m * p.ldc + n + u] = f32_to_bf16(x);
+            }
+        }
+    }
+}
+
+template <bool CONV>
+static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
+    const long long big_tiles = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
+    if (big_tiles >= 192 && p.M >= 96 && p.N >= 96) {
+        p.tiles_m = dh_cdiv(p.M, 128); p.tiles_n = dh_cdiv(p.N, 128);
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, CONV>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+    } else {
+        p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, CONV>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+    }
+}
+
+// called from dh_linear (gemm.hip) for DH_BF16 / DH_BF16_OUT_F32
+int dh_linear_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const float* scale,
+                        const float* shift, const void* residual, int ldres, void* C, int ldc, int M, int N, int K,
+                        int relu, int out_f32, hipStream_t s) {
+    DH_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K && ldc >= N);
+    DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
+    GemmBf16Params p{};
+    p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw;
+    p.bias = bias; p.scale = scale; p.shift = shift; p.res = (const uint16_t*)residual; p.ldres = ldres;
+    p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.relu = relu; p.out_f32 = out_f32;
+    launch_gemm_bf16<false>(p, s);
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* scale, const float* shift,
+                                     const void* residual, void* y, int N, int H, int W, int Cin, int Cout,
+                                     int KS, int stride, int pad, int relu, int dtype, void* stream) {
+    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(x && w && scale && shift && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
+    DH_REQUIRE((Cin % 8) == 0 && KS >= 1 && stride >= 1 && pad >= 0);
+    DH_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0);
+    GemmBf16Params p{};
+    p.Ho = (H + 2 * pad - KS) / stride + 1; p.Wo = (W + 2 * pad - KS) / stride + 1;
+    DH_REQUIRE(p.Ho > 0 && p.Wo > 0 && (long long)N * p.Ho * p.Wo < (1ll << 31));
+    p.A = (const uint16_t*)x; p.W = (const uint16_t*)w; p.ldw = KS * KS * Cin;
+    p.scale = scale; p.shift = shift; p.res = (const uint16_t*)residual; p.ldres = Cout;
+    p.C = y; p.ldc = Cout; p.M = N * p.Ho * p.Wo; p.N = Cout; p.K = KS * KS * Cin; p.relu = relu; p.out_f32 = 0;
+    p.H = H; p.Wd = W; p.Cin = Cin; p.KS = KS; p.stride = stride; p.pad = pad;
+    hipStream_t s = (hipStream_t)stream;
+    if (KS == 1 && stride == 1 && pad == 0) { p.lda = Cin; p.conv = 0; launch_gemm_bf16<false>(p, s); }
+    else { p.conv = 1; launch_gemm_bf16<true>(p, s); }
+    DH_LAUNCH_CHECK();
+}

@@ -11,7 +11,7 @@ import torch
 
 from . import _build
 
-F32, BF16 = 0, 1
+F32, BF16, BF16_OUT_F32 = 0, 1, 2
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 16
 
@@ -22,11 +22,15 @@ _P, _I, _F, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64
 SIGNATURES = {
     "dh_abi_version": [],
     "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
+    "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 9 + [_P],
+    "dh_maxpool3x3s2_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_avgpool_nhwc": [_P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_avgpool_rows": [_P, _P, _I, _I, _I, _P],
     "dh_nchw_to_rows": [_P, _P, _I, _I, _I, _I, _P],
     "dh_label_mean": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dh_conv2d_nhwc_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "dh_embed_rows": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_add_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "dh_attn_self_decode": [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
@@ -176,6 +180,37 @@ def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad=0,
     return out
 
 
+def stem_conv_nhwc(x, w, scale, shift, stride=2, pad=3, relu=True):
+    """x NCHW fp32 image, w fp32 [Cout,Cin,KS,KS] -> channels-last bf16 [N,Ho,Wo,Cout]."""
+    _dev(x, w, scale, shift)
+    n, cin, h, wd = x.shape
+    cout, _, ks, _ = w.shape
+    assert x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
+    out = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+    _launch("dh_stem_conv_nhwc", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), n, cin, h, wd, cout, ks,
+            stride, pad, int(relu), _stream(), flops=2.0 * n * ho * wo * cout * cin * ks * ks,
+            nbytes=4.0 * x.numel() + 2.0 * out.numel())
+    return out
+
+
+def maxpool3x3s2_nhwc(x):
+    _dev(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=x.dtype, device=x.device)
+    _launch("dh_maxpool3x3s2_nhwc", _ptr(x), _ptr(out), n, h, w, c, _dt(x), _stream())
+    return out
+
+
+def avgpool_nhwc(x):
+    """x [N, H, W, C] channels-last -> [N, C]"""
+    _dev(x)
+    n, h, w, c = x.shape
+    out = torch.empty((n, c), dtype=x.dtype, device=x.device)
+    _launch("dh_avgpool_nhwc", _ptr(x), _ptr(out), n, h * w, c, _dt(x), _stream())
+    return out
+
+
 def maxpool3x3s2(x):
     _dev(x)
     n, c, h, w = x.shape
@@ -212,18 +247,42 @@ def label_mean(emb, labels, out):
     return out
 
 
-def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=None):
-    """a [M, K] (row stride may exceed K), w [N, K] -> [M, N]."""
-    _dev(a, w, bias, scale, shift, out)
+def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=None, residual=None,
+           out_dtype=None):
+    """a [M, K] (row stride may exceed K), w [N, K] -> [M, N].  bf16 operands may produce fp32
+    (``out_dtype=torch.float32``: logits)."""
+    _dev(a, w, bias, scale, shift, out, residual)
     m, k = a.shape
     n, k2 = w.shape
-    assert k == k2 and a.stride(1) == 1 and w.stride(1) == 1
+    assert k == k2 and a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == w.dtype
     if out is None:
-        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+        out = torch.empty((m, n), dtype=out_dtype or a.dtype, device=a.device)
     assert out.shape == (m, n) and out.stride(1) == 1
+    dt = _dt(a)
+    if dt == BF16 and out.dtype == torch.float32:
+        dt = BF16_OUT_F32
+    else:
+        assert out.dtype == a.dtype
+    esz = a.element_size()
     _launch("dh_linear", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(scale), _ptr(shift),
-                            _ptr(out), out.stride(0), m, n, k, int(relu), _dt(a), _stream(),
-            flops=2.0 * m * n * k, nbytes=4.0 * (m * k + n * k + m * n), tag=tag)
+            _ptr(residual), residual.stride(0) if residual is not None else 0,
+            _ptr(out), out.stride(0), m, n, k, int(relu), dt, _stream(),
+            flops=2.0 * m * n * k, nbytes=float(esz * (m * k + n * k) + out.element_size() * m * n), tag=tag)
+    return out
+
+
+def conv2d_nhwc_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad=0):
+    """Channels-last bf16 convolution: x [N,H,W,Cin], w [Cout,KS,KS,Cin] -> [N,Ho,Wo,Cout]."""
+    _dev(x, w, scale, shift, residual)
+    n, h, wd, cin = x.shape
+    cout, ks, ks2, cin2 = w.shape
+    assert cin == cin2 and ks == ks2 and x.is_contiguous() and w.is_contiguous()
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
+    out = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+    _launch("dh_conv2d_nhwc_bn_act", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
+            n, h, wd, cin, cout, ks, stride, pad, int(relu), _dt(x), _stream(),
+            flops=2.0 * n * ho * wo * cout * cin * ks * ks,
+            nbytes=2.0 * (x.numel() + w.numel() + out.numel() * (2 if residual is not None else 1)), tag=f"{ks}x{ks}")
     return out
 
 
@@ -252,7 +311,7 @@ def attn_self_decode(qkv, kcache, vcache, src, tokens, out, n_img, rows_per_img,
     _launch("dh_attn_self_decode", _ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(src), src.stride(0),
                                       _ptr(tokens), tokens.stride(0), _ptr(out), n_img, rows_per_img, row_mult,
                                       rows_total, t, d, n_heads, float(scale), pad_index, _dt(qkv), _stream(),
-            nbytes=4.0 * n_img * rows_per_img * ((t + 1) * 2 * d + 2 * d),
+            nbytes=float(qkv.element_size()) * n_img * rows_per_img * ((t + 1) * 2 * d + 2 * d),
             flops=4.0 * n_img * rows_per_img * (t + 1) * d)
     return out
 
@@ -261,7 +320,7 @@ def attn_cross_decode(q, kv, keymask, out, n_img, rows_per_img, s, d, n_heads, s
     _dev(q, kv, keymask, out)
     _launch("dh_attn_cross_decode", _ptr(q), q.stride(0), _ptr(kv), _ptr(keymask), _ptr(out), n_img,
                                        rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream(),
-            nbytes=4.0 * n_img * (s * 2 * d + rows_per_img * 2 * d), flops=4.0 * n_img * rows_per_img * s * d)
+            nbytes=float(q.element_size()) * n_img * (s * 2 * d + rows_per_img * 2 * d), flops=4.0 * n_img * rows_per_img * s * d)
     return out
 
 
@@ -286,7 +345,7 @@ def lstm_prepare(emb, img_emb, tokens, tok_pos, hparent, h_prev, c_prev, xcat0, 
 def lstm_cell(gates, c_cur, h_new, c_new, h_out, ld_out, rows, row_mult, hh):
     _dev(gates, c_cur, h_new, c_new, h_out)
     _launch("dh_lstm_cell", _ptr(gates), _ptr(c_cur), _ptr(h_new), _ptr(c_new), _ptr(h_out), ld_out, rows,
-                               row_mult, hh, _dt(gates), _stream())
+                               row_mult, hh, _dt(h_new), _stream())
 
 
 def beam_row_sample(logits, v, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step,

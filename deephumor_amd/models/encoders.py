@@ -95,36 +95,53 @@ class ImageEncoder(nn.Module, _Planned):
         self.dropout = nn.Dropout(dropout)
 
     def _build_plan(self):
-        convs = []
+        """fp32 weights -> NCHW vector-ALU convolutions (the parity path); bf16 weights -> channels-last
+        activations with every bottleneck conv on the bf16 matrix cores (weights repacked once to
+        [Cout, kh, kw, Cin]); the 3-channel stem stays on the vector ALUs in both."""
+        bf16 = self.linear.weight.dtype == torch.bfloat16
 
-        def conv(c, bn, relu, residual=False):
+        def conv(c, bn, relu, residual=False, stem=False):
             s, b = _bn_affine(bn)
-            return dict(w=c.weight.detach().contiguous(), scale=s, shift=b, stride=c.stride[0],
-                        pad=c.padding[0], relu=relu, residual=residual)
+            w = c.weight.detach()
+            if bf16:
+                w = w.float().contiguous() if stem else w.permute(0, 2, 3, 1).contiguous()
+            else:
+                w = w.contiguous()
+            return dict(w=w, scale=s, shift=b, stride=c.stride[0], pad=c.padding[0], relu=relu, residual=residual)
 
-        stem = conv(self.resnet[0], self.resnet[1], True)
+        blocks = []
+        stem = conv(self.resnet[0], self.resnet[1], True, stem=True)
         for stage in list(self.resnet)[4:]:
             for blk in stage:
-                convs.append(dict(
+                blocks.append(dict(
                     down=conv(blk.downsample[0], blk.downsample[1], False) if blk.downsample is not None else None,
                     c1=conv(blk.conv1, blk.bn1, True), c2=conv(blk.conv2, blk.bn2, True),
                     c3=conv(blk.conv3, blk.bn3, True, residual=True)))
         s, b = _bn_affine(self.bn)
-        return dict(stem=stem, blocks=convs, bn_scale=s, bn_shift=b)
+        return dict(stem=stem, blocks=blocks, bn_scale=s, bn_shift=b, bf16=bf16,
+                    lin_w=self.linear.weight.detach(), lin_b=self.linear.bias.detach().float().contiguous())
 
     @staticmethod
-    def _conv(x, c, residual=None):
-        return hip.conv2d_bn_act(x, c["w"], c["scale"], c["shift"], residual=residual, relu=c["relu"],
-                                 stride=c["stride"], pad=c["pad"])
+    def _conv(x, c, residual=None, nhwc=False):
+        fn = hip.conv2d_nhwc_bn_act if nhwc else hip.conv2d_bn_act
+        return fn(x, c["w"], c["scale"], c["shift"], residual=residual, relu=c["relu"], stride=c["stride"], pad=c["pad"])
 
     def features(self, images):
-        """Trunk output ``[N, 2048, H/32, W/32]`` (encoders.py:56)."""
+        """Trunk output (encoders.py:56): ``[N, 2048, H/32, W/32]`` fp32 on the parity path,
+        channels-last ``[N, H/32, W/32, 2048]`` bf16 on the bf16 path."""
         plan = self._get_plan()
-        x = hip.maxpool3x3s2(self._conv(images.contiguous(), plan["stem"]))
+        nhwc = plan["bf16"]
+        st = plan["stem"]
+        if nhwc:
+            x = hip.stem_conv_nhwc(images.float().contiguous(), st["w"], st["scale"], st["shift"], stride=st["stride"],
+                                   pad=st["pad"], relu=True)
+            x = hip.maxpool3x3s2_nhwc(x)
+        else:
+            x = hip.maxpool3x3s2(self._conv(images.contiguous(), st))
         for blk in plan["blocks"]:
-            idt = x if blk["down"] is None else self._conv(x, blk["down"])
-            y = self._conv(self._conv(x, blk["c1"]), blk["c2"])
-            x = self._conv(y, blk["c3"], residual=idt)
+            idt = x if blk["down"] is None else self._conv(x, blk["down"], nhwc=nhwc)
+            y = self._conv(self._conv(x, blk["c1"], nhwc=nhwc), blk["c2"], nhwc=nhwc)
+            x = self._conv(y, blk["c3"], residual=idt, nhwc=nhwc)
         return x
 
     def forward(self, images):
@@ -132,12 +149,17 @@ class ImageEncoder(nn.Module, _Planned):
         plan = self._get_plan()
         feats = self.features(images)
         n = feats.shape[0]
-        w, b = self.linear.weight.detach(), self.linear.bias.detach()
-        emb = hip.linear(hip.avgpool_rows(feats), w, b, scale=plan["bn_scale"], shift=plan["bn_shift"])
+        w, b = plan["lin_w"], plan["lin_b"]
+        if plan["bf16"]:
+            pooled, rows = hip.avgpool_nhwc(feats), feats.view(n, -1, feats.shape[-1])     # already [N, k*k, 2048]
+        else:
+            pooled = hip.avgpool_rows(feats)
+        emb = hip.linear(pooled, w, b, scale=plan["bn_scale"], shift=plan["bn_shift"])
         if not self.spatial_features:
             return emb
-        rows = hip.nchw_to_rows(feats)                                    # [N, k*k, 2048]
-        spatial = hip.linear(rows.view(-1, rows.shape[-1]), w, b).view(n, rows.shape[1], -1)
+        if not plan["bf16"]:
+            rows = hip.nchw_to_rows(feats)                                    # [N, k*k, 2048]
+        spatial = hip.linear(rows.reshape(-1, rows.shape[-1]), w, b).view(n, rows.shape[1], -1)
         return emb, spatial
 
 
@@ -172,7 +194,7 @@ class ImageLabelEncoder(nn.Module):
         both = torch.empty((n, 2 * e), dtype=image_emb.dtype, device=image_emb.device)
         both[:, :e].copy_(image_emb)
         self.label_encoder(labels, out=both[:, e:])
-        return hip.linear(both, self.linear.weight.detach(), self.linear.bias.detach())
+        return hip.linear(both, self.linear.weight.detach(), self.linear.bias.detach().float())
 
     def forward(self, images, labels):
         _require_eval(self, self.dropout.p)

@@ -32,10 +32,12 @@ class LSTMDecoder(nn.Module, _Planned):
         for l in range(self.lstm.num_layers):
             w = torch.cat([getattr(self.lstm, f"weight_ih_l{l}").detach(),
                            getattr(self.lstm, f"weight_hh_l{l}").detach()], dim=1).contiguous()
-            b = (getattr(self.lstm, f"bias_ih_l{l}").detach() + getattr(self.lstm, f"bias_hh_l{l}").detach()).contiguous()
+            b = (getattr(self.lstm, f"bias_ih_l{l}").detach().float()
+                 + getattr(self.lstm, f"bias_hh_l{l}").detach().float()).contiguous()
             layers.append((w, b))
         return dict(layers=layers, emb=self.embedding.weight.detach(),
-                    cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach())
+                    cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach().float().contiguous(),
+                    dtype=self.classifier.weight.dtype)
 
     def _check_mode(self):
         if self.training and self.lstm.dropout > 0:
@@ -46,22 +48,22 @@ class LSTMDecoder(nn.Module, _Planned):
 
         def __init__(self, dec, n_img, beam, dev):
             self.nl, self.hh, self.e = dec.lstm.num_layers, dec.lstm.hidden_size, dec.lstm.input_size
-            self.dev = dev
+            self.dev, self.dtype = dev, dec.classifier.weight.dtype
             r = n_img * beam
-            self.h = torch.zeros((self.nl, r, self.hh), device=dev)
-            self.c = torch.zeros((self.nl, r, self.hh), device=dev)
+            self.h = torch.zeros((self.nl, r, self.hh), device=dev, dtype=self.dtype)
+            self.c = torch.zeros((self.nl, r, self.hh), device=dev)             # cell state always fp32
             self.started = False
             self._scratch = {}
 
         def scratch(self, rows):
             if rows not in self._scratch:
-                nl, hh, e, dev = self.nl, self.hh, self.e, self.dev
+                nl, hh, e, dev, dt = self.nl, self.hh, self.e, self.dev, self.dtype
                 self._scratch[rows] = dict(
-                    xcat0=torch.empty((rows, e + hh), device=dev),
-                    xcatl=torch.empty((max(nl - 1, 1), rows, 2 * hh), device=dev),
+                    xcat0=torch.empty((rows, e + hh), device=dev, dtype=dt),
+                    xcatl=torch.empty((max(nl - 1, 1), rows, 2 * hh), device=dev, dtype=dt),
                     c_cur=torch.empty((nl, rows, hh), device=dev),
-                    gates=torch.empty((rows, 4 * hh), device=dev),
-                    hout=torch.empty((rows, hh), device=dev))
+                    gates=torch.empty((rows, 4 * hh), device=dev),              # gate pre-activations fp32
+                    hout=torch.empty((rows, hh), device=dev, dtype=dt))
             return self._scratch[rows]
 
     def _step(self, plan, st, rows, rpi, mult, rows_total, img_emb=None, tokens=None, tok_pos=0, hparent=None,
@@ -99,13 +101,13 @@ class LSTMDecoder(nn.Module, _Planned):
         hh = self.lstm.hidden_size
         tokens = captions.to(torch.int32).contiguous()
         st = self._State(self, bs, 1, dev)
-        hs = torch.zeros((bs, steps_out, hh), device=dev)
+        hs = torch.zeros((bs, steps_out, hh), device=dev, dtype=plan["dtype"])
         for t in range(steps_out):
             self._step(plan, st, bs, 1, 1, bs, img_emb=image_emb if t == 0 else None,
                        tokens=None if t == 0 else tokens, tok_pos=t - 1, hout=hs[:, t, :])
         valid = (torch.arange(steps_out)[None, :] < lengths[:, None]).to(dev)
         hs.mul_(valid[..., None])          # pad_packed_sequence zero rows (mask, not arithmetic on valid rows)
-        out = hip.linear(hs.view(bs * steps_out, hh), plan["cls_w"], plan["cls_b"])
+        out = hip.linear(hs.view(bs * steps_out, hh), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32)
         return out.view(bs, steps_out, -1)
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
@@ -117,7 +119,7 @@ class LSTMDecoder(nn.Module, _Planned):
         (rnn_models.py:48-143, incl. the hidden-state indexing at :135-137)."""
         self._check_mode()
         plan = self._get_plan()
-        image_emb = image_emb.reshape(image_emb.shape[0], -1).contiguous()
+        image_emb = image_emb.reshape(image_emb.shape[0], -1).to(plan["dtype"]).contiguous()
         n, b = image_emb.shape[0], beam_size
         dev = image_emb.device
         r = n * b
@@ -128,7 +130,7 @@ class LSTMDecoder(nn.Module, _Planned):
             pos = caption.shape[1]
             helper.set_prefix(caption)
         st = self._State(self, n, b, dev)
-        logits = torch.empty((r, self.num_tokens), device=dev)
+        logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
         # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam
         hout = self._step(plan, st, n, 1, b, r, img_emb=image_emb)
         for j in range(pos):

@@ -102,27 +102,29 @@ class _IncrementalDecoder(nn.Module, _Planned):
     # ---- derived constants: fused QKV / KV weights, scalar scales --------------------------------
     def _build_plan(self):
         d = lambda t: t.detach()
+        f = lambda t: t.detach().float().contiguous()          # bias / LayerNorm vectors stay fp32
         layers = []
         for lyr in self.layers:
             sa = lyr.self_attn
             ent = dict(
                 wqkv=torch.cat([d(sa.fc_q.weight), d(sa.fc_k.weight), d(sa.fc_v.weight)], 0).contiguous(),
-                bqkv=torch.cat([d(sa.fc_q.bias), d(sa.fc_k.bias), d(sa.fc_v.bias)], 0).contiguous(),
-                wo=d(sa.fc_o.weight), bo=d(sa.fc_o.bias), sa_scale=float(sa.scale),
-                ln1=(d(lyr.self_attn_ln.weight), d(lyr.self_attn_ln.bias), lyr.self_attn_ln.eps),
-                w1=d(lyr.pf.fc_1.weight), b1=d(lyr.pf.fc_1.bias), w2=d(lyr.pf.fc_2.weight), b2=d(lyr.pf.fc_2.bias),
-                ln3=(d(lyr.pf_ln.weight), d(lyr.pf_ln.bias), lyr.pf_ln.eps))
+                bqkv=torch.cat([f(sa.fc_q.bias), f(sa.fc_k.bias), f(sa.fc_v.bias)], 0).contiguous(),
+                wo=d(sa.fc_o.weight), bo=f(sa.fc_o.bias), sa_scale=float(sa.scale),
+                ln1=(f(lyr.self_attn_ln.weight), f(lyr.self_attn_ln.bias), lyr.self_attn_ln.eps),
+                w1=d(lyr.pf.fc_1.weight), b1=f(lyr.pf.fc_1.bias), w2=d(lyr.pf.fc_2.weight), b2=f(lyr.pf.fc_2.bias),
+                ln3=(f(lyr.pf_ln.weight), f(lyr.pf_ln.bias), lyr.pf_ln.eps))
             if self._cross:
                 ea = lyr.enc_attn
                 ent.update(
-                    wq=d(ea.fc_q.weight), bq=d(ea.fc_q.bias),
+                    wq=d(ea.fc_q.weight), bq=f(ea.fc_q.bias),
                     wkv=torch.cat([d(ea.fc_k.weight), d(ea.fc_v.weight)], 0).contiguous(),
-                    bkv=torch.cat([d(ea.fc_k.bias), d(ea.fc_v.bias)], 0).contiguous(),
-                    weo=d(ea.fc_o.weight), beo=d(ea.fc_o.bias), ea_scale=float(ea.scale),
-                    ln2=(d(lyr.enc_attn_ln.weight), d(lyr.enc_attn_ln.bias), lyr.enc_attn_ln.eps))
+                    bkv=torch.cat([f(ea.fc_k.bias), f(ea.fc_v.bias)], 0).contiguous(),
+                    weo=d(ea.fc_o.weight), beo=f(ea.fc_o.bias), ea_scale=float(ea.scale),
+                    ln2=(f(lyr.enc_attn_ln.weight), f(lyr.enc_attn_ln.bias), lyr.enc_attn_ln.eps))
             layers.append(ent)
         return dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
-                    scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=d(self.classifier.bias))
+                    scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=f(self.classifier.bias),
+                    dtype=self.classifier.weight.dtype)
 
     def _check_mode(self):
         if self.training and self.dropout.p > 0:
@@ -136,12 +138,13 @@ class _IncrementalDecoder(nn.Module, _Planned):
         def __init__(self, dec, plan, n_img, beam, n_pos, enc_out, dev):
             d, nl = dec.hid_dim, len(dec.layers)
             self.n_img, self.beam, self.rows_total, self.n_pos = n_img, beam, n_img * beam, n_pos
-            self.kc = torch.empty((nl, n_pos, self.rows_total, d), device=dev)
-            self.vc = torch.empty((nl, n_pos, self.rows_total, d), device=dev)
+            self.dtype = plan["dtype"]
+            self.kc = torch.empty((nl, n_pos, self.rows_total, d), device=dev, dtype=self.dtype)
+            self.vc = torch.empty((nl, n_pos, self.rows_total, d), device=dev, dtype=self.dtype)
             self.kv, self.keymask, self.s = None, None, 0
             if enc_out is not None:
                 n, s, _ = enc_out.shape
-                flat = enc_out.contiguous().view(n * s, d)
+                flat = enc_out.to(self.dtype).contiguous().view(n * s, d)
                 self.s = s
                 self.keymask = hip.enc_key_mask(flat)                                   # transformers.py:480-481
                 self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv") for L in plan["layers"]]   # once per image
@@ -151,7 +154,7 @@ class _IncrementalDecoder(nn.Module, _Planned):
 
         def scratch(self, rows):
             if rows not in self._scratch:
-                e = lambda *shape: torch.empty(shape, device=self.dev)
+                e = lambda *shape: torch.empty(shape, device=self.dev, dtype=self.dtype)
                 self._scratch[rows] = dict(x=e(rows, self.d), qkv=e(rows, 3 * self.d), att=e(rows, self.d),
                                            o=e(rows, self.d), q=e(rows, self.d), ff=e(rows, self.pf))
             return self._scratch[rows]
@@ -196,12 +199,12 @@ class _IncrementalDecoder(nn.Module, _Planned):
         tokens[:, :x.shape[1]] = x.to(torch.int32)
         helper_src = (torch.arange(bs, dtype=torch.int32, device=dev))[:, None].expand(bs, seq).contiguous()
         run = self._Run(self, plan, bs, 1, seq, enc_out, dev)
-        hs = torch.empty((bs, seq, self.hid_dim), device=dev)
-        xt = torch.empty((bs, self.hid_dim), device=dev)
+        hs = torch.empty((bs, seq, self.hid_dim), device=dev, dtype=plan["dtype"])
+        xt = torch.empty((bs, self.hid_dim), device=dev, dtype=plan["dtype"])
         for t in range(seq):
-            self._decode_position(plan, run, t, bs, 1, 1, tokens, helper_src, start_emb.contiguous(), x_out=xt)
+            self._decode_position(plan, run, t, bs, 1, 1, tokens, helper_src, start_emb.to(plan["dtype"]).contiguous(), x_out=xt)
             hs[:, t, :].copy_(xt)
-        out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"])
+        out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32)
         return out.view(bs, seq, -1)
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
@@ -223,8 +226,8 @@ class _IncrementalDecoder(nn.Module, _Planned):
             pos = caption.shape[1]
             helper.set_prefix(caption)
         run = self._Run(self, plan, n, b, max_len + 1, enc_out, dev)
-        start_emb = start_emb.contiguous()
-        logits = torch.empty((r, self.num_tokens), device=dev)
+        start_emb = start_emb.to(plan["dtype"]).contiguous()
+        logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
         # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
         for t in range(pos + 1):
             x = self._decode_position(plan, run, t, n, 1, b, helper.tokens, helper.src, start_emb)

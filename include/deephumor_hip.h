@@ -9,8 +9,10 @@
  *     stream sync inside; workspace is supplied by the caller; re-entrant across streams;
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
  *   - returns DH_OK (0) or a DH_ERR_* code; dh_error_string() names it;
- *   - `dtype` is the storage/compute type of activations and weights (DH_F32 today; DH_BF16 entry
- *     points return DH_ERR_UNSUPPORTED until their kernels land); accumulation is always fp32.
+ *   - `dtype` is the storage type of activations and weights: DH_F32 (the parity path, bit-exact
+ *     greedy ids vs the reference) or DH_BF16 (the throughput path: bf16 in HBM, bf16 MFMA, fp32
+ *     accumulation; bias/scale/shift/LayerNorm vectors stay fp32).  An entry point that lacks a
+ *     dtype returns DH_ERR_UNSUPPORTED for it.
  *   - row-major everywhere; images NCHW; "rows" are (image, beam) pairs, image-major.
  */
 #ifndef DEEPHUMOR_HIP_H
@@ -22,10 +24,11 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 1
+#define DH_ABI_VERSION 2
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
-enum { DH_F32 = 0, DH_BF16 = 1 };
+enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
+       DH_BF16_OUT_F32 = 2 };            /* dh_linear only: bf16 operands, fp32 output (logits) */
 
 /* device-side error bits OR-ed into the `err` word of the beam kernels */
 enum { DH_BEAM_ERR_ALL_FILTERED = 1,   /* every logit filtered (-inf): reference raises RuntimeError, beam.py:46 */
@@ -49,6 +52,24 @@ int dh_conv2d_bn_act(const void* x, const void* w, const float* scale, const flo
                      const void* residual, void* y, int N, int Cin, int H, int W, int Cout,
                      int KH, int KW, int stride, int pad, int relu, int dtype, void* stream);
 
+/* Channels-last (NHWC) bf16 convolution on the matrix cores, same fused epilogue.  x [N,H,W,Cin],
+ * w [Cout,KS,KS,Cin] (repacked once from the checkpoint's [Cout,Cin,KS,KS]), residual/y [N,Ho,Wo,Cout].
+ * Implicit GEMM: rows = output pixels, k = (kh,kw,ci); Cin % 8 == 0.  DH_BF16 only. */
+int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* scale, const float* shift,
+                          const void* residual, void* y, int N, int H, int W, int Cin, int Cout,
+                          int KS, int stride, int pad, int relu, int dtype, void* stream);
+
+/* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
+ * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */
+int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const float* shift, void* y,
+                      int N, int Cin, int H, int W, int Cout, int KS, int stride, int pad, int relu,
+                      void* stream);
+
+/* Channels-last bf16 pools of the bf16 path: MaxPool2d(3,2,1) x [N,H,W,C] -> [N,Ho,Wo,C];
+ * AdaptiveAvgPool2d(1) x [N,HW,C] -> y [N,C].  C % 8 == 0.  DH_BF16 only. */
+int dh_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
+int dh_avgpool_nhwc(const void* x, void* y, int N, int HW, int C, int dtype, void* stream);
+
 /* MaxPool2d(kernel 3, stride 2, padding 1) -- trunk index 3.  x [N,C,H,W] -> y [N,C,Ho,Wo]. */
 int dh_maxpool3x3s2(const void* x, void* y, int N, int C, int H, int W, int dtype, void* stream);
 
@@ -68,12 +89,14 @@ int dh_label_mean(const void* emb, const int64_t* labels, void* out, int ld_out,
  * nn.LSTM gate products; transformers.py:97,127,162-163,488)
  * ------------------------------------------------------------------------------------------- */
 
-/* C[m,n] = act( (sum_k A[m,k]*W[n,k] + bias[n]) * scale[n] + shift[n] ), fp32 accumulate on the
- * matrix cores.  A [M,K] lda, W [N,K] ldw (nn.Linear layout), C [M,N] ldc.  bias/scale/shift may be
- * NULL (scale/shift: eval-mode BatchNorm1d folded behind the Linear, encoders.py:61).  K % 4 == 0. */
+/* C[m,n] = act( (sum_k A[m,k]*W[n,k] + bias[n]) * scale[n] + shift[n] + residual[m,n] ), fp32 accumulate
+ * on the matrix cores (fp32: v_mfma_f32_32x32x2_f32, exact; bf16: v_mfma_f32_32x32x16_bf16).
+ * A [M,K] lda, W [N,K] ldw (nn.Linear layout), C [M,N] ldc, residual [M,N] ldres (same type as C's
+ * operands).  bias/scale/shift/residual may be NULL (scale/shift: eval-mode BatchNorm1d folded behind
+ * the Linear, encoders.py:61).  K % 4 == 0 (fp32) / K % 8 == 0 (bf16). */
 int dh_linear(const void* A, int lda, const void* W, int ldw, const float* bias,
-              const float* scale, const float* shift, void* C, int ldc,
-              int M, int N, int K, int relu, int dtype, void* stream);
+              const float* scale, const float* shift, const void* residual, int ldres,
+              void* C, int ldc, int M, int N, int K, int relu, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row addressing shared by the decoder kernels.  A decode step works on `rows` compact rows
@@ -130,17 +153,19 @@ int dh_enc_key_mask(const void* enc_out, uint8_t* keymask, int rows, int D, int 
  * where x_in = emb[tokens[rl*tok_ld + tok_pos]] if tokens != NULL else img_emb[img], and
  * hp = hparent ? hparent[rl] : rl; hp < 0 or h_prev == NULL means zero state.
  * h_prev/c_prev [n_layers, rows_total, Hh]; xcat0 [rows, E+Hh]; xcatl [n_layers-1, rows, 2*Hh];
- * c_cur [n_layers, rows, Hh]. */
+ * c_cur [n_layers, rows, Hh].  Embeddings / hidden states have the storage dtype; the cell state c
+ * (c_prev, c_cur) is always fp32. */
 int dh_lstm_prepare(const void* emb, const void* img_emb, const int32_t* tokens, int tok_ld, int tok_pos,
-                    const int32_t* hparent, const void* h_prev, const void* c_prev,
-                    void* xcat0, void* xcatl, void* c_cur, int rows, int rows_per_img, int row_mult,
+                    const int32_t* hparent, const void* h_prev, const float* c_prev,
+                    void* xcat0, void* xcatl, float* c_cur, int rows, int rows_per_img, int row_mult,
                     int rows_total, int n_layers, int E, int Hh, int dtype, void* stream);
 
-/* gates [rows, 4*Hh] in PyTorch order i,f,g,o (biases already added by dh_linear):
+/* gates [rows, 4*Hh] fp32 in PyTorch order i,f,g,o (biases already added by dh_linear; with bf16
+ * operands use DH_BF16_OUT_F32 there), c_cur / c_new fp32, h_new / h_out in the storage dtype:
  *   c' = sigmoid(f)*c_cur + sigmoid(i)*tanh(g);  h' = sigmoid(o)*tanh(c')
  * writes h_new[rl], c_new[rl] (state at logical rows) and h_out[rc*ld_out + 0..Hh) (next layer's
  * input slot or the classifier input). */
-int dh_lstm_cell(const void* gates, const void* c_cur, void* h_new, void* c_new, void* h_out,
+int dh_lstm_cell(const float* gates, const float* c_cur, void* h_new, float* c_new, void* h_out,
                  int ld_out, int rows, int row_mult, int Hh, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -280,3 +280,51 @@ def test_beam_select_matches_reference_process_logits(hip):
     assert parent.cpu().tolist() == cand_parent[keep].tolist()
     assert hparent.cpu().tolist() == (keep // b).tolist()       # rnn_models.py:135-137 dense-layout quirk
     assert int(done.item()) == int(bool(torch.from_numpy(g["pl_has_ended"])[keep].all()))
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 throughput path: bf16 storage, bf16 MFMA, fp32 accumulate.  References are computed in fp32
+# from the SAME bf16-rounded operands, so the only differences are accumulation order and the final
+# rounding of the output to bf16 (<= 2^-8 relative).
+# ------------------------------------------------------------------------------------------------
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("m,n,k", [(4, 1000, 512), (1280, 512, 512), (300, 4567, 768), (77, 130, 2048), (1, 64, 8)])
+def test_linear_bf16(hip, m, n, k):
+    a, w, b = bf(rnd(m, k, seed=1)), bf(rnd(n, k, seed=2) / k ** 0.5), rnd(n, seed=3)
+    ref = F.linear(a.float(), w.float(), b)
+    out32 = hip.linear(a.cuda(), w.cuda(), b.cuda(), out_dtype=torch.float32)
+    assert out32.dtype == torch.float32
+    close(out32, ref, atol=1e-4 * max(1.0, k ** 0.5 / 8), rtol=1e-4)
+    out = hip.linear(a.cuda(), w.cuda(), b.cuda())
+    assert out.dtype == torch.bfloat16
+    close(out.float(), ref, atol=2e-2, rtol=1e-2)
+    sc, sh, res = rnd(n, seed=4).abs() + 0.5, rnd(n, seed=5), bf(rnd(m, n, seed=6))
+    out = hip.linear(a.cuda(), w.cuda(), b.cuda(), scale=sc.cuda(), shift=sh.cuda(), residual=res.cuda(), relu=True)
+    close(out.float(), torch.relu(ref * sc + sh + res.float()), atol=3e-2, rtol=1e-2)
+
+
+def test_linear_f32_residual(hip):
+    a, w, b, res = rnd(70, 64, seed=1), rnd(50, 64, seed=2), rnd(50, seed=3), rnd(70, 50, seed=4)
+    out = hip.linear(a.cuda(), w.cuda(), b.cuda(), residual=res.cuda())
+    close(out, F.linear(a, w, b) + res, atol=5e-5)
+
+
+@pytest.mark.parametrize("cin,cout,hw,ks,stride,pad,n", [
+    (64, 64, 14, 1, 1, 0, 2), (64, 256, 14, 1, 1, 0, 2), (256, 128, 14, 1, 2, 0, 2), (128, 128, 14, 3, 2, 1, 3),
+    (64, 64, 9, 3, 1, 1, 2), (512, 2048, 7, 1, 1, 0, 3), (512, 512, 7, 3, 1, 1, 3), (1024, 2048, 14, 1, 2, 0, 2),
+    (64, 64, 56, 3, 1, 1, 5)])
+def test_conv_nhwc_bf16(hip, cin, cout, hw, ks, stride, pad, n):
+    x, w = bf(rnd(n, cin, hw, hw, seed=1)), bf(rnd(cout, cin, ks, ks, seed=2) * (2.0 / (cin * ks * ks)) ** 0.5)
+    sc, sh = rnd(cout, seed=3).abs() + 0.5, rnd(cout, seed=4)
+    ref = F.conv2d(x.float(), w.float(), stride=stride, padding=pad) * sc[None, :, None, None] + sh[None, :, None, None]
+    res = bf(rnd(*ref.shape, seed=5))
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous().cuda()
+    w_k = w.permute(0, 2, 3, 1).contiguous().cuda()                 # [Cout, KS, KS, Cin]
+    out = hip.conv2d_nhwc_bn_act(x_nhwc, w_k, sc.cuda(), sh.cuda(), relu=False, stride=stride, pad=pad)
+    close(out.float().permute(0, 3, 1, 2), ref, atol=3e-2, rtol=1e-2)
+    out = hip.conv2d_nhwc_bn_act(x_nhwc, w_k, sc.cuda(), sh.cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda(),
+                                 relu=True, stride=stride, pad=pad)
+    close(out.float().permute(0, 3, 1, 2), torch.relu(ref + res.float()), atol=3e-2, rtol=1e-2)
