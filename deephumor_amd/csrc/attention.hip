@@ -104,6 +104,132 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams<T> p) {
     }
 }
 
+
+// ---- bandwidth-shaped variant (head_dim 32/64/128) ------------------------------------------------------
+// A wave still owns one (row, head), but its 64 lanes are arranged as (key slot, 8-dim chunk):
+// LPK = DH/8 lanes cover one key's head slice with ONE 16-byte load each (bf16; two for fp32), so a
+// wave instruction reads 64/LPK whole key slices (1 KiB for bf16) instead of 64 different lines, and the
+// key loop has L/(64/LPK) iterations of independent loads instead of L dependent ones.  Scores are
+// reduced across the LPK lanes of a key (xor-shuffles), softmax is the same exp/sum/divide as the
+// reference, the weighted value sum is accumulated per (key slot, chunk) and reduced across key slots.
+__device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) { load16(p, v); }
+__device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) { store16(p, v); }
+__device__ __forceinline__ void copy8(float* d, const float* s) {
+    *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(s);
+    *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(s + 4);
+}
+__device__ __forceinline__ void copy8(bf16_t* d, const bf16_t* s) {
+    *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+}
+
+template <typename T, bool CROSS, int DH>
+__global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p) {
+    constexpr int LPK = DH / 8, KPI = 64 / LPK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rc = img * p.rows_per_img + w, rl = rc * p.row_mult;
+    const int D = p.D, L = p.L, t = L - 1;
+    const int kg = lane / LPK, dc = lane % LPK;
+    float* sc = smem + (size_t)w * 2 * p.lcap;
+    int* ph = reinterpret_cast<int*>(sc + p.lcap);
+
+    float qv[8];
+    load8(p.q + (size_t)rc * p.ldq + h * DH + dc * 8, qv);
+
+    float mx = -INFINITY;
+    for (int j0 = 0; j0 < L; j0 += KPI) {
+        const int j = j0 + kg;
+        float e = -INFINITY;
+        if (j < L) {
+            const T* kp;
+            bool masked;
+            int phys = rl;
+            if (CROSS) {
+                kp = p.kv + (size_t)(img * L + j) * (2 * D) + h * DH;
+                masked = p.keymask[img * L + j] != 0;
+            } else {
+                if (j < t) {
+                    phys = p.src[(size_t)rl * p.src_ld + j];
+                    kp = p.kc + ((size_t)j * p.rows_total + phys) * D + h * DH;
+                } else {
+                    kp = p.knew + (size_t)rc * p.ldnew + h * DH;
+                }
+                masked = (j >= 1) && (p.tokens[(size_t)rl * p.tok_ld + j - 1] == p.pad_index);
+            }
+            float kk[8];
+            load8(kp + dc * 8, kk);
+            float a = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fmaf(kk[u], qv[u], a);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
+            e = masked ? -1e8f : a / p.scale;
+            if (dc == 0) { sc[j] = e; if (!CROSS) ph[j] = phys; }
+        }
+        mx = fmaxf(mx, e);
+    }
+    mx = wave_max(mx);
+    __syncthreads();
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) {
+        const float e = expf(sc[j] - mx);
+        sc[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    for (int j = lane; j < L; j += 64) sc[j] = sc[j] / sum;     // attention weights, as torch.softmax
+    __syncthreads();
+
+    float o[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) o[u] = 0.f;
+#pragma unroll 4
+    for (int j0 = 0; j0 < L; j0 += KPI) {
+        const int j = j0 + kg;
+        if (j < L) {
+            const T* vp;
+            if (CROSS) vp = p.kv + (size_t)(img * L + j) * (2 * D) + D + h * DH;
+            else if (j < t) vp = p.vc + ((size_t)j * p.rows_total + ph[j]) * D + h * DH;
+            else vp = p.vnew + (size_t)rc * p.ldnew + h * DH;
+            float vv[8];
+            load8(vp + dc * 8, vv);
+            const float pj = sc[j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o[u] = fmaf(pj, vv[u], o[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int s2 = LPK; s2 < 64; s2 <<= 1) o[u] += __shfl_xor(o[u], s2, 64);
+    if (kg == 0) {
+        store8(p.out + (size_t)rc * D + h * DH + dc * 8, o);
+        if (!CROSS) {   // append this position to the cache at the row's own logical slot
+            copy8(p.kc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.knew + (size_t)rc * p.ldnew + h * DH + dc * 8);
+            copy8(p.vc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.vnew + (size_t)rc * p.ldnew + h * DH + dc * 8);
+        }
+    }
+}
+
+template <typename T, bool CROSS>
+static bool launch_fast(AttnParams<T>& p, int n_img, int n_heads, int rows_per_img, hipStream_t s) {
+    const size_t lds = (size_t)rows_per_img * 2 * p.lcap * sizeof(float);
+    const dim3 grid(n_img, n_heads), block(64 * rows_per_img);
+    if (p.dh == 64) hipLaunchKernelGGL((attn_decode_fast_kernel<T, CROSS, 64>), grid, block, lds, s, p);
+    else if (p.dh == 128) hipLaunchKernelGGL((attn_decode_fast_kernel<T, CROSS, 128>), grid, block, lds, s, p);
+    else if (p.dh == 32) hipLaunchKernelGGL((attn_decode_fast_kernel<T, CROSS, 32>), grid, block, lds, s, p);
+    else return false;
+    return true;
+}
+
 template <typename T>
 static void launch_self(const void* qkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
                         const int32_t* tokens, int tok_ld, void* out, int n_img, int rows_per_img, int row_mult,
@@ -115,6 +241,7 @@ static void launch_self(const void* qkv, void* kcache, void* vcache, const int32
     p.tokens = tokens; p.tok_ld = tok_ld; p.out = (T*)out;
     p.rows_per_img = rows_per_img; p.row_mult = row_mult; p.rows_total = rows_total;
     p.L = t + 1; p.D = D; p.dh = D / n_heads; p.lcap = (t + 1 + 3) & ~3; p.pad_index = pad_index; p.scale = scale;
+    if (launch_fast<T, false>(p, n_img, n_heads, rows_per_img, s)) return;
     const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
     hipLaunchKernelGGL((attn_decode_kernel<T, false>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds, s, p);
 }
@@ -138,6 +265,7 @@ static void launch_cross(const void* q, int ldq, const void* kv, const uint8_t* 
     p.q = (const T*)q; p.ldq = ldq; p.kv = (const T*)kv; p.keymask = keymask; p.out = (T*)out;
     p.rows_per_img = rows_per_img; p.row_mult = 1; p.rows_total = 0;
     p.L = S; p.D = D; p.dh = D / n_heads; p.lcap = (S + 3) & ~3; p.pad_index = -1; p.scale = scale;
+    if (launch_fast<T, true>(p, n_img, n_heads, rows_per_img, s)) return;
     const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
     hipLaunchKernelGGL((attn_decode_kernel<T, true>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds, s, p);
 }

@@ -328,3 +328,22 @@ def test_conv_nhwc_bf16(hip, cin, cout, hw, ks, stride, pad, n):
     out = hip.conv2d_nhwc_bn_act(x_nhwc, w_k, sc.cuda(), sh.cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda(),
                                  relu=True, stride=stride, pad=pad)
     close(out.float().permute(0, 3, 1, 2), torch.relu(ref + res.float()), atol=3e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("d,h", [(128, 8), (512, 4), (256, 8)])
+def test_attn_other_head_dims(hip, d, h):
+    """head_dim 16 -> generic kernel; 128 and 32 -> the (key slot, chunk) kernel."""
+    n_img, beam, t, tmax = 2, 3, 9, 16
+    r, dh = n_img * beam, d // h
+    qkv = rnd(r, 3 * d, seed=d)
+    kc, vc = rnd(tmax + 1, r, d, seed=1), rnd(tmax + 1, r, d, seed=2)
+    src = (torch.arange(r)[:, None] // beam * beam).expand(r, tmax + 1).contiguous().int()
+    tokens = torch.randint(0, 3, (r, tmax), dtype=torch.int32)
+    out = torch.empty(r, d, device="cuda")
+    hip.attn_self_decode(qkv.cuda(), kc.cuda(), vc.cuda(), src.cuda(), tokens.cuda(), out, n_img, beam, 1, r, t, d, h,
+                         float(dh) ** 0.5, 0)
+    for row in range(r):
+        keys = torch.stack([kc[j, src[row, j]] for j in range(t)] + [qkv[row, d:2 * d]]).view(t + 1, h, dh)
+        vals = torch.stack([vc[j, src[row, j]] for j in range(t)] + [qkv[row, 2 * d:]]).view(t + 1, h, dh)
+        masked = torch.tensor([False] + [bool(tokens[row, j - 1] == 0) for j in range(1, t + 1)])
+        close(out[row], _attn_ref(qkv[row, :d].view(h, dh), keys, vals, masked, float(dh) ** 0.5), atol=2e-5)
