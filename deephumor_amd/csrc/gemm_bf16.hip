@@ -41,14 +41,31 @@ struct GemmBf16Params {
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
-template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
+// wait until at most `n` of this wave's vector-memory operations (LDS-DMA included) are outstanding
+__device__ __forceinline__ void wait_vmcnt(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// NS = LDS ring depth: slabs t+1 .. t+NS-1 are in flight (LDS-DMA) while slab t feeds the MFMAs.
+template <int BM, int BN, bool CONV, int NS>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SLAB = A_BYTES + B_BYTES;
     constexpr int WM = BM / 2, WN = BN / 2;              // per-wave sub-tile (2x2 waves)
     constexpr int TM = WM / 16, TN = WN / 16;            // 16x16 MFMA tiles per wave
     constexpr int IA = BM / 32, IB = BN / 32;            // glds instructions per wave per slab
-    constexpr int LDS_BYTES = 2 * SLAB;                  // the fp32 epilogue tile (BM*BN*4 B) fits exactly
+    constexpr int G = IA + IB;                           // LDS-DMA instructions per wave per slab
+    constexpr int LDS_BYTES = NS * SLAB;                 // >= the fp32 epilogue tile (BM*BN*4 B = 2 slabs)
+    static_assert(NS >= 2 && (NS - 2) * G <= 24, "ring depth vs vmcnt encoding");
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
 
     const int nblk = p.tiles_m * p.tiles_n;
@@ -96,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
     }
 
     auto stage = [&](int buf, int k0) {
-        unsigned char* slab = lds + buf * SLAB;
+        unsigned char* slab = lds + __builtin_amdgcn_readfirstlane(buf) * SLAB;
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const int k = k0 + a_swz[i] * 8;
@@ -129,13 +146,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
 
     const int l15 = lane & 15, lq = lane >> 4;
     const int nslab = (p.K + BK - 1) / BK;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // LDS-DMA landed (this wave's part) ...
-    __syncthreads();                                      // ... and everybody else's
+    // prologue: NS-1 slabs in flight
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < nslab) stage(u, u * BK);
     for (int t = 0; t < nslab; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nslab) stage(cur ^ 1, (t + 1) * BK);
-        const unsigned char* sa = lds + cur * SLAB;
+        // slab t has landed once at most min(NS-2, slabs issued after t) newer slabs are still outstanding
+        const int newer = min(NS - 2, nslab - 1 - t);
+        wait_vmcnt(newer * G);
+        __builtin_amdgcn_s_barrier();                     // everyone's part of slab t landed; slab t-1 fully consumed
+        if (t + NS - 1 < nslab) stage((t + NS - 1) % NS, (t + NS - 1) * BK);   // refill the buffer slab t-1 used
+        const unsigned char* sa = lds + (t % NS) * SLAB;
         const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -157,9 +178,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(GemmBf16Params p) {
                 for (int i = 0; i < TM; ++i)
                     acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                  // next slab landed and this one is free to be refilled
     }
+    __syncthreads();                                      // all slabs consumed: LDS is free for the epilogue
 
     // ---- epilogue: acc[j][i][r] = C[m = m0+wm0+16i+(lane&15)][n = n0+wn0+16j+4*(lane>>4)+r] --------------
     float bv[TN][4], sc[TN][4], sh[TN][4];
@@ -249,11 +269,16 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     const long long big_tiles = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
     if (big_tiles >= 192 && p.M >= 96 && p.N >= 96) {
         p.tiles_m = dh_cdiv(p.M, 128); p.tiles_n = dh_cdiv(p.N, 128);
-        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, CONV>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
-    } else {
-        p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, CONV>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, CONV, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        return;
     }
+    p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
+    const int blocks = p.tiles_m * p.tiles_n;
+    // few blocks: one per CU with a deep ring (7 slabs = 112 KB in flight); many blocks: two per CU, 3 in flight each
+    if (blocks <= 320 && p.K > 128)
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, CONV, 8>), dim3(blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 // called from dh_linear (gemm.hip) for DH_BF16 / DH_BF16_OUT_F32
