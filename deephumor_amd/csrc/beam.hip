@@ -165,12 +165,11 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
 // (about top_k..2*top_k values on real logits) is compacted into LDS and the exact threshold,
 // the survivors and the draws are computed there.  Falls back to the 4-pass radix kernel
 // (beam_row_sample_kernel) only through DH_BEAM_ERR_OVERFLOW if > CAP values pass the bound.
-template <int EPT>
-__global__ __launch_bounds__(512) void beam_row_sample_fast_kernel(
+template <int EPT, int NT, int WPE>
+__global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
     const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
     float temperature, int unk, const float* __restrict__ noise, uint64_t seed, int img0, int step,
     int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
-    constexpr int NT = 512;
     __shared__ uint32_t lmax[NT];
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
@@ -185,11 +184,12 @@ __global__ __launch_bounds__(512) void beam_row_sample_fast_kernel(
     const float* row = logits + (size_t)rc * ldl;
     float v[EPT];
     uint32_t best = 0u;                          // key 0 < key of every real float
+    // buffer loads: one shared per-lane offset + scalar strides, hardware bounds check (reads past V
+    // return 0 and are ignored below) -> ~1 VGPR per element instead of an address pair + predicate
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, V * 4, 0x00020000);
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * NT;
-        v[e] = i < V ? row[i] : 0.f;
-    }
+    for (int e = 0; e < EPT; ++e)
+        v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, tid * 4, e * NT * 4, 0));
 #pragma unroll
     for (int e = 0; e < EPT; ++e) {
         const int i = tid + e * NT;
@@ -303,12 +303,13 @@ extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows,
                                   int32_t* err, void* stream) {
     DH_REQUIRE(logits && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
     DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
-#define DH_FAST(EPT) hipLaunchKernelGGL((beam_row_sample_fast_kernel<EPT>), dim3(rows), dim3(512), 0, \
+#define DH_FAST(EPT, NT, WPE) hipLaunchKernelGGL((beam_row_sample_fast_kernel<EPT, NT, WPE>), dim3(rows), dim3(NT), 0, \
         (hipStream_t)stream, logits, ldl, V, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, \
         step, pick_idx, pick_val, err)
-    if (top_k <= 256 && V <= 512 * 8) DH_FAST(8);
-    else if (top_k <= 256 && V <= 512 * 32) DH_FAST(32);
-    else if (top_k <= 256 && V <= 512 * 72) DH_FAST(72);
+    if (top_k <= 256 && V <= 512 * 8) DH_FAST(8, 512, 4);
+    else if (top_k <= 256 && V <= 1024 * 16) DH_FAST(16, 1024, 8);
+    else if (top_k <= 256 && V <= 1024 * 36) DH_FAST(36, 1024, 8);
+    else if (top_k <= 256 && V <= 1024 * 64) DH_FAST(64, 1024, 4);
     else
         hipLaunchKernelGGL(beam_row_sample_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
                            rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step, pick_idx,

@@ -193,27 +193,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
             sc[j][r] = (ok && p.scale) ? p.scale[n] : 1.f;
             sh[j][r] = (ok && p.scale) ? p.shift[n] : 0.f;
         }
-    if (p.out_f32) {
-        float* C = reinterpret_cast<float*>(p.C);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm0 + 16 * i + l15;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = n0 + wn0 + 16 * j + 4 * lq + r;
-                    if (n >= p.N) continue;
-                    float v = (acc[j][i][r] + bv[j][r]) * sc[j][r] + sh[j][r];
-                    if (p.res) v += bf16_to_f32(p.res[(size_t)m * p.ldres + n]);
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    C[(size_t)m * p.ldc + n] = v;
-                }
-        }
-        return;
-    }
-    // bf16 output: stage the fp32 tile in LDS, then finish rows with 16-byte accesses.  Slot s of row m
+    // Stage the fp32 tile in LDS, then finish rows with row-contiguous accesses.  Slot s of row m
     // (16 B = 4 fp32) is stored at slot s ^ (m & (SLOTS-1)): the 16 lanes of a store hit 16 distinct slots.
     constexpr int SLOTS = BN / 4;
     float* ep = reinterpret_cast<float*>(lds);
@@ -230,6 +210,21 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
             *reinterpret_cast<float4*>(ep + row * BN + ((slot ^ (row & (SLOTS - 1))) << 2)) = v;
         }
     __syncthreads();
+    if (p.out_f32) {
+        // fp32 output (logits; leading dimension may be odd): lane <-> consecutive column, so every wave
+        // store is one contiguous run of up to 256 B of a row whatever its alignment
+        float* Cf = reinterpret_cast<float*>(p.C);
+        for (int e = tid; e < BM * BN; e += 256) {
+            const int row = e / BN, col = e - row * BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m >= p.M || n >= p.N) continue;
+            float x = ep[row * BN + ((((col >> 2) ^ (row & (SLOTS - 1))) << 2) | (col & 3))];
+            if (p.res) x += bf16_to_f32(p.res[(size_t)m * p.ldres + n]);
+            if (p.relu) x = fmaxf(x, 0.f);
+            Cf[(size_t)m * p.ldc + n] = x;
+        }
+        return;
+    }
     constexpr int CHUNKS = BN / 8;                        // 16-byte bf16 chunks per tile row
     uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
     const bool fast = ((p.ldc & 7) == 0) && (!p.res || (p.ldres & 7) == 0);
