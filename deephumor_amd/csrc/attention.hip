@@ -219,10 +219,133 @@ __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p)
     }
 }
 
+
+// ---- register-resident variant: every K and V slice of the row's history is requested up front --------
+// Same (key slot, chunk) lane layout, but the key loop is fully unrolled (NIT iterations cover
+// L <= NIT * 64/LPK keys): all K and V loads are issued before the first use, scores stay in
+// registers, softmax is reduced with shuffles only -- no LDS, no block barrier, two dependent memory
+// round trips per wave (ancestor index -> K/V) instead of four.
+template <typename T> struct Raw8;                       // 8 elements kept packed until use
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<bf16_t> { uint4 a; };
+__device__ __forceinline__ void raw_load(const float* p, Raw8<float>& r) {
+    r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ __forceinline__ void raw_load(const bf16_t* p, Raw8<bf16_t>& r) { r.a = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float (&v)[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+__device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float (&v)[8]) {
+    v[0] = __uint_as_float(r.a.x << 16); v[1] = __uint_as_float(r.a.x & 0xFFFF0000u);
+    v[2] = __uint_as_float(r.a.y << 16); v[3] = __uint_as_float(r.a.y & 0xFFFF0000u);
+    v[4] = __uint_as_float(r.a.z << 16); v[5] = __uint_as_float(r.a.z & 0xFFFF0000u);
+    v[6] = __uint_as_float(r.a.w << 16); v[7] = __uint_as_float(r.a.w & 0xFFFF0000u);
+}
+
+template <typename T, bool CROSS, int DH, int NIT>
+__global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) {
+    constexpr int LPK = DH / 8, KPI = 64 / LPK;
+    const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rc = img * p.rows_per_img + w, rl = rc * p.row_mult;
+    const int D = p.D, L = p.L, t = L - 1;
+    const int kg = lane / LPK, dc = lane % LPK;
+
+    const T* kptr[NIT];
+    const T* vptr[NIT];
+    bool live[NIT], masked[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int j = it * KPI + kg;
+        live[it] = j < L;
+        masked[it] = false;
+        kptr[it] = p.q; vptr[it] = p.q;              // any valid address for dead slots (never loaded)
+        if (live[it]) {
+            if (CROSS) {
+                kptr[it] = p.kv + (size_t)(img * L + j) * (2 * D) + h * DH + dc * 8;
+                vptr[it] = kptr[it] + D;
+                masked[it] = p.keymask[img * L + j] != 0;
+            } else if (j < t) {
+                const int phys = p.src[(size_t)rl * p.src_ld + j];
+                const size_t off = ((size_t)j * p.rows_total + phys) * D + h * DH + dc * 8;
+                kptr[it] = p.kc + off; vptr[it] = p.vc + off;
+            } else {
+                kptr[it] = p.knew + (size_t)rc * p.ldnew + h * DH + dc * 8;
+                vptr[it] = p.vnew + (size_t)rc * p.ldnew + h * DH + dc * 8;
+            }
+            if (!CROSS) masked[it] = (j >= 1) && (p.tokens[(size_t)rl * p.tok_ld + j - 1] == p.pad_index);
+        }
+    }
+    Raw8<T> kr[NIT], vr[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) if (live[it]) raw_load(kptr[it], kr[it]);
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) if (live[it]) raw_load(vptr[it], vr[it]);
+    float qv[8];
+    load8(p.q + (size_t)rc * p.ldq + h * DH + dc * 8, qv);
+
+    float e[NIT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        e[it] = -INFINITY;
+        if (live[it]) {
+            float kk[8];
+            raw_unpack(kr[it], kk);
+            float a = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a = fmaf(kk[u], qv[u], a);
+#pragma unroll
+            for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
+            e[it] = masked[it] ? -1e8f : a / p.scale;
+        }
+        mx = fmaxf(mx, e[it]);
+    }
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));      // across key slots
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        e[it] = live[it] ? expf(e[it] - mx) : 0.f;
+        sum += e[it];
+    }
+#pragma unroll
+    for (int o = LPK; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);               // every chunk lane holds its key's e
+    float o8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) o8[u] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        if (live[it]) {
+            float vv[8];
+            raw_unpack(vr[it], vv);
+            const float pj = e[it] / sum;                                             // attention weight, as torch.softmax
+#pragma unroll
+            for (int u = 0; u < 8; ++u) o8[u] = fmaf(pj, vv[u], o8[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int s2 = LPK; s2 < 64; s2 <<= 1) o8[u] += __shfl_xor(o8[u], s2, 64);
+    if (kg == 0) {
+        store8(p.out + (size_t)rc * D + h * DH + dc * 8, o8);
+        if (!CROSS) {
+            copy8(p.kc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.knew + (size_t)rc * p.ldnew + h * DH + dc * 8);
+            copy8(p.vc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.vnew + (size_t)rc * p.ldnew + h * DH + dc * 8);
+        }
+    }
+}
+
 template <typename T, bool CROSS>
 static bool launch_fast(AttnParams<T>& p, int n_img, int n_heads, int rows_per_img, hipStream_t s) {
     const size_t lds = (size_t)rows_per_img * 2 * p.lcap * sizeof(float);
     const dim3 grid(n_img, n_heads), block(64 * rows_per_img);
+    if (p.dh == 64 && p.L <= (sizeof(T) == 2 ? 56 : 40)) {    // the caption models' shape: whole history in registers
+        if (p.L <= 16) hipLaunchKernelGGL((attn_decode_reg_kernel<T, CROSS, 64, 2>), grid, block, 0, s, p);
+        else if (p.L <= 40) hipLaunchKernelGGL((attn_decode_reg_kernel<T, CROSS, 64, 5>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((attn_decode_reg_kernel<T, CROSS, 64, 7>), grid, block, 0, s, p);
+        return true;
+    }
     if (p.dh == 64) hipLaunchKernelGGL((attn_decode_fast_kernel<T, CROSS, 64>), grid, block, lds, s, p);
     else if (p.dh == 128) hipLaunchKernelGGL((attn_decode_fast_kernel<T, CROSS, 128>), grid, block, lds, s, p);
     else if (p.dh == 32) hipLaunchKernelGGL((attn_decode_fast_kernel<T, CROSS, 32>), grid, block, lds, s, p);
