@@ -120,7 +120,7 @@ def roofline_from(summary, prefer=None, dtype="bf16"):
             "algorithmic_flops_per_launch": d["flops"] / d["calls"]}
 
 
-def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtype="bf16"):
+def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtype="bf16", main_line=True):
     import torch.distributed as dist
     from deephumor_amd import hip
     from deephumor_amd.synth import synth_images
@@ -141,20 +141,34 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             _, lens = one_step(model, images, rank * n_local, n_total, seed=0)
         breakdown = prof0.summary()
         dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])
-        watch = {dominant.split("[")[0], "dh_attn_self_decode", "dh_attn_cross_decode"}
+        # watch the dominant "entry[tag]" only (plus the decoder self-attention, the north star's roofline
+        # target, when this workload is the contract line): a few dozen event pairs per step
+        watch = {dominant} | ({"dh_attn_self_decode"} if (workload == "c3" and main_line) else set())
         for w in range(1, warmup):
             _, lens = one_step(model, images, rank * n_local, n_total, seed=w)
         barrier()
         t0 = time.perf_counter()
         # timed region: HIP events (on the launch stream) only around the dominant entry point and the
         # attention kernels, so the roofline line is measured over exactly the steps `value` is
-        with hip.profile(watch=watch) as prof:
+        if main_line:
+            with hip.profile(watch=watch) as prof:
+                for s in range(steps):
+                    _, lens = one_step(model, images, rank * n_local, n_total, seed=100 + s)
+                torch.cuda.synchronize()
+                barrier()
+                dt = time.perf_counter() - t0
+            summary = prof.summary()
+        else:
+            # secondary workload: clean timed steps for its captions/s, then one separately profiled step for
+            # its rooflines (so ~600 event pairs per step do not perturb the number)
             for s in range(steps):
                 _, lens = one_step(model, images, rank * n_local, n_total, seed=100 + s)
             torch.cuda.synchronize()
             barrier()
             dt = time.perf_counter() - t0
-        summary = prof.summary()
+            with hip.profile(watch={dominant, "dh_attn_self_decode", "dh_attn_cross_decode"}) as prof:
+                one_step(model, images, rank * n_local, n_total, seed=999)
+            summary = prof.summary()
     t = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -228,7 +242,7 @@ def main():
         "kernel_breakdown_ms_per_step": res["kernel_breakdown_ms_per_step"],
     }
     if args.workload == "both":
-        r3 = run_workload("c3", args, rank, world, dev, max(1, args.steps // 2), 1, with_cpu, args.dtype)
+        r3 = run_workload("c3", args, rank, world, dev, max(2, args.steps // 2), 1, with_cpu, args.dtype, main_line=False)
         line["c3"] = {"workload": "C3 CaptioningTransformer 6-layer/8-head (spatial feats), same batch/beam settings",
                       "value": r3["value"], "unit": "captions/s", "ms_per_step": r3["ms_per_step"],
                       "roofline": r3["roofline"], "roofline_self_attention": r3.get("roofline_self_attention"),

@@ -1,4 +1,9 @@
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
 #include "common.h"
+#include "prof.h"
 
 extern "C" int dh_abi_version(void) { return DH_ABI_VERSION; }
 
@@ -10,4 +15,90 @@ extern "C" const char* dh_error_string(int code) {
         case DH_ERR_LAUNCH: return "HIP kernel launch failed";
         default: return "unknown error code";
     }
+}
+
+// ---- profiler ---------------------------------------------------------------------------------------
+namespace {
+struct Rec { std::string key; int e0, e1; double flops, bytes; };
+struct Agg { int calls = 0; double ms = 0, flops = 0, bytes = 0; };
+bool g_on = false;
+std::string g_filter;                       // empty = everything, else ",name1,name2,"
+std::vector<hipEvent_t> g_pool;
+int g_used = 0;
+std::vector<Rec> g_recs;
+std::vector<std::pair<std::string, Agg>> g_out;
+thread_local const char* g_tag = nullptr;
+
+int take_event() {
+    if (g_used == (int)g_pool.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return -1;
+        g_pool.push_back(e);
+    }
+    return g_used++;
+}
+}  // namespace
+
+void dh_prof_set_tag(const char* tag) { g_tag = tag; }
+
+DhProfScope::DhProfScope(const char* name, double flops, double bytes, void* stream) : s((hipStream_t)stream), rec(-1) {
+    const char* tag = g_tag;
+    g_tag = nullptr;
+    if (!g_on) return;
+    std::string key(name);
+    if (tag) { key += "["; key += tag; key += "]"; }
+    if (!g_filter.empty() && g_filter.find("," + key + ",") == std::string::npos &&
+        g_filter.find(std::string(",") + name + ",") == std::string::npos) return;
+    const int e0 = take_event(), e1 = take_event();
+    if (e0 < 0 || e1 < 0) return;
+    g_recs.push_back(Rec{key, e0, e1, flops, bytes});
+    rec = (int)g_recs.size() - 1;
+    hipEventRecord(g_pool[e0], s);
+}
+
+DhProfScope::~DhProfScope() {
+    if (rec >= 0) hipEventRecord(g_pool[g_recs[rec].e1], s);
+}
+
+extern "C" void dh_prof_tag(const char* tag) { g_tag = tag; }
+
+extern "C" int dh_prof_begin(const char* filter) {
+    g_filter.clear();
+    if (filter && filter[0]) { g_filter = ","; g_filter += filter; g_filter += ","; }
+    g_recs.clear();
+    g_out.clear();
+    g_used = 0;
+    g_on = true;
+    return DH_OK;
+}
+
+extern "C" int dh_prof_end(void) {
+    g_on = false;
+    std::map<std::string, Agg> agg;
+    std::vector<std::string> order;
+    for (const Rec& r : g_recs) {
+        if (hipEventSynchronize(g_pool[r.e1]) != hipSuccess) return DH_ERR_LAUNCH;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_pool[r.e0], g_pool[r.e1]) != hipSuccess) return DH_ERR_LAUNCH;
+        if (!agg.count(r.key)) order.push_back(r.key);
+        Agg& a = agg[r.key];
+        a.calls += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    }
+    for (const std::string& k : order) g_out.emplace_back(k, agg[k]);
+    g_recs.clear();
+    return DH_OK;
+}
+
+extern "C" int dh_prof_num(void) { return (int)g_out.size(); }
+
+extern "C" int dh_prof_get(int i, char* name, int cap, int* calls, double* ms, double* flops, double* bytes) {
+    if (i < 0 || i >= (int)g_out.size() || !name || cap <= 0) return DH_ERR_BAD_ARG;
+    strncpy(name, g_out[i].first.c_str(), cap - 1);
+    name[cap - 1] = 0;
+    const Agg& a = g_out[i].second;
+    if (calls) *calls = a.calls;
+    if (ms) *ms = a.ms;
+    if (flops) *flops = a.flops;
+    if (bytes) *bytes = a.bytes;
+    return DH_OK;
 }

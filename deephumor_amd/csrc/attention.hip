@@ -10,6 +10,7 @@
 //          exactly as masked_fill does (transformers.py:110-111) -> wave-shuffle max and sum.
 // Phase 2: lane = head dim d: out[d] = sum_j p_j * v_j[d], coalesced 256-B value rows.
 #include "common.h"
+#include "prof.h"
 
 template <typename T>
 struct AttnParams {
@@ -376,6 +377,9 @@ extern "C" int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, 
     DH_REQUIRE(qkv && kcache && vcache && out && n_img > 0 && rows_per_img > 0 && rows_per_img <= DH_BEAM_MAX_BEAMS);
     DH_REQUIRE(t >= 0 && n_heads > 0 && D % n_heads == 0 && ((D / n_heads) % 8) == 0);
     DH_REQUIRE((t == 0 || src) && (t == 0 || pad_index < 0 || tokens));
+    const double esz_ = dtype == DH_F32 ? 4.0 : 2.0;
+    DhProfScope prof("dh_attn_self_decode", 4.0 * n_img * rows_per_img * (t + 1) * D,
+                     esz_ * n_img * rows_per_img * ((t + 1) * 2.0 * D + 2.0 * D), stream);
     DH_DISPATCH_T(dtype, launch_self<T>(qkv, kcache, vcache, src, src_ld, tokens, tok_ld, out, n_img, rows_per_img,
                                         row_mult, rows_total, t, D, n_heads, scale, pad_index, (hipStream_t)stream));
     DH_LAUNCH_CHECK();
@@ -398,6 +402,9 @@ extern "C" int dh_attn_cross_decode(const void* q, int ldq, const void* kv, cons
                                     int dtype, void* stream) {
     DH_REQUIRE(q && kv && keymask && out && n_img > 0 && rows_per_img > 0 && rows_per_img <= DH_BEAM_MAX_BEAMS);
     DH_REQUIRE(S > 0 && n_heads > 0 && D % n_heads == 0 && ((D / n_heads) % 8) == 0 && ldq >= D);
+    const double esz_ = dtype == DH_F32 ? 4.0 : 2.0;
+    DhProfScope prof("dh_attn_cross_decode", 4.0 * n_img * rows_per_img * S * D,
+                     esz_ * n_img * (S * 2.0 * D + rows_per_img * 2.0 * D), stream);
     DH_DISPATCH_T(dtype, launch_cross<T>(q, ldq, kv, keymask, out, n_img, rows_per_img, S, D, n_heads, scale,
                                          (hipStream_t)stream));
     DH_LAUNCH_CHECK();

@@ -8,6 +8,7 @@
 //                     rewrite of tokens / scores / ended flags / KV-ancestor table / parent rows.
 //   beam_finalize   : per image -- final single draw and output copy.
 #include "common.h"
+#include "prof.h"
 
 #define CAP DH_BEAM_MAX_SURVIVORS
 
@@ -303,6 +304,7 @@ extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows,
                                   int32_t* err, void* stream) {
     DH_REQUIRE(logits && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
     DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
+    DhProfScope prof("dh_beam_row_sample", 0.0, 0.0, stream);
 #define DH_FAST(EPT, NT, WPE) hipLaunchKernelGGL((beam_row_sample_fast_kernel<EPT, NT, WPE>), dim3(rows), dim3(NT), 0, \
         (hipStream_t)stream, logits, ldl, V, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, \
         step, pick_idx, pick_val, err)
@@ -421,6 +423,7 @@ extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, in
     DH_REQUIRE(pick_idx && pick_val && tokens && vals && ended && parent && hparent && done && end_step);
     DH_REQUIRE(n_img > 0 && beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && tok_ld > 0 && t >= 0 && temperature > 0.f);
     DH_REQUIRE(!src || src_ld > t);
+    DhProfScope prof("dh_beam_select", 0.0, 0.0, stream);
     SelectParams p{pick_idx, pick_val, tokens, tok_ld, vals, ended, src, src_ld, parent, hparent, done, end_step,
                    beam, first, first_sets_ended, write_pos, t, step_index, eos_index, img0, temperature, noise, seed};
     const size_t lds = (size_t)beam * (tok_ld + (src ? t : 0)) * sizeof(int32_t);
@@ -462,6 +465,7 @@ extern "C" int dh_beam_finalize(const int32_t* tokens, int tok_ld, const float* 
                                 float temperature, const float* noise, uint64_t seed, int img0, void* stream) {
     DH_REQUIRE(tokens && vals && done && end_step && out && out_len && n_img > 0);
     DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && temperature > 0.f);
+    DhProfScope prof("dh_beam_finalize", 0.0, 0.0, stream);
     hipLaunchKernelGGL(beam_finalize_kernel, dim3(n_img), dim3(64), 0, (hipStream_t)stream, tokens, tok_ld, vals,
                        done, end_step, out, out_ld, out_len, beam, len_bias_done, full_len, pad_index,
                        temperature, noise, seed, img0);

@@ -12,6 +12,7 @@
 // (conflict-free: 16 lanes x 16 B cover one 256-B bank row, the co operand is a broadcast).
 // Loads for slab s+1 are issued before the FMAs of slab s and written to LDS after them.
 #include "common.h"
+#include "prof.h"
 
 template <int KS> struct KDecode {
     __device__ static __forceinline__ void run(int k, int& ci, int& kh, int& kw) {
@@ -191,6 +192,9 @@ extern "C" int dh_conv2d_bn_act(const void* x, const void* w, const float* scale
     DH_REQUIRE(p.Ho > 0 && p.Wo > 0 && (long long)N * p.Ho * p.Wo < (1ll << 31));
     p.P = N * p.Ho * p.Wo;
     hipStream_t s = (hipStream_t)stream;
+    dh_prof_set_tag(KH == 1 ? "1x1" : KH == 3 ? "3x3" : "7x7");
+    DhProfScope prof("dh_conv2d_bn_act", 2.0 * p.P * Cout * p.K,
+                     4.0 * ((double)N * Cin * H * W + (double)Cout * p.K + (double)p.P * Cout * (residual ? 2 : 1)), stream);
     const bool big = Cout >= 128;
     if (KH == 1) { if (big) launch_conv<128, 1>(p, s); else launch_conv<64, 1>(p, s); }
     else if (KH == 3) { if (big) launch_conv<128, 3>(p, s); else launch_conv<64, 3>(p, s); }
@@ -208,6 +212,7 @@ extern "C" int dh_stem_conv_nhwc(const float* x, const float* w, const float* sc
     DH_REQUIRE(p.Ho > 0 && p.Wo > 0 && (long long)N * p.Ho * p.Wo < (1ll << 31));
     p.P = N * p.Ho * p.Wo;
     hipStream_t s = (hipStream_t)stream;
+    DhProfScope prof("dh_stem_conv_nhwc", 2.0 * p.P * Cout * p.K, 4.0 * N * Cin * H * W + 2.0 * p.P * Cout, stream);
     if (KS == 7) { if (Cout >= 128) launch_conv<128, 7, true>(p, s); else launch_conv<64, 7, true>(p, s); }
     else { if (Cout >= 128) launch_conv<128, 3, true>(p, s); else launch_conv<64, 3, true>(p, s); }
     DH_LAUNCH_CHECK();
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const bf16_t* __
 extern "C" int dh_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
     if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && (C % 8) == 0);
+    DhProfScope prof("dh_maxpool3x3s2_nhwc", 0.0, 0.0, stream);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)N * Ho * Wo * (C / 8);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const bf16_t* __restr
 extern "C" int dh_avgpool_nhwc(const void* x, void* y, int N, int HW, int C, int dtype, void* stream) {
     if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && (C % 8) == 0);
+    DhProfScope prof("dh_avgpool_nhwc", 0.0, 0.0, stream);
     hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(dh_cdiv((long long)N * (C / 8), 256)), dim3(256), 0,
                        (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, HW, C);
     DH_LAUNCH_CHECK();
@@ -311,6 +318,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
 extern "C" int dh_maxpool3x3s2(const void* x, void* y, int N, int C, int H, int W, int dtype, void* stream) {
     if (dtype != DH_F32) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0);
+    DhProfScope prof("dh_maxpool3x3s2", 0.0, 0.0, stream);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)N * C * Ho * Wo;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
@@ -333,6 +341,7 @@ __global__ __launch_bounds__(256) void avgpool_rows_kernel(const float* __restri
 extern "C" int dh_avgpool_rows(const void* x, void* y, int rows, int HW, int dtype, void* stream) {
     if (dtype != DH_F32) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(x && y && rows > 0 && HW > 0);
+    DhProfScope prof("dh_avgpool_rows", 0.0, 0.0, stream);
     hipLaunchKernelGGL(avgpool_rows_kernel, dim3(dh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)x, (float*)y, rows, HW);
     DH_LAUNCH_CHECK();
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(256) void nchw_to_rows_kernel(const float* __restri
 extern "C" int dh_nchw_to_rows(const void* x, void* y, int N, int C, int HW, int dtype, void* stream) {
     if (dtype != DH_F32) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(x && y && N > 0 && C > 0 && HW > 0 && N < 65536);
+    DhProfScope prof("dh_nchw_to_rows", 0.0, 0.0, stream);
     hipLaunchKernelGGL(nchw_to_rows_kernel, dim3(dh_cdiv(HW, 32), dh_cdiv(C, 32), N), dim3(256), 0,
                        (hipStream_t)stream, (const float*)x, (float*)y, C, HW);
     DH_LAUNCH_CHECK();

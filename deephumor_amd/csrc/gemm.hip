@@ -9,6 +9,7 @@
 // Grid: one block per tile, block ids remapped so that consecutive ids (which share a W panel)
 // stay on one XCD and find it in that XCD's L2.
 #include "common.h"
+#include "prof.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -132,6 +133,8 @@ extern "C" int dh_linear(const void* A, int lda, const void* W, int ldw, const f
     DH_REQUIRE((scale == nullptr) == (shift == nullptr));
     DH_REQUIRE(!residual || ldres >= N);
     hipStream_t s = (hipStream_t)stream;
+    const double esz = dtype == DH_F32 ? 4.0 : 2.0;
+    DhProfScope prof("dh_linear", 2.0 * M * N * K, esz * ((double)M * K + (double)N * K) + (dtype == DH_BF16 ? 2.0 : 4.0) * M * N, stream);
     if (dtype == DH_BF16 || dtype == DH_BF16_OUT_F32)
         return dh_linear_bf16_impl(A, lda, W, ldw, bias, scale, shift, residual, ldres, C, ldc, M, N, K, relu,
                                    dtype == DH_BF16_OUT_F32, s);

@@ -21,6 +21,7 @@
 //     16-byte row-contiguous residual loads / stores -- one rounding, at the very end; fp32 output
 //     (logits, odd leading dimension) is stored straight from registers.
 #include "common.h"
+#include "prof.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -305,6 +306,10 @@ extern "C" int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* 
     p.C = y; p.ldc = Cout; p.M = N * p.Ho * p.Wo; p.N = Cout; p.K = KS * KS * Cin; p.relu = relu; p.out_f32 = 0;
     p.H = H; p.Wd = W; p.Cin = Cin; p.KS = KS; p.stride = stride; p.pad = pad;
     hipStream_t s = (hipStream_t)stream;
+    static const char* const tags[] = {"?", "1x1", "2x2", "3x3", "4x4", "5x5", "6x6", "7x7"};
+    dh_prof_set_tag(tags[KS < 8 ? KS : 0]);
+    DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * p.M * Cout * p.K,
+                     2.0 * ((double)N * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout * (residual ? 2 : 1)), stream);
     if (KS == 1 && stride == 1 && pad == 0) { p.lda = Cin; p.conv = 0; launch_gemm_bf16<false>(p, s); }
     else { p.conv = 1; launch_gemm_bf16<true>(p, s); }
     DH_LAUNCH_CHECK();

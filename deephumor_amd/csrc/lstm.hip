@@ -5,6 +5,7 @@
 // the pointwise cell update.  Storage type T (fp32 or bf16) applies to embeddings and hidden
 // states; gate pre-activations and the cell state c are always fp32.
 #include "common.h"
+#include "prof.h"
 
 template <typename T>
 struct LstmPrepParams {
@@ -47,6 +48,7 @@ extern "C" int dh_lstm_prepare(const void* emb, const void* img_emb, const int32
     DH_REQUIRE(xcat0 && c_cur && rows > 0 && rows_per_img > 0 && row_mult > 0 && n_layers > 0);
     DH_REQUIRE((tokens && emb) || img_emb);
     DH_REQUIRE((E % 8) == 0 && (Hh % 8) == 0 && (n_layers == 1 || xcatl) && ((h_prev == nullptr) == (c_prev == nullptr)));
+    DhProfScope prof("dh_lstm_prepare", 0.0, 0.0, stream);
     DH_DISPATCH_T(dtype, {
         LstmPrepParams<T> p{(const T*)emb, (const T*)img_emb, tokens, tok_ld, tok_pos, hparent, (const T*)h_prev,
                             c_prev, (T*)xcat0, (T*)xcatl, c_cur, rows, rows_per_img, row_mult, rows_total,
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(256) void lstm_cell_kernel(
 extern "C" int dh_lstm_cell(const float* gates, const float* c_cur, void* h_new, float* c_new, void* h_out,
                             int ld_out, int rows, int row_mult, int Hh, int dtype, void* stream) {
     DH_REQUIRE(gates && c_cur && h_new && c_new && h_out && rows > 0 && row_mult > 0 && Hh > 0);
+    DhProfScope prof("dh_lstm_cell", 0.0, 0.0, stream);
     DH_DISPATCH_T(dtype, hipLaunchKernelGGL(lstm_cell_kernel<T>, dim3(rows), dim3(256), 0, (hipStream_t)stream, gates,
                                             c_cur, (T*)h_new, c_new, (T*)h_out, ld_out, rows, row_mult, Hh));
     DH_LAUNCH_CHECK();

@@ -2,6 +2,7 @@
 // label-embedding mean.  HBM/L2-bound streaming kernels: one wave per row, 16-byte accesses,
 // wave-shuffle reductions, fp32 math on fp32 or bf16 storage.
 #include "common.h"
+#include "prof.h"
 
 // x[rc,:] = (start slot ? start_emb[img] : tok_emb[token]) / scale + pos_emb[pos]
 // (transformers.py:455-469: the image embedding is divided by sqrt(hid_dim) together with the tokens)
@@ -38,6 +39,7 @@ extern "C" int dh_embed_rows(const void* tok_emb, const void* pos_emb, const voi
                              int row_mult, int pos, int D, float scale, int dtype, void* stream) {
     DH_REQUIRE(tok_emb && pos_emb && x && rows > 0 && rows_per_img > 0 && row_mult > 0 && pos >= 0);
     DH_REQUIRE((D % 8) == 0 && (tokens || (start_emb && pos == 0)));
+    DhProfScope prof("dh_embed_rows", 0.0, 0.0, stream);
     DH_DISPATCH_T(dtype, hipLaunchKernelGGL(embed_rows_kernel<T>, dim3(dh_cdiv(rows, 4)), dim3(256), 0,
                                             (hipStream_t)stream, (const T*)tok_emb, (const T*)pos_emb,
                                             (const T*)start_emb, tokens, tok_ld, (T*)x, rows, rows_per_img,
@@ -100,6 +102,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
 extern "C" int dh_add_layernorm(const void* x, const void* y, const float* gamma, const float* beta,
                                 void* out, int rows, int D, float eps, int dtype, void* stream) {
     DH_REQUIRE(x && gamma && beta && out && rows > 0 && D > 0 && (D % 8) == 0 && D <= 4096);
+    DhProfScope prof("dh_add_layernorm", 0.0, 0.0, stream);
     const dim3 grid(dh_cdiv(rows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define DH_LN(NV) hipLaunchKernelGGL((add_layernorm_kernel<T, NV>), grid, block, 0, s, (const T*)x, \
@@ -127,6 +130,7 @@ __global__ __launch_bounds__(256) void enc_key_mask_kernel(const T* __restrict__
 
 extern "C" int dh_enc_key_mask(const void* enc_out, uint8_t* keymask, int rows, int D, int dtype, void* stream) {
     DH_REQUIRE(enc_out && keymask && rows > 0 && D > 0);
+    DhProfScope prof("dh_enc_key_mask", 0.0, 0.0, stream);
     DH_DISPATCH_T(dtype, hipLaunchKernelGGL(enc_key_mask_kernel<T>, dim3(dh_cdiv(rows, 4)), dim3(256), 0,
                                             (hipStream_t)stream, (const T*)enc_out, keymask, rows, D));
     DH_LAUNCH_CHECK();
@@ -147,6 +151,7 @@ __global__ __launch_bounds__(256) void label_mean_kernel(const T* __restrict__ e
 extern "C" int dh_label_mean(const void* emb, const int64_t* labels, void* out, int ld_out, int N, int L, int E,
                              int dtype, void* stream) {
     DH_REQUIRE(emb && labels && out && N > 0 && L > 0 && E > 0 && ld_out >= E);
+    DhProfScope prof("dh_label_mean", 0.0, 0.0, stream);
     DH_DISPATCH_T(dtype, hipLaunchKernelGGL(label_mean_kernel<T>, dim3(N), dim3(256), 0, (hipStream_t)stream,
                                             (const T*)emb, labels, (T*)out, ld_out, L, E));
     DH_LAUNCH_CHECK();

@@ -1,0 +1,85 @@
+// Native per-position drivers of the two decoders: ONE C call launches every kernel of a decode
+// position (embedding -> L x [QKV GEMM, self-attention, projection, add+LayerNorm, (cross-attention
+// block), FFN, add+LayerNorm] -> vocabulary GEMM), or of an LSTM time step, on the caller's stream.
+// They only sequence the C-ABI entry points above them -- no allocation, no synchronisation -- so the
+// host cost of a 6-layer decode position is one FFI crossing instead of ~70.
+#include "common.h"
+#include "prof.h"
+
+#define DH_TRY(call) do { const int rc_ = (call); if (rc_ != DH_OK) return rc_; } while (0)
+
+extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_tr_scratch_t* sc,
+                                              const void* start_emb, const int32_t* tokens, int tok_ld,
+                                              const int32_t* src, int src_ld, int n_img, int rows_per_img,
+                                              int row_mult, int rows_total, int t, void* x_out, float* logits,
+                                              void* stream) {
+    DH_REQUIRE(m && sc && m->layers && n_img > 0 && rows_per_img > 0 && t >= 0);
+    const int rows = n_img * rows_per_img, D = m->D, dt = m->dtype;
+    const size_t esz = dt == DH_F32 ? 4 : 2;
+    DH_TRY(dh_embed_rows(m->tok_emb, m->pos_emb, start_emb, tokens, tok_ld, sc->x, rows, rows_per_img, row_mult, t,
+                         D, m->emb_scale, dt, stream));
+    for (int l = 0; l < m->n_layers; ++l) {
+        const dh_tr_layer_t& L = m->layers[l];
+        dh_prof_set_tag("qkv");
+        DH_TRY(dh_linear(sc->x, D, L.wqkv, D, L.bqkv, nullptr, nullptr, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, dt, stream));
+        DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
+                                   row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
+        dh_prof_set_tag("proj");
+        DH_TRY(dh_linear(sc->att, D, L.wo, D, L.bo, nullptr, nullptr, nullptr, 0, sc->o, D, rows, D, D, 0, dt, stream));
+        DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln1_g, L.ln1_b, sc->x, rows, D, L.ln1_eps, dt, stream));
+        if (m->cross) {
+            dh_prof_set_tag("proj");
+            DH_TRY(dh_linear(sc->x, D, L.wq, D, L.bq, nullptr, nullptr, nullptr, 0, sc->q, D, rows, D, D, 0, dt, stream));
+            DH_TRY(dh_attn_cross_decode(sc->q, D, L.kv, m->keymask, sc->att, n_img, rows_per_img, m->S, D, m->n_heads,
+                                        L.ea_scale, dt, stream));
+            dh_prof_set_tag("proj");
+            DH_TRY(dh_linear(sc->att, D, L.weo, D, L.beo, nullptr, nullptr, nullptr, 0, sc->o, D, rows, D, D, 0, dt, stream));
+            DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln2_g, L.ln2_b, sc->x, rows, D, L.ln2_eps, dt, stream));
+        }
+        dh_prof_set_tag("ffn");
+        DH_TRY(dh_linear(sc->x, D, L.w1, D, L.b1, nullptr, nullptr, nullptr, 0, sc->ff, m->pf_dim, rows, m->pf_dim, D, 1, dt, stream));
+        dh_prof_set_tag("ffn");
+        DH_TRY(dh_linear(sc->ff, m->pf_dim, L.w2, m->pf_dim, L.b2, nullptr, nullptr, nullptr, 0, sc->o, D, rows, D, m->pf_dim, 0, dt, stream));
+        void* dst = (l == m->n_layers - 1 && x_out) ? x_out : sc->x;
+        DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln3_g, L.ln3_b, dst, rows, D, L.ln3_eps, dt, stream));
+    }
+    (void)esz;
+    if (logits) {
+        dh_prof_set_tag("vocab");
+        DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, m->V, rows,
+                         m->V, D, 0, dt == DH_F32 ? DH_F32 : DH_BF16_OUT_F32, stream));
+    }
+    return DH_OK;
+}
+
+extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, const void* img_emb,
+                                   const int32_t* tokens, int tok_ld, int tok_pos, const int32_t* hparent,
+                                   int started, int rows, int rows_per_img, int row_mult, int rows_total,
+                                   void* h_out, int ld_out, float* logits, void* stream) {
+    DH_REQUIRE(m && sc && m->layers && rows > 0 && rows_per_img > 0 && row_mult > 0);
+    const int E = m->E, Hh = m->Hh, dt = m->dtype, nl = m->n_layers;
+    const size_t esz = dt == DH_F32 ? 4 : 2;
+    DH_TRY(dh_lstm_prepare(m->emb, img_emb, tokens, tok_ld, tok_pos, hparent, started ? m->h : nullptr,
+                           started ? m->c : nullptr, sc->xcat0, sc->xcatl, sc->c_cur, rows, rows_per_img, row_mult,
+                           rows_total, nl, E, Hh, dt, stream));
+    void* top = h_out ? h_out : sc->hout;
+    const int top_ld = h_out ? ld_out : Hh;
+    const int gate_dt = dt == DH_F32 ? DH_F32 : DH_BF16_OUT_F32;
+    for (int l = 0; l < nl; ++l) {
+        const void* a = l == 0 ? sc->xcat0 : (const char*)sc->xcatl + (size_t)(l - 1) * rows * 2 * Hh * esz;
+        const int k = l == 0 ? E + Hh : 2 * Hh;
+        dh_prof_set_tag("gates");
+        DH_TRY(dh_linear(a, k, m->layers[l].w, k, m->layers[l].b, nullptr, nullptr, nullptr, 0, sc->gates, 4 * Hh, rows,
+                         4 * Hh, k, 0, gate_dt, stream));
+        void* dst = l + 1 < nl ? (void*)((char*)sc->xcatl + (size_t)l * rows * 2 * Hh * esz) : top;
+        const int ld = l + 1 < nl ? 2 * Hh : top_ld;
+        DH_TRY(dh_lstm_cell(sc->gates, sc->c_cur + (size_t)l * rows * Hh, (char*)m->h + (size_t)l * rows_total * Hh * esz,
+                            m->c + (size_t)l * rows_total * Hh, dst, ld, rows, row_mult, Hh, dt, stream));
+    }
+    if (logits) {
+        dh_prof_set_tag("vocab");
+        DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, m->V, rows, m->V, Hh, 0,
+                         gate_dt, stream));
+    }
+    return DH_OK;
+}

@@ -18,6 +18,36 @@ MAX_BEAMS = 16
 _c = ctypes
 _P, _I, _F, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64
 
+class TrLayer(_c.Structure):
+    _fields_ = ([(n, _P) for n in ("wqkv", "wo", "w1", "w2", "wq", "weo", "bqkv", "bo", "b1", "b2", "bq", "beo",
+                                   "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b")]
+                + [(n, _F) for n in ("ln1_eps", "ln2_eps", "ln3_eps", "sa_scale", "ea_scale")] + [("_pad", _I)]
+                + [(n, _P) for n in ("kcache", "vcache", "kv")])
+
+
+class TrModel(_c.Structure):
+    _fields_ = ([(n, _I) for n in ("n_layers", "D", "n_heads", "pf_dim", "V", "pad_index", "cross", "S", "dtype")]
+                + [("emb_scale", _F), ("layers", _c.POINTER(TrLayer))]
+                + [(n, _P) for n in ("tok_emb", "pos_emb", "cls_w", "cls_b", "keymask")])
+
+
+class TrScratch(_c.Structure):
+    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff")]
+
+
+class LstmLayer(_c.Structure):
+    _fields_ = [("w", _P), ("b", _P)]
+
+
+class LstmModel(_c.Structure):
+    _fields_ = ([(n, _I) for n in ("n_layers", "E", "Hh", "V", "dtype", "_pad")] + [("layers", _c.POINTER(LstmLayer))]
+                + [(n, _P) for n in ("emb", "cls_w", "cls_b", "h", "c")])
+
+
+class LstmScratch(_c.Structure):
+    _fields_ = [(n, _P) for n in ("xcat0", "xcatl", "c_cur", "gates", "hout")]
+
+
 # name -> argtypes, mirrors include/deephumor_hip.h line by line
 SIGNATURES = {
     "dh_abi_version": [],
@@ -41,8 +71,19 @@ SIGNATURES = {
     "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _I, _I, _P, _P, _P, _P],
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
                        _U64, _I, _P],
+    "dh_transformer_decode_position": [_c.POINTER(TrModel), _c.POINTER(TrScratch), _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
+                                       _P, _P, _P],
+    "dh_lstm_decode_step": [_c.POINTER(LstmModel), _c.POINTER(LstmScratch), _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P,
+                            _I, _P, _P],
+    "dh_prof_begin": [_c.c_char_p],
+    "dh_prof_end": [],
+    "dh_prof_num": [],
+    "dh_prof_get": [_I, _c.c_char_p, _I, _c.POINTER(_I), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
+                    _c.POINTER(_c.c_double)],
     "dh_beam_finalize": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _U64, _I, _P],
 }
+
+
 
 _lib = None
 
@@ -73,6 +114,8 @@ def load():
         fn.restype = _I
     lib.dh_error_string.argtypes = [_I]
     lib.dh_error_string.restype = _c.c_char_p
+    lib.dh_prof_tag.argtypes = [_c.c_char_p]
+    lib.dh_prof_tag.restype = None
     _lib = lib
     return lib
 
@@ -83,59 +126,57 @@ def _check(code, name):
 
 
 class Profiler:
-    """Per-entry-point HIP-event timing on the stream the kernels are launched on (torch's current
-    stream).  ``with hip.profile(watch={...}) as prof`` brackets every watched C-ABI call with an
-    event pair; ``prof.summary()`` gives calls, total/avg ms and the algorithmic flops/bytes the
-    wrappers attach.  Used by bench.py for the roofline line; off (zero overhead) otherwise."""
+    """Per-entry-point timing with HIP events recorded INSIDE the library on the launch stream
+    (``dh_prof_begin`` / ``dh_prof_end``), so launches made by the native step drivers are seen too.
+    ``with hip.profile(watch={...}) as prof`` ... ``prof.summary()`` -> {"entry[tag]": calls, ms, flops, bytes}
+    with the algorithmic flops/bytes the library attaches to each launch.  Off otherwise."""
 
     def __init__(self, watch=None):
-        self.watch = None if watch is None else set(watch)
-        self.events = []
-
-    def wants(self, name):
-        return self.watch is None or name in self.watch
+        self.watch = None if watch is None else sorted(watch)
+        self._summary = None
 
     def __enter__(self):
         global _prof
         self._prev, _prof = _prof, self
+        _check(load().dh_prof_begin(",".join(self.watch).encode() if self.watch else None), "dh_prof_begin")
         return self
 
     def __exit__(self, *exc):
         global _prof
         _prof = self._prev
+        self.summary()
 
     def summary(self):
-        torch.cuda.synchronize()
-        out = {}
-        for name, tag, e0, e1, flops, nbytes in self.events:
-            key = name if tag is None else f"{name}[{tag}]"
-            d = out.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-            d["calls"] += 1
-            d["ms"] += e0.elapsed_time(e1)
-            d["flops"] += flops
-            d["bytes"] += nbytes
-        return out
+        if self._summary is None:
+            lib = load()
+            _check(lib.dh_prof_end(), "dh_prof_end")
+            out = {}
+            name = _c.create_string_buffer(96)
+            calls, ms, fl, by = _I(), _c.c_double(), _c.c_double(), _c.c_double()
+            for i in range(lib.dh_prof_num()):
+                _check(lib.dh_prof_get(i, name, 96, _c.byref(calls), _c.byref(ms), _c.byref(fl), _c.byref(by)), "dh_prof_get")
+                out[name.value.decode()] = dict(calls=calls.value, ms=ms.value, flops=fl.value, bytes=by.value)
+            self._summary = out
+        return self._summary
 
 
 _prof = None
+_fns = {}
 
 
 def profile(watch=None):
     return Profiler(watch)
 
 
-def _launch(name, *args, flops=0.0, nbytes=0.0, tag=None):
-    fn = getattr(load(), name)
-    p = _prof
-    if p is not None and p.wants(name):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        code = fn(*args)
-        e1.record()
-        p.events.append((name, tag, e0, e1, flops, nbytes))
-    else:
-        code = fn(*args)
-    _check(code, name)
+def _launch(name, *args, tag=None, **_ignored):
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(load(), name)
+    if tag is not None and _prof is not None:
+        load().dh_prof_tag(tag.encode())
+    code = fn(*args)
+    if code != 0:
+        _check(code, name)
 
 
 def _ptr(t):
@@ -373,3 +414,17 @@ def beam_finalize(tokens, vals, done, end_step, out, out_len, n_img, beam, len_b
     _launch("dh_beam_finalize", _ptr(tokens), tokens.stride(0), _ptr(vals), _ptr(done), _ptr(end_step),
                                    _ptr(out), out.stride(0), _ptr(out_len), n_img, beam, len_bias_done, full_len,
                                    pad_index, float(temperature), _ptr(noise), seed, img0, _stream())
+
+
+def transformer_decode_position(model, scratch, start_emb, tokens, src, n_img, rows_per_img, row_mult, rows_total, t,
+                                x_out=None, logits=None):
+    _launch("dh_transformer_decode_position", _c.byref(model), _c.byref(scratch), _ptr(start_emb), _ptr(tokens),
+            tokens.stride(0), _ptr(src), src.stride(0), n_img, rows_per_img, row_mult, rows_total, t, _ptr(x_out),
+            _ptr(logits), _stream())
+
+
+def lstm_decode_step(model, scratch, img_emb, tokens, tok_pos, hparent, started, rows, rows_per_img, row_mult,
+                     rows_total, h_out=None, logits=None):
+    _launch("dh_lstm_decode_step", _c.byref(model), _c.byref(scratch), _ptr(img_emb), _ptr(tokens),
+            tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(hparent), int(started), rows, rows_per_img,
+            row_mult, rows_total, _ptr(h_out), h_out.stride(0) if h_out is not None else 0, _ptr(logits), _stream())

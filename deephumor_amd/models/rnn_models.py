@@ -44,48 +44,51 @@ class LSTMDecoder(nn.Module, _Planned):
             raise RuntimeError("deephumor_amd implements the inference path; call model.eval()")
 
     class _State:
-        """Recurrent state of n_img*beam logical rows + per-step scratch (cached per row count)."""
+        """Recurrent state of n_img*beam logical rows + per-step scratch (cached per row count), described to
+        the native step driver (``dh_lstm_decode_step``) through plain C structs."""
 
-        def __init__(self, dec, n_img, beam, dev):
+        def __init__(self, dec, plan, n_img, beam, dev):
             self.nl, self.hh, self.e = dec.lstm.num_layers, dec.lstm.hidden_size, dec.lstm.input_size
-            self.dev, self.dtype = dev, dec.classifier.weight.dtype
-            r = n_img * beam
+            self.dev, self.dtype = dev, plan["dtype"]
+            self.rows_total = r = n_img * beam
             self.h = torch.zeros((self.nl, r, self.hh), device=dev, dtype=self.dtype)
             self.c = torch.zeros((self.nl, r, self.hh), device=dev)             # cell state always fp32
             self.started = False
             self._scratch = {}
+            self.c_layers = (hip.LstmLayer * self.nl)()
+            for i, (w, b) in enumerate(plan["layers"]):
+                self.c_layers[i].w, self.c_layers[i].b = w.data_ptr(), b.data_ptr()
+            m = self.c_model = hip.LstmModel()
+            m.n_layers, m.E, m.Hh, m.V = self.nl, self.e, self.hh, dec.num_tokens
+            m.dtype = hip.F32 if self.dtype == torch.float32 else hip.BF16
+            m.layers = self.c_layers
+            m.emb, m.cls_w, m.cls_b = plan["emb"].data_ptr(), plan["cls_w"].data_ptr(), plan["cls_b"].data_ptr()
+            m.h, m.c = self.h.data_ptr(), self.c.data_ptr()
 
         def scratch(self, rows):
             if rows not in self._scratch:
                 nl, hh, e, dev, dt = self.nl, self.hh, self.e, self.dev, self.dtype
-                self._scratch[rows] = dict(
+                bufs = dict(
                     xcat0=torch.empty((rows, e + hh), device=dev, dtype=dt),
                     xcatl=torch.empty((max(nl - 1, 1), rows, 2 * hh), device=dev, dtype=dt),
                     c_cur=torch.empty((nl, rows, hh), device=dev),
                     gates=torch.empty((rows, 4 * hh), device=dev),              # gate pre-activations fp32
                     hout=torch.empty((rows, hh), device=dev, dtype=dt))
+                c = hip.LstmScratch()
+                for k, v in bufs.items():
+                    setattr(c, k, v.data_ptr())
+                bufs["c"] = c
+                self._scratch[rows] = bufs
             return self._scratch[rows]
 
     def _step(self, plan, st, rows, rpi, mult, rows_total, img_emb=None, tokens=None, tok_pos=0, hparent=None,
-              hout=None):
-        """One LSTM time step for ``rows`` compact rows; returns the top layer's h ``[rows, Hh]``."""
-        nl, hh, e = st.nl, st.hh, st.e
+              hout=None, logits=None):
+        """One LSTM time step for ``rows`` compact rows (+ classifier if ``logits``): one native call."""
         sc = st.scratch(rows)
-        xcat0, xcatl, c_cur, gates = sc["xcat0"], sc["xcatl"], sc["c_cur"], sc["gates"]
-        hip.lstm_prepare(plan["emb"], img_emb, tokens, tok_pos, hparent,
-                         st.h if st.started else None, st.c if st.started else None,
-                         xcat0, xcatl, c_cur, rows, rpi, mult, rows_total, nl, e, hh)
-        hout = sc["hout"] if hout is None else hout
-        for l in range(nl):
-            w, b = plan["layers"][l]
-            hip.linear(xcat0 if l == 0 else xcatl[l - 1], w, b, out=gates, tag="gates")
-            if l + 1 < nl:
-                dst, ld = xcatl[l], 2 * hh
-            else:
-                dst, ld = hout, hout.stride(0)
-            hip.lstm_cell(gates, c_cur[l], st.h[l], st.c[l], dst, ld, rows, mult, hh)
+        hip.lstm_decode_step(st.c_model, sc["c"], img_emb, tokens, tok_pos, hparent, st.started, rows, rpi, mult,
+                             rows_total, h_out=hout, logits=logits)
         st.started = True
-        return hout
+        return hout if hout is not None else sc["hout"]
 
     def forward(self, image_emb, captions, lengths=None):
         """Teacher-forced logits ``[bs, max(lengths), num_tokens]`` (reference rnn_models.py:28-46).
@@ -100,14 +103,14 @@ class LSTMDecoder(nn.Module, _Planned):
         steps_out = int(lengths.max())
         hh = self.lstm.hidden_size
         tokens = captions.to(torch.int32).contiguous()
-        st = self._State(self, bs, 1, dev)
+        st = self._State(self, plan, bs, 1, dev)
         hs = torch.zeros((bs, steps_out, hh), device=dev, dtype=plan["dtype"])
         for t in range(steps_out):
             self._step(plan, st, bs, 1, 1, bs, img_emb=image_emb if t == 0 else None,
                        tokens=None if t == 0 else tokens, tok_pos=t - 1, hout=hs[:, t, :])
         valid = (torch.arange(steps_out)[None, :] < lengths[:, None]).to(dev)
         hs.mul_(valid[..., None])          # pad_packed_sequence zero rows (mask, not arithmetic on valid rows)
-        out = hip.linear(hs.view(bs * steps_out, hh), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32)
+        out = hip.linear(hs.view(bs * steps_out, hh), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
         return out.view(bs, steps_out, -1)
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
@@ -129,19 +132,18 @@ class LSTMDecoder(nn.Module, _Planned):
         if caption is not None:
             pos = caption.shape[1]
             helper.set_prefix(caption)
-        st = self._State(self, n, b, dev)
+        st = self._State(self, plan, n, b, dev)
         logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
         # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam
-        hout = self._step(plan, st, n, 1, b, r, img_emb=image_emb)
+        lg = logits[:n]
+        self._step(plan, st, n, 1, b, r, img_emb=image_emb, logits=lg if pos == 0 else None)
         for j in range(pos):
-            hout = self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j)
-        lg = hip.linear(hout, plan["cls_w"], plan["cls_b"], out=logits[:n], tag="vocab")
+            self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j, logits=lg if j == pos - 1 else None)
         if logits_hook is not None:
             logits_hook(pos, lg)
         helper.step(lg, first=True, write_pos=pos, t=0, step_index=pos, first_sets_ended=True)
         for i in range(pos + 1, max_len):
-            hout = self._step(plan, st, r, b, 1, r, tokens=helper.tokens, tok_pos=i - 1, hparent=helper.hparent)
-            hip.linear(hout, plan["cls_w"], plan["cls_b"], out=logits, tag="vocab")
+            self._step(plan, st, r, b, 1, r, tokens=helper.tokens, tok_pos=i - 1, hparent=helper.hparent, logits=logits)
             if logits_hook is not None:
                 logits_hook(i, logits)
             helper.step(logits, first=False, write_pos=i, t=0, step_index=i)

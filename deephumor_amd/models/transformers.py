@@ -133,7 +133,8 @@ class _IncrementalDecoder(nn.Module, _Planned):
             raise TypeError("pad_index=None is unusable in the reference too (transformers.py:451); pass an int")
 
     class _Run:
-        """KV cache + cross-attention operands + scratch for one batch."""
+        """KV cache + cross-attention operands + scratch for one batch, described to the native step
+        driver (``dh_transformer_decode_position``) through plain C structs."""
 
         def __init__(self, dec, plan, n_img, beam, n_pos, enc_out, dev):
             d, nl = dec.hid_dim, len(dec.layers)
@@ -151,38 +152,48 @@ class _IncrementalDecoder(nn.Module, _Planned):
             self._scratch = {}
             self.pf = dec.layers[0].pf.fc_1.out_features
             self.d, self.dev = d, dev
+            P = lambda t: 0 if t is None else t.data_ptr()
+            self.c_layers = (hip.TrLayer * nl)()
+            for i, L in enumerate(plan["layers"]):
+                c = self.c_layers[i]
+                c.wqkv, c.wo, c.w1, c.w2 = P(L["wqkv"]), P(L["wo"]), P(L["w1"]), P(L["w2"])
+                c.bqkv, c.bo, c.b1, c.b2 = P(L["bqkv"]), P(L["bo"]), P(L["b1"]), P(L["b2"])
+                c.ln1_g, c.ln1_b, c.ln1_eps = P(L["ln1"][0]), P(L["ln1"][1]), L["ln1"][2]
+                c.ln3_g, c.ln3_b, c.ln3_eps = P(L["ln3"][0]), P(L["ln3"][1]), L["ln3"][2]
+                c.sa_scale = L["sa_scale"]
+                if dec._cross:
+                    c.wq, c.weo, c.bq, c.beo = P(L["wq"]), P(L["weo"]), P(L["bq"]), P(L["beo"])
+                    c.ln2_g, c.ln2_b, c.ln2_eps, c.ea_scale = P(L["ln2"][0]), P(L["ln2"][1]), L["ln2"][2], L["ea_scale"]
+                    c.kv = P(self.kv[i])
+                c.kcache, c.vcache = self.kc[i].data_ptr(), self.vc[i].data_ptr()
+            m = self.c_model = hip.TrModel()
+            m.n_layers, m.D, m.n_heads, m.pf_dim, m.V = nl, d, dec.n_heads, self.pf, dec.num_tokens
+            m.pad_index, m.cross, m.S = dec.pad_index, int(dec._cross), self.s
+            m.dtype = hip.F32 if self.dtype == torch.float32 else hip.BF16
+            m.emb_scale = plan["scale"]
+            m.layers = self.c_layers
+            m.tok_emb, m.pos_emb, m.cls_w, m.cls_b = P(plan["tok"]), P(plan["pos"]), P(plan["cls_w"]), P(plan["cls_b"])
+            m.keymask = P(self.keymask)
 
         def scratch(self, rows):
             if rows not in self._scratch:
                 e = lambda *shape: torch.empty(shape, device=self.dev, dtype=self.dtype)
-                self._scratch[rows] = dict(x=e(rows, self.d), qkv=e(rows, 3 * self.d), att=e(rows, self.d),
-                                           o=e(rows, self.d), q=e(rows, self.d), ff=e(rows, self.pf))
+                bufs = dict(x=e(rows, self.d), qkv=e(rows, 3 * self.d), att=e(rows, self.d),
+                            o=e(rows, self.d), q=e(rows, self.d), ff=e(rows, self.pf))
+                c = hip.TrScratch()
+                for k, v in bufs.items():
+                    setattr(c, k, v.data_ptr())
+                bufs["c"] = c
+                self._scratch[rows] = bufs
             return self._scratch[rows]
 
-    def _decode_position(self, plan, run, t, rows, rpi, mult, tokens, src, start_emb, x_out=None):
-        """Hidden state of position ``t`` for ``rows`` compact rows (all layers), [rows, D]."""
-        d, h = self.hid_dim, self.n_heads
+    def _decode_position(self, plan, run, t, rows, rpi, mult, tokens, src, start_emb, x_out=None, logits=None):
+        """Hidden state of position ``t`` for ``rows`` compact rows (all layers) [rows, D]; with ``logits``
+        (fp32 [rows, V]) also the classifier -- one native call (``dh_transformer_decode_position``)."""
         sc = run.scratch(rows)
-        x = sc["x"]
-        hip.embed_rows(plan["tok"], plan["pos"], start_emb, tokens, x, rows, rpi, mult, t, plan["scale"])
-        n_layers = len(plan["layers"])
-        for li, L in enumerate(plan["layers"]):
-            hip.linear(x, L["wqkv"], L["bqkv"], out=sc["qkv"], tag="qkv")
-            hip.attn_self_decode(sc["qkv"], run.kc[li], run.vc[li], src, tokens, sc["att"], run.n_img, rpi, mult,
-                                 run.rows_total, t, d, h, L["sa_scale"], self.pad_index)
-            hip.linear(sc["att"], L["wo"], L["bo"], out=sc["o"], tag="proj")
-            hip.add_layernorm(x, sc["o"], L["ln1"][0], L["ln1"][1], out=x, eps=L["ln1"][2])
-            if self._cross:
-                hip.linear(x, L["wq"], L["bq"], out=sc["q"], tag="proj")
-                hip.attn_cross_decode(sc["q"], run.kv[li], run.keymask, sc["att"], run.n_img, rpi, run.s, d, h,
-                                      L["ea_scale"])
-                hip.linear(sc["att"], L["weo"], L["beo"], out=sc["o"], tag="proj")
-                hip.add_layernorm(x, sc["o"], L["ln2"][0], L["ln2"][1], out=x, eps=L["ln2"][2])
-            hip.linear(x, L["w1"], L["b1"], relu=True, out=sc["ff"], tag="ffn")
-            hip.linear(sc["ff"], L["w2"], L["b2"], out=sc["o"], tag="ffn")
-            last = li == n_layers - 1 and x_out is not None
-            hip.add_layernorm(x, sc["o"], L["ln3"][0], L["ln3"][1], out=x_out if last else x, eps=L["ln3"][2])
-        return x_out if x_out is not None else x
+        hip.transformer_decode_position(run.c_model, sc["c"], start_emb, tokens, src, run.n_img, rpi, mult,
+                                        run.rows_total, t, x_out=x_out, logits=logits)
+        return x_out if x_out is not None else sc["x"]
 
     def _forward(self, x, enc_out, start_emb):
         self._check_mode()
@@ -204,7 +215,7 @@ class _IncrementalDecoder(nn.Module, _Planned):
         for t in range(seq):
             self._decode_position(plan, run, t, bs, 1, 1, tokens, helper_src, start_emb.to(plan["dtype"]).contiguous(), x_out=xt)
             hs[:, t, :].copy_(xt)
-        out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32)
+        out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
         return out.view(bs, seq, -1)
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
@@ -229,15 +240,15 @@ class _IncrementalDecoder(nn.Module, _Planned):
         start_emb = start_emb.to(plan["dtype"]).contiguous()
         logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
         # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
+        lg = logits[:n]
         for t in range(pos + 1):
-            x = self._decode_position(plan, run, t, n, 1, b, helper.tokens, helper.src, start_emb)
-        lg = hip.linear(x, plan["cls_w"], plan["cls_b"], out=logits[:n], tag="vocab")
+            self._decode_position(plan, run, t, n, 1, b, helper.tokens, helper.src, start_emb,
+                                  logits=lg if t == pos else None)
         if logits_hook is not None:
             logits_hook(pos, lg)
         helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False)
         for i in range(pos + 1, max_len + 1):
-            x = self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, start_emb)
-            hip.linear(x, plan["cls_w"], plan["cls_b"], out=logits, tag="vocab")
+            self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, start_emb, logits=logits)
             if logits_hook is not None:
                 logits_hook(i, logits)
             # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 2
+#define DH_ABI_VERSION 3
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -214,6 +214,74 @@ int dh_beam_finalize(const int32_t* tokens, int tok_ld, const float* vals, const
                      const int32_t* end_step, int32_t* out, int out_ld, int32_t* out_len,
                      int n_img, int beam, int len_bias_done, int full_len, int pad_index,
                      float temperature, const float* noise, uint64_t seed, int img0, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Native step drivers: one call = every kernel of one decode position / one LSTM time step,
+ * sequenced on `stream` from weights described by plain C structs (host arrays of device pointers).
+ * Replaces the Python-side per-layer loops of TransformerDecoder.forward (transformers.py:455-488,
+ * KV-cached form) and of one nn.LSTM step + classifier (rnn_models.py:107-109).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dh_tr_layer {
+    const void *wqkv, *wo, *w1, *w2, *wq, *weo;            /* [3D,D] [D,D] [PF,D] [D,PF] [D,D] [D,D], storage dtype */
+    const float *bqkv, *bo, *b1, *b2, *bq, *beo;           /* fp32 biases */
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+    float ln1_eps, ln2_eps, ln3_eps, sa_scale, ea_scale;
+    int _pad;
+    void *kcache, *vcache;                                  /* this layer's self-attention cache [pos][rows_total][D] */
+    const void* kv;                                         /* this layer's cross-attention K|V [n_img*S][2D] or NULL */
+} dh_tr_layer_t;
+
+typedef struct dh_tr_model {
+    int n_layers, D, n_heads, pf_dim, V, pad_index, cross, S, dtype;
+    float emb_scale;
+    const dh_tr_layer_t* layers;                            /* host array [n_layers] */
+    const void *tok_emb, *pos_emb, *cls_w;
+    const float* cls_b;
+    const uint8_t* keymask;                                 /* [n_img*S] or NULL */
+} dh_tr_model_t;
+
+typedef struct dh_tr_scratch { void *x, *qkv, *att, *o, *q, *ff; } dh_tr_scratch_t;   /* [rows, D|3D|D|D|D|PF] */
+
+/* Hidden state of position t for n_img*rows_per_img compact rows; x_out (optional, [rows,D]) receives the
+ * last layer's output instead of scratch->x; logits (optional, fp32 [rows,V]) = classifier(x). */
+int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_tr_scratch_t* sc,
+                                   const void* start_emb, const int32_t* tokens, int tok_ld,
+                                   const int32_t* src, int src_ld, int n_img, int rows_per_img,
+                                   int row_mult, int rows_total, int t, void* x_out, float* logits,
+                                   void* stream);
+
+typedef struct dh_lstm_layer { const void* w; const float* b; } dh_lstm_layer_t;   /* [4Hh, in+Hh] = [W_ih|W_hh], b_ih+b_hh */
+
+typedef struct dh_lstm_model {
+    int n_layers, E, Hh, V, dtype, _pad;
+    const dh_lstm_layer_t* layers;                          /* host array [n_layers] */
+    const void *emb, *cls_w;
+    const float* cls_b;
+    void* h;                                                /* recurrent state [n_layers, rows_total, Hh], storage dtype */
+    float* c;                                               /* cell state, fp32 */
+} dh_lstm_model_t;
+
+typedef struct dh_lstm_scratch { void *xcat0, *xcatl; float *c_cur, *gates; void* hout; } dh_lstm_scratch_t;
+
+/* One LSTM time step for `rows` compact rows (dh_lstm_prepare + per layer gate GEMM + dh_lstm_cell) and,
+ * if logits != NULL, the classifier.  started == 0: zero initial state.  h_out (optional, row stride
+ * ld_out) receives the top layer's h instead of scratch->hout. */
+int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, const void* img_emb,
+                        const int32_t* tokens, int tok_ld, int tok_pos, const int32_t* hparent,
+                        int started, int rows, int rows_per_img, int row_mult, int rows_total,
+                        void* h_out, int ld_out, float* logits, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Launch profiler (measurement infrastructure, not on the data path): while enabled, every launch made
+ * through this library is bracketed by HIP events on its stream.  filter: NULL/"" = all entry points,
+ * else comma-separated entry-point names.  dh_prof_end() synchronises the recorded events and
+ * aggregates per "entry[tag]": calls, total ms, algorithmic flops and bytes.
+ * ------------------------------------------------------------------------------------------- */
+int dh_prof_begin(const char* filter);
+int dh_prof_end(void);
+int dh_prof_num(void);
+int dh_prof_get(int i, char* name, int cap, int* calls, double* ms, double* flops, double* bytes);
+void dh_prof_tag(const char* tag);
 
 #ifdef __cplusplus
 }
