@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 V_WORD = 36541          # deephumor_demo.ipynb:524
 MAX_LEN = 32            # deephumor_demo.ipynb:1127
 BEAM, TOP_K, TEMP = 5, 50, 1.0
+STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))   # image sub-batches decoded concurrently (HIP streams)
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
@@ -55,7 +56,7 @@ def build_model(workload, dev, dtype="bf16"):
 def one_step(model, images, img0, n_total, seed):
     from deephumor_amd.dist import gather_captions
     toks, lens = model.generate_batch(images, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP,
-                                      seed=seed, img0=img0)
+                                      seed=seed, img0=img0, streams=STREAMS)
     return gather_captions(toks, lens, n_total)
 
 
@@ -136,7 +137,9 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
 
     lens = None
     with torch.no_grad():
-        # warm-up pass 0 doubles as the per-kernel breakdown (HIP events around every C-ABI launch)
+        # untimed: a cold pass (code-object loading, allocator growth), then the per-kernel breakdown pass
+        # (HIP events around every launch made through the library)
+        one_step(model, images, rank * n_local, n_total, seed=0)
         with hip.profile() as prof0:
             _, lens = one_step(model, images, rank * n_local, n_total, seed=0)
         breakdown = prof0.summary()

@@ -101,3 +101,51 @@ class BeamSearchHelper:
     def all_ended(self):
         """Host-visible early-exit test (one sync; callers poll it sparsely, not per token)."""
         return bool(self.done.cpu().numpy().all())
+
+
+_STREAMS = {}
+
+
+def run_interleaved(make_session, n_img, n_streams):
+    """Runs ``make_session(lo, hi)`` -- a generator that decodes images ``[lo, hi)`` and yields after every
+    position, returning ``(tokens, lengths)`` -- either once, or as ``n_streams`` image sub-batches advanced
+    round-robin on separate HIP streams.  Decode positions are chains of small, latency-bound kernels
+    (a 640-row GEMM fills a fraction of the 256 CUs); two independent chains in flight fill the gaps.
+    Captions are unchanged: every image's noise is keyed by its global index (``img0 + lo``)."""
+    n_streams = max(1, min(n_streams, n_img))
+    if n_streams == 1:
+        gen = make_session(0, n_img)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as e:
+                return e.value
+    main = torch.cuda.current_stream()
+    dev = main.device
+    pool = _STREAMS.setdefault(dev, [])
+    while len(pool) < n_streams:
+        pool.append(torch.cuda.Stream(device=dev))
+    base, extra = divmod(n_img, n_streams)
+    bounds, lo = [], 0
+    for i in range(n_streams):
+        hi = lo + base + (1 if i < extra else 0)
+        bounds.append((lo, hi))
+        lo = hi
+    gens, results, alive = [], [None] * n_streams, set(range(n_streams))
+    for (lo, hi), st in zip(bounds, pool):
+        st.wait_stream(main)
+        gens.append(make_session(lo, hi))
+    while alive:
+        for i in sorted(alive):
+            with torch.cuda.stream(pool[i]):
+                try:
+                    next(gens[i])
+                except StopIteration as e:
+                    results[i] = e.value
+                    alive.discard(i)
+    for st in pool[:n_streams]:
+        main.wait_stream(st)
+    for toks, lens in results:
+        toks.record_stream(main)
+        lens.record_stream(main)
+    return torch.cat([r[0] for r in results], 0), torch.cat([r[1] for r in results], 0)

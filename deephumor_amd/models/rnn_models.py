@@ -10,7 +10,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamSearchHelper
+from .beam import BeamSearchHelper, run_interleaved
 from .encoders import _Planned
 
 
@@ -114,40 +114,48 @@ class LSTMDecoder(nn.Module, _Planned):
         return out.view(bs, steps_out, -1)
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
-                       eos_index=3, seed=0, img0=0, noise_source=None, logits_hook=None):
+                       eos_index=3, seed=0, img0=0, noise_source=None, logits_hook=None, streams=1):
         """Batched beam-search sampling for ``image_emb [N, 1, E]`` or ``[N, E]``.
 
         Returns ``(tokens int64 [N, max_len] zero-padded, lengths int64 [N])``; row ``i`` equals
         what the reference's ``generate`` returns for image ``i`` under the same random draws
-        (rnn_models.py:48-143, incl. the hidden-state indexing at :135-137)."""
+        (rnn_models.py:48-143, incl. the hidden-state indexing at :135-137).  ``streams`` > 1 decodes
+        that many image sub-batches concurrently on separate HIP streams (same captions)."""
         self._check_mode()
         plan = self._get_plan()
         image_emb = image_emb.reshape(image_emb.shape[0], -1).to(plan["dtype"]).contiguous()
-        n, b = image_emb.shape[0], beam_size
-        dev = image_emb.device
-        r = n * b
-        helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
-                                  max_len=max_len, seed=seed, img0=img0, noise_source=noise_source)
-        pos = 0
-        if caption is not None:
-            pos = caption.shape[1]
-            helper.set_prefix(caption)
-        st = self._State(self, plan, n, b, dev)
-        logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
-        # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam
-        lg = logits[:n]
-        self._step(plan, st, n, 1, b, r, img_emb=image_emb, logits=lg if pos == 0 else None)
-        for j in range(pos):
-            self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j, logits=lg if j == pos - 1 else None)
-        if logits_hook is not None:
-            logits_hook(pos, lg)
-        helper.step(lg, first=True, write_pos=pos, t=0, step_index=pos, first_sets_ended=True)
-        for i in range(pos + 1, max_len):
-            self._step(plan, st, r, b, 1, r, tokens=helper.tokens, tok_pos=i - 1, hparent=helper.hparent, logits=logits)
+
+        def session(lo, hi):
+            n, b = hi - lo, beam_size
+            r = n * b
+            dev = image_emb.device
+            helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
+                                      max_len=max_len, seed=seed, img0=img0 + lo, noise_source=noise_source)
+            pos = 0
+            if caption is not None:
+                pos = caption.shape[1]
+                helper.set_prefix(caption[lo:hi])
+            st = self._State(self, plan, n, b, dev)
+            logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
+            # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam
+            lg = logits[:n]
+            self._step(plan, st, n, 1, b, r, img_emb=image_emb[lo:hi], logits=lg if pos == 0 else None)
+            for j in range(pos):
+                self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j, logits=lg if j == pos - 1 else None)
             if logits_hook is not None:
-                logits_hook(i, logits)
-            helper.step(logits, first=False, write_pos=i, t=0, step_index=i)
-        return helper.finalize(len_bias_done=1, full_len=max_len)
+                logits_hook(pos, lg)
+            helper.step(lg, first=True, write_pos=pos, t=0, step_index=pos, first_sets_ended=True)
+            yield
+            for i in range(pos + 1, max_len):
+                self._step(plan, st, r, b, 1, r, tokens=helper.tokens, tok_pos=i - 1, hparent=helper.hparent,
+                           logits=logits)
+                if logits_hook is not None:
+                    logits_hook(i, logits)
+                helper.step(logits, first=False, write_pos=i, t=0, step_index=i)
+                yield
+            return helper.finalize(len_bias_done=1, full_len=max_len)
+
+        return run_interleaved(session, image_emb.shape[0], streams)
 
     def generate(self, image_emb, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):

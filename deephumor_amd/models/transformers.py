@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamSearchHelper
+from .beam import BeamSearchHelper, run_interleaved
 from .encoders import _Planned
 
 
@@ -219,41 +219,49 @@ class _IncrementalDecoder(nn.Module, _Planned):
         return out.view(bs, seq, -1)
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
-                        seed=0, img0=0, noise_source=None, logits_hook=None):
+                        seed=0, img0=0, noise_source=None, logits_hook=None, streams=1):
         self._check_mode()
         plan = self._get_plan()
-        n, b = start_emb.shape[0], beam_size
-        r = n * b
-        dev = start_emb.device
         if max_len + 1 > self.pos_embedding.num_embeddings:
             raise IndexError("index out of range in self")    # reference: pos_embedding lookup, SURVEY.md section 5
-        helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
-                                  max_len=max_len, src_len=max_len + 1, seed=seed, img0=img0,
-                                  noise_source=noise_source)
-        if self.pad_index != 0:
-            helper.tokens.fill_(self.pad_index)
-        pos = 0
-        if caption is not None:
-            pos = caption.shape[1]
-            helper.set_prefix(caption)
-        run = self._Run(self, plan, n, b, max_len + 1, enc_out, dev)
         start_emb = start_emb.to(plan["dtype"]).contiguous()
-        logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
-        # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
-        lg = logits[:n]
-        for t in range(pos + 1):
-            self._decode_position(plan, run, t, n, 1, b, helper.tokens, helper.src, start_emb,
-                                  logits=lg if t == pos else None)
-        if logits_hook is not None:
-            logits_hook(pos, lg)
-        helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False)
-        for i in range(pos + 1, max_len + 1):
-            self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, start_emb, logits=logits)
+
+        def session(lo, hi):
+            """Decodes images [lo, hi); yields after every position (see ``run_interleaved``)."""
+            n, b = hi - lo, beam_size
+            r = n * b
+            dev = start_emb.device
+            helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
+                                      max_len=max_len, src_len=max_len + 1, seed=seed, img0=img0 + lo,
+                                      noise_source=noise_source)
+            if self.pad_index != 0:
+                helper.tokens.fill_(self.pad_index)
+            pos = 0
+            if caption is not None:
+                pos = caption.shape[1]
+                helper.set_prefix(caption[lo:hi])
+            run = self._Run(self, plan, n, b, max_len + 1, None if enc_out is None else enc_out[lo:hi], dev)
+            semb = start_emb[lo:hi]
+            logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
+            # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
+            lg = logits[:n]
+            for t in range(pos + 1):
+                self._decode_position(plan, run, t, n, 1, b, helper.tokens, helper.src, semb,
+                                      logits=lg if t == pos else None)
+                yield
             if logits_hook is not None:
-                logits_hook(i, logits)
-            # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn
-            helper.step(logits, first=False, write_pos=i, t=i, step_index=i)
-        return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index)
+                logits_hook(pos, lg)
+            helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False)
+            for i in range(pos + 1, max_len + 1):
+                self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, semb, logits=logits)
+                if logits_hook is not None:
+                    logits_hook(i, logits)
+                # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn
+                helper.step(logits, first=False, write_pos=i, t=i, step_index=i)
+                yield
+            return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index)
+
+        return run_interleaved(session, start_emb.shape[0], streams)
 
 
 class TransformerDecoder(_IncrementalDecoder):

@@ -189,6 +189,10 @@ def test_batched_beam_equals_per_image_and_oracle_properties(kind, images):
             assert t1[0].tolist() == toks[i].tolist() and int(l1[0]) == int(lens[i])
         t2, l2 = model.generate_batch(images[2:].cuda(), img0=2, **kw)
         assert t2.tolist() == toks[2:].tolist()
+        # sub-batches decoded concurrently on separate HIP streams give the same captions
+        for k in (2, 3):
+            ts, ls = model.generate_batch(images.cuda(), streams=k, **kw)
+            assert ts.tolist() == toks.tolist() and ls.tolist() == lens.tolist()
         other, _ = model.generate_batch(images.cuda(), **dict(kw, seed=43))
     assert other.tolist() != toks.tolist()
     assert int(lens.max()) <= 16 and int(toks.max()) < 1000 and not bool((toks == 1).any())     # <unk> never sampled
