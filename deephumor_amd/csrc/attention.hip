@@ -337,6 +337,80 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
     }
 }
 
+
+// ---- cross-attention through LDS ---------------------------------------------------------------------------
+// The S patch keys/values of an (image, head) are shared by all its beams (transformers.py:544).  The
+// workgroup (one wave per beam) stages that K|V head slice ONCE in LDS with coalesced 16-byte loads; then
+// lane = key: every lane owns one key row (row stride padded by 16 B: conflict-free 16-byte LDS reads) and
+// computes its full dot product against the broadcast query -- no cross-lane traffic for QK^T; softmax is two
+// wave reductions; for PV the two half-waves take even / odd keys and each lane owns a pair of head dims.
+template <typename T, int HPB>          // HPB heads per workgroup: fewer, fatter waves (wave dispatch is the floor)
+__global__ __launch_bounds__(1024) void attn_cross_lds_kernel(AttnParams<T> p) {
+    constexpr int DH = 64, VN = Vec16<T>::N, CPR = DH / VN;          // 16-byte chunks per row
+    constexpr int ROW = DH + VN;                                       // padded row (elements)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int img = blockIdx.x, h0 = blockIdx.y * HPB, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nthreads = blockDim.x, S = p.L, D = p.D;
+    T* ks = reinterpret_cast<T*>(smem_raw);                            // [HPB][S][ROW]
+    T* vs = ks + (size_t)HPB * S * ROW;                                // [HPB][S][ROW]
+    float* fbase = reinterpret_cast<float*>(vs + (size_t)HPB * S * ROW);   // per wave: q[HPB*64] then p[64]
+    float* qs = fbase + w * (HPB * 64 + 64);
+    float* ps = qs + HPB * 64;
+    const int per_head = S * CPR;
+    for (int c = threadIdx.x; c < HPB * per_head * 2; c += nthreads) {
+        const int isv = c >= HPB * per_head, cc = isv ? c - HPB * per_head : c;
+        const int hh = cc / per_head, r = cc - hh * per_head, j = r / CPR, ch = r - j * CPR;
+        const uint4 val = *reinterpret_cast<const uint4*>(p.kv + (size_t)(img * S + j) * (2 * D) + (isv ? D : 0) + (h0 + hh) * DH + ch * VN);
+        *reinterpret_cast<uint4*>((isv ? vs : ks) + ((size_t)hh * S + j) * ROW + ch * VN) = val;
+    }
+    const int rc = img * p.rows_per_img + w;
+#pragma unroll
+    for (int hh = 0; hh < HPB; ++hh) qs[hh * 64 + lane] = ldf(p.q + (size_t)rc * p.ldq + (h0 + hh) * DH + lane);
+    const bool masked = lane < S && p.keymask[img * S + lane] != 0;
+    __syncthreads();
+    const int d2 = (lane & 31) * 2, par = lane >> 5;
+#pragma unroll 1
+    for (int hh = 0; hh < HPB; ++hh) {
+        const T* kh = ks + (size_t)hh * S * ROW;
+        const T* vh = vs + (size_t)hh * S * ROW;
+        float e = -INFINITY;
+        if (lane < S) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+            for (int ch = 0; ch < CPR; ++ch) {
+                float kk[VN];
+                load16(kh + (size_t)lane * ROW + ch * VN, kk);
+#pragma unroll
+                for (int u = 0; u < VN; u += 4) {
+                    const float4 qq = *reinterpret_cast<const float4*>(qs + hh * 64 + ch * VN + u);
+                    a0 = fmaf(kk[u], qq.x, a0); a1 = fmaf(kk[u + 1], qq.y, a1);
+                    a2 = fmaf(kk[u + 2], qq.z, a2); a3 = fmaf(kk[u + 3], qq.w, a3);
+                }
+            }
+            e = masked ? -1e8f : ((a0 + a1) + (a2 + a3)) / p.scale;
+        }
+        const float mx = wave_max(e);
+        const float ex = lane < S ? expf(e - mx) : 0.f;
+        const float sum = wave_sum(ex);
+        ps[lane] = ex / sum;                                           // attention weights, as torch.softmax
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");         // ps is wave-private: order write -> reads
+        // PV: lane l -> dims 2*(l&31), +1 ; half-wave (l>>5) takes keys of its parity
+        float o0 = 0.f, o1 = 0.f;
+        for (int j = par; j < S; j += 2) {
+            const float pj = ps[j];
+            o0 = fmaf(pj, ldf(vh + (size_t)j * ROW + d2), o0);
+            o1 = fmaf(pj, ldf(vh + (size_t)j * ROW + d2 + 1), o1);
+        }
+        o0 += __shfl_xor(o0, 32, 64);
+        o1 += __shfl_xor(o1, 32, 64);
+        if (par == 0) {
+            stf(p.out + (size_t)rc * D + (h0 + hh) * DH + d2, o0);
+            stf(p.out + (size_t)rc * D + (h0 + hh) * DH + d2 + 1, o1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+}
+
 template <typename T, bool CROSS>
 static bool launch_fast(AttnParams<T>& p, int n_img, int n_heads, int rows_per_img, hipStream_t s) {
     const size_t lds = (size_t)rows_per_img * 2 * p.lcap * sizeof(float);
@@ -392,6 +466,16 @@ static void launch_cross(const void* q, int ldq, const void* kv, const uint8_t* 
     p.q = (const T*)q; p.ldq = ldq; p.kv = (const T*)kv; p.keymask = keymask; p.out = (T*)out;
     p.rows_per_img = rows_per_img; p.row_mult = 1; p.rows_total = 0;
     p.L = S; p.D = D; p.dh = D / n_heads; p.lcap = (S + 3) & ~3; p.pad_index = -1; p.scale = scale;
+    if (p.dh == 64 && S <= 64) {                         // the caption models' shape: K|V staged once per (image, head group)
+        constexpr int VN = Vec16<T>::N;
+        const int hpb = 1;     // measured: 1 head per workgroup 20 us, 4 heads 24 us per launch (per-wave latency chain dominates)
+        const size_t lds = (size_t)2 * hpb * S * (64 + VN) * sizeof(T) + (size_t)rows_per_img * (hpb * 64 + 64) * sizeof(float);
+        const dim3 grid(n_img, n_heads / hpb), block(64 * rows_per_img);
+        if (hpb == 4) hipLaunchKernelGGL((attn_cross_lds_kernel<T, 4>), grid, block, lds, s, p);
+        else if (hpb == 2) hipLaunchKernelGGL((attn_cross_lds_kernel<T, 2>), grid, block, lds, s, p);
+        else hipLaunchKernelGGL((attn_cross_lds_kernel<T, 1>), grid, block, lds, s, p);
+        return;
+    }
     if (launch_fast<T, true>(p, n_img, n_heads, rows_per_img, s)) return;
     const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
     hipLaunchKernelGGL((attn_decode_kernel<T, true>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds, s, p);
