@@ -166,61 +166,23 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
 // (about top_k..2*top_k values on real logits) is compacted into LDS and the exact threshold,
 // the survivors and the draws are computed there.  Falls back to the 4-pass radix kernel
 // (beam_row_sample_kernel) only through DH_BEAM_ERR_OVERFLOW if > CAP values pass the bound.
-template <int EPT, int NT, int WPE>
-__global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
-    const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
-    float temperature, int unk, const float* __restrict__ noise, uint64_t seed, int img0, int step,
-    int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
-    __shared__ uint32_t lmax[NT];
-    __shared__ int hist[256];
-    __shared__ uint32_t s_prefix;
-    __shared__ int s_k, s_cnt, wtot[4];
-    __shared__ int idx_a[CAP], idx_b[CAP];
-    __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
-    __shared__ float red[NT];
-    __shared__ int picks[DH_BEAM_MAX_BEAMS];
-    __shared__ uint32_t s_thr;
+struct RowLds {
+    int* idx_a; int* idx_b; float* val_a; float* val_b; float* qv; float* red; int* picks; int* s_cnt; uint32_t* s_thr;
+};
 
-    const int rc = blockIdx.x, tid = threadIdx.x;
-    const float* row = logits + (size_t)rc * ldl;
-    float v[EPT];
-    uint32_t best = 0u;                          // key 0 < key of every real float
-    // buffer loads: one shared per-lane offset + scalar strides, hardware bounds check (reads past V
-    // return 0 and are ignored below) -> ~1 VGPR per element instead of an address pair + predicate
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, V * 4, 0x00020000);
-#pragma unroll
-    for (int e = 0; e < EPT; ++e)
-        v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, tid * 4, e * NT * 4, 0));
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * NT;
-        if (i < V) best = max(best, f2key(v[e]));
-    }
-    lmax[tid] = best;
-    if (tid == 0) { s_prefix = 0u; s_k = top_k; s_cnt = 0; }
-    // k-th largest of the 512 thread maxima (one key per thread: cheap LDS radix select)
-    uint32_t mask = 0u;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        const uint32_t prefix = s_prefix;
-        if ((best & mask) == prefix) atomicAdd(&hist[(best >> shift) & 255u], 1);
-        __syncthreads();
-        radix_pick_digit(hist, 1, shift, prefix, &s_prefix, &s_k, wtot);
-        mask |= 0xFFu << shift;
-    }
-    const uint32_t bound = s_prefix;             // <= key of the row's k-th largest value
-    // compact every value >= bound
-#pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-        const int i = tid + e * NT;
-        if (i < V && f2key(v[e]) >= bound) {
-            const int p = atomicAdd(&s_cnt, 1);
-            if (p < CAP) { idx_a[p] = i; val_a[p] = v[e]; }
-        }
-    }
-    __syncthreads();
+// Common tail of the row kernels.  On entry idx_a/val_a hold *s_cnt candidates that include every value >= the
+// row's k-th largest (block-synchronised).  Exact threshold -> survivors (ties kept, unk dropped) -> index
+// order -> softmax(filtered / T) -> Exp(1) race for `beam` picks -> log_softmax over the picks.
+template <int NT>
+__device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int rows_per_img, int beam, int top_k,
+                                         float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
+                                         int img0, int step, int32_t* __restrict__ pick_idx,
+                                         float* __restrict__ pick_val, int32_t* __restrict__ err) {
+    const int tid = threadIdx.x;
+    int* idx_a = L.idx_a; int* idx_b = L.idx_b; float* val_a = L.val_a; float* val_b = L.val_b;
+    float* qv = L.qv; float* red = L.red; int* picks = L.picks;
+#define s_cnt (*L.s_cnt)
+#define s_thr (*L.s_thr)
     int n0 = s_cnt;
     if (n0 > CAP) { if (tid == 0) atomicOr(err, DH_BEAM_ERR_OVERFLOW); n0 = CAP; }
     // exact k-th largest among the candidates: the value whose "strictly greater" count is < k <= "greater or equal"
@@ -296,6 +258,143 @@ __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
             pick_val[(size_t)rc * beam + b] = pi >= 0 ? (val_a[pi] - mx) - lse : -INFINITY;
         }
     }
+#undef s_cnt
+#undef s_thr
+}
+
+template <int EPT, int NT, int WPE>
+__global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
+    const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
+    float temperature, int unk, const float* __restrict__ noise, uint64_t seed, int img0, int step,
+    int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
+    __shared__ uint32_t lmax[NT];
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_k, s_cnt, wtot[4];
+    __shared__ int idx_a[CAP], idx_b[CAP];
+    __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
+    __shared__ float red[NT];
+    __shared__ int picks[DH_BEAM_MAX_BEAMS];
+    __shared__ uint32_t s_thr;
+
+    const int rc = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (size_t)rc * ldl;
+    float v[EPT];
+    uint32_t best = 0u;                          // key 0 < key of every real float
+    // buffer loads: one shared per-lane offset + scalar strides, hardware bounds check (reads past V
+    // return 0 and are ignored below) -> ~1 VGPR per element instead of an address pair + predicate
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, V * 4, 0x00020000);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, tid * 4, e * NT * 4, 0));
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * NT;
+        if (i < V) best = max(best, f2key(v[e]));
+    }
+    lmax[tid] = best;
+    if (tid == 0) { s_prefix = 0u; s_k = top_k; s_cnt = 0; }
+    // k-th largest of the 512 thread maxima (one key per thread: cheap LDS radix select)
+    uint32_t mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        if ((best & mask) == prefix) atomicAdd(&hist[(best >> shift) & 255u], 1);
+        __syncthreads();
+        radix_pick_digit(hist, 1, shift, prefix, &s_prefix, &s_k, wtot);
+        mask |= 0xFFu << shift;
+    }
+    const uint32_t bound = s_prefix;             // <= key of the row's k-th largest value
+    // compact every value >= bound
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int i = tid + e * NT;
+        if (i < V && f2key(v[e]) >= bound) {
+            const int p = atomicAdd(&s_cnt, 1);
+            if (p < CAP) { idx_a[p] = i; val_a[p] = v[e]; }
+        }
+    }
+    __syncthreads();
+    const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
+    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, img0, step, pick_idx, pick_val, err);
+}
+
+// ---- group-max guided variant -----------------------------------------------------------------------------
+// The vocabulary GEMM (dh_vocab_logits) leaves, next to the logits, the maximum of every group of `gcols`
+// consecutive columns of each row.  The k-th largest GROUP maximum is a lower bound of the row's k-th largest
+// value (k groups hold a value >= it), and only groups whose maximum reaches that bound can contain one of the
+// top-k values: about top_k of the ~570 groups.  So this kernel reads ~9 % of the row instead of all of it.
+template <int NT>
+__global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
+    const float* __restrict__ logits, int ldl, int V, const float* __restrict__ gmax, int gm_ld, int n_groups,
+    int gcols, int rows_per_img, int beam, int top_k, float temperature, int unk, const float* __restrict__ noise,
+    uint64_t seed, int img0, int step, int32_t* __restrict__ pick_idx, float* __restrict__ pick_val,
+    int32_t* __restrict__ err) {
+    constexpr int MAXG = 1024;
+    __shared__ uint32_t gkey[MAXG];
+    __shared__ int glist[MAXG];
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix, s_thr;
+    __shared__ int s_k, s_cnt, s_ng, wtot[4];
+    __shared__ int idx_a[CAP], idx_b[CAP];
+    __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
+    __shared__ float red[NT];
+    __shared__ int picks[DH_BEAM_MAX_BEAMS];
+    const int rc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = logits + (size_t)rc * ldl;
+    for (int g = tid; g < n_groups; g += NT) gkey[g] = f2key(gmax[(size_t)rc * gm_ld + g]);
+    if (tid == 0) { s_prefix = 0u; s_k = min(top_k, n_groups); s_cnt = 0; s_ng = 0; }
+    uint32_t mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        for (int g = tid; g < n_groups; g += NT)
+            if ((gkey[g] & mask) == prefix) atomicAdd(&hist[(gkey[g] >> shift) & 255u], 1);
+        __syncthreads();
+        radix_pick_digit(hist, 1, shift, prefix, &s_prefix, &s_k, wtot);
+        mask |= 0xFFu << shift;
+    }
+    const uint32_t bound = s_prefix;                 // k-th largest group maximum
+    for (int g = tid; g < n_groups; g += NT)
+        if (gkey[g] >= bound) glist[atomicAdd(&s_ng, 1)] = g;
+    __syncthreads();
+    const int ng = s_ng;
+    for (int q = wave; q < ng; q += NT / 64) {       // one wave per selected group, coalesced 256-B reads
+        const int g = glist[q];
+        for (int c = lane; c < gcols; c += 64) {
+            const int i = g * gcols + c;
+            if (i < V) {
+                const float v = row[i];
+                if (f2key(v) >= bound) {
+                    const int pp = atomicAdd(&s_cnt, 1);
+                    if (pp < CAP) { idx_a[pp] = i; val_a[pp] = v; }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
+    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, img0, step, pick_idx, pick_val, err);
+}
+
+extern "C" int dh_beam_row_sample_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld,
+                                         int n_groups, int group_cols, int rows, int rows_per_img, int beam,
+                                         int top_k, float temperature, int unk_index, const float* noise,
+                                         uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
+                                         int32_t* err, void* stream) {
+    DH_REQUIRE(logits && group_max && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
+    DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
+    DH_REQUIRE(n_groups > 0 && n_groups <= 1024 && top_k <= n_groups && gm_ld >= n_groups && group_cols > 0 &&
+               (long long)n_groups * group_cols >= V);
+    DhProfScope prof("dh_beam_row_sample", 0.0, 0.0, stream);
+    hipLaunchKernelGGL((beam_row_sample_groups_kernel<256>), dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
+                       group_max, gm_ld, n_groups, group_cols, rows_per_img, beam, top_k, temperature, unk_index, noise,
+                       seed, img0, step, pick_idx, pick_val, err);
+    DH_LAUNCH_CHECK();
 }
 
 extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,

@@ -37,6 +37,7 @@ struct GemmBf16Params {
     int M, N, K, relu, out_f32;
     int conv, H, Wd, Cin, Ho, Wo, KS, stride, pad;     // conv loader: A = NHWC input
     int tiles_m, tiles_n;
+    float* gmax; int gmax_ld;                          // optional: per-row maxima of each wave-wide column group
 };
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -194,6 +195,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
             sc[j][r] = (ok && p.scale) ? p.scale[n] : 1.f;
             sh[j][r] = (ok && p.scale) ? p.shift[n] : 0.f;
         }
+    if (p.gmax) {
+        // maximum of this wave's WN consecutive output columns for each of its rows (beam-search pre-filter)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            float mxv = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n0 + wn0 + 16 * j + 4 * lq + r < p.N) mxv = fmaxf(mxv, (acc[j][i][r] + bv[j][r]) * sc[j][r] + sh[j][r]);
+            mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
+            mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
+            const int m = m0 + wm0 + 16 * i + l15;
+            if (lq == 0 && m < p.M) p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;
+        }
+    }
     // Stage the fp32 tile in LDS, then finish rows with row-contiguous accesses.  Slot s of row m
     // (16 B = 4 fp32) is stored at slot s ^ (m & (SLOTS-1)): the 16 lanes of a store hit 16 distinct slots.
     constexpr int SLOTS = BN / 4;
@@ -312,5 +329,23 @@ extern "C" int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* 
                      2.0 * ((double)N * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout * (residual ? 2 : 1)), stream);
     if (KS == 1 && stride == 1 && pad == 0) { p.lda = Cin; p.conv = 0; launch_gemm_bf16<false>(p, s); }
     else { p.conv = 1; launch_gemm_bf16<true>(p, s); }
+    DH_LAUNCH_CHECK();
+}
+
+// Vocabulary projection for beam search: logits[M,V] fp32 = A[M,K] * W[V,K]^T + bias, plus group_max[m, g] =
+// max of logits[m, 64g .. 64g+63] (always the 128x128 tile: its waves own 64-column groups).
+extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float* bias, float* logits, int ldl,
+                               float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream) {
+    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(A && W && logits && group_max && M > 0 && V > 0 && K > 0 && ldl >= V && gm_ld >= 2 * dh_cdiv(V, 128));
+    DH_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
+    DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
+    dh_prof_set_tag("vocab");
+    DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);
+    GemmBf16Params p{};
+    p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = bias;
+    p.C = logits; p.ldc = ldl; p.M = M; p.N = V; p.K = K; p.out_f32 = 1; p.gmax = group_max; p.gmax_ld = gm_ld;
+    p.tiles_m = dh_cdiv(M, 128); p.tiles_n = dh_cdiv(V, 128);
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, false, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, (hipStream_t)stream, p);
     DH_LAUNCH_CHECK();
 }

@@ -72,9 +72,11 @@ SIGNATURES = {
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
                        _U64, _I, _P],
     "dh_transformer_decode_position": [_c.POINTER(TrModel), _c.POINTER(TrScratch), _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
-                                       _P, _P, _P],
+                                       _P, _P, _P, _I, _P],
     "dh_lstm_decode_step": [_c.POINTER(LstmModel), _c.POINTER(LstmScratch), _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P,
-                            _I, _P, _P],
+                            _I, _P, _P, _I, _P],
+    "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _I, _I, _P, _P, _P, _P],
     "dh_prof_begin": [_c.c_char_p],
     "dh_prof_end": [],
     "dh_prof_num": [],
@@ -398,6 +400,23 @@ def beam_row_sample(logits, v, rows, rows_per_img, beam, top_k, temperature, unk
                                      _ptr(pick_val), _ptr(err), _stream())
 
 
+def vocab_logits(a, w, bias, logits, group_max):
+    """bf16 a [M,K], w [V,K] -> fp32 logits [M,V] + group_max [M, n_groups(V)] (max of every 64-column group)."""
+    _dev(a, w, bias, logits, group_max)
+    m, k = a.shape
+    v = w.shape[0]
+    _launch("dh_vocab_logits", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(logits), logits.stride(0),
+            _ptr(group_max), group_max.stride(0), m, v, k, _dt(a), _stream())
+
+
+def beam_row_sample_groups(logits, v, group_max, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed,
+                           img0, step, pick_idx, pick_val, err):
+    _dev(logits, group_max, noise, pick_idx, pick_val, err)
+    _launch("dh_beam_row_sample_groups", _ptr(logits), logits.stride(0), v, _ptr(group_max), group_max.stride(0),
+            n_groups(v), GROUP_COLS, rows, rows_per_img, beam, top_k, float(temperature), unk_index, _ptr(noise), seed,
+            img0, step, _ptr(pick_idx), _ptr(pick_val), _ptr(err), _stream())
+
+
 def beam_select(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, n_img, beam, first,
                 first_sets_ended, write_pos, t, step_index, temperature, eos_index, noise, seed, img0):
     _dev(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, noise)
@@ -416,15 +435,23 @@ def beam_finalize(tokens, vals, done, end_step, out, out_len, n_img, beam, len_b
                                    pad_index, float(temperature), _ptr(noise), seed, img0, _stream())
 
 
+GROUP_COLS = 64     # column-group width of dh_vocab_logits' group maxima
+
+
+def n_groups(v):
+    return 2 * ((v + 127) // 128)
+
+
 def transformer_decode_position(model, scratch, start_emb, tokens, src, n_img, rows_per_img, row_mult, rows_total, t,
-                                x_out=None, logits=None):
+                                x_out=None, logits=None, group_max=None):
     _launch("dh_transformer_decode_position", _c.byref(model), _c.byref(scratch), _ptr(start_emb), _ptr(tokens),
             tokens.stride(0), _ptr(src), src.stride(0), n_img, rows_per_img, row_mult, rows_total, t, _ptr(x_out),
-            _ptr(logits), _stream())
+            _ptr(logits), _ptr(group_max), group_max.stride(0) if group_max is not None else 0, _stream())
 
 
 def lstm_decode_step(model, scratch, img_emb, tokens, tok_pos, hparent, started, rows, rows_per_img, row_mult,
-                     rows_total, h_out=None, logits=None):
+                     rows_total, h_out=None, logits=None, group_max=None):
     _launch("dh_lstm_decode_step", _c.byref(model), _c.byref(scratch), _ptr(img_emb), _ptr(tokens),
             tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(hparent), int(started), rows, rows_per_img,
-            row_mult, rows_total, _ptr(h_out), h_out.stride(0) if h_out is not None else 0, _ptr(logits), _stream())
+            row_mult, rows_total, _ptr(h_out), h_out.stride(0) if h_out is not None else 0, _ptr(logits),
+            _ptr(group_max), group_max.stride(0) if group_max is not None else 0, _stream())

@@ -61,16 +61,22 @@ class BeamSearchHelper:
         t = self.noise_source(kind, step, shape)
         return None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
 
-    def step(self, logits, first, write_pos, t, step_index, first_sets_ended=False):
+    def step(self, logits, first, write_pos, t, step_index, first_sets_ended=False, group_max=None):
         """One beam step from ``logits`` ([n_img, V] if ``first`` else [n_img*beam, V]):
         beam.py:55-108 + the caller-side candidate draw (rnn_models.py:116-128, transformers.py:557-569)."""
         rows = logits.shape[0]
         rpi = 1 if first else self.beam_size
         assert rows == self.n_img * rpi
         v = logits.shape[1]
-        hip.beam_row_sample(logits, v, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
-                            self._noise("row", step_index, (rows, v)), self.seed, self.img0, step_index,
-                            self.pick_idx, self.pick_val, self.err)
+        if group_max is not None and self.top_k <= hip.n_groups(v):   # k group maxima bound the k-th logit
+            # bf16 path: the vocabulary GEMM left per-row maxima of every 64-column group (dh_vocab_logits)
+            hip.beam_row_sample_groups(logits, v, group_max, rows, rpi, self.beam_size, self.top_k, self.temperature,
+                                       self.unk_index, self._noise("row", step_index, (rows, v)), self.seed, self.img0,
+                                       step_index, self.pick_idx, self.pick_val, self.err)
+        else:
+            hip.beam_row_sample(logits, v, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
+                                self._noise("row", step_index, (rows, v)), self.seed, self.img0, step_index,
+                                self.pick_idx, self.pick_val, self.err)
         noise = None if first else self._noise("cand", step_index, (self.n_img, self.beam_size ** 2))
         hip.beam_select(self.pick_idx, self.pick_val, self.tokens, self.vals, self.has_ended, self.src,
                         self.parent, self.hparent, self.done, self.end_step, self.n_img, self.beam_size, first,

@@ -82,11 +82,11 @@ class LSTMDecoder(nn.Module, _Planned):
             return self._scratch[rows]
 
     def _step(self, plan, st, rows, rpi, mult, rows_total, img_emb=None, tokens=None, tok_pos=0, hparent=None,
-              hout=None, logits=None):
+              hout=None, logits=None, group_max=None):
         """One LSTM time step for ``rows`` compact rows (+ classifier if ``logits``): one native call."""
         sc = st.scratch(rows)
         hip.lstm_decode_step(st.c_model, sc["c"], img_emb, tokens, tok_pos, hparent, st.started, rows, rpi, mult,
-                             rows_total, h_out=hout, logits=logits)
+                             rows_total, h_out=hout, logits=logits, group_max=group_max)
         st.started = True
         return hout if hout is not None else sc["hout"]
 
@@ -137,21 +137,27 @@ class LSTMDecoder(nn.Module, _Planned):
                 helper.set_prefix(caption[lo:hi])
             st = self._State(self, plan, n, b, dev)
             logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
+            gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
+                    if plan["dtype"] == torch.bfloat16 else None)                    # column-group maxima (bf16 path)
+            gm = None if gmax is None else gmax[:n]
             # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam
             lg = logits[:n]
-            self._step(plan, st, n, 1, b, r, img_emb=image_emb[lo:hi], logits=lg if pos == 0 else None)
+            self._step(plan, st, n, 1, b, r, img_emb=image_emb[lo:hi], logits=lg if pos == 0 else None,
+                       group_max=gm if pos == 0 else None)
             for j in range(pos):
-                self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j, logits=lg if j == pos - 1 else None)
+                last = j == pos - 1
+                self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j, logits=lg if last else None,
+                           group_max=gm if last else None)
             if logits_hook is not None:
                 logits_hook(pos, lg)
-            helper.step(lg, first=True, write_pos=pos, t=0, step_index=pos, first_sets_ended=True)
+            helper.step(lg, first=True, write_pos=pos, t=0, step_index=pos, first_sets_ended=True, group_max=gm)
             yield
             for i in range(pos + 1, max_len):
                 self._step(plan, st, r, b, 1, r, tokens=helper.tokens, tok_pos=i - 1, hparent=helper.hparent,
-                           logits=logits)
+                           logits=logits, group_max=gmax)
                 if logits_hook is not None:
                     logits_hook(i, logits)
-                helper.step(logits, first=False, write_pos=i, t=0, step_index=i)
+                helper.step(logits, first=False, write_pos=i, t=0, step_index=i, group_max=gmax)
                 yield
             return helper.finalize(len_bias_done=1, full_len=max_len)
 

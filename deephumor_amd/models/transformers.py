@@ -187,12 +187,13 @@ class _IncrementalDecoder(nn.Module, _Planned):
                 self._scratch[rows] = bufs
             return self._scratch[rows]
 
-    def _decode_position(self, plan, run, t, rows, rpi, mult, tokens, src, start_emb, x_out=None, logits=None):
+    def _decode_position(self, plan, run, t, rows, rpi, mult, tokens, src, start_emb, x_out=None, logits=None,
+                         group_max=None):
         """Hidden state of position ``t`` for ``rows`` compact rows (all layers) [rows, D]; with ``logits``
         (fp32 [rows, V]) also the classifier -- one native call (``dh_transformer_decode_position``)."""
         sc = run.scratch(rows)
         hip.transformer_decode_position(run.c_model, sc["c"], start_emb, tokens, src, run.n_img, rpi, mult,
-                                        run.rows_total, t, x_out=x_out, logits=logits)
+                                        run.rows_total, t, x_out=x_out, logits=logits, group_max=group_max)
         return x_out if x_out is not None else sc["x"]
 
     def _forward(self, x, enc_out, start_emb):
@@ -243,21 +244,25 @@ class _IncrementalDecoder(nn.Module, _Planned):
             run = self._Run(self, plan, n, b, max_len + 1, None if enc_out is None else enc_out[lo:hi], dev)
             semb = start_emb[lo:hi]
             logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
+            gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
+                    if plan["dtype"] == torch.bfloat16 else None)                    # column-group maxima (bf16 path)
+            gm = None if gmax is None else gmax[:n]
             # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
             lg = logits[:n]
             for t in range(pos + 1):
                 self._decode_position(plan, run, t, n, 1, b, helper.tokens, helper.src, semb,
-                                      logits=lg if t == pos else None)
+                                      logits=lg if t == pos else None, group_max=gm if t == pos else None)
                 yield
             if logits_hook is not None:
                 logits_hook(pos, lg)
-            helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False)
+            helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False, group_max=gm)
             for i in range(pos + 1, max_len + 1):
-                self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, semb, logits=logits)
+                self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, semb, logits=logits,
+                                      group_max=gmax)
                 if logits_hook is not None:
                     logits_hook(i, logits)
                 # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn
-                helper.step(logits, first=False, write_pos=i, t=i, step_index=i)
+                helper.step(logits, first=False, write_pos=i, t=i, step_index=i, group_max=gmax)
                 yield
             return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index)
 

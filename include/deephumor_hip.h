@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 3
+#define DH_ABI_VERSION 4
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -97,6 +97,12 @@ int dh_label_mean(const void* emb, const int64_t* labels, void* out, int ld_out,
 int dh_linear(const void* A, int lda, const void* W, int ldw, const float* bias,
               const float* scale, const float* shift, const void* residual, int ldres,
               void* C, int ldc, int M, int N, int K, int relu, int dtype, void* stream);
+
+/* Vocabulary projection feeding beam search (bf16 operands): logits [M,V] fp32 = A*W^T + bias, and
+ * group_max[m, g] = max(logits[m, 64g .. 64g+63]) for g < 2*ceil(V/128) (row stride gm_ld) -- the pre-filter
+ * dh_beam_row_sample_groups uses to read only the ~top_k column groups that can hold a top-k logit. */
+int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float* bias, float* logits, int ldl,
+                    float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row addressing shared by the decoder kernels.  A decode step works on `rows` compact rows
@@ -185,6 +191,14 @@ int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_p
                        uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
                        int32_t* err, void* stream);
 
+/* Same contract as dh_beam_row_sample, guided by the column-group maxima of dh_vocab_logits: the k-th largest
+ * group maximum bounds the k-th largest logit from below, so only groups whose maximum reaches it are read. */
+int dh_beam_row_sample_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld,
+                              int n_groups, int group_cols, int rows, int rows_per_img, int beam,
+                              int top_k, float temperature, int unk_index, const float* noise,
+                              uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
+                              int32_t* err, void* stream);
+
 /* Per image: builds the candidate list (a live beam contributes `beam` candidates, an ended beam one
  * with token 0 / score +0), draws `beam` of them without replacement from softmax(cand_val/T),
  * and rewrites the image's beam state IN PLACE.
@@ -243,12 +257,13 @@ typedef struct dh_tr_model {
 typedef struct dh_tr_scratch { void *x, *qkv, *att, *o, *q, *ff; } dh_tr_scratch_t;   /* [rows, D|3D|D|D|D|PF] */
 
 /* Hidden state of position t for n_img*rows_per_img compact rows; x_out (optional, [rows,D]) receives the
- * last layer's output instead of scratch->x; logits (optional, fp32 [rows,V]) = classifier(x). */
+ * last layer's output instead of scratch->x; logits (optional, fp32 [rows,V]) = classifier(x); with
+ * group_max != NULL (bf16 only) the classifier is dh_vocab_logits. */
 int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_tr_scratch_t* sc,
                                    const void* start_emb, const int32_t* tokens, int tok_ld,
                                    const int32_t* src, int src_ld, int n_img, int rows_per_img,
                                    int row_mult, int rows_total, int t, void* x_out, float* logits,
-                                   void* stream);
+                                   float* group_max, int gm_ld, void* stream);
 
 typedef struct dh_lstm_layer { const void* w; const float* b; } dh_lstm_layer_t;   /* [4Hh, in+Hh] = [W_ih|W_hh], b_ih+b_hh */
 
@@ -269,7 +284,7 @@ typedef struct dh_lstm_scratch { void *xcat0, *xcatl; float *c_cur, *gates; void
 int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, const void* img_emb,
                         const int32_t* tokens, int tok_ld, int tok_pos, const int32_t* hparent,
                         int started, int rows, int rows_per_img, int row_mult, int rows_total,
-                        void* h_out, int ld_out, float* logits, void* stream);
+                        void* h_out, int ld_out, float* logits, float* group_max, int gm_ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Launch profiler (measurement infrastructure, not on the data path): while enabled, every launch made

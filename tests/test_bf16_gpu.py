@@ -137,3 +137,34 @@ def test_models_bf16_close_to_reference(kind):
         assert first_ok >= 3
         toks, lens = model.generate_batch(*gargs, max_len=32, beam_size=5, top_k=50, seed=3)
         assert tuple(toks.shape) == (4, 32) and int(toks.max()) < 1000 and not bool((toks == 1).any())
+
+
+@pytest.mark.parametrize("v,beam,top_k", [(36541, 5, 50), (1000, 3, 16), (4000, 7, 50)])
+def test_vocab_logits_group_max_and_guided_sampling(hip, v, beam, top_k):
+    """dh_vocab_logits = dh_linear(out fp32) + per-row maxima of every 64-column group; the group-guided row
+    sampler picks exactly what the full-row sampler picks."""
+    rows, k = 37, 512
+    a, w, b = bf(rnd(rows, k, seed=1)), bf(rnd(v, k, seed=2) * 0.12), rnd(v, seed=3)
+    logits = torch.empty(rows, v, device="cuda")
+    ng = hip.n_groups(v)
+    gmax = torch.full((rows, ng), float("nan"), device="cuda")
+    hip.vocab_logits(a.cuda(), w.cuda(), b.cuda(), logits, gmax)
+    ref = hip.linear(a.cuda(), w.cuda(), b.cuda(), out_dtype=torch.float32)
+    assert torch.equal(logits, ref)
+    pad = torch.full((rows, ng * 64 - v), float("-inf"), device="cuda")
+    want = torch.cat([logits, pad], 1).view(rows, ng, 64).max(-1).values
+    assert torch.equal(gmax, want)
+    noise = torch.empty(rows, v).exponential_(1, generator=torch.Generator().manual_seed(5)).cuda()
+    out = []
+    for guided in (False, True):
+        pi = torch.empty(rows, beam, dtype=torch.int32, device="cuda")
+        pv = torch.empty(rows, beam, device="cuda")
+        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        if guided:
+            hip.beam_row_sample_groups(logits, v, gmax, rows, 1, beam, top_k, 1.1, 1, noise, 0, 0, 0, pi, pv, err)
+        else:
+            hip.beam_row_sample(logits, v, rows, 1, beam, top_k, 1.1, 1, noise, 0, 0, 0, pi, pv, err)
+        assert int(err.item()) == 0
+        out.append((pi.cpu(), pv.cpu()))
+    assert torch.equal(out[0][0], out[1][0])
+    np.testing.assert_allclose(out[0][1].numpy(), out[1][1].numpy(), atol=1e-6)
