@@ -25,6 +25,7 @@ bool g_on = false;
 std::string g_filter;                       // empty = everything, else ",name1,name2,"
 std::vector<hipEvent_t> g_pool;
 int g_used = 0;
+int g_stride = 1, g_seen = 0;          // record every g_stride-th matching launch
 std::vector<Rec> g_recs;
 std::vector<std::pair<std::string, Agg>> g_out;
 thread_local const char* g_tag = nullptr;
@@ -49,6 +50,7 @@ DhProfScope::DhProfScope(const char* name, double flops, double bytes, void* str
     if (tag) { key += "["; key += tag; key += "]"; }
     if (!g_filter.empty() && g_filter.find("," + key + ",") == std::string::npos &&
         g_filter.find(std::string(",") + name + ",") == std::string::npos) return;
+    if ((g_seen++ % g_stride) != 0) return;
     const int e0 = take_event(), e1 = take_event();
     if (e0 < 0 || e1 < 0) return;
     g_recs.push_back(Rec{key, e0, e1, flops, bytes});
@@ -68,7 +70,14 @@ extern "C" int dh_prof_begin(const char* filter) {
     g_recs.clear();
     g_out.clear();
     g_used = 0;
+    g_seen = 0;
     g_on = true;
+    return DH_OK;
+}
+
+extern "C" int dh_prof_set_stride(int n) {
+    if (n < 1) return DH_ERR_BAD_ARG;
+    g_stride = n;
     return DH_OK;
 }
 

@@ -58,11 +58,13 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 // NS = LDS ring depth: slabs t+1 .. t+NS-1 are in flight (LDS-DMA) while slab t feeds the MFMAs.
-template <int BM, int BN, bool CONV, int NS>
+// WAVES_M x (4 / WAVES_M) waves tile the BM x BN block.
+template <int BM, int BN, int WAVES_M, bool CONV, int NS>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SLAB = A_BYTES + B_BYTES;
-    constexpr int WM = BM / 2, WN = BN / 2;              // per-wave sub-tile (2x2 waves)
+    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave sub-tile
     constexpr int TM = WM / 16, TN = WN / 16;            // 16x16 MFMA tiles per wave
     constexpr int IA = BM / 32, IB = BN / 32;            // glds instructions per wave per slab
     constexpr int G = IA + IB;                           // LDS-DMA instructions per wave per slab
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
+    const int wm0 = (wave % WAVES_M) * WM, wn0 = (wave / WAVES_M) * WN;
     const int lr = lane >> 3, lpos = lane & 7;           // loader: row within the 8-row group, LDS chunk slot
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(dh_zero_page);
 
@@ -282,16 +284,23 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     const long long big_tiles = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
     if (big_tiles >= 192 && p.M >= 96 && p.N >= 96) {
         p.tiles_m = dh_cdiv(p.M, 128); p.tiles_n = dh_cdiv(p.N, 128);
-        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, CONV, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, CONV, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        return;
+    }
+    if (p.N <= 64 && p.M >= 256 * 512) {
+        // narrow outputs with very many rows (stage-1 convolutions): 256 x 64 tiles, 4 waves stacked along M, so the
+        // 64 weight rows are staged once per 256 pixels and every wave still owns a 64 x 64 accumulator
+        p.tiles_m = dh_cdiv(p.M, 256); p.tiles_n = dh_cdiv(p.N, 64);
+        hipLaunchKernelGGL((gemm_bf16_kernel<256, 64, 4, CONV, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
         return;
     }
     p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
     const int blocks = p.tiles_m * p.tiles_n;
     // few blocks: one per CU with a deep ring (7 slabs = 112 KB in flight); many blocks: two per CU, 3 in flight each
     if (blocks <= 320 && p.K > 128)
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, CONV, 8>), dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 8>), dim3(blocks), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 // called from dh_linear (gemm.hip) for DH_BF16 / DH_BF16_OUT_F32
@@ -346,6 +355,6 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
     p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = bias;
     p.C = logits; p.ldc = ldl; p.M = M; p.N = V; p.K = K; p.out_f32 = 1; p.gmax = group_max; p.gmax_ld = gm_ld;
     p.tiles_m = dh_cdiv(M, 128); p.tiles_n = dh_cdiv(V, 128);
-    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, false, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, false, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, (hipStream_t)stream, p);
     DH_LAUNCH_CHECK();
 }

@@ -78,6 +78,7 @@ SIGNATURES = {
     "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _I, _I, _P, _P, _P, _P],
     "dh_prof_begin": [_c.c_char_p],
+    "dh_prof_set_stride": [_I],
     "dh_prof_end": [],
     "dh_prof_num": [],
     "dh_prof_get": [_I, _c.c_char_p, _I, _c.POINTER(_I), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
@@ -133,13 +134,15 @@ class Profiler:
     ``with hip.profile(watch={...}) as prof`` ... ``prof.summary()`` -> {"entry[tag]": calls, ms, flops, bytes}
     with the algorithmic flops/bytes the library attaches to each launch.  Off otherwise."""
 
-    def __init__(self, watch=None):
+    def __init__(self, watch=None, stride=1):
         self.watch = None if watch is None else sorted(watch)
+        self.stride = stride
         self._summary = None
 
     def __enter__(self):
         global _prof
         self._prev, _prof = _prof, self
+        _check(load().dh_prof_set_stride(self.stride), "dh_prof_set_stride")
         _check(load().dh_prof_begin(",".join(self.watch).encode() if self.watch else None), "dh_prof_begin")
         return self
 
@@ -166,8 +169,8 @@ _prof = None
 _fns = {}
 
 
-def profile(watch=None):
-    return Profiler(watch)
+def profile(watch=None, stride=1):
+    return Profiler(watch, stride)
 
 
 def _launch(name, *args, tag=None, **_ignored):

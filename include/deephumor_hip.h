@@ -293,6 +293,8 @@ int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, c
  * aggregates per "entry[tag]": calls, total ms, algorithmic flops and bytes.
  * ------------------------------------------------------------------------------------------- */
 int dh_prof_begin(const char* filter);
+int dh_prof_set_stride(int n);           /* record only every n-th matching launch (default 1): sampling keeps
+                                            the perturbation of a timed region small */
 int dh_prof_end(void);
 int dh_prof_num(void);
 int dh_prof_get(int i, char* name, int cap, int* calls, double* ms, double* flops, double* bytes);
