@@ -156,3 +156,59 @@ extern "C" int dh_label_mean(const void* emb, const int64_t* labels, void* out, 
                                             (const T*)emb, labels, (T*)out, ld_out, L, E));
     DH_LAUNCH_CHECK();
 }
+
+// ---- teacher-forced scoring (deephumor/experiments/metrics.py:4-9) ---------------------------------------------
+// logp[r] = log_softmax(logits[r, :])[targets[r]] = logits[r, t] - max - log(sum(exp(logits - max))).
+// One workgroup per row, the V logits are read once (HBM-bound: rows*V*4 B), two block reductions.
+__global__ __launch_bounds__(256) void token_logprob_kernel(const float* __restrict__ logits, int ldl, int V,
+                                                             const int64_t* __restrict__ targets, float* __restrict__ logp) {
+    __shared__ float red[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (size_t)r * ldl;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i]);
+    red[tid] = m;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] = fmaxf(red[tid], red[tid + s2]); __syncthreads(); }
+    m = red[0];
+    __syncthreads();
+    float s = 0.f;
+    for (int i = tid; i < V; i += 256) s += expf(row[i] - m);
+    red[tid] = s;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] += red[tid + s2]; __syncthreads(); }
+    if (tid == 0) {
+        const int64_t t = targets[r];
+        logp[r] = (t >= 0 && t < V) ? (row[t] - m) - logf(red[0]) : 0.f;
+    }
+}
+
+extern "C" int dh_token_logprob(const float* logits, int ldl, int V, const int64_t* targets, float* logp, int rows,
+                                void* stream) {
+    DH_REQUIRE(logits && targets && logp && rows > 0 && V > 0 && ldl >= V);
+    DhProfScope prof("dh_token_logprob", 0.0, 4.0 * rows * V, stream);
+    hipLaunchKernelGGL(token_logprob_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, targets, logp);
+    DH_LAUNCH_CHECK();
+}
+
+// pp[b] = exp(-sum_t [targets[b,t] != pad] * logp[b,t] / lengths[b])   (metrics.py:5-8), one wave per sequence
+__global__ __launch_bounds__(64) void seq_perplexity_kernel(const float* __restrict__ logp, const int64_t* __restrict__ targets,
+                                                             const int64_t* __restrict__ lengths, float* __restrict__ pp,
+                                                             int L, int pad_index) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float len = (float)lengths[b];
+    float s = 0.f;
+    for (int t = lane; t < L; t += 64)
+        if (targets[(size_t)b * L + t] != pad_index) s += logp[(size_t)b * L + t] / len;
+    s = wave_sum(s);
+    if (lane == 0) pp[b] = expf(-s);
+}
+
+extern "C" int dh_seq_perplexity(const float* logp, const int64_t* targets, const int64_t* lengths, float* pp,
+                                 int n_seq, int L, int pad_index, void* stream) {
+    DH_REQUIRE(logp && targets && lengths && pp && n_seq > 0 && L > 0);
+    DhProfScope prof("dh_seq_perplexity", 0.0, 0.0, stream);
+    hipLaunchKernelGGL(seq_perplexity_kernel, dim3(n_seq), dim3(64), 0, (hipStream_t)stream, logp, targets, lengths, pp, L,
+                       pad_index);
+    DH_LAUNCH_CHECK();
+}

@@ -77,6 +77,8 @@ SIGNATURES = {
                             _I, _P, _P, _I, _P],
     "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _I, _I, _P, _P, _P, _P],
+    "dh_token_logprob": [_P, _I, _I, _P, _P, _I, _P],
+    "dh_seq_perplexity": [_P, _P, _P, _P, _I, _I, _I, _P],
     "dh_prof_begin": [_c.c_char_p],
     "dh_prof_set_stride": [_I],
     "dh_prof_end": [],
@@ -458,3 +460,23 @@ def lstm_decode_step(model, scratch, img_emb, tokens, tok_pos, hparent, started,
             tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(hparent), int(started), rows, rows_per_img,
             row_mult, rows_total, _ptr(h_out), h_out.stride(0) if h_out is not None else 0, _ptr(logits),
             _ptr(group_max), group_max.stride(0) if group_max is not None else 0, _stream())
+
+
+def token_logprob(logits, targets):
+    """logits fp32 [rows, V], targets int64 [rows] -> log_softmax(logits)[targets] fp32 [rows]."""
+    _dev(logits, targets)
+    assert logits.dtype == torch.float32 and targets.dtype == torch.int64 and logits.stride(1) == 1
+    rows, v = logits.shape
+    out = torch.empty((rows,), dtype=torch.float32, device=logits.device)
+    _launch("dh_token_logprob", _ptr(logits), logits.stride(0), v, _ptr(targets.contiguous()), _ptr(out), rows, _stream())
+    return out
+
+
+def seq_perplexity(logp, targets, lengths, pad_index=0):
+    """logp fp32 [n, L], targets int64 [n, L], lengths int64 [n] -> per-sequence perplexity fp32 [n]."""
+    _dev(logp, targets, lengths)
+    n, l = targets.shape
+    out = torch.empty((n,), dtype=torch.float32, device=logp.device)
+    _launch("dh_seq_perplexity", _ptr(logp.contiguous()), _ptr(targets.contiguous()), _ptr(lengths.contiguous()),
+            _ptr(out), n, l, pad_index, _stream())
+    return out

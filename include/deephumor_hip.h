@@ -230,6 +230,18 @@ int dh_beam_finalize(const int32_t* tokens, int tok_ld, const float* vals, const
                      float temperature, const float* noise, uint64_t seed, int img0, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Teacher-forced scoring (deephumor/experiments/metrics.py:4-9; call shape trainer.py:69-81)
+ * ------------------------------------------------------------------------------------------- */
+
+/* logp[r] = log_softmax(logits[r, 0..V))[targets[r]]; logits fp32 [rows, ldl]; targets int64 [rows]. */
+int dh_token_logprob(const float* logits, int ldl, int V, const int64_t* targets, float* logp, int rows,
+                     void* stream);
+
+/* pp[b] = exp(-sum_t [targets[b,t] != pad_index] * logp[b,t] / lengths[b]); logp/targets [n_seq, L]. */
+int dh_seq_perplexity(const float* logp, const int64_t* targets, const int64_t* lengths, float* pp,
+                      int n_seq, int L, int pad_index, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Native step drivers: one call = every kernel of one decode position / one LSTM time step,
  * sequenced on `stream` from weights described by plain C structs (host arrays of device pointers).
  * Replaces the Python-side per-layer loops of TransformerDecoder.forward (transformers.py:455-488,

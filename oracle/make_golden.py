@@ -105,6 +105,49 @@ def greedy_with_margins(model, kind, image, label, caption, max_len=32):
     return ids.reshape(-1).numpy(), np.array(margins, np.float32), np.array(top1, np.int64)
 
 
+def text_and_metric_goldens():
+    """G8: host text helpers (inference.py:11-89, vocab.py, tokenizers.py) and the perplexity metric (metrics.py:4-9),
+    recorded from the reference.  ``deephumor.experiments`` cannot be imported as a package here (tensorboard is
+    absent), so its two dependency-free files are loaded by path."""
+    import importlib.util
+    from deephumor.data import WordPunctTokenizer, CharTokenizer
+    from deephumor.data.vocab import build_vocab
+
+    def by_path(name):
+        spec = importlib.util.spec_from_file_location("ref_" + name, f"/root/reference/deephumor/experiments/{name}.py")
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    inf, met = by_path("inference"), by_path("metrics")
+    docs = ["One does not simply <sep> walk into Mordor !", "y u no <sep> use the gpu ?!",
+            "i don't always test <sep> but when i do , it's in production...", "such wow <emp> <sep> much kernel",
+            "not sure if fast <sep> or just cached", "brace yourselves <sep> the benchmarks are coming"] * 2
+    wt, ct = WordPunctTokenizer(), CharTokenizer()
+    wv, cv = build_vocab(docs, wt, min_df=2), build_vocab(docs, ct, min_df=2)
+    out = {"docs": docs, "word_vocab": wv.tokens, "char_vocab": cv.tokens, "cases": []}
+    for c in ("One does not simply walk into MORDOR!!", "y u no compile, bro?", "unknownword <sep> it's fine..."):
+        ws, cs = inf.text_to_seq(c, wv, wt), inf.text_to_seq(c, cv, ct)
+        out["cases"].append({"text": c, "word_tokens": wt.tokenize(c.lower()), "char_tokens": ct.tokenize(c.lower()),
+                             "word_seq": ws[0].tolist(), "char_seq": cs[0].tolist(),
+                             "word_text": inf.seq_to_text(torch.cat([ws[0], torch.tensor([3, 7])]), wv),
+                             "char_text": inf.seq_to_text(cs[0], cv, delimiter='')})
+    splits = ["one does not simply <sep> walk into mordor !", "<bos> top text , with comma <sep>  bottom ... <eos>",
+              "no separator here", "a <sep> b <sep> c ?"]
+    out["splits"] = [{"text": t, "all": inf.split_caption(t), "two": inf.split_caption(t, 2),
+                      "three": inf.split_caption(t, 3)} for t in splits]
+    g = torch.Generator().manual_seed(5)
+    logits = torch.randn(4, 9, 50, generator=g) * 2
+    targets = torch.randint(6, 50, (4, 9), generator=g)
+    lengths = torch.tensor([9, 5, 7, 2])
+    for r, n in enumerate(lengths.tolist()):
+        targets[r, n:] = 0
+    out["perplexity"] = {"seed": 5, "value": float(met.perplexity(logits.clone(), targets, lengths, 0)),
+                         "lengths": lengths.tolist()}
+    with open(os.path.join(OUT, "g8_text_and_metrics.json"), "w") as f:
+        json.dump(out, f, indent=1)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -218,6 +261,7 @@ def main():
     g4.update(mn_p=p.numpy(), mn_picks=picks.numpy(), mn_noise=q.numpy())
     np.savez_compressed(os.path.join(OUT, "g4_beam_helper.npz"), **g4)
 
+    text_and_metric_goldens()
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote", OUT)

@@ -377,3 +377,11 @@ def model_generate(kind, sd, hp, image, label=None, caption=None, max_len=25, te
         if "LSTM" in kind:
             return lstm_decoder_generate(sd, "decoder", start.unsqueeze(1), **kw)
         return transformer_generate(sd, "decoder", start, enc_out, hp["pad_index"], hp["n_heads"], **kw)
+
+
+def perplexity(logits, targets, lengths, pad_index=PAD):
+    """deephumor/experiments/metrics.py:4-9: mean over sequences of exp(-sum_t log p(target_t) / length)."""
+    logp = logits.log_softmax(-1).gather(-1, targets.unsqueeze(-1)).squeeze(-1)
+    logp = logp / lengths.unsqueeze(1)
+    logp = logp.masked_fill(targets == pad_index, 0.)
+    return (-logp.sum(dim=-1)).exp().mean()

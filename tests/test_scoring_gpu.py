@@ -1,0 +1,56 @@
+"""Teacher-forced scoring: perplexity kernels vs the reference's value and the oracle,
+corpus scoring with per-template encoder caching vs the oracle's per-pair forward."""
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import GOLDEN, synthetic_sd, synth_images  # noqa: E402
+
+
+def test_perplexity_kernels():
+    from deephumor_amd.experiments import perplexity
+    from oracle.ref_path import perplexity as ref_pp
+    gold = json.load(open(os.path.join(GOLDEN, "g8_text_and_metrics.json")))["perplexity"]
+    g = torch.Generator().manual_seed(gold["seed"])
+    logits = torch.randn(4, 9, 50, generator=g) * 2
+    targets = torch.randint(6, 50, (4, 9), generator=g)
+    lengths = torch.tensor(gold["lengths"])
+    for r, n in enumerate(lengths.tolist()):
+        targets[r, n:] = 0
+    pp = perplexity(logits.cuda(), targets.cuda(), lengths.cuda())
+    assert abs(float(pp) - gold["value"]) < 1e-4 * gold["value"]
+    big = torch.randn(3, 7, 36541, generator=g) * 3
+    tg = torch.randint(6, 36541, (3, 7), generator=g)
+    ln = torch.tensor([7, 7, 4])
+    tg[2, 4:] = 0
+    want = float(ref_pp(big, tg, ln))
+    assert abs(float(perplexity(big.cuda(), tg.cuda(), ln.cuda())) - want) < 1e-4 * want
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_score_captions_with_template_caching(kind):
+    import deephumor_amd.models as M
+    from deephumor_amd.experiments import score_captions
+    from oracle import ref_path as R
+    sd, hp = synthetic_sd(kind)
+    model = getattr(M, kind)(**hp).eval()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    templates = synth_images(3, seed=0)
+    g = torch.Generator().manual_seed(3)
+    n, l = 7, 12
+    caps = torch.randint(6, 1000, (n, l), generator=g)
+    lengths = torch.tensor([12, 9, 12, 5, 7, 12, 3])
+    for r, k in enumerate(lengths.tolist()):
+        caps[r, k - 1] = 3                       # <eos>
+        caps[r, k:] = 0
+    tidx = torch.tensor([0, 1, 2, 2, 1, 0, 0])
+    got = score_captions(model, templates.cuda(), tidx.cuda(), caps.cuda(), lengths.cuda(), batch_size=4).cpu()
+    for i in range(n):
+        logits = R.model_forward(kind, sd, hp, templates[tidx[i]:tidx[i] + 1], caps[i:i + 1, :-1])[:, :l]
+        want = float(R.perplexity(logits, caps[i:i + 1], lengths[i:i + 1]))
+        assert abs(float(got[i]) - want) < 2e-3 * want, (i, float(got[i]), want)
