@@ -20,6 +20,7 @@
 //   * the bf16 epilogue stages the fp32 tile through LDS (XOR-swizzled 16-B slots) and finishes with
 //     16-byte row-contiguous residual loads / stores -- one rounding, at the very end; fp32 output
 //     (logits, odd leading dimension) is stored straight from registers.
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 
@@ -58,15 +59,16 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 }
 
 // NS = LDS ring depth: slabs t+1 .. t+NS-1 are in flight (LDS-DMA) while slab t feeds the MFMAs.
-// WAVES_M x (4 / WAVES_M) waves tile the BM x BN block.
-template <int BM, int BN, int WAVES_M, bool CONV, int NS>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
+// NW waves per workgroup, arranged WAVES_M x (NW / WAVES_M) over the BM x BN block.
+template <int BM, int BN, int WAVES_M, bool CONV, int NS, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
+    constexpr int NT = 64 * NW;
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SLAB = A_BYTES + B_BYTES;
-    constexpr int WAVES_N = 4 / WAVES_M;
+    constexpr int WAVES_N = NW / WAVES_M;
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;  // per-wave sub-tile
     constexpr int TM = WM / 16, TN = WN / 16;            // 16x16 MFMA tiles per wave
-    constexpr int IA = BM / 32, IB = BN / 32;            // glds instructions per wave per slab
+    constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW);  // glds instructions per wave per slab (8 rows each)
     constexpr int G = IA + IB;                           // LDS-DMA instructions per wave per slab
     constexpr int LDS_BYTES = NS * SLAB;                 // >= the fp32 epilogue tile (BM*BN*4 B = 2 slabs)
     static_assert(NS >= 2 && (NS - 2) * G <= 24, "ring depth vs vmcnt encoding");
@@ -234,7 +236,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
         // fp32 output (logits; leading dimension may be odd): lane <-> consecutive column, so every wave
         // store is one contiguous run of up to 256 B of a row whatever its alignment
         float* Cf = reinterpret_cast<float*>(p.C);
-        for (int e = tid; e < BM * BN; e += 256) {
+        for (int e = tid; e < BM * BN; e += NT) {
             const int row = e / BN, col = e - row * BN;
             const int m = m0 + row, n = n0 + col;
             if (m >= p.M || n >= p.N) continue;
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Params p) {
     constexpr int CHUNKS = BN / 8;                        // 16-byte bf16 chunks per tile row
     uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
     const bool fast = ((p.ldc & 7) == 0) && (!p.res || (p.ldres & 7) == 0);
-    for (int c = tid; c < BM * CHUNKS; c += 256) {
+    for (int c = tid; c < BM * CHUNKS; c += NT) {
         const int row = c / CHUNKS, ch = c - row * CHUNKS;
         const int m = m0 + row, n = n0 + ch * 8;
         if (m >= p.M || n >= p.N) continue;
@@ -284,7 +286,10 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     const long long big_tiles = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
     if (big_tiles >= 192 && p.M >= 96 && p.N >= 96) {
         p.tiles_m = dh_cdiv(p.M, 128); p.tiles_n = dh_cdiv(p.N, 128);
-        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, CONV, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        // 8 waves (4 x 2, each 32 x 64) on the 128 x 128 tile, 2 workgroups per CU = 4 waves per SIMD: measured
+        // 510 TF vs 450 TF with 4 waves per workgroup and 300 TF with one 4-wave workgroup and a deeper ring --
+        // the MFMA pipe needs co-resident waves to cover each wave's LDS-read/barrier gaps
+        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
         return;
     }
     if (p.N <= 64 && p.M >= 256 * 512) {
@@ -355,6 +360,6 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
     p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = bias;
     p.C = logits; p.ldc = ldl; p.M = M; p.N = V; p.K = K; p.out_f32 = 1; p.gmax = group_max; p.gmax_ld = gm_ld;
     p.tiles_m = dh_cdiv(M, 128); p.tiles_n = dh_cdiv(V, 128);
-    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 2, false, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 4, false, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
     DH_LAUNCH_CHECK();
 }
