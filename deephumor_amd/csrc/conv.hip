@@ -218,6 +218,27 @@ extern "C" int dh_stem_conv_nhwc(const float* x, const float* w, const float* sc
     DH_LAUNCH_CHECK();
 }
 
+// ---- image packing for the matrix-core stem: NCHW fp32 [N,C,H,W] (C <= 8) -> NHWC bf16 [N,H,W,8], channels C..7 zero ----
+__global__ __launch_bounds__(256) void pack_nchw_to_nhwc8_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+                                                                   int C, int HW, size_t total) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
+        const size_t n = i / HW, p = i - n * HW;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < C ? x[(n * C + c) * HW + p] : 0.f;
+        store16(y + i * 8, v);
+    }
+}
+
+extern "C" int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, void* stream) {
+    DH_REQUIRE(x && y && N > 0 && C > 0 && C <= 8 && H > 0 && W > 0);
+    DhProfScope prof("dh_pack_nchw_to_nhwc8", 0.0, (double)N * H * W * (4.0 * C + 16.0), stream);
+    const size_t total = (size_t)N * H * W;
+    const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+    hipLaunchKernelGGL(pack_nchw_to_nhwc8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, C, H * W, total);
+    DH_LAUNCH_CHECK();
+}
+
 // ---- channels-last bf16 pools (bf16 path) ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                                  int N, int H, int W, int C, int Ho, int Wo) {

@@ -53,6 +53,7 @@ SIGNATURES = {
     "dh_abi_version": [],
     "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 9 + [_P],
+    "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_avgpool_nhwc": [_P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -239,6 +240,16 @@ def stem_conv_nhwc(x, w, scale, shift, stride=2, pad=3, relu=True):
     _launch("dh_stem_conv_nhwc", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), n, cin, h, wd, cout, ks,
             stride, pad, int(relu), _stream(), flops=2.0 * n * ho * wo * cout * cin * ks * ks,
             nbytes=4.0 * x.numel() + 2.0 * out.numel())
+    return out
+
+
+def pack_nchw_to_nhwc8(x):
+    """x NCHW fp32 [N,C<=8,H,W] -> channels-last bf16 [N,H,W,8] (zero-padded channels)."""
+    _dev(x)
+    n, c, h, w = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    out = torch.empty((n, h, w, 8), dtype=torch.bfloat16, device=x.device)
+    _launch("dh_pack_nchw_to_nhwc8", _ptr(x), _ptr(out), n, c, h, w, _stream())
     return out
 
 

@@ -97,14 +97,19 @@ class ImageEncoder(nn.Module, _Planned):
     def _build_plan(self):
         """fp32 weights -> NCHW vector-ALU convolutions (the parity path); bf16 weights -> channels-last
         activations with every bottleneck conv on the bf16 matrix cores (weights repacked once to
-        [Cout, kh, kw, Cin]); the 3-channel stem stays on the vector ALUs in both."""
+        [Cout, kh, kw, Cin]; the stem's 3 input channels are zero-padded to 8)."""
         bf16 = self.linear.weight.dtype == torch.bfloat16
 
         def conv(c, bn, relu, residual=False, stem=False):
             s, b = _bn_affine(bn)
             w = c.weight.detach()
-            if bf16:
-                w = w.float().contiguous() if stem else w.permute(0, 2, 3, 1).contiguous()
+            if bf16 and stem:
+                # 3 input channels zero-padded to 8: the stem becomes a Cin=8 channels-last conv on the matrix cores
+                w8 = torch.zeros((w.shape[0], w.shape[2], w.shape[3], 8), dtype=w.dtype, device=w.device)
+                w8[..., :w.shape[1]] = w.permute(0, 2, 3, 1)
+                w = w8.contiguous()
+            elif bf16:
+                w = w.permute(0, 2, 3, 1).contiguous()
             else:
                 w = w.contiguous()
             return dict(w=w, scale=s, shift=b, stride=c.stride[0], pad=c.padding[0], relu=relu, residual=residual)
@@ -133,8 +138,7 @@ class ImageEncoder(nn.Module, _Planned):
         nhwc = plan["bf16"]
         st = plan["stem"]
         if nhwc:
-            x = hip.stem_conv_nhwc(images.float().contiguous(), st["w"], st["scale"], st["shift"], stride=st["stride"],
-                                   pad=st["pad"], relu=True)
+            x = self._conv(hip.pack_nchw_to_nhwc8(images.float().contiguous()), st, nhwc=True)
             x = hip.maxpool3x3s2_nhwc(x)
         else:
             x = hip.maxpool3x3s2(self._conv(images.contiguous(), st))

@@ -65,6 +65,10 @@ int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const 
                       int N, int Cin, int H, int W, int Cout, int KS, int stride, int pad, int relu,
                       void* stream);
 
+/* Input packing for a matrix-core stem: NCHW fp32 image [N,C,H,W] (C <= 8) -> channels-last bf16 [N,H,W,8] with
+ * channels C..7 zero, so the 7x7 stem is a dh_conv2d_nhwc_bn_act with Cin = 8 (weights zero-padded likewise). */
+int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, void* stream);
+
 /* Channels-last bf16 pools of the bf16 path: MaxPool2d(3,2,1) x [N,H,W,C] -> [N,Ho,Wo,C];
  * AdaptiveAvgPool2d(1) x [N,HW,C] -> y [N,C].  C % 8 == 0.  DH_BF16 only. */
 int dh_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);
