@@ -29,7 +29,8 @@ sys.path.insert(0, ROOT)
 V_WORD = 36541          # deephumor_demo.ipynb:524
 MAX_LEN = 32            # deephumor_demo.ipynb:1127
 BEAM, TOP_K, TEMP = 5, 50, 1.0
-STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))   # image sub-batches decoded concurrently (HIP streams)
+STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))
+GRAPH = False        # set by --graph   # image sub-batches decoded concurrently (HIP streams)
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
@@ -53,10 +54,14 @@ def build_model(workload, dev, dtype="bf16"):
     return model, sd, model._hp
 
 
-def one_step(model, images, img0, n_total, seed):
+def one_step(model, images, img0, n_total, seed, eager=False):
     from deephumor_amd.dist import gather_captions
-    toks, lens = model.generate_batch(images, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP,
-                                      seed=seed, img0=img0, streams=STREAMS)
+    if GRAPH and not eager:      # whole step replayed from a captured hipGraph (profiling passes run eagerly: events need real launches)
+        toks, lens = model.generate_batch_graphed(images, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP,
+                                                  seed=seed, img0=img0)
+    else:
+        toks, lens = model.generate_batch(images, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP,
+                                          seed=seed, img0=img0, streams=STREAMS)
     return gather_captions(toks, lens, n_total)
 
 
@@ -141,7 +146,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
         # (HIP events around every launch made through the library)
         one_step(model, images, rank * n_local, n_total, seed=0)
         with hip.profile() as prof0:
-            _, lens = one_step(model, images, rank * n_local, n_total, seed=0)
+            _, lens = one_step(model, images, rank * n_local, n_total, seed=0, eager=True)
         breakdown = prof0.summary()
         dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])
         # watch the dominant "entry[tag]" only (plus the decoder self-attention, the north star's roofline
@@ -153,7 +158,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
         t0 = time.perf_counter()
         # timed region: HIP events (on the launch stream) only around the dominant entry point and the
         # attention kernels, so the roofline line is measured over exactly the steps `value` is
-        if main_line:
+        if main_line and not GRAPH:
             with hip.profile(watch=watch, stride=4) as prof:     # every 4th launch: <0.3 ms of events per step
                 for s in range(steps):
                     _, lens = one_step(model, images, rank * n_local, n_total, seed=100 + s)
@@ -170,13 +175,27 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             barrier()
             dt = time.perf_counter() - t0
             with hip.profile(watch={dominant, "dh_attn_self_decode", "dh_attn_cross_decode"}) as prof:
-                one_step(model, images, rank * n_local, n_total, seed=999)
+                one_step(model, images, rank * n_local, n_total, seed=999, eager=True)
             summary = prof.summary()
     t = torch.tensor([dt], device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    res = {"value": n_total * steps / dt, "ms_per_step": dt / steps * 1e3,
+    graph_res = None
+    if main_line and not GRAPH and world == 1:
+        # the same K steps replayed from a captured hipGraph (reported next to the contract number, which is eager
+        # because the roofline events need real launches)
+        with torch.no_grad():
+            kw = dict(max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP)
+            model.generate_batch_graphed(images, seed=1, **kw)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for s in range(steps):
+                model.generate_batch_graphed(images, seed=100 + s, **kw)
+            torch.cuda.synchronize()
+            tg = time.perf_counter() - tg
+        graph_res = {"value": n_total * steps / tg, "unit": "captions/s", "ms_per_step": tg / steps * 1e3}
+    res = {"value": n_total * steps / dt, "ms_per_step": dt / steps * 1e3, "hipgraph_replay": graph_res,
            "mean_caption_len": float(lens.float().mean()) if lens is not None else None}
     total_ms = sum(d["ms"] for d in breakdown.values())
     res["kernel_breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])}
@@ -208,10 +227,14 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3", "both"], default="both")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images for the CPU baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (eager by default: "
+                    "the in-library event profiler of the roofline line needs real launches)")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
                     help="storage/MFMA operand type of the measured path (BASELINE configs C2/C3: bf16)")
     args = ap.parse_args()
 
+    global GRAPH
+    GRAPH = args.graph
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -242,6 +265,7 @@ def main():
         "greedy_token_match_vs_cpu_ref": res.get("greedy_token_match_vs_cpu_ref"),
         "greedy_token_match_bf16_vs_cpu_ref": res.get("greedy_token_match_bf16_vs_cpu_ref"),
         "speedup_vs_cpu": res.get("speedup_vs_cpu"), "mean_caption_len": res["mean_caption_len"],
+        "hipgraph_replay": res.get("hipgraph_replay"),
         "kernel_breakdown_ms_per_step": res["kernel_breakdown_ms_per_step"],
     }
     if args.workload == "both":

@@ -63,7 +63,7 @@ __device__ __forceinline__ float block_reduce_256(float v, float* red, bool is_m
 
 __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
-    float temperature, int unk, const float* __restrict__ noise, uint64_t seed, int img0, int step,
+    float temperature, int unk, const float* __restrict__ noise, uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step,
     int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
     __shared__ int hist[4][256];
     __shared__ uint32_t s_prefix;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     const int img = rc / rows_per_img, rin = rc % rows_per_img;
     for (int i = tid; i < n; i += 256) {
         const float nz = noise ? noise[(size_t)rc * ldl + idx_b[i]]
-                               : philox_exp1(seed, (uint32_t)(img0 + img), (uint32_t)step, 0u, (uint32_t)rin, (uint32_t)idx_b[i]);
+                               : philox_exp1(seed ^ (seed_ptr ? *seed_ptr : 0ull), (uint32_t)(img0 + img), (uint32_t)step, 0u, (uint32_t)rin, (uint32_t)idx_b[i]);
         qv[i] = (qv[i] / s) / nz;
     }
     if (tid < DH_BEAM_MAX_BEAMS) picks[tid] = -1;
@@ -176,7 +176,7 @@ struct RowLds {
 template <int NT>
 __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int rows_per_img, int beam, int top_k,
                                          float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
-                                         int img0, int step, int32_t* __restrict__ pick_idx,
+                                         const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
                                          float* __restrict__ pick_val, int32_t* __restrict__ err) {
     const int tid = threadIdx.x;
     int* idx_a = L.idx_a; int* idx_b = L.idx_b; float* val_a = L.val_a; float* val_b = L.val_b;
@@ -233,7 +233,7 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
     const int img = rc / rows_per_img, rin = rc % rows_per_img;
     for (int i = tid; i < n; i += NT) {
         const float nz = noise ? noise[(size_t)rc * ldl + idx_a[i]]
-                               : philox_exp1(seed, (uint32_t)(img0 + img), (uint32_t)step, 0u, (uint32_t)rin, (uint32_t)idx_a[i]);
+                               : philox_exp1(seed ^ (seed_ptr ? *seed_ptr : 0ull), (uint32_t)(img0 + img), (uint32_t)step, 0u, (uint32_t)rin, (uint32_t)idx_a[i]);
         qv[i] = (qv[i] / s) / nz;
     }
     if (tid < DH_BEAM_MAX_BEAMS) picks[tid] = -1;
@@ -265,7 +265,7 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
 template <int EPT, int NT, int WPE>
 __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
     const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
-    float temperature, int unk, const float* __restrict__ noise, uint64_t seed, int img0, int step,
+    float temperature, int unk, const float* __restrict__ noise, uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step,
     int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
     __shared__ uint32_t lmax[NT];
     __shared__ int hist[256];
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
     }
     __syncthreads();
     const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
-    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, img0, step, pick_idx, pick_val, err);
+    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err);
 }
 
 // ---- group-max guided variant -----------------------------------------------------------------------------
@@ -330,7 +330,7 @@ template <int NT>
 __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     const float* __restrict__ logits, int ldl, int V, const float* __restrict__ gmax, int gm_ld, int n_groups,
     int gcols, int rows_per_img, int beam, int top_k, float temperature, int unk, const float* __restrict__ noise,
-    uint64_t seed, int img0, int step, int32_t* __restrict__ pick_idx, float* __restrict__ pick_val,
+    uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx, float* __restrict__ pick_val,
     int32_t* __restrict__ err) {
     constexpr int MAXG = 1024;
     __shared__ uint32_t gkey[MAXG];
@@ -378,13 +378,13 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     }
     __syncthreads();
     const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
-    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, img0, step, pick_idx, pick_val, err);
+    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err);
 }
 
 extern "C" int dh_beam_row_sample_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld,
                                          int n_groups, int group_cols, int rows, int rows_per_img, int beam,
                                          int top_k, float temperature, int unk_index, const float* noise,
-                                         uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
+                                         uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* pick_idx, float* pick_val,
                                          int32_t* err, void* stream) {
     DH_REQUIRE(logits && group_max && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
     DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
@@ -393,19 +393,19 @@ extern "C" int dh_beam_row_sample_groups(const float* logits, int ldl, int V, co
     DhProfScope prof("dh_beam_row_sample", 0.0, 0.0, stream);
     hipLaunchKernelGGL((beam_row_sample_groups_kernel<256>), dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
                        group_max, gm_ld, n_groups, group_cols, rows_per_img, beam, top_k, temperature, unk_index, noise,
-                       seed, img0, step, pick_idx, pick_val, err);
+                       seed, seed_ptr, img0, step, pick_idx, pick_val, err);
     DH_LAUNCH_CHECK();
 }
 
 extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,
                                   int top_k, float temperature, int unk_index, const float* noise,
-                                  uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
+                                  uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* pick_idx, float* pick_val,
                                   int32_t* err, void* stream) {
     DH_REQUIRE(logits && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
     DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
     DhProfScope prof("dh_beam_row_sample", 0.0, 0.0, stream);
 #define DH_FAST(EPT, NT, WPE) hipLaunchKernelGGL((beam_row_sample_fast_kernel<EPT, NT, WPE>), dim3(rows), dim3(NT), 0, \
-        (hipStream_t)stream, logits, ldl, V, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, \
+        (hipStream_t)stream, logits, ldl, V, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, seed_ptr, img0, \
         step, pick_idx, pick_val, err)
     if (top_k <= 256 && V <= 512 * 8) DH_FAST(8, 512, 4);
     else if (top_k <= 256 && V <= 1024 * 16) DH_FAST(16, 1024, 8);
@@ -413,7 +413,7 @@ extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows,
     else if (top_k <= 256 && V <= 1024 * 64) DH_FAST(64, 1024, 4);
     else
         hipLaunchKernelGGL(beam_row_sample_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
-                           rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step, pick_idx,
+                           rows_per_img, beam, top_k, temperature, unk_index, noise, seed, seed_ptr, img0, step, pick_idx,
                            pick_val, err);
 #undef DH_FAST
     DH_LAUNCH_CHECK();
@@ -425,7 +425,7 @@ struct SelectParams {
     int32_t* tokens; int tok_ld; float* vals; uint8_t* ended; int32_t* src; int src_ld;
     int32_t* parent; int32_t* hparent; uint8_t* done; int32_t* end_step;
     int beam, first, first_sets_ended, write_pos, t, step_index, eos, img0;
-    float temperature; const float* noise; uint64_t seed;
+    float temperature; const float* noise; uint64_t seed; const uint64_t* seed_ptr;
 };
 
 __global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
         s = wave_sum(s);
         for (int c = lane; c < n; c += 64) {
             const float nz = p.noise ? p.noise[(size_t)img * B * B + c]
-                                     : philox_exp1(p.seed, (uint32_t)(p.img0 + img), (uint32_t)p.step_index, 1u, 0u, (uint32_t)c);
+                                     : philox_exp1(p.seed ^ (p.seed_ptr ? *p.seed_ptr : 0ull), (uint32_t)(p.img0 + img), (uint32_t)p.step_index, 1u, 0u, (uint32_t)c);
             q[c] = (q[c] / s) / nz;
         }
         __syncthreads();
@@ -517,14 +517,14 @@ extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, in
                               float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent,
                               int32_t* hparent, uint8_t* done, int32_t* end_step, int n_img, int beam,
                               int first, int first_sets_ended, int write_pos, int t, int step_index,
-                              float temperature, int eos_index, const float* noise, uint64_t seed, int img0,
-                              void* stream) {
+                              float temperature, int eos_index, const float* noise, uint64_t seed,
+                              const uint64_t* seed_ptr, int img0, void* stream) {
     DH_REQUIRE(pick_idx && pick_val && tokens && vals && ended && parent && hparent && done && end_step);
     DH_REQUIRE(n_img > 0 && beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && tok_ld > 0 && t >= 0 && temperature > 0.f);
     DH_REQUIRE(!src || src_ld > t);
     DhProfScope prof("dh_beam_select", 0.0, 0.0, stream);
     SelectParams p{pick_idx, pick_val, tokens, tok_ld, vals, ended, src, src_ld, parent, hparent, done, end_step,
-                   beam, first, first_sets_ended, write_pos, t, step_index, eos_index, img0, temperature, noise, seed};
+                   beam, first, first_sets_ended, write_pos, t, step_index, eos_index, img0, temperature, noise, seed, seed_ptr};
     const size_t lds = (size_t)beam * (tok_ld + (src ? t : 0)) * sizeof(int32_t);
     hipLaunchKernelGGL(beam_select_kernel, dim3(n_img), dim3(64), lds, (hipStream_t)stream, p);
     DH_LAUNCH_CHECK();
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(
     const int32_t* __restrict__ tokens, int tok_ld, const float* __restrict__ vals, const uint8_t* __restrict__ done,
     const int32_t* __restrict__ end_step, int32_t* __restrict__ out, int out_ld, int32_t* __restrict__ out_len,
     int beam, int len_bias_done, int full_len, int pad_index, float temperature, const float* __restrict__ noise,
-    uint64_t seed, int img0) {
+    uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0) {
     const int img = blockIdx.x, lane = threadIdx.x, base = img * beam;
     // ind = multinomial(softmax(vals / T), 1) == arg-max of p / Exp(1) (first index on ties)
     float x = lane < beam ? vals[base + lane] / temperature : -INFINITY;
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(
     float qq = -1.f;
     if (lane < beam) {
         const float nz = noise ? noise[(size_t)img * beam + lane]
-                               : philox_exp1(seed, (uint32_t)(img0 + img), 0xFFFFFFFFu, 2u, 0u, (uint32_t)lane);
+                               : philox_exp1(seed ^ (seed_ptr ? *seed_ptr : 0ull), (uint32_t)(img0 + img), 0xFFFFFFFFu, 2u, 0u, (uint32_t)lane);
         qq = (e / s) / nz;
     }
     const float best = wave_max(qq);
@@ -561,12 +561,13 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(
 extern "C" int dh_beam_finalize(const int32_t* tokens, int tok_ld, const float* vals, const uint8_t* done,
                                 const int32_t* end_step, int32_t* out, int out_ld, int32_t* out_len,
                                 int n_img, int beam, int len_bias_done, int full_len, int pad_index,
-                                float temperature, const float* noise, uint64_t seed, int img0, void* stream) {
+                                float temperature, const float* noise, uint64_t seed, const uint64_t* seed_ptr, int img0,
+                                void* stream) {
     DH_REQUIRE(tokens && vals && done && end_step && out && out_len && n_img > 0);
     DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && temperature > 0.f);
     DhProfScope prof("dh_beam_finalize", 0.0, 0.0, stream);
     hipLaunchKernelGGL(beam_finalize_kernel, dim3(n_img), dim3(64), 0, (hipStream_t)stream, tokens, tok_ld, vals,
                        done, end_step, out, out_ld, out_len, beam, len_bias_done, full_len, pad_index,
-                       temperature, noise, seed, img0);
+                       temperature, noise, seed, seed_ptr, img0);
     DH_LAUNCH_CHECK();
 }

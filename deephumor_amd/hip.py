@@ -69,15 +69,15 @@ SIGNATURES = {
     "dh_enc_key_mask": [_P, _P, _I, _I, _I, _P],
     "dh_lstm_prepare": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_lstm_cell": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _I, _I, _P, _P, _P, _P],
+    "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
-                       _U64, _I, _P],
+                       _U64, _P, _I, _P],
     "dh_transformer_decode_position": [_c.POINTER(TrModel), _c.POINTER(TrScratch), _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
                                        _P, _P, _P, _I, _P],
     "dh_lstm_decode_step": [_c.POINTER(LstmModel), _c.POINTER(LstmScratch), _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P,
                             _I, _P, _P, _I, _P],
     "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _I, _I, _P, _P, _P, _P],
+    "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_token_logprob": [_P, _I, _I, _P, _P, _I, _P],
     "dh_seq_perplexity": [_P, _P, _P, _P, _I, _I, _I, _P],
     "dh_prof_begin": [_c.c_char_p],
@@ -86,7 +86,7 @@ SIGNATURES = {
     "dh_prof_num": [],
     "dh_prof_get": [_I, _c.c_char_p, _I, _c.POINTER(_I), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
                     _c.POINTER(_c.c_double)],
-    "dh_beam_finalize": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _U64, _I, _P],
+    "dh_beam_finalize": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _U64, _P, _I, _P],
 }
 
 
@@ -408,12 +408,12 @@ def lstm_cell(gates, c_cur, h_new, c_new, h_out, ld_out, rows, row_mult, hh):
 
 
 def beam_row_sample(logits, v, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step,
-                    pick_idx, pick_val, err):
+                    pick_idx, pick_val, err, seed_ptr=None):
     _dev(logits, noise, pick_idx, pick_val, err)
     assert logits.dtype == torch.float32
     _launch("dh_beam_row_sample", _ptr(logits), logits.stride(0), v, rows, rows_per_img, beam, top_k,
-                                     float(temperature), unk_index, _ptr(noise), seed, img0, step, _ptr(pick_idx),
-                                     _ptr(pick_val), _ptr(err), _stream())
+                                     float(temperature), unk_index, _ptr(noise), seed, _ptr(seed_ptr), img0, step,
+                                     _ptr(pick_idx), _ptr(pick_val), _ptr(err), _stream())
 
 
 def vocab_logits(a, w, bias, logits, group_max):
@@ -426,29 +426,29 @@ def vocab_logits(a, w, bias, logits, group_max):
 
 
 def beam_row_sample_groups(logits, v, group_max, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed,
-                           img0, step, pick_idx, pick_val, err):
+                           img0, step, pick_idx, pick_val, err, seed_ptr=None):
     _dev(logits, group_max, noise, pick_idx, pick_val, err)
     _launch("dh_beam_row_sample_groups", _ptr(logits), logits.stride(0), v, _ptr(group_max), group_max.stride(0),
             n_groups(v), GROUP_COLS, rows, rows_per_img, beam, top_k, float(temperature), unk_index, _ptr(noise), seed,
-            img0, step, _ptr(pick_idx), _ptr(pick_val), _ptr(err), _stream())
+            _ptr(seed_ptr), img0, step, _ptr(pick_idx), _ptr(pick_val), _ptr(err), _stream())
 
 
 def beam_select(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, n_img, beam, first,
-                first_sets_ended, write_pos, t, step_index, temperature, eos_index, noise, seed, img0):
+                first_sets_ended, write_pos, t, step_index, temperature, eos_index, noise, seed, img0, seed_ptr=None):
     _dev(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, noise)
     _launch("dh_beam_select", _ptr(pick_idx), _ptr(pick_val), _ptr(tokens), tokens.stride(0), _ptr(vals),
                                  _ptr(ended), _ptr(src), src.stride(0) if src is not None else 0, _ptr(parent),
                                  _ptr(hparent), _ptr(done), _ptr(end_step), n_img, beam, int(first),
                                  int(first_sets_ended), write_pos, t, step_index, float(temperature), eos_index,
-                                 _ptr(noise), seed, img0, _stream())
+                                 _ptr(noise), seed, _ptr(seed_ptr), img0, _stream())
 
 
 def beam_finalize(tokens, vals, done, end_step, out, out_len, n_img, beam, len_bias_done, full_len, pad_index,
-                  temperature, noise, seed, img0):
+                  temperature, noise, seed, img0, seed_ptr=None):
     _dev(tokens, vals, done, end_step, out, out_len, noise)
     _launch("dh_beam_finalize", _ptr(tokens), tokens.stride(0), _ptr(vals), _ptr(done), _ptr(end_step),
                                    _ptr(out), out.stride(0), _ptr(out_len), n_img, beam, len_bias_done, full_len,
-                                   pad_index, float(temperature), _ptr(noise), seed, img0, _stream())
+                                   pad_index, float(temperature), _ptr(noise), seed, _ptr(seed_ptr), img0, _stream())
 
 
 GROUP_COLS = 64     # column-group width of dh_vocab_logits' group maxima

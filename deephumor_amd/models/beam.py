@@ -24,7 +24,7 @@ class BeamSearchHelper:
     """
 
     def __init__(self, temperature=1.0, beam_size=10, top_k=50, unk_index=1, eos_index=3, device='cuda',
-                 n_img=1, max_len=25, src_len=0, seed=0, img0=0, noise_source=None):
+                 n_img=1, max_len=25, src_len=0, seed=0, img0=0, noise_source=None, seed_tensor=None):
         assert beam_size <= top_k, '`beam_size` should be less than `top_k`'          # beam.py:9
         if beam_size > hip.MAX_BEAMS:
             raise ValueError(f"beam_size <= {hip.MAX_BEAMS} supported")
@@ -32,6 +32,9 @@ class BeamSearchHelper:
         self.unk_index, self.eos_index, self.device = unk_index, eos_index, device
         self.n_img, self.max_len = n_img, max_len
         self.seed, self.img0, self.noise_source = int(seed), int(img0), noise_source
+        # optional device-resident int64 word XOR-ed into the seed by the kernels: lets a captured hipGraph of the
+        # whole decode be replayed with a fresh seed (kernel arguments are frozen at capture)
+        self.seed_tensor = seed_tensor
         r = n_img * beam_size
         dev = device
         self.tokens = torch.zeros((r, max_len), dtype=torch.int32, device=dev)
@@ -72,30 +75,38 @@ class BeamSearchHelper:
             # bf16 path: the vocabulary GEMM left per-row maxima of every 64-column group (dh_vocab_logits)
             hip.beam_row_sample_groups(logits, v, group_max, rows, rpi, self.beam_size, self.top_k, self.temperature,
                                        self.unk_index, self._noise("row", step_index, (rows, v)), self.seed, self.img0,
-                                       step_index, self.pick_idx, self.pick_val, self.err)
+                                       step_index, self.pick_idx, self.pick_val, self.err, seed_ptr=self.seed_tensor)
         else:
             hip.beam_row_sample(logits, v, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
                                 self._noise("row", step_index, (rows, v)), self.seed, self.img0, step_index,
-                                self.pick_idx, self.pick_val, self.err)
+                                self.pick_idx, self.pick_val, self.err, seed_ptr=self.seed_tensor)
         noise = None if first else self._noise("cand", step_index, (self.n_img, self.beam_size ** 2))
         hip.beam_select(self.pick_idx, self.pick_val, self.tokens, self.vals, self.has_ended, self.src,
                         self.parent, self.hparent, self.done, self.end_step, self.n_img, self.beam_size, first,
                         first_sets_ended, write_pos, t, step_index, self.temperature, self.eos_index, noise,
-                        self.seed, self.img0)
+                        self.seed, self.img0, seed_ptr=self.seed_tensor)
 
-    def finalize(self, len_bias_done, full_len, pad_index=0):
-        """Final draw among the beams and output copy; returns (tokens int64 [n_img, max_len], lengths)."""
+    def finalize(self, len_bias_done, full_len, pad_index=0, defer_check=False):
+        """Final draw among the beams and output copy; returns (tokens int64 [n_img, max_len], lengths).
+        ``defer_check``: skip the host read of the device error word (hipGraph capture) -- the caller checks
+        ``self.err`` after replay."""
         out = torch.empty((self.n_img, self.max_len), dtype=torch.int32, device=self.device)
         out_len = torch.empty((self.n_img,), dtype=torch.int32, device=self.device)
         hip.beam_finalize(self.tokens, self.vals, self.done, self.end_step, out, out_len, self.n_img, self.beam_size,
                           len_bias_done, full_len, pad_index, self.temperature,
-                          self._noise("final", 0, (self.n_img, self.beam_size)), self.seed, self.img0)
+                          self._noise("final", 0, (self.n_img, self.beam_size)), self.seed, self.img0,
+                          seed_ptr=self.seed_tensor)
+        if defer_check:
+            return out.long(), out_len.long(), self.err
         self.check()
         return out.long(), out_len.long()
 
     def check(self):
         """Raises like the reference does when every logit of a row was filtered (beam.py:46)."""
-        code = int(self.err.item())
+        self.raise_for(int(self.err.item()))
+
+    @staticmethod
+    def raise_for(code):
         if code & hip.ERR_ALL_FILTERED:
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0 "
                                "(every logit of a row was filtered: <unk> was the only top-k token)")

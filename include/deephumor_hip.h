@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 4
+#define DH_ABI_VERSION 5
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -187,21 +187,22 @@ int dh_lstm_cell(const float* gates, const float* c_cur, void* h_new, float* c_n
  * p = softmax(filtered / temperature), draw `beam` tokens without replacement as the top-`beam`
  * of p / Exp(1)-noise (== torch.multinomial on CPU), gather, log_softmax over the picks.
  *   logits [rows, ldl] fp32 (read only); pick_idx/pick_val [rows, beam]
- *   noise: NULL -> counter-based Philox noise keyed by (seed, img0+img, step, row, token);
+ *   noise: NULL -> counter-based Philox noise keyed by (seed ^ *seed_ptr, img0+img, step, row, token)
+ *          (seed_ptr: optional device-resident word, so a captured hipGraph can be replayed with new seeds);
  *          else [rows, ldl] fp32 Exp(1) samples supplied by the caller (RNG-replay parity tests)
  *   err: int32 word, DH_BEAM_ERR_* bits are OR-ed in. */
 int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,
                        int top_k, float temperature, int unk_index, const float* noise,
-                       uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
-                       int32_t* err, void* stream);
+                       uint64_t seed, const uint64_t* seed_ptr, int img0, int step, int32_t* pick_idx,
+                       float* pick_val, int32_t* err, void* stream);
 
 /* Same contract as dh_beam_row_sample, guided by the column-group maxima of dh_vocab_logits: the k-th largest
  * group maximum bounds the k-th largest logit from below, so only groups whose maximum reaches it are read. */
 int dh_beam_row_sample_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld,
                               int n_groups, int group_cols, int rows, int rows_per_img, int beam,
                               int top_k, float temperature, int unk_index, const float* noise,
-                              uint64_t seed, int img0, int step, int32_t* pick_idx, float* pick_val,
-                              int32_t* err, void* stream);
+                              uint64_t seed, const uint64_t* seed_ptr, int img0, int step, int32_t* pick_idx,
+                              float* pick_val, int32_t* err, void* stream);
 
 /* Per image: builds the candidate list (a live beam contributes `beam` candidates, an ended beam one
  * with token 0 / score +0), draws `beam` of them without replacement from softmax(cand_val/T),
@@ -221,8 +222,8 @@ int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* toke
                    float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent,
                    int32_t* hparent, uint8_t* done, int32_t* end_step, int n_img, int beam,
                    int first, int first_sets_ended, int write_pos, int t, int step_index,
-                   float temperature, int eos_index, const float* noise, uint64_t seed, int img0,
-                   void* stream);
+                   float temperature, int eos_index, const float* noise, uint64_t seed,
+                   const uint64_t* seed_ptr, int img0, void* stream);
 
 /* Per image: final draw ind ~ softmax(vals/T) (k=1 -> arg-max of p/noise), copies
  * tokens[img*beam+ind, 0..len) to out[img, :] (rest = pad) and writes len, where
@@ -231,7 +232,8 @@ int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* toke
 int dh_beam_finalize(const int32_t* tokens, int tok_ld, const float* vals, const uint8_t* done,
                      const int32_t* end_step, int32_t* out, int out_ld, int32_t* out_len,
                      int n_img, int beam, int len_bias_done, int full_len, int pad_index,
-                     float temperature, const float* noise, uint64_t seed, int img0, void* stream);
+                     float temperature, const float* noise, uint64_t seed, const uint64_t* seed_ptr, int img0,
+                     void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Teacher-forced scoring (deephumor/experiments/metrics.py:4-9; call shape trainer.py:69-81)

@@ -38,7 +38,7 @@ def test_library_builds_loads_and_exports_every_symbol():
     for name in hip.SIGNATURES:
         assert name in protos, f"{name} bound but not declared in include/deephumor_hip.h"
     lib.dh_abi_version.restype = ctypes.c_int
-    assert lib.dh_abi_version() == 4
+    assert lib.dh_abi_version() == 5
     lib.dh_error_string.restype = ctypes.c_char_p
     assert lib.dh_error_string(1).startswith(b"bad argument")
 
@@ -50,4 +50,4 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.dh_linear(None, 0, None, 0, None, None, None, None, 0, None, 0, 4, 4, 4, 0, hip.F32, None) == 1
     assert lib.dh_maxpool3x3s2(None, None, 1, 1, 4, 4, 7, None) == 2
     assert lib.dh_conv2d_bn_act(None, None, None, None, None, None, 1, 3, 8, 8, 8, 5, 5, 1, 0, 1, hip.F32, None) == 1
-    assert lib.dh_beam_row_sample(None, 0, 10, 1, 1, 3, 2, 1.0, 1, None, 0, 0, 0, None, None, None, None) == 1
+    assert lib.dh_beam_row_sample(None, 0, 10, 1, 1, 3, 2, 1.0, 1, None, 0, None, 0, 0, None, None, None, None) == 1

@@ -28,7 +28,7 @@ def images():
 def test_native_library_is_loaded():
     from deephumor_amd import hip
     lib = hip.load()
-    assert lib.dh_abi_version() == 4
+    assert lib.dh_abi_version() == 5
     with open("/proc/self/maps") as f:
         assert "libdeephumor_hip.so" in f.read()
 
@@ -202,3 +202,16 @@ def test_cpu_tensors_fail_loudly():
     model, _, _ = build("CaptioningLSTM")
     with pytest.raises(RuntimeError, match="no CPU"):
         model.cpu()(synth_images(1), torch.zeros(1, 4, dtype=torch.long))
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_hipgraph_replay_equals_eager(kind, images):
+    """The captured graph, replayed with other images and other seeds, gives exactly the eager captions."""
+    model, _, _ = build(kind)
+    kw = dict(max_len=10, beam_size=3, top_k=20, temperature=1.2)
+    with torch.no_grad():
+        for seed, imgs in ((5, images), (9, images.flip(0)), (5, images)):
+            want_t, want_l = model.generate_batch(imgs.cuda(), seed=seed, **kw)
+            got_t, got_l = model.generate_batch_graphed(imgs.cuda(), seed=seed, **kw)
+            assert got_t.tolist() == want_t.tolist() and got_l.tolist() == want_l.tolist()
+    assert len(model._graphs) == 1
