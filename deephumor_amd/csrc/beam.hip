@@ -437,29 +437,36 @@ __global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
     const int img = blockIdx.x, lane = threadIdx.x, B = p.beam, base = img * B;
     if (p.done[img]) return;
 
-    if (lane == 0) {
-        int c = 0;
-        if (p.first) {
-            for (int j = 0; j < B; ++j, ++c) {
-                const int tok = p.pick_idx[(size_t)img * B + j];
-                ctok[c] = tok; cval[c] = p.pick_val[(size_t)img * B + j]; cpar[c] = 0;
-                cend[c] = (uint8_t)(p.first_sets_ended && tok == p.eos);
-                keep[j] = j;
-            }
-        } else {
-            for (int b = 0; b < B; ++b) {
-                const bool was = p.ended[base + b] != 0;
-                const float v0 = p.vals[base + b];
-                for (int j = 0; j < (was ? 1 : B); ++j, ++c) {
-                    const int tok = was ? 0 : p.pick_idx[(size_t)(base + b) * B + j];
-                    ctok[c] = tok;
-                    cval[c] = v0 + (was ? 0.f : p.pick_val[(size_t)(base + b) * B + j]);
-                    cpar[c] = b;
-                    cend[c] = (uint8_t)(was || tok == p.eos);
-                }
-            }
+    // candidate list in the reference's order: beam b contributes 1 candidate if it has ended, else B.
+    // Every lane derives the (short) offset table itself; candidates are then filled in parallel.
+    if (p.first) {
+        for (int j = lane; j < B; j += 64) {
+            const int tok = p.pick_idx[(size_t)img * B + j];
+            ctok[j] = tok; cval[j] = p.pick_val[(size_t)img * B + j]; cpar[j] = 0;
+            cend[j] = (uint8_t)(p.first_sets_ended && tok == p.eos);
+            keep[j] = j;
         }
-        s_n = c;
+        if (lane == 0) s_n = B;
+    } else {
+        int off[DH_BEAM_MAX_BEAMS + 1];
+        off[0] = 0;
+#pragma unroll
+        for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b)
+            off[b + 1] = off[b] + (b < B ? (p.ended[base + b] ? 1 : B) : 0);
+        const int total = off[B];
+        for (int c = lane; c < total; c += 64) {
+            int b = 0;
+#pragma unroll
+            for (int k = 1; k < DH_BEAM_MAX_BEAMS; ++k) b += (k < B && c >= off[k]);
+            const int j = c - off[b];
+            const bool was = p.ended[base + b] != 0;
+            const int tok = was ? 0 : p.pick_idx[(size_t)(base + b) * B + j];
+            ctok[c] = tok;
+            cval[c] = p.vals[base + b] + (was ? 0.f : p.pick_val[(size_t)(base + b) * B + j]);
+            cpar[c] = b;
+            cend[c] = (uint8_t)(was || tok == p.eos);
+        }
+        if (lane == 0) s_n = total;
     }
     __syncthreads();
     const int n = s_n;

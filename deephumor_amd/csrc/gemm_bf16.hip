@@ -236,6 +236,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         // fp32 output (logits; leading dimension may be odd): lane <-> consecutive column, so every wave
         // store is one contiguous run of up to 256 B of a row whatever its alignment
         float* Cf = reinterpret_cast<float*>(p.C);
+        if ((p.ldc & 3) == 0 && ((uintptr_t)Cf & 15) == 0 && !p.res) {
+            // row stride a multiple of 4 floats (the decoders pad the logits rows that way): one 16-byte LDS
+            // read + one 16-byte global store per 4 columns, a wave writes whole 512-B row segments
+            for (int e = tid; e < BM * SLOTS; e += NT) {
+                const int row = e / SLOTS, slot = e - row * SLOTS;
+                const int m = m0 + row, n = n0 + slot * 4;
+                if (m >= p.M || n >= p.N) continue;
+                float4 v = *reinterpret_cast<const float4*>(ep + row * BN + ((slot ^ (row & (SLOTS - 1))) << 2));
+                if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (n + 4 <= p.N) *reinterpret_cast<float4*>(Cf + (size_t)m * p.ldc + n) = v;
+                else {      // last, partial group of the row (static indexing: no scratch)
+                    float* dst = Cf + (size_t)m * p.ldc + n;
+                    dst[0] = v.x;
+                    if (n + 1 < p.N) dst[1] = v.y;
+                    if (n + 2 < p.N) dst[2] = v.z;
+                }
+            }
+            return;
+        }
         for (int e = tid; e < BM * BN; e += NT) {
             const int row = e / BN, col = e - row * BN;
             const int m = m0 + row, n = n0 + col;

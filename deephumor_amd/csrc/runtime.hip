@@ -12,8 +12,8 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
                                               const void* start_emb, const int32_t* tokens, int tok_ld,
                                               const int32_t* src, int src_ld, int n_img, int rows_per_img,
                                               int row_mult, int rows_total, int t, void* x_out, float* logits,
-                                              float* group_max, int gm_ld, void* stream) {
-    DH_REQUIRE(m && sc && m->layers && n_img > 0 && rows_per_img > 0 && t >= 0);
+                                              int ldl, float* group_max, int gm_ld, void* stream) {
+    DH_REQUIRE(m && sc && m->layers && n_img > 0 && rows_per_img > 0 && t >= 0 && (!logits || ldl >= m->V));
     const int rows = n_img * rows_per_img, D = m->D, dt = m->dtype;
     const size_t esz = dt == DH_F32 ? 4 : 2;
     DH_TRY(dh_embed_rows(m->tok_emb, m->pos_emb, start_emb, tokens, tok_ld, sc->x, rows, rows_per_img, row_mult, t,
@@ -45,11 +45,11 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
     }
     (void)esz;
     if (logits && group_max && dt == DH_BF16) {
-        DH_TRY(dh_vocab_logits(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, logits, m->V, group_max, gm_ld, rows, m->V, D,
+        DH_TRY(dh_vocab_logits(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, D,
                                dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
-        DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, m->V, rows,
+        DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows,
                          m->V, D, 0, dt == DH_F32 ? DH_F32 : DH_BF16_OUT_F32, stream));
     }
     return DH_OK;
@@ -58,8 +58,8 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
 extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, const void* img_emb,
                                    const int32_t* tokens, int tok_ld, int tok_pos, const int32_t* hparent,
                                    int started, int rows, int rows_per_img, int row_mult, int rows_total,
-                                   void* h_out, int ld_out, float* logits, float* group_max, int gm_ld, void* stream) {
-    DH_REQUIRE(m && sc && m->layers && rows > 0 && rows_per_img > 0 && row_mult > 0);
+                                   void* h_out, int ld_out, float* logits, int ldl, float* group_max, int gm_ld, void* stream) {
+    DH_REQUIRE(m && sc && m->layers && rows > 0 && rows_per_img > 0 && row_mult > 0 && (!logits || ldl >= m->V));
     const int E = m->E, Hh = m->Hh, dt = m->dtype, nl = m->n_layers;
     const size_t esz = dt == DH_F32 ? 4 : 2;
     DH_TRY(dh_lstm_prepare(m->emb, img_emb, tokens, tok_ld, tok_pos, hparent, started ? m->h : nullptr,
@@ -80,10 +80,10 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
                             m->c + (size_t)l * rows_total * Hh, dst, ld, rows, row_mult, Hh, dt, stream));
     }
     if (logits && group_max && dt == DH_BF16) {
-        DH_TRY(dh_vocab_logits(top, top_ld, m->cls_w, Hh, m->cls_b, logits, m->V, group_max, gm_ld, rows, m->V, Hh, dt, stream));
+        DH_TRY(dh_vocab_logits(top, top_ld, m->cls_w, Hh, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
-        DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, m->V, rows, m->V, Hh, 0,
+        DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,
                          gate_dt, stream));
     }
     return DH_OK;

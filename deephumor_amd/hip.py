@@ -73,9 +73,9 @@ SIGNATURES = {
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
                        _U64, _P, _I, _P],
     "dh_transformer_decode_position": [_c.POINTER(TrModel), _c.POINTER(TrScratch), _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
-                                       _P, _P, _P, _I, _P],
+                                       _P, _P, _I, _P, _I, _P],
     "dh_lstm_decode_step": [_c.POINTER(LstmModel), _c.POINTER(LstmScratch), _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P,
-                            _I, _P, _P, _I, _P],
+                            _I, _P, _I, _P, _I, _P],
     "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_token_logprob": [_P, _I, _I, _P, _P, _I, _P],
@@ -462,7 +462,8 @@ def transformer_decode_position(model, scratch, start_emb, tokens, src, n_img, r
                                 x_out=None, logits=None, group_max=None):
     _launch("dh_transformer_decode_position", _c.byref(model), _c.byref(scratch), _ptr(start_emb), _ptr(tokens),
             tokens.stride(0), _ptr(src), src.stride(0), n_img, rows_per_img, row_mult, rows_total, t, _ptr(x_out),
-            _ptr(logits), _ptr(group_max), group_max.stride(0) if group_max is not None else 0, _stream())
+            _ptr(logits), logits.stride(0) if logits is not None else 0, _ptr(group_max),
+            group_max.stride(0) if group_max is not None else 0, _stream())
 
 
 def lstm_decode_step(model, scratch, img_emb, tokens, tok_pos, hparent, started, rows, rows_per_img, row_mult,
@@ -470,7 +471,8 @@ def lstm_decode_step(model, scratch, img_emb, tokens, tok_pos, hparent, started,
     _launch("dh_lstm_decode_step", _c.byref(model), _c.byref(scratch), _ptr(img_emb), _ptr(tokens),
             tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(hparent), int(started), rows, rows_per_img,
             row_mult, rows_total, _ptr(h_out), h_out.stride(0) if h_out is not None else 0, _ptr(logits),
-            _ptr(group_max), group_max.stride(0) if group_max is not None else 0, _stream())
+            logits.stride(0) if logits is not None else 0, _ptr(group_max),
+            group_max.stride(0) if group_max is not None else 0, _stream())
 
 
 def token_logprob(logits, targets):

@@ -58,11 +58,18 @@ class BeamSearchHelper:
         p = caption.shape[1]
         self.tokens[:, :p] = caption.to(torch.int32).repeat_interleave(self.beam_size, dim=0)
 
-    def _noise(self, kind, step, shape):
+    def _noise(self, kind, step, shape, ld=None):
         if self.noise_source is None:
             return None
         t = self.noise_source(kind, step, shape)
-        return None if t is None else t.to(device=self.device, dtype=torch.float32).contiguous()
+        if t is None:
+            return None
+        t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if ld is not None and ld != t.shape[1]:          # row noise is indexed with the logits' (padded) row stride
+            buf = torch.ones((t.shape[0], ld), dtype=torch.float32, device=self.device)
+            buf[:, :t.shape[1]] = t
+            t = buf
+        return t
 
     def step(self, logits, first, write_pos, t, step_index, first_sets_ended=False, group_max=None):
         """One beam step from ``logits`` ([n_img, V] if ``first`` else [n_img*beam, V]):
@@ -74,11 +81,11 @@ class BeamSearchHelper:
         if group_max is not None and self.top_k <= hip.n_groups(v):   # k group maxima bound the k-th logit
             # bf16 path: the vocabulary GEMM left per-row maxima of every 64-column group (dh_vocab_logits)
             hip.beam_row_sample_groups(logits, v, group_max, rows, rpi, self.beam_size, self.top_k, self.temperature,
-                                       self.unk_index, self._noise("row", step_index, (rows, v)), self.seed, self.img0,
+                                       self.unk_index, self._noise("row", step_index, (rows, v), logits.stride(0)), self.seed, self.img0,
                                        step_index, self.pick_idx, self.pick_val, self.err, seed_ptr=self.seed_tensor)
         else:
             hip.beam_row_sample(logits, v, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
-                                self._noise("row", step_index, (rows, v)), self.seed, self.img0, step_index,
+                                self._noise("row", step_index, (rows, v), logits.stride(0)), self.seed, self.img0, step_index,
                                 self.pick_idx, self.pick_val, self.err, seed_ptr=self.seed_tensor)
         noise = None if first else self._noise("cand", step_index, (self.n_img, self.beam_size ** 2))
         hip.beam_select(self.pick_idx, self.pick_val, self.tokens, self.vals, self.has_ended, self.src,

@@ -137,7 +137,8 @@ class LSTMDecoder(nn.Module, _Planned):
                 pos = caption.shape[1]
                 helper.set_prefix(caption[lo:hi])
             st = self._State(self, plan, n, b, dev)
-            logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
+            # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
+            logits = torch.empty((r, (self.num_tokens + 63) // 64 * 64), device=dev)[:, :self.num_tokens]
             gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
                     if plan["dtype"] == torch.bfloat16 else None)                    # column-group maxima (bf16 path)
             gm = None if gmax is None else gmax[:n]

@@ -244,7 +244,8 @@ class _IncrementalDecoder(nn.Module, _Planned):
                 helper.set_prefix(caption[lo:hi])
             run = self._Run(self, plan, n, b, max_len + 1, None if enc_out is None else enc_out[lo:hi], dev)
             semb = start_emb[lo:hi]
-            logits = torch.empty((r, self.num_tokens), device=dev)                  # logits always fp32
+            # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
+            logits = torch.empty((r, (self.num_tokens + 63) // 64 * 64), device=dev)[:, :self.num_tokens]
             gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
                     if plan["dtype"] == torch.bfloat16 else None)                    # column-group maxima (bf16 path)
             gm = None if gmax is None else gmax[:n]

@@ -275,12 +275,12 @@ typedef struct dh_tr_model {
 typedef struct dh_tr_scratch { void *x, *qkv, *att, *o, *q, *ff; } dh_tr_scratch_t;   /* [rows, D|3D|D|D|D|PF] */
 
 /* Hidden state of position t for n_img*rows_per_img compact rows; x_out (optional, [rows,D]) receives the
- * last layer's output instead of scratch->x; logits (optional, fp32 [rows,V]) = classifier(x); with
+ * last layer's output instead of scratch->x; logits (optional, fp32 [rows,V], row stride ldl) = classifier(x); with
  * group_max != NULL (bf16 only) the classifier is dh_vocab_logits. */
 int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_tr_scratch_t* sc,
                                    const void* start_emb, const int32_t* tokens, int tok_ld,
                                    const int32_t* src, int src_ld, int n_img, int rows_per_img,
-                                   int row_mult, int rows_total, int t, void* x_out, float* logits,
+                                   int row_mult, int rows_total, int t, void* x_out, float* logits, int ldl,
                                    float* group_max, int gm_ld, void* stream);
 
 typedef struct dh_lstm_layer { const void* w; const float* b; } dh_lstm_layer_t;   /* [4Hh, in+Hh] = [W_ih|W_hh], b_ih+b_hh */
@@ -302,7 +302,8 @@ typedef struct dh_lstm_scratch { void *xcat0, *xcatl; float *c_cur, *gates; void
 int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, const void* img_emb,
                         const int32_t* tokens, int tok_ld, int tok_pos, const int32_t* hparent,
                         int started, int rows, int rows_per_img, int row_mult, int rows_total,
-                        void* h_out, int ld_out, float* logits, float* group_max, int gm_ld, void* stream);
+                        void* h_out, int ld_out, float* logits, int ldl, float* group_max, int gm_ld,
+                        void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Launch profiler (measurement infrastructure, not on the data path): while enabled, every launch made
