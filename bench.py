@@ -119,11 +119,22 @@ def roofline_from(summary, prefer=None, dtype="bf16"):
         return {"kernel": key, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                 "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
                 "algorithmic_bytes_per_launch": d["bytes"] / d["calls"]}
-    ach = d["flops"] / d["calls"] / sec / 1e12
     peak = PEAK_F32_TFLOPS if (dtype == "f32" or key.startswith("dh_stem")) else PEAK_BF16_TFLOPS
+    # the roofline that bounds these launches: algorithmic intensity (flop per algorithmic byte) against the
+    # ridge peak_flops / peak_bytes -- e.g. the 1x1 convolutions with K <= 256 are HBM-bound, not MFMA-bound
+    intensity = d["flops"] / d["bytes"] if d["bytes"] else float("inf")
+    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if intensity < ridge:
+        ach = d["bytes"] / d["calls"] / sec / 1e9
+        return {"kernel": key, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
+                "algorithmic_bytes_per_launch": d["bytes"] / d["calls"],
+                "algorithmic_flops_per_launch": d["flops"] / d["calls"], "flop_per_byte": intensity,
+                "tflops": d["flops"] / d["calls"] / sec / 1e12}
+    ach = d["flops"] / d["calls"] / sec / 1e12
     return {"kernel": key, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
             "frac": ach / peak, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
-            "algorithmic_flops_per_launch": d["flops"] / d["calls"]}
+            "algorithmic_flops_per_launch": d["flops"] / d["calls"], "flop_per_byte": intensity}
 
 
 def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtype="bf16", main_line=True):
