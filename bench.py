@@ -42,7 +42,7 @@ _SD_CACHE = {}
 def build_model(workload, dev, dtype="bf16"):
     import deephumor_amd.models as M
     from deephumor_amd.synth import synth_state_dict
-    cls = M.CaptioningLSTM if workload == "c2" else M.CaptioningTransformer
+    cls = {"c2": M.CaptioningLSTM, "c3": M.CaptioningTransformer, "c5": M.CaptioningTransformerWithLabels}[workload]
     model = cls(V_WORD).eval()
     if workload not in _SD_CACHE:
         _SD_CACHE[workload] = synth_state_dict(model.state_dict(), seed=1234)
@@ -54,8 +54,12 @@ def build_model(workload, dev, dtype="bf16"):
     return model, sd, model._hp
 
 
-def one_step(model, images, img0, n_total, seed, eager=False):
+def one_step(model, images, img0, n_total, seed, eager=False, labels=None, beam=None):
     from deephumor_amd.dist import gather_captions
+    if labels is not None:      # config C5: ImageLabelEncoder (+ spatial features) + CaptioningTransformer, beam 10
+        toks, lens = model.generate_batch(images, labels, max_len=MAX_LEN, beam_size=beam, top_k=TOP_K, temperature=TEMP,
+                                          seed=seed, img0=img0)
+        return gather_captions(toks, lens, n_total)
     if GRAPH and not eager:      # whole step replayed from a captured hipGraph (profiling passes run eagerly: events need real launches)
         toks, lens = model.generate_batch_graphed(images, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP,
                                                   seed=seed, img0=img0)
@@ -66,7 +70,42 @@ def one_step(model, images, img0, n_total, seed, eager=False):
 
 
 def kind_of(workload):
-    return "CaptioningLSTM" if workload == "c2" else "CaptioningTransformer"
+    return {"c2": "CaptioningLSTM", "c3": "CaptioningTransformer", "c5": "CaptioningTransformerWithLabels"}[workload]
+
+
+def run_c5(args, rank, world, dev, dtype):
+    """BASELINE config 5: the full 300-template sweep (ImageLabelEncoder + CaptioningTransformer, beam 10), templates
+    sharded 38/38/38/38/37/37/37/37 over 8 ranks (all 300 on one), uneven shards gathered with one padded all_gather."""
+    import torch.distributed as dist
+    from deephumor_amd.dist import shard_range
+    from deephumor_amd.synth import synth_images
+    import numpy as np
+    model, sd, hp = build_model("c5", dev, dtype)
+    n_total = 300
+    lo, hi = shard_range(n_total, rank, world)
+    images = synth_images(hi - lo, seed=2, first=lo).to(dev)
+    g = np.random.Generator(np.random.Philox(key=[1, 0]))
+    labels = torch.from_numpy(g.integers(6, V_WORD, size=(n_total, 3)).astype(np.int64))[lo:hi].to(dev)
+    with torch.no_grad():
+        one_step(model, images, lo, n_total, 0, labels=labels, beam=10)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        reps = max(1, args.steps)
+        for s in range(reps):
+            toks, lens = one_step(model, images, lo, n_total, 100 + s, labels=labels, beam=10)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    return {"workload": "C5 ImageLabelEncoder + CaptioningTransformer (spatial feats), beam=10, 300-template sweep",
+            "value": n_total * reps / dt, "unit": "captions/s", "sweeps": reps, "ms_per_sweep": dt / reps * 1e3,
+            "templates": n_total, "gathered": int(toks.shape[0]), "dtype": dtype}
 
 
 def cpu_baseline(workload, sd, hp, n_sample):
@@ -235,7 +274,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE configs: 256)")
-    ap.add_argument("--workload", choices=["c2", "c3", "both"], default="both")
+    ap.add_argument("--workload", choices=["c2", "c3", "both", "c5"], default="both")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images for the CPU baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (eager by default: "
@@ -259,6 +298,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload == "c5":
+        res = run_c5(args, rank, world, dev, args.dtype)
+        if rank == 0:
+            print(json.dumps(dict(res, metric="captions/sec (224x224, 32-tok, beam=10, 300-template sweep)", n_gpus=world,
+                                  higher_is_better=True, scaling="strong", vs_baseline=None, data="synthetic")))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     main_wl = "c2" if args.workload in ("c2", "both") else "c3"
     with_cpu = (world == 1) and not args.no_cpu
     res = run_workload(main_wl, args, rank, world, dev, args.steps, args.warmup, with_cpu, args.dtype)
