@@ -117,6 +117,15 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         b_base[i] = p.W + (size_t)(b_ok[i] ? n : 0) * p.ldw;
     }
 
+    // conv loader, Cin % 64 == 0 (every bottleneck conv): a 64-wide k slab lies inside ONE filter tap, so the tap
+    // (kh, kw) and its first channel are wave-uniform and advance incrementally with the slabs (stage() is called
+    // with k0 = 0, 64, 128, ... in order) -- no per-lane integer divisions in the loop
+    const bool tap_uniform = CONV && (p.Cin & 63) == 0;
+    int st_kh = 0, st_kw = 0, st_ci = 0, st_off = 0;
+    const uint16_t* a_pix[IA];
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+        a_pix[i] = CONV ? a_base[i] + ((ptrdiff_t)a_ih0[i] * p.Wd + a_iw0[i]) * p.Cin + a_swz[i] * 8 : nullptr;
     auto stage = [&](int buf, int k0) {
         unsigned char* slab = lds + __builtin_amdgcn_readfirstlane(buf) * SLAB;
 #pragma unroll
@@ -125,15 +134,26 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             const void* src = zero;
             if (a_ok[i] && k < p.K) {
                 if (CONV) {
-                    const int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.KS, kw = tap - kh * p.KS;
-                    const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
-                        src = a_base[i] + ((size_t)ih * p.Wd + iw) * p.Cin + ci;
+                    if (tap_uniform) {
+                        // a_pix = address of (pixel of tap (0,0), this lane's chunk); the tap offset is wave-uniform
+                        if ((unsigned)(a_ih0[i] + st_kh) < (unsigned)p.H && (unsigned)(a_iw0[i] + st_kw) < (unsigned)p.Wd)
+                            src = a_pix[i] + st_off;
+                    } else {
+                        const int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.KS, kw = tap - kh * p.KS;
+                        const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
+                            src = a_base[i] + ((size_t)ih * p.Wd + iw) * p.Cin + ci;
+                    }
                 } else {
                     src = a_base[i] + k;
                 }
             }
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+        }
+        if (tap_uniform) {
+            st_ci += BK;
+            if (st_ci == p.Cin) { st_ci = 0; if (++st_kw == p.KS) { st_kw = 0; ++st_kh; } }
+            st_off = (st_kh * p.Wd + st_kw) * p.Cin + st_ci;
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
