@@ -36,7 +36,7 @@ struct GemmBf16Params {
     void* C; int ldc;
     int M, N, K, relu, out_f32;
     int conv, H, Wd, Cin, Ho, Wo, KS, stride, pad;     // conv loader: A = NHWC input
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, n_fast;                      // n_fast: consecutive workgroups walk the N tiles of one M tile
     float* gmax; int gmax_ld;                          // optional: per-row maxima of each wave-wide column group
 };
 
@@ -79,7 +79,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
+    // tile order: by default consecutive workgroups share a weight panel (tn) and walk over M; with a small weight
+    // matrix (L2-resident anyway) they share the activation tile instead, so it is fetched from HBM once, not tiles_n times
+    const int tm = p.n_fast ? bid / p.tiles_n : bid % p.tiles_m, tn = p.n_fast ? bid % p.tiles_n : bid / p.tiles_m;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -170,6 +172,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int l15 = lane & 15, lq = lane >> 4;
+    // per-column epilogue constants, requested BEFORE the first slab so their latency hides behind the operand
+    // loads (a K = 64 convolution has a single slab): out = (acc + bias) * mul + add with
+    //   scale given: mul = scale, add = shift (bias, if any, is fetched late -- only the tiny BatchNorm1d linear has both)
+    //   otherwise  : mul = 1,     add = bias
+    float mulv[TN][4], addv[TN][4];
+    const float* addp = p.scale ? p.shift : p.bias;
+    const bool vec = (p.N & 3) == 0 && ((((uintptr_t)p.scale) | ((uintptr_t)addp)) & 15) == 0;
+    if (vec) {                        // 16-byte loads up front; an odd N (vocabulary) takes 4-byte loads after the loop
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + 16 * j + 4 * lq;
+            const bool ok = n < p.N;
+            const float4 one = make_float4(1.f, 1.f, 1.f, 1.f), zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 mv = (ok && p.scale) ? *reinterpret_cast<const float4*>(p.scale + n) : one;
+            const float4 av = (ok && addp) ? *reinterpret_cast<const float4*>(addp + n) : zero4;
+            mulv[j][0] = mv.x; mulv[j][1] = mv.y; mulv[j][2] = mv.z; mulv[j][3] = mv.w;
+            addv[j][0] = av.x; addv[j][1] = av.y; addv[j][2] = av.z; addv[j][3] = av.w;
+        }
+    }
     const int nslab = (p.K + BK - 1) / BK;
     // prologue: NS-1 slabs in flight
 #pragma unroll
@@ -207,17 +228,26 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
     __syncthreads();                                      // all slabs consumed: LDS is free for the epilogue
 
     // ---- epilogue: acc[j][i][r] = C[m = m0+wm0+16i+(lane&15)][n = n0+wn0+16j+4*(lane>>4)+r] --------------
-    float bv[TN][4], sc[TN][4], sh[TN][4];
+    if (!vec) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wn0 + 16 * j + 4 * lq + r;
-            const bool ok = n < p.N;
-            bv[j][r] = (ok && p.bias) ? p.bias[n] : 0.f;
-            sc[j][r] = (ok && p.scale) ? p.scale[n] : 1.f;
-            sh[j][r] = (ok && p.scale) ? p.shift[n] : 0.f;
-        }
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn0 + 16 * j + 4 * lq + r;
+                const bool ok = n < p.N;
+                mulv[j][r] = (ok && p.scale) ? p.scale[n] : 1.f;
+                addv[j][r] = (ok && addp) ? addp[n] : 0.f;
+            }
+    }
+    if (p.bias && p.scale) {                              // rare: bias AND BatchNorm affine -> fold the bias into add
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn0 + 16 * j + 4 * lq + r;
+                if (n < p.N) addv[j][r] = fmaf(p.bias[n], mulv[j][r], addv[j][r]);
+            }
+    }
     if (p.gmax) {
         // maximum of this wave's WN consecutive output columns for each of its rows (beam-search pre-filter)
 #pragma unroll
@@ -227,7 +257,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (n0 + wn0 + 16 * j + 4 * lq + r < p.N) mxv = fmaxf(mxv, (acc[j][i][r] + bv[j][r]) * sc[j][r] + sh[j][r]);
+                    if (n0 + wn0 + 16 * j + 4 * lq + r < p.N) mxv = fmaxf(mxv, fmaf(acc[j][i][r], mulv[j][r], addv[j][r]));
             mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
             mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
             const int m = m0 + wm0 + 16 * i + l15;
@@ -244,10 +274,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         for (int j = 0; j < TN; ++j) {
             const int row = wm0 + 16 * i + l15, slot = (wn0 + 16 * j) / 4 + lq;
             float4 v;
-            v.x = (acc[j][i][0] + bv[j][0]) * sc[j][0] + sh[j][0];
-            v.y = (acc[j][i][1] + bv[j][1]) * sc[j][1] + sh[j][1];
-            v.z = (acc[j][i][2] + bv[j][2]) * sc[j][2] + sh[j][2];
-            v.w = (acc[j][i][3] + bv[j][3]) * sc[j][3] + sh[j][3];
+            v.x = fmaf(acc[j][i][0], mulv[j][0], addv[j][0]);
+            v.y = fmaf(acc[j][i][1], mulv[j][1], addv[j][1]);
+            v.z = fmaf(acc[j][i][2], mulv[j][2], addv[j][2]);
+            v.w = fmaf(acc[j][i][3], mulv[j][3], addv[j][3]);
             *reinterpret_cast<float4*>(ep + row * BN + ((slot ^ (row & (SLOTS - 1))) << 2)) = v;
         }
     __syncthreads();
@@ -321,6 +351,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
 
 template <bool CONV>
 static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
+    {   // measured on the ResNet-50 layers at 256 images: 4.63 -> 4.45 ms over all bottleneck convolutions
+        const double w_bytes = 2.0 * p.N * p.K, a_bytes = 2.0 * p.M * (CONV ? p.Cin : p.K);
+        p.n_fast = w_bytes <= 8.0 * 1024 * 1024 && a_bytes > w_bytes;
+    }
+    // (K <= 128 layers: 64 x 64, 128 x 64 and 64 x 128 tiles were all slower than 128 x 128: 245 / 204 / 205 vs 175 us)
     const long long big_tiles = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
     // >= 192 big tiles (measured: lowering the threshold to 128/100/40 tiles does not help gates / ffn / qkv / proj)
     if (big_tiles >= 192 && p.M >= 96 && p.N >= 96) {
@@ -332,10 +367,15 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
         return;
     }
     if (p.N <= 64 && p.M >= 256 * 512) {
-        // narrow outputs with very many rows (stage-1 convolutions): 256 x 64 tiles, 4 waves stacked along M, so the
-        // 64 weight rows are staged once per 256 pixels and every wave still owns a 64 x 64 accumulator
+        // narrow outputs with very many rows (stage-1 convolutions): 3x3 -> 256 x 64 tiles on 8 waves (the 64 weight
+        // rows are staged once per 256 pixels; measured 127 us vs 146 us with 4 waves, 135 us with 128 x 64 tiles)
         p.tiles_m = dh_cdiv(p.M, 256); p.tiles_n = dh_cdiv(p.N, 64);
-        hipLaunchKernelGGL((gemm_bf16_kernel<256, 64, 4, CONV, 2>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        if (CONV) {
+            hipLaunchKernelGGL((gemm_bf16_kernel<256, 64, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
+        } else {    // dense 1x1 (HBM-bound, ~5 TB/s): smaller tiles, 3 workgroups per CU
+            p.tiles_m = dh_cdiv(p.M, 128);
+            hipLaunchKernelGGL((gemm_bf16_kernel<128, 64, 2, CONV, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+        }
         return;
     }
     p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
@@ -385,6 +425,208 @@ extern "C" int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* 
     DH_LAUNCH_CHECK();
 }
 
+// ---- persistent vocabulary-projection kernel ---------------------------------------------------------------
+// The classifier GEMM is short in K (K = hidden size = 512: 8 slabs per 128 x 128 tile), so a one-tile-per-workgroup
+// kernel spends about half of its time filling the ring and draining the epilogue.  Here a workgroup walks a
+// sequence of tiles and the LDS ring never drains: the slab loads of tile i+1 are in flight during the last
+// MFMAs and the epilogue of tile i.  The epilogue needs no LDS -- an accumulator quad is 4 consecutive logits of
+// one row, stored straight from registers as 16-byte stores (a wave covers 256 contiguous bytes of 16 rows over
+// its 4 column blocks) -- so there is no barrier between the last MFMA of a tile and the first of the next.
+// vmcnt bookkeeping (MI355X_MICROARCH: loads, stores and LDS-DMA retire in issue order): the wait for slab g
+// allows the stores of the previous tile's epilogue to stay outstanding when that tile was interior (then their
+// number is fixed: TM*TN logits stores + TM group-max stores); after an edge tile it waits for everything.
+struct VocabParams {
+    const uint16_t* A; int lda;
+    const uint16_t* W; int ldw;
+    const float* bias;
+    float* C; int ldc;
+    float* gmax; int gmax_ld;
+    int M, N, K, tiles_m, tiles_n;
+};
+
+#define DH_VMCNT_CASE(x) case x: asm volatile("s_waitcnt vmcnt(" #x ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vmcnt_any(int n) {
+    switch (n) {
+        DH_VMCNT_CASE(1) DH_VMCNT_CASE(2) DH_VMCNT_CASE(3) DH_VMCNT_CASE(4) DH_VMCNT_CASE(5) DH_VMCNT_CASE(6)
+        DH_VMCNT_CASE(7) DH_VMCNT_CASE(8) DH_VMCNT_CASE(9) DH_VMCNT_CASE(10) DH_VMCNT_CASE(11) DH_VMCNT_CASE(12)
+        DH_VMCNT_CASE(13) DH_VMCNT_CASE(14) DH_VMCNT_CASE(15) DH_VMCNT_CASE(16) DH_VMCNT_CASE(17) DH_VMCNT_CASE(18)
+        DH_VMCNT_CASE(19) DH_VMCNT_CASE(20) DH_VMCNT_CASE(21) DH_VMCNT_CASE(22) DH_VMCNT_CASE(23) DH_VMCNT_CASE(24)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+template <int NS, int BM, int NW>
+__global__ __launch_bounds__(64 * NW, (NS * (BM + 128) * 128 <= 72 * 1024 ? 2 : 1)) void vocab_logits_kernel(VocabParams p) {
+    constexpr int BN = 128, BK = 64, WAVES_M = BM / 32;
+    constexpr int A_BYTES = BM * 128, SLAB = A_BYTES + BN * 128;
+    constexpr int WM = BM / WAVES_M, WN = BN / (NW / WAVES_M);      // 32 x 64 per wave
+    constexpr int TM = WM / 16, TN = WN / 16;
+    constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW), G = IA + IB;
+    constexpr int N_STORE = TM * TN + TM;                          // stores of one interior-tile epilogue, per wave
+    static_assert((NS - 2) * G + N_STORE + 1 <= 24, "vmcnt switch range");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * SLAB + NW * 256];
+    unsigned char* bias_lds = lds + NS * SLAB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 256;   // wave-private
+
+    // this workgroup's tiles: XCD x (= blockIdx % 8) owns one contiguous range of tile ids (tm fastest: the 10 M tiles
+    // of a classifier-weight panel are neighbours in time on one L2); its workgroups interleave over that range
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int nbx = ((int)gridDim.x - xcd + 7) >> 3;
+    const int q = ntiles / 8, r = ntiles % 8;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int count = q + (xcd < r ? 1 : 0);
+    const int my_tiles = idx < count ? (count - idx + nbx - 1) / nbx : 0;
+    if (my_tiles == 0) return;
+    const int nslab = (p.K + BK - 1) / BK, total = my_tiles * nslab;       // host guarantees nslab >= NS
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave % WAVES_M) * WM, wn0 = (wave / WAVES_M) * WN;
+    const int lr = lane >> 3, lpos = lane & 7, swz = lpos ^ lr;   // loader: row in the 8-row group, source chunk
+    const int l15 = lane & 15, lq = lane >> 4;
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(dh_zero_page);
+
+    // ---- loader state: the tile whose slabs are being staged (runs NS-1 slabs ahead of the MFMAs) ---------------
+    const uint16_t* a_src[IA]; const uint16_t* b_src[IB];
+    bool a_ok[IA], b_ok[IB];
+    int ld_it = 0, ld_s = 0, ld_g = 0;
+    auto set_load_tile = [&](int it) {
+        const int tile = first + idx + it * nbx, tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int m = tm * BM + (wave * IA + i) * 8 + lr;
+            a_ok[i] = m < p.M;
+            a_src[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.lda + swz * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int n = tn * BN + (wave * IB + i) * 8 + lr;
+            b_ok[i] = n < p.N;
+            b_src[i] = p.W + (size_t)(b_ok[i] ? n : 0) * p.ldw + swz * 8;
+        }
+    };
+    auto stage_next = [&]() {
+        unsigned char* slab = lds + __builtin_amdgcn_readfirstlane(ld_g % NS) * SLAB;
+        const int k0 = ld_s * BK;
+        const bool kin = k0 + swz * 8 < p.K;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const void* src = (a_ok[i] && kin) ? (const void*)(a_src[i] + k0) : (const void*)zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const void* src = (b_ok[i] && kin) ? (const void*)(b_src[i] + k0) : (const void*)zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+        }
+        ++ld_g;
+        if (++ld_s == nslab) { ld_s = 0; if (++ld_it < my_tiles) set_load_tile(ld_it); }
+    };
+
+    set_load_tile(0);
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u) stage_next();        // NS - 1 slabs ahead (total >= nslab >= NS)
+    int g = 0;
+    bool prev_full = false;
+    for (int it = 0; it < my_tiles; ++it) {
+        const int tile = first + idx + it * nbx, tm = tile % p.tiles_m, tn = tile / p.tiles_m;
+        const int m0 = tm * BM, n0 = tn * BN;
+        const bool full = m0 + BM <= p.M && n0 + BN <= p.N;           // wave-uniform
+        f32x4 acc[TN][TM];
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < nslab; ++t, ++g) {
+            // Operations of this wave issued AFTER the loads of slab g (staged NS-1 iterations ago), oldest first:
+            //   the slabs g+1 .. g+NS-2, the previous tile's epilogue stores when that epilogue ran within the last
+            //   NS-1 iterations (t <= NS-2; counted only if that tile was interior, i.e. their number is fixed), and
+            //   this tile's bias LDS-DMA (issued at t == 0, so younger than slab g for 1 <= t <= NS-2).
+            int allow = min(NS - 2, total - 1 - g) * G;
+            if (t <= NS - 2 && it > 0 && prev_full) allow += N_STORE;
+            if (t >= 1 && t <= NS - 2) allow += 1;
+            wait_vmcnt_any(allow);
+            __builtin_amdgcn_s_barrier();                 // slab g complete for every wave; slab g-1 fully consumed
+            if (t == 0) {
+                // this wave's 64 bias values -> its private LDS strip (one 4-byte LDS-DMA per lane); older than the tile's
+                // last slab, so the wait in front of that slab's MFMAs also covers it
+                const int n = n0 + wn0 + lane;
+                const void* src = (p.bias && n < p.N) ? (const void*)(p.bias + n) : (const void*)zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)bias_lds, 4, 0, 0);
+            }
+            if (ld_g < total) stage_next();               // refill the buffer slab g-1 used
+            const unsigned char* sa = lds + (g % NS) * SLAB;
+            const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = kk * 4 + lq;
+                bf16x8 fa[TM], fw[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int rr = wm0 + i * 16 + l15;
+                    fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + rr * 128 + ((c ^ (rr & 7)) << 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int rr = wn0 + j * 16 + l15;
+                    fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + rr * 128 + ((c ^ (rr & 7)) << 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+            }
+        }
+        // ---- epilogue, registers only: acc[j][i][r] = logit[m0+wm0+16i+l15][n0+wn0+16j+4lq+r] -------------------
+        float4 b4[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(bias_lds + (16 * j + 4 * lq) * 4);
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm0 + 16 * i + l15;
+                float* crow = p.C + (size_t)m * p.ldc + n0 + wn0 + 4 * lq;
+                float mxv = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float4 v;
+                    v.x = acc[j][i][0] + b4[j].x; v.y = acc[j][i][1] + b4[j].y;
+                    v.z = acc[j][i][2] + b4[j].z; v.w = acc[j][i][3] + b4[j].w;
+                    mxv = fmaxf(fmaxf(mxv, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+                    *reinterpret_cast<float4*>(crow + 16 * j) = v;
+                }
+                mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
+                mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
+                if (lq == 0) p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm0 + 16 * i + l15;
+                float mxv = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float bj[4] = {b4[j].x, b4[j].y, b4[j].z, b4[j].w};
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int n = n0 + wn0 + 16 * j + 4 * lq + rr;
+                        if (n < p.N) {
+                            const float v = acc[j][i][rr] + bj[rr];
+                            mxv = fmaxf(mxv, v);
+                            if (m < p.M) p.C[(size_t)m * p.ldc + n] = v;
+                        }
+                    }
+                }
+                mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
+                mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
+                if (lq == 0 && m < p.M) p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;   // -inf for a group past V
+            }
+        }
+        prev_full = full;
+    }
+}
+
 // Vocabulary projection for beam search: logits[M,V] fp32 = A[M,K] * W[V,K]^T + bias, plus group_max[m, g] =
 // max of logits[m, 64g .. 64g+63] (always the 128x128 tile: its waves own 64-column groups).
 extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float* bias, float* logits, int ldl,
@@ -395,6 +637,18 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
     dh_prof_set_tag("vocab");
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);
+    if ((ldl % 4) == 0 && ((uintptr_t)logits % 16) == 0 && K >= 128) {
+        VocabParams v{};
+        v.A = (const uint16_t*)A; v.lda = lda; v.W = (const uint16_t*)W; v.ldw = ldw; v.bias = bias;
+        v.C = logits; v.ldc = ldl; v.gmax = group_max; v.gmax_ld = gm_ld; v.M = M; v.N = V; v.K = K;
+        v.tiles_m = dh_cdiv(M, 128); v.tiles_n = dh_cdiv(V, 128);
+        const int ntiles = v.tiles_m * v.tiles_n;
+        // measured at M = 1280, V = 36,541, K = 512 (us per launch): 2-slab ring, two 8-wave workgroups per CU 84;
+        // 3- / 4-slab ring with one workgroup per CU 107 / 105; 256 x 128 tiles on 16 waves 85 / 84 (2 / 3 slabs);
+        // the one-tile-per-workgroup kernel below 93.  Without the 187 MB of logits stores the kernel takes 67 us.
+        hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, (hipStream_t)stream, v);
+        DH_LAUNCH_CHECK();
+    }
     GemmBf16Params p{};
     p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = bias;
     p.C = logits; p.ldc = ldl; p.M = M; p.N = V; p.K = K; p.out_f32 = 1; p.gmax = group_max; p.gmax_ld = gm_ld;

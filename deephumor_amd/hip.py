@@ -98,6 +98,11 @@ def lib_path():
     return _build.LIB_PATH
 
 
+def _ab_override():
+    """Developer A/B switch: DEEPHUMOR_HIP_LIB=<other build of the same ABI> (kernel experiments in scratch/)."""
+    return os.environ.get("DEEPHUMOR_HIP_LIB")
+
+
 def load():
     """Loads (building first if a compiler is present and sources are newer) the shared library."""
     global _lib
@@ -113,7 +118,7 @@ def load():
     if not os.path.exists(path):
         raise RuntimeError(f"deephumor_amd: HIP extension missing at {path}; run `python __graft_entry__.py build`. "
                            "There is no CPU fallback on the product path.")
-    lib = ctypes.CDLL(path)
+    lib = ctypes.CDLL(_ab_override() or path)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)             # AttributeError if the ABI lost a symbol
         fn.argtypes = argtypes

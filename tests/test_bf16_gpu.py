@@ -139,13 +139,15 @@ def test_models_bf16_close_to_reference(kind):
         assert tuple(toks.shape) == (4, 32) and int(toks.max()) < 1000 and not bool((toks == 1).any())
 
 
+@pytest.mark.parametrize("padded", [False, True])
+@pytest.mark.parametrize("rows", [37, 300])
 @pytest.mark.parametrize("v,beam,top_k", [(36541, 5, 50), (1000, 3, 16), (4000, 7, 50)])
-def test_vocab_logits_group_max_and_guided_sampling(hip, v, beam, top_k):
+def test_vocab_logits_group_max_and_guided_sampling(hip, v, beam, top_k, rows, padded):
     """dh_vocab_logits = dh_linear(out fp32) + per-row maxima of every 64-column group; the group-guided row
     sampler picks exactly what the full-row sampler picks."""
-    rows, k = 37, 512
+    k = 512
     a, w, b = bf(rnd(rows, k, seed=1)), bf(rnd(v, k, seed=2) * 0.12), rnd(v, seed=3)
-    logits = torch.empty(rows, v, device="cuda")
+    logits = torch.empty(rows, (v + 63) // 64 * 64 if padded else v, device="cuda")[:, :v]   # decoders pad the row stride
     ng = hip.n_groups(v)
     gmax = torch.full((rows, ng), float("nan"), device="cuda")
     hip.vocab_logits(a.cuda(), w.cuda(), b.cuda(), logits, gmax)
@@ -154,7 +156,9 @@ def test_vocab_logits_group_max_and_guided_sampling(hip, v, beam, top_k):
     pad = torch.full((rows, ng * 64 - v), float("-inf"), device="cuda")
     want = torch.cat([logits, pad], 1).view(rows, ng, 64).max(-1).values
     assert torch.equal(gmax, want)
-    noise = torch.empty(rows, v).exponential_(1, generator=torch.Generator().manual_seed(5)).cuda()
+    noise = torch.ones(rows, logits.stride(0))                       # explicit noise shares the logits row stride
+    noise[:, :v] = torch.empty(rows, v).exponential_(1, generator=torch.Generator().manual_seed(5))
+    noise = noise.cuda()
     out = []
     for guided in (False, True):
         pi = torch.empty(rows, beam, dtype=torch.int32, device="cuda")
@@ -168,3 +172,20 @@ def test_vocab_logits_group_max_and_guided_sampling(hip, v, beam, top_k):
         out.append((pi.cpu(), pv.cpu()))
     assert torch.equal(out[0][0], out[1][0])
     np.testing.assert_allclose(out[0][1].numpy(), out[1][1].numpy(), atol=1e-6)
+
+
+def test_vocab_logits_full_size_repeatable(hip):
+    """BASELINE-size classifier (1280 beam rows x 36,541 tokens, K = 512): the persistent kernel (several tiles per
+    workgroup, ring never drained) against the one-tile-per-workgroup GEMM, bit for bit, over repeated launches."""
+    rows, v, k = 1280, 36541, 512
+    a, w, b = bf(rnd(rows, k, seed=11)).cuda(), (bf(rnd(v, k, seed=12) * 0.1)).cuda(), rnd(v, seed=13).cuda()
+    ref = hip.linear(a, w, b, out_dtype=torch.float32)
+    ng = hip.n_groups(v)
+    pad = torch.full((rows, ng * 64 - v), float("-inf"), device="cuda")
+    want_g = torch.cat([ref, pad], 1).view(rows, ng, 64).max(-1).values
+    for rep in range(6):
+        logits = torch.full((rows, (v + 63) // 64 * 64), float("nan"), device="cuda")[:, :v]
+        gmax = torch.full((rows, ng), float("nan"), device="cuda")
+        hip.vocab_logits(a, w, b, logits, gmax)
+        assert torch.equal(logits, ref), rep
+        assert torch.equal(gmax, want_g), rep
