@@ -62,6 +62,35 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
     DH_REQUIRE(m && sc && m->layers && rows > 0 && rows_per_img > 0 && row_mult > 0 && (!logits || ldl >= m->V));
     const int E = m->E, Hh = m->Hh, dt = m->dtype, nl = m->n_layers;
     const size_t esz = dt == DH_F32 ? 4 : 2;
+    bool fused = dt == DH_BF16 && m->h_alt && m->c_alt;
+    for (int l = 0; l < nl; ++l) fused = fused && m->layers[l].w_il && m->layers[l].b_il;
+    if (fused) {
+        DH_REQUIRE(started >= 0 && started <= 2);
+        void* top = h_out ? h_out : sc->hout;
+        const int top_ld = h_out ? ld_out : Hh;
+        const char* hr = started == 0 ? nullptr : (const char*)(started == 1 ? m->h : m->h_alt);
+        const float* cr = started == 0 ? nullptr : (started == 1 ? m->c : m->c_alt);
+        char* hw = (char*)(started == 1 ? m->h_alt : m->h);
+        float* cw = started == 1 ? m->c_alt : m->c;
+        for (int l = 0; l < nl; ++l) {
+            const size_t so = (size_t)l * rows_total * Hh;
+            const void* x = l == 0 ? img_emb : (const char*)sc->xcatl + (size_t)(l - 1) * rows * 2 * Hh * esz;
+            void* dst = l + 1 < nl ? (void*)((char*)sc->xcatl + (size_t)l * rows * 2 * Hh * esz) : top;
+            DH_TRY(dh_lstm_layer_fused(x, l == 0 ? E : 2 * Hh, l == 0 ? rows_per_img : 1, l == 0 ? m->emb : nullptr,
+                                       l == 0 ? tokens : nullptr, tok_ld, tok_pos, hr ? hr + so * esz : nullptr,
+                                       cr ? cr + so : nullptr, hparent, hw + so * esz, cw + so, dst,
+                                       l + 1 < nl ? 2 * Hh : top_ld, m->layers[l].w_il, m->layers[l].b_il, rows, row_mult,
+                                       l == 0 ? E : Hh, Hh, dt, stream));
+        }
+        if (logits && group_max) {
+            DH_TRY(dh_vocab_logits(top, top_ld, m->cls_w, Hh, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
+        } else if (logits) {
+            dh_prof_set_tag("vocab");
+            DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,
+                             DH_BF16_OUT_F32, stream));
+        }
+        return DH_OK;
+    }
     DH_TRY(dh_lstm_prepare(m->emb, img_emb, tokens, tok_ld, tok_pos, hparent, started ? m->h : nullptr,
                            started ? m->c : nullptr, sc->xcat0, sc->xcatl, sc->c_cur, rows, rows_per_img, row_mult,
                            rows_total, nl, E, Hh, dt, stream));

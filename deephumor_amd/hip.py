@@ -36,12 +36,12 @@ class TrScratch(_c.Structure):
 
 
 class LstmLayer(_c.Structure):
-    _fields_ = [("w", _P), ("b", _P)]
+    _fields_ = [("w", _P), ("b", _P), ("w_il", _P), ("b_il", _P)]
 
 
 class LstmModel(_c.Structure):
     _fields_ = ([(n, _I) for n in ("n_layers", "E", "Hh", "V", "dtype", "_pad")] + [("layers", _c.POINTER(LstmLayer))]
-                + [(n, _P) for n in ("emb", "cls_w", "cls_b", "h", "c")])
+                + [(n, _P) for n in ("emb", "cls_w", "cls_b", "h", "c", "h_alt", "c_alt")])
 
 
 class LstmScratch(_c.Structure):
@@ -69,6 +69,7 @@ SIGNATURES = {
     "dh_enc_key_mask": [_P, _P, _I, _I, _I, _P],
     "dh_lstm_prepare": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_lstm_cell": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_lstm_layer_fused": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
                        _U64, _P, _I, _P],
@@ -469,6 +470,16 @@ def transformer_decode_position(model, scratch, start_emb, tokens, src, n_img, r
             tokens.stride(0), _ptr(src), src.stride(0), n_img, rows_per_img, row_mult, rows_total, t, _ptr(x_out),
             _ptr(logits), logits.stride(0) if logits is not None else 0, _ptr(group_max),
             group_max.stride(0) if group_max is not None else 0, _stream())
+
+
+def lstm_layer_fused(x_rows, x_div, emb, tokens, tok_pos, h_prev, c_prev, hparent, h_next, c_next, h_out, w_il, b_il,
+                     rows, row_mult, e, hh):
+    """One LSTM layer time step in one launch (bf16, gate-interleaved weights); see include/deephumor_hip.h."""
+    _dev(h_next, c_next, h_out, w_il, b_il)
+    _launch("dh_lstm_layer_fused", _ptr(x_rows), x_rows.stride(0) if x_rows is not None else 0, x_div, _ptr(emb),
+            _ptr(tokens), tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(h_prev), _ptr(c_prev),
+            _ptr(hparent), _ptr(h_next), _ptr(c_next), _ptr(h_out), h_out.stride(0), _ptr(w_il), _ptr(b_il), rows,
+            row_mult, e, hh, BF16, _stream())
 
 
 def lstm_decode_step(model, scratch, img_emb, tokens, tok_pos, hparent, started, rows, rows_per_img, row_mult,

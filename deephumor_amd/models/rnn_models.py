@@ -34,7 +34,14 @@ class LSTMDecoder(nn.Module, _Planned):
                            getattr(self.lstm, f"weight_hh_l{l}").detach()], dim=1).contiguous()
             b = (getattr(self.lstm, f"bias_ih_l{l}").detach().float()
                  + getattr(self.lstm, f"bias_hh_l{l}").detach().float()).contiguous()
-            layers.append((w, b))
+            if w.dtype == torch.bfloat16:
+                # gate-interleaved copy for the fused step kernel: row 4u+g = gate g (i, f, g, o) of hidden unit u
+                hh = self.lstm.hidden_size
+                w_il = w.view(4, hh, -1).permute(1, 0, 2).reshape(4 * hh, -1).contiguous()
+                b_il = b.view(4, hh).t().reshape(-1).contiguous()
+            else:
+                w_il = b_il = None
+            layers.append((w, b, w_il, b_il))
         return dict(layers=layers, emb=self.embedding.weight.detach(),
                     cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach().float().contiguous(),
                     dtype=self.classifier.weight.dtype)
@@ -53,17 +60,22 @@ class LSTMDecoder(nn.Module, _Planned):
             self.rows_total = r = n_img * beam
             self.h = torch.zeros((self.nl, r, self.hh), device=dev, dtype=self.dtype)
             self.c = torch.zeros((self.nl, r, self.hh), device=dev)             # cell state always fp32
-            self.started = False
+            self.started = 0                                                    # 0: zero state, then 1, 2, 1, 2, ...
             self._scratch = {}
             self.c_layers = (hip.LstmLayer * self.nl)()
-            for i, (w, b) in enumerate(plan["layers"]):
+            for i, (w, b, w_il, b_il) in enumerate(plan["layers"]):
                 self.c_layers[i].w, self.c_layers[i].b = w.data_ptr(), b.data_ptr()
+                if w_il is not None:
+                    self.c_layers[i].w_il, self.c_layers[i].b_il = w_il.data_ptr(), b_il.data_ptr()
             m = self.c_model = hip.LstmModel()
             m.n_layers, m.E, m.Hh, m.V = self.nl, self.e, self.hh, dec.num_tokens
             m.dtype = hip.F32 if self.dtype == torch.float32 else hip.BF16
             m.layers = self.c_layers
             m.emb, m.cls_w, m.cls_b = plan["emb"].data_ptr(), plan["cls_w"].data_ptr(), plan["cls_b"].data_ptr()
             m.h, m.c = self.h.data_ptr(), self.c.data_ptr()
+            if self.dtype == torch.bfloat16:      # fused step kernel: other workgroups still gather the old state rows
+                self.h_alt, self.c_alt = torch.zeros_like(self.h), torch.zeros_like(self.c)
+                m.h_alt, m.c_alt = self.h_alt.data_ptr(), self.c_alt.data_ptr()
 
         def scratch(self, rows):
             if rows not in self._scratch:
@@ -87,7 +99,7 @@ class LSTMDecoder(nn.Module, _Planned):
         sc = st.scratch(rows)
         hip.lstm_decode_step(st.c_model, sc["c"], img_emb, tokens, tok_pos, hparent, st.started, rows, rpi, mult,
                              rows_total, h_out=hout, logits=logits, group_max=group_max)
-        st.started = True
+        st.started = 2 if st.started == 1 else 1
         return hout if hout is not None else sc["hout"]
 
     def forward(self, image_emb, captions, lengths=None):

@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 5
+#define DH_ABI_VERSION 6
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -283,7 +283,10 @@ int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_tr_scratch_t
                                    int row_mult, int rows_total, int t, void* x_out, float* logits, int ldl,
                                    float* group_max, int gm_ld, void* stream);
 
-typedef struct dh_lstm_layer { const void* w; const float* b; } dh_lstm_layer_t;   /* [4Hh, in+Hh] = [W_ih|W_hh], b_ih+b_hh */
+typedef struct dh_lstm_layer {
+    const void* w; const float* b;          /* [4Hh, in+Hh] = [W_ih|W_hh], b_ih+b_hh (PyTorch gate order i,f,g,o) */
+    const void* w_il; const float* b_il;    /* optional (bf16): the same, gate-interleaved: row 4u+g = gate g of unit u */
+} dh_lstm_layer_t;
 
 typedef struct dh_lstm_model {
     int n_layers, E, Hh, V, dtype, _pad;
@@ -292,13 +295,27 @@ typedef struct dh_lstm_model {
     const float* cls_b;
     void* h;                                                /* recurrent state [n_layers, rows_total, Hh], storage dtype */
     float* c;                                               /* cell state, fp32 */
+    void* h_alt; float* c_alt;                              /* optional second state buffers (fused bf16 step: ping-pong) */
 } dh_lstm_model_t;
 
 typedef struct dh_lstm_scratch { void *xcat0, *xcatl; float *c_cur, *gates; void* hout; } dh_lstm_scratch_t;
 
-/* One LSTM time step for `rows` compact rows (dh_lstm_prepare + per layer gate GEMM + dh_lstm_cell) and,
- * if logits != NULL, the classifier.  started == 0: zero initial state.  h_out (optional, row stride
- * ld_out) receives the top layer's h instead of scratch->hout. */
+/* One LSTM layer time step in one launch (bf16): gates = [x | h_prev[parent]] * w_il^T + b_il on the matrix cores,
+ * cell update in the epilogue.  x row of compact row m: emb[tokens[m*row_mult*tok_ld + tok_pos]] if tokens, else
+ * x_rows[(m / x_div) * ldx].  h_prev / c_prev (NULL = zero state) are gathered through hparent (NULL = identity)
+ * at logical row m*row_mult; h_next / c_next (different buffers) are written at the logical row, h_out at row m. */
+int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const void* emb, const int32_t* tokens, int tok_ld,
+                        int tok_pos, const void* h_prev, const float* c_prev, const int32_t* hparent, void* h_next,
+                        float* c_next, void* h_out, int ld_out, const void* w_il, const float* b_il, int rows,
+                        int row_mult, int E, int Hh, int dtype, void* stream);
+
+/* One LSTM time step for `rows` compact rows and, if logits != NULL, the classifier.  h_out (optional, row stride
+ * ld_out) receives the top layer's h instead of scratch->hout.
+ *   started == 0: zero initial state; the new state is written to m->h / m->c.
+ *   fp32, or bf16 without w_il / h_alt: dh_lstm_prepare + per layer gate GEMM + dh_lstm_cell, state updated in place
+ *     (any started != 0 reads m->h / m->c).
+ *   bf16 with w_il, b_il, h_alt, c_alt: one dh_lstm_layer_fused launch per layer; started == 1 reads m->h / m->c and
+ *     writes h_alt / c_alt, started == 2 the reverse -- the caller alternates 0, 1, 2, 1, 2, ... */
 int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, const void* img_emb,
                         const int32_t* tokens, int tok_ld, int tok_pos, const int32_t* hparent,
                         int started, int rows, int rows_per_img, int row_mult, int rows_total,

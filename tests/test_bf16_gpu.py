@@ -189,3 +189,44 @@ def test_vocab_logits_full_size_repeatable(hip):
         hip.vocab_logits(a, w, b, logits, gmax)
         assert torch.equal(logits, ref), rep
         assert torch.equal(gmax, want_g), rep
+
+
+@pytest.mark.parametrize("rows,row_mult,e,hh,use_tokens,with_state", [
+    (37, 1, 64, 128, True, True), (8, 5, 256, 512, False, False), (130, 1, 512, 512, False, True),
+    (64, 1, 256, 512, True, True)])
+def test_lstm_layer_fused_matches_cell_math(hip, rows, row_mult, e, hh, use_tokens, with_state):
+    """dh_lstm_layer_fused (operand gather + gate GEMM + cell update in one launch, gate-interleaved weights) against
+    the LSTM cell equations in fp32 on the same bf16-rounded operands, incl. the beam-parent gather of the state."""
+    g = torch.Generator().manual_seed(rows * 7 + e)
+    rows_total = rows * row_mult
+    w = bf(torch.randn(4 * hh, e + hh, generator=g) * 0.05)
+    b = torch.randn(4 * hh, generator=g) * 0.1
+    w_il = w.view(4, hh, -1).permute(1, 0, 2).reshape(4 * hh, -1).contiguous().cuda()
+    b_il = b.view(4, hh).t().reshape(-1).contiguous().cuda()
+    emb = bf(torch.randn(50, e, generator=g))
+    tokens = torch.randint(0, 50, (rows_total, 6), generator=g, dtype=torch.int32)
+    x_rows = bf(torch.randn(rows, e, generator=g))
+    h_prev = bf(torch.randn(rows_total, hh, generator=g) * 0.5)
+    c_prev = torch.randn(rows_total, hh, generator=g)
+    hparent = torch.randint(0, rows_total, (rows_total,), generator=g, dtype=torch.int32)
+    h_next = torch.full((rows_total, hh), 9.0).bfloat16().cuda()
+    c_next = torch.full((rows_total, hh), 9.0).cuda()
+    h_out = torch.zeros(rows, hh + 8).bfloat16().cuda()[:, :hh]
+    hip.lstm_layer_fused(None if use_tokens else x_rows.cuda(), 1, emb.cuda() if use_tokens else None,
+                         tokens.cuda() if use_tokens else None, 3, h_prev.cuda() if with_state else None,
+                         c_prev.cuda() if with_state else None, hparent.cuda() if with_state else None, h_next, c_next, h_out,
+                         w_il, b_il, rows, row_mult, e, hh)
+    rl = torch.arange(rows) * row_mult
+    x = emb.float()[tokens[rl, 3].long()] if use_tokens else x_rows.float()
+    hp = hparent[rl].long()
+    h0 = h_prev.float()[hp] if with_state else torch.zeros(rows, hh)
+    c0 = c_prev[hp] if with_state else torch.zeros(rows, hh)
+    gates = torch.cat([x, h0], 1) @ w.float().t() + b
+    i, f, gg, o = gates.split(hh, dim=1)
+    c1 = torch.sigmoid(f) * c0 + torch.sigmoid(i) * torch.tanh(gg)
+    h1 = torch.sigmoid(o) * torch.tanh(c1)
+    np.testing.assert_allclose(c_next.cpu()[rl].numpy(), c1.numpy(), atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(h_next.cpu().float()[rl].numpy(), h1.numpy(), atol=1e-2, rtol=1e-2)
+    assert torch.equal(h_out.cpu(), h_next.cpu()[rl])
+    if row_mult > 1:                        # rows between the logical rows are untouched
+        assert float(c_next.cpu()[1].min()) == 9.0
