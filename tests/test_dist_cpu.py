@@ -1,6 +1,8 @@
 """world_size-2 gloo test of the image-sharding path (no GPU): shard arithmetic and the single
 all_gather of results reproduce the unsharded order, including uneven shards."""
+import datetime
 import os
+import socket
 
 import torch
 import torch.distributed as dist
@@ -29,18 +31,24 @@ def _fake_generate(lo, hi, t=6):
 
 def _worker(rank, world, port, n_total, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     toks, lens = generate_sharded(_fake_generate, n_total)
     ret[rank] = (toks.clone(), lens.clone())
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_ranks_gather_in_global_order():
     for n_total in (8, 7):
         with mp.Manager() as mgr:
             ret = mgr.dict()
-            mp.spawn(_worker, args=(2, 29500 + n_total, n_total, ret), nprocs=2, join=True)
+            mp.spawn(_worker, args=(2, _free_port(), n_total, ret), nprocs=2, join=True)
             want_t, want_l = _fake_generate(0, n_total)
             for r in range(2):
                 toks, lens = ret[r]
