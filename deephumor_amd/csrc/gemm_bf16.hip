@@ -380,11 +380,18 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     }
     p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
     const int blocks = p.tiles_m * p.tiles_n;
-    // few blocks: one per CU with a deep ring (7 slabs = 112 KB in flight); many blocks: two per CU, 3 in flight each
-    if (blocks <= 320 && p.K > 128)
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 8>), dim3(blocks), dim3(256), 0, s, p);
-    else
+    // ring depth (16 KB per slab) by workgroup count, so that all tiles are co-resident in ONE round where possible:
+    // <= 320: one per CU with a deep ring (7 slabs in flight); <= 512: two per CU; <= 768: three; <= 1280: five
+    // (the fused LSTM step, 640 workgroups: 20.7 us with 4 slabs / 1.25 rounds, 16.6 us with 3 slabs / one round)
+    static const int force_ns = getenv("DH_GEMM64_NS") ? atoi(getenv("DH_GEMM64_NS")) : 0;
+    if (force_ns == 4 || blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)
         hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
+    else if (blocks <= 320)
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 8>), dim3(blocks), dim3(256), 0, s, p);
+    else if (blocks <= 768)
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 3>), dim3(blocks), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 2>), dim3(blocks), dim3(256), 0, s, p);
 }
 
 // called from dh_linear (gemm.hip) for DH_BF16 / DH_BF16_OUT_F32

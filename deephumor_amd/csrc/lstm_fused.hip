@@ -42,8 +42,9 @@ __device__ __forceinline__ void lf_wait_vmcnt(int n) {
 
 __device__ __forceinline__ float lf_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+template <int NS>
 __global__ __launch_bounds__(256) void lstm_layer_fused_kernel(LstmFusedParams p) {
-    constexpr int BM = 64, BN = 64, BK = 64, NS = 4, NW = 4, WAVES_M = 2;
+    constexpr int BM = 64, BN = 64, BK = 64, NW = 4, WAVES_M = 2;
     constexpr int A_BYTES = BM * 128, SLAB = A_BYTES + BN * 128;
     constexpr int WM = 32, WN = 32, TM = 2, TN = 2;
     constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW), G = IA + IB;      // 2 + 2 LDS-DMA instructions per wave per slab
@@ -204,6 +205,15 @@ extern "C" int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const
     p.tiles_m = dh_cdiv(rows, 64); p.tiles_n = dh_cdiv(4 * Hh, 64);
     const double K = E + Hh;
     DhProfScope prof("dh_lstm_layer_fused", 2.0 * rows * 4 * Hh * K, 2.0 * (rows * K + 4.0 * Hh * K) + 12.0 * rows * Hh, stream);
-    hipLaunchKernelGGL(lstm_layer_fused_kernel, dim3(p.tiles_m * p.tiles_n), dim3(256), 0, (hipStream_t)stream, p);
+    // ring depth by workgroup count so that all tiles are co-resident in ONE round where possible (16 KB per slab):
+    // measured at 1280 rows x 2048 gate columns (640 workgroups): 4 slabs (2 per CU, 1.25 rounds) 20.7 / 24.3 us,
+    // 3 slabs (3 per CU) 16.6 / 19.0 us, 2 slabs (5 per CU) 16.4 / 18.6 us  (E = 256 / 512)
+    const int blocks = p.tiles_m * p.tiles_n;
+    if (blocks > 768 && blocks <= 1280)
+        hipLaunchKernelGGL(lstm_layer_fused_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else if (blocks > 512 && blocks <= 768)
+        hipLaunchKernelGGL(lstm_layer_fused_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(lstm_layer_fused_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
     DH_LAUNCH_CHECK();
 }
