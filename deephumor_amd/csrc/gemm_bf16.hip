@@ -36,6 +36,7 @@ struct GemmBf16Params {
     void* C; int ldc;
     int M, N, K, relu, out_f32;
     int conv, H, Wd, Cin, Ho, Wo, KS, stride, pad;     // conv loader: A = NHWC input
+    unsigned cin_magic, ks_magic;                      // k / Cin == (k * cin_magic) >> 20 for k < K; tap / KS likewise
     int tiles_m, tiles_n, n_fast;                      // n_fast: consecutive workgroups walk the N tiles of one M tile
     float* gmax; int gmax_ld;                          // optional: per-row maxima of each wave-wide column group
 };
@@ -128,40 +129,72 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
 #pragma unroll
     for (int i = 0; i < IA; ++i)
         a_pix[i] = CONV ? a_base[i] + ((ptrdiff_t)a_ih0[i] * p.Wd + a_iw0[i]) * p.Cin + a_swz[i] * 8 : nullptr;
+    // dense operands with K % 64 == 0 (no K tail): one running source pointer per LDS-DMA piece, rows outside M / N
+    // parked on the zero page with step 0 -- no selects or multiplies in the loop (the SIMD's instruction issue bounds
+    // this loop, see vocab_logits_kernel)
+    const bool stepping = (p.K & 63) == 0;
+    const uint16_t* a_run[IA]; const uint16_t* b_run[IB];
+    int a_stp[IA], b_stp[IB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        a_run[i] = (!CONV && a_ok[i]) ? a_base[i] + a_swz[i] * 8 : reinterpret_cast<const uint16_t*>(zero);
+        a_stp[i] = (!CONV && a_ok[i]) ? BK : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+        b_run[i] = b_ok[i] ? b_base[i] + b_swz[i] * 8 : reinterpret_cast<const uint16_t*>(zero);
+        b_stp[i] = b_ok[i] ? BK : 0;
+    }
     auto stage = [&](int buf, int k0) {
         unsigned char* slab = lds + __builtin_amdgcn_readfirstlane(buf) * SLAB;
+        if (!CONV && stepping) {
 #pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const int k = k0 + a_swz[i] * 8;
-            const void* src = zero;
-            if (a_ok[i] && k < p.K) {
-                if (CONV) {
-                    if (tap_uniform) {
+            for (int i = 0; i < IA; ++i) {
+                __builtin_amdgcn_global_load_lds((gptr_t)a_run[i], (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+                a_run[i] += a_stp[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                const int k = k0 + a_swz[i] * 8;
+                const void* src = zero;
+                if (a_ok[i] && k < p.K) {
+                    if (!CONV) {
+                        src = a_base[i] + k;
+                    } else if (tap_uniform) {
                         // a_pix = address of (pixel of tap (0,0), this lane's chunk); the tap offset is wave-uniform
                         if ((unsigned)(a_ih0[i] + st_kh) < (unsigned)p.H && (unsigned)(a_iw0[i] + st_kw) < (unsigned)p.Wd)
                             src = a_pix[i] + st_off;
                     } else {
-                        const int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.KS, kw = tap - kh * p.KS;
+                        // k -> (tap, ci), tap -> (kh, kw) by multiply-shift with host-verified magic numbers
+                        const int tap = (int)(((unsigned)k * p.cin_magic) >> 20), ci = k - tap * p.Cin;
+                        const int kh = (int)(((unsigned)tap * p.ks_magic) >> 20), kw = tap - kh * p.KS;
                         const int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
                         if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.Wd)
                             src = a_base[i] + ((size_t)ih * p.Wd + iw) * p.Cin + ci;
                     }
-                } else {
-                    src = a_base[i] + k;
                 }
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+            if (tap_uniform) {
+                st_ci += BK;
+                if (st_ci == p.Cin) { st_ci = 0; if (++st_kw == p.KS) { st_kw = 0; ++st_kh; } }
+                st_off = (st_kh * p.Wd + st_kw) * p.Cin + st_ci;
+            }
         }
-        if (tap_uniform) {
-            st_ci += BK;
-            if (st_ci == p.Cin) { st_ci = 0; if (++st_kw == p.KS) { st_kw = 0; ++st_kh; } }
-            st_off = (st_kh * p.Wd + st_kw) * p.Cin + st_ci;
-        }
+        if (stepping) {
 #pragma unroll
-        for (int i = 0; i < IB; ++i) {
-            const int k = k0 + b_swz[i] * 8;
-            const void* src = (b_ok[i] && k < p.K) ? (const void*)(b_base[i] + k) : (const void*)zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+            for (int i = 0; i < IB; ++i) {
+                __builtin_amdgcn_global_load_lds((gptr_t)b_run[i], (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+                b_run[i] += b_stp[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < IB; ++i) {
+                const int k = k0 + b_swz[i] * 8;
+                const void* src = (b_ok[i] && k < p.K) ? (const void*)(b_base[i] + k) : (const void*)zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+            }
         }
     };
 
@@ -422,6 +455,17 @@ extern "C" int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* 
     p.scale = scale; p.shift = shift; p.res = (const uint16_t*)residual; p.ldres = Cout;
     p.C = y; p.ldc = Cout; p.M = N * p.Ho * p.Wo; p.N = Cout; p.K = KS * KS * Cin; p.relu = relu; p.out_f32 = 0;
     p.H = H; p.Wd = W; p.Cin = Cin; p.KS = KS; p.stride = stride; p.pad = pad;
+    {   // division by Cin / KS in the generic (not tap-uniform) loader as multiply-shift; verified exhaustively here
+        auto magic = [](int d, int limit) -> unsigned {
+            const unsigned mg = (unsigned)(((1u << 20) + d - 1) / d);
+            if ((unsigned long long)limit * mg >= (1ull << 32)) return 0;
+            for (int v = 0; v < limit; ++v)
+                if ((int)(((unsigned)v * mg) >> 20) != v / d) return 0;
+            return mg;
+        };
+        p.cin_magic = magic(Cin, p.K); p.ks_magic = magic(KS, KS * KS);
+        DH_REQUIRE((Cin % 64) == 0 || (p.cin_magic && p.ks_magic));
+    }
     hipStream_t s = (hipStream_t)stream;
     static const char* const tags[] = {"?", "1x1", "2x2", "3x3", "4x4", "5x5", "6x6", "7x7"};
     dh_prof_set_tag(tags[KS < 8 ? KS : 0]);
@@ -458,19 +502,27 @@ __device__ __forceinline__ void wait_vmcnt_any(int n) {
         DH_VMCNT_CASE(7) DH_VMCNT_CASE(8) DH_VMCNT_CASE(9) DH_VMCNT_CASE(10) DH_VMCNT_CASE(11) DH_VMCNT_CASE(12)
         DH_VMCNT_CASE(13) DH_VMCNT_CASE(14) DH_VMCNT_CASE(15) DH_VMCNT_CASE(16) DH_VMCNT_CASE(17) DH_VMCNT_CASE(18)
         DH_VMCNT_CASE(19) DH_VMCNT_CASE(20) DH_VMCNT_CASE(21) DH_VMCNT_CASE(22) DH_VMCNT_CASE(23) DH_VMCNT_CASE(24)
+        DH_VMCNT_CASE(25) DH_VMCNT_CASE(26) DH_VMCNT_CASE(27) DH_VMCNT_CASE(28) DH_VMCNT_CASE(29) DH_VMCNT_CASE(30)
+        DH_VMCNT_CASE(31) DH_VMCNT_CASE(32) DH_VMCNT_CASE(33) DH_VMCNT_CASE(34) DH_VMCNT_CASE(35) DH_VMCNT_CASE(36)
+        DH_VMCNT_CASE(37) DH_VMCNT_CASE(38) DH_VMCNT_CASE(39) DH_VMCNT_CASE(40) DH_VMCNT_CASE(41) DH_VMCNT_CASE(42)
+        DH_VMCNT_CASE(43) DH_VMCNT_CASE(44) DH_VMCNT_CASE(45) DH_VMCNT_CASE(46) DH_VMCNT_CASE(47) DH_VMCNT_CASE(48)
+        DH_VMCNT_CASE(49) DH_VMCNT_CASE(50) DH_VMCNT_CASE(51) DH_VMCNT_CASE(52) DH_VMCNT_CASE(53) DH_VMCNT_CASE(54)
+        DH_VMCNT_CASE(55) DH_VMCNT_CASE(56) DH_VMCNT_CASE(57) DH_VMCNT_CASE(58) DH_VMCNT_CASE(59) DH_VMCNT_CASE(60)
+        DH_VMCNT_CASE(61) DH_VMCNT_CASE(62) DH_VMCNT_CASE(63)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
 
-template <int NS, int BM, int NW>
-__global__ __launch_bounds__(64 * NW, (NS * (BM + 128) * 128 <= 72 * 1024 ? 2 : 1)) void vocab_logits_kernel(VocabParams p) {
-    constexpr int BN = 128, BK = 64, WAVES_M = BM / 32;
+template <int NS, int BM, int BN, int WAVES_M, int NW>
+__global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1)) void vocab_logits_kernel(VocabParams p) {
+    constexpr int BK = 64;
     constexpr int A_BYTES = BM * 128, SLAB = A_BYTES + BN * 128;
-    constexpr int WM = BM / WAVES_M, WN = BN / (NW / WAVES_M);      // 32 x 64 per wave
+    constexpr int WM = BM / WAVES_M, WN = BN / (NW / WAVES_M);      // per-wave sub-tile; WN = 64 = one column group
+    static_assert(WN == 64, "a wave owns one 64-column group (group_max, bias strip)");
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW), G = IA + IB;
     constexpr int N_STORE = TM * TN + TM;                          // stores of one interior-tile epilogue, per wave
-    static_assert((NS - 2) * G + N_STORE + 1 <= 24, "vmcnt switch range");
+    static_assert((NS - 2) * G + N_STORE + 1 <= 63, "vmcnt encoding");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NS * SLAB + NW * 256];
     unsigned char* bias_lds = lds + NS * SLAB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 256;   // wave-private
 
@@ -494,37 +546,41 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + 128) * 128 <= 72 * 1024 ? 2 : 
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(dh_zero_page);
 
     // ---- loader state: the tile whose slabs are being staged (runs NS-1 slabs ahead of the MFMAs) ---------------
-    const uint16_t* a_src[IA]; const uint16_t* b_src[IB];
-    bool a_ok[IA], b_ok[IB];
+    // Per LDS-DMA piece one running source pointer and a per-lane step: rows outside M / V point at the zero page with
+    // step 0, so the loop carries no bounds selects (K % 64 == 0 is required by the host: no K tail either).  The
+    // SIMD's instruction issue, not the MFMA pipe, bounds this loop (PMC: SQ_ACTIVE_INST_ANY ~ all SIMD cycles), so
+    // every VALU instruction removed from the staging path shows up in the kernel time.
+    const uint16_t* a_ptr[IA]; const uint16_t* b_ptr[IB];
+    int a_step[IA], b_step[IB];
     int ld_it = 0, ld_s = 0, ld_g = 0;
     auto set_load_tile = [&](int it) {
         const int tile = first + idx + it * nbx, tm = tile % p.tiles_m, tn = tile / p.tiles_m;
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const int m = tm * BM + (wave * IA + i) * 8 + lr;
-            a_ok[i] = m < p.M;
-            a_src[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.lda + swz * 8;
+            const bool ok = m < p.M;
+            a_ptr[i] = ok ? p.A + (size_t)m * p.lda + swz * 8 : reinterpret_cast<const uint16_t*>(zero);
+            a_step[i] = ok ? BK : 0;
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const int n = tn * BN + (wave * IB + i) * 8 + lr;
-            b_ok[i] = n < p.N;
-            b_src[i] = p.W + (size_t)(b_ok[i] ? n : 0) * p.ldw + swz * 8;
+            const bool ok = n < p.N;
+            b_ptr[i] = ok ? p.W + (size_t)n * p.ldw + swz * 8 : reinterpret_cast<const uint16_t*>(zero);
+            b_step[i] = ok ? BK : 0;
         }
     };
     auto stage_next = [&]() {
         unsigned char* slab = lds + __builtin_amdgcn_readfirstlane(ld_g % NS) * SLAB;
-        const int k0 = ld_s * BK;
-        const bool kin = k0 + swz * 8 < p.K;
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const void* src = (a_ok[i] && kin) ? (const void*)(a_src[i] + k0) : (const void*)zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[i], (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+            a_ptr[i] += a_step[i];
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            const void* src = (b_ok[i] && kin) ? (const void*)(b_src[i] + k0) : (const void*)zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[i], (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+            b_ptr[i] += b_step[i];
         }
         ++ld_g;
         if (++ld_s == nslab) { ld_s = 0; if (++ld_it < my_tiles) set_load_tile(ld_it); }
@@ -554,6 +610,27 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + 128) * 128 <= 72 * 1024 ? 2 : 
             if (t >= 1 && t <= NS - 2) allow += 1;
             wait_vmcnt_any(allow);
             __builtin_amdgcn_s_barrier();                 // slab g complete for every wave; slab g-1 fully consumed
+            const unsigned char* sa = lds + (g % NS) * SLAB;
+            const unsigned char* sb = sa + A_BYTES;
+            // all fragments of the slab first (12 ds_read_b128 back to back, one wait), then the 16 MFMAs back to back:
+            // the other waves of the SIMD issue during the single LDS wait instead of during four short ones
+            bf16x8 fa[2][TM], fw[2][TN];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int c = kk * 4 + lq;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int rr = wm0 + i * 16 + l15;
+                    fa[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + rr * 128 + ((c ^ (rr & 7)) << 4)));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int rr = wn0 + j * 16 + l15;
+                    fw[kk][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + rr * 128 + ((c ^ (rr & 7)) << 4)));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the LDS-DMA issue (the most expensive instructions of the loop) goes into the LDS-read latency window
             if (t == 0) {
                 // this wave's 64 bias values -> its private LDS strip (one 4-byte LDS-DMA per lane); older than the tile's
                 // last slab, so the wait in front of that slab's MFMAs also covers it
@@ -562,28 +639,15 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + 128) * 128 <= 72 * 1024 ? 2 : 
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)bias_lds, 4, 0, 0);
             }
             if (ld_g < total) stage_next();               // refill the buffer slab g-1 used
-            const unsigned char* sa = lds + (g % NS) * SLAB;
-            const unsigned char* sb = sa + A_BYTES;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int c = kk * 4 + lq;
-                bf16x8 fa[TM], fw[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int rr = wm0 + i * 16 + l15;
-                    fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + rr * 128 + ((c ^ (rr & 7)) << 4)));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int rr = wn0 + j * 16 + l15;
-                    fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + rr * 128 + ((c ^ (rr & 7)) << 4)));
-                }
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
-            }
+                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fa[kk][i], acc[j][i], 0, 0, 0);
         }
         // ---- epilogue, registers only: acc[j][i][r] = logit[m0+wm0+16i+l15][n0+wn0+16j+4lq+r] -------------------
         float4 b4[TN];
@@ -644,7 +708,7 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
     dh_prof_set_tag("vocab");
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);
-    if ((ldl % 4) == 0 && ((uintptr_t)logits % 16) == 0 && K >= 128) {
+    if ((ldl % 4) == 0 && ((uintptr_t)logits % 16) == 0 && K >= 128 && (K % 64) == 0) {
         VocabParams v{};
         v.A = (const uint16_t*)A; v.lda = lda; v.W = (const uint16_t*)W; v.ldw = ldw; v.bias = bias;
         v.C = logits; v.ldc = ldl; v.gmax = group_max; v.gmax_ld = gm_ld; v.M = M; v.N = V; v.K = K;
@@ -653,7 +717,9 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         // measured at M = 1280, V = 36,541, K = 512 (us per launch): 2-slab ring, two 8-wave workgroups per CU 84;
         // 3- / 4-slab ring with one workgroup per CU 107 / 105; 256 x 128 tiles on 16 waves 85 / 84 (2 / 3 slabs);
         // the one-tile-per-workgroup kernel below 93.  Without the 187 MB of logits stores the kernel takes 67 us.
-        hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, (hipStream_t)stream, v);
+        // (256 x 128 tiles with 64 x 64 per wave: 83 / 89 us with a 2- / 3-slab ring; 256 x 256 with 128 x 64 per wave: 90 us --
+        //  at two waves per SIMD this simple schedule does not fill the matrix pipe; 128 x 128 below: 78 us)
+        hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, (hipStream_t)stream, v);
         DH_LAUNCH_CHECK();
     }
     GemmBf16Params p{};
