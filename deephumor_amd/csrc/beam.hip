@@ -217,19 +217,25 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
         idx_a[r] = me; val_a[r] = val_b[i];
     }
     __syncthreads();
+    // block max / sum: wave shuffles, then the NT/64 wave partials through LDS (2 barriers each instead of a log2(NT) tree)
+    constexpr int NWV = NT / 64;
     float m = -INFINITY;
     for (int i = tid; i < n; i += NT) m = fmaxf(m, val_a[i] / temperature);
-    red[tid] = m;
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
     __syncthreads();
-    for (int s2 = NT / 2; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] = fmaxf(red[tid], red[tid + s2]); __syncthreads(); }
     m = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) m = fmaxf(m, red[w]);
     __syncthreads();
     float s = 0.f;
     for (int i = tid; i < n; i += NT) { const float e = expf(val_a[i] / temperature - m); qv[i] = e; s += e; }
-    red[tid] = s;
+    s = wave_sum(s);
+    if ((tid & 63) == 0) red[tid >> 6] = s;
     __syncthreads();
-    for (int s2 = NT / 2; s2 > 0; s2 >>= 1) { if (tid < s2) red[tid] = red[tid] + red[tid + s2]; __syncthreads(); }
     s = red[0];
+#pragma unroll
+    for (int w = 1; w < NWV; ++w) s += red[w];      // same order in every thread: one value for the whole block
     const int img = rc / rows_per_img, rin = rc % rows_per_img;
     for (int i = tid; i < n; i += NT) {
         const float nz = noise ? noise[(size_t)rc * ldl + idx_a[i]]
@@ -332,10 +338,9 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     int gcols, int rows_per_img, int beam, int top_k, float temperature, int unk, const float* __restrict__ noise,
     uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx, float* __restrict__ pick_val,
     int32_t* __restrict__ err) {
-    constexpr int MAXG = 1024;
-    __shared__ uint32_t gkey[MAXG];
+    constexpr int MAXG = 1024, GPT = MAXG / NT;       // group keys per thread, kept in registers
     __shared__ int glist[MAXG];
-    __shared__ int hist[256];
+    __shared__ int hist[2][256];
     __shared__ uint32_t s_prefix, s_thr;
     __shared__ int s_k, s_cnt, s_ng, wtot[4];
     __shared__ int idx_a[CAP], idx_b[CAP];
@@ -344,37 +349,50 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     __shared__ int picks[DH_BEAM_MAX_BEAMS];
     const int rc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (size_t)rc * ldl;
-    for (int g = tid; g < n_groups; g += NT) gkey[g] = f2key(gmax[(size_t)rc * gm_ld + g]);
-    if (tid == 0) { s_prefix = 0u; s_k = min(top_k, n_groups); s_cnt = 0; s_ng = 0; }
-    uint32_t mask = 0u;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        if (tid < 256) hist[tid] = 0;
-        __syncthreads();
-        const uint32_t prefix = s_prefix;
-        for (int g = tid; g < n_groups; g += NT)
-            if ((gkey[g] & mask) == prefix) atomicAdd(&hist[(gkey[g] >> shift) & 255u], 1);
-        __syncthreads();
-        radix_pick_digit(hist, 1, shift, prefix, &s_prefix, &s_k, wtot);
-        mask |= 0xFFu << shift;
+    uint32_t gk[GPT];
+#pragma unroll
+    for (int e = 0; e < GPT; ++e) {
+        const int g = tid + e * NT;
+        gk[e] = g < n_groups ? f2key(gmax[(size_t)rc * gm_ld + g]) : 0u;      // key 0 < key of every real float
     }
-    const uint32_t bound = s_prefix;                 // k-th largest group maximum
-    for (int g = tid; g < n_groups; g += NT)
-        if (gkey[g] >= bound) glist[atomicAdd(&s_ng, 1)] = g;
+    for (int i = tid; i < 512; i += NT) (&hist[0][0])[i] = 0;
+    if (tid == 0) { s_prefix = 0u; s_k = min(top_k, n_groups); s_cnt = 0; s_ng = 0; }
+    __syncthreads();
+    // Lower edge of the 16-bit key bucket (sign, exponent, 7 mantissa bits) that holds the k-th largest group maximum:
+    // at least k groups -- hence at least k logits -- are >= it, and only a handful of extra groups share the bucket.
+    // Two radix passes instead of the four an exact k-th largest needs.
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int shift = 24 - 8 * pass;
+        const uint32_t prefix = s_prefix, mask = pass == 0 ? 0u : 0xFF000000u;
+#pragma unroll
+        for (int e = 0; e < GPT; ++e)
+            if (tid + e * NT < n_groups && (gk[e] & mask) == prefix) atomicAdd(&hist[pass][(gk[e] >> shift) & 255u], 1);
+        __syncthreads();
+        radix_pick_digit(hist[pass], 1, shift, prefix, &s_prefix, &s_k, wtot);
+    }
+    const uint32_t bound = s_prefix;                 // <= the row's k-th largest logit (as a key)
+#pragma unroll
+    for (int e = 0; e < GPT; ++e)
+        if (tid + e * NT < n_groups && gk[e] >= bound) glist[atomicAdd(&s_ng, 1)] = tid + e * NT;
     __syncthreads();
     const int ng = s_ng;
-    for (int q = wave; q < ng; q += NT / 64) {       // one wave per selected group, coalesced 256-B reads
-        const int g = glist[q];
-        for (int c = lane; c < gcols; c += 64) {
-            const int i = g * gcols + c;
-            if (i < V) {
-                const float v = row[i];
-                if (f2key(v) >= bound) {
-                    const int pp = atomicAdd(&s_cnt, 1);
-                    if (pp < CAP) { idx_a[pp] = i; val_a[pp] = v; }
-                }
-            }
+    // one wave per selected group (coalesced 256-B reads), four groups in flight per wave
+    constexpr int NWV = NT / 64, UN = 4;
+    for (int q0 = wave; q0 < ng; q0 += NWV * UN) {
+        float v[UN]; int ci[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int q = q0 + u * NWV;
+            ci[u] = q < ng ? glist[q] * gcols + lane : V;
+            v[u] = (lane < gcols && ci[u] < V) ? row[ci[u]] : 0.f;
         }
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            if (lane < gcols && ci[u] < V && f2key(v[u]) >= bound) {
+                const int pp = atomicAdd(&s_cnt, 1);
+                if (pp < CAP) { idx_a[pp] = ci[u]; val_a[pp] = v[u]; }
+            }
     }
     __syncthreads();
     const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
@@ -388,7 +406,7 @@ extern "C" int dh_beam_row_sample_groups(const float* logits, int ldl, int V, co
                                          int32_t* err, void* stream) {
     DH_REQUIRE(logits && group_max && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
     DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
-    DH_REQUIRE(n_groups > 0 && n_groups <= 1024 && top_k <= n_groups && gm_ld >= n_groups && group_cols > 0 &&
+    DH_REQUIRE(n_groups > 0 && n_groups <= 1024 && top_k <= n_groups && gm_ld >= n_groups && group_cols > 0 && group_cols <= 64 &&
                (long long)n_groups * group_cols >= V);
     DhProfScope prof("dh_beam_row_sample", 0.0, 0.0, stream);
     hipLaunchKernelGGL((beam_row_sample_groups_kernel<256>), dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,

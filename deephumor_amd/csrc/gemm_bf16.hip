@@ -417,6 +417,7 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     // <= 320: one per CU with a deep ring (7 slabs in flight); <= 512: two per CU; <= 768: three; <= 1280: five
     // (the fused LSTM step, 640 workgroups: 20.7 us with 4 slabs / 1.25 rounds, 16.6 us with 3 slabs / one round)
     static const int force_ns = getenv("DH_GEMM64_NS") ? atoi(getenv("DH_GEMM64_NS")) : 0;
+    // (32 x 64 tiles for the 160-workgroup decoder projections: slower -- proj 5.5 -> 6.1 ms, ffn 6.0 -> 7.6 ms per C3 step)
     if (force_ns == 4 || blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)
         hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
     else if (blocks <= 320)
