@@ -666,7 +666,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
                     v.x = acc[j][i][0] + b4[j].x; v.y = acc[j][i][1] + b4[j].y;
                     v.z = acc[j][i][2] + b4[j].z; v.w = acc[j][i][3] + b4[j].w;
                     mxv = fmaxf(fmaxf(mxv, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
-                    *reinterpret_cast<float4*>(crow + 16 * j) = v;
+                    *reinterpret_cast<float4*>(crow + 16 * j) = v;     // (non-temporal stores measured slower: 82 vs 78 us)
                 }
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
