@@ -720,6 +720,9 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         // the one-tile-per-workgroup kernel below 93.  Without the 187 MB of logits stores the kernel takes 67 us.
         // (256 x 128 tiles with 64 x 64 per wave: 83 / 89 us with a 2- / 3-slab ring; 256 x 256 with 128 x 64 per wave: 90 us --
         //  at two waves per SIMD this simple schedule does not fill the matrix pipe; 128 x 128 below: 78 us)
+        // (a two-group variant -- the workgroup's wave halves run the loop one barrier apart so that one half's MFMAs
+        //  overlap the other half's LDS reads / LDS-DMA issue; 3-slab ring, 16 waves on 256 x 128 -- measured 75.6 us
+        //  against 78 us standalone and no difference in the full step, so it is not kept)
         hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, (hipStream_t)stream, v);
         DH_LAUNCH_CHECK();
     }
