@@ -388,7 +388,9 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
         const double w_bytes = 2.0 * p.N * p.K, a_bytes = 2.0 * p.M * (CONV ? p.Cin : p.K);
         p.n_fast = w_bytes <= 8.0 * 1024 * 1024 && a_bytes > w_bytes;
     }
-    // (K <= 128 layers: 64 x 64, 128 x 64 and 64 x 128 tiles were all slower than 128 x 128: 245 / 204 / 205 vs 175 us)
+    // (K <= 128 layers: 64 x 64, 128 x 64 and 64 x 128 tiles were all slower than 128 x 128: 245 / 204 / 205 vs 175 us;
+    //  the persistent kernel with a register-only bf16 epilogue (8-byte stores / residual loads in accumulator layout):
+    //  K = 64: 166 vs 176 us, K = 128 + residual: 156 vs 127 us, K = 256: 77 vs 64 us -- the LDS-staged 16-byte rows win)
     const long long big_tiles = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
     // >= 192 big tiles (measured: lowering the threshold to 128/100/40 tiles does not help gates / ffn / qkv / proj)
     if (big_tiles >= 192 && p.M >= 96 && p.N >= 96) {

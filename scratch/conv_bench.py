@@ -24,16 +24,16 @@ for name, h, cin, cout, ks, s, _ in cfgs:
     w = (torch.randn(cout, ks, ks, cin, device='cuda') * 0.05).bfloat16()
     sc, sh = torch.ones(cout, device='cuda'), torch.zeros(cout, device='cuda')
     pad = 1 if ks == 3 else 0
-    res = None
-    for _ in range(2): y = hip.conv2d_nhwc_bn_act(x, w, sc, sh, stride=s, pad=pad)
+    res = torch.randn(N, h // s, h // s, cout, device='cuda').bfloat16() if name.startswith('c3') else None
+    for _ in range(2): y = hip.conv2d_nhwc_bn_act(x, w, sc, sh, residual=res, stride=s, pad=pad)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(5): y = hip.conv2d_nhwc_bn_act(x, w, sc, sh, stride=s, pad=pad)
+    for _ in range(5): y = hip.conv2d_nhwc_bn_act(x, w, sc, sh, residual=res, stride=s, pad=pad)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     ho = y.shape[1]
     fl = 2.0 * N * ho * ho * cout * cin * ks * ks
-    by = 2.0 * (x.numel() + y.numel() + w.numel())
+    by = 2.0 * (x.numel() + y.numel() * (2 if res is not None else 1) + w.numel())
     seen[key] = ms; tot += ms
     print(f"{name:12s} H{h:3d} {cin:4d}->{cout:4d} k{ks} s{s}: {ms*1e3:7.1f} us  {fl/ms/1e9:7.1f} TF  {by/ms/1e6:7.1f} GB/s  M={N*ho*ho} K={cin*ks*ks}")
 print("total ms", tot)
