@@ -215,3 +215,33 @@ def test_hipgraph_replay_equals_eager(kind, images):
             got_t, got_l = model.generate_batch_graphed(imgs.cuda(), seed=seed, **kw)
             assert got_t.tolist() == want_t.tolist() and got_l.tolist() == want_l.tolist()
     assert len(model._graphs) == 1
+
+
+@pytest.mark.parametrize("kind,hp", [
+    ("CaptioningLSTM", dict(num_tokens=1000, emb_dim=512, hidden_size=512, num_layers=3)),
+    ("CaptioningTransformer", dict(num_tokens=1000, hid_dim=512, n_layers=3, n_heads=8, pf_dim=2048, max_len=128)),
+])
+def test_released_checkpoint_hyperparameters(kind, hp, images, tmp_path):
+    """the released checkpoints' shapes (LSTM 512/512/3, 3-layer Transformer) through
+    ``save`` / ``from_pretrained`` ({'model', 'hp'} files): greedy ids of the fp32 HIP path == the CPU oracle's,
+    and the bf16 path (3-layer fused LSTM step with E = 512) agrees on the first token."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import load_synthetic
+    from oracle import ref_path as R
+    model = load_synthetic(getattr(M, kind)(**hp).eval(), seed=77)
+    path = str(tmp_path / "released.pth")
+    model.save(path)
+    again = getattr(M, kind).from_pretrained(path).eval()
+    assert again._hp == model._hp and set(again.state_dict()) == set(model.state_dict())
+    sd = {k: v.clone() for k, v in again.state_dict().items()}
+    with torch.no_grad():
+        toks, lens = again.cuda().generate_batch(images[:2].cuda(), max_len=20, beam_size=1, top_k=1)
+    for i in range(2):
+        want = R.model_generate(kind, sd, again._hp, images[i:i + 1], max_len=20, beam_size=1, top_k=1).reshape(-1).tolist()
+        assert toks[i, :int(lens[i])].cpu().tolist() == want, (kind, i)
+    with torch.no_grad():
+        tb, _ = again.bfloat16().generate_batch(images[:2].cuda(), max_len=20, beam_size=1, top_k=1)
+    assert tb[:, 0].cpu().tolist() == toks[:, 0].cpu().tolist()
