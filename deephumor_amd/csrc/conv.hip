@@ -239,6 +239,29 @@ extern "C" int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int 
     DH_LAUNCH_CHECK();
 }
 
+// ---- image preprocessing on device (the notebook's ToTensor + Normalize, ipynb:565-567) ----
+// u8 [N,H,W,C] (the decoded image as PIL / numpy hold it) -> fp32 NCHW (x / 255 - mean[c]) / std[c]: the same
+// IEEE operations in the same order as torchvision's ToTensor().div(255) and Normalize's sub_().div_() -> bit-exact.
+__global__ __launch_bounds__(256) void normalize_u8_hwc_kernel(const uint8_t* __restrict__ x, const float* __restrict__ mean,
+                                                                const float* __restrict__ stdv, float* __restrict__ y,
+                                                                int C, int HW, size_t total) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
+        const size_t n = i / HW, p = i - n * HW;
+        for (int c = 0; c < C; ++c)
+            y[(n * C + c) * HW + p] = ((float)x[i * C + c] / 255.0f - mean[c]) / stdv[c];
+    }
+}
+
+extern "C" int dh_normalize_u8_hwc(const uint8_t* x, const float* mean, const float* stdv, float* y, int N, int H, int W,
+                                   int C, void* stream) {
+    DH_REQUIRE(x && mean && stdv && y && N > 0 && C > 0 && C <= 8 && H > 0 && W > 0);
+    DhProfScope prof("dh_normalize_u8_hwc", 0.0, (double)N * H * W * C * 5.0, stream);
+    const size_t total = (size_t)N * H * W;
+    const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
+    hipLaunchKernelGGL(normalize_u8_hwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, stdv, y, C, H * W, total);
+    DH_LAUNCH_CHECK();
+}
+
 // ---- channels-last bf16 pools (bf16 path) ------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                                  int N, int H, int W, int C, int Ho, int Wo) {

@@ -41,3 +41,17 @@ def split_caption(text, num_blocks=None):
     if num_blocks is None:
         return blocks
     return (blocks + [''] * max(0, num_blocks - len(blocks)))[:num_blocks]
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def images_to_tensor(images_u8, mean=IMAGENET_MEAN, std=IMAGENET_STD):
+    """Decoded, already resized RGB images uint8 ``[N, H, W, 3]`` on the GPU -> the normalised fp32 ``[N, 3, H, W]``
+    batch the encoders take: the notebook's ``ToTensor`` + ``Normalize`` (deephumor_demo.ipynb:565-567) as one
+    device kernel."""
+    from .. import hip
+    dev = images_u8.device
+    return hip.normalize_u8_hwc(images_u8.contiguous(), torch.tensor(mean, dtype=torch.float32, device=dev),
+                                torch.tensor(std, dtype=torch.float32, device=dev))

@@ -54,6 +54,7 @@ SIGNATURES = {
     "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _P],
+    "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_avgpool_nhwc": [_P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -470,6 +471,16 @@ def transformer_decode_position(model, scratch, start_emb, tokens, src, n_img, r
             tokens.stride(0), _ptr(src), src.stride(0), n_img, rows_per_img, row_mult, rows_total, t, _ptr(x_out),
             _ptr(logits), logits.stride(0) if logits is not None else 0, _ptr(group_max),
             group_max.stride(0) if group_max is not None else 0, _stream())
+
+
+def normalize_u8_hwc(x, mean, std):
+    """uint8 [N,H,W,C] -> fp32 [N,C,H,W] (x / 255 - mean) / std, as torchvision ToTensor + Normalize."""
+    _dev(x, mean, std)
+    assert x.dtype == torch.uint8 and x.is_contiguous() and x.dim() == 4
+    n, h, w, c = x.shape
+    y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    _launch("dh_normalize_u8_hwc", _ptr(x), _ptr(mean), _ptr(std), _ptr(y), n, h, w, c, _stream())
+    return y
 
 
 def lstm_layer_fused(x_rows, x_div, emb, tokens, tok_pos, h_prev, c_prev, hparent, h_next, c_next, h_out, w_il, b_il,

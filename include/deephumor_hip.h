@@ -69,6 +69,11 @@ int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const 
  * channels C..7 zero, so the 7x7 stem is a dh_conv2d_nhwc_bn_act with Cin = 8 (weights zero-padded likewise). */
 int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, void* stream);
 
+/* Image preprocessing on device: u8 [N,H,W,C] -> fp32 NCHW (x / 255 - mean[c]) / std[c], bit-identical to
+ * torchvision ToTensor + Normalize (deephumor_demo.ipynb:565-567; the resize stays with the image decoder). */
+int dh_normalize_u8_hwc(const uint8_t* x, const float* mean, const float* stdv, float* y, int N, int H, int W, int C,
+                        void* stream);
+
 /* Channels-last bf16 pools of the bf16 path: MaxPool2d(3,2,1) x [N,H,W,C] -> [N,Ho,Wo,C];
  * AdaptiveAvgPool2d(1) x [N,HW,C] -> y [N,C].  C % 8 == 0.  DH_BF16 only. */
 int dh_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);

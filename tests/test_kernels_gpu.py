@@ -347,3 +347,14 @@ def test_attn_other_head_dims(hip, d, h):
         vals = torch.stack([vc[j, src[row, j]] for j in range(t)] + [qkv[row, 2 * d:]]).view(t + 1, h, dh)
         masked = torch.tensor([False] + [bool(tokens[row, j - 1] == 0) for j in range(1, t + 1)])
         close(out[row], _attn_ref(qkv[row, :d].view(h, dh), keys, vals, masked, float(dh) ** 0.5), atol=2e-5)
+
+
+def test_normalize_u8_matches_totensor_normalize():
+    """dh_normalize_u8_hwc == ToTensor().div(255) followed by Normalize's sub_().div_(), bit for bit."""
+    from deephumor_amd.experiments.inference import images_to_tensor, IMAGENET_MEAN, IMAGENET_STD
+    g = torch.Generator().manual_seed(3)
+    u8 = torch.randint(0, 256, (3, 37, 53, 3), generator=g, dtype=torch.uint8)
+    want = u8.permute(0, 3, 1, 2).float().div(255)
+    want = want.sub(torch.tensor(IMAGENET_MEAN)[None, :, None, None]).div(torch.tensor(IMAGENET_STD)[None, :, None, None])
+    got = images_to_tensor(u8.cuda()).cpu()
+    assert torch.equal(got, want)
