@@ -62,19 +62,47 @@ def _bn_affine(bn):
 
 
 class _Planned:
-    """Lazily derived device-side constants, rebuilt when any parameter/buffer changes."""
+    """Lazily derived device-side constants, rebuilt when any parameter/buffer changes (storage pointer or in-place
+    version counter).  The tensor list is cached -- walking a ResNet-50's modules costs more host time per call than
+    the key itself -- and dropped whenever the module is converted or (re)loaded (``_apply``: ``.to`` / ``.cuda`` /
+    ``.bfloat16``; ``load_state_dict``), the two ways standard PyTorch code replaces parameter or buffer objects."""
 
-    def _plan_key(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+    def _plan_tensors_list(self, refresh=False):
+        ts = self.__dict__.get("_plan_tensors")
+        if ts is None or refresh:
+            ts = list(self.parameters()) + list(self.buffers())
+            object.__setattr__(self, "_plan_tensors", ts)
+        return ts
+
+    def _plan_key(self, refresh=False):
+        ts = self._plan_tensors_list(refresh)
+        return tuple(t.data_ptr() for t in ts), tuple(t._version for t in ts)
+
+    def _drop_plan(self):
+        for m in self.modules():
+            if isinstance(m, _Planned):
+                m.__dict__.pop("_plan_tensors", None)
+                m.__dict__.pop("_plan_cache", None)
+
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._drop_plan()
+        return out
+
+    def load_state_dict(self, *a, **kw):
+        out = super().load_state_dict(*a, **kw)
+        self._drop_plan()
+        return out
 
     def _get_plan(self):
         key = self._plan_key()
-        if getattr(self, "_plan_cache", None) is None or self._plan_cache[0] != key:
+        if self.__dict__.get("_plan_cache") is None or self._plan_cache[0] != key:
+            key = self._plan_key(refresh=True)            # something changed: re-walk the modules, then rebuild
             object.__setattr__(self, "_plan_cache", (key, self._build_plan()))
         return self._plan_cache[1]
 
 
-class ImageEncoder(nn.Module, _Planned):
+class ImageEncoder(_Planned, nn.Module):
     """ResNet-50 image encoder (reference encoders.py:7-70).
 
     ``forward(images[N,3,H,W])`` returns ``emb [N, emb_dim]`` or, with ``spatial_features``,

@@ -14,7 +14,7 @@ from .beam import BeamSearchHelper, run_interleaved
 from .encoders import _Planned
 
 
-class LSTMDecoder(nn.Module, _Planned):
+class LSTMDecoder(_Planned, nn.Module):
     """LSTM-based decoder (reference rnn_models.py:8-26)."""
 
     def __init__(self, num_tokens, emb_dim=256, hidden_size=512,

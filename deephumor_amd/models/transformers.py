@@ -81,7 +81,7 @@ class TransformerEncoder(nn.Module):
         raise NotImplementedError("TransformerEncoder is dead code in the reference and not on the caption path")
 
 
-class _IncrementalDecoder(nn.Module, _Planned):
+class _IncrementalDecoder(_Planned, nn.Module):
     """Shared engine of TransformerDecoder / SelfAttentionTransformerDecoder."""
 
     _layer_cls = None
