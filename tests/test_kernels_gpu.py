@@ -291,7 +291,10 @@ def bf(x):
     return x.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize("m,n,k", [(4, 1000, 512), (1280, 512, 512), (300, 4567, 768), (77, 130, 2048), (1, 64, 8)])
+@pytest.mark.parametrize("m,n,k", [(4, 1000, 512), (1280, 512, 512), (300, 4567, 768), (77, 130, 2048), (1, 64, 8),
+                                   (1280, 2048, 512),     # 640 workgroups of 64 x 64: 3-slab ring, three per CU
+                                   (65, 25000, 512),      # 782 workgroups: 2-slab ring, five per CU
+                                   (1280, 3072, 520)])    # 128 x 128 tiles, K not a multiple of 64 (K tail, no pointer stepping)
 def test_linear_bf16(hip, m, n, k):
     a, w, b = bf(rnd(m, k, seed=1)), bf(rnd(n, k, seed=2) / k ** 0.5), rnd(n, seed=3)
     ref = F.linear(a.float(), w.float(), b)
@@ -315,7 +318,9 @@ def test_linear_f32_residual(hip):
 @pytest.mark.parametrize("cin,cout,hw,ks,stride,pad,n", [
     (64, 64, 14, 1, 1, 0, 2), (64, 256, 14, 1, 1, 0, 2), (256, 128, 14, 1, 2, 0, 2), (128, 128, 14, 3, 2, 1, 3),
     (64, 64, 9, 3, 1, 1, 2), (512, 2048, 7, 1, 1, 0, 3), (512, 512, 7, 3, 1, 1, 3), (1024, 2048, 14, 1, 2, 0, 2),
-    (64, 64, 56, 3, 1, 1, 5)])
+    (64, 64, 56, 3, 1, 1, 5),
+    # >= 131,072 output pixels with 64 output channels: the 256 x 64 (3x3) and 128 x 64 (dense 1x1) tile configurations
+    (64, 64, 56, 3, 1, 1, 43), (256, 64, 56, 1, 1, 0, 43), (64, 256, 56, 1, 1, 0, 11)])
 def test_conv_nhwc_bf16(hip, cin, cout, hw, ks, stride, pad, n):
     x, w = bf(rnd(n, cin, hw, hw, seed=1)), bf(rnd(cout, cin, ks, ks, seed=2) * (2.0 / (cin * ks * ks)) ** 0.5)
     sc, sh = rnd(cout, seed=3).abs() + 0.5, rnd(cout, seed=4)
