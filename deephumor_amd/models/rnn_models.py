@@ -58,8 +58,9 @@ class LSTMDecoder(_Planned, nn.Module):
             self.nl, self.hh, self.e = dec.lstm.num_layers, dec.lstm.hidden_size, dec.lstm.input_size
             self.dev, self.dtype = dev, plan["dtype"]
             self.rows_total = r = n_img * beam
-            self.h = torch.zeros((self.nl, r, self.hh), device=dev, dtype=self.dtype)
-            self.c = torch.zeros((self.nl, r, self.hh), device=dev)             # cell state always fp32
+            # never read before it is written: the first step runs with started == 0 (zero state by flag)
+            self.h = torch.empty((self.nl, r, self.hh), device=dev, dtype=self.dtype)
+            self.c = torch.empty((self.nl, r, self.hh), device=dev)             # cell state always fp32
             self.started = 0                                                    # 0: zero state, then 1, 2, 1, 2, ...
             self._scratch = {}
             self.c_layers = (hip.LstmLayer * self.nl)()
@@ -74,7 +75,7 @@ class LSTMDecoder(_Planned, nn.Module):
             m.emb, m.cls_w, m.cls_b = plan["emb"].data_ptr(), plan["cls_w"].data_ptr(), plan["cls_b"].data_ptr()
             m.h, m.c = self.h.data_ptr(), self.c.data_ptr()
             if self.dtype == torch.bfloat16:      # fused step kernel: other workgroups still gather the old state rows
-                self.h_alt, self.c_alt = torch.zeros_like(self.h), torch.zeros_like(self.c)
+                self.h_alt, self.c_alt = torch.empty_like(self.h), torch.empty_like(self.c)
                 m.h_alt, m.c_alt = self.h_alt.data_ptr(), self.c_alt.data_ptr()
 
         def scratch(self, rows):
