@@ -254,6 +254,24 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
     const T* kptr[NIT];
     const T* vptr[NIT];
     bool live[NIT], masked[NIT];
+    // Index loads first, all of them, with clamped (always valid) indices and no per-slot branches: the ancestor row
+    // of every key slot, the token that decides its pad mask / the cross-attention key mask.  Issued back to back they
+    // cost ONE memory round trip; loaded inside the per-slot conditionals they cost one round trip EACH (the compiler
+    // has to wait before the dependent address arithmetic of that slot): 2.3 us per 8 keys of history.
+    int phys[NIT], aux[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) { phys[it] = 0; aux[it] = 0; }
+    if (CROSS) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) aux[it] = p.keymask[img * L + min(it * KPI + kg, L - 1)];
+    } else if (t > 0) {                                  // wave-uniform
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) phys[it] = p.src[(size_t)rl * p.src_ld + min(it * KPI + kg, t - 1)];
+        if (p.tokens) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) aux[it] = p.tokens[(size_t)rl * p.tok_ld + min(max(it * KPI + kg - 1, 0), t - 1)];
+        }
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int j = it * KPI + kg;
@@ -264,16 +282,15 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
             if (CROSS) {
                 kptr[it] = p.kv + (size_t)(img * L + j) * (2 * D) + h * DH + dc * 8;
                 vptr[it] = kptr[it] + D;
-                masked[it] = p.keymask[img * L + j] != 0;
+                masked[it] = aux[it] != 0;
             } else if (j < t) {
-                const int phys = p.src[(size_t)rl * p.src_ld + j];
-                const size_t off = ((size_t)j * p.rows_total + phys) * D + h * DH + dc * 8;
+                const size_t off = ((size_t)j * p.rows_total + phys[it]) * D + h * DH + dc * 8;
                 kptr[it] = p.kc + off; vptr[it] = p.vc + off;
             } else {
                 kptr[it] = p.knew + (size_t)rc * p.ldnew + h * DH + dc * 8;
                 vptr[it] = p.vnew + (size_t)rc * p.ldnew + h * DH + dc * 8;
             }
-            if (!CROSS) masked[it] = (j >= 1) && (p.tokens[(size_t)rl * p.tok_ld + j - 1] == p.pad_index);
+            if (!CROSS) masked[it] = (j >= 1) && p.tokens && (aux[it] == p.pad_index);
         }
     }
     Raw8<T> kr[NIT], vr[NIT];
@@ -283,6 +300,7 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
     for (int it = 0; it < NIT; ++it) if (live[it]) raw_load(vptr[it], vr[it]);
     float qv[8];
     load8(p.q + (size_t)rc * p.ldq + h * DH + dc * 8, qv);
+    __builtin_amdgcn_sched_barrier(0);                 // every K, V and q load is issued before any of the arithmetic below
 
     float e[NIT];
     float mx = -INFINITY;
@@ -295,22 +313,24 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
             float a = 0.f;
 #pragma unroll
             for (int u = 0; u < 8; ++u) a = fmaf(kk[u], qv[u], a);
+            if (LPK == 8) a = sum8(a);                // DPP fold over the row's 8 chunk lanes
+            else {
 #pragma unroll
-            for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
+                for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
+            }
             e[it] = masked[it] ? -1e8f : a / p.scale;
         }
         mx = fmaxf(mx, e[it]);
     }
-#pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));      // across key slots
+    mx = wave_max(mx);                                                              // across key slots
     float sum = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         e[it] = live[it] ? expf(e[it] - mx) : 0.f;
         sum += e[it];
     }
-#pragma unroll
-    for (int o = LPK; o < 64; o <<= 1) sum += __shfl_xor(sum, o, 64);               // every chunk lane holds its key's e
+    // every chunk lane holds its key's e: the wave sum counts each key LPK times
+    sum = wave_sum(sum) / (float)LPK;
     float o8[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) o8[u] = 0.f;

@@ -11,20 +11,39 @@
 
 static inline int dh_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide all-reduce without the LDS crossbar: hipcc lowers __shfl_xor to ds_bpermute_b32 + s_waitcnt lgkmcnt(0)
+// (six dependent ~100-cycle round trips per reduction); here the 16 lanes of a DPP row are folded with four DPP moves
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror) and the four rows with v_readlane.
+// Must be called by all 64 lanes (wave-uniform control flow), like the shuffles they replace.
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+    const int x = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_get_i(int x) { return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ float lane_get(float v, int l) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+// sum / max over aligned groups of 8 lanes (every lane of the group gets the result)
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_get<0xB1>(v); v += dpp_get<0x4E>(v); v += dpp_get<0x141>(v);
     return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = sum8(v);
+    v += dpp_get<0x140>(v);                               // the other 8 lanes of the 16-lane row
+    return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_get<0xB1>(v)); v = fmaxf(v, dpp_get<0x4E>(v));
+    v = fmaxf(v, dpp_get<0x141>(v)); v = fmaxf(v, dpp_get<0x140>(v));
+    return fmaxf(fmaxf(lane_get(v, 0), lane_get(v, 16)), fmaxf(lane_get(v, 32), lane_get(v, 48)));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_get_i<0xB1>(v); v += dpp_get_i<0x4E>(v); v += dpp_get_i<0x141>(v); v += dpp_get_i<0x140>(v);
+    return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+           (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
 }
 
 // Philox4x32-10 counter-based generator: one call gives four 32-bit words that depend only on
