@@ -352,8 +352,10 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     uint32_t gk[GPT];
 #pragma unroll
     for (int e = 0; e < GPT; ++e) {
+        // unconditional loads at a clamped index (one memory round trip for all of them, not one per conditional load)
         const int g = tid + e * NT;
-        gk[e] = g < n_groups ? f2key(gmax[(size_t)rc * gm_ld + g]) : 0u;      // key 0 < key of every real float
+        const uint32_t k = f2key(gmax[(size_t)rc * gm_ld + min(g, n_groups - 1)]);
+        gk[e] = g < n_groups ? k : 0u;                                        // key 0 < key of every real float
     }
     for (int i = tid; i < 512; i += NT) (&hist[0][0])[i] = 0;
     if (tid == 0) { s_prefix = 0u; s_k = min(top_k, n_groups); s_cnt = 0; s_ng = 0; }
@@ -467,10 +469,13 @@ __global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
         if (lane == 0) s_n = B;
     } else {
         int off[DH_BEAM_MAX_BEAMS + 1];
+        uint8_t was_ended[DH_BEAM_MAX_BEAMS];
+#pragma unroll
+        for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b) was_ended[b] = p.ended[base + min(b, B - 1)];   // one round trip for all
         off[0] = 0;
 #pragma unroll
         for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b)
-            off[b + 1] = off[b] + (b < B ? (p.ended[base + b] ? 1 : B) : 0);
+            off[b + 1] = off[b] + (b < B ? (was_ended[b] ? 1 : B) : 0);
         const int total = off[B];
         for (int c = lane; c < total; c += 64) {
             int b = 0;
