@@ -57,30 +57,38 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= rows) return;
     const T* xr = x + (size_t)r * D;
-    const T* yr = y ? y + (size_t)r * D : nullptr;
-    float v[NV][VN];
-    float s = 0.f;
+    const T* yr = y ? y + (size_t)r * D : xr;
+    // every load of the kernel is requested up front at a clamped (always valid) offset, without per-vector branches:
+    // one memory round trip instead of one per conditional load (x, y, gamma, beta used to cost four)
+    float v[NV][VN], b[NV][VN], gm[NV][VN], bt[NV][VN];
+    bool live[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int d = (lane + i * 64) * VN;
-        if (d < D) {
-            load16(xr + d, v[i]);
-            if (yr) {
-                float b[VN];
-                load16(yr + d, b);
+        live[i] = d < D;
+        const int dd = live[i] ? d : 0;
+        load16(xr + dd, v[i]);
+        load16(yr + dd, b[i]);
 #pragma unroll
-                for (int j = 0; j < VN; ++j) v[i][j] += b[j];
-            }
+        for (int j = 0; j < VN; j += 4) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + dd + j), b4 = *reinterpret_cast<const float4*>(beta + dd + j);
+            gm[i][j] = g4.x; gm[i][j + 1] = g4.y; gm[i][j + 2] = g4.z; gm[i][j + 3] = g4.w;
+            bt[i][j] = b4.x; bt[i][j + 1] = b4.y; bt[i][j + 2] = b4.z; bt[i][j + 3] = b4.w;
+        }
+    }
+    float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < VN; ++j) s += v[i][j];
+    for (int i = 0; i < NV; ++i) {
+        if (live[i]) {
+#pragma unroll
+            for (int j = 0; j < VN; ++j) { if (y) v[i][j] += b[i][j]; s += v[i][j]; }
         }
     }
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int d = (lane + i * 64) * VN;
-        if (d < D) {
+        if (live[i]) {
 #pragma unroll
             for (int j = 0; j < VN; ++j) { const float a = v[i][j] - mean; q += a * a; }
         }
@@ -89,12 +97,11 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     T* o = out + (size_t)r * D;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int d = (lane + i * 64) * VN;
-        if (d < D) {
+        if (live[i]) {
             float w[VN];
 #pragma unroll
-            for (int j = 0; j < VN; ++j) w[j] = (v[i][j] - mean) * rstd * gamma[d + j] + beta[d + j];
-            store16(o + d, w);
+            for (int j = 0; j < VN; ++j) w[j] = (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j];
+            store16(o + (lane + i * 64) * VN, w);
         }
     }
 }
@@ -102,6 +109,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
 extern "C" int dh_add_layernorm(const void* x, const void* y, const float* gamma, const float* beta,
                                 void* out, int rows, int D, float eps, int dtype, void* stream) {
     DH_REQUIRE(x && gamma && beta && out && rows > 0 && D > 0 && (D % 8) == 0 && D <= 4096);
+    DH_REQUIRE(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0);
     DhProfScope prof("dh_add_layernorm", 0.0, 0.0, stream);
     const dim3 grid(dh_cdiv(rows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
@@ -109,7 +117,7 @@ extern "C" int dh_add_layernorm(const void* x, const void* y, const float* gamma
                                      (const T*)y, gamma, beta, (T*)out, rows, D, eps)
     DH_DISPATCH_T(dtype, {
         const int per_pass = 64 * Vec16<T>::N;
-        if (D <= 2 * per_pass) DH_LN(2); else if (D <= 4 * per_pass) DH_LN(4);
+        if (D <= per_pass) DH_LN(1); else if (D <= 2 * per_pass) DH_LN(2); else if (D <= 4 * per_pass) DH_LN(4);
         else if (D <= 8 * per_pass) DH_LN(8); else DH_LN(16);
     });
 #undef DH_LN
