@@ -297,6 +297,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             if (lq == 0 && m < p.M) p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;
         }
     }
+    // bf16 output with a residual: this thread's residual chunks (one 16-byte chunk per epilogue iteration) are requested
+    // NOW, so they are in flight while the tile is staged through LDS -- loaded inside the loop below each of them
+    // cost a full memory round trip (load, wait, add, store, next)
+    constexpr int CHUNKS = BN / 8;                        // 16-byte bf16 chunks per tile row
+    constexpr int EP_IT = (BM * CHUNKS + NT - 1) / NT;
+    const bool fast = ((p.ldc & 7) == 0) && (!p.res || (p.ldres & 7) == 0);
+    uint4 rq[EP_IT];
+    if (!p.out_f32 && p.res && fast) {
+#pragma unroll
+        for (int it = 0; it < EP_IT; ++it) {
+            const int c = tid + it * NT, row = c / CHUNKS, ch = c - row * CHUNKS;
+            const int m = m0 + row, n = n0 + ch * 8;
+            const bool ok = c < BM * CHUNKS && m < p.M && n + 8 <= p.N;
+            rq[it] = *reinterpret_cast<const uint4*>(p.res + (ok ? (size_t)m * p.ldres + n : 0));
+        }
+    }
     // Stage the fp32 tile in LDS, then finish rows with row-contiguous accesses.  Slot s of row m
     // (16 B = 4 fp32) is stored at slot s ^ (m & (SLOTS-1)): the 16 lanes of a store hit 16 distinct slots.
     constexpr int SLOTS = BN / 4;
@@ -348,10 +364,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         }
         return;
     }
-    constexpr int CHUNKS = BN / 8;                        // 16-byte bf16 chunks per tile row
     uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
-    const bool fast = ((p.ldc & 7) == 0) && (!p.res || (p.ldres & 7) == 0);
-    for (int c = tid; c < BM * CHUNKS; c += NT) {
+#pragma unroll
+    for (int it = 0; it < EP_IT; ++it) {
+        const int c = tid + it * NT;
+        if (c >= BM * CHUNKS) break;
         const int row = c / CHUNKS, ch = c - row * CHUNKS;
         const int m = m0 + row, n = n0 + ch * 8;
         if (m >= p.M || n >= p.N) continue;
@@ -361,10 +378,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
         if (fast && n + 8 <= p.N) {
             if (p.res) {
-                float q[8];
-                load16(reinterpret_cast<const bf16_t*>(p.res + (size_t)m * p.ldres + n), q);
+                const uint32_t w4[4] = {rq[it].x, rq[it].y, rq[it].z, rq[it].w};
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] += q[u];
+                for (int u = 0; u < 4; ++u) {
+                    v[2 * u] += __uint_as_float(w4[u] << 16);
+                    v[2 * u + 1] += __uint_as_float(w4[u] & 0xFFFF0000u);
+                }
             }
             if (p.relu) {
 #pragma unroll
