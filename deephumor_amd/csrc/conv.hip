@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
     // ---- loader roles -------------------------------------------------------------------------
     const int a_co = tid / (BK / AK), a_k = (tid % (BK / AK)) * AK;     // weight row / first k of this thread
     const bool a_ok = co0 + a_co < p.Cout;
-    const float* a_ptr = p.w + (size_t)(co0 + a_co) * p.K;
+    const float* a_ptr = p.w + (size_t)(a_ok ? co0 + a_co : 0) * p.K;
     const int b_px = tid & 127, b_k = (tid >> 7) * 8;
     const int pp = p0 + b_px;
     const bool b_ok = pp < p.P;
@@ -58,8 +58,11 @@ __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
     auto load_slab = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < AK; ++i) {
+            // unconditional loads at clamped offsets, then select: conditional loads are waited for one by one
             const int k = k0 + a_k + i;
-            ra[i] = (a_ok && k < p.K) ? a_ptr[k] : 0.f;
+            const bool ok = a_ok && k < p.K;
+            const float t = a_ptr[ok ? k : 0];
+            ra[i] = ok ? t : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -68,7 +71,8 @@ __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
             KDecode<KS>::run(k, ci, kh, kw);
             const int ih = ih0 + kh, iw = iw0 + kw;
             const bool ok = b_ok && k < p.K && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            rb[i] = ok ? b_ptr[(size_t)ci * HW + ih * p.W + iw] : 0.f;
+            const float t = b_ptr[ok ? (size_t)ci * HW + ih * p.W + iw : 0];
+            rb[i] = ok ? t : 0.f;
         }
     };
     auto store_slab = [&]() {
@@ -224,8 +228,15 @@ __global__ __launch_bounds__(256) void pack_nchw_to_nhwc8_kernel(const float* __
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
         const size_t n = i / HW, p = i - n * HW;
         float v[8];
+        // channels 0..3 at a clamped channel index without a branch (RGB: one memory round trip for the pixel instead
+        // of one per conditional load), 4..7 only if the input really has them
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = c < C ? x[(n * C + c) * HW + p] : 0.f;
+        for (int c = 0; c < 4; ++c) {
+            const float t = x[(n * C + min(c, C - 1)) * HW + p];
+            v[c] = c < C ? t : 0.f;
+        }
+#pragma unroll
+        for (int c = 4; c < 8; ++c) v[c] = c < C ? x[(n * C + c) * HW + p] : 0.f;
         store16(y + i * 8, v);
     }
 }

@@ -51,15 +51,18 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(
     auto load_slab = [&](int k0) {
 #pragma unroll
         for (int p = 0; p < PA; ++p) {
+            // unconditional load at a clamped offset, then select: conditional loads are waited for one by one
             const int m = m0 + lrow + 32 * p, k = k0 + lk;
-            ra[p] = (m < M && k < K) ? *reinterpret_cast<const float4*>(A + (size_t)m * lda + k)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = m < M && k < K;
+            const float4 t = *reinterpret_cast<const float4*>(A + (ok ? (size_t)m * lda + k : 0));
+            ra[p] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int p = 0; p < PB; ++p) {
             const int n = n0 + lrow + 32 * p, k = k0 + lk;
-            rb[p] = (n < N && k < K) ? *reinterpret_cast<const float4*>(W + (size_t)n * ldw + k)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = n < N && k < K;
+            const float4 t = *reinterpret_cast<const float4*>(W + (ok ? (size_t)n * ldw + k : 0));
+            rb[p] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto store_slab = [&]() {
