@@ -52,3 +52,32 @@ def generate_sharded(generate_fn, n_total, group=None):
     lo, hi = shard_range(n_total, rank, world)
     tokens, lengths = generate_fn(lo, hi)
     return gather_captions(tokens, lengths, n_total, group)
+
+
+def gather_rows(x, n_total, group=None):
+    """``x [n_local, ...]`` (any dtype: logits, log-probabilities, perplexities) -> ``[n_total, ...]`` on every
+    rank in global row order: the north star's "all-gather of logits" -- one ``all_gather_into_tensor`` per call on
+    shards padded to the largest one (contiguous ``shard_range`` shards)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    world = dist.get_world_size(group)
+    cap = -(-n_total // world)
+    packed = torch.zeros((cap,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    packed[:x.shape[0]] = x
+    out = torch.empty((world * cap,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, packed.contiguous(), group=group)
+    rows = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        rows.append(out[r * cap:r * cap + (hi - lo)])
+    return torch.cat(rows, 0)
+
+
+def score_sharded(score_fn, n_total, group=None):
+    """Teacher-forced scoring sharded by caption batch: ``score_fn(lo, hi) -> [hi - lo, ...]`` (e.g. per-caption
+    perplexities from ``experiments.scoring.score_captions`` on captions ``lo..hi``) on this rank's contiguous
+    shard, then one all-gather so that every rank holds all ``n_total`` rows."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    lo, hi = shard_range(n_total, rank, world)
+    return gather_rows(score_fn(lo, hi), n_total, group)

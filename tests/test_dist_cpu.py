@@ -53,3 +53,24 @@ def test_two_ranks_gather_in_global_order():
             for r in range(2):
                 toks, lens = ret[r]
                 assert torch.equal(toks, want_t) and torch.equal(lens, want_l)
+
+
+def _score_worker(rank, world, port, n_total, ret):
+    from deephumor_amd.dist import score_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    full = score_sharded(lambda lo, hi: torch.arange(lo, hi, dtype=torch.float32)[:, None] * torch.tensor([1.0, 0.5, 0.25]), n_total)
+    ret[rank] = full.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_score_rows_gather_in_global_order():
+    """gather_rows / score_sharded (the scoring path's all-gather of float rows), even and uneven shards."""
+    for n_total in (10, 9):
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_score_worker, args=(2, _free_port(), n_total, ret), nprocs=2, join=True)
+            want = torch.arange(n_total, dtype=torch.float32)[:, None] * torch.tensor([1.0, 0.5, 0.25])
+            for r in range(2):
+                assert torch.equal(ret[r], want)
