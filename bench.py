@@ -73,6 +73,48 @@ def kind_of(workload):
     return {"c2": "CaptioningLSTM", "c3": "CaptioningTransformer", "c5": "CaptioningTransformerWithLabels"}[workload]
 
 
+def run_score(args, rank, world, dev, dtype, kind):
+    """teacher-forced scoring (per-caption perplexity) of a caption corpus with per-template
+    encoder-feature caching: 300 templates x 30 captions of 32 tokens, captions sharded over the ranks, one
+    all-gather of the perplexities."""
+    import numpy as np
+    from deephumor_amd.dist import score_sharded
+    from deephumor_amd.experiments.scoring import score_captions
+    from deephumor_amd.synth import synth_images
+    model, sd, hp = build_model(kind, dev, dtype)
+    n_tpl, per = 300, 30
+    n_total = n_tpl * per
+    images = synth_images(n_tpl, seed=3).to(dev)
+    g = np.random.Generator(np.random.Philox(key=[7, 0]))
+    lengths = torch.from_numpy(g.integers(8, 33, size=(n_total,)).astype(np.int64))
+    caps = torch.from_numpy(g.integers(6, V_WORD, size=(n_total, 32)).astype(np.int64))
+    for r in range(n_total):
+        caps[r, lengths[r] - 1] = 3                 # <eos>
+        caps[r, lengths[r]:] = 0
+    tpl = torch.arange(n_total, dtype=torch.int64) // per
+    caps, lengths_d = caps.to(dev), lengths.to(dev)
+
+    def run():
+        return score_sharded(lambda lo, hi: score_captions(model, images, tpl[lo:hi], caps[lo:hi], lengths_d[lo:hi]), n_total)
+
+    pp = run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = max(1, args.steps)
+    for _ in range(reps):
+        pp = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    return {"workload": f"teacher-forced scoring, {kind_of(kind)}, 300 templates x 30 captions x 32 tokens, V={V_WORD}",
+            "value": n_total * reps / dt, "unit": "captions scored/s", "passes": reps, "ms_per_pass": dt / reps * 1e3,
+            "captions": n_total, "mean_perplexity": float(pp.float().mean()), "dtype": dtype}
+
+
 def run_c5(args, rank, world, dev, dtype):
     """BASELINE config 5: the full 300-template sweep (ImageLabelEncoder + CaptioningTransformer, beam 10), templates
     sharded 38/38/38/38/37/37/37/37 over 8 ranks (all 300 on one), uneven shards gathered with one padded all_gather."""
@@ -282,7 +324,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE configs: 256)")
-    ap.add_argument("--workload", choices=["c2", "c3", "both", "c5"], default="both")
+    ap.add_argument("--workload", choices=["c2", "c3", "both", "c5", "score-c2", "score-c3"], default="both")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images for the CPU baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (eager by default: "
@@ -306,6 +348,16 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if args.workload.startswith("score-"):
+        res = run_score(args, rank, world, dev, args.dtype, args.workload.split("-")[1])
+        if rank == 0:
+            print(json.dumps(dict(res, metric="captions scored/sec (teacher-forced perplexity, 32 tokens)", n_gpus=world,
+                                  higher_is_better=True, scaling="strong", vs_baseline=None, data="synthetic")))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     if args.workload == "c5":
         res = run_c5(args, rank, world, dev, args.dtype)
         if rank == 0:
