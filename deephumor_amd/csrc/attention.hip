@@ -23,6 +23,7 @@ struct AttnParams {
     T* out;
     int rows_per_img, row_mult, rows_total, L, D, dh, lcap, pad_index;
     float scale;
+    int row_si;                           // compact row of (image, w) = img * row_si + w (decode: rows_per_img; prefill chunks: n_pos)
 };
 
 template <typename T, bool CROSS>
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams<T> p) {
     constexpr int VN = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rc = img * p.rows_per_img + w, rl = rc * p.row_mult;
+    const int rc = img * p.row_si + w, rl = rc * p.row_mult;
     const int dh = p.dh, D = p.D, L = p.L, t = L - 1;
     float* qs = smem + (size_t)w * (dh + 2 * p.lcap);
     float* sc = qs + dh;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p)
     constexpr int LPK = DH / 8, KPI = 64 / LPK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rc = img * p.rows_per_img + w, rl = rc * p.row_mult;
+    const int rc = img * p.row_si + w, rl = rc * p.row_mult;
     const int D = p.D, L = p.L, t = L - 1;
     const int kg = lane / LPK, dc = lane % LPK;
     float* sc = smem + (size_t)w * 2 * p.lcap;
@@ -247,7 +248,7 @@ template <typename T, bool CROSS, int DH, int NIT>
 __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) {
     constexpr int LPK = DH / 8, KPI = 64 / LPK;
     const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rc = img * p.rows_per_img + w, rl = rc * p.row_mult;
+    const int rc = img * p.row_si + w, rl = rc * p.row_mult;
     const int D = p.D, L = p.L, t = L - 1;
     const int kg = lane / LPK, dc = lane % LPK;
 
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(1024) void attn_cross_lds_kernel(AttnParams<T> p) {
         const uint4 val = *reinterpret_cast<const uint4*>(p.kv + (size_t)(img * S + j) * (2 * D) + (isv ? D : 0) + (h0 + hh) * DH + ch * VN);
         *reinterpret_cast<uint4*>((isv ? vs : ks) + ((size_t)hh * S + j) * ROW + ch * VN) = val;
     }
-    const int rc = img * p.rows_per_img + w;
+    const int rc = img * p.row_si + w;
 #pragma unroll
     for (int hh = 0; hh < HPB; ++hh) qs[hh * 64 + lane] = ldf(p.q + (size_t)rc * p.ldq + (h0 + hh) * DH + lane);
     const bool masked = lane < S && p.keymask[img * S + lane] != 0;
@@ -457,7 +458,7 @@ static void launch_self(const void* qkv, void* kcache, void* vcache, const int32
     p.knew = (const T*)qkv + D; p.vnew = (const T*)qkv + 2 * D; p.ldnew = 3 * D;
     p.kc = (T*)kcache; p.vc = (T*)vcache; p.src = src; p.src_ld = src_ld;
     p.tokens = tokens; p.tok_ld = tok_ld; p.out = (T*)out;
-    p.rows_per_img = rows_per_img; p.row_mult = row_mult; p.rows_total = rows_total;
+    p.rows_per_img = rows_per_img; p.row_mult = row_mult; p.rows_total = rows_total; p.row_si = rows_per_img;
     p.L = t + 1; p.D = D; p.dh = D / n_heads; p.lcap = (t + 1 + 3) & ~3; p.pad_index = pad_index; p.scale = scale;
     if (launch_fast<T, false>(p, n_img, n_heads, rows_per_img, s)) return;
     const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
@@ -481,10 +482,10 @@ extern "C" int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, 
 
 template <typename T>
 static void launch_cross(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out, int n_img,
-                         int rows_per_img, int S, int D, int n_heads, float scale, hipStream_t s) {
+                         int rows_per_img, int S, int D, int n_heads, float scale, hipStream_t s, int row_si = 0) {
     AttnParams<T> p{};
     p.q = (const T*)q; p.ldq = ldq; p.kv = (const T*)kv; p.keymask = keymask; p.out = (T*)out;
-    p.rows_per_img = rows_per_img; p.row_mult = 1; p.rows_total = 0;
+    p.rows_per_img = rows_per_img; p.row_mult = 1; p.rows_total = 0; p.row_si = row_si > 0 ? row_si : rows_per_img;
     p.L = S; p.D = D; p.dh = D / n_heads; p.lcap = (S + 3) & ~3; p.pad_index = -1; p.scale = scale;
     if (p.dh == 64 && S <= 64) {                         // the caption models' shape: K|V staged once per (image, head group)
         constexpr int VN = Vec16<T>::N;
@@ -511,5 +512,115 @@ extern "C" int dh_attn_cross_decode(const void* q, int ldq, const void* kv, cons
                      esz_ * n_img * (S * 2.0 * D + rows_per_img * 2.0 * D), stream);
     DH_DISPATCH_T(dtype, launch_cross<T>(q, ldq, kv, keymask, out, n_img, rows_per_img, S, D, n_heads, scale,
                                          (hipStream_t)stream));
+    DH_LAUNCH_CHECK();
+}
+
+
+// ---- teacher-forced (prefill) attention: every position of every sequence in one launch ---------------------------
+// Rows are sequence-major: row n * n_pos + t holds position t of sequence n, qkv [rows, 3D] comes from ONE batched
+// projection GEMM.  A wave owns (row, head) as in attn_decode_reg_kernel; the history of position t is simply rows
+// n * n_pos + 0 .. t of the same matrix (causal mask = the key count), so there is no KV cache and no ancestor table.
+template <typename T, int NIT>
+__global__ __launch_bounds__(256) void attn_self_prefill_kernel(const T* __restrict__ qkv, const int32_t* __restrict__ tokens,
+                                                                 int tok_ld, T* __restrict__ out, int rows, int n_pos, int D,
+                                                                 float scale, int pad_index) {
+    constexpr int DH = 64, LPK = DH / 8, KPI = 64 / LPK;
+    const int rc = blockIdx.x * 4 + (threadIdx.x >> 6), h = blockIdx.y, lane = threadIdx.x & 63;
+    if (rc >= rows) return;
+    const int n = rc / n_pos, t = rc - n * n_pos, L = t + 1;
+    const int kg = lane / LPK, dc = lane % LPK;
+    const size_t ld = 3 * (size_t)D;
+    int aux[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) aux[it] = 0;
+    if (tokens && t > 0) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) aux[it] = tokens[(size_t)n * tok_ld + min(max(it * KPI + kg - 1, 0), t - 1)];
+    }
+    bool live[NIT], masked[NIT];
+    Raw8<T> kr[NIT], vr[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int j = it * KPI + kg;
+        live[it] = j < L;
+        masked[it] = live[it] && j >= 1 && tokens && aux[it] == pad_index;
+        const T* kp = qkv + ((size_t)n * n_pos + min(j, t)) * ld + D + h * DH + dc * 8;
+        raw_load(kp, kr[it]);
+        raw_load(kp + D, vr[it]);
+    }
+    float qv[8];
+    load8(qkv + (size_t)rc * ld + h * DH + dc * 8, qv);
+    __builtin_amdgcn_sched_barrier(0);
+    float e[NIT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        float kk[8];
+        raw_unpack(kr[it], kk);
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a = fmaf(kk[u], qv[u], a);
+        a = sum8(a);
+        e[it] = !live[it] ? -INFINITY : (masked[it] ? -1e8f : a / scale);
+        mx = fmaxf(mx, e[it]);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        e[it] = live[it] ? expf(e[it] - mx) : 0.f;
+        sum += e[it];
+    }
+    sum = wave_sum(sum) / (float)LPK;
+    float o8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) o8[u] = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        float vv[8];
+        raw_unpack(vr[it], vv);
+        const float pj = e[it] / sum;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) o8[u] = fmaf(pj, vv[u], o8[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int s2 = LPK; s2 < 64; s2 <<= 1) o8[u] += __shfl_xor(o8[u], s2, 64);
+    if (kg == 0) store8(out + (size_t)rc * D + h * DH + dc * 8, o8);
+}
+
+extern "C" int dh_attn_self_prefill(const void* qkv, const int32_t* tokens, int tok_ld, void* out, int n_seq, int n_pos,
+                                    int D, int n_heads, float scale, int pad_index, int dtype, void* stream) {
+    DH_REQUIRE(qkv && out && n_seq > 0 && n_pos > 0 && n_heads > 0 && D == n_heads * 64);
+    DH_REQUIRE(n_pos <= (dtype == DH_F32 ? 40 : 56) && (pad_index < 0 || n_pos == 1 || tokens));
+    const int rows = n_seq * n_pos;
+    const double esz_ = dtype == DH_F32 ? 4.0 : 2.0;
+    DhProfScope prof("dh_attn_self_prefill", 2.0 * rows * (n_pos + 1) * D, esz_ * rows * 4.0 * D, stream);
+    const dim3 grid(dh_cdiv(rows, 4), n_heads), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == DH_F32)
+        hipLaunchKernelGGL((attn_self_prefill_kernel<float, 5>), grid, block, 0, s, (const float*)qkv, tokens, tok_ld, (float*)out,
+                           rows, n_pos, D, scale, pad_index);
+    else
+        hipLaunchKernelGGL((attn_self_prefill_kernel<bf16_t, 7>), grid, block, 0, s, (const bf16_t*)qkv, tokens, tok_ld,
+                           (bf16_t*)out, rows, n_pos, D, scale, pad_index);
+    DH_LAUNCH_CHECK();
+}
+
+// Cross-attention for sequence-major prefill rows (row n * n_pos + t): the decode kernels take at most
+// DH_BEAM_MAX_BEAMS query rows per image and launch, so the positions go in chunks of that many.
+extern "C" int dh_attn_cross_prefill(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out, int n_img,
+                                     int n_pos, int S, int D, int n_heads, float scale, int dtype, void* stream) {
+    DH_REQUIRE(q && kv && keymask && out && n_img > 0 && n_pos > 0 && S > 0 && n_heads > 0 && D % n_heads == 0);
+    DH_REQUIRE(((D / n_heads) % 8) == 0 && ldq >= D);
+    const size_t esz = dtype == DH_F32 ? 4 : 2;
+    DhProfScope prof("dh_attn_cross_prefill", 4.0 * n_img * n_pos * S * D, (double)esz * n_img * (S * 2.0 * D + n_pos * 2.0 * D), stream);
+    for (int t0 = 0; t0 < n_pos; t0 += DH_BEAM_MAX_BEAMS) {
+        const int cnt = n_pos - t0 < DH_BEAM_MAX_BEAMS ? n_pos - t0 : DH_BEAM_MAX_BEAMS;
+        const char* qc = (const char*)q + (size_t)t0 * ldq * esz;
+        char* oc = (char*)out + (size_t)t0 * D * esz;
+        DH_DISPATCH_T(dtype, launch_cross<T>(qc, ldq, kv, keymask, oc, n_img, cnt, S, D, n_heads, scale, (hipStream_t)stream, n_pos));
+    }
     DH_LAUNCH_CHECK();
 }

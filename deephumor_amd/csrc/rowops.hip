@@ -47,6 +47,40 @@ extern "C" int dh_embed_rows(const void* tok_emb, const void* pos_emb, const voi
     DH_LAUNCH_CHECK();
 }
 
+// Teacher-forced (prefill) form of embed_rows: every position of every sequence, rows sequence-major
+// (row n * n_pos + t): x = (t == 0 ? start_emb[n] : tok_emb[tokens[n, t-1]]) / scale + pos_emb[t].
+template <typename T>
+__global__ __launch_bounds__(256) void embed_prefill_kernel(
+    const T* __restrict__ tok_emb, const T* __restrict__ pos_emb, const T* __restrict__ start_emb,
+    const int32_t* __restrict__ tokens, int tok_ld, T* __restrict__ x, int rows, int n_pos, int D, float scale) {
+    constexpr int VN = Vec16<T>::N;
+    const int rc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (rc >= rows) return;
+    const int n = rc / n_pos, t = rc - n * n_pos;
+    const T* src = t == 0 ? start_emb + (size_t)n * D : tok_emb + (size_t)tokens[(size_t)n * tok_ld + t - 1] * D;
+    const T* pe = pos_emb + (size_t)t * D;
+    T* dst = x + (size_t)rc * D;
+    for (int d = lane * VN; d < D; d += 64 * VN) {
+        float a[VN], b[VN], o[VN];
+        load16(src + d, a);
+        load16(pe + d, b);
+#pragma unroll
+        for (int i = 0; i < VN; ++i) o[i] = a[i] / scale + b[i];
+        store16(dst + d, o);
+    }
+}
+
+extern "C" int dh_embed_prefill(const void* tok_emb, const void* pos_emb, const void* start_emb, const int32_t* tokens,
+                                int tok_ld, void* x, int n_seq, int n_pos, int D, float scale, int dtype, void* stream) {
+    DH_REQUIRE(tok_emb && pos_emb && start_emb && x && n_seq > 0 && n_pos > 0 && (n_pos == 1 || tokens) && (D % 8) == 0);
+    DhProfScope prof("dh_embed_prefill", 0.0, 0.0, stream);
+    const int rows = n_seq * n_pos;
+    DH_DISPATCH_T(dtype, hipLaunchKernelGGL(embed_prefill_kernel<T>, dim3(dh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
+                                            (const T*)tok_emb, (const T*)pos_emb, (const T*)start_emb, tokens, tok_ld, (T*)x,
+                                            rows, n_pos, D, scale));
+    DH_LAUNCH_CHECK();
+}
+
 // out = LayerNorm(x + y): mean and biased variance over the row in two in-register passes
 // (same formulation as torch's RowwiseMoments: var = E[(v-mean)^2]), rstd = 1/sqrt(var+eps).
 template <typename T, int NV>   // 16-byte vectors per lane kept in registers

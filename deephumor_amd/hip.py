@@ -70,6 +70,9 @@ SIGNATURES = {
     "dh_enc_key_mask": [_P, _P, _I, _I, _I, _P],
     "dh_lstm_prepare": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_lstm_cell": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_embed_prefill": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _F, _I, _P],
+    "dh_attn_self_prefill": [_P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P],
+    "dh_attn_cross_prefill": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_lstm_layer_fused": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
@@ -387,6 +390,32 @@ def attn_cross_decode(q, kv, keymask, out, n_img, rows_per_img, s, d, n_heads, s
     _launch("dh_attn_cross_decode", _ptr(q), q.stride(0), _ptr(kv), _ptr(keymask), _ptr(out), n_img,
                                        rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream(),
             nbytes=float(q.element_size()) * n_img * (s * 2 * d + rows_per_img * 2 * d), flops=4.0 * n_img * rows_per_img * s * d)
+    return out
+
+
+def embed_prefill(tok_emb, pos_emb, start_emb, tokens, n_seq, n_pos, scale):
+    """Sequence-major rows [n_seq * n_pos, D] of all positions (teacher forcing)."""
+    _dev(tok_emb, pos_emb, start_emb, tokens)
+    d = tok_emb.shape[1]
+    x = torch.empty((n_seq * n_pos, d), dtype=tok_emb.dtype, device=tok_emb.device)
+    _launch("dh_embed_prefill", _ptr(tok_emb), _ptr(pos_emb), _ptr(start_emb), _ptr(tokens), tokens.stride(0), _ptr(x), n_seq,
+            n_pos, d, float(scale), _dt(tok_emb), _stream())
+    return x
+
+
+def attn_self_prefill(qkv, tokens, n_seq, n_pos, d, n_heads, scale, pad_index):
+    _dev(qkv, tokens)
+    out = torch.empty((n_seq * n_pos, d), dtype=qkv.dtype, device=qkv.device)
+    _launch("dh_attn_self_prefill", _ptr(qkv), _ptr(tokens), tokens.stride(0), _ptr(out), n_seq, n_pos, d, n_heads,
+            float(scale), pad_index, _dt(qkv), _stream())
+    return out
+
+
+def attn_cross_prefill(q, kv, keymask, n_img, n_pos, s, d, n_heads, scale):
+    _dev(q, kv, keymask)
+    out = torch.empty((n_img * n_pos, d), dtype=q.dtype, device=q.device)
+    _launch("dh_attn_cross_prefill", _ptr(q), q.stride(0), _ptr(kv), _ptr(keymask), _ptr(out), n_img, n_pos, s, d, n_heads,
+            float(scale), _dt(q), _stream())
     return out
 
 

@@ -74,6 +74,19 @@ int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, v
 int dh_normalize_u8_hwc(const uint8_t* x, const float* mean, const float* stdv, float* y, int N, int H, int W, int C,
                         void* stream);
 
+/* Teacher-forced (prefill) forms of the decoder row kernels -- forward() over all positions at once (transformers.py
+ * DecoderLayer.forward with the causal + pad mask of :471-478).  Rows are sequence-major: row n*n_pos + t.
+ *   dh_embed_prefill      x = (t == 0 ? start_emb[n] : tok_emb[tokens[n, t-1]]) / scale + pos_emb[t]
+ *   dh_attn_self_prefill  causal self-attention over qkv [rows, 3D] of ONE projection GEMM (no KV cache); head dim 64,
+ *                         n_pos <= 56 (bf16) / 40 (fp32); key j >= 1 masked where tokens[n, j-1] == pad_index
+ *   dh_attn_cross_prefill every position of image n against that image's S patch keys kv [n_img*S, 2D] */
+int dh_embed_prefill(const void* tok_emb, const void* pos_emb, const void* start_emb, const int32_t* tokens, int tok_ld,
+                     void* x, int n_seq, int n_pos, int D, float scale, int dtype, void* stream);
+int dh_attn_self_prefill(const void* qkv, const int32_t* tokens, int tok_ld, void* out, int n_seq, int n_pos, int D,
+                         int n_heads, float scale, int pad_index, int dtype, void* stream);
+int dh_attn_cross_prefill(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out, int n_img, int n_pos,
+                          int S, int D, int n_heads, float scale, int dtype, void* stream);
+
 /* Channels-last bf16 pools of the bf16 path: MaxPool2d(3,2,1) x [N,H,W,C] -> [N,Ho,Wo,C];
  * AdaptiveAvgPool2d(1) x [N,HW,C] -> y [N,C].  C % 8 == 0.  DH_BF16 only. */
 int dh_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream);

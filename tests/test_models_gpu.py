@@ -245,3 +245,24 @@ def test_released_checkpoint_hyperparameters(kind, hp, images, tmp_path):
     with torch.no_grad():
         tb, _ = again.bfloat16().generate_batch(images[:2].cuda(), max_len=20, beam_size=1, top_k=1)
     assert tb[:, 0].cpu().tolist() == toks[:, 0].cpu().tolist()
+
+
+@pytest.mark.parametrize("kind,bf16", [("CaptioningTransformerBase", False), ("CaptioningTransformerWithLabels", False),
+                                       ("CaptioningTransformer", True), ("CaptioningTransformerBase", True)])
+def test_forward_prefill_equals_position_by_position(kind, bf16, images):
+    """forward() in prefill form (batched GEMMs, one causal-attention launch per layer, cross-attention in position
+    chunks) against the same forward run position by position on the decode engine (KV cache): same logits."""
+    model, _, _ = build(kind)
+    if bf16:
+        model = model.bfloat16()
+    cap, lengths, labels = captions_and_lengths()
+    args = (images.cuda(), cap.cuda(), lengths) + ((labels.cuda(),) if "WithLabels" in kind else ())
+    dec = model.decoder
+    with torch.no_grad():
+        assert dec._prefill_ok(dec._get_plan(), cap.shape[1] + 1 if kind != "CaptioningTransformer" else 49)
+        fast = model(*args)
+        dec._prefill_ok = lambda plan, seq: False
+        slow = model(*args)
+    assert fast.shape == slow.shape
+    tol = 2e-2 if bf16 else 2e-5
+    np.testing.assert_allclose(fast.cpu().numpy(), slow.cpu().numpy(), atol=tol, rtol=0)
