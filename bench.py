@@ -95,7 +95,7 @@ def run_score(args, rank, world, dev, dtype, kind):
     caps, lengths_d = caps.to(dev), lengths.to(dev)
 
     def run():
-        return score_sharded(lambda lo, hi: score_captions(model, images, tpl[lo:hi], caps[lo:hi], lengths_d[lo:hi]), n_total)
+        return score_sharded(lambda lo, hi: score_captions(model, images, tpl[lo:hi], caps[lo:hi], lengths_d[lo:hi], batch_size=args.score_batch), n_total)
 
     pp = run()
     torch.cuda.synchronize()
@@ -327,6 +327,7 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c3", "both", "c5", "score-c2", "score-c3"], default="both")
     ap.add_argument("--cpu-sample", type=int, default=8, help="images for the CPU baseline leg (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--score-batch", type=int, default=1024, help="captions per teacher-forced batch (score-* workloads)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (eager by default: "
                     "the in-library event profiler of the roofline line needs real launches)")
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",

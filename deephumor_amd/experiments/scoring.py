@@ -32,7 +32,7 @@ def score_captions(model, template_images, template_index, captions, lengths, la
             tgt = captions[lo:hi]                       # tokens + <eos>, zero padded (datasets.py:72-79, no <bos>)
             inp = tgt[:, :-1]                           # trainer.py:69-73: model(images, captions[:, :-1], lengths)
             if spatial is not None:
-                logits = model.decoder(inp, enc_out=spatial.index_select(0, idx), start_emb=emb)
+                logits = model.decoder(inp, enc_out=spatial.index_select(0, idx), start_emb=emb, num_positions=tgt.shape[1])
             elif hasattr(model.decoder, "lstm"):
                 logits = model.decoder(emb, inp, None)
             else:

@@ -196,7 +196,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                                         run.rows_total, t, x_out=x_out, logits=logits, group_max=group_max)
         return x_out if x_out is not None else sc["x"]
 
-    def _forward(self, x, enc_out, start_emb):
+    def _forward(self, x, enc_out, start_emb, num_positions=None):
         self._check_mode()
         plan = self._get_plan()
         bs, dec_len = x.shape
@@ -207,8 +207,11 @@ class _IncrementalDecoder(_Planned, nn.Module):
         seq = dec_len if enc_out is None else max(dec_len, enc_out.shape[1])          # transformers.py:450
         if seq > self.pos_embedding.num_embeddings:
             raise IndexError("index out of range in self")                            # pos-embedding lookup
+        if num_positions is not None:                     # causal: positions >= num_positions cannot influence the rest
+            seq = max(1, min(seq, int(num_positions)))
         tokens = torch.full((bs, max(seq - 1, 1)), self.pad_index, dtype=torch.int32, device=dev)
-        tokens[:, :x.shape[1]] = x.to(torch.int32)
+        ncopy = min(x.shape[1], tokens.shape[1])
+        tokens[:, :ncopy] = x[:, :ncopy].to(torch.int32)
         if self._prefill_ok(plan, seq):
             return self._forward_prefill(plan, tokens, enc_out, start_emb.to(plan["dtype"]).contiguous(), bs, seq)
         helper_src = (torch.arange(bs, dtype=torch.int32, device=dev))[:, None].expand(bs, seq).contiguous()
@@ -314,9 +317,12 @@ class TransformerDecoder(_IncrementalDecoder):
     _layer_cls = DecoderLayer
     _cross = True
 
-    def forward(self, x, enc_out, start_emb=None):
-        """Teacher-forced logits ``[bs, max(len(x)+1, S), num_tokens]`` (transformers.py:432-490)."""
-        return self._forward(x, enc_out, start_emb)
+    def forward(self, x, enc_out, start_emb=None, *, num_positions=None):
+        """Teacher-forced logits ``[bs, max(len(x)+1, S), num_tokens]`` (transformers.py:432-490).  The reference pads
+        the decoder input up to the number of image patches (:450), so a 32-token caption costs 49 positions;
+        ``num_positions`` (not in the reference) returns only the first ``num_positions`` of them -- identical values,
+        the mask is causal -- for callers such as the perplexity scorer that never look further."""
+        return self._forward(x, enc_out, start_emb, num_positions)
 
     def generate_batch(self, start_emb, enc_out, caption=None, max_len=25, temperature=1.0, beam_size=10,
                        top_k=50, eos_index=3, **kw):

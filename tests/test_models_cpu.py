@@ -33,7 +33,9 @@ def test_signatures_follow_the_reference():
     assert names(M.LSTMDecoder.__init__)[1:] == ["num_tokens", "emb_dim", "hidden_size", "num_layers", "dropout", "embedding"]
     assert names(M.LSTMDecoder.generate)[1:8] == ["image_emb", "caption", "max_len", "temperature", "beam_size", "top_k", "eos_index"]
     assert names(M.TransformerDecoder.__init__)[1:] == ["num_tokens", "hid_dim", "n_layers", "n_heads", "pf_dim", "dropout", "pad_index", "max_len"]
-    assert names(M.TransformerDecoder.forward)[1:] == ["x", "enc_out", "start_emb"]
+    assert names(M.TransformerDecoder.forward)[1:4] == ["x", "enc_out", "start_emb"]
+    extra = [p for p in inspect.signature(M.TransformerDecoder.forward).parameters.values()][4:]
+    assert all(p.kind is inspect.Parameter.KEYWORD_ONLY for p in extra)        # extensions never shift the positionals
     assert names(M.TransformerDecoder.generate)[1:9] == ["start_emb", "enc_out", "caption", "max_len", "temperature", "beam_size", "top_k", "eos_index"]
     assert names(M.SelfAttentionTransformerDecoder.generate)[1:8] == ["start_emb", "caption", "max_len", "temperature", "beam_size", "top_k", "eos_index"]
     assert names(M.CaptioningLSTM.__init__)[1:] == ["num_tokens", "emb_dim", "hidden_size", "num_layers", "enc_dropout", "dec_dropout"]
