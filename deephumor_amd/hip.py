@@ -217,7 +217,8 @@ def _dt(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise TypeError(f"unsupported dtype {t.dtype}")
+    raise TypeError(f"unsupported dtype {t.dtype}: the kernels compute in fp32 (parity path) or bf16 (matrix cores, fp32 "
+                    "accumulation) -- use model.float() or model.bfloat16(); fp16 checkpoints load into either")
 
 
 # ------------------------------------------------------------------------------------------------
