@@ -293,17 +293,19 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
     res["kernel_breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])}
     res["kernel_ms_sum"] = round(total_ms, 3)
     res["roofline"] = roofline_from(summary, prefer=dominant, dtype=dtype)
-    try:     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process)
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_hbm_traffic.json")))
-        ent = pmc.get(workload, {}).get(res["roofline"]["kernel"]) if dtype == "bf16" else None
-        if ent:
-            res["roofline"]["traffic"] = ent["traffic_bytes_per_launch"]
-            res["roofline"]["traffic_source"] = "profiles/r1/pmc_hbm_traffic.json (" + ent["note"] + ")"
-    except (OSError, ValueError, KeyError, TypeError):
-        pass
     if workload == "c3":
         res["roofline_self_attention"] = roofline_from(summary, prefer="dh_attn_self_decode", dtype=dtype)
         res["roofline_cross_attention"] = roofline_from(summary, prefer="dh_attn_cross_decode", dtype=dtype)
+    try:     # HBM traffic of those kernels from the committed PMC passes (rocprofv3 cannot run inside this process)
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_hbm_traffic.json")))
+        for key in ("roofline", "roofline_self_attention", "roofline_cross_attention"):
+            rl = res.get(key)
+            ent = pmc.get(workload, {}).get(rl["kernel"]) if (rl and dtype == "bf16") else None
+            if ent:
+                rl["traffic"] = ent["traffic_bytes_per_launch"]
+                rl["traffic_source"] = "profiles/r1/pmc_hbm_traffic.json (" + ent["note"] + ")"
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
     if rank == 0 and with_cpu:
         # the parity gate is the fp32 path: bit-exact greedy ids vs the CPU reference path
         m32 = model if dtype == "f32" else build_model(workload, dev, "f32")[0]
