@@ -391,6 +391,9 @@ def main():
         "hipgraph_replay": res.get("hipgraph_replay"),
         "kernel_breakdown_ms_per_step": res["kernel_breakdown_ms_per_step"],
     }
+    if main_wl == "c3":
+        line["roofline_self_attention"] = res.get("roofline_self_attention")
+        line["roofline_cross_attention"] = res.get("roofline_cross_attention")
     if args.workload == "both":
         r3 = run_workload("c3", args, rank, world, dev, max(2, args.steps // 2), 1, with_cpu, args.dtype, main_line=False)
         line["c3"] = {"workload": "C3 CaptioningTransformer 6-layer/8-head (spatial feats), same batch/beam settings",
