@@ -515,6 +515,9 @@ struct VocabParams {
     float* C; int ldc;
     float* gmax; int gmax_ld;
     int M, N, K, tiles_m, tiles_n;
+    // LSE mode (teacher-forced scoring): no logits; per (row, 64-column group) max and sum of exp(logit - max), and the
+    // logit of each row's target column
+    float* gsum; const int64_t* targets; float* tgt_logit;
 };
 
 #define DH_VMCNT_CASE(x) case x: asm volatile("s_waitcnt vmcnt(" #x ")" ::: "memory"); break;
@@ -535,7 +538,7 @@ __device__ __forceinline__ void wait_vmcnt_any(int n) {
     }
 }
 
-template <int NS, int BM, int BN, int WAVES_M, int NW>
+template <int NS, int BM, int BN, int WAVES_M, int NW, bool LSE = false>
 __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1)) void vocab_logits_kernel(VocabParams p) {
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * 128, SLAB = A_BYTES + BN * 128;
@@ -675,6 +678,44 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
         float4 b4[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b4[j] = *reinterpret_cast<const float4*>(bias_lds + (16 * j + 4 * lq) * 4);
+        if constexpr (LSE) {
+            // log-sum-exp partials instead of the logits: group max, sum of exp(logit - group max), target logit
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm0 + 16 * i + l15;
+                const int64_t tcol = m < p.M ? p.targets[m] - (int64_t)(n0 + wn0) : -1;
+                float v[TN][4];
+                float mxv = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float bj[4] = {b4[j].x, b4[j].y, b4[j].z, b4[j].w};
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int n = n0 + wn0 + 16 * j + 4 * lq + rr;
+                        v[j][rr] = n < p.N ? acc[j][i][rr] + bj[rr] : -INFINITY;
+                        mxv = fmaxf(mxv, v[j][rr]);
+                        if (tcol == 16 * j + 4 * lq + rr) p.tgt_logit[m] = v[j][rr];
+                    }
+                }
+                mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
+                mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
+                float se = 0.f;
+                if (mxv > -INFINITY) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int rr = 0; rr < 4; ++rr) se += expf(v[j][rr] - mxv);       // exp(-inf) = 0 for columns past V
+                }
+                se += __shfl_xor(se, 16, 64);
+                se += __shfl_xor(se, 32, 64);
+                if (lq == 0 && m < p.M) {
+                    p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;
+                    p.gsum[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = se;
+                }
+            }
+            prev_full = false;          // (the number of stores is data dependent here: the next wait takes all of them)
+            continue;
+        }
         if (full) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -757,5 +798,51 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
     p.C = logits; p.ldc = ldl; p.M = M; p.N = V; p.K = K; p.out_f32 = 1; p.gmax = group_max; p.gmax_ld = gm_ld;
     p.tiles_m = dh_cdiv(M, 128); p.tiles_n = dh_cdiv(V, 128);
     hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 4, false, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+    DH_LAUNCH_CHECK();
+}
+
+
+// ---- teacher-forced scoring without materialising the logits --------------------------------------------------------
+// logp[m] = log_softmax(A[m,:] W^T + bias)[targets[m]]: the classifier GEMM leaves per (row, 64-column group) the maximum
+// and the sum of exp(logit - maximum) plus the target's logit (36,541 fp32 logits per row never go to memory), and one
+// wave per row folds the groups: M = max_g, S = sum_g gsum_g * exp(gmax_g - M), logp = target - M - log S.
+__global__ __launch_bounds__(256) void lse_combine_kernel(const float* __restrict__ gmax, const float* __restrict__ gsum, int ld,
+                                                           int n_groups, const float* __restrict__ tgt, const int64_t* __restrict__ targets,
+                                                           int V, float* __restrict__ logp, int rows) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float m = -INFINITY;
+    for (int g = lane; g < n_groups; g += 64) m = fmaxf(m, gmax[(size_t)r * ld + g]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int g = lane; g < n_groups; g += 64) {
+        const float gm = gmax[(size_t)r * ld + g];
+        if (gm > -INFINITY) s += gsum[(size_t)r * ld + g] * expf(gm - m);
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int64_t t = targets[r];
+        logp[r] = (t >= 0 && t < V) ? (tgt[r] - m) - logf(s) : 0.f;
+    }
+}
+
+extern "C" int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, const float* bias, const int64_t* targets,
+                                float* logp, float* group_max, float* group_sum, float* target_logit, int gm_ld, int M, int V,
+                                int K, int dtype, void* stream) {
+    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(A && W && targets && logp && group_max && group_sum && target_logit && M > 0 && V > 0 && K > 0);
+    DH_REQUIRE(gm_ld >= 2 * dh_cdiv(V, 128) && (K % 64) == 0 && K >= 128 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
+    DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
+    dh_prof_set_tag("logprob");
+    DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K), stream);
+    VocabParams v{};
+    v.A = (const uint16_t*)A; v.lda = lda; v.W = (const uint16_t*)W; v.ldw = ldw; v.bias = bias;
+    v.gmax = group_max; v.gmax_ld = gm_ld; v.gsum = group_sum; v.targets = targets; v.tgt_logit = target_logit;
+    v.M = M; v.N = V; v.K = K; v.tiles_m = dh_cdiv(M, 128); v.tiles_n = dh_cdiv(V, 128);
+    const int ntiles = v.tiles_m * v.tiles_n;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8, true>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, s, v);
+    hipLaunchKernelGGL(lse_combine_kernel, dim3(dh_cdiv(M, 4)), dim3(256), 0, s, group_max, group_sum, gm_ld, 2 * dh_cdiv(V, 128),
+                       target_logit, targets, V, logp, M);
     DH_LAUNCH_CHECK();
 }

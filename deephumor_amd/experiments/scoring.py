@@ -6,7 +6,7 @@ the decoders then run their teacher-forced ``forward`` (same incremental engine 
 perplexity kernels score every caption (call shape of trainer.py:63-81)."""
 import torch
 
-from .metrics import sequence_perplexity
+from .metrics import sequence_perplexity, sequence_perplexity_from_hidden
 
 
 def score_captions(model, template_images, template_index, captions, lengths, labels=None, batch_size=256,
@@ -31,12 +31,25 @@ def score_captions(model, template_images, template_index, captions, lengths, la
             emb = feats.index_select(0, idx)
             tgt = captions[lo:hi]                       # tokens + <eos>, zero padded (datasets.py:72-79, no <bos>)
             inp = tgt[:, :-1]                           # trainer.py:69-73: model(images, captions[:, :-1], lengths)
+            dec = model.decoder
+            if feats.dtype == torch.bfloat16:
+                # bf16 path: hidden states -> fused classifier + log-softmax gather, the [rows, V] logits never exist
+                if hasattr(dec, "lstm"):
+                    hidden, _, _ = dec.hidden_states(emb, inp, None)
+                else:
+                    hidden = dec._forward(inp, None if spatial is None else spatial.index_select(0, idx), emb,
+                                          num_positions=tgt.shape[1], return_hidden=True)
+                plan = dec._get_plan()
+                hidden = hidden[:, :tgt.shape[1]].contiguous()
+                out.append(sequence_perplexity_from_hidden(hidden, plan["cls_w"], plan["cls_b"], tgt.contiguous(),
+                                                           lengths[lo:hi], pad_index))
+                continue
             if spatial is not None:
-                logits = model.decoder(inp, enc_out=spatial.index_select(0, idx), start_emb=emb, num_positions=tgt.shape[1])
-            elif hasattr(model.decoder, "lstm"):
-                logits = model.decoder(emb, inp, None)
+                logits = dec(inp, enc_out=spatial.index_select(0, idx), start_emb=emb, num_positions=tgt.shape[1])
+            elif hasattr(dec, "lstm"):
+                logits = dec(emb, inp, None)
             else:
-                logits = model.decoder(inp, start_emb=emb)
+                logits = dec(inp, start_emb=emb)
             # output position p (0 = image slot) predicts caption token p: pred[:, :max_len] (trainer.py:75)
             logits = logits[:, :tgt.shape[1]].contiguous()
             out.append(sequence_perplexity(logits, tgt.contiguous(), lengths[lo:hi], pad_index))

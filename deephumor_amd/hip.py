@@ -81,6 +81,7 @@ SIGNATURES = {
                                        _P, _P, _I, _P, _I, _P],
     "dh_lstm_decode_step": [_c.POINTER(LstmModel), _c.POINTER(LstmScratch), _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P,
                             _I, _P, _I, _P, _I, _P],
+    "dh_vocab_logprob": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_token_logprob": [_P, _I, _I, _P, _P, _I, _P],
@@ -460,6 +461,21 @@ def vocab_logits(a, w, bias, logits, group_max):
     v = w.shape[0]
     _launch("dh_vocab_logits", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(logits), logits.stride(0),
             _ptr(group_max), group_max.stride(0), m, v, k, _dt(a), _stream())
+
+
+def vocab_logprob(a, w, bias, targets):
+    """bf16 a [M,K], w [V,K], int64 targets [M] -> fp32 log_softmax(a @ w.T + bias)[targets] [M]; the [M,V] logits are
+    never written (per-group log-sum-exp partials in the classifier GEMM's epilogue)."""
+    _dev(a, w, bias, targets)
+    m, k = a.shape
+    v = w.shape[0]
+    ng = n_groups(v)
+    scratch = torch.empty((2, m, ng), dtype=torch.float32, device=a.device)
+    tgt = torch.empty((m,), dtype=torch.float32, device=a.device)
+    logp = torch.empty((m,), dtype=torch.float32, device=a.device)
+    _launch("dh_vocab_logprob", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(targets.contiguous()), _ptr(logp),
+            _ptr(scratch[0]), _ptr(scratch[1]), _ptr(tgt), ng, m, v, k, _dt(a), _stream())
+    return logp
 
 
 def beam_row_sample_groups(logits, v, group_max, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed,

@@ -106,6 +106,14 @@ class LSTMDecoder(_Planned, nn.Module):
     def forward(self, image_emb, captions, lengths=None):
         """Teacher-forced logits ``[bs, max(lengths), num_tokens]`` (reference rnn_models.py:28-46).
         Rows past ``lengths[i]`` are the packed-sequence zeros, i.e. the classifier bias."""
+        hs, bs, steps_out = self.hidden_states(image_emb, captions, lengths)
+        plan = self._get_plan()
+        out = hip.linear(hs.view(bs * steps_out, -1), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
+        return out.view(bs, steps_out, -1)
+
+    def hidden_states(self, image_emb, captions, lengths=None):
+        """The top layer's hidden states ``[bs, max(lengths), hidden]`` in front of the classifier (zero past
+        ``lengths[i]``, as ``pad_packed_sequence`` leaves them) -> ``(hs, bs, steps)``."""
         self._check_mode()
         plan = self._get_plan()
         bs, steps = captions.shape[0], captions.shape[1] + 1
@@ -123,8 +131,7 @@ class LSTMDecoder(_Planned, nn.Module):
                        tokens=None if t == 0 else tokens, tok_pos=t - 1, hout=hs[:, t, :])
         valid = (torch.arange(steps_out)[None, :] < lengths[:, None]).to(dev)
         hs.mul_(valid[..., None])          # pad_packed_sequence zero rows (mask, not arithmetic on valid rows)
-        out = hip.linear(hs.view(bs * steps_out, hh), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
-        return out.view(bs, steps_out, -1)
+        return hs, bs, steps_out
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, seed=0, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,

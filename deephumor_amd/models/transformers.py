@@ -196,7 +196,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                                         run.rows_total, t, x_out=x_out, logits=logits, group_max=group_max)
         return x_out if x_out is not None else sc["x"]
 
-    def _forward(self, x, enc_out, start_emb, num_positions=None):
+    def _forward(self, x, enc_out, start_emb, num_positions=None, return_hidden=False):
         self._check_mode()
         plan = self._get_plan()
         bs, dec_len = x.shape
@@ -213,7 +213,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
         ncopy = min(x.shape[1], tokens.shape[1])
         tokens[:, :ncopy] = x[:, :ncopy].to(torch.int32)
         if self._prefill_ok(plan, seq):
-            return self._forward_prefill(plan, tokens, enc_out, start_emb.to(plan["dtype"]).contiguous(), bs, seq)
+            return self._forward_prefill(plan, tokens, enc_out, start_emb.to(plan["dtype"]).contiguous(), bs, seq, return_hidden)
         helper_src = (torch.arange(bs, dtype=torch.int32, device=dev))[:, None].expand(bs, seq).contiguous()
         run = self._Run(self, plan, bs, 1, seq, enc_out, dev)
         hs = torch.empty((bs, seq, self.hid_dim), device=dev, dtype=plan["dtype"])
@@ -221,6 +221,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
         for t in range(seq):
             self._decode_position(plan, run, t, bs, 1, 1, tokens, helper_src, start_emb.to(plan["dtype"]).contiguous(), x_out=xt)
             hs[:, t, :].copy_(xt)
+        if return_hidden:
+            return hs
         out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
         return out.view(bs, seq, -1)
 
@@ -230,7 +232,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
         limit = 56 if plan["dtype"] == torch.bfloat16 else 40
         return self.hid_dim == 64 * self.n_heads and seq <= limit
 
-    def _forward_prefill(self, plan, tokens, enc_out, start_emb, bs, seq):
+    def _forward_prefill(self, plan, tokens, enc_out, start_emb, bs, seq, return_hidden=False):
         """Teacher-forced forward in prefill form: rows are sequence-major (row n*seq + t); per layer one QKV GEMM
         over all bs*seq rows, one causal self-attention launch, projection + residual LayerNorm, (cross-attention in
         chunks of positions), FFN -- ~12 launches per layer instead of ~11 per layer AND position."""
@@ -256,6 +258,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
             ff = hip.linear(x, L["w1"], L["b1"], relu=True, tag="ffn")
             o = hip.linear(ff, L["w2"], L["b2"], tag="ffn")
             x = hip.add_layernorm(x, o, L["ln3"][0], L["ln3"][1], eps=L["ln3"][2])
+        if return_hidden:
+            return x.view(bs, seq, d)
         out = hip.linear(x, plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
         return out.view(bs, seq, -1)
 

@@ -214,6 +214,13 @@ int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_p
                        uint64_t seed, const uint64_t* seed_ptr, int img0, int step, int32_t* pick_idx,
                        float* pick_val, int32_t* err, void* stream);
 
+/* Teacher-forced scoring without materialising the logits (bf16): logp[m] = log_softmax(A[m,:] W^T + bias)[targets[m]]
+ * (metrics.py:4-9 via F.cross_entropy).  group_max / group_sum [M, gm_ld >= 2*ceil(V/128)] and target_logit [M] are
+ * scratch.  targets outside [0, V) give logp = 0.  K % 64 == 0, K >= 128. */
+int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, const float* bias, const int64_t* targets, float* logp,
+                     float* group_max, float* group_sum, float* target_logit, int gm_ld, int M, int V, int K, int dtype,
+                     void* stream);
+
 /* Same contract as dh_beam_row_sample, guided by the column-group maxima of dh_vocab_logits: the k-th largest
  * group maximum bounds the k-th largest logit from below, so only groups whose maximum reaches it are read. */
 int dh_beam_row_sample_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld,

@@ -230,3 +230,17 @@ def test_lstm_layer_fused_matches_cell_math(hip, rows, row_mult, e, hh, use_toke
     assert torch.equal(h_out.cpu(), h_next.cpu()[rl])
     if row_mult > 1:                        # rows between the logical rows are untouched
         assert float(c_next.cpu()[1].min()) == 9.0
+
+
+@pytest.mark.parametrize("rows,v", [(300, 36541), (1280, 36541), (37, 1000), (200, 4000)])
+def test_vocab_logprob_matches_log_softmax(hip, rows, v):
+    """dh_vocab_logprob (log-sum-exp partials in the classifier GEMM epilogue, logits never written) against
+    log_softmax of the materialised fp32 logits of the same GEMM."""
+    k = 512
+    a, w, b = bf(rnd(rows, k, seed=21)).cuda(), (bf(rnd(v, k, seed=22) * 0.1)).cuda(), rnd(v, seed=23).cuda()
+    targets = torch.randint(0, v, (rows,), generator=torch.Generator().manual_seed(5))
+    targets[0], targets[1] = v - 1, 0
+    ref = torch.log_softmax(hip.linear(a, w, b, out_dtype=torch.float32), dim=-1).cpu()
+    want = ref[torch.arange(rows), targets]
+    got = hip.vocab_logprob(a, w, b, targets.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-4, rtol=0)

@@ -54,3 +54,32 @@ def test_score_captions_with_template_caching(kind):
         logits = R.model_forward(kind, sd, hp, templates[tidx[i]:tidx[i] + 1], caps[i:i + 1, :-1])[:, :l]
         want = float(R.perplexity(logits, caps[i:i + 1], lengths[i:i + 1]))
         assert abs(float(got[i]) - want) < 2e-3 * want, (i, float(got[i]), want)
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer", "CaptioningTransformerBase"))
+def test_bf16_scoring_from_hidden_states_equals_logits_path(kind):
+    """bf16 ``score_captions`` (hidden states -> dh_vocab_logprob, no logits in memory) against the perplexity of the
+    same bf16 model's materialised ``forward()`` logits; and close to the fp32 reference path's perplexity."""
+    import deephumor_amd.models as M
+    from deephumor_amd.experiments import score_captions
+    from deephumor_amd.experiments.metrics import sequence_perplexity
+    sd, hp = synthetic_sd(kind)
+    model = getattr(M, kind)(**hp).eval()
+    model.load_state_dict(sd)
+    templates = synth_images(3, seed=0).cuda()
+    g = torch.Generator().manual_seed(4)
+    n, l = 9, 14
+    caps = torch.randint(6, 1000, (n, l), generator=g)
+    lengths = torch.tensor([14, 9, 14, 5, 7, 14, 3, 11, 14])
+    for r, k in enumerate(lengths.tolist()):
+        caps[r, k - 1] = 3
+        caps[r, k:] = 0
+    tidx = torch.tensor([0, 1, 2, 2, 1, 0, 0, 1, 2])
+    with torch.no_grad():
+        ref32 = score_captions(model.cuda(), templates, tidx.cuda(), caps.cuda(), lengths.cuda(), batch_size=4).cpu()
+        m16 = model.bfloat16()
+        got = score_captions(m16, templates, tidx.cuda(), caps.cuda(), lengths.cuda(), batch_size=4).cpu()
+        logits = m16(templates[tidx.cuda()], caps[:, :-1].cuda(), None)[:, :l].contiguous()
+        want = sequence_perplexity(logits, caps.cuda(), lengths.cuda()).cpu()
+    assert torch.allclose(got, want, rtol=2e-3), (got, want)
+    assert torch.allclose(got, ref32, rtol=0.25), (got, ref32)
