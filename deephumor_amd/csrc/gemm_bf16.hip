@@ -449,6 +449,8 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
         hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 2>), dim3(blocks), dim3(256), 0, s, p);
 }
 
+static bool launch_persistent_f32(const GemmBf16Params& p, hipStream_t s);   // defined below vocab_logits_kernel
+
 // called from dh_linear (gemm.hip) for DH_BF16 / DH_BF16_OUT_F32
 int dh_linear_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const float* scale,
                         const float* shift, const void* residual, int ldres, void* C, int ldc, int M, int N, int K,
@@ -459,6 +461,7 @@ int dh_linear_bf16_impl(const void* A, int lda, const void* W, int ldw, const fl
     p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw;
     p.bias = bias; p.scale = scale; p.shift = shift; p.res = (const uint16_t*)residual; p.ldres = ldres;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.relu = relu; p.out_f32 = out_f32;
+    if (out_f32 && launch_persistent_f32(p, s)) DH_LAUNCH_CHECK();
     launch_gemm_bf16<false>(p, s);
     DH_LAUNCH_CHECK();
 }
@@ -546,8 +549,9 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
     static_assert(WN == 64, "a wave owns one 64-column group (group_max, bias strip)");
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW), G = IA + IB;
-    constexpr int N_STORE = TM * TN + TM;                          // stores of one interior-tile epilogue, per wave
-    static_assert((NS - 2) * G + N_STORE + 1 <= 63, "vmcnt encoding");
+    constexpr int N_STORE_MAX = TM * TN + TM;                      // stores of one interior-tile epilogue, per wave
+    const int N_STORE = TM * TN + (p.gmax ? TM : 0);               // (group maxima are optional: plain fp32-output GEMM)
+    static_assert((NS - 2) * G + N_STORE_MAX + 1 <= 63, "vmcnt encoding");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NS * SLAB + NW * 256];
     unsigned char* bias_lds = lds + NS * SLAB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 256;   // wave-private
 
@@ -732,7 +736,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
                 }
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
-                if (lq == 0) p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;
+                if (lq == 0 && p.gmax) p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;
             }
         } else {
 #pragma unroll
@@ -754,11 +758,25 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
                 }
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
-                if (lq == 0 && m < p.M) p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;   // -inf for a group past V
+                if (lq == 0 && m < p.M && p.gmax) p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / WN] = mxv;   // -inf for a group past V
             }
         }
         prev_full = full;
     }
+}
+
+// fp32-output dense GEMMs with many tiles (teacher-forced classifier: [bs*T, V] logits): the persistent kernel without
+// the group maxima (600 vs 385 TF for the one-tile-per-workgroup kernel with its LDS-staged fp32 epilogue).
+static bool launch_persistent_f32(const GemmBf16Params& p, hipStream_t s) {
+    if (p.scale || p.res || p.relu || p.gmax || (p.K & 63) || p.K < 128) return false;
+    if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
+    const int tiles_m = dh_cdiv(p.M, 128), tiles_n = dh_cdiv(p.N, 128);
+    if ((long long)tiles_m * tiles_n < 1024) return false;
+    VocabParams v{};
+    v.A = p.A; v.lda = p.lda; v.W = p.W; v.ldw = p.ldw; v.bias = p.bias; v.C = (float*)p.C; v.ldc = p.ldc;
+    v.M = p.M; v.N = p.N; v.K = p.K; v.tiles_m = tiles_m; v.tiles_n = tiles_n;
+    hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8>), dim3(512), dim3(512), 0, s, v);
+    return true;
 }
 
 // Vocabulary projection for beam search: logits[M,V] fp32 = A[M,K] * W[V,K]^T + bias, plus group_max[m, g] =

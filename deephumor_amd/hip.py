@@ -327,7 +327,12 @@ def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=No
     n, k2 = w.shape
     assert k == k2 and a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == w.dtype
     if out is None:
-        out = torch.empty((m, n), dtype=out_dtype or a.dtype, device=a.device)
+        if a.dtype == torch.bfloat16 and out_dtype == torch.float32 and (n % 4) and m * n >= (1 << 24):
+            # large fp32 logits: rows padded to 64 floats (16-byte aligned rows) so that the persistent classifier kernel
+            # with its 16-byte register stores applies; the result is a [m, n] view of the padded buffer
+            out = torch.empty((m, (n + 63) // 64 * 64), dtype=torch.float32, device=a.device)[:, :n]
+        else:
+            out = torch.empty((m, n), dtype=out_dtype or a.dtype, device=a.device)
     assert out.shape == (m, n) and out.stride(1) == 1
     dt = _dt(a)
     if dt == BF16 and out.dtype == torch.float32:
