@@ -417,6 +417,7 @@ __global__ __launch_bounds__(1024) void attn_cross_lds_kernel(AttnParams<T> p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");         // ps is wave-private: order write -> reads
         // PV: lane l -> dims 2*(l&31), +1 ; half-wave (l>>5) takes keys of its parity
         float o0 = 0.f, o1 = 0.f;
+#pragma unroll 5
         for (int j = par; j < S; j += 2) {
             const float pj = ps[j];
             o0 = fmaf(pj, ldf(vh + (size_t)j * ROW + d2), o0);
