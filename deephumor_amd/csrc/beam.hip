@@ -30,11 +30,17 @@ __device__ __forceinline__ void radix_pick_digit(const int* hist, int n_hist, in
     int c = 0, suf = 0;
     if (tid < 256) {
         for (int h = 0; h < n_hist; ++h) c += hist[h * 256 + tid];
-        suf = c;                                   // inclusive suffix sum inside the wave (towards higher lanes)
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_down(suf, o, 64);
-            if (lane + o < 64) suf += t;
+        // inclusive suffix sum inside the wave (towards higher lanes): DPP row_shl scan inside the 16-lane rows (a lane
+        // shifted in from beyond the row end reads 0), then the totals of the higher rows through v_readlane
+        suf = c;
+        suf += __builtin_amdgcn_update_dpp(0, suf, 0x101, 0xF, 0xF, true);
+        suf += __builtin_amdgcn_update_dpp(0, suf, 0x102, 0xF, 0xF, true);
+        suf += __builtin_amdgcn_update_dpp(0, suf, 0x104, 0xF, 0xF, true);
+        suf += __builtin_amdgcn_update_dpp(0, suf, 0x108, 0xF, 0xF, true);
+        {
+            const int t1 = __builtin_amdgcn_readlane(suf, 16), t2 = __builtin_amdgcn_readlane(suf, 32), t3 = __builtin_amdgcn_readlane(suf, 48);
+            const int row = lane >> 4;
+            suf += row == 0 ? t1 + t2 + t3 : row == 1 ? t2 + t3 : row == 2 ? t3 : 0;
         }
         if (lane == 0) wtot[wave] = suf;
     }
@@ -68,8 +74,8 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     __shared__ int hist[4][256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_k, s_cnt, wtot[4];
-    __shared__ int idx_a[CAP], idx_b[CAP];
-    __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
+    __shared__ __attribute__((aligned(16))) int idx_a[CAP], idx_b[CAP];
+    __shared__ __attribute__((aligned(16))) float val_a[CAP], val_b[CAP], qv[CAP];
     __shared__ float red[256];
     __shared__ int picks[DH_BEAM_MAX_BEAMS];
 
@@ -251,17 +257,17 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
         if (r < beam) picks[r] = i;
     }
     __syncthreads();
-    if (tid == 0) {
-        if (n < beam) atomicOr(err, DH_BEAM_ERR_TOO_FEW);
-        float mx = -INFINITY;
-        for (int b = 0; b < beam; ++b) if (picks[b] >= 0) mx = fmaxf(mx, val_a[picks[b]]);
-        float se = 0.f;
-        for (int b = 0; b < beam; ++b) if (picks[b] >= 0) se += expf(val_a[picks[b]] - mx);
+    if (tid < 64) {
+        // log_softmax over the gathered (un-tempered) logits of the picks (beam.py:79): lane b owns pick b
+        if (tid == 0 && n < beam) atomicOr(err, DH_BEAM_ERR_TOO_FEW);
+        const int pi = tid < beam ? picks[tid] : -1;
+        const float lv = pi >= 0 ? val_a[pi] : -INFINITY;
+        const float mx = wave_max(lv);
+        const float se = wave_sum(pi >= 0 ? expf(lv - mx) : 0.f);
         const float lse = logf(se);
-        for (int b = 0; b < beam; ++b) {
-            const int pi = picks[b];
-            pick_idx[(size_t)rc * beam + b] = pi >= 0 ? idx_a[pi] : 0;
-            pick_val[(size_t)rc * beam + b] = pi >= 0 ? (val_a[pi] - mx) - lse : -INFINITY;
+        if (tid < beam) {
+            pick_idx[(size_t)rc * beam + tid] = pi >= 0 ? idx_a[pi] : 0;
+            pick_val[(size_t)rc * beam + tid] = pi >= 0 ? (lv - mx) - lse : -INFINITY;
         }
     }
 #undef s_cnt
@@ -277,8 +283,8 @@ __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_k, s_cnt, wtot[4];
-    __shared__ int idx_a[CAP], idx_b[CAP];
-    __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
+    __shared__ __attribute__((aligned(16))) int idx_a[CAP], idx_b[CAP];
+    __shared__ __attribute__((aligned(16))) float val_a[CAP], val_b[CAP], qv[CAP];
     __shared__ float red[NT];
     __shared__ int picks[DH_BEAM_MAX_BEAMS];
     __shared__ uint32_t s_thr;
@@ -343,8 +349,8 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     __shared__ int hist[2][256];
     __shared__ uint32_t s_prefix, s_thr;
     __shared__ int s_k, s_cnt, s_ng, wtot[4];
-    __shared__ int idx_a[CAP], idx_b[CAP];
-    __shared__ float val_a[CAP], val_b[CAP], qv[CAP];
+    __shared__ __attribute__((aligned(16))) int idx_a[CAP], idx_b[CAP];
+    __shared__ __attribute__((aligned(16))) float val_a[CAP], val_b[CAP], qv[CAP];
     __shared__ float red[NT];
     __shared__ int picks[DH_BEAM_MAX_BEAMS];
     const int rc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -379,15 +385,15 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
         if (tid + e * NT < n_groups && gk[e] >= bound) glist[atomicAdd(&s_ng, 1)] = tid + e * NT;
     __syncthreads();
     const int ng = s_ng;
-    // one wave per selected group (coalesced 256-B reads), four groups in flight per wave
-    constexpr int NWV = NT / 64, UN = 4;
+    // one wave per selected group (coalesced 256-B reads), all of a wave's groups requested before the first is used
+    constexpr int NWV = NT / 64, UN = 16;     // 64 groups in one round of loads (a row selects ~55)
     for (int q0 = wave; q0 < ng; q0 += NWV * UN) {
         float v[UN]; int ci[UN];
 #pragma unroll
         for (int u = 0; u < UN; ++u) {
             const int q = q0 + u * NWV;
-            ci[u] = q < ng ? glist[q] * gcols + lane : V;
-            v[u] = (lane < gcols && ci[u] < V) ? row[ci[u]] : 0.f;
+            ci[u] = q < ng ? glist[min(q, ng - 1)] * gcols + lane : V;
+            v[u] = row[min(ci[u], V - 1)];                  // unconditional (clamped) loads: all in flight together
         }
 #pragma unroll
         for (int u = 0; u < UN; ++u)
