@@ -38,6 +38,9 @@ struct GemmBf16Params {
     int conv, H, Wd, Cin, Ho, Wo, KS, stride, pad;     // conv loader: A = NHWC input
     unsigned cin_magic, ks_magic;                      // k / Cin == (k * cin_magic) >> 20 for k < K; tap / KS likewise
     int tiles_m, tiles_n, n_fast;                      // n_fast: consecutive workgroups walk the N tiles of one M tile
+    // dense mode, optional second A source for k >= K1 (the fused "conv3 + downsample" of a ResNet stage's first block):
+    // row m = output pixel (n, oh, ow) reads channels of input pixel (n, oh*a2_stride, ow*a2_stride) of the NHWC tensor A2
+    const uint16_t* A2; int K1, a2_H, a2_W, a2_C, a2_stride, a2_Ho, a2_Wo;
     float* gmax; int gmax_ld;                          // optional: per-row maxima of each wave-wide column group
 };
 
@@ -134,11 +137,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
     // this loop, see vocab_logits_kernel)
     const bool stepping = (p.K & 63) == 0;
     const uint16_t* a_run[IA]; const uint16_t* b_run[IB];
+    const uint16_t* a2_run[IA];
     int a_stp[IA], b_stp[IB];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
         a_run[i] = (!CONV && a_ok[i]) ? a_base[i] + a_swz[i] * 8 : reinterpret_cast<const uint16_t*>(zero);
         a_stp[i] = (!CONV && a_ok[i]) ? BK : 0;
+        a2_run[i] = reinterpret_cast<const uint16_t*>(zero);
+        if (!CONV && p.A2 && a_ok[i]) {
+            const int m = m0 + (wave * IA + i) * 8 + lr;
+            const int hw = p.a2_Ho * p.a2_Wo, n = m / hw, r = m - n * hw, oh = r / p.a2_Wo, ow = r - oh * p.a2_Wo;
+            a2_run[i] = p.A2 + (((size_t)n * p.a2_H + (size_t)oh * p.a2_stride) * p.a2_W + (size_t)ow * p.a2_stride) * p.a2_C + a_swz[i] * 8;
+        }
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
@@ -148,6 +158,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
     auto stage = [&](int buf, int k0) {
         unsigned char* slab = lds + __builtin_amdgcn_readfirstlane(buf) * SLAB;
         if (!CONV && stepping) {
+            if (p.A2 && k0 == p.K1) {                     // wave-uniform: the remaining slabs come from the second source
+#pragma unroll
+                for (int i = 0; i < IA; ++i) a_run[i] = a2_run[i];
+            }
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
                 __builtin_amdgcn_global_load_lds((gptr_t)a_run[i], (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
@@ -777,6 +791,28 @@ static bool launch_persistent_f32(const GemmBf16Params& p, hipStream_t s) {
     v.M = p.M; v.N = p.N; v.K = p.K; v.tiles_m = tiles_m; v.tiles_n = tiles_n;
     hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8>), dim3(512), dim3(512), 0, s, v);
     return true;
+}
+
+// A ResNet stage's first bottleneck ends in relu(bn3(conv3(y)) + bn_d(downsample(x))): two 1x1 convolutions into the same
+// output.  With the BatchNorm scales folded into the (bf16) weights -- w = [W3 * s3 | Wd * sd] over K = C1 + C2 -- this
+// is ONE GEMM over the virtual operand [y | x at the strided pixels]: the 411 MB (stage 1) identity tensor is neither
+// written by a downsample launch nor read back as a residual.  y: NHWC [N, Ho, Wo, C1]; x: NHWC [N, H, W, C2].
+extern "C" int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w, const float* shift, void* out, int N, int Ho,
+                                    int Wo, int C1, int H, int W, int C2, int stride, int Cout, int relu, int dtype,
+                                    void* stream) {
+    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(y && x && w && shift && out && N > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0 && Cout > 0 && stride >= 1);
+    DH_REQUIRE((C1 % 64) == 0 && (C2 % 64) == 0 && C1 > 0 && C2 > 0 && (Ho - 1) * stride < H && (Wo - 1) * stride < W);
+    DH_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && (long long)N * Ho * Wo < (1ll << 31));
+    GemmBf16Params p{};
+    p.A = (const uint16_t*)y; p.lda = C1; p.W = (const uint16_t*)w; p.ldw = C1 + C2; p.bias = shift;
+    p.C = out; p.ldc = Cout; p.M = N * Ho * Wo; p.N = Cout; p.K = C1 + C2; p.relu = relu;
+    p.A2 = (const uint16_t*)x; p.K1 = C1; p.a2_H = H; p.a2_W = W; p.a2_C = C2; p.a2_stride = stride; p.a2_Ho = Ho; p.a2_Wo = Wo;
+    dh_prof_set_tag("1x1");
+    DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * p.M * Cout * p.K,
+                     2.0 * ((double)p.M * C1 + (double)p.M * C2 + (double)Cout * p.K + (double)p.M * Cout), stream);
+    launch_gemm_bf16<false>(p, (hipStream_t)stream);
+    DH_LAUNCH_CHECK();
 }
 
 // Vocabulary projection for beam search: logits[M,V] fp32 = A[M,K] * W[V,K]^T + bias, plus group_max[m, g] =

@@ -54,6 +54,7 @@ SIGNATURES = {
     "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _P],
+    "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_avgpool_nhwc": [_P, _P, _I, _I, _I, _I, _P],
@@ -522,6 +523,19 @@ def transformer_decode_position(model, scratch, start_emb, tokens, src, n_img, r
             tokens.stride(0), _ptr(src), src.stride(0), n_img, rows_per_img, row_mult, rows_total, t, _ptr(x_out),
             _ptr(logits), logits.stride(0) if logits is not None else 0, _ptr(group_max),
             group_max.stride(0) if group_max is not None else 0, _stream())
+
+
+def conv1x1_dual_nhwc(y, x, w_cat, shift, stride, relu=True):
+    """relu(y (*) W3' + x[strided] (*) Wd' + shift): conv3 + downsample of a stage's first bottleneck as one GEMM
+    (bf16, NHWC; ``w_cat`` [Cout, C1 + C2] has the BatchNorm scales folded in)."""
+    _dev(y, x, w_cat, shift)
+    n, ho, wo, c1 = y.shape
+    _, h, w_, c2 = x.shape
+    cout = w_cat.shape[0]
+    out = torch.empty((n, ho, wo, cout), dtype=y.dtype, device=y.device)
+    _launch("dh_conv1x1_dual_nhwc", _ptr(y), _ptr(x), _ptr(w_cat), _ptr(shift), _ptr(out), n, ho, wo, c1, h, w_, c2, stride,
+            cout, int(relu), _dt(y), _stream())
+    return out
 
 
 def normalize_u8_hwc(x, mean, std):

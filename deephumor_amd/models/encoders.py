@@ -146,10 +146,22 @@ class ImageEncoder(_Planned, nn.Module):
         stem = conv(self.resnet[0], self.resnet[1], True, stem=True)
         for stage in list(self.resnet)[4:]:
             for blk in stage:
-                blocks.append(dict(
+                ent = dict(
                     down=conv(blk.downsample[0], blk.downsample[1], False) if blk.downsample is not None else None,
                     c1=conv(blk.conv1, blk.bn1, True), c2=conv(blk.conv2, blk.bn2, True),
-                    c3=conv(blk.conv3, blk.bn3, True, residual=True)))
+                    c3=conv(blk.conv3, blk.bn3, True, residual=True), dual=None)
+                if bf16 and ent["down"] is not None:
+                    # first block of a stage on the bf16 path: relu(bn3(conv3(y)) + bn_d(downsample(x))) as ONE GEMM over
+                    # [y | x at the strided pixels] with the BatchNorm scales folded into the weights -- the identity
+                    # tensor (411 MB in stage 1 at 256 images) is neither written nor read back
+                    c3, dn = ent["c3"], ent["down"]
+                    cout = c3["w"].shape[0]
+                    w_cat = torch.cat([c3["w"].float().view(cout, -1) * c3["scale"][:, None],
+                                       dn["w"].float().view(cout, -1) * dn["scale"][:, None]], 1)
+                    if c3["w"].shape[-1] % 64 == 0 and dn["w"].shape[-1] % 64 == 0:
+                        ent["dual"] = dict(w=w_cat.to(torch.bfloat16).contiguous(), shift=(c3["shift"] + dn["shift"]).contiguous(),
+                                           stride=dn["stride"])
+                blocks.append(ent)
         s, b = _bn_affine(self.bn)
         return dict(stem=stem, blocks=blocks, bn_scale=s, bn_shift=b, bf16=bf16,
                     lin_w=self.linear.weight.detach(), lin_b=self.linear.bias.detach().float().contiguous())
@@ -171,8 +183,12 @@ class ImageEncoder(_Planned, nn.Module):
         else:
             x = hip.maxpool3x3s2(self._conv(images.contiguous(), st))
         for blk in plan["blocks"]:
-            idt = x if blk["down"] is None else self._conv(x, blk["down"], nhwc=nhwc)
             y = self._conv(self._conv(x, blk["c1"], nhwc=nhwc), blk["c2"], nhwc=nhwc)
+            if blk["dual"] is not None:
+                d = blk["dual"]
+                x = hip.conv1x1_dual_nhwc(y, x, d["w"], d["shift"], d["stride"], relu=True)
+                continue
+            idt = x if blk["down"] is None else self._conv(x, blk["down"], nhwc=nhwc)
             x = self._conv(y, blk["c3"], residual=idt, nhwc=nhwc)
         return x
 

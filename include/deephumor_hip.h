@@ -65,6 +65,13 @@ int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const 
                       int N, int Cin, int H, int W, int Cout, int KS, int stride, int pad, int relu,
                       void* stream);
 
+/* relu(conv3(y) + downsample(x) + shift) as ONE launch: the end of a ResNet stage's first bottleneck (torchvision
+ * Bottleneck.forward: out = relu(bn3(conv3(out)) + downsample(x))).  w = [W3 * bn3_scale | Wd * bnd_scale]
+ * [Cout, C1 + C2] bf16 (the BatchNorm scales folded into the weights), shift = bn3_shift + bnd_shift.
+ * y NHWC [N,Ho,Wo,C1], x NHWC [N,H,W,C2] read at pixel (oh*stride, ow*stride); C1, C2 % 64 == 0.  DH_BF16 only. */
+int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w, const float* shift, void* out, int N, int Ho, int Wo,
+                         int C1, int H, int W, int C2, int stride, int Cout, int relu, int dtype, void* stream);
+
 /* Input packing for a matrix-core stem: NCHW fp32 image [N,C,H,W] (C <= 8) -> channels-last bf16 [N,H,W,8] with
  * channels C..7 zero, so the 7x7 stem is a dh_conv2d_nhwc_bn_act with Cin = 8 (weights zero-padded likewise). */
 int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, void* stream);

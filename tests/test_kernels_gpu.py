@@ -363,3 +363,21 @@ def test_normalize_u8_matches_totensor_normalize():
     want = want.sub(torch.tensor(IMAGENET_MEAN)[None, :, None, None]).div(torch.tensor(IMAGENET_STD)[None, :, None, None])
     got = images_to_tensor(u8.cuda()).cpu()
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("c1,c2,cout,hw,stride,n", [(64, 64, 256, 14, 1, 3), (128, 256, 512, 14, 2, 2), (256, 512, 1024, 8, 2, 2),
+                                                   (64, 64, 256, 56, 1, 9)])
+def test_conv1x1_dual_matches_conv3_plus_downsample(hip, c1, c2, cout, hw, stride, n):
+    """dh_conv1x1_dual_nhwc == relu(bn3(conv3(y)) + bn_d(downsample(x))) in fp32 on the same bf16-rounded tensors (the
+    BatchNorm scales are folded into the bf16 weights of the fused form, hence the bf16-level tolerance)."""
+    ho = (hw - 1) // stride + 1
+    y, x = bf(rnd(n, c1, ho, ho, seed=1)), bf(rnd(n, c2, hw, hw, seed=2))
+    w3, wd = bf(rnd(cout, c1, 1, 1, seed=3) * (2.0 / c1) ** 0.5), bf(rnd(cout, c2, 1, 1, seed=4) * (2.0 / c2) ** 0.5)
+    s3, sd = rnd(cout, seed=5).abs() * 0.3 + 0.2, rnd(cout, seed=6).abs() * 0.3 + 0.5
+    b3, bd = rnd(cout, seed=7), rnd(cout, seed=8)
+    ref = torch.relu(F.conv2d(y.float(), w3.float()) * s3[None, :, None, None] + b3[None, :, None, None]
+                     + F.conv2d(x.float(), wd.float(), stride=stride) * sd[None, :, None, None] + bd[None, :, None, None])
+    w_cat = torch.cat([w3.float().view(cout, c1) * s3[:, None], wd.float().view(cout, c2) * sd[:, None]], 1).to(torch.bfloat16)
+    out = hip.conv1x1_dual_nhwc(y.permute(0, 2, 3, 1).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(),
+                                w_cat.contiguous().cuda(), (b3 + bd).cuda(), stride)
+    close(out.float().permute(0, 3, 1, 2), ref, atol=4e-2, rtol=2e-2)
