@@ -840,10 +840,9 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         //  overlap the other half's LDS reads / LDS-DMA issue; 3-slab ring, 16 waves on 256 x 128 -- measured 75.6 us
         //  against 78 us standalone and no difference in the full step, so it is not kept)
         // (also tried, bit-exact but slower than this kernel's 78 us: 256 x 256 tiles, 128 x 64 per wave, K slabs of 32 in a
-        //  4-slab ring, the two wave halves one barrier apart -- 85 us with LDS-DMA, 170 us register-staged.  Its PMC
-        //  points at the L2 -> CU line traffic: with 64-byte row segments every 128-byte line is fetched twice, so the
-        //  kernel moves the same ~730 MB of lines per launch (~12 TB/s) as the 128 x 128 tile with full-line slabs.
-        //  A larger tile needs a K-slab-major packing of both operands to pay off: DESIGN.md section 9.)
+        //  4-slab ring, the two wave halves one barrier apart -- 85 us with LDS-DMA, 170 us register-staged; with 64-byte
+        //  row segments every 128-byte line is fetched twice.  scratch/dma_probe shows the LDS-DMA path itself sustains
+        //  110-125 GB/s per CU against the ~46 GB/s this kernel draws: DESIGN.md section 9.)
         hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, (hipStream_t)stream, v);
         DH_LAUNCH_CHECK();
     }
