@@ -135,13 +135,15 @@ class LSTMDecoder(_Planned, nn.Module):
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, seed=0, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
-                        defer_check=False):
+                       defer_check=False, early_stop_every=0):
         """Batched beam-search sampling for ``image_emb [N, 1, E]`` or ``[N, E]``.
 
         Returns ``(tokens int64 [N, max_len] zero-padded, lengths int64 [N])``; row ``i`` equals
         what the reference's ``generate`` returns for image ``i`` under the same random draws
         (rnn_models.py:48-143, incl. the hidden-state indexing at :135-137).  ``streams`` > 1 decodes
-        that many image sub-batches concurrently on separate HIP streams (same captions)."""
+        that many image sub-batches concurrently on separate HIP streams (same captions).
+        ``early_stop_every=k`` (> 0) checks every k steps whether every image has finished (the reference's
+        ``all_ended()`` break, rnn_models.py:131) and stops decoding then -- one host sync per check, same captions."""
         self._check_mode()
         plan = self._get_plan()
         image_emb = image_emb.reshape(image_emb.shape[0], -1).to(plan["dtype"]).contiguous()
@@ -181,6 +183,8 @@ class LSTMDecoder(_Planned, nn.Module):
                     logits_hook(i, logits)
                 helper.step(logits, first=False, write_pos=i, t=0, step_index=i, group_max=gmax)
                 yield
+                if early_stop_every and (i - pos) % early_stop_every == 0 and bool(helper.done.all()):
+                    break                                   # finished images are frozen by dh_beam_select: nothing left to do
             return helper.finalize(len_bias_done=1, full_len=max_len, defer_check=defer_check)
 
         return run_interleaved(session, image_emb.shape[0], streams)

@@ -265,7 +265,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
                         seed=0, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
-                        defer_check=False):
+                        defer_check=False, early_stop_every=0):
         self._check_mode()
         plan = self._get_plan()
         if max_len + 1 > self.pos_embedding.num_embeddings:
@@ -310,6 +310,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn
                 helper.step(logits, first=False, write_pos=i, t=i, step_index=i, group_max=gmax)
                 yield
+                if early_stop_every and (i - pos) % early_stop_every == 0 and bool(helper.done.all()):
+                    break                                   # all_ended() break of the reference (transformers.py:585)
             return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index, defer_check=defer_check)
 
         return run_interleaved(session, start_emb.shape[0], streams)

@@ -284,3 +284,17 @@ def test_long_caption_uses_the_long_history_kernels(kind, images):
     with torch.no_grad():
         tb, lb = model.bfloat16().generate_batch(images[:2].cuda(), max_len=100, beam_size=3, top_k=10, seed=1)
     assert tuple(tb.shape) == (2, 100) and int(lb.max()) <= 100
+
+
+@pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
+def test_early_stop_gives_the_same_captions(kind, images):
+    """``early_stop_every``: decoding stops once every image has finished (the reference's all_ended() break); the
+    captions equal those of the full-length loop.  <eos> is made likely so that all images finish early."""
+    model, _, _ = build(kind)
+    kw = dict(max_len=32, beam_size=3, top_k=10, seed=5)
+    with torch.no_grad():
+        model.decoder.classifier.bias[3] += 9.0
+        full = model.generate_batch(images.cuda(), **kw)
+        early = model.generate_batch(images.cuda(), early_stop_every=2, **kw)
+    assert torch.equal(full[0], early[0]) and torch.equal(full[1], early[1])
+    assert int(full[1].min()) < 32          # <eos> was sampled: images do finish before max_len
