@@ -3,8 +3,10 @@
 Drop-in for ``deephumor.models.rnn_models.LSTMDecoder`` (reference rnn_models.py:8-143): same
 constructor, ``forward(image_emb, captions, lengths)`` and ``generate(image_emb, caption, ...)``;
 ``generate_batch`` is the new batched entry point (the reference is strictly one image per call,
-SURVEY.md section 2b).  One time step = ``dh_lstm_prepare`` (state/embedding gather incl. beam
-reorder) + per layer ``dh_linear`` (fused [x|h] gate GEMM on the matrix cores) + ``dh_lstm_cell``.
+SURVEY.md section 2b).  One time step of one layer is ONE launch on the bf16 path (``dh_lstm_layer_fused``: the
+[x | h_prev[beam parent]] operand gathered by the loader, gate GEMM on the matrix cores, cell update in the epilogue,
+state ping-pong); on the fp32 parity path ``dh_lstm_prepare`` (state/embedding gather incl. beam reorder) + per layer
+``dh_linear`` ([x|h] gate GEMM) + ``dh_lstm_cell``.  Both are sequenced by the native ``dh_lstm_decode_step``.
 """
 import torch
 from torch import nn

@@ -10,7 +10,9 @@ re-runs the whole padded sequence through all layers for every generated token a
 vocabulary classifier to all ``max(max_len+1, 49)`` positions; here every position is decoded
 ONCE against a per-layer KV cache kept in HBM, for all images and beams of a batch at a time, and
 beam reordering is an ancestor-index table, never a cache copy.  ``forward()`` (teacher forcing)
-runs on the same incremental engine, so it and ``generate()`` share every kernel.
+runs all positions at once in prefill form (batched GEMMs, one causal self-attention launch per layer,
+``_forward_prefill``) when the sequence fits the register-resident attention kernels (<= 56 positions in bf16,
+40 in fp32), and otherwise position by position on the incremental engine; both give the same logits (tested).
 """
 import torch
 from torch import nn
