@@ -51,6 +51,8 @@ def build_model(workload, dev, dtype="bf16"):
     model = model.to(dev)
     if dtype == "bf16":
         model = model.bfloat16()
+    elif dtype == "f16":
+        model = model.half()
     return model, sd, model._hp
 
 
@@ -332,7 +334,7 @@ def main():
     ap.add_argument("--score-batch", type=int, default=1024, help="captions per teacher-forced batch (score-* workloads)")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (eager by default: "
                     "the in-library event profiler of the roofline line needs real launches)")
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16",
+    ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default="bf16",
                     help="storage/MFMA operand type of the measured path (BASELINE configs C2/C3: bf16)")
     args = ap.parse_args()
 

@@ -29,10 +29,19 @@ def needs_build():
 
 
 def build(force=False, verbose=False):
-    """Compiles every HIP source for gfx950 and links the C-ABI shared library."""
-    if not force and not needs_build():
-        return LIB_PATH
+    """Compiles every HIP source for gfx950 and links the C-ABI shared library.  Serialised across processes by a file
+    lock; the library is linked under a temporary name and moved into place atomically, so a concurrent loader never
+    maps a half-written file."""
+    import fcntl
     os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not needs_build():
+            return LIB_PATH
+        return _build_locked(verbose)
+
+
+def _build_locked(verbose):
     objs = []
     procs = []
     for src in SOURCES:
@@ -47,10 +56,12 @@ def build(force=False, verbose=False):
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    tmp = LIB_PATH + f".tmp{os.getpid()}"
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", tmp] + objs
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{res.stdout.decode()}")
+    os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

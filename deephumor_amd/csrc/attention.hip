@@ -119,16 +119,21 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) { load16(p, v); }
+__device__ __forceinline__ void load8(const f16_t* p, float (&v)[8]) { load16(p, v); }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) { store16(p, v); }
+__device__ __forceinline__ void store8(f16_t* p, const float (&v)[8]) { store16(p, v); }
 __device__ __forceinline__ void copy8(float* d, const float* s) {
     *reinterpret_cast<float4*>(d) = *reinterpret_cast<const float4*>(s);
     *reinterpret_cast<float4*>(d + 4) = *reinterpret_cast<const float4*>(s + 4);
 }
 __device__ __forceinline__ void copy8(bf16_t* d, const bf16_t* s) {
+    *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+}
+__device__ __forceinline__ void copy8(f16_t* d, const f16_t* s) {
     *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
 }
 
@@ -230,10 +235,16 @@ __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p)
 template <typename T> struct Raw8;                       // 8 elements kept packed until use
 template <> struct Raw8<float> { float4 a, b; };
 template <> struct Raw8<bf16_t> { uint4 a; };
+template <> struct Raw8<f16_t> { uint4 a; };
 __device__ __forceinline__ void raw_load(const float* p, Raw8<float>& r) {
     r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4);
 }
 __device__ __forceinline__ void raw_load(const bf16_t* p, Raw8<bf16_t>& r) { r.a = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void raw_load(const f16_t* p, Raw8<f16_t>& r) { r.a = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void raw_unpack(const Raw8<f16_t>& r, float (&v)[8]) {
+    unpack_f16x2(r.a.x, v[0], v[1]); unpack_f16x2(r.a.y, v[2], v[3]);
+    unpack_f16x2(r.a.z, v[4], v[5]); unpack_f16x2(r.a.w, v[6], v[7]);
+}
 __device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float (&v)[8]) {
     v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
 }
@@ -603,9 +614,13 @@ extern "C" int dh_attn_self_prefill(const void* qkv, const int32_t* tokens, int 
     if (dtype == DH_F32)
         hipLaunchKernelGGL((attn_self_prefill_kernel<float, 5>), grid, block, 0, s, (const float*)qkv, tokens, tok_ld, (float*)out,
                            rows, n_pos, D, scale, pad_index);
-    else
+    else if (dtype == DH_BF16)
         hipLaunchKernelGGL((attn_self_prefill_kernel<bf16_t, 7>), grid, block, 0, s, (const bf16_t*)qkv, tokens, tok_ld,
                            (bf16_t*)out, rows, n_pos, D, scale, pad_index);
+    else if (dtype == DH_F16)
+        hipLaunchKernelGGL((attn_self_prefill_kernel<f16_t, 7>), grid, block, 0, s, (const f16_t*)qkv, tokens, tok_ld,
+                           (f16_t*)out, rows, n_pos, D, scale, pad_index);
+    else return DH_ERR_UNSUPPORTED;
     DH_LAUNCH_CHECK();
 }
 
@@ -623,5 +638,61 @@ extern "C" int dh_attn_cross_prefill(const void* q, int ldq, const void* kv, con
         char* oc = (char*)out + (size_t)t0 * D * esz;
         DH_DISPATCH_T(dtype, launch_cross<T>(qc, ldq, kv, keymask, oc, n_img, cnt, S, D, n_heads, scale, (hipStream_t)stream, n_pos));
     }
+    DH_LAUNCH_CHECK();
+}
+
+
+// ---- MultiHeadAttentionLayer.forward with an explicit boolean mask (transformers.py:82-127) -----------------------
+// The module-level API of the reference: q, k, v are the projected [bs*L, D] matrices (fc_q / fc_k / fc_v outputs, row
+// b*L + t), mask is the caller's [bs, L, L] boolean tensor (1 = masked_fill(-1e8)) or NULL; out = softmax(q k^T / scale) v
+// with heads merged back, [bs*L, D].  One wave per (query row, head): lane = key for the scores (LDS), lane = head
+// dim for the weighted value sum.  Any head dim, L <= 4096.  Not a hot-path kernel (generate / forward use the
+// cached / prefill kernels above); exact softmax formulation of the reference.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_masked_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ k, int ldk,
+                                                           const T* __restrict__ v, int ldv, const uint8_t* __restrict__ mask,
+                                                           T* __restrict__ out, int rows, int L, int D, int dh, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + w, h = blockIdx.y;
+    float* qs = smem + (size_t)w * (dh + L);
+    float* sc = qs + dh;
+    const bool live = r < rows;
+    const int b = live ? r / L : 0, t = live ? r - b * L : 0;
+    if (live)
+        for (int d = lane; d < dh; d += 64) qs[d] = ldf(q + (size_t)r * ldq + h * dh + d);
+    __syncthreads();
+    if (!live) return;
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) {
+        const T* kp = k + (size_t)(b * L + j) * ldk + h * dh;
+        float a = 0.f;
+        for (int d = 0; d < dh; ++d) a = fmaf(ldf(kp + d), qs[d], a);
+        float e = a / scale;
+        if (mask && mask[((size_t)b * L + t) * L + j]) e = -1e8f;
+        sc[j] = e;
+        mx = fmaxf(mx, e);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) { const float e = expf(sc[j] - mx); sc[j] = e; sum += e; }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // sc is wave-private: order the writes before the reads below
+    for (int d = lane; d < dh; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < L; ++j) acc = fmaf(sc[j] / sum, ldf(v + (size_t)(b * L + j) * ldv + h * dh + d), acc);
+        stf(out + (size_t)r * D + h * dh + d, acc);
+    }
+}
+
+extern "C" int dh_attn_masked(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const uint8_t* mask,
+                              void* out, int bs, int L, int D, int n_heads, float scale, int dtype, void* stream) {
+    DH_REQUIRE(q && k && v && out && bs > 0 && L > 0 && L <= 4096 && n_heads > 0 && D % n_heads == 0);
+    DH_REQUIRE(ldq >= D && ldk >= D && ldv >= D);
+    const int rows = bs * L, dh = D / n_heads;
+    DhProfScope prof("dh_attn_masked", 4.0 * rows * L * D, 0.0, stream);
+    const size_t lds = (size_t)4 * (dh + L) * sizeof(float);
+    DH_DISPATCH_T(dtype, hipLaunchKernelGGL(attn_masked_kernel<T>, dim3(dh_cdiv(rows, 4), n_heads), dim3(256), lds, (hipStream_t)stream,
+                                            (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, mask, (T*)out, rows, L, D, dh, scale));
     DH_LAUNCH_CHECK();
 }

@@ -165,13 +165,48 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
 }
 
 
+// Exact candidate set of a row for the pre-filtered kernels' overflow case (their bound let more than CAP values
+// through -- flat or heavily tied logits): k-th largest key by the 4-pass MSB-first radix select over the whole row
+// (as beam_row_sample_kernel), then every value >= it is compacted into idx_a / val_a (*s_cnt = their number; more
+// than CAP only if that many logits tie at the threshold).  hist: 4 x 256 ints.  Block-uniform call; synchronised on return.
+template <int NT>
+__device__ void radix_row_candidates(const float* __restrict__ row, int V, int top_k, int* hist, uint32_t* s_prefix, int* s_k,
+                                     int* s_cnt, int* wtot, int* idx_a, float* val_a) {
+    const int tid = threadIdx.x, hw = (tid >> 6) & 3;
+    __syncthreads();
+    if (tid == 0) { *s_prefix = 0u; *s_k = top_k; *s_cnt = 0; }
+    uint32_t mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 1024; i += NT) hist[i] = 0;
+        __syncthreads();
+        const uint32_t prefix = *s_prefix;
+        for (int i = tid; i < V; i += NT) {
+            const uint32_t key = f2key(row[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[hw * 256 + ((key >> shift) & 255u)], 1);
+        }
+        __syncthreads();
+        radix_pick_digit(hist, 4, shift, prefix, s_prefix, s_k, wtot);
+        mask |= 0xFFu << shift;
+    }
+    const uint32_t thr = *s_prefix;
+    for (int i = tid; i < V; i += NT) {
+        const float v = row[i];
+        if (f2key(v) >= thr) {
+            const int p = atomicAdd(s_cnt, 1);
+            if (p < CAP) { idx_a[p] = i; val_a[p] = v; }
+        }
+    }
+    __syncthreads();
+}
+
 // ---- single-pass variant --------------------------------------------------------------------------
 // The logits row is read from HBM exactly ONCE, straight into registers (512 threads x EPT values,
 // every load issued up front).  A valid lower bound of the k-th largest value is the k-th largest of
 // the 512 per-thread maxima (k <= 512): at least k elements are >= it.  Everything >= that bound
 // (about top_k..2*top_k values on real logits) is compacted into LDS and the exact threshold,
-// the survivors and the draws are computed there.  Falls back to the 4-pass radix kernel
-// (beam_row_sample_kernel) only through DH_BEAM_ERR_OVERFLOW if > CAP values pass the bound.
+// the survivors and the draws are computed there.  If more than CAP values pass the bound (flat / tied
+// logits) the kernel re-derives the exact candidate set in place with radix_row_candidates.
 struct RowLds {
     int* idx_a; int* idx_b; float* val_a; float* val_b; float* qv; float* red; int* picks; int* s_cnt; uint32_t* s_thr;
 };
@@ -190,6 +225,7 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
 #define s_cnt (*L.s_cnt)
 #define s_thr (*L.s_thr)
     int n0 = s_cnt;
+    __syncthreads();                // every wave has read the candidate count before thread 0 resets it below
     if (n0 > CAP) { if (tid == 0) atomicOr(err, DH_BEAM_ERR_OVERFLOW); n0 = CAP; }
     // exact k-th largest among the candidates: the value whose "strictly greater" count is < k <= "greater or equal"
     for (int i = tid; i < n0; i += NT) {
@@ -280,7 +316,7 @@ __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
     float temperature, int unk, const float* __restrict__ noise, uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step,
     int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
     __shared__ uint32_t lmax[NT];
-    __shared__ int hist[256];
+    __shared__ int hist[4 * 256];
     __shared__ uint32_t s_prefix;
     __shared__ int s_k, s_cnt, wtot[4];
     __shared__ __attribute__((aligned(16))) int idx_a[CAP], idx_b[CAP];
@@ -305,7 +341,7 @@ __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
         if (i < V) best = max(best, f2key(v[e]));
     }
     lmax[tid] = best;
-    if (tid == 0) { s_prefix = 0u; s_k = top_k; s_cnt = 0; }
+    if (tid == 0) { s_prefix = 0u; s_k = top_k; s_cnt = 0; s_thr = 0u; }
     // k-th largest of the 512 thread maxima (one key per thread: cheap LDS radix select)
     uint32_t mask = 0u;
     for (int pass = 0; pass < 4; ++pass) {
@@ -329,6 +365,7 @@ __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
         }
     }
     __syncthreads();
+    if (s_cnt > CAP) radix_row_candidates<NT>(row, V, top_k, hist, &s_prefix, &s_k, &s_cnt, wtot, idx_a, val_a);
     const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
     row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err);
 }
@@ -346,7 +383,7 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     int32_t* __restrict__ err) {
     constexpr int MAXG = 1024, GPT = MAXG / NT;       // group keys per thread, kept in registers
     __shared__ int glist[MAXG];
-    __shared__ int hist[2][256];
+    __shared__ int hist[4][256];
     __shared__ uint32_t s_prefix, s_thr;
     __shared__ int s_k, s_cnt, s_ng, wtot[4];
     __shared__ __attribute__((aligned(16))) int idx_a[CAP], idx_b[CAP];
@@ -364,7 +401,7 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
         gk[e] = g < n_groups ? k : 0u;                                        // key 0 < key of every real float
     }
     for (int i = tid; i < 512; i += NT) (&hist[0][0])[i] = 0;
-    if (tid == 0) { s_prefix = 0u; s_k = min(top_k, n_groups); s_cnt = 0; s_ng = 0; }
+    if (tid == 0) { s_prefix = 0u; s_k = min(top_k, n_groups); s_cnt = 0; s_ng = 0; s_thr = 0u; }
     __syncthreads();
     // Lower edge of the 16-bit key bucket (sign, exponent, 7 mantissa bits) that holds the k-th largest group maximum:
     // at least k groups -- hence at least k logits -- are >= it, and only a handful of extra groups share the bucket.
@@ -403,6 +440,7 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
             }
     }
     __syncthreads();
+    if (s_cnt > CAP) radix_row_candidates<NT>(row, V, top_k, &hist[0][0], &s_prefix, &s_k, &s_cnt, wtot, idx_a, val_a);
     const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
     row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err);
 }

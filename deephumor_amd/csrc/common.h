@@ -66,15 +66,19 @@ __device__ __forceinline__ float philox_exp1(uint64_t seed, uint32_t img, uint32
                                              uint32_t row, uint32_t idx) {
     uint32_t o[4];
     philox4x32(idx, row, step, kind, (uint32_t)seed ^ (img * 0x9E3779B1u), (uint32_t)(seed >> 32) + img, o);
-    float u = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+    // 23 random bits: (i + 0.5) / 2^23 is exact in fp32 for every i < 2^23, so u stays strictly inside (0, 1)
+    // (with 24 bits, i = 2^24 - 1 rounds to u == 1.0f and the Exp(1) sample would be 0)
+    float u = ((float)(o[0] >> 9) + 0.5f) * (1.0f / 8388608.0f);
     return -logf(u);
 }
 
-// ---- storage-type helpers: T = float (parity path) or __bf16 (throughput path); math is fp32 ---------
+// ---- storage-type helpers: T = float (parity path), __bf16 or _Float16 (throughput paths); math is fp32 ---------
 typedef __bf16 bf16_t;
+typedef _Float16 f16_t;
 template <typename T> struct Vec16;                 // elements per 16-byte access
 template <> struct Vec16<float> { static constexpr int N = 4; };
 template <> struct Vec16<bf16_t> { static constexpr int N = 8; };
+template <> struct Vec16<f16_t> { static constexpr int N = 8; };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float((uint32_t)b << 16); }
 __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (bf16_t)f); }
@@ -102,6 +106,31 @@ __device__ __forceinline__ void store16(bf16_t* p, const float (&v)[8]) {
     t.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
     *reinterpret_cast<uint4*>(p) = t;
 }
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(f16_t, h); }
+__device__ __forceinline__ uint16_t f32_to_f16(float f) { return __builtin_bit_cast(uint16_t, (f16_t)f); }
+// two packed fp16 values of one 32-bit word -> fp32 (low half first)
+__device__ __forceinline__ void unpack_f16x2(uint32_t w, float& lo, float& hi) {
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+    lo = (float)h.x; hi = (float)h.y;
+}
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    f16x2_t h; h.x = (f16_t)lo; h.y = (f16_t)hi;
+    return __builtin_bit_cast(uint32_t, h);
+}
+__device__ __forceinline__ void load16(const f16_t* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    unpack_f16x2(t.x, v[0], v[1]); unpack_f16x2(t.y, v[2], v[3]);
+    unpack_f16x2(t.z, v[4], v[5]); unpack_f16x2(t.w, v[6], v[7]);
+}
+__device__ __forceinline__ void store16(f16_t* p, const float (&v)[8]) {
+    uint4 t;
+    t.x = pack_f16x2(v[0], v[1]); t.y = pack_f16x2(v[2], v[3]);
+    t.z = pack_f16x2(v[4], v[5]); t.w = pack_f16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = t;
+}
+__device__ __forceinline__ float ldf(const f16_t* p) { return (float)*p; }
+__device__ __forceinline__ void stf(f16_t* p, float v) { *p = (f16_t)v; }
 __device__ __forceinline__ float ldf(const float* p) { return *p; }
 __device__ __forceinline__ float ldf(const bf16_t* p) { return (float)*p; }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
@@ -110,4 +139,37 @@ __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
 #define DH_DISPATCH_T(dtype, ...)                                             \
     if ((dtype) == DH_F32) { using T = float; __VA_ARGS__; }                  \
     else if ((dtype) == DH_BF16) { using T = bf16_t; __VA_ARGS__; }           \
+    else if ((dtype) == DH_F16) { using T = f16_t; __VA_ARGS__; }             \
     else return DH_ERR_UNSUPPORTED;
+
+// the two 16-bit storage types (bf16 / fp16 in HBM, MFMA operands, fp32 accumulation)
+#define DH_IS_16BIT(dtype) ((dtype) == DH_BF16 || (dtype) == DH_F16)
+#define DH_DISPATCH_16(dtype, ...)                                            \
+    if ((dtype) == DH_BF16) { using T = bf16_t; __VA_ARGS__; }                \
+    else if ((dtype) == DH_F16) { using T = f16_t; __VA_ARGS__; }             \
+    else return DH_ERR_UNSUPPORTED;
+
+// Matrix-core operand traits of the 16-bit types: 8 k-values per lane of v_mfma_f32_16x16x32_{bf16,f16}; raw 16-bit
+// patterns <-> fp32 (kernels that move operands as uint16_t / uint4 and only convert at the edges)
+typedef float dh_f32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct Op16;
+template <> struct Op16<bf16_t> {
+    typedef __bf16 vec8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ dh_f32x4 mfma(uint4 a, uint4 b, dh_f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return f32_to_bf16(f); }
+    static __device__ __forceinline__ float to_f32(uint16_t h) { return bf16_to_f32(h); }
+    static __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
+        lo = __uint_as_float(w << 16); hi = __uint_as_float(w & 0xFFFF0000u);
+    }
+};
+template <> struct Op16<f16_t> {
+    typedef _Float16 vec8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ dh_f32x4 mfma(uint4 a, uint4 b, dh_f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ uint16_t from_f32(float f) { return f32_to_f16(f); }
+    static __device__ __forceinline__ float to_f32(uint16_t h) { return f16_to_f32(h); }
+    static __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) { unpack_f16x2(w, lo, hi); }
+};

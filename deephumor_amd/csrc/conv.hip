@@ -28,8 +28,10 @@ struct ConvParams {
     int N, Cin, H, W, Cout, Ho, Wo, stride, pad, relu, K, P;   // K = Cin*KS*KS, P = N*Ho*Wo
 };
 
-template <int TM, int KS, bool NHWC_BF16_OUT>
+// OUT16 = void: NCHW fp32 output (parity path); bf16_t / f16_t: channels-last 16-bit output (stem of the 16-bit paths)
+template <int TM, int KS, typename OUT16>
 __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
+    constexpr bool NHWC_BF16_OUT = !__is_same(OUT16, void);
     constexpr int TN = 128, BK = 16, LDA = TM + 4;
     constexpr int CO_T = TM / 16;            // output channels per thread (8 or 4)
     constexpr int AK = (TM * BK) / 256;      // weights loaded per thread per slab (8 or 4)
@@ -111,9 +113,9 @@ __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
     }
 
     // ---- epilogue: y = act(acc*scale + shift (+ residual)) --------------------------------------
-    if (NHWC_BF16_OUT) {
-        // stem of the bf16 path: NCHW fp32 image in, channels-last bf16 out (4 consecutive channels per store)
-        bf16_t* yo = reinterpret_cast<bf16_t*>(p.y);
+    if constexpr (NHWC_BF16_OUT) {
+        // stem of the 16-bit paths: NCHW fp32 image in, channels-last bf16 / fp16 out (4 consecutive channels per store)
+        uint16_t* yo = reinterpret_cast<uint16_t*>(p.y);
 #pragma unroll
         for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
                     for (int c = 0; c < 4; ++c) {
                         float v = acc[ig * 4 + c][g * 4 + j] * p.scale[cb + c] + p.shift[cb + c];
                         if (p.relu) v = fmaxf(v, 0.f);
-                        h[c] = f32_to_bf16(v);
+                        h[c] = Op16<OUT16>::from_f32(v);
                     }
                     uint2 pk;
                     pk.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
@@ -178,9 +180,9 @@ __global__ __launch_bounds__(256) void conv_bn_act_kernel(ConvParams p) {
     }
 }
 
-template <int TM, int KS, bool NHWC_BF16_OUT = false>
+template <int TM, int KS, typename OUT16 = void>
 static void launch_conv(const ConvParams& p, hipStream_t s) {
-    hipLaunchKernelGGL((conv_bn_act_kernel<TM, KS, NHWC_BF16_OUT>), dim3(dh_cdiv(p.P, 128), dh_cdiv(p.Cout, TM)),
+    hipLaunchKernelGGL((conv_bn_act_kernel<TM, KS, OUT16>), dim3(dh_cdiv(p.P, 128), dh_cdiv(p.Cout, TM)),
                        dim3(256), 0, s, p);
 }
 
@@ -208,7 +210,7 @@ extern "C" int dh_conv2d_bn_act(const void* x, const void* w, const float* scale
 
 extern "C" int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const float* shift, void* y,
                                  int N, int Cin, int H, int W, int Cout, int KS, int stride, int pad, int relu,
-                                 void* stream) {
+                                 int dtype, void* stream) {
     DH_REQUIRE(x && w && scale && shift && y && N > 0 && Cin > 0 && H > 0 && W > 0 && Cout > 0 && (Cout % 4) == 0);
     DH_REQUIRE((KS == 7 || KS == 3) && stride >= 1 && pad >= 0);
     ConvParams p{x, w, scale, shift, nullptr, (float*)y, N, Cin, H, W, Cout, (H + 2 * pad - KS) / stride + 1,
@@ -217,13 +219,16 @@ extern "C" int dh_stem_conv_nhwc(const float* x, const float* w, const float* sc
     p.P = N * p.Ho * p.Wo;
     hipStream_t s = (hipStream_t)stream;
     DhProfScope prof("dh_stem_conv_nhwc", 2.0 * p.P * Cout * p.K, 4.0 * N * Cin * H * W + 2.0 * p.P * Cout, stream);
-    if (KS == 7) { if (Cout >= 128) launch_conv<128, 7, true>(p, s); else launch_conv<64, 7, true>(p, s); }
-    else { if (Cout >= 128) launch_conv<128, 3, true>(p, s); else launch_conv<64, 3, true>(p, s); }
+    DH_DISPATCH_16(dtype, {
+        if (KS == 7) { if (Cout >= 128) launch_conv<128, 7, T>(p, s); else launch_conv<64, 7, T>(p, s); }
+        else { if (Cout >= 128) launch_conv<128, 3, T>(p, s); else launch_conv<64, 3, T>(p, s); }
+    });
     DH_LAUNCH_CHECK();
 }
 
 // ---- image packing for the matrix-core stem: NCHW fp32 [N,C,H,W] (C <= 8) -> NHWC bf16 [N,H,W,8], channels C..7 zero ----
-__global__ __launch_bounds__(256) void pack_nchw_to_nhwc8_kernel(const float* __restrict__ x, bf16_t* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void pack_nchw_to_nhwc8_kernel(const float* __restrict__ x, T* __restrict__ y,
                                                                    int C, int HW, size_t total) {
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
         const size_t n = i / HW, p = i - n * HW;
@@ -241,12 +246,12 @@ __global__ __launch_bounds__(256) void pack_nchw_to_nhwc8_kernel(const float* __
     }
 }
 
-extern "C" int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, void* stream) {
+extern "C" int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, int dtype, void* stream) {
     DH_REQUIRE(x && y && N > 0 && C > 0 && C <= 8 && H > 0 && W > 0);
     DhProfScope prof("dh_pack_nchw_to_nhwc8", 0.0, (double)N * H * W * (4.0 * C + 16.0), stream);
     const size_t total = (size_t)N * H * W;
     const int grid = (int)((total + 255) / 256 < 32768 ? (total + 255) / 256 : 32768);
-    hipLaunchKernelGGL(pack_nchw_to_nhwc8_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (bf16_t*)y, C, H * W, total);
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL(pack_nchw_to_nhwc8_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (T*)y, C, H * W, total));
     DH_LAUNCH_CHECK();
 }
 
@@ -274,7 +279,8 @@ extern "C" int dh_normalize_u8_hwc(const uint8_t* x, const float* mean, const fl
 }
 
 // ---- channels-last bf16 pools (bf16 path) ------------------------------------------------------------------
-__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                                  int N, int H, int W, int C, int Ho, int Wo) {
     const int c8 = C / 8;
     const size_t total = (size_t)N * Ho * Wo * c8;
@@ -306,19 +312,20 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_kernel(const bf16_t* __
 }
 
 extern "C" int dh_maxpool3x3s2_nhwc(const void* x, void* y, int N, int H, int W, int C, int dtype, void* stream) {
-    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && (C % 8) == 0);
     DhProfScope prof("dh_maxpool3x3s2_nhwc", 0.0, 0.0, stream);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const size_t total = (size_t)N * Ho * Wo * (C / 8);
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
-                       (bf16_t*)y, N, H, W, C, Ho, Wo);
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const T*)x,
+                                             (T*)y, N, H, W, C, Ho, Wo));
     DH_LAUNCH_CHECK();
 }
 
 // x [N, HW, C] -> y [N, C]: mean over the HW positions, fp32 accumulation
-__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y,
                                                             int N, int HW, int C) {
     const int c8 = C / 8;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -339,11 +346,11 @@ __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const bf16_t* __restr
 }
 
 extern "C" int dh_avgpool_nhwc(const void* x, void* y, int N, int HW, int C, int dtype, void* stream) {
-    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && (C % 8) == 0);
     DhProfScope prof("dh_avgpool_nhwc", 0.0, 0.0, stream);
-    hipLaunchKernelGGL(avgpool_nhwc_kernel, dim3(dh_cdiv((long long)N * (C / 8), 256)), dim3(256), 0,
-                       (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, N, HW, C);
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL(avgpool_nhwc_kernel<T>, dim3(dh_cdiv((long long)N * (C / 8), 256)), dim3(256), 0,
+                                             (hipStream_t)stream, (const T*)x, (T*)y, N, HW, C));
     DH_LAUNCH_CHECK();
 }
 

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(
 
 int dh_linear_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const float* scale,
                         const float* shift, const void* residual, int ldres, void* C, int ldc, int M, int N, int K,
-                        int relu, int out_f32, hipStream_t s);
+                        int relu, int out_f32, int f16, hipStream_t s);
 
 extern "C" int dh_linear(const void* A, int lda, const void* W, int ldw, const float* bias,
                          const float* scale, const float* shift, const void* residual, int ldres,
@@ -137,10 +137,10 @@ extern "C" int dh_linear(const void* A, int lda, const void* W, int ldw, const f
     DH_REQUIRE(!residual || ldres >= N);
     hipStream_t s = (hipStream_t)stream;
     const double esz = dtype == DH_F32 ? 4.0 : 2.0;
-    DhProfScope prof("dh_linear", 2.0 * M * N * K, esz * ((double)M * K + (double)N * K) + (dtype == DH_BF16 ? 2.0 : 4.0) * M * N, stream);
-    if (dtype == DH_BF16 || dtype == DH_BF16_OUT_F32)
+    DhProfScope prof("dh_linear", 2.0 * M * N * K, esz * ((double)M * K + (double)N * K) + (DH_IS_16BIT(dtype) ? 2.0 : 4.0) * M * N, stream);
+    if (dtype == DH_BF16 || dtype == DH_BF16_OUT_F32 || dtype == DH_F16 || dtype == DH_F16_OUT_F32)
         return dh_linear_bf16_impl(A, lda, W, ldw, bias, scale, shift, residual, ldres, C, ldc, M, N, K, relu,
-                                   dtype == DH_BF16_OUT_F32, s);
+                                   dtype == DH_BF16_OUT_F32 || dtype == DH_F16_OUT_F32, dtype == DH_F16 || dtype == DH_F16_OUT_F32, s);
     if (dtype != DH_F32) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE((K % 4) == 0 && (lda % 4) == 0 && (ldw % 4) == 0 && lda >= K && ldw >= K && ldc >= N);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);

@@ -1,5 +1,6 @@
-// bf16 matrix-core engine: C[M,N] = act((A[M,K] * W[N,K]^T + bias) * scale + shift (+ residual)),
-// bf16 operands, fp32 accumulation in v_mfma_f32_16x16x32_bf16, bf16 or fp32 output.
+// 16-bit matrix-core engine: C[M,N] = act((A[M,K] * W[N,K]^T + bias) * scale + shift (+ residual)),
+// bf16 or fp16 operands (template parameter OT; the data path moves raw 16-bit patterns and is type-agnostic),
+// fp32 accumulation in v_mfma_f32_16x16x32_{bf16,f16}, 16-bit or fp32 output.
 //
 // One kernel, two A-operand loaders:
 //   dense  : A is a row-major [M, lda] matrix (every nn.Linear / LSTM gate / vocabulary product);
@@ -23,8 +24,7 @@
 #include "common.h"
 #include "prof.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef dh_f32x4 f32x4;
 
 __device__ uint4 dh_zero_page[4];        // zero-initialised: source of padding chunks
 
@@ -63,7 +63,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 // NS = LDS ring depth: slabs t+1 .. t+NS-1 are in flight (LDS-DMA) while slab t feeds the MFMAs.
 // NW waves per workgroup, arranged WAVES_M x (NW / WAVES_M) over the BM x BN block.
-template <int BM, int BN, int WAVES_M, bool CONV, int NS, int NW = 4>
+template <typename OT, int BM, int BN, int WAVES_M, bool CONV, int NS, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
     constexpr int NT = 64 * NW;
     constexpr int BK = 64;
@@ -254,22 +254,22 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int g = kk * 4 + lq;                    // logical 16-B chunk holding k = kk*32 + 8*lq .. +7
-            bf16x8 fa[TM], fw[TN];
+            uint4 fa[TM], fw[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int r = wm0 + i * 16 + l15;
-                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + r * 128 + ((g ^ (r & 7)) << 4)));
+                fa[i] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((g ^ (r & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = wn0 + j * 16 + l15;
-                fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + r * 128 + ((g ^ (r & 7)) << 4)));
+                fw[j] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((g ^ (r & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = Op16<OT>::mfma(fw[j], fa[i], acc[j][i]);
         }
     }
     __syncthreads();                                      // all slabs consumed: LDS is free for the epilogue
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             const int m = m0 + row, n = n0 + col;
             if (m >= p.M || n >= p.N) continue;
             float x = ep[row * BN + ((((col >> 2) ^ (row & (SLOTS - 1))) << 2) | (col & 3))];
-            if (p.res) x += bf16_to_f32(p.res[(size_t)m * p.ldres + n]);
+            if (p.res) x += Op16<OT>::to_f32(p.res[(size_t)m * p.ldres + n]);
             if (p.relu) x = fmaxf(x, 0.f);
             Cf[(size_t)m * p.ldc + n] = x;
         }
@@ -395,27 +395,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
                 const uint32_t w4[4] = {rq[it].x, rq[it].y, rq[it].z, rq[it].w};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    v[2 * u] += __uint_as_float(w4[u] << 16);
-                    v[2 * u + 1] += __uint_as_float(w4[u] & 0xFFFF0000u);
+                    float lo, hi;
+                    Op16<OT>::unpack2(w4[u], lo, hi);
+                    v[2 * u] += lo; v[2 * u + 1] += hi;
                 }
             }
             if (p.relu) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u) v[u] = fmaxf(v[u], 0.f);
             }
-            store16(reinterpret_cast<bf16_t*>(C + (size_t)m * p.ldc + n), v);
+            store16(reinterpret_cast<OT*>(C + (size_t)m * p.ldc + n), v);
         } else {
             for (int u = 0; u < 8 && n + u < p.N; ++u) {
                 float x = v[u];
-                if (p.res) x += bf16_to_f32(p.res[(size_t)m * p.ldres + n + u]);
+                if (p.res) x += Op16<OT>::to_f32(p.res[(size_t)m * p.ldres + n + u]);
                 if (p.relu) x = fmaxf(x, 0.f);
-                C[(size_t)m * p.ldc + n + u] = f32_to_bf16(x);
+                C[(size_t)m * p.ldc + n + u] = Op16<OT>::from_f32(x);
             }
         }
     }
 }
 
-template <bool CONV>
+template <typename OT, bool CONV>
 static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     {   // measured on the ResNet-50 layers at 256 images: 4.63 -> 4.45 ms over all bottleneck convolutions
         const double w_bytes = 2.0 * p.N * p.K, a_bytes = 2.0 * p.M * (CONV ? p.Cin : p.K);
@@ -431,7 +432,7 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
         // 8 waves (4 x 2, each 32 x 64) on the 128 x 128 tile, 2 workgroups per CU = 4 waves per SIMD: measured
         // 510 TF vs 450 TF with 4 waves per workgroup and 300 TF with one 4-wave workgroup and a deeper ring --
         // the MFMA pipe needs co-resident waves to cover each wave's LDS-read/barrier gaps
-        hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
         return;
     }
     if (p.N <= 64 && p.M >= 256 * 512) {
@@ -439,10 +440,10 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
         // rows are staged once per 256 pixels; measured 127 us vs 146 us with 4 waves, 135 us with 128 x 64 tiles)
         p.tiles_m = dh_cdiv(p.M, 256); p.tiles_n = dh_cdiv(p.N, 64);
         if (CONV) {
-            hipLaunchKernelGGL((gemm_bf16_kernel<256, 64, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 256, 64, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
         } else {    // dense 1x1 (HBM-bound, ~5 TB/s): smaller tiles, 3 workgroups per CU
             p.tiles_m = dh_cdiv(p.M, 128);
-            hipLaunchKernelGGL((gemm_bf16_kernel<128, 64, 2, CONV, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 64, 2, CONV, 2, 4>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
         }
         return;
     }
@@ -454,38 +455,43 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     static const int force_ns = getenv("DH_GEMM64_NS") ? atoi(getenv("DH_GEMM64_NS")) : 0;
     // (32 x 64 tiles for the 160-workgroup decoder projections: slower -- proj 5.5 -> 6.1 ms, ffn 6.0 -> 7.6 ms per C3 step)
     if (force_ns == 4 || blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
     else if (blocks <= 320)
         // 8 waves on the 64 x 64 tile (32 x 16 per wave): twice the waves issuing LDS-DMA for the 7 slabs in flight --
         // these launches are bound by how fast one workgroup per CU can pull its operands (proj 5.75 -> 5.5 ms per C3 step)
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 8, 8>), dim3(blocks), dim3(512), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, CONV, 8, 8>), dim3(blocks), dim3(512), 0, s, p);
     else if (blocks <= 768)
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 3>), dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, CONV, 3>), dim3(blocks), dim3(256), 0, s, p);
     else
-        hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, 2, CONV, 2>), dim3(blocks), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, CONV, 2>), dim3(blocks), dim3(256), 0, s, p);
 }
 
-static bool launch_persistent_f32(const GemmBf16Params& p, hipStream_t s);   // defined below vocab_logits_kernel
+template <typename OT> static bool launch_persistent_f32(const GemmBf16Params& p, hipStream_t s);   // defined below vocab_logits_kernel
 
 // called from dh_linear (gemm.hip) for DH_BF16 / DH_BF16_OUT_F32
 int dh_linear_bf16_impl(const void* A, int lda, const void* W, int ldw, const float* bias, const float* scale,
                         const float* shift, const void* residual, int ldres, void* C, int ldc, int M, int N, int K,
-                        int relu, int out_f32, hipStream_t s) {
+                        int relu, int out_f32, int f16, hipStream_t s) {
     DH_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K && ldc >= N);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
     GemmBf16Params p{};
     p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw;
     p.bias = bias; p.scale = scale; p.shift = shift; p.res = (const uint16_t*)residual; p.ldres = ldres;
     p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.relu = relu; p.out_f32 = out_f32;
-    if (out_f32 && launch_persistent_f32(p, s)) DH_LAUNCH_CHECK();
-    launch_gemm_bf16<false>(p, s);
+    if (f16) {
+        if (out_f32 && launch_persistent_f32<f16_t>(p, s)) DH_LAUNCH_CHECK();
+        launch_gemm_bf16<f16_t, false>(p, s);
+    } else {
+        if (out_f32 && launch_persistent_f32<bf16_t>(p, s)) DH_LAUNCH_CHECK();
+        launch_gemm_bf16<bf16_t, false>(p, s);
+    }
     DH_LAUNCH_CHECK();
 }
 
 extern "C" int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* scale, const float* shift,
                                      const void* residual, void* y, int N, int H, int W, int Cin, int Cout,
                                      int KS, int stride, int pad, int relu, int dtype, void* stream) {
-    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(x && w && scale && shift && y && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0);
     DH_REQUIRE((Cin % 8) == 0 && KS >= 1 && stride >= 1 && pad >= 0);
     DH_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0);
@@ -512,8 +518,10 @@ extern "C" int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* 
     dh_prof_set_tag(tags[KS < 8 ? KS : 0]);
     DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * p.M * Cout * p.K,
                      2.0 * ((double)N * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout * (residual ? 2 : 1)), stream);
-    if (KS == 1 && stride == 1 && pad == 0) { p.lda = Cin; p.conv = 0; launch_gemm_bf16<false>(p, s); }
-    else { p.conv = 1; launch_gemm_bf16<true>(p, s); }
+    DH_DISPATCH_16(dtype, {
+        if (KS == 1 && stride == 1 && pad == 0) { p.lda = Cin; p.conv = 0; launch_gemm_bf16<T, false>(p, s); }
+        else { p.conv = 1; launch_gemm_bf16<T, true>(p, s); }
+    });
     DH_LAUNCH_CHECK();
 }
 
@@ -557,7 +565,7 @@ __device__ __forceinline__ void wait_vmcnt_any(int n) {
     }
 }
 
-template <int NS, int BM, int BN, int WAVES_M, int NW, bool LSE = false>
+template <typename OT, int NS, int BM, int BN, int WAVES_M, int NW, bool LSE = false>
 __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1)) void vocab_logits_kernel(VocabParams p) {
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * 128, SLAB = A_BYTES + BN * 128;
@@ -659,19 +667,19 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
             const unsigned char* sb = sa + A_BYTES;
             // all fragments of the slab first (12 ds_read_b128 back to back, one wait), then the 16 MFMAs back to back:
             // the other waves of the SIMD issue during the single LDS wait instead of during four short ones
-            bf16x8 fa[2][TM], fw[2][TN];
+            uint4 fa[2][TM], fw[2][TN];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const int c = kk * 4 + lq;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int rr = wm0 + i * 16 + l15;
-                    fa[kk][i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + rr * 128 + ((c ^ (rr & 7)) << 4)));
+                    fa[kk][i] = *reinterpret_cast<const uint4*>(sa + rr * 128 + ((c ^ (rr & 7)) << 4));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int rr = wn0 + j * 16 + l15;
-                    fw[kk][j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + rr * 128 + ((c ^ (rr & 7)) << 4)));
+                    fw[kk][j] = *reinterpret_cast<const uint4*>(sb + rr * 128 + ((c ^ (rr & 7)) << 4));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
                 for (int j = 0; j < TN; ++j)
 #pragma unroll
                     for (int i = 0; i < TM; ++i)
-                        acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[kk][j], fa[kk][i], acc[j][i], 0, 0, 0);
+                        acc[j][i] = Op16<OT>::mfma(fw[kk][j], fa[kk][i], acc[j][i]);
         }
         // ---- epilogue, registers only: acc[j][i][r] = logit[m0+wm0+16i+l15][n0+wn0+16j+4lq+r] -------------------
         float4 b4[TN];
@@ -783,6 +791,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
 
 // fp32-output dense GEMMs with many tiles (teacher-forced classifier: [bs*T, V] logits): the persistent kernel without
 // the group maxima (600 vs 385 TF for the one-tile-per-workgroup kernel with its LDS-staged fp32 epilogue).
+template <typename OT>
 static bool launch_persistent_f32(const GemmBf16Params& p, hipStream_t s) {
     if (p.scale || p.res || p.relu || p.gmax || (p.K & 63) || p.K < 128) return false;
     if ((p.ldc & 3) || ((uintptr_t)p.C & 15)) return false;
@@ -791,7 +800,7 @@ static bool launch_persistent_f32(const GemmBf16Params& p, hipStream_t s) {
     VocabParams v{};
     v.A = p.A; v.lda = p.lda; v.W = p.W; v.ldw = p.ldw; v.bias = p.bias; v.C = (float*)p.C; v.ldc = p.ldc;
     v.M = p.M; v.N = p.N; v.K = p.K; v.tiles_m = tiles_m; v.tiles_n = tiles_n;
-    hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8>), dim3(512), dim3(512), 0, s, v);
+    hipLaunchKernelGGL((vocab_logits_kernel<OT, 2, 128, 128, 4, 8>), dim3(512), dim3(512), 0, s, v);
     return true;
 }
 
@@ -802,7 +811,7 @@ static bool launch_persistent_f32(const GemmBf16Params& p, hipStream_t s) {
 extern "C" int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w, const float* shift, void* out, int N, int Ho,
                                     int Wo, int C1, int H, int W, int C2, int stride, int Cout, int relu, int dtype,
                                     void* stream) {
-    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(y && x && w && shift && out && N > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0 && Cout > 0 && stride >= 1);
     DH_REQUIRE((C1 % 64) == 0 && (C2 % 64) == 0 && C1 > 0 && C2 > 0 && (Ho - 1) * stride < H && (Wo - 1) * stride < W);
     DH_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && (long long)N * Ho * Wo < (1ll << 31));
@@ -813,7 +822,7 @@ extern "C" int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w,
     dh_prof_set_tag("1x1");
     DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * p.M * Cout * p.K,
                      2.0 * ((double)p.M * C1 + (double)p.M * C2 + (double)Cout * p.K + (double)p.M * Cout), stream);
-    launch_gemm_bf16<false>(p, (hipStream_t)stream);
+    DH_DISPATCH_16(dtype, launch_gemm_bf16<T, false>(p, (hipStream_t)stream));
     DH_LAUNCH_CHECK();
 }
 
@@ -821,7 +830,7 @@ extern "C" int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w,
 // max of logits[m, 64g .. 64g+63] (always the 128x128 tile: its waves own 64-column groups).
 extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float* bias, float* logits, int ldl,
                                float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream) {
-    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(A && W && logits && group_max && M > 0 && V > 0 && K > 0 && ldl >= V && gm_ld >= 2 * dh_cdiv(V, 128));
     DH_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
@@ -845,14 +854,16 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         //  4-slab ring, the two wave halves one barrier apart -- 85 us with LDS-DMA, 170 us register-staged; with 64-byte
         //  row segments every 128-byte line is fetched twice.  scratch/dma_probe shows the LDS-DMA path itself sustains
         //  110-125 GB/s per CU against the ~46 GB/s this kernel draws: DESIGN.md section 9.)
-        hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, (hipStream_t)stream, v);
+        DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0,
+                                                 (hipStream_t)stream, v));
         DH_LAUNCH_CHECK();
     }
     GemmBf16Params p{};
     p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = bias;
     p.C = logits; p.ldc = ldl; p.M = M; p.N = V; p.K = K; p.out_f32 = 1; p.gmax = group_max; p.gmax_ld = gm_ld;
     p.tiles_m = dh_cdiv(M, 128); p.tiles_n = dh_cdiv(V, 128);
-    hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, 4, false, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, (hipStream_t)stream, p);
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL((gemm_bf16_kernel<T, 128, 128, 4, false, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0,
+                                             (hipStream_t)stream, p));
     DH_LAUNCH_CHECK();
 }
 
@@ -884,7 +895,7 @@ __global__ __launch_bounds__(256) void lse_combine_kernel(const float* __restric
 extern "C" int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, const float* bias, const int64_t* targets,
                                 float* logp, float* group_max, float* group_sum, float* target_logit, int gm_ld, int M, int V,
                                 int K, int dtype, void* stream) {
-    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(A && W && targets && logp && group_max && group_sum && target_logit && M > 0 && V > 0 && K > 0);
     DH_REQUIRE(gm_ld >= 2 * dh_cdiv(V, 128) && (K % 64) == 0 && K >= 128 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
@@ -896,7 +907,7 @@ extern "C" int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, 
     v.M = M; v.N = V; v.K = K; v.tiles_m = dh_cdiv(M, 128); v.tiles_n = dh_cdiv(V, 128);
     const int ntiles = v.tiles_m * v.tiles_n;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((vocab_logits_kernel<2, 128, 128, 4, 8, true>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, s, v);
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 4, 8, true>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0, s, v));
     hipLaunchKernelGGL(lse_combine_kernel, dim3(dh_cdiv(M, 4)), dim3(256), 0, s, group_max, group_sum, gm_ld, 2 * dh_cdiv(V, 128),
                        target_logit, targets, V, logp, M);
     DH_LAUNCH_CHECK();

@@ -15,8 +15,7 @@
 #include "common.h"
 #include "prof.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef dh_f32x4 f32x4;
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
@@ -49,7 +48,7 @@ __device__ __forceinline__ float lf_tanh(float x) {
     return copysignf(t, x);
 }
 
-template <int NS>
+template <typename OT, int NS>
 __global__ __launch_bounds__(256) void lstm_layer_fused_kernel(LstmFusedParams p) {
     constexpr int BM = 64, BN = 64, BK = 64, NW = 4, WAVES_M = 2;
     constexpr int A_BYTES = BM * 128, SLAB = A_BYTES + BN * 128;
@@ -170,22 +169,22 @@ __global__ __launch_bounds__(256) void lstm_layer_fused_kernel(LstmFusedParams p
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int c = kk * 4 + lq;
-            bf16x8 fa[TM], fw[TN];
+            uint4 fa[TM], fw[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int r = wm0 + i * 16 + l15;
-                fa[i] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + r * 128 + ((c ^ (r & 7)) << 4)));
+                fa[i] = *reinterpret_cast<const uint4*>(sa + r * 128 + ((c ^ (r & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int r = wn0 + j * 16 + l15;
-                fw[j] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sb + r * 128 + ((c ^ (r & 7)) << 4)));
+                fw[j] = *reinterpret_cast<const uint4*>(sb + r * 128 + ((c ^ (r & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[j][i], 0, 0, 0);
+                    acc[j][i] = Op16<OT>::mfma(fw[j], fa[i], acc[j][i]);
         }
     }
     // ---- cell update in registers: acc[j][i] = (i, f, g, o) pre-activations of unit u for row m -------------------
@@ -201,7 +200,7 @@ __global__ __launch_bounds__(256) void lstm_layer_fused_kernel(LstmFusedParams p
             const float gg = acc[j][i][2] + b4[j].z, go = acc[j][i][3] + b4[j].w;
             const float c1 = lf_sigmoid(gf) * c0[i][j] + lf_sigmoid(gi) * lf_tanh(gg);
             const float h1 = lf_sigmoid(go) * lf_tanh(c1);
-            const uint16_t hb = f32_to_bf16(h1);
+            const uint16_t hb = Op16<OT>::from_f32(h1);
             p.c_next[(size_t)rl_e[i] * p.Hh + u] = c1;
             p.h_next[(size_t)rl_e[i] * p.Hh + u] = hb;
             p.h_out[(size_t)m * p.ld_out + u] = hb;
@@ -214,7 +213,7 @@ extern "C" int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const
                                    const int32_t* hparent, void* h_next, float* c_next, void* h_out, int ld_out,
                                    const void* w_il, const float* b_il, int rows, int row_mult, int E, int Hh,
                                    int dtype, void* stream) {
-    if (dtype != DH_BF16) return DH_ERR_UNSUPPORTED;
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE((x_rows || (emb && tokens)) && h_next && c_next && h_out && w_il && b_il);
     DH_REQUIRE(rows > 0 && row_mult > 0 && x_div > 0 && (E % 8) == 0 && (Hh % 8) == 0 && (ldx % 8) == 0 && ld_out >= Hh);
     DH_REQUIRE((h_prev == nullptr) == (c_prev == nullptr) && h_prev != h_next && c_prev != c_next);
@@ -233,11 +232,13 @@ extern "C" int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const
     // measured at 1280 rows x 2048 gate columns (640 workgroups): 4 slabs (2 per CU, 1.25 rounds) 20.7 / 24.3 us,
     // 3 slabs (3 per CU) 16.6 / 19.0 us, 2 slabs (5 per CU) 16.4 / 18.6 us  (E = 256 / 512)
     const int blocks = p.tiles_m * p.tiles_n;
-    if (blocks > 768 && blocks <= 1280)
-        hipLaunchKernelGGL(lstm_layer_fused_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else if (blocks > 512 && blocks <= 768)
-        hipLaunchKernelGGL(lstm_layer_fused_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(lstm_layer_fused_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    DH_DISPATCH_16(dtype, {
+        if (blocks > 768 && blocks <= 1280)
+            hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        else if (blocks > 512 && blocks <= 768)
+            hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    });
     DH_LAUNCH_CHECK();
 }

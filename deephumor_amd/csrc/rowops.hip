@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void embed_prefill_kernel(
     const int rc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (rc >= rows) return;
     const int n = rc / n_pos, t = rc - n * n_pos;
-    const T* src = t == 0 ? start_emb + (size_t)n * D : tok_emb + (size_t)tokens[(size_t)n * tok_ld + t - 1] * D;
+    // with a start embedding the image occupies slot 0 and token j sits at position j + 1 (transformers.py:455-458)
+    const T* src = start_emb ? (t == 0 ? start_emb + (size_t)n * D : tok_emb + (size_t)tokens[(size_t)n * tok_ld + t - 1] * D)
+                             : tok_emb + (size_t)tokens[(size_t)n * tok_ld + t] * D;
     const T* pe = pos_emb + (size_t)t * D;
     T* dst = x + (size_t)rc * D;
     for (int d = lane * VN; d < D; d += 64 * VN) {
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void embed_prefill_kernel(
 
 extern "C" int dh_embed_prefill(const void* tok_emb, const void* pos_emb, const void* start_emb, const int32_t* tokens,
                                 int tok_ld, void* x, int n_seq, int n_pos, int D, float scale, int dtype, void* stream) {
-    DH_REQUIRE(tok_emb && pos_emb && start_emb && x && n_seq > 0 && n_pos > 0 && (n_pos == 1 || tokens) && (D % 8) == 0);
+    DH_REQUIRE(tok_emb && pos_emb && x && n_seq > 0 && n_pos > 0 && ((start_emb && n_pos == 1) || tokens) && (D % 8) == 0);
     DhProfScope prof("dh_embed_prefill", 0.0, 0.0, stream);
     const int rows = n_seq * n_pos;
     DH_DISPATCH_T(dtype, hipLaunchKernelGGL(embed_prefill_kernel<T>, dim3(dh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream,
@@ -175,6 +177,75 @@ extern "C" int dh_enc_key_mask(const void* enc_out, uint8_t* keymask, int rows, 
     DhProfScope prof("dh_enc_key_mask", 0.0, 0.0, stream);
     DH_DISPATCH_T(dtype, hipLaunchKernelGGL(enc_key_mask_kernel<T>, dim3(dh_cdiv(rows, 4)), dim3(256), 0,
                                             (hipStream_t)stream, (const T*)enc_out, keymask, rows, D));
+    DH_LAUNCH_CHECK();
+}
+
+// ---- mask helpers of the reference's module API (transformers.py:12-40, 480-481) ------------------------------------
+// get_pad_mask: mask[b, q, k] = (key[b, k] == pad_index)
+__global__ __launch_bounds__(256) void pad_mask_kernel(const int64_t* __restrict__ key, uint8_t* __restrict__ mask, int Lq, int Lk,
+                                                        long long pad_index, size_t total) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
+        const size_t b = i / ((size_t)Lq * Lk);
+        const int k = (int)(i % Lk);
+        mask[i] = (uint8_t)(key[b * Lk + k] == pad_index);
+    }
+}
+
+extern "C" int dh_pad_mask(const int64_t* key, uint8_t* mask, int bs, int Lq, int Lk, long long pad_index, void* stream) {
+    DH_REQUIRE(key && mask && bs > 0 && Lq > 0 && Lk > 0);
+    DhProfScope prof("dh_pad_mask", 0.0, 0.0, stream);
+    const size_t total = (size_t)bs * Lq * Lk;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(pad_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, key, mask, Lq, Lk, pad_index, total);
+    DH_LAUNCH_CHECK();
+}
+
+// get_autoregressive_mask: mask[b, q, k] = (k > q)   (torch.triu(ones, 1))
+__global__ __launch_bounds__(256) void autoregressive_mask_kernel(uint8_t* __restrict__ mask, int L, size_t total) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
+        const int k = (int)(i % L), q = (int)((i / L) % L);
+        mask[i] = (uint8_t)(k > q);
+    }
+}
+
+extern "C" int dh_autoregressive_mask(uint8_t* mask, int bs, int L, void* stream) {
+    DH_REQUIRE(mask && bs > 0 && L > 0);
+    DhProfScope prof("dh_autoregressive_mask", 0.0, 0.0, stream);
+    const size_t total = (size_t)bs * L * L;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(autoregressive_mask_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, mask, L, total);
+    DH_LAUNCH_CHECK();
+}
+
+// a |= b over n bytes (input_mask = pad_mask | autoregressive_mask, transformers.py:477)
+__global__ __launch_bounds__(256) void mask_or_kernel(uint8_t* __restrict__ a, const uint8_t* __restrict__ b, size_t n) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256ull) a[i] = (uint8_t)((a[i] | b[i]) != 0);
+}
+
+extern "C" int dh_mask_or(uint8_t* a, const uint8_t* b, long long n, void* stream) {
+    DH_REQUIRE(a && b && n > 0);
+    DhProfScope prof("dh_mask_or", 0.0, 0.0, stream);
+    const int grid = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(mask_or_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a, b, (size_t)n);
+    DH_LAUNCH_CHECK();
+}
+
+// enc_inp_mask[r] = all(enc_out[r, :] != 0) as int64 0/1  (transformers.py:480)
+template <typename T>
+__global__ __launch_bounds__(256) void enc_nonzero_rows_kernel(const T* __restrict__ e, int64_t* __restrict__ m, int rows, int D) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    int z = 0;
+    for (int d = lane; d < D; d += 64) z |= (ldf(e + (size_t)r * D + d) == 0.f);
+    z = __any(z);
+    if (lane == 0) m[r] = z ? 0 : 1;
+}
+
+extern "C" int dh_enc_nonzero_rows(const void* enc_out, int64_t* out, int rows, int D, int dtype, void* stream) {
+    DH_REQUIRE(enc_out && out && rows > 0 && D > 0);
+    DhProfScope prof("dh_enc_nonzero_rows", 0.0, 0.0, stream);
+    DH_DISPATCH_T(dtype, hipLaunchKernelGGL(enc_nonzero_rows_kernel<T>, dim3(dh_cdiv(rows, 4)), dim3(256), 0,
+                                            (hipStream_t)stream, (const T*)enc_out, out, rows, D));
     DH_LAUNCH_CHECK();
 }
 

@@ -44,13 +44,13 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
         DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln3_g, L.ln3_b, dst, rows, D, L.ln3_eps, dt, stream));
     }
     (void)esz;
-    if (logits && group_max && dt == DH_BF16) {
+    if (logits && group_max && DH_IS_16BIT(dt)) {
         DH_TRY(dh_vocab_logits(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, D,
                                dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
         DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows,
-                         m->V, D, 0, dt == DH_F32 ? DH_F32 : DH_BF16_OUT_F32, stream));
+                         m->V, D, 0, dt == DH_F32 ? DH_F32 : (dt == DH_F16 ? DH_F16_OUT_F32 : DH_BF16_OUT_F32), stream));
     }
     return DH_OK;
 }
@@ -62,7 +62,7 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
     DH_REQUIRE(m && sc && m->layers && rows > 0 && rows_per_img > 0 && row_mult > 0 && (!logits || ldl >= m->V));
     const int E = m->E, Hh = m->Hh, dt = m->dtype, nl = m->n_layers;
     const size_t esz = dt == DH_F32 ? 4 : 2;
-    bool fused = dt == DH_BF16 && m->h_alt && m->c_alt;
+    bool fused = DH_IS_16BIT(dt) && m->h_alt && m->c_alt;
     for (int l = 0; l < nl; ++l) fused = fused && m->layers[l].w_il && m->layers[l].b_il;
     if (fused) {
         DH_REQUIRE(started >= 0 && started <= 2);
@@ -87,7 +87,7 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
         } else if (logits) {
             dh_prof_set_tag("vocab");
             DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,
-                             DH_BF16_OUT_F32, stream));
+                             dt == DH_F16 ? DH_F16_OUT_F32 : DH_BF16_OUT_F32, stream));
         }
         return DH_OK;
     }
@@ -96,7 +96,7 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
                            rows_total, nl, E, Hh, dt, stream));
     void* top = h_out ? h_out : sc->hout;
     const int top_ld = h_out ? ld_out : Hh;
-    const int gate_dt = dt == DH_F32 ? DH_F32 : DH_BF16_OUT_F32;
+    const int gate_dt = dt == DH_F32 ? DH_F32 : (dt == DH_F16 ? DH_F16_OUT_F32 : DH_BF16_OUT_F32);
     for (int l = 0; l < nl; ++l) {
         const void* a = l == 0 ? sc->xcat0 : (const char*)sc->xcatl + (size_t)(l - 1) * rows * 2 * Hh * esz;
         const int k = l == 0 ? E + Hh : 2 * Hh;
@@ -108,7 +108,7 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
         DH_TRY(dh_lstm_cell(sc->gates, sc->c_cur + (size_t)l * rows * Hh, (char*)m->h + (size_t)l * rows_total * Hh * esz,
                             m->c + (size_t)l * rows_total * Hh, dst, ld, rows, row_mult, Hh, dt, stream));
     }
-    if (logits && group_max && dt == DH_BF16) {
+    if (logits && group_max && DH_IS_16BIT(dt)) {
         DH_TRY(dh_vocab_logits(top, top_ld, m->cls_w, Hh, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");

@@ -6,6 +6,7 @@ the decoders then run their teacher-forced ``forward`` (same incremental engine 
 perplexity kernels score every caption (call shape of trainer.py:63-81)."""
 import torch
 
+from .. import hip
 from .metrics import sequence_perplexity, sequence_perplexity_from_hidden
 
 
@@ -32,7 +33,7 @@ def score_captions(model, template_images, template_index, captions, lengths, la
             tgt = captions[lo:hi]                       # tokens + <eos>, zero padded (datasets.py:72-79, no <bos>)
             inp = tgt[:, :-1]                           # trainer.py:69-73: model(images, captions[:, :-1], lengths)
             dec = model.decoder
-            if feats.dtype == torch.bfloat16:
+            if feats.dtype in hip.HALF_DTYPES:
                 # bf16 path: hidden states -> fused classifier + log-softmax gather, the [rows, V] logits never exist
                 if hasattr(dec, "lstm"):
                     hidden, _, _ = dec.hidden_states(emb, inp, None)

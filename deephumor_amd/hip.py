@@ -11,7 +11,9 @@ import torch
 
 from . import _build
 
-F32, BF16, BF16_OUT_F32 = 0, 1, 2
+F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
+ABI_VERSION = 7
+HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 16
 
@@ -52,8 +54,8 @@ class LstmScratch(_c.Structure):
 SIGNATURES = {
     "dh_abi_version": [],
     "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
-    "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 9 + [_P],
-    "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _P],
+    "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
+    "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -69,6 +71,11 @@ SIGNATURES = {
     "dh_attn_self_decode": [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dh_attn_cross_decode": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_enc_key_mask": [_P, _P, _I, _I, _I, _P],
+    "dh_pad_mask": [_P, _P, _I, _I, _I, _c.c_longlong, _P],
+    "dh_autoregressive_mask": [_P, _I, _I, _P],
+    "dh_mask_or": [_P, _P, _c.c_longlong, _P],
+    "dh_enc_nonzero_rows": [_P, _P, _I, _I, _I, _P],
+    "dh_attn_masked": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dh_lstm_prepare": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_lstm_cell": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_embed_prefill": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _F, _I, _P],
@@ -111,17 +118,20 @@ def _ab_override():
 
 
 def load():
-    """Loads (building first if a compiler is present and sources are newer) the shared library."""
+    """Loads the shared library.  A single-process run with a compiler present rebuilds it first when the sources are
+    newer (developer convenience; the build itself is serialised by a file lock and replaces the library atomically).
+    Under a multi-process launcher (WORLD_SIZE > 1) nothing is ever built here -- every rank would race on the same
+    files: run ``python __graft_entry__.py build`` first."""
     global _lib
     if _lib is not None:
         return _lib
     path = lib_path()
-    if not os.path.exists(path) or (_build.needs_build() and os.path.exists(_build._hipcc())):
+    solo = int(os.environ.get("WORLD_SIZE", "1")) == 1 and int(os.environ.get("LOCAL_RANK", "0")) == 0
+    if solo and os.path.exists(_build._hipcc()) and (not os.path.exists(path) or _build.needs_build()):
         try:
             _build.build()
         except Exception as e:  # pragma: no cover - depends on toolchain presence
-            if not os.path.exists(path):
-                raise RuntimeError(f"deephumor_amd: cannot build {path}: {e}") from e
+            raise RuntimeError(f"deephumor_amd: cannot build {path}: {e}") from e
     if not os.path.exists(path):
         raise RuntimeError(f"deephumor_amd: HIP extension missing at {path}; run `python __graft_entry__.py build`. "
                            "There is no CPU fallback on the product path.")
@@ -134,6 +144,9 @@ def load():
     lib.dh_error_string.restype = _c.c_char_p
     lib.dh_prof_tag.argtypes = [_c.c_char_p]
     lib.dh_prof_tag.restype = None
+    if lib.dh_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"deephumor_amd: {path} has ABI v{lib.dh_abi_version()}, this binding expects v{ABI_VERSION}; "
+                           "rebuild with `python __graft_entry__.py build`")
     _lib = lib
     return lib
 
@@ -188,7 +201,7 @@ def profile(watch=None, stride=1):
     return Profiler(watch, stride)
 
 
-def _launch(name, *args, tag=None, **_ignored):
+def _launch(name, *args, tag=None):
     fn = _fns.get(name)
     if fn is None:
         fn = _fns[name] = getattr(load(), name)
@@ -219,8 +232,10 @@ def _dt(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
-    raise TypeError(f"unsupported dtype {t.dtype}: the kernels compute in fp32 (parity path) or bf16 (matrix cores, fp32 "
-                    "accumulation) -- use model.float() or model.bfloat16(); fp16 checkpoints load into either")
+    if t.dtype == torch.float16:
+        return F16
+    raise TypeError(f"unsupported dtype {t.dtype}: the kernels compute in fp32 (parity path) or with bf16 / fp16 operands on "
+                    "the matrix cores (fp32 accumulation) -- use model.float(), model.bfloat16() or model.half()")
 
 
 # ------------------------------------------------------------------------------------------------
@@ -236,33 +251,30 @@ def conv2d_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, pad=0,
         out = torch.empty((n, cout, ho, wo), dtype=x.dtype, device=x.device)
     _launch("dh_conv2d_bn_act", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
                                    n, cin, h, wd, cout, kh, kw, stride, pad, int(relu), _dt(x), _stream(),
-            flops=2.0 * n * ho * wo * cout * cin * kh * kw,
-            nbytes=4.0 * (x.numel() + w.numel() + out.numel() * (2 if residual is not None else 1)),
             tag=f"{kh}x{kw}")
     return out
 
 
-def stem_conv_nhwc(x, w, scale, shift, stride=2, pad=3, relu=True):
-    """x NCHW fp32 image, w fp32 [Cout,Cin,KS,KS] -> channels-last bf16 [N,Ho,Wo,Cout]."""
+def stem_conv_nhwc(x, w, scale, shift, stride=2, pad=3, relu=True, out_dtype=torch.bfloat16):
+    """x NCHW fp32 image, w fp32 [Cout,Cin,KS,KS] -> channels-last bf16 / fp16 [N,Ho,Wo,Cout]."""
     _dev(x, w, scale, shift)
     n, cin, h, wd = x.shape
     cout, _, ks, _ = w.shape
     assert x.dtype == torch.float32 and w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous()
     ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
-    out = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x.device)
+    out = torch.empty((n, ho, wo, cout), dtype=out_dtype, device=x.device)
     _launch("dh_stem_conv_nhwc", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), n, cin, h, wd, cout, ks,
-            stride, pad, int(relu), _stream(), flops=2.0 * n * ho * wo * cout * cin * ks * ks,
-            nbytes=4.0 * x.numel() + 2.0 * out.numel())
+            stride, pad, int(relu), _dt(out), _stream())
     return out
 
 
-def pack_nchw_to_nhwc8(x):
-    """x NCHW fp32 [N,C<=8,H,W] -> channels-last bf16 [N,H,W,8] (zero-padded channels)."""
+def pack_nchw_to_nhwc8(x, out_dtype=torch.bfloat16):
+    """x NCHW fp32 [N,C<=8,H,W] -> channels-last bf16 / fp16 [N,H,W,8] (zero-padded channels)."""
     _dev(x)
     n, c, h, w = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous()
-    out = torch.empty((n, h, w, 8), dtype=torch.bfloat16, device=x.device)
-    _launch("dh_pack_nchw_to_nhwc8", _ptr(x), _ptr(out), n, c, h, w, _stream())
+    out = torch.empty((n, h, w, 8), dtype=out_dtype, device=x.device)
+    _launch("dh_pack_nchw_to_nhwc8", _ptr(x), _ptr(out), n, c, h, w, _dt(out), _stream())
     return out
 
 
@@ -321,14 +333,14 @@ def label_mean(emb, labels, out):
 
 def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=None, residual=None,
            out_dtype=None):
-    """a [M, K] (row stride may exceed K), w [N, K] -> [M, N].  bf16 operands may produce fp32
+    """a [M, K] (row stride may exceed K), w [N, K] -> [M, N].  bf16 / fp16 operands may produce fp32
     (``out_dtype=torch.float32``: logits)."""
     _dev(a, w, bias, scale, shift, out, residual)
     m, k = a.shape
     n, k2 = w.shape
     assert k == k2 and a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == w.dtype
     if out is None:
-        if a.dtype == torch.bfloat16 and out_dtype == torch.float32 and (n % 4) and m * n >= (1 << 24):
+        if a.dtype in HALF_DTYPES and out_dtype == torch.float32 and (n % 4) and m * n >= (1 << 24):
             # large fp32 logits: rows padded to 64 floats (16-byte aligned rows) so that the persistent classifier kernel
             # with its 16-byte register stores applies; the result is a [m, n] view of the padded buffer
             out = torch.empty((m, (n + 63) // 64 * 64), dtype=torch.float32, device=a.device)[:, :n]
@@ -336,15 +348,13 @@ def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=No
             out = torch.empty((m, n), dtype=out_dtype or a.dtype, device=a.device)
     assert out.shape == (m, n) and out.stride(1) == 1
     dt = _dt(a)
-    if dt == BF16 and out.dtype == torch.float32:
-        dt = BF16_OUT_F32
+    if dt in (BF16, F16) and out.dtype == torch.float32:
+        dt = BF16_OUT_F32 if dt == BF16 else F16_OUT_F32
     else:
         assert out.dtype == a.dtype
-    esz = a.element_size()
     _launch("dh_linear", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(scale), _ptr(shift),
             _ptr(residual), residual.stride(0) if residual is not None else 0,
-            _ptr(out), out.stride(0), m, n, k, int(relu), dt, _stream(),
-            flops=2.0 * m * n * k, nbytes=float(esz * (m * k + n * k) + out.element_size() * m * n), tag=tag)
+            _ptr(out), out.stride(0), m, n, k, int(relu), dt, _stream(), tag=tag)
     return out
 
 
@@ -357,9 +367,7 @@ def conv2d_nhwc_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, p
     ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
     out = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
     _launch("dh_conv2d_nhwc_bn_act", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
-            n, h, wd, cin, cout, ks, stride, pad, int(relu), _dt(x), _stream(),
-            flops=2.0 * n * ho * wo * cout * cin * ks * ks,
-            nbytes=2.0 * (x.numel() + w.numel() + out.numel() * (2 if residual is not None else 1)), tag=f"{ks}x{ks}")
+            n, h, wd, cin, cout, ks, stride, pad, int(relu), _dt(x), _stream(), tag=f"{ks}x{ks}")
     return out
 
 
@@ -387,17 +395,14 @@ def attn_self_decode(qkv, kcache, vcache, src, tokens, out, n_img, rows_per_img,
     _dev(qkv, kcache, vcache, src, tokens, out)
     _launch("dh_attn_self_decode", _ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(src), src.stride(0),
                                       _ptr(tokens), tokens.stride(0), _ptr(out), n_img, rows_per_img, row_mult,
-                                      rows_total, t, d, n_heads, float(scale), pad_index, _dt(qkv), _stream(),
-            nbytes=float(qkv.element_size()) * n_img * rows_per_img * ((t + 1) * 2 * d + 2 * d),
-            flops=4.0 * n_img * rows_per_img * (t + 1) * d)
+                                      rows_total, t, d, n_heads, float(scale), pad_index, _dt(qkv), _stream())
     return out
 
 
 def attn_cross_decode(q, kv, keymask, out, n_img, rows_per_img, s, d, n_heads, scale):
     _dev(q, kv, keymask, out)
     _launch("dh_attn_cross_decode", _ptr(q), q.stride(0), _ptr(kv), _ptr(keymask), _ptr(out), n_img,
-                                       rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream(),
-            nbytes=float(q.element_size()) * n_img * (s * 2 * d + rows_per_img * 2 * d), flops=4.0 * n_img * rows_per_img * s * d)
+                                       rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream())
     return out
 
 
@@ -433,6 +438,57 @@ def enc_key_mask(enc_out):
     rows, d = enc_out.shape
     out = torch.empty((rows,), dtype=torch.uint8, device=enc_out.device)
     _launch("dh_enc_key_mask", _ptr(enc_out), _ptr(out), rows, d, _dt(enc_out), _stream())
+    return out
+
+
+def pad_mask(query, key, pad_index=0):
+    """Reference ``get_pad_mask`` (transformers.py:12-26): bool [bs, query_len, key_len], True where key == pad_index."""
+    _dev(query, key)
+    bs, lq = query.shape[:2]
+    lk = key.shape[1]
+    key = key.to(torch.int64).contiguous()
+    mask = torch.empty((bs, lq, lk), dtype=torch.uint8, device=key.device)
+    _launch("dh_pad_mask", _ptr(key), _ptr(mask), bs, lq, lk, int(pad_index), _stream())
+    return mask.view(torch.bool)
+
+
+def autoregressive_mask(seq):
+    """Reference ``get_autoregressive_mask`` (transformers.py:29-40): bool [bs, L, L], True above the diagonal."""
+    _dev(seq)
+    bs, l = seq.shape[:2]
+    mask = torch.empty((bs, l, l), dtype=torch.uint8, device=seq.device)
+    _launch("dh_autoregressive_mask", _ptr(mask), bs, l, _stream())
+    return mask.view(torch.bool)
+
+
+def mask_or(a, b):
+    """a | b for two boolean masks of the same shape (new tensor)."""
+    _dev(a, b)
+    assert a.shape == b.shape
+    out = a.contiguous().view(torch.uint8).clone()
+    _launch("dh_mask_or", _ptr(out), _ptr(b.contiguous().view(torch.uint8)), out.numel(), _stream())
+    return out.view(torch.bool)
+
+
+def enc_nonzero_rows(enc_out):
+    """enc_out [bs, L, D] -> int64 [bs, L]: 1 where no element of the row is 0 (transformers.py:480)."""
+    _dev(enc_out)
+    bs, l, d = enc_out.shape
+    out = torch.empty((bs, l), dtype=torch.int64, device=enc_out.device)
+    _launch("dh_enc_nonzero_rows", _ptr(enc_out.contiguous()), _ptr(out), bs * l, d, _dt(enc_out), _stream())
+    return out
+
+
+def attn_masked(q, k, v, mask, bs, l, d, n_heads, scale):
+    """q, k, v projected rows [bs*l, d]; mask bool/uint8 [bs, l, l] or None -> [bs*l, d]."""
+    _dev(q, k, v, mask)
+    out = torch.empty((bs * l, d), dtype=q.dtype, device=q.device)
+    if mask is not None:
+        mask = mask.contiguous()
+        mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        assert tuple(mask.shape) == (bs, l, l)
+    _launch("dh_attn_masked", _ptr(q), q.stride(0), _ptr(k), k.stride(0), _ptr(v), v.stride(0), _ptr(mask), _ptr(out),
+            bs, l, d, n_heads, float(scale), _dt(q), _stream())
     return out
 
 
@@ -555,7 +611,7 @@ def lstm_layer_fused(x_rows, x_div, emb, tokens, tok_pos, h_prev, c_prev, hparen
     _launch("dh_lstm_layer_fused", _ptr(x_rows), x_rows.stride(0) if x_rows is not None else 0, x_div, _ptr(emb),
             _ptr(tokens), tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(h_prev), _ptr(c_prev),
             _ptr(hparent), _ptr(h_next), _ptr(c_next), _ptr(h_out), h_out.stride(0), _ptr(w_il), _ptr(b_il), rows,
-            row_mult, e, hh, BF16, _stream())
+            row_mult, e, hh, _dt(w_il), _stream())
 
 
 def lstm_decode_step(model, scratch, img_emb, tokens, tok_pos, hparent, started, rows, rows_per_img, row_mult,

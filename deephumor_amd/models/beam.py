@@ -119,17 +119,29 @@ class BeamSearchHelper:
 
     @staticmethod
     def raise_for(code):
+        if code == 0:
+            return
         if code & hip.ERR_ALL_FILTERED:
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0 "
                                "(every logit of a row was filtered: <unk> was the only top-k token)")
         if code & hip.ERR_OVERFLOW:
-            raise RuntimeError("more than 1024 logits tie at the top-k threshold")
+            raise RuntimeError("more than 1024 logits of a row tie at its top-k threshold (DH_BEAM_MAX_SURVIVORS); "
+                               "the reference would sample among all of them")
         if code & hip.ERR_TOO_FEW:
             raise RuntimeError("fewer positive-probability tokens than beams (top_k == beam_size with <unk> in the top-k)")
 
     def all_ended(self):
         """Host-visible early-exit test (one sync; callers poll it sparsely, not per token)."""
         return bool(self.done.cpu().numpy().all())
+
+
+def resolve_seed(seed):
+    """``seed=None`` (the default of every ``generate``): a fresh 62-bit Philox key drawn from torch's default CPU
+    generator -- the generator the reference's ``torch.multinomial`` calls consume (beam.py:46) -- so ``torch.manual_seed``
+    controls ``generate`` and successive calls give different captions, as with the reference.  An int is used as is."""
+    if seed is None:
+        return int(torch.randint(0, 1 << 62, (), dtype=torch.int64).item())
+    return int(seed)
 
 
 _STREAMS = {}

@@ -9,7 +9,7 @@ config 5).
 import torch
 from torch import nn
 
-from .encoders import ImageEncoder, ImageLabelEncoder, SpatialImageLabelEncoder
+from .encoders import ImageEncoder, ImageLabelEncoder, SpatialImageLabelEncoder, _Planned
 from .rnn_models import LSTMDecoder
 from .transformers import SelfAttentionTransformerDecoder, TransformerDecoder
 
@@ -33,7 +33,13 @@ class _CaptioningBase(nn.Module):
     def _one(toks, lens):
         return toks[0, :int(lens[0])].squeeze()
 
-    def generate_batch_graphed(self, *inputs, seed=0, caption=None, **kw):
+    def _plan_signature(self):
+        """Identity of everything a captured graph holds raw pointers to or derives constants from: storage pointer and
+        in-place version counter of every parameter and buffer of the model."""
+        ts = list(self.parameters()) + list(self.buffers())
+        return tuple(t.data_ptr() for t in ts), tuple(t._version for t in ts)
+
+    def generate_batch_graphed(self, *inputs, seed=None, caption=None, **kw):
         """``generate_batch`` replayed from a captured hipGraph (torch.cuda.CUDAGraph on ROCm).
 
         The whole pass -- encoder, every decode position (a chain of ~70 dependent launches per position for
@@ -41,12 +47,23 @@ class _CaptioningBase(nn.Module):
         replayed with one host call; inputs are copied into the graph's static buffers and the seed is passed
         through a device-resident word the beam kernels XOR into their Philox key, so replays with different
         seeds give the captions eager mode gives.  Worth 2-4 % at 256 images (the chain is GPU-latency-bound,
-        not host-bound); the graph keeps its activations / KV cache allocated."""
-        from .beam import BeamSearchHelper
+        not host-bound); the graph keeps its activations / KV cache allocated.
+
+        A captured graph holds raw pointers to the weights and to the tensors the plans derive from them (fused QKV
+        matrices, folded BatchNorm vectors, repacked convolution weights): it is valid only for the weight versions it
+        was captured with.  Every cached graph therefore records the models' plan signature and keeps the plans
+        themselves alive; ``load_state_dict`` / ``.to()`` / in-place weight updates change the signature and the
+        graph is re-captured instead of replayed against stale or freed memory."""
+        from .beam import BeamSearchHelper, resolve_seed
+        seed = resolve_seed(seed)
         key = (tuple((tuple(t.shape), t.dtype) for t in inputs), None if caption is None else tuple(caption.shape),
                tuple(sorted(kw.items())), next(self.parameters()).dtype)
         cache = self.__dict__.setdefault("_graphs", {})
         state = cache.get(key)
+        sig = self._plan_signature()
+        if state is not None and state[5] != sig:
+            cache.clear()                                 # weights changed: every captured graph points at dead tensors
+            state = None
         if state is None:
             static = [t.clone() for t in inputs]
             scap = None if caption is None else caption.clone()
@@ -64,8 +81,10 @@ class _CaptioningBase(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(graph):
                 out = run()
-            state = cache[key] = (graph, static, scap, seed_t, out)
-        graph, static, scap, seed_t, (toks, lens, err) = state
+            sig = self._plan_signature()                  # (the warm-up built the plans)
+            plans = [m._get_plan() for m in self.modules() if isinstance(m, _Planned)]     # outlive the graph
+            state = cache[key] = (graph, static, scap, seed_t, out, sig, plans)
+        graph, static, scap, seed_t, (toks, lens, err) = state[:5]
         for dst, src in zip(static, inputs):
             dst.copy_(src)
         if scap is not None:

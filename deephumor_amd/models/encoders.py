@@ -126,7 +126,8 @@ class ImageEncoder(_Planned, nn.Module):
         """fp32 weights -> NCHW vector-ALU convolutions (the parity path); bf16 weights -> channels-last
         activations with every bottleneck conv on the bf16 matrix cores (weights repacked once to
         [Cout, kh, kw, Cin]; the stem's 3 input channels are zero-padded to 8)."""
-        bf16 = self.linear.weight.dtype == torch.bfloat16
+        wdt = self.linear.weight.dtype
+        bf16 = wdt in hip.HALF_DTYPES            # the 16-bit paths (bf16 / fp16 storage and MFMA operands)
 
         def conv(c, bn, relu, residual=False, stem=False):
             s, b = _bn_affine(bn)
@@ -159,11 +160,11 @@ class ImageEncoder(_Planned, nn.Module):
                     w_cat = torch.cat([c3["w"].float().view(cout, -1) * c3["scale"][:, None],
                                        dn["w"].float().view(cout, -1) * dn["scale"][:, None]], 1)
                     if c3["w"].shape[-1] % 64 == 0 and dn["w"].shape[-1] % 64 == 0:
-                        ent["dual"] = dict(w=w_cat.to(torch.bfloat16).contiguous(), shift=(c3["shift"] + dn["shift"]).contiguous(),
+                        ent["dual"] = dict(w=w_cat.to(wdt).contiguous(), shift=(c3["shift"] + dn["shift"]).contiguous(),
                                            stride=dn["stride"])
                 blocks.append(ent)
         s, b = _bn_affine(self.bn)
-        return dict(stem=stem, blocks=blocks, bn_scale=s, bn_shift=b, bf16=bf16,
+        return dict(stem=stem, blocks=blocks, bn_scale=s, bn_shift=b, bf16=bf16, dtype=wdt,
                     lin_w=self.linear.weight.detach(), lin_b=self.linear.bias.detach().float().contiguous())
 
     @staticmethod
@@ -178,7 +179,7 @@ class ImageEncoder(_Planned, nn.Module):
         nhwc = plan["bf16"]
         st = plan["stem"]
         if nhwc:
-            x = self._conv(hip.pack_nchw_to_nhwc8(images.float().contiguous()), st, nhwc=True)
+            x = self._conv(hip.pack_nchw_to_nhwc8(images.float().contiguous(), out_dtype=plan["dtype"]), st, nhwc=True)
             x = hip.maxpool3x3s2_nhwc(x)
         else:
             x = hip.maxpool3x3s2(self._conv(images.contiguous(), st))

@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamSearchHelper, run_interleaved
+from .beam import BeamSearchHelper, resolve_seed, run_interleaved
 from .encoders import _Planned
 
 
@@ -36,7 +36,7 @@ class LSTMDecoder(_Planned, nn.Module):
                            getattr(self.lstm, f"weight_hh_l{l}").detach()], dim=1).contiguous()
             b = (getattr(self.lstm, f"bias_ih_l{l}").detach().float()
                  + getattr(self.lstm, f"bias_hh_l{l}").detach().float()).contiguous()
-            if w.dtype == torch.bfloat16:
+            if w.dtype in hip.HALF_DTYPES:
                 # gate-interleaved copy for the fused step kernel: row 4u+g = gate g (i, f, g, o) of hidden unit u
                 hh = self.lstm.hidden_size
                 w_il = w.view(4, hh, -1).permute(1, 0, 2).reshape(4 * hh, -1).contiguous()
@@ -72,11 +72,11 @@ class LSTMDecoder(_Planned, nn.Module):
                     self.c_layers[i].w_il, self.c_layers[i].b_il = w_il.data_ptr(), b_il.data_ptr()
             m = self.c_model = hip.LstmModel()
             m.n_layers, m.E, m.Hh, m.V = self.nl, self.e, self.hh, dec.num_tokens
-            m.dtype = hip.F32 if self.dtype == torch.float32 else hip.BF16
+            m.dtype = {torch.float32: hip.F32, torch.bfloat16: hip.BF16, torch.float16: hip.F16}[self.dtype]
             m.layers = self.c_layers
             m.emb, m.cls_w, m.cls_b = plan["emb"].data_ptr(), plan["cls_w"].data_ptr(), plan["cls_b"].data_ptr()
             m.h, m.c = self.h.data_ptr(), self.c.data_ptr()
-            if self.dtype == torch.bfloat16:      # fused step kernel: other workgroups still gather the old state rows
+            if self.dtype in hip.HALF_DTYPES:     # fused step kernel: other workgroups still gather the old state rows
                 self.h_alt, self.c_alt = torch.empty_like(self.h), torch.empty_like(self.c)
                 m.h_alt, m.c_alt = self.h_alt.data_ptr(), self.c_alt.data_ptr()
 
@@ -136,7 +136,7 @@ class LSTMDecoder(_Planned, nn.Module):
         return hs, bs, steps_out
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
-                       eos_index=3, seed=0, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
+                       eos_index=3, seed=None, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
                        defer_check=False, early_stop_every=0):
         """Batched beam-search sampling for ``image_emb [N, 1, E]`` or ``[N, E]``.
 
@@ -148,6 +148,7 @@ class LSTMDecoder(_Planned, nn.Module):
         ``all_ended()`` break, rnn_models.py:131) and stops decoding then -- one host sync per check, same captions."""
         self._check_mode()
         plan = self._get_plan()
+        seed = resolve_seed(seed)
         image_emb = image_emb.reshape(image_emb.shape[0], -1).to(plan["dtype"]).contiguous()
 
         def session(lo, hi):
@@ -164,7 +165,7 @@ class LSTMDecoder(_Planned, nn.Module):
             # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
             logits = torch.empty((r, (self.num_tokens + 63) // 64 * 64), device=dev)[:, :self.num_tokens]
             gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
-                    if plan["dtype"] == torch.bfloat16 else None)                    # column-group maxima (bf16 path)
+                    if plan["dtype"] in hip.HALF_DTYPES else None)                   # column-group maxima (16-bit paths)
             gm = None if gmax is None else gmax[:n]
             # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam
             lg = logits[:n]

@@ -18,12 +18,42 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamSearchHelper, run_interleaved
+from .beam import BeamSearchHelper, resolve_seed, run_interleaved
 from .encoders import _Planned
 
 
+def get_pad_mask(query, key, pad_index=0):
+    """Padding mask from the Query and Key id sequences (reference transformers.py:12-26):
+    bool ``[bs, query_len, key_len]``, True where ``key == pad_index``."""
+    return hip.pad_mask(query, key, pad_index)
+
+
+def get_autoregressive_mask(seq):
+    """Autoregressive mask for the decoder inputs (reference transformers.py:29-40): bool ``[bs, L, L]``, True above
+    the diagonal."""
+    return hip.autoregressive_mask(seq)
+
+
+def _no_train_dropout(module):
+    if module.training and module.dropout.p > 0:
+        raise RuntimeError("deephumor_amd implements the inference path; call model.eval()")
+
+
+def _fp32(t):
+    return t.detach().float().contiguous()
+
+
+def _add_ln(x, y, ln):
+    bs, l, d = x.shape
+    out = hip.add_layernorm(x.reshape(bs * l, d).contiguous(), y.reshape(bs * l, d).contiguous(), _fp32(ln.weight),
+                            _fp32(ln.bias), eps=ln.eps)
+    return out.view(bs, l, d)
+
+
 class MultiHeadAttentionLayer(nn.Module):
-    """Parameter holder of the reference layer (transformers.py:43-80): fc_q/fc_k/fc_v/fc_o + scale."""
+    """The reference layer (transformers.py:43-129): fc_q / fc_k / fc_v / fc_o + ``scale``.  The captioning decoders do
+    not call this ``forward`` (they run the KV-cached / prefill kernels on the fused weights); it serves callers of the
+    module API: four ``dh_linear`` launches around ``dh_attn_masked``."""
 
     def __init__(self, hid_dim=512, n_heads=8, dropout=0.):
         super().__init__()
@@ -36,6 +66,21 @@ class MultiHeadAttentionLayer(nn.Module):
         self.dropout = nn.Dropout(dropout)
         self.scale = nn.Parameter(torch.sqrt(torch.tensor(self.head_dim, dtype=torch.float32)), requires_grad=False)
 
+    def forward(self, query, key, value, mask=None):
+        """``query/key/value [bs, seq_len, hid_dim]``, ``mask`` bool ``[bs, seq_len, seq_len]`` (True = masked with
+        -1e8) -> ``[bs, seq_len, hid_dim]`` (transformers.py:82-129).  As in the reference, K and V are viewed with the
+        QUERY's sequence length (:94,:102-103), so all three must have the same length."""
+        _no_train_dropout(self)
+        bs, seq_len = query.shape[:2]
+        d = self.hid_dim
+        if key.shape[0] * key.shape[1] != bs * seq_len or value.shape[0] * value.shape[1] != bs * seq_len:
+            raise RuntimeError(f"shape '[{bs}, {seq_len}, {self.n_heads}, {self.head_dim}]' is invalid for input of size "
+                               f"{key.numel()}")                              # the reference's k.view(...) error
+        lin = lambda x, fc: hip.linear(x.reshape(bs * seq_len, d).contiguous(), fc.weight.detach(), _fp32(fc.bias))
+        q, k, v = lin(query, self.fc_q), lin(key, self.fc_k), lin(value, self.fc_v)
+        x = hip.attn_masked(q, k, v, mask, bs, seq_len, d, self.n_heads, float(self.scale))
+        return hip.linear(x, self.fc_o.weight.detach(), _fp32(self.fc_o.bias)).view(bs, seq_len, d)
+
 
 class PositionwiseFeedforwardLayer(nn.Module):
     """fc_2(relu(fc_1(x))) (transformers.py:132-165)."""
@@ -45,6 +90,13 @@ class PositionwiseFeedforwardLayer(nn.Module):
         self.fc_1 = nn.Linear(hid_dim, pf_dim)
         self.fc_2 = nn.Linear(pf_dim, hid_dim)
         self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x):
+        """``[bs, seq_len, hid_dim] -> [bs, seq_len, hid_dim]`` (transformers.py:151-165)."""
+        _no_train_dropout(self)
+        shape = x.shape
+        h = hip.linear(x.reshape(-1, shape[-1]).contiguous(), self.fc_1.weight.detach(), _fp32(self.fc_1.bias), relu=True)
+        return hip.linear(h, self.fc_2.weight.detach(), _fp32(self.fc_2.bias)).view(shape)
 
 
 class DecoderLayer(nn.Module):
@@ -60,6 +112,14 @@ class DecoderLayer(nn.Module):
         self.pf_ln = nn.LayerNorm(hid_dim)
         self.dropout = nn.Dropout(dropout)
 
+    def forward(self, x, enc_out, input_mask=None, enc_mask=None):
+        """Module-API form of one layer (transformers.py:343-377): ``x, enc_out [bs, seq_len, hid_dim]``, masks bool
+        ``[bs, seq_len, seq_len]``."""
+        _no_train_dropout(self)
+        x = _add_ln(x, self.self_attn(x, x, x, mask=input_mask), self.self_attn_ln)
+        x = _add_ln(x, self.enc_attn(x, enc_out, enc_out, mask=enc_mask), self.enc_attn_ln)
+        return _add_ln(x, self.pf(x), self.pf_ln)
+
 
 class SelfAttentionDecoderLayer(nn.Module):
     """Decoder layer without encoder attention (transformers.py:582-636)."""
@@ -71,6 +131,12 @@ class SelfAttentionDecoderLayer(nn.Module):
         self.pf = PositionwiseFeedforwardLayer(hid_dim, pf_dim, dropout)
         self.pf_ln = nn.LayerNorm(hid_dim)
         self.dropout = nn.Dropout(dropout)
+
+    def forward(self, x, input_mask=None):
+        """Module-API form of one layer (transformers.py:612-636)."""
+        _no_train_dropout(self)
+        x = _add_ln(x, self.self_attn(x, x, x, mask=input_mask), self.self_attn_ln)
+        return _add_ln(x, self.pf(x), self.pf_ln)
 
 
 class TransformerEncoder(nn.Module):
@@ -133,6 +199,12 @@ class _IncrementalDecoder(_Planned, nn.Module):
             raise RuntimeError("deephumor_amd implements the inference path; call model.eval()")
         if self.pad_index is None:
             raise TypeError("pad_index=None is unusable in the reference too (transformers.py:451); pass an int")
+        if self.pad_index != 0:
+            # the reference compares the image slot's stand-in id 1 (transformers.py:474) and the 0/1 encoder-row flags
+            # (:480-481) with pad_index: pad_index == 1 masks the image slot and inverts the encoder mask, any other
+            # value disables the encoder mask.  The vocabulary fixes <pad> = 0 (data/vocab.py:5-12); the cached kernels
+            # implement that case only.  (The module-API layers above take explicit masks and have no such limit.)
+            raise NotImplementedError("TransformerDecoder kernels implement pad_index == 0 (the vocabulary's <pad>)")
 
     class _Run:
         """KV cache + cross-attention operands + scratch for one batch, described to the native step
@@ -171,7 +243,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             m = self.c_model = hip.TrModel()
             m.n_layers, m.D, m.n_heads, m.pf_dim, m.V = nl, d, dec.n_heads, self.pf, dec.num_tokens
             m.pad_index, m.cross, m.S = dec.pad_index, int(dec._cross), self.s
-            m.dtype = hip.F32 if self.dtype == torch.float32 else hip.BF16
+            m.dtype = {torch.float32: hip.F32, torch.bfloat16: hip.BF16, torch.float16: hip.F16}[self.dtype]
             m.emb_scale = plan["scale"]
             m.layers = self.c_layers
             m.tok_emb, m.pos_emb, m.cls_w, m.cls_b = P(plan["tok"]), P(plan["pos"]), P(plan["cls_w"]), P(plan["cls_b"])
@@ -199,12 +271,12 @@ class _IncrementalDecoder(_Planned, nn.Module):
         return x_out if x_out is not None else sc["x"]
 
     def _forward(self, x, enc_out, start_emb, num_positions=None, return_hidden=False):
+        if start_emb is None:
+            return self._forward_modules(x, enc_out)
         self._check_mode()
         plan = self._get_plan()
         bs, dec_len = x.shape
-        dev = start_emb.device if start_emb is not None else x.device
-        if start_emb is None:
-            raise NotImplementedError("forward without start_emb is never used by the captioning models")
+        dev = start_emb.device
         dec_len += 1
         seq = dec_len if enc_out is None else max(dec_len, enc_out.shape[1])          # transformers.py:450
         if seq > self.pos_embedding.num_embeddings:
@@ -228,10 +300,39 @@ class _IncrementalDecoder(_Planned, nn.Module):
         out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
         return out.view(bs, seq, -1)
 
+    def _forward_modules(self, x, enc_out):
+        """``forward`` WITHOUT a start embedding (transformers.py:432 default ``start_emb=None``; never used by the
+        captioning models): the reference's own formulation on the module-API layers -- pad ``x`` / ``enc_out`` to a
+        common length (:450-452), embeddings (:455-469), pad | causal input mask (:473-477), encoder-row mask
+        (:480-481), layers, classifier."""
+        bs, dec_len = x.shape
+        dt = self.classifier.weight.dtype
+        seq = dec_len if enc_out is None else max(dec_len, enc_out.shape[1])
+        if seq > self.pos_embedding.num_embeddings:
+            raise IndexError("index out of range in self")
+        ids = torch.full((bs, seq), self.pad_index, dtype=torch.int64, device=x.device)
+        ids[:, :dec_len] = x
+        emb = hip.embed_prefill(self.tok_embedding.weight.detach(), self.pos_embedding.weight.detach(), None,
+                                ids.to(torch.int32).contiguous(), bs, seq, float(self.scale)).view(bs, seq, self.hid_dim)
+        input_mask = hip.mask_or(get_pad_mask(ids, ids, pad_index=self.pad_index), get_autoregressive_mask(ids))
+        h = emb
+        if enc_out is not None:
+            enc = torch.zeros((bs, seq, self.hid_dim), dtype=dt, device=x.device)
+            enc[:, :enc_out.shape[1]] = enc_out.to(dt)
+            enc_mask = get_pad_mask(ids, hip.enc_nonzero_rows(enc), pad_index=self.pad_index)
+            for layer in self.layers:
+                h = layer(h, enc, input_mask=input_mask, enc_mask=enc_mask)
+        else:
+            for layer in self.layers:
+                h = layer(h, input_mask=input_mask)
+        out = hip.linear(h.reshape(bs * seq, self.hid_dim), self.classifier.weight.detach(), _fp32(self.classifier.bias),
+                         out_dtype=torch.float32, tag="vocab")
+        return out.view(bs, seq, -1)
+
     def _prefill_ok(self, plan, seq):
         """All positions at once (batched GEMMs, one causal-attention launch per layer) when the attention kernels'
         register-resident history covers the sequence; otherwise position by position on the decode engine."""
-        limit = 56 if plan["dtype"] == torch.bfloat16 else 40
+        limit = 56 if plan["dtype"] in hip.HALF_DTYPES else 40
         return self.hid_dim == 64 * self.n_heads and seq <= limit
 
     def _forward_prefill(self, plan, tokens, enc_out, start_emb, bs, seq, return_hidden=False):
@@ -266,10 +367,11 @@ class _IncrementalDecoder(_Planned, nn.Module):
         return out.view(bs, seq, -1)
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
-                        seed=0, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
+                        seed=None, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
                         defer_check=False, early_stop_every=0):
         self._check_mode()
         plan = self._get_plan()
+        seed = resolve_seed(seed)
         if max_len + 1 > self.pos_embedding.num_embeddings:
             raise IndexError("index out of range in self")    # reference: pos_embedding lookup, SURVEY.md section 5
         start_emb = start_emb.to(plan["dtype"]).contiguous()
@@ -293,7 +395,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
             logits = torch.empty((r, (self.num_tokens + 63) // 64 * 64), device=dev)[:, :self.num_tokens]
             gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
-                    if plan["dtype"] == torch.bfloat16 else None)                    # column-group maxima (bf16 path)
+                    if plan["dtype"] in hip.HALF_DTYPES else None)                   # column-group maxima (16-bit paths)
             gm = None if gmax is None else gmax[:n]
             # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
             lg = logits[:n]

@@ -10,8 +10,9 @@
  *   - `stream` is a hipStream_t passed as void* (0 = the null stream);
  *   - returns DH_OK (0) or a DH_ERR_* code; dh_error_string() names it;
  *   - `dtype` is the storage type of activations and weights: DH_F32 (the parity path, bit-exact
- *     greedy ids vs the reference) or DH_BF16 (the throughput path: bf16 in HBM, bf16 MFMA, fp32
- *     accumulation; bias/scale/shift/LayerNorm vectors stay fp32).  An entry point that lacks a
+ *     greedy ids vs the reference) or DH_BF16 / DH_F16 (the throughput paths: 16-bit storage in HBM, 16-bit MFMA
+ *     operands, fp32 accumulation; bias/scale/shift/LayerNorm vectors stay fp32; wherever a comment below says
+ *     "bf16" or "DH_BF16 only" the entry point takes DH_F16 as well).  An entry point that lacks a
  *     dtype returns DH_ERR_UNSUPPORTED for it.
  *   - row-major everywhere; images NCHW; "rows" are (image, beam) pairs, image-major.
  */
@@ -24,11 +25,13 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 6
+#define DH_ABI_VERSION 7
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
-       DH_BF16_OUT_F32 = 2 };            /* dh_linear only: bf16 operands, fp32 output (logits) */
+       DH_BF16_OUT_F32 = 2,              /* dh_linear only: bf16 operands, fp32 output (logits) */
+       DH_F16 = 3,                       /* IEEE half storage / v_mfma_f32_16x16x32_f16 operands (BASELINE config 5) */
+       DH_F16_OUT_F32 = 4 };             /* dh_linear only: fp16 operands, fp32 output */
 
 /* device-side error bits OR-ed into the `err` word of the beam kernels */
 enum { DH_BEAM_ERR_ALL_FILTERED = 1,   /* every logit filtered (-inf): reference raises RuntimeError, beam.py:46 */
@@ -63,7 +66,7 @@ int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* scale, cons
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */
 int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const float* shift, void* y,
                       int N, int Cin, int H, int W, int Cout, int KS, int stride, int pad, int relu,
-                      void* stream);
+                      int dtype, void* stream);
 
 /* relu(conv3(y) + downsample(x) + shift) as ONE launch: the end of a ResNet stage's first bottleneck (torchvision
  * Bottleneck.forward: out = relu(bn3(conv3(out)) + downsample(x))).  w = [W3 * bn3_scale | Wd * bnd_scale]
@@ -74,7 +77,7 @@ int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w, const floa
 
 /* Input packing for a matrix-core stem: NCHW fp32 image [N,C,H,W] (C <= 8) -> channels-last bf16 [N,H,W,8] with
  * channels C..7 zero, so the 7x7 stem is a dh_conv2d_nhwc_bn_act with Cin = 8 (weights zero-padded likewise). */
-int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, void* stream);
+int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, int dtype, void* stream);
 
 /* Image preprocessing on device: u8 [N,H,W,C] -> fp32 NCHW (x / 255 - mean[c]) / std[c], bit-identical to
  * torchvision ToTensor + Normalize (deephumor_demo.ipynb:565-567; the resize stays with the image decoder). */
@@ -83,7 +86,8 @@ int dh_normalize_u8_hwc(const uint8_t* x, const float* mean, const float* stdv, 
 
 /* Teacher-forced (prefill) forms of the decoder row kernels -- forward() over all positions at once (transformers.py
  * DecoderLayer.forward with the causal + pad mask of :471-478).  Rows are sequence-major: row n*n_pos + t.
- *   dh_embed_prefill      x = (t == 0 ? start_emb[n] : tok_emb[tokens[n, t-1]]) / scale + pos_emb[t]
+ *   dh_embed_prefill      x = (t == 0 ? start_emb[n] : tok_emb[tokens[n, t-1]]) / scale + pos_emb[t]; start_emb == NULL:
+ *                         x = tok_emb[tokens[n, t]] / scale + pos_emb[t] (forward without an image slot, transformers.py:432)
  *   dh_attn_self_prefill  causal self-attention over qkv [rows, 3D] of ONE projection GEMM (no KV cache); head dim 64,
  *                         n_pos <= 56 (bf16) / 40 (fp32); key j >= 1 masked where tokens[n, j-1] == pad_index
  *   dh_attn_cross_prefill every position of image n against that image's S patch keys kv [n_img*S, 2D] */
@@ -177,6 +181,22 @@ int dh_attn_cross_decode(const void* q, int ldq, const void* kv, const uint8_t* 
 
 /* keymask[r] = any(enc_out[r, :] == 0)  (transformers.py:480-481).  enc_out [rows, D]. */
 int dh_enc_key_mask(const void* enc_out, uint8_t* keymask, int rows, int D, int dtype, void* stream);
+
+/* Module-level API of the reference's transformer building blocks (the captioning models never call these directly;
+ * they exist so that MultiHeadAttentionLayer.forward / DecoderLayer.forward / get_pad_mask / get_autoregressive_mask
+ * keep working for callers of deephumor.models):
+ *   dh_pad_mask             mask[b,q,k] = (key[b,k] == pad_index), uint8 [bs,Lq,Lk]        transformers.py:12-26
+ *   dh_autoregressive_mask  mask[b,q,k] = (k > q), uint8 [bs,L,L]                          transformers.py:29-40
+ *   dh_mask_or              a |= b over n bytes (input_mask = pad | causal)                transformers.py:477
+ *   dh_enc_nonzero_rows     out[r] = all(enc_out[r,:] != 0) as int64                       transformers.py:480
+ *   dh_attn_masked          softmax(q k^T / scale masked_fill(mask, -1e8)) v, heads merged transformers.py:99-124
+ *                           q/k/v [bs*L, ld*] projected rows, mask uint8 [bs,L,L] or NULL, out [bs*L, D] */
+int dh_pad_mask(const int64_t* key, uint8_t* mask, int bs, int Lq, int Lk, long long pad_index, void* stream);
+int dh_autoregressive_mask(uint8_t* mask, int bs, int L, void* stream);
+int dh_mask_or(uint8_t* a, const uint8_t* b, long long n, void* stream);
+int dh_enc_nonzero_rows(const void* enc_out, int64_t* out, int rows, int D, int dtype, void* stream);
+int dh_attn_masked(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const uint8_t* mask,
+                   void* out, int bs, int L, int D, int n_heads, float scale, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LSTM cell (nn.LSTM single time step; rnn_models.py:80,108)
