@@ -135,10 +135,13 @@ class BeamSearchHelper:
         return bool(self.done.cpu().numpy().all())
 
 
-def resolve_seed(seed):
+def resolve_seed(seed, noise_source=None):
     """``seed=None`` (the default of every ``generate``): a fresh 62-bit Philox key drawn from torch's default CPU
     generator -- the generator the reference's ``torch.multinomial`` calls consume (beam.py:46) -- so ``torch.manual_seed``
-    controls ``generate`` and successive calls give different captions, as with the reference.  An int is used as is."""
+    controls ``generate`` and successive calls give different captions, as with the reference.  An int is used as is.
+    With caller-supplied noise (RNG-replay parity tests) the Philox key is unused and nothing is drawn."""
+    if seed is None and noise_source is not None:
+        return 0
     if seed is None:
         return int(torch.randint(0, 1 << 62, (), dtype=torch.int64).item())
     return int(seed)

@@ -148,7 +148,7 @@ class LSTMDecoder(_Planned, nn.Module):
         ``all_ended()`` break, rnn_models.py:131) and stops decoding then -- one host sync per check, same captions."""
         self._check_mode()
         plan = self._get_plan()
-        seed = resolve_seed(seed)
+        seed = resolve_seed(seed, noise_source)
         image_emb = image_emb.reshape(image_emb.shape[0], -1).to(plan["dtype"]).contiguous()
 
         def session(lo, hi):

@@ -371,7 +371,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                         defer_check=False, early_stop_every=0):
         self._check_mode()
         plan = self._get_plan()
-        seed = resolve_seed(seed)
+        seed = resolve_seed(seed, noise_source)
         if max_len + 1 > self.pos_embedding.num_embeddings:
             raise IndexError("index out of range in self")    # reference: pos_embedding lookup, SURVEY.md section 5
         start_emb = start_emb.to(plan["dtype"]).contiguous()
