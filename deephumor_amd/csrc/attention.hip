@@ -696,3 +696,193 @@ extern "C" int dh_attn_masked(const void* q, int ldq, const void* k, int ldk, co
                                             (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, mask, (T*)out, rows, L, D, dh, scale));
     DH_LAUNCH_CHECK();
 }
+
+
+// ---- cross-attention on the matrix cores, operands straight from HBM into MFMA fragments (16-bit paths) -----------------
+// The S <= 64 patch keys / values of an (image, head) are shared by all its beams (transformers.py:544).  Once per batch
+// and layer dh_attn_cross_pack re-lays the encoder K|V rows out per (image, head) in exactly the order an MFMA fragment
+// load wants them:
+//   Kp [img][head][64 keys][64 d]            key-major (keys >= S are zero rows)
+//   Vt [img][head][64 d][64 key slots]       d-major (V transposed), key slot ks = 32*kk + 8*lq + e holds key
+//                                            16*(2*kk + (e >> 2)) + 4*lq + (e & 3)
+// With that, ONE wave handles one (image, head) with no LDS and no barrier: every lane's 16-byte loads ARE its MFMA
+// operands (8 K fragments, 8 V^T fragments, 2 q fragments: all requested up front, one memory round trip),
+//   S[m][key]  = sum_d q[m][d] K[key][d]      4 key tiles x 2 k-steps of v_mfma_f32_16x16x32 (rows m = beams, <= 16)
+//   softmax over the keys of a row: 16 values in the lane's own accumulators + the 3 other lanes of the row's column quad
+//   out[m][d]  = sum_ks P[m][ks] V^T[d][ks]   the lane's OWN probabilities, rounded to the 16-bit type, are its B operand:
+//                                            the key-slot permutation above is chosen so that no cross-lane move is needed
+// Masked keys get -1e8 exactly as masked_fill does (transformers.py:110-111); keys >= S do not exist (weight 0).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cross_pack_kernel(const T* __restrict__ kv, T* __restrict__ kp, T* __restrict__ vt,
+                                                               int S, int D, int H) {
+    // one workgroup per (image, head): stage the V head slice [S][64] in LDS, write K rows straight through and V transposed
+    __shared__ uint16_t vs[64][64 + 2];
+    const int img = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(kv);
+    uint16_t* kd = reinterpret_cast<uint16_t*>(kp) + ((size_t)img * H + h) * 4096;
+    uint16_t* vd = reinterpret_cast<uint16_t*>(vt) + ((size_t)img * H + h) * 4096;
+    for (int c = tid; c < 64 * 8; c += 256) {                   // 16-byte chunks of the [64 keys][64 d] K tile
+        const int key = c >> 3, ch = c & 7;
+        uint4 val = make_uint4(0u, 0u, 0u, 0u), vv = val;
+        if (key < S) {
+            const uint16_t* row = src + (size_t)(img * S + key) * (2 * D) + h * 64 + ch * 8;
+            val = *reinterpret_cast<const uint4*>(row);
+            vv = *reinterpret_cast<const uint4*>(row + D);
+        }
+        *reinterpret_cast<uint4*>(kd + key * 64 + ch * 8) = val;
+        const uint16_t* pv = reinterpret_cast<const uint16_t*>(&vv);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) vs[key][ch * 8 + u] = pv[u];
+    }
+    __syncthreads();
+    for (int c = tid; c < 64 * 64; c += 256) {                  // Vt[d][ks]
+        const int d = c >> 6, ks = c & 63;
+        const int kk = ks >> 5, lq = (ks >> 3) & 3, e = ks & 7;
+        const int key = 16 * (2 * kk + (e >> 2)) + 4 * lq + (e & 3);
+        vd[d * 64 + ks] = vs[key][d];
+    }
+}
+
+extern "C" int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img, int S, int D, int n_heads, int dtype,
+                                  void* stream) {
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(kv && kp && vt && n_img > 0 && S > 0 && S <= 64 && n_heads > 0 && D == 64 * n_heads);
+    DH_REQUIRE(((uintptr_t)kv % 16) == 0 && ((uintptr_t)kp % 16) == 0 && ((uintptr_t)vt % 16) == 0);
+    DhProfScope prof("dh_attn_cross_pack", 0.0, 2.0 * n_img * (2.0 * S * D + 2.0 * 64 * D), stream);
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL(attn_cross_pack_kernel<T>, dim3(n_img, n_heads), dim3(256), 0, (hipStream_t)stream,
+                                             (const T*)kv, (T*)kp, (T*)vt, S, D, n_heads));
+    DH_LAUNCH_CHECK();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ kp,
+                                                               const T* __restrict__ vt, const uint8_t* __restrict__ keymask,
+                                                               T* __restrict__ out, int n_img, int rows_per_img, int row_si, int S,
+                                                               int D, int H, float scale) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wid >= n_img * H) return;                                  // wave-uniform
+    const int img = wid / H, h = wid - img * H;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const uint16_t* kb = reinterpret_cast<const uint16_t*>(kp) + ((size_t)img * H + h) * 4096;
+    const uint16_t* vb = reinterpret_cast<const uint16_t*>(vt) + ((size_t)img * H + h) * 4096;
+    // every load of the kernel up front: K / V^T fragments, the row's q fragments, the key-mask bytes of the lane's 16 keys
+    uint4 kf[4][2], vf[4][2], qf[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+            vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+        }
+    const bool live = l15 < rows_per_img;
+    const size_t qrow = (size_t)img * row_si + (live ? l15 : 0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(q) + qrow * ldq + h * 64 + 32 * kk + 8 * lq);
+        qf[kk] = live ? t : make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t mk[4];                                                 // mask bytes of keys 16j + 4lq .. + 3 (clamped reads)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t w = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * j + 4 * lq + r;
+            w |= (uint32_t)(keymask[img * S + min(key, S - 1)] != 0) << (8 * r);
+        }
+        mk[j] = w;
+    }
+    dh_f32x4 sacc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sacc[j] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) sacc[j] = Op16<T>::mfma(kf[j][kk], qf[kk], sacc[j]);     // S[m = l15][key = 16j + 4lq + r]
+    }
+    float e[4][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * j + 4 * lq + r;
+            const bool masked = (mk[j] >> (8 * r)) & 0xFFu;
+            e[j][r] = key < S ? (masked ? -1e8f : sacc[j][r] / scale) : -INFINITY;
+            mx = fmaxf(mx, e[j][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { e[j][r] = expf(e[j][r] - mx); sum += e[j][r]; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    // the lane's own 16 weights, rounded to the operand type, in key-slot order: k-step kk, element e <-> (j = 2kk + (e >> 2), r = e & 3)
+    uint4 pf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e0 = 2 * u, e1 = 2 * u + 1;
+            const float p0 = e[2 * kk + (e0 >> 2)][e0 & 3] / sum, p1 = e[2 * kk + (e1 >> 2)][e1 & 3] / sum;   // as torch.softmax
+            w[u] = (uint32_t)Op16<T>::from_f32(p0) | ((uint32_t)Op16<T>::from_f32(p1) << 16);
+        }
+        pf[kk] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    uint16_t* orow = reinterpret_cast<uint16_t*>(out) + qrow * D + h * 64;
+#pragma unroll
+    for (int jd = 0; jd < 4; ++jd) {
+        dh_f32x4 o = dh_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) o = Op16<T>::mfma(vf[jd][kk], pf[kk], o);                 // out[m = l15][d = 16jd + 4lq + r]
+        if (live) {
+            uint2 pk;
+            pk.x = (uint32_t)Op16<T>::from_f32(o[0]) | ((uint32_t)Op16<T>::from_f32(o[1]) << 16);
+            pk.y = (uint32_t)Op16<T>::from_f32(o[2]) | ((uint32_t)Op16<T>::from_f32(o[3]) << 16);
+            *reinterpret_cast<uint2*>(orow + 16 * jd + 4 * lq) = pk;
+        }
+    }
+}
+
+// q [n_img * row_si rows, ldq] (image i's rows start at row i * row_si; rows_per_img <= 16 of them are used), out likewise
+// [.., D]; kp / vt from dh_attn_cross_pack.
+static int launch_cross_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out, int n_img,
+                               int rows_per_img, int row_si, int S, int D, int n_heads, float scale, int dtype, hipStream_t s) {
+    const int waves = n_img * n_heads;
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL(attn_cross_mfma_kernel<T>, dim3(dh_cdiv(waves, 4)), dim3(256), 0, s, (const T*)q, ldq,
+                                             (const T*)kp, (const T*)vt, keymask, (T*)out, n_img, rows_per_img, row_si, S, D, n_heads, scale));
+    return DH_OK;
+}
+
+extern "C" int dh_attn_cross_decode_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
+                                           int n_img, int rows_per_img, int S, int D, int n_heads, float scale, int dtype,
+                                           void* stream) {
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(q && kp && vt && keymask && out && n_img > 0 && rows_per_img > 0 && rows_per_img <= 16);
+    DH_REQUIRE(S > 0 && S <= 64 && n_heads > 0 && D == 64 * n_heads && ldq >= D && (ldq % 8) == 0);
+    DH_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)kp % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0);
+    DhProfScope prof("dh_attn_cross_decode", 4.0 * n_img * rows_per_img * S * D, 2.0 * n_img * (S * 2.0 * D + rows_per_img * 2.0 * D), stream);
+    const int rc = launch_cross_packed(q, ldq, kp, vt, keymask, out, n_img, rows_per_img, rows_per_img, S, D, n_heads, scale, dtype,
+                                       (hipStream_t)stream);
+    if (rc != DH_OK) return rc;
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_attn_cross_prefill_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
+                                            int n_img, int n_pos, int S, int D, int n_heads, float scale, int dtype, void* stream) {
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(q && kp && vt && keymask && out && n_img > 0 && n_pos > 0 && S > 0 && S <= 64 && n_heads > 0 && D == 64 * n_heads);
+    DH_REQUIRE(ldq >= D && (ldq % 8) == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)out % 8) == 0);
+    DhProfScope prof("dh_attn_cross_prefill", 4.0 * n_img * n_pos * S * D, 2.0 * n_img * (S * 2.0 * D + n_pos * 2.0 * D), stream);
+    for (int t0 = 0; t0 < n_pos; t0 += 16) {           // 16 query rows per MFMA tile: the positions go in chunks of 16
+        const int cnt = n_pos - t0 < 16 ? n_pos - t0 : 16;
+        const char* qc = (const char*)q + (size_t)t0 * ldq * 2;
+        char* oc = (char*)out + (size_t)t0 * D * 2;
+        const int rc = launch_cross_packed(qc, ldq, kp, vt, keymask, oc, n_img, cnt, n_pos, S, D, n_heads, scale, dtype, (hipStream_t)stream);
+        if (rc != DH_OK) return rc;
+    }
+    DH_LAUNCH_CHECK();
+}

@@ -42,7 +42,37 @@ struct GemmBf16Params {
     // row m = output pixel (n, oh, ow) reads channels of input pixel (n, oh*a2_stride, ow*a2_stride) of the NHWC tensor A2
     const uint16_t* A2; int K1, a2_H, a2_W, a2_C, a2_stride, a2_Ho, a2_Wo;
     float* gmax; int gmax_ld;                          // optional: per-row maxima of each wave-wide column group
+    // ---- deferred LayerNorm (template flag LNX; decode / prefill chain of the 16-bit Transformer decoders) -------------
+    // Rows travel PRE-LayerNorm together with per-(row, 64-column tile) partial statistics (mean, M2 = sum of squared
+    // deviations from that mean) left by the GEMM that produced them; a row's mean / rstd is the fixed-order (Chan)
+    // combination of its tiles -- deterministic, no atomics.
+    const float2* a_stats; int a_nt; float a_eps;      // A rows are pre-LN: W has gamma folded in (W' = W * gamma[k]), bias has
+    const float* a_colsum;                             //   beta folded in; out = rstd * (acc - mu * colsum[n]) + bias[n], colsum[n] = sum_k W'[n,k]
+    const float2* r_stats; int r_nt; float r_eps;      // residual rows are pre-LN: res' = (res - mu) * rstd * r_gamma[n] + r_beta[n]
+    const float* r_gamma; const float* r_beta;
+    float2* o_stats;                                   // out: partial statistics of the OUTPUT rows, [M][N / 64] (requires BN == 64)
 };
+
+// mean and rstd of a row from its nt <= 8 tile partials (each over 64 elements): Chan's parallel combination in a fixed order
+__device__ __forceinline__ void ln_combine(const float2* st, int nt, float eps, float& mu, float& rstd) {
+    float2 v[8];
+#pragma unroll
+    for (int t = 0; t < 8; t += 2) {                    // 16-byte loads, clamped: all issued back to back
+        const float4 q = *reinterpret_cast<const float4*>(st + (t < nt ? t : 0));
+        v[t] = make_float2(q.x, q.y); v[t + 1] = make_float2(q.z, q.w);
+    }
+    float ms = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ms += t < nt ? v[t].x : 0.f;
+    mu = ms / (float)nt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float d = v[t].x - mu;
+        m2 += t < nt ? fmaf(64.f * d, d, v[t].y) : 0.f;
+    }
+    rstd = 1.0f / sqrtf(m2 / (float)(nt * 64) + eps);
+}
 
 typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
@@ -63,7 +93,7 @@ __device__ __forceinline__ void wait_vmcnt(int n) {
 
 // NS = LDS ring depth: slabs t+1 .. t+NS-1 are in flight (LDS-DMA) while slab t feeds the MFMAs.
 // NW waves per workgroup, arranged WAVES_M x (NW / WAVES_M) over the BM x BN block.
-template <typename OT, int BM, int BN, int WAVES_M, bool CONV, int NS, int NW = 4>
+template <typename OT, int BM, int BN, int WAVES_M, bool CONV, int NS, int NW = 4, bool LNX = false>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
     constexpr int NT = 64 * NW;
     constexpr int BK = 64;
@@ -238,6 +268,25 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             addv[j][0] = av.x; addv[j][1] = av.y; addv[j][2] = av.z; addv[j][3] = av.w;
         }
     }
+    // deferred LayerNorm on the A rows: this lane's rows' (mean, rstd) and its columns' folded-weight row sums
+    float a_mu[TM], a_rs[TM], csum[TN][4];
+    bool a_fold = false;
+    if constexpr (LNX) {
+        a_fold = p.a_stats != nullptr;
+        if (a_fold) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = min(m0 + wm0 + 16 * i + l15, p.M - 1);
+                ln_combine(p.a_stats + (size_t)m * p.a_nt, p.a_nt, p.a_eps, a_mu[i], a_rs[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + 16 * j + 4 * lq;
+                const float4 c4 = n < p.N ? *reinterpret_cast<const float4*>(p.a_colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                csum[j][0] = c4.x; csum[j][1] = c4.y; csum[j][2] = c4.z; csum[j][3] = c4.w;
+            }
+        }
+    }
     const int nslab = (p.K + BK - 1) / BK;
     // prologue: NS-1 slabs in flight
 #pragma unroll
@@ -318,6 +367,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
     constexpr int EP_IT = (BM * CHUNKS + NT - 1) / NT;
     const bool fast = ((p.ldc & 7) == 0) && (!p.res || (p.ldres & 7) == 0);
     uint4 rq[EP_IT];
+    float r_mu[EP_IT], r_rs[EP_IT];
+    float4 rg[EP_IT][2], rb[EP_IT][2];
+    bool r_ln = false;
     if (!p.out_f32 && p.res && fast) {
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) {
@@ -325,6 +377,19 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             const int m = m0 + row, n = n0 + ch * 8;
             const bool ok = c < BM * CHUNKS && m < p.M && n + 8 <= p.N;
             rq[it] = *reinterpret_cast<const uint4*>(p.res + (ok ? (size_t)m * p.ldres + n : 0));
+        }
+        if constexpr (LNX) {
+            r_ln = p.r_stats != nullptr;
+            if (r_ln) {
+#pragma unroll
+                for (int it = 0; it < EP_IT; ++it) {
+                    const int c = tid + it * NT, row = c / CHUNKS, ch = c - row * CHUNKS;
+                    const int m = min(m0 + row, p.M - 1), n = min(n0 + ch * 8, p.N - 8);
+                    ln_combine(p.r_stats + (size_t)m * p.r_nt, p.r_nt, p.r_eps, r_mu[it], r_rs[it]);
+                    rg[it][0] = *reinterpret_cast<const float4*>(p.r_gamma + n); rg[it][1] = *reinterpret_cast<const float4*>(p.r_gamma + n + 4);
+                    rb[it][0] = *reinterpret_cast<const float4*>(p.r_beta + n); rb[it][1] = *reinterpret_cast<const float4*>(p.r_beta + n + 4);
+                }
+            }
         }
     }
     // Stage the fp32 tile in LDS, then finish rows with row-contiguous accesses.  Slot s of row m
@@ -337,10 +402,17 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         for (int j = 0; j < TN; ++j) {
             const int row = wm0 + 16 * i + l15, slot = (wn0 + 16 * j) / 4 + lq;
             float4 v;
-            v.x = fmaf(acc[j][i][0], mulv[j][0], addv[j][0]);
-            v.y = fmaf(acc[j][i][1], mulv[j][1], addv[j][1]);
-            v.z = fmaf(acc[j][i][2], mulv[j][2], addv[j][2]);
-            v.w = fmaf(acc[j][i][3], mulv[j][3], addv[j][3]);
+            if (LNX && a_fold) {        // LayerNorm of the A rows applied on the accumulators: rstd * (acc - mu * colsum) + bias'
+                v.x = fmaf(a_rs[i], fmaf(-a_mu[i], csum[j][0], acc[j][i][0]), addv[j][0]);
+                v.y = fmaf(a_rs[i], fmaf(-a_mu[i], csum[j][1], acc[j][i][1]), addv[j][1]);
+                v.z = fmaf(a_rs[i], fmaf(-a_mu[i], csum[j][2], acc[j][i][2]), addv[j][2]);
+                v.w = fmaf(a_rs[i], fmaf(-a_mu[i], csum[j][3], acc[j][i][3]), addv[j][3]);
+            } else {
+                v.x = fmaf(acc[j][i][0], mulv[j][0], addv[j][0]);
+                v.y = fmaf(acc[j][i][1], mulv[j][1], addv[j][1]);
+                v.z = fmaf(acc[j][i][2], mulv[j][2], addv[j][2]);
+                v.w = fmaf(acc[j][i][3], mulv[j][3], addv[j][3]);
+            }
             *reinterpret_cast<float4*>(ep + row * BN + ((slot ^ (row & (SLOTS - 1))) << 2)) = v;
         }
     __syncthreads();
@@ -379,6 +451,53 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         return;
     }
     uint16_t* C = reinterpret_cast<uint16_t*>(p.C);
+    if constexpr (LNX) {
+        if (p.o_stats) {
+            // statistics-emitting form (N % 64 == 0, 16-byte rows: checked by the host): every lane takes part in the 8-lane row
+            // reductions, so no early exits; the statistics are those of the ROUNDED values the consumers will read
+            static_assert(BN == 64, "one statistics tile = one 64-column GEMM tile");
+#pragma unroll
+            for (int it = 0; it < EP_IT; ++it) {
+                const int c = tid + it * NT, row = c / CHUNKS, ch = c - row * CHUNKS;
+                const int m = m0 + row, n = n0 + ch * 8;
+                const int sw = row & (SLOTS - 1);
+                const float4 lo = *reinterpret_cast<const float4*>(ep + row * BN + (((2 * ch) ^ sw) << 2));
+                const float4 hi = *reinterpret_cast<const float4*>(ep + row * BN + (((2 * ch + 1) ^ sw) << 2));
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+                if (p.res) {
+                    const uint32_t w4[4] = {rq[it].x, rq[it].y, rq[it].z, rq[it].w};
+                    float rr[8];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) Op16<OT>::unpack2(w4[u], rr[2 * u], rr[2 * u + 1]);
+                    if (r_ln) {
+                        const float g8[8] = {rg[it][0].x, rg[it][0].y, rg[it][0].z, rg[it][0].w, rg[it][1].x, rg[it][1].y, rg[it][1].z, rg[it][1].w};
+                        const float b8[8] = {rb[it][0].x, rb[it][0].y, rb[it][0].z, rb[it][0].w, rb[it][1].x, rb[it][1].y, rb[it][1].z, rb[it][1].w};
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) rr[u] = fmaf((rr[u] - r_mu[it]) * r_rs[it], g8[u], b8[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] += rr[u];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = fmaxf(v[u], 0.f);
+                }
+                float s1 = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { v[u] = Op16<OT>::to_f32(Op16<OT>::from_f32(v[u])); s1 += v[u]; }
+                const float mean = sum8(s1) * (1.0f / 64.0f);
+                float s2 = 0.f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const float d = v[u] - mean; s2 = fmaf(d, d, s2); }
+                s2 = sum8(s2);
+                if (m < p.M) {
+                    store16(reinterpret_cast<OT*>(C + (size_t)m * p.ldc + n), v);
+                    if (ch == 0) p.o_stats[(size_t)m * p.tiles_n + tn] = make_float2(mean, s2);
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int it = 0; it < EP_IT; ++it) {
         const int c = tid + it * NT;
@@ -393,12 +512,17 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         if (fast && n + 8 <= p.N) {
             if (p.res) {
                 const uint32_t w4[4] = {rq[it].x, rq[it].y, rq[it].z, rq[it].w};
+                float rr[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    float lo, hi;
-                    Op16<OT>::unpack2(w4[u], lo, hi);
-                    v[2 * u] += lo; v[2 * u + 1] += hi;
+                for (int u = 0; u < 4; ++u) Op16<OT>::unpack2(w4[u], rr[2 * u], rr[2 * u + 1]);
+                if (LNX && r_ln) {
+                    const float g8[8] = {rg[it][0].x, rg[it][0].y, rg[it][0].z, rg[it][0].w, rg[it][1].x, rg[it][1].y, rg[it][1].z, rg[it][1].w};
+                    const float b8[8] = {rb[it][0].x, rb[it][0].y, rb[it][0].z, rb[it][0].w, rb[it][1].x, rb[it][1].y, rb[it][1].z, rb[it][1].w};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) rr[u] = fmaf((rr[u] - r_mu[it]) * r_rs[it], g8[u], b8[u]);
                 }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] += rr[u];
             }
             if (p.relu) {
 #pragma unroll
@@ -426,8 +550,9 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     //  the persistent kernel with a register-only bf16 epilogue (8-byte stores / residual loads in accumulator layout):
     //  K = 64: 166 vs 176 us, K = 128 + residual: 156 vs 127 us, K = 256: 77 vs 64 us -- the LDS-staged 16-byte rows win)
     const long long big_tiles = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
+    const bool lnx = !CONV && (p.a_stats || p.r_stats || p.o_stats);
     // >= 192 big tiles (measured: lowering the threshold to 128/100/40 tiles does not help gates / ffn / qkv / proj)
-    if (big_tiles >= 192 && p.M >= 96 && p.N >= 96) {
+    if (big_tiles >= 192 && p.M >= 96 && p.N >= 96 && !lnx) {
         p.tiles_m = dh_cdiv(p.M, 128); p.tiles_n = dh_cdiv(p.N, 128);
         // 8 waves (4 x 2, each 32 x 64) on the 128 x 128 tile, 2 workgroups per CU = 4 waves per SIMD: measured
         // 510 TF vs 450 TF with 4 waves per workgroup and 300 TF with one 4-wave workgroup and a deeper ring --
@@ -435,7 +560,7 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
         hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
         return;
     }
-    if (p.N <= 64 && p.M >= 256 * 512) {
+    if (p.N <= 64 && p.M >= 256 * 512 && !lnx) {
         // narrow outputs with very many rows (stage-1 convolutions): 3x3 -> 256 x 64 tiles on 8 waves (the 64 weight
         // rows are staged once per 256 pixels; measured 127 us vs 146 us with 4 waves, 135 us with 128 x 64 tiles)
         p.tiles_m = dh_cdiv(p.M, 256); p.tiles_n = dh_cdiv(p.N, 64);
@@ -449,6 +574,17 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     }
     p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
     const int blocks = p.tiles_m * p.tiles_n;
+    if (!CONV && (p.a_stats || p.r_stats || p.o_stats)) {       // deferred-LayerNorm forms: the 64 x 64 kernels, same ring choice
+        if (blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 4, 4, true>), dim3(blocks), dim3(256), 0, s, p);
+        else if (blocks <= 320)
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 8, 8, true>), dim3(blocks), dim3(512), 0, s, p);
+        else if (blocks <= 768)
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 3, 4, true>), dim3(blocks), dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 2, 4, true>), dim3(blocks), dim3(256), 0, s, p);
+        return;
+    }
     // ring depth (16 KB per slab) by workgroup count, so that all tiles are co-resident in ONE round where possible:
     // <= 320: one per CU with a deep ring (7 slabs in flight); <= 512: two per CU; <= 768: three; <= 1280: five
     // (the fused LSTM step, 640 workgroups: 20.7 us with 4 slabs / 1.25 rounds, 16.6 us with 3 slabs / one round)
@@ -485,6 +621,30 @@ int dh_linear_bf16_impl(const void* A, int lda, const void* W, int ldw, const fl
         if (out_f32 && launch_persistent_f32<bf16_t>(p, s)) DH_LAUNCH_CHECK();
         launch_gemm_bf16<bf16_t, false>(p, s);
     }
+    DH_LAUNCH_CHECK();
+}
+
+// dh_linear with deferred LayerNorm (include/deephumor_hip.h: dh_ln_fold_t)
+extern "C" int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldres,
+                            void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream) {
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(A && W && C && ln && M > 0 && N > 0 && K > 0 && (K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
+    DH_REQUIRE(ldc >= N && (ldc % 8) == 0 && (N % 8) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)C % 16) == 0);
+    DH_REQUIRE(!residual || (ldres >= N && (ldres % 8) == 0 && ((uintptr_t)residual % 16) == 0));
+    DH_REQUIRE(!ln->a_stats || (ln->a_colsum && bias && ln->a_tiles >= 2 && ln->a_tiles <= 8 && (ln->a_tiles % 2) == 0 && ln->a_tiles * 64 == K &&
+                                ((uintptr_t)ln->a_stats % 16) == 0 && ((uintptr_t)ln->a_colsum % 16) == 0 && ((uintptr_t)bias % 16) == 0 && (N % 4) == 0));
+    DH_REQUIRE(!ln->r_stats || (residual && ln->r_gamma && ln->r_beta && ln->r_tiles >= 2 && ln->r_tiles <= 8 && (ln->r_tiles % 2) == 0 &&
+                                ln->r_tiles * 64 == N && ((uintptr_t)ln->r_stats % 16) == 0 && ((uintptr_t)ln->r_gamma % 16) == 0 &&
+                                ((uintptr_t)ln->r_beta % 16) == 0));
+    DH_REQUIRE(!ln->o_stats || ((N % 64) == 0 && ((uintptr_t)ln->o_stats % 8) == 0));
+    GemmBf16Params p{};
+    p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = bias;
+    p.res = (const uint16_t*)residual; p.ldres = ldres; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.relu = relu;
+    p.a_stats = (const float2*)ln->a_stats; p.a_nt = ln->a_tiles; p.a_eps = ln->a_eps; p.a_colsum = ln->a_colsum;
+    p.r_stats = (const float2*)ln->r_stats; p.r_nt = ln->r_tiles; p.r_eps = ln->r_eps; p.r_gamma = ln->r_gamma; p.r_beta = ln->r_beta;
+    p.o_stats = (float2*)ln->o_stats;
+    DhProfScope prof("dh_linear", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)), stream);
+    DH_DISPATCH_16(dtype, launch_gemm_bf16<T, false>(p, (hipStream_t)stream));
     DH_LAUNCH_CHECK();
 }
 

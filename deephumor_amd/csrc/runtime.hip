@@ -8,6 +8,69 @@
 
 #define DH_TRY(call) do { const int rc_ = (call); if (rc_ != DH_OK) return rc_; } while (0)
 
+static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* q, void* att, int n_img, int rows_per_img,
+                           int dt, void* stream) {
+    if (L.kp && L.vt && DH_IS_16BIT(dt) && m->S <= 64 && m->D == 64 * m->n_heads && rows_per_img <= 16)
+        return dh_attn_cross_decode_packed(q, m->D, L.kp, L.vt, m->keymask, att, n_img, rows_per_img, m->S, m->D, m->n_heads,
+                                           L.ea_scale, dt, stream);
+    return dh_attn_cross_decode(q, m->D, L.kv, m->keymask, att, n_img, rows_per_img, m->S, m->D, m->n_heads, L.ea_scale, dt, stream);
+}
+
+// The decode position on the deferred-LayerNorm chain (16-bit dtypes): 8 launches per layer instead of 11.  The residual
+// stream is kept PRE-LayerNorm (buffers X = sc->x, Y1 = sc->o, Y2 = sc->y2 with partial statistics st0 / st1 / st2); every
+// LayerNorm is applied where its output is consumed: folded into the next projection (gamma in the weight, beta in the bias,
+// mean / rstd on the accumulators) and onto the residual operand of the next output projection (transformers.py:356-375).
+static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_t* sc, const int32_t* tokens, int tok_ld,
+                                    const int32_t* src, int src_ld, int n_img, int rows_per_img, int row_mult, int rows_total,
+                                    int t, void* x_final, void* stream) {
+    const int rows = n_img * rows_per_img, D = m->D, PF = m->pf_dim, dt = m->dtype, nt = D / 64;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const dh_tr_layer_t& L = m->layers[l];
+        const dh_tr_layer_t* P = l > 0 ? &m->layers[l - 1] : nullptr;       // its LN3 is pending on X
+        dh_ln_fold_t f{};
+        // 1. qkv = LN3_prev(X) Wqkv^T + b  (layer 0: X is the embedding, no LayerNorm in front)
+        if (P) { f.a_stats = sc->st0; f.a_tiles = nt; f.a_eps = P->ln3_eps; f.a_colsum = L.cs_qkv; }
+        dh_prof_set_tag("qkv");
+        DH_TRY(dh_linear_ln(sc->x, D, P ? L.wqkv_f : L.wqkv, D, P ? L.bqkv_f : L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
+        DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
+                                   row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
+        // 2. Y1 = LN3_prev(X) + att Wo^T + bo, statistics of Y1 -> st1
+        f = dh_ln_fold_t{};
+        if (P) { f.r_stats = sc->st0; f.r_tiles = nt; f.r_eps = P->ln3_eps; f.r_gamma = P->ln3_g; f.r_beta = P->ln3_b; }
+        f.o_stats = sc->st1;
+        dh_prof_set_tag("proj");
+        DH_TRY(dh_linear_ln(sc->att, D, L.wo, D, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
+        const void* yin = sc->o; const float* st_in = sc->st1;               // rows entering the FFN block, LayerNorm pending
+        const float *g_in = L.ln1_g, *b_in = L.ln1_b; float eps_in = L.ln1_eps;
+        if (m->cross) {
+            // 3. q = LN1(Y1) Wq^T + bq
+            f = dh_ln_fold_t{};
+            f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
+            dh_prof_set_tag("proj");
+            DH_TRY(dh_linear_ln(sc->o, D, L.wq_f, D, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
+            DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
+            // 4. Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2
+            f = dh_ln_fold_t{};
+            f.r_stats = sc->st1; f.r_tiles = nt; f.r_eps = L.ln1_eps; f.r_gamma = L.ln1_g; f.r_beta = L.ln1_b; f.o_stats = sc->st2;
+            dh_prof_set_tag("proj");
+            DH_TRY(dh_linear_ln(sc->att, D, L.weo, D, L.beo, sc->o, D, sc->y2, D, rows, D, D, 0, &f, dt, stream));
+            yin = sc->y2; st_in = sc->st2; g_in = L.ln2_g; b_in = L.ln2_b; eps_in = L.ln2_eps;
+        }
+        // 5. ff = relu(LN(Yin) W1^T + b1)
+        f = dh_ln_fold_t{};
+        f.a_stats = st_in; f.a_tiles = nt; f.a_eps = eps_in; f.a_colsum = L.cs_1;
+        dh_prof_set_tag("ffn");
+        DH_TRY(dh_linear_ln(yin, D, L.w1_f, D, L.b1_f, nullptr, 0, sc->ff, PF, rows, PF, D, 1, &f, dt, stream));
+        // 6. X = LN(Yin) + ff W2^T + b2, statistics -> st0  (LN3 of this layer now pending on X)
+        f = dh_ln_fold_t{};
+        f.r_stats = st_in; f.r_tiles = nt; f.r_eps = eps_in; f.r_gamma = g_in; f.r_beta = b_in; f.o_stats = sc->st0;
+        dh_prof_set_tag("ffn");
+        DH_TRY(dh_linear_ln(sc->ff, PF, L.w2, PF, L.b2, yin, D, sc->x, D, rows, D, PF, 0, &f, dt, stream));
+    }
+    const dh_tr_layer_t& Z = m->layers[m->n_layers - 1];
+    return dh_add_layernorm(sc->x, nullptr, Z.ln3_g, Z.ln3_b, x_final, rows, D, Z.ln3_eps, dt, stream);
+}
+
 extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_tr_scratch_t* sc,
                                               const void* start_emb, const int32_t* tokens, int tok_ld,
                                               const int32_t* src, int src_ld, int n_img, int rows_per_img,
@@ -18,6 +81,24 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
     const size_t esz = dt == DH_F32 ? 4 : 2;
     DH_TRY(dh_embed_rows(m->tok_emb, m->pos_emb, start_emb, tokens, tok_ld, sc->x, rows, rows_per_img, row_mult, t,
                          D, m->emb_scale, dt, stream));
+    bool deferred = DH_IS_16BIT(dt) && (D % 128) == 0 && D <= 512 && sc->y2 && sc->st0 && sc->st1 && sc->st2;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const dh_tr_layer_t& L = m->layers[l];
+        deferred = deferred && L.w1_f && L.b1_f && L.cs_1 && (l == 0 || (L.wqkv_f && L.bqkv_f && L.cs_qkv)) &&
+                   (!m->cross || (L.wq_f && L.bq_f && L.cs_q));
+    }
+    if (deferred) {
+        void* xf = x_out ? x_out : sc->att;          // the final LayerNorm's output feeds the classifier (att is free by then)
+        DH_TRY(decode_position_deferred(m, sc, tokens, tok_ld, src, src_ld, n_img, rows_per_img, row_mult, rows_total, t, xf, stream));
+        if (logits && group_max) {
+            DH_TRY(dh_vocab_logits(xf, D, m->cls_w, D, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, D, dt, stream));
+        } else if (logits) {
+            dh_prof_set_tag("vocab");
+            DH_TRY(dh_linear(xf, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, D, 0,
+                             dt == DH_F16 ? DH_F16_OUT_F32 : DH_BF16_OUT_F32, stream));
+        }
+        return DH_OK;
+    }
     for (int l = 0; l < m->n_layers; ++l) {
         const dh_tr_layer_t& L = m->layers[l];
         dh_prof_set_tag("qkv");
@@ -30,8 +111,7 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
         if (m->cross) {
             dh_prof_set_tag("proj");
             DH_TRY(dh_linear(sc->x, D, L.wq, D, L.bq, nullptr, nullptr, nullptr, 0, sc->q, D, rows, D, D, 0, dt, stream));
-            DH_TRY(dh_attn_cross_decode(sc->q, D, L.kv, m->keymask, sc->att, n_img, rows_per_img, m->S, D, m->n_heads,
-                                        L.ea_scale, dt, stream));
+            DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
             dh_prof_set_tag("proj");
             DH_TRY(dh_linear(sc->att, D, L.weo, D, L.beo, nullptr, nullptr, nullptr, 0, sc->o, D, rows, D, D, 0, dt, stream));
             DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln2_g, L.ln2_b, sc->x, rows, D, L.ln2_eps, dt, stream));

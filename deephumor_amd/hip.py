@@ -24,7 +24,8 @@ class TrLayer(_c.Structure):
     _fields_ = ([(n, _P) for n in ("wqkv", "wo", "w1", "w2", "wq", "weo", "bqkv", "bo", "b1", "b2", "bq", "beo",
                                    "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b")]
                 + [(n, _F) for n in ("ln1_eps", "ln2_eps", "ln3_eps", "sa_scale", "ea_scale")] + [("_pad", _I)]
-                + [(n, _P) for n in ("kcache", "vcache", "kv")])
+                + [(n, _P) for n in ("kcache", "vcache", "kv")]
+                + [(n, _P) for n in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1", "kp", "vt")])
 
 
 class TrModel(_c.Structure):
@@ -34,7 +35,13 @@ class TrModel(_c.Structure):
 
 
 class TrScratch(_c.Structure):
-    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff")]
+    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2")]
+
+
+class LnFold(_c.Structure):
+    """``dh_ln_fold_t``: deferred-LayerNorm options of ``dh_linear_ln``."""
+    _fields_ = [("a_stats", _P), ("a_tiles", _I), ("a_eps", _F), ("a_colsum", _P),
+                ("r_stats", _P), ("r_tiles", _I), ("r_eps", _F), ("r_gamma", _P), ("r_beta", _P), ("o_stats", _P)]
 
 
 class LstmLayer(_c.Structure):
@@ -65,6 +72,10 @@ SIGNATURES = {
     "dh_nchw_to_rows": [_P, _P, _I, _I, _I, _I, _P],
     "dh_label_mean": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dh_linear_ln": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
+    "dh_attn_cross_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_attn_cross_decode_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "dh_attn_cross_prefill_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_conv2d_nhwc_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "dh_embed_rows": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_add_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
@@ -355,6 +366,56 @@ def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=No
     _launch("dh_linear", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(scale), _ptr(shift),
             _ptr(residual), residual.stride(0) if residual is not None else 0,
             _ptr(out), out.stride(0), m, n, k, int(relu), dt, _stream(), tag=tag)
+    return out
+
+
+def linear_ln(a, w, bias, out=None, residual=None, relu=False, a_ln=None, r_ln=None, want_stats=False, tag=None):
+    """``dh_linear_ln``: 16-bit ``a [M, K] @ w[N, K].T + bias (+ residual)`` with deferred LayerNorm.
+    ``a_ln = (stats [M, K/64, 2], eps, colsum [N])``: ``a`` is pre-LayerNorm, ``w`` / ``bias`` have gamma / beta folded in;
+    ``r_ln = (stats [M, N/64, 2], eps, gamma, beta)``: the residual rows are pre-LayerNorm;
+    ``want_stats``: also returns the partial statistics ``[M, N/64, 2]`` of the output rows."""
+    _dev(a, w, bias, out, residual)
+    m, k = a.shape
+    n = w.shape[0]
+    assert a.dtype in HALF_DTYPES and a.dtype == w.dtype and a.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    f = LnFold()
+    if a_ln is not None:
+        st, eps, colsum = a_ln
+        f.a_stats, f.a_tiles, f.a_eps, f.a_colsum = _ptr(st), k // 64, float(eps), _ptr(colsum)
+    if r_ln is not None:
+        st, eps, gamma, beta = r_ln
+        f.r_stats, f.r_tiles, f.r_eps, f.r_gamma, f.r_beta = _ptr(st), n // 64, float(eps), _ptr(gamma), _ptr(beta)
+    stats = torch.empty((m, n // 64, 2), dtype=torch.float32, device=a.device) if want_stats else None
+    f.o_stats = _ptr(stats)
+    _launch("dh_linear_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(residual),
+            residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
+            _dt(a), _stream(), tag=tag)
+    return (out, stats) if want_stats else out
+
+
+def attn_cross_pack(kv, n_img, s, d, n_heads):
+    """kv [n_img*S, 2D] (16-bit) -> (kp, vt) [n_img, n_heads, 64, 64] each: the matrix-core cross-attention layout."""
+    _dev(kv)
+    kp = torch.empty((n_img, n_heads, 64, 64), dtype=kv.dtype, device=kv.device)
+    vt = torch.empty_like(kp)
+    _launch("dh_attn_cross_pack", _ptr(kv), _ptr(kp), _ptr(vt), n_img, s, d, n_heads, _dt(kv), _stream())
+    return kp, vt
+
+
+def attn_cross_decode_packed(q, kp, vt, keymask, out, n_img, rows_per_img, s, d, n_heads, scale):
+    _dev(q, kp, vt, keymask, out)
+    _launch("dh_attn_cross_decode_packed", _ptr(q), q.stride(0), _ptr(kp), _ptr(vt), _ptr(keymask), _ptr(out), n_img,
+            rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream())
+    return out
+
+
+def attn_cross_prefill_packed(q, kp, vt, keymask, n_img, n_pos, s, d, n_heads, scale):
+    _dev(q, kp, vt, keymask)
+    out = torch.empty((n_img * n_pos, d), dtype=q.dtype, device=q.device)
+    _launch("dh_attn_cross_prefill_packed", _ptr(q), q.stride(0), _ptr(kp), _ptr(vt), _ptr(keymask), _ptr(out), n_img, n_pos,
+            s, d, n_heads, float(scale), _dt(q), _stream())
     return out
 
 

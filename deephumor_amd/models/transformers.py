@@ -190,6 +190,20 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     weo=d(ea.fc_o.weight), beo=f(ea.fc_o.bias), ea_scale=float(ea.scale),
                     ln2=(f(lyr.enc_attn_ln.weight), f(lyr.enc_attn_ln.bias), lyr.enc_attn_ln.eps))
             layers.append(ent)
+        dt = self.classifier.weight.dtype
+        if dt in hip.HALF_DTYPES and self.hid_dim % 128 == 0 and self.hid_dim <= 512:
+            # deferred-LayerNorm chain (dh_linear_ln): the gamma of the LayerNorm in front of a projection folded into its
+            # weight, beta into its bias, plus the row sums of the folded (rounded) weight
+            def fold(w, b, ln):
+                g, be = ln[0], ln[1]
+                wf = (w.float() * g[None, :]).to(dt).contiguous()
+                return wf, (b + (w.float() * be[None, :]).sum(1)).contiguous(), wf.float().sum(1).contiguous()
+            for i, ent in enumerate(layers):
+                if i > 0:
+                    ent["wqkv_f"], ent["bqkv_f"], ent["cs_qkv"] = fold(ent["wqkv"], ent["bqkv"], layers[i - 1]["ln3"])
+                if self._cross:
+                    ent["wq_f"], ent["bq_f"], ent["cs_q"] = fold(ent["wq"], ent["bq"], ent["ln1"])
+                ent["w1_f"], ent["b1_f"], ent["cs_1"] = fold(ent["w1"], ent["b1"], ent["ln2"] if self._cross else ent["ln1"])
         return dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
                     scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=f(self.classifier.bias),
                     dtype=self.classifier.weight.dtype)
@@ -216,13 +230,16 @@ class _IncrementalDecoder(_Planned, nn.Module):
             self.dtype = plan["dtype"]
             self.kc = torch.empty((nl, n_pos, self.rows_total, d), device=dev, dtype=self.dtype)
             self.vc = torch.empty((nl, n_pos, self.rows_total, d), device=dev, dtype=self.dtype)
-            self.kv, self.keymask, self.s = None, None, 0
+            self.kv, self.keymask, self.s, self.packed = None, None, 0, None
             if enc_out is not None:
                 n, s, _ = enc_out.shape
                 flat = enc_out.to(self.dtype).contiguous().view(n * s, d)
                 self.s = s
                 self.keymask = hip.enc_key_mask(flat)                                   # transformers.py:480-481
                 self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv") for L in plan["layers"]]   # once per image
+                if self.dtype in hip.HALF_DTYPES and s <= 64 and d == 64 * dec.n_heads and beam <= 16:
+                    # matrix-core cross-attention: K | V re-laid out per (image, head) in MFMA operand order, once per batch
+                    self.packed = [hip.attn_cross_pack(kv, n, s, d, dec.n_heads) for kv in self.kv]
             self._scratch = {}
             self.pf = dec.layers[0].pf.fc_1.out_features
             self.d, self.dev = d, dev
@@ -239,6 +256,11 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     c.wq, c.weo, c.bq, c.beo = P(L["wq"]), P(L["weo"]), P(L["bq"]), P(L["beo"])
                     c.ln2_g, c.ln2_b, c.ln2_eps, c.ea_scale = P(L["ln2"][0]), P(L["ln2"][1]), L["ln2"][2], L["ea_scale"]
                     c.kv = P(self.kv[i])
+                    if self.packed is not None:
+                        c.kp, c.vt = P(self.packed[i][0]), P(self.packed[i][1])
+                for name in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1"):
+                    if name in L:
+                        setattr(c, name, P(L[name]))
                 c.kcache, c.vcache = self.kc[i].data_ptr(), self.vc[i].data_ptr()
             m = self.c_model = hip.TrModel()
             m.n_layers, m.D, m.n_heads, m.pf_dim, m.V = nl, d, dec.n_heads, self.pf, dec.num_tokens
@@ -254,6 +276,10 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 e = lambda *shape: torch.empty(shape, device=self.dev, dtype=self.dtype)
                 bufs = dict(x=e(rows, self.d), qkv=e(rows, 3 * self.d), att=e(rows, self.d),
                             o=e(rows, self.d), q=e(rows, self.d), ff=e(rows, self.pf))
+                if self.dtype in hip.HALF_DTYPES:      # deferred-LayerNorm chain: one more row buffer + partial statistics
+                    bufs["y2"] = e(rows, self.d)
+                    for k in ("st0", "st1", "st2"):
+                        bufs[k] = torch.empty((rows, self.d // 64, 2), device=self.dev, dtype=torch.float32)
                 c = hip.TrScratch()
                 for k, v in bufs.items():
                     setattr(c, k, v.data_ptr())
@@ -347,15 +373,51 @@ class _IncrementalDecoder(_Planned, nn.Module):
             s_enc = enc_out.shape[1]
             flat = enc_out.to(dt).contiguous().view(bs * s_enc, d)
             keymask = hip.enc_key_mask(flat)                                          # transformers.py:480-481
+        packed_ok = dt in hip.HALF_DTYPES and 0 < s_enc <= 64
+
+        def cross(q, L):
+            kv = hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv")
+            if packed_ok:                                  # matrix-core cross-attention, 16 positions per launch
+                kp, vt = hip.attn_cross_pack(kv, bs, s_enc, d, nh)
+                return hip.attn_cross_prefill_packed(q, kp, vt, keymask, bs, seq, s_enc, d, nh, L["ea_scale"])
+            return hip.attn_cross_prefill(q, kv, keymask, bs, seq, s_enc, d, nh, L["ea_scale"])
+
+        if "w1_f" in plan["layers"][0]:
+            # 16-bit dtypes: the deferred-LayerNorm chain of dh_transformer_decode_position (csrc/runtime.hip), all positions
+            # at once -- the same arithmetic per row, so prefill and incremental decoding agree
+            st = pend = None                               # statistics of x / (gamma, beta, eps) of the LayerNorm pending on x
+            for L in plan["layers"]:
+                if pend is None:
+                    qkv = hip.linear_ln(x, L["wqkv"], L["bqkv"], tag="qkv")
+                else:
+                    qkv = hip.linear_ln(x, L["wqkv_f"], L["bqkv_f"], a_ln=(st, pend[2], L["cs_qkv"]), tag="qkv")
+                att = hip.attn_self_prefill(qkv, tokens, bs, seq, d, nh, L["sa_scale"], self.pad_index)
+                y, sy = hip.linear_ln(att, L["wo"], L["bo"], residual=x, want_stats=True, tag="proj",
+                                      r_ln=None if pend is None else (st, pend[2], pend[0], pend[1]))
+                ln_in = L["ln1"]
+                if self._cross:
+                    q = hip.linear_ln(y, L["wq_f"], L["bq_f"], a_ln=(sy, L["ln1"][2], L["cs_q"]), tag="proj")
+                    att = cross(q, L)
+                    y, sy = hip.linear_ln(att, L["weo"], L["beo"], residual=y, want_stats=True, tag="proj",
+                                          r_ln=(sy, L["ln1"][2], L["ln1"][0], L["ln1"][1]))
+                    ln_in = L["ln2"]
+                ff = hip.linear_ln(y, L["w1_f"], L["b1_f"], relu=True, a_ln=(sy, ln_in[2], L["cs_1"]), tag="ffn")
+                x, st = hip.linear_ln(ff, L["w2"], L["b2"], residual=y, want_stats=True, tag="ffn",
+                                      r_ln=(sy, ln_in[2], ln_in[0], ln_in[1]))
+                pend = L["ln3"]
+            x = hip.add_layernorm(x, None, pend[0], pend[1], eps=pend[2])
+            if return_hidden:
+                return x.view(bs, seq, d)
+            out = hip.linear(x, plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
+            return out.view(bs, seq, -1)
         for L in plan["layers"]:
             qkv = hip.linear(x, L["wqkv"], L["bqkv"], tag="qkv")
             att = hip.attn_self_prefill(qkv, tokens, bs, seq, d, nh, L["sa_scale"], self.pad_index)
             o = hip.linear(att, L["wo"], L["bo"], tag="proj")
             x = hip.add_layernorm(x, o, L["ln1"][0], L["ln1"][1], eps=L["ln1"][2])
             if self._cross:
-                kv = hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv")
                 q = hip.linear(x, L["wq"], L["bq"], tag="proj")
-                att = hip.attn_cross_prefill(q, kv, keymask, bs, seq, s_enc, d, nh, L["ea_scale"])
+                att = cross(q, L)
                 o = hip.linear(att, L["weo"], L["beo"], tag="proj")
                 x = hip.add_layernorm(x, o, L["ln2"][0], L["ln2"][1], eps=L["ln2"][2])
             ff = hip.linear(x, L["w1"], L["b1"], relu=True, tag="ffn")

@@ -131,6 +131,24 @@ int dh_linear(const void* A, int lda, const void* W, int ldw, const float* bias,
               const float* scale, const float* shift, const void* residual, int ldres,
               void* C, int ldc, int M, int N, int K, int relu, int dtype, void* stream);
 
+/* dh_linear with DEFERRED LayerNorm (16-bit dtypes): the post-LN decoder layer x = LN(x + sublayer(x))
+ * (transformers.py:356-375) without a LayerNorm launch.  Rows travel PRE-LayerNorm together with per-(row, 64-column tile)
+ * partial statistics {mean, M2 = sum of squared deviations from that mean}, [rows][D/64][2] fp32, written by the GEMM
+ * that produced the rows (o_stats); a row's mean / rstd is the fixed-order combination of its tiles (deterministic).
+ *   a_stats != NULL: the A rows are pre-LN.  The caller folded gamma into the weight (W'[n,k] = W[n,k] * gamma[k]) and
+ *       beta into the bias (bias'[n] = bias[n] + sum_k beta[k] W[n,k]); a_colsum[n] = sum_k W'[n,k].  Then
+ *       C = act( rstd[m] * (A W'^T - mu[m] * a_colsum) + bias' ) == act( LN(A) W^T + bias ).     a_tiles = K / 64 <= 8.
+ *   r_stats != NULL: the residual rows are pre-LN: residual' = (residual - mu) * rstd * r_gamma[n] + r_beta[n].  r_tiles = N / 64.
+ *   o_stats != NULL: partial statistics of the (rounded) output rows are written to o_stats[m][N / 64] (N % 64 == 0).
+ * All of a_stats / r_stats / o_stats may be NULL (then this is dh_linear with bias + residual). */
+typedef struct dh_ln_fold {
+    const float* a_stats; int a_tiles; float a_eps; const float* a_colsum;
+    const float* r_stats; int r_tiles; float r_eps; const float* r_gamma; const float* r_beta;
+    float* o_stats;
+} dh_ln_fold_t;
+int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldres,
+                 void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream);
+
 /* Vocabulary projection feeding beam search (bf16 operands): logits [M,V] fp32 = A*W^T + bias, and
  * group_max[m, g] = max(logits[m, 64g .. 64g+63]) for g < 2*ceil(V/128) (row stride gm_ld) -- the pre-filter
  * dh_beam_row_sample_groups uses to read only the ~top_k column groups that can hold a top-k logit. */
@@ -178,6 +196,17 @@ int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, const int32
 int dh_attn_cross_decode(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out,
                          int n_img, int rows_per_img, int S, int D, int n_heads, float scale,
                          int dtype, void* stream);
+
+/* The same attention on the matrix cores (16-bit dtypes, head dim 64, S <= 64, rows_per_img <= 16).  dh_attn_cross_pack
+ * re-lays kv out ONCE per batch and layer as kp [n_img][n_heads][64 keys][64] and vt [n_img][n_heads][64][64 key slots]
+ * (V transposed, key slots permuted into MFMA operand order, keys >= S zero) -- 16 KB per (image, head).  One wave then
+ * handles one (image, head) straight from HBM: no LDS, no barrier, one memory round trip.  _prefill_packed: every
+ * position of image n (rows n*n_pos + t), in chunks of 16 positions. */
+int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img, int S, int D, int n_heads, int dtype, void* stream);
+int dh_attn_cross_decode_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
+                                int n_img, int rows_per_img, int S, int D, int n_heads, float scale, int dtype, void* stream);
+int dh_attn_cross_prefill_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
+                                 int n_img, int n_pos, int S, int D, int n_heads, float scale, int dtype, void* stream);
 
 /* keymask[r] = any(enc_out[r, :] == 0)  (transformers.py:480-481).  enc_out [rows, D]. */
 int dh_enc_key_mask(const void* enc_out, uint8_t* keymask, int rows, int D, int dtype, void* stream);
@@ -313,6 +342,15 @@ typedef struct dh_tr_layer {
     int _pad;
     void *kcache, *vcache;                                  /* this layer's self-attention cache [pos][rows_total][D] */
     const void* kv;                                         /* this layer's cross-attention K|V [n_img*S][2D] or NULL */
+    /* optional (16-bit dtypes): the deferred-LayerNorm chain (dh_linear_ln).  Weights with the gamma of the LayerNorm in
+     * FRONT of them folded in, biases with its beta folded in, row sums of the folded weights:
+     *   wqkv_f / bqkv_f / cs_qkv : LN3 of the PREVIOUS layer (NULL for layer 0, whose input is the embedding)
+     *   wq_f / bq_f / cs_q       : LN1 of this layer (cross-attention query projection)
+     *   w1_f / b1_f / cs_1       : the LayerNorm in front of the FFN (LN2; LN1 in the decoder without encoder attention)
+     * w1_f == NULL selects the plain chain with dh_add_layernorm launches. */
+    const void *wqkv_f, *wq_f, *w1_f;
+    const float *bqkv_f, *bq_f, *b1_f, *cs_qkv, *cs_q, *cs_1;
+    const void *kp, *vt;                                    /* optional: kv re-laid out by dh_attn_cross_pack (matrix-core cross-attention) */
 } dh_tr_layer_t;
 
 typedef struct dh_tr_model {
@@ -324,7 +362,11 @@ typedef struct dh_tr_model {
     const uint8_t* keymask;                                 /* [n_img*S] or NULL */
 } dh_tr_model_t;
 
-typedef struct dh_tr_scratch { void *x, *qkv, *att, *o, *q, *ff; } dh_tr_scratch_t;   /* [rows, D|3D|D|D|D|PF] */
+typedef struct dh_tr_scratch {
+    void *x, *qkv, *att, *o, *q, *ff;       /* [rows, D|3D|D|D|D|PF] */
+    void* y2;                               /* [rows, D]      second pre-LayerNorm row buffer of the deferred chain (or NULL) */
+    float *st0, *st1, *st2;                 /* [rows, D/64, 2] partial LayerNorm statistics of x / o / y2 (or NULL) */
+} dh_tr_scratch_t;
 
 /* Hidden state of position t for n_img*rows_per_img compact rows; x_out (optional, [rows,D]) receives the
  * last layer's output instead of scratch->x; logits (optional, fp32 [rows,V], row stride ldl) = classifier(x); with

@@ -290,3 +290,79 @@ def test_bf16_generate_odd_shapes(kind, n_img, beam, top_k, max_len):
             tb, lb = model.generate_batch(*args(k, n_img), img0=k, **kw)
             # bf16 GEMM tiles differ with the batch size only in which rows share a tile, not in any row's arithmetic
             assert torch.equal(torch.cat([ta, tb]), t1) and torch.equal(torch.cat([la, lb]), l1)
+
+
+@pytest.mark.parametrize("n_img,beam,s", [(3, 5, 49), (2, 16, 64), (5, 1, 10), (7, 10, 49)])
+def test_cross_attention_on_matrix_cores(hip, n_img, beam, s):
+    """dh_attn_cross_pack + dh_attn_cross_decode_packed (one wave per (image, head), operands straight into MFMA
+    fragments) against masked softmax attention in fp32 on the same rounded operands, and against the LDS kernel."""
+    d, h, dh = 512, 8, 64
+    r = n_img * beam
+    q, kv = bf(rnd(r, d, seed=31)), bf(rnd(n_img * s, 2 * d, seed=32))
+    mask = torch.zeros(n_img * s, dtype=torch.uint8)
+    mask[3] = 1
+    if n_img > 1:
+        mask[s:2 * s] = 1                                   # an image with every key masked -> uniform weights
+    kp, vt = hip.attn_cross_pack(kv.cuda(), n_img, s, d, h)
+    out = torch.full((r, d), 7.0, device="cuda", dtype=HALF)
+    hip.attn_cross_decode_packed(q.cuda(), kp, vt, mask.cuda(), out, n_img, beam, s, d, h, 8.0)
+    old = torch.empty_like(out)
+    hip.attn_cross_decode(q.cuda(), kv.cuda(), mask.cuda(), old, n_img, beam, s, d, h, 8.0)
+    for row in range(r):
+        i = row // beam
+        keys = kv.float()[i * s:(i + 1) * s, :d].reshape(s, h, dh)
+        vals = kv.float()[i * s:(i + 1) * s, d:].reshape(s, h, dh)
+        energy = (torch.einsum("hd,lhd->hl", q.float()[row].view(h, dh), keys) / 8.0).masked_fill(mask[i * s:(i + 1) * s].bool()[None], -1e8)
+        ref = torch.einsum("hl,lhd->hd", torch.softmax(energy, -1), vals).reshape(-1)
+        np.testing.assert_allclose(out[row].float().cpu().numpy(), ref.numpy(), atol=2e-2, rtol=1e-2)
+    np.testing.assert_allclose(out.float().cpu().numpy(), old.float().cpu().numpy(), atol=2e-2, rtol=1e-2)
+    # prefill form: 21 positions per image in chunks of 16
+    n_pos = 21
+    qp = bf(rnd(n_img * n_pos, d, seed=33))
+    got = hip.attn_cross_prefill_packed(qp.cuda(), kp, vt, mask.cuda(), n_img, n_pos, s, d, h, 8.0)
+    want = hip.attn_cross_prefill(qp.cuda(), kv.cuda(), mask.cuda(), n_img, n_pos, s, d, h, 8.0)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want.float().cpu().numpy(), atol=2e-2, rtol=1e-2)
+
+
+def _tile_stats(y):
+    """Reference partial statistics: per (row, 64-column tile) mean and sum of squared deviations."""
+    t = y.view(y.shape[0], -1, 64)
+    mean = t.mean(-1)
+    return torch.stack([mean, ((t - mean[..., None]) ** 2).sum(-1)], -1)
+
+
+@pytest.mark.parametrize("m", [37, 1280, 256])
+def test_linear_with_deferred_layernorm(hip, m):
+    """dh_linear_ln: LayerNorm of the A rows applied on the accumulators (gamma / beta folded into weight / bias),
+    LayerNorm of the residual rows applied in the epilogue, partial statistics of the output rows -- against
+    F.layer_norm + F.linear in fp32 on the same rounded operands."""
+    d, n = 512, 512
+    g = torch.Generator().manual_seed(m)
+    y = bf(torch.randn(m, d, generator=g) * 1.7 + 0.3)                       # pre-LayerNorm rows (non-zero mean)
+    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2
+    w, b = bf(torch.randn(n, d, generator=g) / d ** 0.5), torch.randn(n, generator=g) * 0.1
+    stats = _tile_stats(y.float())
+    # (a) output = LN(y) W^T + b via folding
+    wf = bf(w.float() * gamma[None, :])
+    bfold = b + (w.float() * beta[None, :]).sum(1)
+    colsum = wf.float().sum(1)
+    out = hip.linear_ln(y.cuda(), wf.cuda(), bfold.cuda(), a_ln=(stats.cuda(), 1e-5, colsum.cuda()))
+    ln = F.layer_norm(y.float(), (d,), gamma, beta, 1e-5)
+    want = F.linear(ln, w.float(), b)
+    np.testing.assert_allclose(out.float().cpu().numpy(), want.numpy(), atol=6e-2 if HALF == torch.bfloat16 else 1.5e-2, rtol=2e-2)
+    # (b) output = LN(y) + a W2^T + b2 with statistics of the output
+    a = bf(torch.randn(m, 256, generator=g))
+    w2, b2 = bf(torch.randn(n, 256, generator=g) / 16.0), torch.randn(n, generator=g) * 0.1
+    out2, st2 = hip.linear_ln(a.cuda(), w2.cuda(), b2.cuda(), residual=y.cuda(), want_stats=True,
+                              r_ln=(stats.cuda(), 1e-5, gamma.cuda(), beta.cuda()))
+    want2 = ln + F.linear(a.float(), w2.float(), b2)
+    np.testing.assert_allclose(out2.float().cpu().numpy(), want2.numpy(), atol=5e-2 if HALF == torch.bfloat16 else 8e-3, rtol=1e-2)
+    ref_st = _tile_stats(out2.float().cpu())                                 # statistics of the ROUNDED output
+    np.testing.assert_allclose(st2.cpu()[..., 0].numpy(), ref_st[..., 0].numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(st2.cpu()[..., 1].numpy(), ref_st[..., 1].numpy(), atol=2e-3, rtol=1e-4)
+    # (c) chained: the statistics reproduce the LayerNorm of the next consumer
+    out3 = hip.linear_ln(out2, wf.cuda(), bfold.cuda(), a_ln=(st2, 1e-5, colsum.cuda()))
+    want3 = F.linear(F.layer_norm(out2.float().cpu(), (d,), gamma, beta, 1e-5), w.float(), b)
+    np.testing.assert_allclose(out3.float().cpu().numpy(), want3.numpy(), atol=6e-2 if HALF == torch.bfloat16 else 1.5e-2, rtol=2e-2)
+    # plain form == dh_linear
+    assert torch.equal(hip.linear_ln(a.cuda(), w2.cuda(), b2.cuda()), hip.linear(a.cuda(), w2.cuda(), b2.cuda()))
