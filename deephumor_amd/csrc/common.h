@@ -72,6 +72,25 @@ __device__ __forceinline__ float philox_exp1(uint64_t seed, uint32_t img, uint32
     return -logf(u);
 }
 
+// ---- LDS-DMA (global -> LDS without staging VGPRs) issued through inline assembly ----------------------------------
+// hipcc's own builtin (__builtin_amdgcn_global_load_lds) is tracked by the compiler's waitcnt insertion as a store to
+// LDS that may alias ANY later LDS read: it then puts an `s_waitcnt vmcnt(0)` in front of the ds_reads of every loop
+// iteration, which drains the whole LDS ring each time -- a ring of N slabs behaves like a ring of one, the loads of
+// slab t+1 never overlap the MFMAs of slab t, and the counted `s_waitcnt vmcnt(N)` of the kernels is dead code
+// (measured: the K = 2048 decoder GEMM 25 us -> the pure ring transfer takes 7 us).  As inline assembly the transfer is
+// invisible to that pass; ordering is the kernels' own counted vmcnt waits + barriers (loads, stores and LDS-DMA retire
+// in issue order).  Compiler-generated waits for ordinary loads stay correct: they can only over-wait.
+// `lds_dst` must be wave-uniform (the hardware adds lane * size itself); M0 carries it (one wait state before use).
+typedef void __attribute__((address_space(3)))* dh_lptr_t;
+__device__ __forceinline__ void dh_lds_dma16(const void* gsrc, void* lds_dst) {
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dh_lptr_t)lds_dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m), "v"(gsrc) : "memory");
+}
+__device__ __forceinline__ void dh_lds_dma4(const void* gsrc, void* lds_dst) {
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dh_lptr_t)lds_dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(m), "v"(gsrc) : "memory");
+}
+
 // ---- storage-type helpers: T = float (parity path), __bf16 or _Float16 (throughput paths); math is fp32 ---------
 typedef __bf16 bf16_t;
 typedef _Float16 f16_t;

@@ -78,18 +78,25 @@ typedef const void __attribute__((address_space(1)))* gptr_t;
 typedef void __attribute__((address_space(3)))* lptr_t;
 
 // wait until at most `n` of this wave's vector-memory operations (LDS-DMA included) are outstanding
-__device__ __forceinline__ void wait_vmcnt(int n) {
+#define DH_VMCNT_CASE(x) case x: asm volatile("s_waitcnt vmcnt(" #x ")" ::: "memory"); break;
+__device__ __forceinline__ void wait_vmcnt_any(int n) {
     switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        DH_VMCNT_CASE(1) DH_VMCNT_CASE(2) DH_VMCNT_CASE(3) DH_VMCNT_CASE(4) DH_VMCNT_CASE(5) DH_VMCNT_CASE(6)
+        DH_VMCNT_CASE(7) DH_VMCNT_CASE(8) DH_VMCNT_CASE(9) DH_VMCNT_CASE(10) DH_VMCNT_CASE(11) DH_VMCNT_CASE(12)
+        DH_VMCNT_CASE(13) DH_VMCNT_CASE(14) DH_VMCNT_CASE(15) DH_VMCNT_CASE(16) DH_VMCNT_CASE(17) DH_VMCNT_CASE(18)
+        DH_VMCNT_CASE(19) DH_VMCNT_CASE(20) DH_VMCNT_CASE(21) DH_VMCNT_CASE(22) DH_VMCNT_CASE(23) DH_VMCNT_CASE(24)
+        DH_VMCNT_CASE(25) DH_VMCNT_CASE(26) DH_VMCNT_CASE(27) DH_VMCNT_CASE(28) DH_VMCNT_CASE(29) DH_VMCNT_CASE(30)
+        DH_VMCNT_CASE(31) DH_VMCNT_CASE(32) DH_VMCNT_CASE(33) DH_VMCNT_CASE(34) DH_VMCNT_CASE(35) DH_VMCNT_CASE(36)
+        DH_VMCNT_CASE(37) DH_VMCNT_CASE(38) DH_VMCNT_CASE(39) DH_VMCNT_CASE(40) DH_VMCNT_CASE(41) DH_VMCNT_CASE(42)
+        DH_VMCNT_CASE(43) DH_VMCNT_CASE(44) DH_VMCNT_CASE(45) DH_VMCNT_CASE(46) DH_VMCNT_CASE(47) DH_VMCNT_CASE(48)
+        DH_VMCNT_CASE(49) DH_VMCNT_CASE(50) DH_VMCNT_CASE(51) DH_VMCNT_CASE(52) DH_VMCNT_CASE(53) DH_VMCNT_CASE(54)
+        DH_VMCNT_CASE(55) DH_VMCNT_CASE(56) DH_VMCNT_CASE(57) DH_VMCNT_CASE(58) DH_VMCNT_CASE(59) DH_VMCNT_CASE(60)
+        DH_VMCNT_CASE(61) DH_VMCNT_CASE(62) DH_VMCNT_CASE(63)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
+
+__device__ __forceinline__ void wait_vmcnt(int n) { wait_vmcnt_any(n); }
 
 // NS = LDS ring depth: slabs t+1 .. t+NS-1 are in flight (LDS-DMA) while slab t feeds the MFMAs.
 // NW waves per workgroup, arranged WAVES_M x (NW / WAVES_M) over the BM x BN block.
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             }
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
-                __builtin_amdgcn_global_load_lds((gptr_t)a_run[i], (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+                dh_lds_dma16(a_run[i], slab + (wave * IA + i) * 1024);
                 a_run[i] += a_stp[i];
             }
         } else {
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
                             src = a_base[i] + ((size_t)ih * p.Wd + iw) * p.Cin + ci;
                     }
                 }
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+                dh_lds_dma16(src, slab + (wave * IA + i) * 1024);
             }
             if (tap_uniform) {
                 st_ci += BK;
@@ -229,7 +236,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         if (stepping) {
 #pragma unroll
             for (int i = 0; i < IB; ++i) {
-                __builtin_amdgcn_global_load_lds((gptr_t)b_run[i], (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+                dh_lds_dma16(b_run[i], slab + A_BYTES + (wave * IB + i) * 1024);
                 b_run[i] += b_stp[i];
             }
         } else {
@@ -237,7 +244,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             for (int i = 0; i < IB; ++i) {
                 const int k = k0 + b_swz[i] * 8;
                 const void* src = (b_ok[i] && k < p.K) ? (const void*)(b_base[i] + k) : (const void*)zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+                dh_lds_dma16(src, slab + A_BYTES + (wave * IB + i) * 1024);
             }
         }
     };
@@ -707,24 +714,6 @@ struct VocabParams {
     float* gsum; const int64_t* targets; float* tgt_logit;
 };
 
-#define DH_VMCNT_CASE(x) case x: asm volatile("s_waitcnt vmcnt(" #x ")" ::: "memory"); break;
-__device__ __forceinline__ void wait_vmcnt_any(int n) {
-    switch (n) {
-        DH_VMCNT_CASE(1) DH_VMCNT_CASE(2) DH_VMCNT_CASE(3) DH_VMCNT_CASE(4) DH_VMCNT_CASE(5) DH_VMCNT_CASE(6)
-        DH_VMCNT_CASE(7) DH_VMCNT_CASE(8) DH_VMCNT_CASE(9) DH_VMCNT_CASE(10) DH_VMCNT_CASE(11) DH_VMCNT_CASE(12)
-        DH_VMCNT_CASE(13) DH_VMCNT_CASE(14) DH_VMCNT_CASE(15) DH_VMCNT_CASE(16) DH_VMCNT_CASE(17) DH_VMCNT_CASE(18)
-        DH_VMCNT_CASE(19) DH_VMCNT_CASE(20) DH_VMCNT_CASE(21) DH_VMCNT_CASE(22) DH_VMCNT_CASE(23) DH_VMCNT_CASE(24)
-        DH_VMCNT_CASE(25) DH_VMCNT_CASE(26) DH_VMCNT_CASE(27) DH_VMCNT_CASE(28) DH_VMCNT_CASE(29) DH_VMCNT_CASE(30)
-        DH_VMCNT_CASE(31) DH_VMCNT_CASE(32) DH_VMCNT_CASE(33) DH_VMCNT_CASE(34) DH_VMCNT_CASE(35) DH_VMCNT_CASE(36)
-        DH_VMCNT_CASE(37) DH_VMCNT_CASE(38) DH_VMCNT_CASE(39) DH_VMCNT_CASE(40) DH_VMCNT_CASE(41) DH_VMCNT_CASE(42)
-        DH_VMCNT_CASE(43) DH_VMCNT_CASE(44) DH_VMCNT_CASE(45) DH_VMCNT_CASE(46) DH_VMCNT_CASE(47) DH_VMCNT_CASE(48)
-        DH_VMCNT_CASE(49) DH_VMCNT_CASE(50) DH_VMCNT_CASE(51) DH_VMCNT_CASE(52) DH_VMCNT_CASE(53) DH_VMCNT_CASE(54)
-        DH_VMCNT_CASE(55) DH_VMCNT_CASE(56) DH_VMCNT_CASE(57) DH_VMCNT_CASE(58) DH_VMCNT_CASE(59) DH_VMCNT_CASE(60)
-        DH_VMCNT_CASE(61) DH_VMCNT_CASE(62) DH_VMCNT_CASE(63)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
 template <typename OT, int NS, int BM, int BN, int WAVES_M, int NW, bool LSE = false>
 __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1)) void vocab_logits_kernel(VocabParams p) {
     constexpr int BK = 64;
@@ -787,12 +776,12 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
         unsigned char* slab = lds + __builtin_amdgcn_readfirstlane(ld_g % NS) * SLAB;
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[i], (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+            dh_lds_dma16(a_ptr[i], slab + (wave * IA + i) * 1024);
             a_ptr[i] += a_step[i];
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[i], (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+            dh_lds_dma16(b_ptr[i], slab + A_BYTES + (wave * IB + i) * 1024);
             b_ptr[i] += b_step[i];
         }
         ++ld_g;
@@ -849,7 +838,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
                 // last slab, so the wait in front of that slab's MFMAs also covers it
                 const int n = n0 + wn0 + lane;
                 const void* src = (p.bias && n < p.N) ? (const void*)(p.bias + n) : (const void*)zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)bias_lds, 4, 0, 0);
+                dh_lds_dma4(src, bias_lds);
             }
             if (ld_g < total) stage_next();               // refill the buffer slab g-1 used
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

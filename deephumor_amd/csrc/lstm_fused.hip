@@ -118,12 +118,12 @@ __global__ __launch_bounds__(256) void lstm_layer_fused_kernel(LstmFusedParams p
                 if (k < p.E) src = ax[i] + k;
                 else if (ah[i]) src = ah[i] + (k - p.E);
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + (wave * IA + i) * 1024), 16, 0, 0);
+            dh_lds_dma16(src, slab + (wave * IA + i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
             const void* src = (b_ok[i] && k < K) ? (const void*)(b_src[i] + k0) : (const void*)zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(slab + A_BYTES + (wave * IB + i) * 1024), 16, 0, 0);
+            dh_lds_dma16(src, slab + A_BYTES + (wave * IB + i) * 1024);
         }
     };
 

@@ -14,6 +14,8 @@ runs all positions at once in prefill form (batched GEMMs, one causal self-atten
 ``_forward_prefill``) when the sequence fits the register-resident attention kernels (<= 56 positions in bf16,
 40 in fp32), and otherwise position by position on the incremental engine; both give the same logits (tested).
 """
+import os
+
 import torch
 from torch import nn
 
@@ -191,7 +193,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     ln2=(f(lyr.enc_attn_ln.weight), f(lyr.enc_attn_ln.bias), lyr.enc_attn_ln.eps))
             layers.append(ent)
         dt = self.classifier.weight.dtype
-        if dt in hip.HALF_DTYPES and self.hid_dim % 128 == 0 and self.hid_dim <= 512:
+        if dt in hip.HALF_DTYPES and self.hid_dim % 128 == 0 and self.hid_dim <= 512 and not os.environ.get("DH_NO_DEFERRED_LN"):
             # deferred-LayerNorm chain (dh_linear_ln): the gamma of the LayerNorm in front of a projection folded into its
             # weight, beta into its bias, plus the row sums of the folded (rounded) weight
             def fold(w, b, ln):
@@ -237,7 +239,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 self.s = s
                 self.keymask = hip.enc_key_mask(flat)                                   # transformers.py:480-481
                 self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv") for L in plan["layers"]]   # once per image
-                if self.dtype in hip.HALF_DTYPES and s <= 64 and d == 64 * dec.n_heads and beam <= 16:
+                if (self.dtype in hip.HALF_DTYPES and s <= 64 and d == 64 * dec.n_heads and beam <= 16
+                        and not os.environ.get("DH_NO_PACKED_CROSS")):
                     # matrix-core cross-attention: K | V re-laid out per (image, head) in MFMA operand order, once per batch
                     self.packed = [hip.attn_cross_pack(kv, n, s, d, dec.n_heads) for kv in self.kv]
             self._scratch = {}
