@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
-"""Benchmark of the image -> caption hot path on MI355X (contract: see the task brief / DESIGN.md).
+"""Benchmark of the image -> caption hot path on MI355X (contract: see the task brief / DESIGN.md section 6b).
 
     python bench.py --gpus 1 --steps K --warmup W                 # one rank
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic images that are already resident
-in HBM: ResNet-50 encoder -> decoder -> beam-search generate (beam=5, top_k=50, 32 tokens) for
-``--batch`` images per rank, followed -- when N > 1 -- by the single all_gather of token ids.
-``value`` = captions finished by all ranks / wall time (max over ranks), weak scaling (256 images
-per GPU).  Workloads (BASELINE.json configs): ``c2`` = CaptioningLSTM (default, configs[1]);
-``c3`` = CaptioningTransformer 6-layer/8-head.  The default run reports c2 as the contract line and
-attaches a short c3 measurement (with the decoder self-attention roofline) under ``"c3"``.
+A "step" is one pass of the hot path over one batch of synthetic images that are already resident in HBM:
+ResNet-50 encoder -> decoder -> beam-search generate (beam=5, top_k=50, 32 tokens) for ``--batch`` images per rank,
+followed -- when N > 1 -- by the single all_gather of token ids.  ``value`` = captions finished by all ranks / wall time
+(max over ranks), weak scaling (256 images per GPU).  Workloads (BASELINE.json configs): ``c2`` = CaptioningLSTM
+(default, configs[1]); ``c3`` = CaptioningTransformer 6-layer/8-head; ``c5`` = the 300-template fp16 beam-10 sweep.
+The default run reports c2 as the contract line and attaches a c3 measurement under ``"c3"``.
 
-Only the ``cpu_baseline`` leg and the greedy parity check import ``oracle/`` (the CPU restatement of
-the reference); the measured path is the HIP library only.
+What the line carries besides the contract fields:
+  roofline           ONE kernel template at ONE shape -- the launch key (entry[role]{MxNxK}) with the largest share of the
+                     step -- timed with HIP events recorded inside the library on the launch stream, every launch of it,
+                     inside the timed region; priced against MFMA peak or HBM bandwidth by its arithmetic intensity
+  encoder_layers     per-shape table of the encoder's convolution launches (from an untimed, fully instrumented pass)
+  cpu_baseline       the oracle (CPU restatement of the reference) on this box's host cores: thread-count sweep,
+                     warm-up + best of 3 (rank 0, N = 1 only)
+  fp32_parity_path   captions/s of the fp32 path -- the one whose greedy ids are bit-exact vs the CPU reference
+  host_inclusive     pinned host images in -> token ids in pinned host memory out: sequential, and software-pipelined
+                     (copy + encoder of batch i+1 on their own streams while batch i decodes; deephumor_amd/pipeline.py)
+
+Only the ``cpu_baseline`` leg and the greedy parity check import ``oracle/``; the measured path is the HIP library only.
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -30,11 +41,11 @@ V_WORD = 36541          # deephumor_demo.ipynb:524
 MAX_LEN = 32            # deephumor_demo.ipynb:1127
 BEAM, TOP_K, TEMP = 5, 50, 1.0
 STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))
-GRAPH = False        # set by --graph   # image sub-batches decoded concurrently (HIP streams)
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
-PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak
-
+PEAK_16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
+PMC_FILE = os.path.join(ROOT, "profiles", "r2", "pmc_hbm_traffic.json")
+TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 _SD_CACHE = {}
 
@@ -49,30 +60,335 @@ def build_model(workload, dev, dtype="bf16"):
     sd = _SD_CACHE[workload]
     model.load_state_dict(sd)
     model = model.to(dev)
-    if dtype == "bf16":
-        model = model.bfloat16()
-    elif dtype == "f16":
-        model = model.half()
+    if dtype != "f32":
+        model = model.to(TORCH_DTYPE[dtype])
     return model, sd, model._hp
-
-
-def one_step(model, images, img0, n_total, seed, eager=False, labels=None, beam=None):
-    from deephumor_amd.dist import gather_captions
-    if labels is not None:      # config C5: ImageLabelEncoder (+ spatial features) + CaptioningTransformer, beam 10
-        toks, lens = model.generate_batch(images, labels, max_len=MAX_LEN, beam_size=beam, top_k=TOP_K, temperature=TEMP,
-                                          seed=seed, img0=img0)
-        return gather_captions(toks, lens, n_total)
-    if GRAPH and not eager:      # whole step replayed from a captured hipGraph (profiling passes run eagerly: events need real launches)
-        toks, lens = model.generate_batch_graphed(images, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP,
-                                                  seed=seed, img0=img0)
-    else:
-        toks, lens = model.generate_batch(images, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP,
-                                          seed=seed, img0=img0, streams=STREAMS)
-    return gather_captions(toks, lens, n_total)
 
 
 def kind_of(workload):
     return {"c2": "CaptioningLSTM", "c3": "CaptioningTransformer", "c5": "CaptioningTransformerWithLabels"}[workload]
+
+
+def workload_name(workload):
+    return {"c2": "C2 CaptioningLSTM + ImageEncoder (emb 256, hidden 512, 2 layers)",
+            "c3": "C3 CaptioningTransformer 6-layer/8-head (spatial feats)",
+            "c5": "C5 ImageLabelEncoder + CaptioningTransformer (spatial feats), beam=10, 300-template sweep"}[workload]
+
+
+def one_step(model, images, img0, n_total, seed, graph=False):
+    from deephumor_amd.dist import gather_captions
+    kw = dict(max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP, seed=seed, img0=img0)
+    if graph:      # whole step replayed from a captured hipGraph
+        toks, lens = model.generate_batch_graphed(images, **kw)
+    else:
+        toks, lens = model.generate_batch(images, streams=STREAMS, **kw)
+    return gather_captions(toks, lens, n_total)
+
+
+# ---- rooflines ----------------------------------------------------------------------------------------------------
+def price(key, d, dtype):
+    """One launch key (calls, ms, algorithmic flops / bytes) against the roofline that bounds it."""
+    sec = d["ms"] / 1e3 / max(d["calls"], 1)
+    fl, by = d["flops"] / max(d["calls"], 1), d["bytes"] / max(d["calls"], 1)
+    peak = PEAK_F32_TFLOPS if dtype == "f32" else PEAK_16_TFLOPS
+    out = {"kernel": key, "launches": d["calls"], "avg_launch_us": sec * 1e6, "traffic": None}
+    if by:
+        out["algorithmic_bytes_per_launch"] = by
+    if fl:
+        out["algorithmic_flops_per_launch"] = fl
+    if not by and not fl:
+        return dict(out, bound=None, achieved=None, peak=None, unit=None, frac=None)
+    intensity = fl / by if by else float("inf")
+    if fl and by:
+        out["flop_per_byte"] = intensity
+    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if not fl or intensity < ridge:
+        ach = by / sec / 1e9
+        out.update(bound="hbm", achieved=ach, peak=PEAK_HBM_GBS, unit="GB/s", frac=ach / PEAK_HBM_GBS)
+        if fl:
+            out["tflops"] = fl / sec / 1e12
+    else:
+        ach = fl / sec / 1e12
+        out.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak)
+    return out
+
+
+def attach_traffic(rl, workload, dtype):
+    """HBM traffic per launch of the roofline kernel from the committed PMC passes of THIS tree (rocprofv3 --pmc cannot
+    run inside this process); the file names the commit it was measured on."""
+    if rl is None or dtype != "bf16":
+        return rl
+    try:
+        pmc = json.load(open(PMC_FILE))
+        ent = pmc.get(workload, {}).get(rl["kernel"])
+        if ent:
+            rl["traffic"] = ent["traffic_bytes_per_launch"]
+            rl["traffic_over_algorithmic"] = ent["traffic_bytes_per_launch"] / rl["algorithmic_bytes_per_launch"]
+            rl["traffic_source"] = f"profiles/r2/pmc_hbm_traffic.json @ {pmc.get('commit', '?')} ({ent.get('note', '')})"
+    except (OSError, ValueError, KeyError, TypeError):
+        pass
+    return rl
+
+
+def merge_keys(summary, pred):
+    """Sum of all launch keys selected by ``pred`` (e.g. every history depth of the self-attention kernel)."""
+    sel = [v for k, v in summary.items() if pred(k)]
+    if not sel:
+        return None
+    return {f: sum(v[f] for v in sel) for f in ("calls", "ms", "flops", "bytes")}
+
+
+def encoder_table(breakdown, dtype):
+    rows = []
+    for k, d in breakdown.items():
+        if not k.startswith("dh_conv2d"):
+            continue
+        r = price(k, d, dtype)
+        rows.append({"key": k, "launches": r["launches"], "us": round(r["avg_launch_us"], 1), "bound": r["bound"],
+                     "frac": round(r["frac"], 3), "gflop": round(r.get("algorithmic_flops_per_launch", 0) / 1e9, 2),
+                     "mbytes": round(r.get("algorithmic_bytes_per_launch", 0) / 1e6, 1)})
+    rows.sort(key=lambda r: -r["us"] * r["launches"])
+    return rows
+
+
+# ---- CPU legs -----------------------------------------------------------------------------------------------------
+def cpu_baseline(workload, sd, hp):
+    """The oracle (CPU restatement of the reference: per-image generate, full re-forward per token, fp32) timed on this
+    box's host cores on a bounded sample of the same workload: torch thread-count sweep on short captions, then warm-up +
+    best of 3 full-length captions at the best thread count."""
+    from oracle import ref_path as R
+    from deephumor_amd.synth import synth_images
+    imgs = synth_images(3, seed=0)
+    kind = kind_of(workload)
+    gen = lambda i, n: R.model_generate(kind, sd, hp, imgs[i:i + 1], max_len=n, temperature=TEMP, beam_size=BEAM, top_k=TOP_K)
+    t_all = time.perf_counter()
+    torch.manual_seed(0)
+    saved = torch.get_num_threads()
+    sweep = {}
+    short = 6
+    cands = sorted({t for t in (8, 16, 32, 64, 128) if t <= (os.cpu_count() or 8)} | {min(8, os.cpu_count() or 8)})
+    for th in cands:
+        torch.set_num_threads(th)
+        gen(0, 2)                                         # warm-up at this thread count
+        t0 = time.perf_counter()
+        gen(0, short)
+        sweep[th] = time.perf_counter() - t0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    gen(0, 2)
+    times, n_tok = [], 0
+    for i in range(3):
+        t0 = time.perf_counter()
+        ids = gen(i, MAX_LEN)
+        times.append(time.perf_counter() - t0)
+        n_tok += ids.numel()
+    torch.set_num_threads(saved)
+    return {"value": 1.0 / min(times), "unit": "captions/s", "cores": best, "kind": "port", "host_cpus": os.cpu_count(),
+            "thread_sweep_s_per_short_caption": {str(k): round(v, 3) for k, v in sweep.items()},
+            "times_s": [round(t, 3) for t in times],
+            "sample": f"3 images (best of 3), {kind} V={V_WORD}, beam={BEAM}, top_k={TOP_K}, max_len={MAX_LEN}, per-image generate "
+                      f"with full re-forward per token (reference algorithm), threads swept over {cands} on {short}-token captions, "
+                      f"{time.perf_counter() - t_all:.1f} s in all, mean length {n_tok / 3:.1f}",
+            "oracle_vs_reference": "profiles/r2/oracle_vs_reference_timing.json (build container, 8 vCPU)"}
+
+
+def greedy_match(workload, model, sd, hp, n_check):
+    """Greedy decode (beam_size=1, top_k=1) token match of the HIP path vs the CPU oracle."""
+    from oracle import ref_path as R
+    from deephumor_amd.synth import synth_images
+    imgs = synth_images(n_check, seed=0)
+    with torch.no_grad():
+        toks, lens = model.generate_batch(imgs.to(next(model.parameters()).device), max_len=MAX_LEN, beam_size=1, top_k=1)
+    same = total = 0
+    for i in range(n_check):
+        want = R.model_generate(kind_of(workload), sd, hp, imgs[i:i + 1], max_len=MAX_LEN, beam_size=1, top_k=1).reshape(-1).tolist()
+        got = toks[i, :int(lens[i])].cpu().tolist()
+        total += max(len(want), len(got))
+        same += sum(int(a == b) for a, b in zip(want, got))
+    return same / max(total, 1)
+
+
+# ---- the timed region ----------------------------------------------------------------------------------------------
+def timed_region(step_fn, steps, world, device):
+    """Contract of the brief: barrier + device synchronize, EXACTLY ``steps`` calls of ``step_fn(s)``, device synchronize +
+    barrier, wall time = MAX over ranks (one all_reduce).  Returns ``(seconds, last result of step_fn)``.  Used by every
+    workload; ``tests/test_dist_cpu.py`` drives it over gloo with a stubbed step."""
+    import torch.distributed as dist
+    multi = world > 1 and dist.is_available() and dist.is_initialized()
+    cuda = torch.device(device).type == "cuda"
+
+    def fence():
+        if cuda:
+            torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        if cuda:
+            torch.cuda.synchronize()
+
+    out = None
+    fence()
+    t0 = time.perf_counter()
+    for s in range(steps):
+        out = step_fn(s)
+    fence()
+    dt = time.perf_counter() - t0
+    if multi:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, out
+
+
+# ---- legs on the GPU ----------------------------------------------------------------------------------------------
+def timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=None, graph=False):
+    from deephumor_amd import hip
+    world = n_total // n_local
+    step = lambda s: one_step(model, images, rank * n_local, n_total, seed=100 + s, graph=graph)
+    if watch:
+        with hip.profile(watch=watch) as prof:
+            dt, out = timed_region(step, steps, world, images.device)
+        return dt, out[1], prof.summary()
+    dt, out = timed_region(step, steps, world, images.device)
+    return dt, out[1], {}
+
+
+def host_inclusive(model, n_local, steps):
+    """Pinned host images -> token ids in pinned host memory (SURVEY 8(d)'s metric definition), sequential and pipelined."""
+    from deephumor_amd.pipeline import CaptionPipeline
+    from deephumor_amd.synth import synth_images
+    pinned = synth_images(n_local, seed=0).pin_memory()
+    kw = dict(max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP)
+    out = {}
+    for name, overlap in (("sequential", False), ("pipelined", True)):
+        pipe = CaptionPipeline(model, overlap=overlap, **kw)
+        for _ in pipe.run([(pinned,)] * 2, seeds=[1, 2]):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in pipe.run([(pinned,)] * steps, seeds=range(100, 100 + steps)):
+            pass
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[name] = {"value": n_local * steps / dt, "unit": "captions/s", "ms_per_step": dt / steps * 1e3}
+    out["note"] = ("images start in pinned host memory, ids end in pinned host memory; pipelined = H2D copy and encoder of batch "
+                   "i+1 on their own HIP streams while batch i decodes")
+    return out
+
+
+def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtype="bf16", main_line=True):
+    import torch.distributed as dist
+    from deephumor_amd import hip
+    from deephumor_amd.synth import synth_images
+    model, sd, hp = build_model(workload, dev, dtype)
+    n_local, n_total = args.batch, args.batch * world
+    images = synth_images(n_local, seed=0, first=rank * n_local).to(dev)     # resident in HBM before timing
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    graph = args.graph
+    with torch.no_grad():
+        # untimed: a cold pass (code-object loading, allocator growth), then one fully instrumented pass (HIP events around
+        # every launch made through the library) for the per-kernel breakdown and the choice of the roofline kernel
+        one_step(model, images, rank * n_local, n_total, seed=0)
+        with hip.profile() as prof0:
+            one_step(model, images, rank * n_local, n_total, seed=0)
+        breakdown = prof0.summary()
+        dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])          # ONE kernel template at ONE shape
+        for w in range(1, warmup):
+            one_step(model, images, rank * n_local, n_total, seed=w, graph=graph)
+        if main_line and not graph:
+            # timed region: events only around the launches of the dominant key (a few dozen pairs per step)
+            dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch={dominant})
+        else:
+            dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, graph=graph)
+    res = {"value": n_total * steps / dt, "ms_per_step": dt / steps * 1e3,
+           "mean_caption_len": float(lens.float().mean()) if lens is not None else None}
+    by_entry = {}
+    for k, v in breakdown.items():
+        base = re.sub(r"\{.*\}$", "", k)
+        by_entry[base] = by_entry.get(base, 0.0) + v["ms"]
+    res["kernel_breakdown_ms_per_step"] = {k: round(v, 3) for k, v in sorted(by_entry.items(), key=lambda kv: -kv[1])}
+    res["kernel_breakdown_note"] = ("untimed pass with HIP events around every launch: the events add ~15 % to a chain of "
+                                    "small launches; per-kernel shares of the clean run: profiles/r2/*_kernel_stats.csv (rocprofv3)")
+    src = summary if dominant in summary else breakdown
+    res["roofline"] = attach_traffic(price(dominant, src[dominant], dtype), workload, dtype)
+    res["roofline"]["measured"] = "timed region, every launch" if dominant in summary else "instrumented pass"
+    res["encoder_layers"] = encoder_table(breakdown, dtype)
+    if workload in ("c3", "c5"):
+        for name, entry in (("roofline_self_attention", "dh_attn_self_decode"), ("roofline_cross_attention", "dh_attn_cross_decode")):
+            m = merge_keys(breakdown, lambda k: k.startswith(entry))
+            if m:
+                res[name] = attach_traffic(price(entry, m, dtype), workload, dtype)
+                res[name]["measured"] = "instrumented pass (events around every launch; rocprofv3 kernel-only times are ~2 us lower)"
+        sa, ca = res.get("roofline_self_attention"), res.get("roofline_cross_attention")
+        if sa and ca:
+            tot_b = sa["algorithmic_bytes_per_launch"] * sa["launches"] + ca["algorithmic_bytes_per_launch"] * ca["launches"]
+            tot_s = (sa["avg_launch_us"] * sa["launches"] + ca["avg_launch_us"] * ca["launches"]) * 1e-6
+            res["roofline_decoder_attention_combined"] = {"bound": "hbm", "achieved": tot_b / tot_s / 1e9, "peak": PEAK_HBM_GBS,
+                                                          "unit": "GB/s", "frac": tot_b / tot_s / 1e9 / PEAK_HBM_GBS}
+    if main_line and world == 1 and not graph:
+        with torch.no_grad():
+            one_step(model, images, 0, n_total, seed=1, graph=True)
+            tg, _, _ = timed_steps(model, images, 0, n_local, n_total, steps, barrier, graph=True)
+        res["hipgraph_replay"] = {"value": n_total * steps / tg, "unit": "captions/s", "ms_per_step": tg / steps * 1e3}
+    if world == 1 and not args.quick:
+        with torch.no_grad():
+            res["host_inclusive"] = host_inclusive(model, n_local, max(3, steps // 2))
+    if rank == 0 and with_cpu:
+        # the parity gate is the fp32 path: bit-exact greedy ids vs the CPU reference path -- timed here too
+        if dtype == "f32":
+            m32 = model
+        else:
+            del model
+            torch.cuda.empty_cache()
+            m32 = build_model(workload, dev, "f32")[0]
+        res["greedy_token_match_vs_cpu_ref"] = greedy_match(workload, m32, sd, hp, 2)
+        if dtype != "f32":
+            with torch.no_grad():
+                one_step(m32, images, 0, n_total, seed=0)
+                t32, _, _ = timed_steps(m32, images, 0, n_local, n_total, 3, barrier)
+            res["fp32_parity_path"] = {"value": n_total * 3 / t32, "unit": "captions/s", "ms_per_step": t32 / 3 * 1e3, "steps": 3,
+                                       "note": "same step, fp32 storage + exact-fp32 arithmetic: the path whose greedy ids are bit-exact"}
+            del m32
+            torch.cuda.empty_cache()
+            model = build_model(workload, dev, dtype)[0]
+            res[f"greedy_token_match_{dtype}_vs_cpu_ref"] = greedy_match(workload, model, sd, hp, 2)
+        res["cpu_baseline"] = cpu_baseline(workload, sd, hp)
+        res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+    torch.cuda.empty_cache()
+    return res
+
+
+def run_c5(args, rank, world, dev, dtype):
+    """BASELINE config 5: the full 300-template sweep (ImageLabelEncoder + CaptioningTransformer, beam 10), templates
+    sharded 38/38/38/38/37/37/37/37 over 8 ranks (all 300 on one), uneven shards gathered with one padded all_gather."""
+    import numpy as np
+    import torch.distributed as dist
+    from deephumor_amd.dist import gather_captions, shard_range
+    from deephumor_amd.synth import synth_images
+    model, sd, hp = build_model("c5", dev, dtype)
+    n_total = 300
+    lo, hi = shard_range(n_total, rank, world)
+    images = synth_images(hi - lo, seed=2, first=lo).to(dev)
+    g = np.random.Generator(np.random.Philox(key=[1, 0]))
+    labels = torch.from_numpy(g.integers(6, V_WORD, size=(n_total, 3)).astype(np.int64))[lo:hi].to(dev)
+
+    def sweep(seed):
+        toks, lens = model.generate_batch(images, labels, max_len=MAX_LEN, beam_size=10, top_k=TOP_K, temperature=TEMP,
+                                          seed=seed, img0=lo)
+        return gather_captions(toks, lens, n_total)
+
+    with torch.no_grad():
+        sweep(0)
+        reps = max(1, args.steps)
+        dt, (toks, lens) = timed_region(lambda s: sweep(100 + s), reps, world, dev)
+    return {"workload": workload_name("c5"), "value": n_total * reps / dt, "unit": "captions/s", "sweeps": reps,
+            "ms_per_sweep": dt / reps * 1e3, "templates": n_total, "gathered": int(toks.shape[0]), "dtype": dtype,
+            "mean_caption_len": float(lens.float().mean())}
 
 
 def run_score(args, rank, world, dev, dtype, kind):
@@ -100,317 +416,97 @@ def run_score(args, rank, world, dev, dtype, kind):
         return score_sharded(lambda lo, hi: score_captions(model, images, tpl[lo:hi], caps[lo:hi], lengths_d[lo:hi], batch_size=args.score_batch), n_total)
 
     pp = run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
     reps = max(1, args.steps)
-    for _ in range(reps):
-        pp = run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt, pp = timed_region(lambda s: run(), reps, world, dev)
     return {"workload": f"teacher-forced scoring, {kind_of(kind)}, 300 templates x 30 captions x 32 tokens, V={V_WORD}",
             "value": n_total * reps / dt, "unit": "captions scored/s", "passes": reps, "ms_per_pass": dt / reps * 1e3,
             "captions": n_total, "mean_perplexity": float(pp.float().mean()), "dtype": dtype}
 
 
-def run_c5(args, rank, world, dev, dtype):
-    """BASELINE config 5: the full 300-template sweep (ImageLabelEncoder + CaptioningTransformer, beam 10), templates
-    sharded 38/38/38/38/37/37/37/37 over 8 ranks (all 300 on one), uneven shards gathered with one padded all_gather."""
-    import torch.distributed as dist
-    from deephumor_amd.dist import shard_range
-    from deephumor_amd.synth import synth_images
-    import numpy as np
-    model, sd, hp = build_model("c5", dev, dtype)
-    n_total = 300
-    lo, hi = shard_range(n_total, rank, world)
-    images = synth_images(hi - lo, seed=2, first=lo).to(dev)
-    g = np.random.Generator(np.random.Philox(key=[1, 0]))
-    labels = torch.from_numpy(g.integers(6, V_WORD, size=(n_total, 3)).astype(np.int64))[lo:hi].to(dev)
-    with torch.no_grad():
-        one_step(model, images, lo, n_total, 0, labels=labels, beam=10)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        reps = max(1, args.steps)
-        for s in range(reps):
-            toks, lens = one_step(model, images, lo, n_total, 100 + s, labels=labels, beam=10)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-    t = torch.tensor([dt], device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    return {"workload": "C5 ImageLabelEncoder + CaptioningTransformer (spatial feats), beam=10, 300-template sweep",
-            "value": n_total * reps / dt, "unit": "captions/s", "sweeps": reps, "ms_per_sweep": dt / reps * 1e3,
-            "templates": n_total, "gathered": int(toks.shape[0]), "dtype": dtype}
-
-
-def cpu_baseline(workload, sd, hp, n_sample):
-    """The oracle (CPU restatement of the reference: per-image generate, full re-forward per token,
-    fp32, torch CPU threads) timed on this box's host cores on a bounded sample of the same workload."""
-    from oracle import ref_path as R
-    from deephumor_amd.synth import synth_images
-    imgs = synth_images(n_sample, seed=0)
-    torch.manual_seed(0)
-    R.model_generate(kind_of(workload), sd, hp, imgs[:1], max_len=4, beam_size=BEAM, top_k=TOP_K)   # warm-up
-    t0 = time.perf_counter()
-    n_tok = 0
-    for i in range(n_sample):
-        ids = R.model_generate(kind_of(workload), sd, hp, imgs[i:i + 1], max_len=MAX_LEN, temperature=TEMP,
-                               beam_size=BEAM, top_k=TOP_K)
-        n_tok += ids.numel()
-    dt = time.perf_counter() - t0
-    return {"value": n_sample / dt, "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"{n_sample} images, {kind_of(workload)} V={V_WORD}, beam={BEAM}, top_k={TOP_K}, "
-                      f"max_len={MAX_LEN}, per-image generate with full re-forward per token (reference algorithm), "
-                      f"{dt:.1f} s, mean length {n_tok / n_sample:.1f}"}
-
-
-def greedy_match(workload, model, sd, hp, n_check):
-    """Greedy decode (beam_size=1, top_k=1) token match of the HIP path vs the CPU oracle."""
-    from oracle import ref_path as R
-    from deephumor_amd.synth import synth_images
-    imgs = synth_images(n_check, seed=0)
-    with torch.no_grad():
-        toks, lens = model.generate_batch(imgs.to(next(model.parameters()).device), max_len=MAX_LEN, beam_size=1, top_k=1)
-    same = total = 0
-    for i in range(n_check):
-        want = R.model_generate(kind_of(workload), sd, hp, imgs[i:i + 1], max_len=MAX_LEN, beam_size=1, top_k=1).reshape(-1).tolist()
-        got = toks[i, :int(lens[i])].cpu().tolist()
-        total += max(len(want), len(got))
-        same += sum(int(a == b) for a, b in zip(want, got))
-    return same / max(total, 1)
-
-
-def roofline_from(summary, prefer=None, dtype="bf16"):
-    """Picks the dominant kernel (by measured time) -- or ``prefer`` -- and prices it against its roofline."""
-    if not summary:
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
         return None
-    key = prefer if prefer in summary else max(summary, key=lambda k: summary[k]["ms"])
-    d = summary[key]
-    sec = d["ms"] / 1e3 / max(d["calls"], 1)
-    if key.startswith("dh_attn"):
-        ach = d["bytes"] / d["calls"] / sec / 1e9
-        return {"kernel": key, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
-                "algorithmic_bytes_per_launch": d["bytes"] / d["calls"]}
-    peak = PEAK_F32_TFLOPS if (dtype == "f32" or key.startswith("dh_stem")) else PEAK_BF16_TFLOPS
-    # the roofline that bounds these launches: algorithmic intensity (flop per algorithmic byte) against the
-    # ridge peak_flops / peak_bytes -- e.g. the 1x1 convolutions with K <= 256 are HBM-bound, not MFMA-bound
-    intensity = d["flops"] / d["bytes"] if d["bytes"] else float("inf")
-    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
-    if intensity < ridge:
-        ach = d["bytes"] / d["calls"] / sec / 1e9
-        return {"kernel": key, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
-                "algorithmic_bytes_per_launch": d["bytes"] / d["calls"],
-                "algorithmic_flops_per_launch": d["flops"] / d["calls"], "flop_per_byte": intensity,
-                "tflops": d["flops"] / d["calls"] / sec / 1e12}
-    ach = d["flops"] / d["calls"] / sec / 1e12
-    return {"kernel": key, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-            "frac": ach / peak, "traffic": None, "avg_launch_us": sec * 1e6, "launches": d["calls"],
-            "algorithmic_flops_per_launch": d["flops"] / d["calls"], "flop_per_byte": intensity}
-
-
-def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtype="bf16", main_line=True):
-    import torch.distributed as dist
-    from deephumor_amd import hip
-    from deephumor_amd.synth import synth_images
-    model, sd, hp = build_model(workload, dev, dtype)
-    n_local, n_total = args.batch, args.batch * world
-    images = synth_images(n_local, seed=0, first=rank * n_local).to(dev)     # resident in HBM before timing
-    torch.cuda.synchronize()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    lens = None
-    with torch.no_grad():
-        # untimed: a cold pass (code-object loading, allocator growth), then the per-kernel breakdown pass
-        # (HIP events around every launch made through the library)
-        one_step(model, images, rank * n_local, n_total, seed=0)
-        with hip.profile() as prof0:
-            _, lens = one_step(model, images, rank * n_local, n_total, seed=0, eager=True)
-        breakdown = prof0.summary()
-        dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])
-        # watch the dominant "entry[tag]" only (plus the decoder self-attention, the north star's roofline
-        # target, when this workload is the contract line): a few dozen event pairs per step
-        watch = {dominant} | ({"dh_attn_self_decode"} if (workload == "c3" and main_line) else set())
-        for w in range(1, warmup):
-            _, lens = one_step(model, images, rank * n_local, n_total, seed=w)
-        barrier()
-        t0 = time.perf_counter()
-        # timed region: HIP events (on the launch stream) only around the dominant entry point and the
-        # attention kernels, so the roofline line is measured over exactly the steps `value` is
-        if main_line and not GRAPH:
-            with hip.profile(watch=watch, stride=4) as prof:     # every 4th launch: <0.3 ms of events per step
-                for s in range(steps):
-                    _, lens = one_step(model, images, rank * n_local, n_total, seed=100 + s)
-                torch.cuda.synchronize()
-                barrier()
-                dt = time.perf_counter() - t0
-            summary = prof.summary()
-        else:
-            # secondary workload: clean timed steps for its captions/s, then one separately profiled step for
-            # its rooflines (so ~600 event pairs per step do not perturb the number)
-            for s in range(steps):
-                _, lens = one_step(model, images, rank * n_local, n_total, seed=100 + s)
-            torch.cuda.synchronize()
-            barrier()
-            dt = time.perf_counter() - t0
-            with hip.profile(watch={dominant, "dh_attn_self_decode", "dh_attn_cross_decode"}) as prof:
-                one_step(model, images, rank * n_local, n_total, seed=999, eager=True)
-            summary = prof.summary()
-    t = torch.tensor([dt], device=dev)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-    graph_res = None
-    if main_line and not GRAPH and world == 1:
-        # the same K steps replayed from a captured hipGraph (reported next to the contract number, which is eager
-        # because the roofline events need real launches)
-        with torch.no_grad():
-            kw = dict(max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP)
-            model.generate_batch_graphed(images, seed=1, **kw)
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            for s in range(steps):
-                model.generate_batch_graphed(images, seed=100 + s, **kw)
-            torch.cuda.synchronize()
-            tg = time.perf_counter() - tg
-        graph_res = {"value": n_total * steps / tg, "unit": "captions/s", "ms_per_step": tg / steps * 1e3}
-    res = {"value": n_total * steps / dt, "ms_per_step": dt / steps * 1e3, "hipgraph_replay": graph_res,
-           "mean_caption_len": float(lens.float().mean()) if lens is not None else None}
-    total_ms = sum(d["ms"] for d in breakdown.values())
-    res["kernel_breakdown_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(breakdown.items(), key=lambda kv: -kv[1]["ms"])}
-    res["kernel_ms_sum"] = round(total_ms, 3)
-    res["roofline"] = roofline_from(summary, prefer=dominant, dtype=dtype)
-    if workload == "c3":
-        res["roofline_self_attention"] = roofline_from(summary, prefer="dh_attn_self_decode", dtype=dtype)
-        res["roofline_cross_attention"] = roofline_from(summary, prefer="dh_attn_cross_decode", dtype=dtype)
-    try:     # HBM traffic of those kernels from the committed PMC passes (rocprofv3 cannot run inside this process)
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1", "pmc_hbm_traffic.json")))
-        for key in ("roofline", "roofline_self_attention", "roofline_cross_attention"):
-            rl = res.get(key)
-            ent = pmc.get(workload, {}).get(rl["kernel"]) if (rl and dtype == "bf16") else None
-            if ent:
-                rl["traffic"] = ent["traffic_bytes_per_launch"]
-                rl["traffic_source"] = "profiles/r1/pmc_hbm_traffic.json (" + ent["note"] + ")"
-    except (OSError, ValueError, KeyError, TypeError):
-        pass
-    if rank == 0 and with_cpu:
-        # the parity gate is the fp32 path: bit-exact greedy ids vs the CPU reference path
-        m32 = model if dtype == "f32" else build_model(workload, dev, "f32")[0]
-        res["greedy_token_match_vs_cpu_ref"] = greedy_match(workload, m32, sd, hp, 2)
-        if dtype != "f32":
-            res["greedy_token_match_bf16_vs_cpu_ref"] = greedy_match(workload, model, sd, hp, 2)
-            del m32
-        res["cpu_baseline"] = cpu_baseline(workload, sd, hp, args.cpu_sample if workload == "c2" else max(2, args.cpu_sample // 4))
-        res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
-    del model
-    torch.cuda.empty_cache()
-    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE configs: 256)")
     ap.add_argument("--workload", choices=["c2", "c3", "both", "c5", "score-c2", "score-c3"], default="both")
-    ap.add_argument("--cpu-sample", type=int, default=8, help="images for the CPU baseline leg (rank 0, N=1 only)")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / fp32 parity legs")
+    ap.add_argument("--quick", action="store_true", help="only the timed steps and the roofline (no host-inclusive / CPU legs)")
     ap.add_argument("--score-batch", type=int, default=1024, help="captions per teacher-forced batch (score-* workloads)")
-    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (eager by default: "
-                    "the in-library event profiler of the roofline line needs real launches)")
-    ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default="bf16",
-                    help="storage/MFMA operand type of the measured path (BASELINE configs C2/C3: bf16)")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured hipGraph (the in-library event "
+                    "profiler of the roofline line needs real launches, so the roofline then comes from the instrumented pass)")
+    ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default=None,
+                    help="storage/MFMA operand type of the measured path (BASELINE configs C2-C4: bf16, C5: fp16)")
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = "f16" if args.workload == "c5" else "bf16"
 
-    global GRAPH
-    GRAPH = args.graph
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU); see scripts/run_c4.sh")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    n_ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        n_ranks_seen = dist.get_world_size()
+
+    def finish(line):
+        line["n_ranks_seen"] = n_ranks_seen          # what the process group itself reports (RCCL saw N ranks)
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            dist.destroy_process_group()
 
     if args.workload.startswith("score-"):
         res = run_score(args, rank, world, dev, args.dtype, args.workload.split("-")[1])
-        if rank == 0:
-            print(json.dumps(dict(res, metric="captions scored/sec (teacher-forced perplexity, 32 tokens)", n_gpus=world,
-                                  higher_is_better=True, scaling="strong", vs_baseline=None, data="synthetic")))
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish(dict(res, metric="captions scored/sec (teacher-forced perplexity, 32 tokens)", n_gpus=world,
+                           higher_is_better=True, scaling="strong", vs_baseline=None, data="synthetic"))
     if args.workload == "c5":
         res = run_c5(args, rank, world, dev, args.dtype)
-        if rank == 0:
-            print(json.dumps(dict(res, metric="captions/sec (224x224, 32-tok, beam=10, 300-template sweep)", n_gpus=world,
-                                  higher_is_better=True, scaling="strong", vs_baseline=None, data="synthetic")))
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        return finish(dict(res, metric="captions/sec (224x224, 32-tok, beam=10, 300-template sweep)", n_gpus=world,
+                           higher_is_better=True, scaling="strong", vs_baseline=None, data="synthetic",
+                           config={"workload": workload_name("c5"), "beam_size": 10, "top_k": TOP_K, "vocab": V_WORD,
+                                   "parallelism": f"templates sharded x{world} (uneven shards), one padded all_gather of ids"}))
     main_wl = "c2" if args.workload in ("c2", "both") else "c3"
-    with_cpu = (world == 1) and not args.no_cpu
+    with_cpu = (world == 1) and not args.no_cpu and not args.quick
     res = run_workload(main_wl, args, rank, world, dev, args.steps, args.warmup, with_cpu, args.dtype)
     line = {
         "metric": "captions/sec (224x224, 32-tok, beam=5)", "value": res["value"], "unit": "captions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": ("C2 CaptioningLSTM + ImageEncoder (emb 256, hidden 512, 2 layers)" if main_wl == "c2" else
-                                "C3 CaptioningTransformer 6-layer/8-head (spatial feats)"),
+        "config": {"workload": workload_name(main_wl),
                    "images_per_gpu": args.batch, "global_batch": args.batch * world, "vocab": V_WORD,
                    "max_len": MAX_LEN, "beam_size": BEAM, "top_k": TOP_K, "temperature": TEMP,
                    "parallelism": f"image-sharded x{world}, one all_gather of token ids per batch",
-                   "weights": "synthetic name-keyed (seed 1234)", "encoder_in_timed_region": True},
+                   "weights": "synthetic name-keyed (seed 1234)", "encoder_in_timed_region": True,
+                   "inputs": "device-resident fp32 NCHW images (host-inclusive rates under host_inclusive)",
+                   "hipgraph": bool(args.graph), "commit": git_head()},
         "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"),
-        "greedy_token_match_vs_cpu_ref": res.get("greedy_token_match_vs_cpu_ref"),
-        "greedy_token_match_bf16_vs_cpu_ref": res.get("greedy_token_match_bf16_vs_cpu_ref"),
-        "speedup_vs_cpu": res.get("speedup_vs_cpu"), "mean_caption_len": res["mean_caption_len"],
-        "hipgraph_replay": res.get("hipgraph_replay"),
-        "kernel_breakdown_ms_per_step": res["kernel_breakdown_ms_per_step"],
     }
-    if main_wl == "c3":
-        line["roofline_self_attention"] = res.get("roofline_self_attention")
-        line["roofline_cross_attention"] = res.get("roofline_cross_attention")
+    for k in ("greedy_token_match_vs_cpu_ref", f"greedy_token_match_{args.dtype}_vs_cpu_ref", "speedup_vs_cpu", "mean_caption_len",
+              "fp32_parity_path", "host_inclusive", "hipgraph_replay", "kernel_breakdown_ms_per_step", "kernel_breakdown_note",
+              "encoder_layers", "roofline_self_attention", "roofline_cross_attention", "roofline_decoder_attention_combined"):
+        if k in res:
+            line[k] = res[k]
     if args.workload == "both":
-        r3 = run_workload("c3", args, rank, world, dev, max(2, args.steps // 2), 1, with_cpu, args.dtype, main_line=False)
-        line["c3"] = {"workload": "C3 CaptioningTransformer 6-layer/8-head (spatial feats), same batch/beam settings",
-                      "value": r3["value"], "unit": "captions/s", "ms_per_step": r3["ms_per_step"],
-                      "roofline": r3["roofline"], "roofline_self_attention": r3.get("roofline_self_attention"),
-                      "roofline_cross_attention": r3.get("roofline_cross_attention"),
-                      "cpu_baseline": r3.get("cpu_baseline"), "speedup_vs_cpu": r3.get("speedup_vs_cpu"),
-                      "greedy_token_match_vs_cpu_ref": r3.get("greedy_token_match_vs_cpu_ref"),
-                      "kernel_breakdown_ms_per_step": r3["kernel_breakdown_ms_per_step"]}
-    if rank == 0:
-        print(json.dumps(line))
-    if world > 1:
-        import torch.distributed as dist
-        dist.barrier()
-        dist.destroy_process_group()
+        r3 = run_workload("c3", args, rank, world, dev, max(3, args.steps // 2), 1, with_cpu, args.dtype, main_line=False)
+        r3.pop("encoder_layers", None)
+        line["c3"] = dict(r3, workload=workload_name("c3") + ", same batch/beam settings", unit="captions/s")
+    finish(line)
 
 
 if __name__ == "__main__":

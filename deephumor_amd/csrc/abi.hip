@@ -1,4 +1,5 @@
 #include <string.h>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <map>
@@ -29,6 +30,8 @@ int g_stride = 1, g_seen = 0;          // record every g_stride-th matching laun
 std::vector<Rec> g_recs;
 std::vector<std::pair<std::string, Agg>> g_out;
 thread_local const char* g_tag = nullptr;
+thread_local int g_dims[3] = {0, 0, 0};
+std::mutex g_mu;                            // the recorder's state is shared by every host thread / stream that launches
 
 int take_event() {
     if (g_used == (int)g_pool.size()) {
@@ -41,14 +44,22 @@ int take_event() {
 }  // namespace
 
 void dh_prof_set_tag(const char* tag) { g_tag = tag; }
+void dh_prof_set_dims(int m, int n, int k) { g_dims[0] = m; g_dims[1] = n; g_dims[2] = k; }
 
 DhProfScope::DhProfScope(const char* name, double flops, double bytes, void* stream) : s((hipStream_t)stream), rec(-1) {
     const char* tag = g_tag;
+    const int dm = g_dims[0], dn = g_dims[1], dk = g_dims[2];
     g_tag = nullptr;
+    g_dims[0] = g_dims[1] = g_dims[2] = 0;
+    if (!g_on) return;
+    std::lock_guard<std::mutex> lock(g_mu);
     if (!g_on) return;
     std::string key(name);
     if (tag) { key += "["; key += tag; key += "]"; }
-    if (!g_filter.empty() && g_filter.find("," + key + ",") == std::string::npos &&
+    const std::string base = key;
+    if (dm > 0) { key += "{" + std::to_string(dm) + "x" + std::to_string(dn) + "x" + std::to_string(dk) + "}"; }
+    // a filter entry may name the full key ("dh_linear[vocab]{1280x36541x512}"), the entry + role, or the bare entry point
+    if (!g_filter.empty() && g_filter.find("," + key + ",") == std::string::npos && g_filter.find("," + base + ",") == std::string::npos &&
         g_filter.find(std::string(",") + name + ",") == std::string::npos) return;
     if ((g_seen++ % g_stride) != 0) return;
     const int e0 = take_event(), e1 = take_event();
@@ -59,12 +70,15 @@ DhProfScope::DhProfScope(const char* name, double flops, double bytes, void* str
 }
 
 DhProfScope::~DhProfScope() {
-    if (rec >= 0) hipEventRecord(g_pool[g_recs[rec].e1], s);
+    if (rec < 0) return;
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (rec < (int)g_recs.size()) hipEventRecord(g_pool[g_recs[rec].e1], s);
 }
 
 extern "C" void dh_prof_tag(const char* tag) { g_tag = tag; }
 
 extern "C" int dh_prof_begin(const char* filter) {
+    std::lock_guard<std::mutex> lock(g_mu);
     g_filter.clear();
     if (filter && filter[0]) { g_filter = ","; g_filter += filter; g_filter += ","; }
     g_recs.clear();
@@ -82,6 +96,7 @@ extern "C" int dh_prof_set_stride(int n) {
 }
 
 extern "C" int dh_prof_end(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
     g_on = false;
     std::map<std::string, Agg> agg;
     std::vector<std::string> order;

@@ -199,6 +199,7 @@ extern "C" int dh_conv2d_bn_act(const void* x, const void* w, const float* scale
     p.P = N * p.Ho * p.Wo;
     hipStream_t s = (hipStream_t)stream;
     dh_prof_set_tag(KH == 1 ? "1x1" : KH == 3 ? "3x3" : "7x7");
+    dh_prof_set_dims(p.P, Cout, p.K);
     DhProfScope prof("dh_conv2d_bn_act", 2.0 * p.P * Cout * p.K,
                      4.0 * ((double)N * Cin * H * W + (double)Cout * p.K + (double)p.P * Cout * (residual ? 2 : 1)), stream);
     const bool big = Cout >= 128;

@@ -137,6 +137,7 @@ extern "C" int dh_linear(const void* A, int lda, const void* W, int ldw, const f
     DH_REQUIRE(!residual || ldres >= N);
     hipStream_t s = (hipStream_t)stream;
     const double esz = dtype == DH_F32 ? 4.0 : 2.0;
+    dh_prof_set_dims(M, N, K);
     DhProfScope prof("dh_linear", 2.0 * M * N * K, esz * ((double)M * K + (double)N * K) + (DH_IS_16BIT(dtype) ? 2.0 : 4.0) * M * N, stream);
     if (dtype == DH_BF16 || dtype == DH_BF16_OUT_F32 || dtype == DH_F16 || dtype == DH_F16_OUT_F32)
         return dh_linear_bf16_impl(A, lda, W, ldw, bias, scale, shift, residual, ldres, C, ldc, M, N, K, relu,

@@ -564,7 +564,13 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
         // 8 waves (4 x 2, each 32 x 64) on the 128 x 128 tile, 2 workgroups per CU = 4 waves per SIMD: measured
         // 510 TF vs 450 TF with 4 waves per workgroup and 300 TF with one 4-wave workgroup and a deeper ring --
         // the MFMA pipe needs co-resident waves to cover each wave's LDS-read/barrier gaps
-        hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
+        static const int ns128 = getenv("DH_GEMM128_NS") ? atoi(getenv("DH_GEMM128_NS")) : 2;
+        if (ns128 == 3)
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 3, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
+        else if (ns128 == 4)
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 4, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
+        else
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
         return;
     }
     if (p.N <= 64 && p.M >= 256 * 512 && !lnx) {
@@ -650,6 +656,7 @@ extern "C" int dh_linear_ln(const void* A, int lda, const void* W, int ldw, cons
     p.a_stats = (const float2*)ln->a_stats; p.a_nt = ln->a_tiles; p.a_eps = ln->a_eps; p.a_colsum = ln->a_colsum;
     p.r_stats = (const float2*)ln->r_stats; p.r_nt = ln->r_tiles; p.r_eps = ln->r_eps; p.r_gamma = ln->r_gamma; p.r_beta = ln->r_beta;
     p.o_stats = (float2*)ln->o_stats;
+    dh_prof_set_dims(M, N, K);
     DhProfScope prof("dh_linear", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)), stream);
     DH_DISPATCH_16(dtype, launch_gemm_bf16<T, false>(p, (hipStream_t)stream));
     DH_LAUNCH_CHECK();
@@ -683,6 +690,7 @@ extern "C" int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* 
     hipStream_t s = (hipStream_t)stream;
     static const char* const tags[] = {"?", "1x1", "2x2", "3x3", "4x4", "5x5", "6x6", "7x7"};
     dh_prof_set_tag(tags[KS < 8 ? KS : 0]);
+    dh_prof_set_dims(p.M, Cout, p.K);
     DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * p.M * Cout * p.K,
                      2.0 * ((double)N * H * W * Cin + (double)Cout * p.K + (double)p.M * Cout * (residual ? 2 : 1)), stream);
     DH_DISPATCH_16(dtype, {
@@ -969,6 +977,7 @@ extern "C" int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w,
     p.C = out; p.ldc = Cout; p.M = N * Ho * Wo; p.N = Cout; p.K = C1 + C2; p.relu = relu;
     p.A2 = (const uint16_t*)x; p.K1 = C1; p.a2_H = H; p.a2_W = W; p.a2_C = C2; p.a2_stride = stride; p.a2_Ho = Ho; p.a2_Wo = Wo;
     dh_prof_set_tag("1x1");
+    dh_prof_set_dims(p.M, Cout, p.K);
     DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * p.M * Cout * p.K,
                      2.0 * ((double)p.M * C1 + (double)p.M * C2 + (double)Cout * p.K + (double)p.M * Cout), stream);
     DH_DISPATCH_16(dtype, launch_gemm_bf16<T, false>(p, (hipStream_t)stream));
@@ -984,6 +993,7 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
     DH_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
     dh_prof_set_tag("vocab");
+    dh_prof_set_dims(M, V, K);
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);
     if ((ldl % 4) == 0 && ((uintptr_t)logits % 16) == 0 && K >= 128 && (K % 64) == 0) {
         VocabParams v{};
@@ -1003,8 +1013,17 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         //  4-slab ring, the two wave halves one barrier apart -- 85 us with LDS-DMA, 170 us register-staged; with 64-byte
         //  row segments every 128-byte line is fetched twice.  scratch/dma_probe shows the LDS-DMA path itself sustains
         //  110-125 GB/s per CU against the ~46 GB/s this kernel draws: DESIGN.md section 9.)
-        DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0,
-                                                 (hipStream_t)stream, v));
+        static const int vns = getenv("DH_VOCAB_NS") ? atoi(getenv("DH_VOCAB_NS")) : 2;
+        if (vns == 3) {
+            DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 3, 128, 128, 4, 8>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0,
+                                                     (hipStream_t)stream, v));
+        } else if (vns == 4) {
+            DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 4, 128, 128, 4, 8>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0,
+                                                     (hipStream_t)stream, v));
+        } else {
+            DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0,
+                                                     (hipStream_t)stream, v));
+        }
         DH_LAUNCH_CHECK();
     }
     GemmBf16Params p{};
@@ -1049,6 +1068,7 @@ extern "C" int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, 
     DH_REQUIRE(gm_ld >= 2 * dh_cdiv(V, 128) && (K % 64) == 0 && K >= 128 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
     dh_prof_set_tag("logprob");
+    dh_prof_set_dims(M, V, K);
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K), stream);
     VocabParams v{};
     v.A = (const uint16_t*)A; v.lda = lda; v.W = (const uint16_t*)W; v.ldw = ldw; v.bias = bias;

@@ -11,3 +11,4 @@ struct DhProfScope {
     ~DhProfScope();
 };
 void dh_prof_set_tag(const char* tag);       // role of the next launch (qkv / proj / ffn / vocab / gates ...)
+void dh_prof_set_dims(int m, int n, int k);  // GEMM shape of the next launch: the profiler keys it "entry[tag]{MxNxK}"

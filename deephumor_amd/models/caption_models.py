@@ -33,6 +33,18 @@ class _CaptioningBase(nn.Module):
     def _one(toks, lens):
         return toks[0, :int(lens[0])].squeeze()
 
+    # ``generate_batch`` = ``decode(encode(...))``.  The two halves are exposed separately so that a serving loop can run
+    # the encoder of batch i+1 on one HIP stream while batch i decodes on another (deephumor_amd/pipeline.py): the decode
+    # positions are chains of small latency-bound launches that leave most CUs idle, the encoder is throughput-bound.
+    def encode(self, *inputs):
+        """Image (+ label) encoder -> tuple of feature tensors consumed by ``decode``."""
+        raise NotImplementedError
+
+    def decode(self, encoded, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
+        """Batched beam-search decoding of ``encode``'s output -> ``(tokens [N, max_len], lengths [N])``."""
+        return self.decoder.generate_batch(*encoded, caption=caption, max_len=max_len, temperature=temperature,
+                                           beam_size=beam_size, top_k=top_k, eos_index=eos_index, **kw)
+
     def _plan_signature(self):
         """Identity of everything a captured graph holds raw pointers to or derives constants from: storage pointer and
         in-place version counter of every parameter and buffer of the model."""
@@ -110,11 +122,12 @@ class CaptioningLSTM(_CaptioningBase):
     def forward(self, images, captions, lengths=None):
         return self.decoder(self.encoder(images), captions, lengths)
 
+    def encode(self, images):
+        return (self.encoder(images),)
+
     def generate_batch(self, images, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, **kw):
-        return self.decoder.generate_batch(self.encoder(images), caption=caption, max_len=max_len,
-                                           temperature=temperature, beam_size=beam_size, top_k=top_k,
-                                           eos_index=eos_index, **kw)
+        return self.decode(self.encode(images), caption, max_len, temperature, beam_size, top_k, eos_index, **kw)
 
     def generate(self, image, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
@@ -138,11 +151,12 @@ class CaptioningLSTMWithLabels(_CaptioningBase):
     def forward(self, images, captions, lengths, labels):
         return self.decoder(self.encoder(images=images, labels=labels), captions, lengths)
 
+    def encode(self, images, labels):
+        return (self.encoder(images, labels),)
+
     def generate_batch(self, images, labels, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, **kw):
-        return self.decoder.generate_batch(self.encoder(images, labels), caption=caption, max_len=max_len,
-                                           temperature=temperature, beam_size=beam_size, top_k=top_k,
-                                           eos_index=eos_index, **kw)
+        return self.decode(self.encode(images, labels), caption, max_len, temperature, beam_size, top_k, eos_index, **kw)
 
     def generate(self, image, label, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
@@ -172,11 +186,12 @@ class CaptioningTransformerBase(_CaptioningBase, _TransformerHP):
     def forward(self, images, captions, lengths=None):
         return self.decoder(captions, start_emb=self.encoder(images))
 
+    def encode(self, images):
+        return (self.encoder(images),)
+
     def generate_batch(self, images, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, **kw):
-        return self.decoder.generate_batch(self.encoder(images), caption=caption, max_len=max_len,
-                                           temperature=temperature, beam_size=beam_size, top_k=top_k,
-                                           eos_index=eos_index, **kw)
+        return self.decode(self.encode(images), caption, max_len, temperature, beam_size, top_k, eos_index, **kw)
 
     def generate(self, image, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
@@ -200,12 +215,12 @@ class CaptioningTransformer(_CaptioningBase, _TransformerHP):
         image_emb, image_spatial_emb = self.encoder(images)
         return self.decoder(captions, enc_out=image_spatial_emb, start_emb=image_emb)
 
+    def encode(self, images):
+        return tuple(self.encoder(images))                  # (image_emb, image_spatial_emb)
+
     def generate_batch(self, images, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, **kw):
-        image_emb, image_spatial_emb = self.encoder(images)
-        return self.decoder.generate_batch(image_emb, image_spatial_emb, caption=caption, max_len=max_len,
-                                           temperature=temperature, beam_size=beam_size, top_k=top_k,
-                                           eos_index=eos_index, **kw)
+        return self.decode(self.encode(images), caption, max_len, temperature, beam_size, top_k, eos_index, **kw)
 
     def generate(self, image, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
@@ -229,12 +244,12 @@ class CaptioningTransformerWithLabels(_CaptioningBase, _TransformerHP):
         start, spatial = self.encoder(images, labels)
         return self.decoder(captions, enc_out=spatial, start_emb=start)
 
+    def encode(self, images, labels):
+        return tuple(self.encoder(images, labels))          # (start_emb, image_spatial_emb)
+
     def generate_batch(self, images, labels, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, **kw):
-        start, spatial = self.encoder(images, labels)
-        return self.decoder.generate_batch(start, spatial, caption=caption, max_len=max_len,
-                                           temperature=temperature, beam_size=beam_size, top_k=top_k,
-                                           eos_index=eos_index, **kw)
+        return self.decode(self.encode(images, labels), caption, max_len, temperature, beam_size, top_k, eos_index, **kw)
 
     def generate(self, image, label, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):

@@ -1,0 +1,103 @@
+"""Software pipeline over consecutive image batches: host images in, host token ids out.
+
+The reference's ``generate`` is strictly one image at a time (caption_models.py:48-74): image -> encoder -> decoder loop ->
+ids.  Batched over images this hot path has two very different halves on an MI355X: the ResNet-50 encoder is a
+throughput-bound stack of large GEMM-shaped launches, the decode positions are chains of small latency-bound launches
+that leave most of the 256 CUs idle.  ``CaptionPipeline`` therefore runs, on separate HIP streams,
+
+    copy stream  : pinned host images of batch i+1  -> HBM           (async H2D, double-buffered)
+    encode stream: encoder of batch i+1                               (waits for its copy)
+    decode stream: beam-search decode of batch i, ids -> pinned host  (waits for its encoder; async D2H)
+
+so that the copy and the encoder of the next batch fill the CUs / the PCIe link while the current batch decodes.
+Captions are the ones ``generate_batch`` gives for the same ``seed`` / ``img0`` (the streams only reorder independent
+work).  Nothing here computes: every operation is a kernel of libdeephumor_hip.so or a copy.
+"""
+import torch
+
+__all__ = ["CaptionPipeline"]
+
+
+class CaptionPipeline:
+    def __init__(self, model, overlap=True, **gen_kw):
+        self.model, self.gen_kw, self.overlap = model, gen_kw, overlap
+        self.dev = next(model.parameters()).device
+        if overlap:
+            self.copy_s, self.enc_s, self.dec_s = (torch.cuda.Stream(device=self.dev) for _ in range(3))
+        else:
+            self.copy_s = self.enc_s = self.dec_s = torch.cuda.current_stream(self.dev)
+        self._dev_in = {}            # (slot, shape, dtype) -> device staging tensor (double-buffered)
+        self._host_out = {}
+        self._slot = 0
+
+    # -- stages ------------------------------------------------------------------------------------------------------
+    def _stage(self, host_inputs):
+        """H2D of one batch (tensors in pinned host memory copy asynchronously) on the copy stream; device-resident
+        tensors pass through."""
+        slot, out = self._slot, []
+        self._slot ^= 1
+        with torch.cuda.stream(self.copy_s):
+            for j, t in enumerate(host_inputs):
+                if t.is_cuda:
+                    out.append(t)
+                    continue
+                key = (slot, j, tuple(t.shape), t.dtype)
+                buf = self._dev_in.get(key)
+                if buf is None:
+                    buf = self._dev_in[key] = torch.empty(t.shape, dtype=t.dtype, device=self.dev)
+                buf.copy_(t, non_blocking=True)
+                out.append(buf)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_s)
+        return out, ev
+
+    def _encode(self, staged, ev):
+        with torch.cuda.stream(self.enc_s), torch.no_grad():
+            self.enc_s.wait_event(ev)
+            enc = self.model.encode(*staged)
+            done = torch.cuda.Event()
+            done.record(self.enc_s)
+        for t in enc:
+            t.record_stream(self.dec_s)
+        return enc, done
+
+    def _decode(self, enc, ev, seed, img0, to_host):
+        with torch.cuda.stream(self.dec_s), torch.no_grad():
+            self.dec_s.wait_event(ev)
+            toks, lens = self.model.decode(enc, seed=seed, img0=img0, **self.gen_kw)
+            if to_host:
+                key = tuple(toks.shape)
+                bufs = self._host_out.get(key)
+                if bufs is None:
+                    bufs = self._host_out[key] = (torch.empty(toks.shape, dtype=toks.dtype).pin_memory(),
+                                                  torch.empty(lens.shape, dtype=lens.dtype).pin_memory())
+                bufs[0].copy_(toks, non_blocking=True)
+                bufs[1].copy_(lens, non_blocking=True)
+                toks, lens = bufs
+            done = torch.cuda.Event()
+            done.record(self.dec_s)
+        return toks, lens, done
+
+    # -- driver ------------------------------------------------------------------------------------------------------
+    def run(self, batches, seeds=None, img0=0, to_host=True):
+        """``batches``: iterable of input tuples (``(images,)`` or ``(images, labels)``), host (ideally pinned) or device
+        tensors.  Yields ``(tokens, lengths)`` per batch, in order; with ``to_host`` they live in pinned host memory that
+        is reused two batches later -- consume or clone them before that.  All work of a batch has completed when it is
+        yielded."""
+        it = iter(batches)
+        seeds = iter(seeds) if seeds is not None else None
+        cur = next(it, None)
+        if cur is None:
+            return
+        enc, ev = self._encode(*self._stage(cur))
+        while cur is not None:
+            nxt = next(it, None)
+            if nxt is not None:                      # issue the next batch's copy + encoder BEFORE this batch's decode
+                nxt_enc, nxt_ev = self._encode(*self._stage(nxt))
+            seed = next(seeds) if seeds is not None else None
+            toks, lens, done = self._decode(enc, ev, seed, img0, to_host)
+            done.synchronize()
+            yield toks, lens
+            cur = nxt
+            if nxt is not None:
+                enc, ev = nxt_enc, nxt_ev

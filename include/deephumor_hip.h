@@ -418,9 +418,11 @@ int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, c
 
 /* ---------------------------------------------------------------------------------------------
  * Launch profiler (measurement infrastructure, not on the data path): while enabled, every launch made
- * through this library is bracketed by HIP events on its stream.  filter: NULL/"" = all entry points,
- * else comma-separated entry-point names.  dh_prof_end() synchronises the recorded events and
- * aggregates per "entry[tag]": calls, total ms, algorithmic flops and bytes.
+ * through this library is bracketed by HIP events on its stream.  Launches are keyed "entry[role]{MxNxK}" (role: qkv /
+ * proj / ffn / vocab / 1x1 / 3x3 ...; the shape suffix for GEMM-shaped launches).  filter: NULL/"" = everything, else
+ * comma-separated full keys, "entry[role]" prefixes or bare entry-point names.  dh_prof_end() synchronises the recorded
+ * events and aggregates per key: calls, total ms, algorithmic flops and bytes.  The recorder is mutex-protected (launches
+ * may come from several host threads / streams); the kernels' data path is unaffected.
  * ------------------------------------------------------------------------------------------- */
 int dh_prof_begin(const char* filter);
 int dh_prof_set_stride(int n);           /* record only every n-th matching launch (default 1): sampling keeps

@@ -74,3 +74,43 @@ def test_score_rows_gather_in_global_order():
             want = torch.arange(n_total, dtype=torch.float32)[:, None] * torch.tensor([1.0, 0.5, 0.25])
             for r in range(2):
                 assert torch.equal(ret[r], want)
+
+
+def _bench_worker(rank, world, port, n_total, ret):
+    """bench.py's multi-rank control flow on CPU: barrier -> K steps -> barrier -> MAX all-reduce of the wall time, with
+    the model stubbed (captions = a function of the global image index) and the C5-style uneven shards going through
+    gather_captions."""
+    import sys
+    import time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from deephumor_amd.dist import gather_captions
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    lo, hi = shard_range(n_total, rank, world)
+    calls = []
+
+    def step(s):
+        calls.append(s)
+        time.sleep(0.05 * (rank + 1))                    # rank 1 is slower: the reported time must be ITS time
+        toks, lens = _fake_generate(lo, hi)
+        return gather_captions(toks, lens, n_total)
+
+    dt, (toks, lens) = bench.timed_region(step, 3, world, "cpu")
+    ret[rank] = (dt, calls, toks.clone(), lens.clone(), dist.get_world_size())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_timed_region_over_two_ranks():
+    n_total = 7                                           # uneven: 4 + 3 images
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_bench_worker, args=(2, _free_port(), n_total, ret), nprocs=2, join=True)
+        want_t, want_l = _fake_generate(0, n_total)
+        for r in range(2):
+            dt, calls, toks, lens, seen = ret[r]
+            assert calls == [0, 1, 2] and seen == 2                         # EXACTLY K steps on every rank
+            assert torch.equal(toks, want_t) and torch.equal(lens, want_l)  # whole batch, global order, on every rank
+            assert dt >= 3 * 0.1 - 0.02                                     # max over ranks (rank 1 sleeps 0.1 s per step)
+        assert abs(ret[0][0] - ret[1][0]) < 1e-9                            # one all-reduced number

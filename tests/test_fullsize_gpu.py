@@ -1,0 +1,72 @@
+"""BASELINE-size runs inside ``-m gpu``: the workloads bench.py times, checked -- not only timed.
+  * fp32, 256 images, V = 36,541, greedy: rows {0, 77, 255} of the batch equal the CPU oracle's ids
+  * bf16 C2 / C3 at 256 images x beam 5: run-to-run equality and 128 + 128 split (``img0``) equality at the tile
+    configurations the full batch selects (gemm_bf16.hip picks tiles by workgroup count)
+  * the C5 shape: fp16, 300 templates x beam 10 with labels: run-to-run equality and a 150 + 150 split
+Sized to stay under about a minute in all."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+V = 36541
+
+
+def _model(kind, dtype):
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import synth_state_dict
+    model = getattr(M, kind)(V).eval()
+    sd = synth_state_dict(model.state_dict(), seed=1234)
+    model.load_state_dict(sd)
+    model = model.cuda()
+    if dtype != torch.float32:
+        model = model.to(dtype)
+    return model, sd
+
+
+@pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
+def test_fp32_full_batch_greedy_rows_equal_the_oracle(kind):
+    from oracle import ref_path as R
+    from deephumor_amd.synth import synth_images
+    model, sd = _model(kind, torch.float32)
+    imgs = synth_images(256, seed=0)
+    with torch.no_grad():
+        toks, lens = model.generate_batch(imgs.cuda(), max_len=32, beam_size=1, top_k=1)
+    for i in (0, 77, 255):
+        want = R.model_generate(kind, sd, model._hp, imgs[i:i + 1], max_len=32, beam_size=1, top_k=1).reshape(-1).tolist()
+        assert toks[i, :int(lens[i])].cpu().tolist() == want, (kind, i)
+
+
+@pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
+def test_bf16_full_batch_is_repeatable_and_split_invariant(kind):
+    from deephumor_amd.synth import synth_images
+    model, _ = _model(kind, torch.bfloat16)
+    imgs = synth_images(256, seed=0).cuda()
+    kw = dict(max_len=32, beam_size=5, top_k=50, temperature=1.0, seed=42)
+    with torch.no_grad():
+        t1, l1 = model.generate_batch(imgs, **kw)
+        t2, l2 = model.generate_batch(imgs, **kw)
+        assert torch.equal(t1, t2) and torch.equal(l1, l2)
+        ta, la = model.generate_batch(imgs[:128], img0=0, **kw)
+        tb, lb = model.generate_batch(imgs[128:], img0=128, **kw)
+    assert tuple(t1.shape) == (256, 32) and int(t1.max()) < V and not bool((t1 == 1).any())
+    # a row's arithmetic does not depend on which rows share its tile: the 128-image halves reproduce the batch
+    assert torch.equal(torch.cat([ta, tb]), t1) and torch.equal(torch.cat([la, lb]), l1)
+
+
+def test_c5_shape_fp16_beam10_300_templates():
+    import numpy as np
+    from deephumor_amd.synth import synth_images
+    model, _ = _model("CaptioningTransformerWithLabels", torch.float16)
+    imgs = synth_images(300, seed=2).cuda()
+    g = np.random.Generator(np.random.Philox(key=[1, 0]))
+    labels = torch.from_numpy(g.integers(6, V, size=(300, 3)).astype(np.int64)).cuda()
+    kw = dict(max_len=32, beam_size=10, top_k=50, temperature=1.0, seed=7)
+    with torch.no_grad():
+        t1, l1 = model.generate_batch(imgs, labels, **kw)
+        t2, l2 = model.generate_batch(imgs, labels, **kw)
+        assert torch.equal(t1, t2) and torch.equal(l1, l2)
+        ta, la = model.generate_batch(imgs[:150], labels[:150], img0=0, **kw)
+        tb, lb = model.generate_batch(imgs[150:], labels[150:], img0=150, **kw)
+    assert tuple(t1.shape) == (300, 32) and int(t1.max()) < V and not bool((t1 == 1).any()) and int(l1.min()) >= 1
+    assert torch.equal(torch.cat([ta, tb]), t1) and torch.equal(torch.cat([la, lb]), l1)
