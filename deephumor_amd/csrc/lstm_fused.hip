@@ -232,10 +232,11 @@ extern "C" int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const
     // measured at 1280 rows x 2048 gate columns (640 workgroups): 4 slabs (2 per CU, 1.25 rounds) 20.7 / 24.3 us,
     // 3 slabs (3 per CU) 16.6 / 19.0 us, 2 slabs (5 per CU) 16.4 / 18.6 us  (E = 256 / 512)
     const int blocks = p.tiles_m * p.tiles_n;
+    static const int force_ns = getenv("DH_LSTM_NS") ? atoi(getenv("DH_LSTM_NS")) : 0;
     DH_DISPATCH_16(dtype, {
-        if (blocks > 768 && blocks <= 1280)
+        if (force_ns == 2 || (!force_ns && blocks > 768 && blocks <= 1280))
             hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-        else if (blocks > 512 && blocks <= 768)
+        else if (force_ns == 3 || (!force_ns && blocks > 512 && blocks <= 768))
             hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
         else
             hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);

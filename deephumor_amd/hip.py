@@ -65,6 +65,8 @@ SIGNATURES = {
     "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "dh_resize_u8_hwc": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dh_normalize_pack_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_avgpool_nhwc": [_P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
@@ -662,6 +664,31 @@ def normalize_u8_hwc(x, mean, std):
     n, h, w, c = x.shape
     y = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
     _launch("dh_normalize_u8_hwc", _ptr(x), _ptr(mean), _ptr(std), _ptr(y), n, h, w, c, _stream())
+    return y
+
+
+def resize_u8_hwc(x, out_h, out_w, coeff_x, coeff_y):
+    """uint8 [N,H,W,C] -> uint8 [N,out_h,out_w,C]: Pillow's BILINEAR resample (``transforms.Resize``), bit-exact.
+    ``coeff_*`` = (bounds int32 [n_out,2], weights int32 [n_out,ksize]) device tensors, or None when that size is unchanged."""
+    _dev(x)
+    assert x.dtype == torch.uint8 and x.is_contiguous() and x.dim() == 4
+    n, h, w, c = x.shape
+    dst = torch.empty((n, out_h, out_w, c), dtype=torch.uint8, device=x.device)
+    tmp = torch.empty((n, h, out_w, c), dtype=torch.uint8, device=x.device) if (h != out_h and w != out_w) else None
+    bx, kx = coeff_x if coeff_x is not None else (None, None)
+    by, ky = coeff_y if coeff_y is not None else (None, None)
+    _launch("dh_resize_u8_hwc", _ptr(x), _ptr(tmp), _ptr(dst), _ptr(bx), _ptr(kx), kx.shape[1] if kx is not None else 0,
+            _ptr(by), _ptr(ky), ky.shape[1] if ky is not None else 0, n, h, w, out_h, out_w, c, _stream())
+    return dst
+
+
+def normalize_pack_u8(x, mean, std, out_dtype=torch.bfloat16):
+    """uint8 [N,H,W,C<=8] -> normalised 16-bit channels-last [N,H,W,8] (the stem convolution's packed input)."""
+    _dev(x, mean, std)
+    assert x.dtype == torch.uint8 and x.is_contiguous() and x.dim() == 4
+    n, h, w, c = x.shape
+    y = torch.empty((n, h, w, 8), dtype=out_dtype, device=x.device)
+    _launch("dh_normalize_pack_u8", _ptr(x), _ptr(mean), _ptr(std), _ptr(y), n, h, w, c, _dt(y), _stream())
     return y
 
 

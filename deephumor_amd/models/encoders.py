@@ -179,7 +179,11 @@ class ImageEncoder(_Planned, nn.Module):
         nhwc = plan["bf16"]
         st = plan["stem"]
         if nhwc:
-            x = self._conv(hip.pack_nchw_to_nhwc8(images.float().contiguous(), out_dtype=plan["dtype"]), st, nhwc=True)
+            if images.dim() == 4 and images.shape[-1] == 8 and images.dtype == plan["dtype"]:
+                packed = images.contiguous()              # already normalised + packed (experiments.inference.preprocess_images)
+            else:
+                packed = hip.pack_nchw_to_nhwc8(images.float().contiguous(), out_dtype=plan["dtype"])
+            x = self._conv(packed, st, nhwc=True)
             x = hip.maxpool3x3s2_nhwc(x)
         else:
             x = hip.maxpool3x3s2(self._conv(images.contiguous(), st))

@@ -80,9 +80,24 @@ int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w, const floa
 int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, int dtype, void* stream);
 
 /* Image preprocessing on device: u8 [N,H,W,C] -> fp32 NCHW (x / 255 - mean[c]) / std[c], bit-identical to
- * torchvision ToTensor + Normalize (deephumor_demo.ipynb:565-567; the resize stays with the image decoder). */
+ * torchvision ToTensor + Normalize (deephumor_demo.ipynb:566-567; the resize in front of it: dh_resize_u8_hwc). */
 int dh_normalize_u8_hwc(const uint8_t* x, const float* mean, const float* stdv, float* y, int N, int H, int W, int C,
                         void* stream);
+
+/* transforms.Resize((Hout, Wout)) of the notebook's pipeline (deephumor_demo.ipynb:565) for decoded 8-bit images on device:
+ * Pillow's antialiased BILINEAR resample, bit-exact (horizontal pass into the 8-bit intermediate `tmp` [N,Hin,Wout,C], then
+ * vertical; 22-bit fixed-point weights, accumulator 2^21 + sum, result clip8(acc >> 22)).  bounds_* [n_out][2] = (first
+ * source index, count) and k* [n_out][ksize_*] int32 weights come from the host (Pillow's precompute_coeffs in double
+ * precision: deephumor_amd.experiments.inference.resize_coefficients); a pass whose sizes agree is skipped.  C <= 8. */
+int dh_resize_u8_hwc(const uint8_t* src, uint8_t* tmp, uint8_t* dst, const int32_t* bounds_x, const int32_t* kx, int ksize_x,
+                     const int32_t* bounds_y, const int32_t* ky, int ksize_y, int N, int Hin, int Win, int Hout, int Wout,
+                     int C, void* stream);
+
+/* ToTensor + Normalize fused with the stem's input packing (16-bit paths): u8 [N,H,W,C] -> normalised bf16 / fp16
+ * channels-last [N,H,W,8] (channels C..7 zero), bit-identical to dh_pack_nchw_to_nhwc8(dh_normalize_u8_hwc(x)) -- the
+ * matrix-core stem convolution reads it directly, no fp32 NCHW tensor in front of conv1. */
+int dh_normalize_pack_u8(const uint8_t* x, const float* mean, const float* stdv, void* y, int N, int H, int W, int C,
+                         int dtype, void* stream);
 
 /* Teacher-forced (prefill) forms of the decoder row kernels -- forward() over all positions at once (transformers.py
  * DecoderLayer.forward with the causal + pad mask of :471-478).  Rows are sequence-major: row n*n_pos + t.

@@ -381,3 +381,41 @@ def test_conv1x1_dual_matches_conv3_plus_downsample(hip, c1, c2, cout, hw, strid
     out = hip.conv1x1_dual_nhwc(y.permute(0, 2, 3, 1).contiguous().cuda(), x.permute(0, 2, 3, 1).contiguous().cuda(),
                                 w_cat.contiguous().cuda(), (b3 + bd).cuda(), stride)
     close(out.float().permute(0, 3, 1, 2), ref, atol=4e-2, rtol=2e-2)
+
+
+def test_device_resize_is_bit_exact_vs_pillow_golden(hip):
+    """dh_resize_u8_hwc against the G9 golden (real Pillow outputs) and the numpy oracle, incl. one-pass cases."""
+    import hashlib
+    from oracle.make_resize_golden import CASES, image
+    from oracle.resize_ref import resize_bilinear_u8
+    from deephumor_amd.experiments.inference import resize_images
+    g = golden("g9_resize.npz")
+    for name, (h, w, oh, ow) in CASES.items():
+        img = image(name, h, w)
+        batch = torch.from_numpy(np.stack([img, img[::-1].copy()])).cuda()           # two images per launch
+        out = resize_images(batch, (oh, ow)).cpu().numpy()
+        assert hashlib.sha256(out[0].tobytes()).digest() == g[f"{name}_sha"].tobytes(), name
+        assert (out[1] == resize_bilinear_u8(img[::-1].copy(), oh, ow)).all(), name
+
+
+def test_fused_normalize_pack_feeds_the_stem_identically():
+    """preprocess_images(dtype=bf16) (resize -> normalise + pack fused, no fp32 tensor in front of conv1) gives the encoder
+    exactly what the reference-shaped route (fp32 NCHW batch -> pack) gives."""
+    import deephumor_amd.models as M
+    from deephumor_amd.experiments.inference import preprocess_images
+    from helpers import synthetic_sd
+    g = torch.Generator().manual_seed(4)
+    u8 = torch.randint(0, 256, (3, 300, 260, 3), generator=g, dtype=torch.uint8).cuda()
+    x32 = preprocess_images(u8, dtype=torch.float32)
+    assert tuple(x32.shape) == (3, 3, 224, 224) and x32.dtype == torch.float32
+    sd, hp = synthetic_sd("CaptioningTransformer")
+    model = M.CaptioningTransformer(**hp).eval()
+    model.load_state_dict(sd)
+    for dt in (torch.bfloat16, torch.float16):
+        m16 = model.cuda().to(dt)
+        packed = preprocess_images(u8, dtype=dt)
+        assert tuple(packed.shape) == (3, 224, 224, 8) and packed.dtype == dt
+        with torch.no_grad():
+            e1, s1 = m16.encoder(x32)
+            e2, s2 = m16.encoder(packed)
+        assert torch.equal(e1, e2) and torch.equal(s1, s2)

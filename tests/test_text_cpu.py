@@ -47,3 +47,25 @@ def test_oracle_perplexity_matches_reference():
     for r, n in enumerate(lengths.tolist()):
         targets[r, n:] = 0
     assert abs(float(perplexity(logits, targets, lengths)) - G["perplexity"]["value"]) < 1e-3 * G["perplexity"]["value"]
+
+
+def test_resize_oracle_and_host_coefficients_match_pillow_golden():
+    """G9: outputs of the real Pillow (Image.resize(..., BILINEAR) = torchvision Resize on PIL images) recorded in the build
+    container; the numpy restatement reproduces them bit for bit, and the product's host-side coefficient tables equal the
+    oracle's."""
+    import hashlib
+    import numpy as np
+    from helpers import golden
+    from oracle.make_resize_golden import CASES, image
+    from oracle.resize_ref import coefficients, resize_bilinear_u8
+    from deephumor_amd.experiments.inference import resize_coefficients
+    g = golden("g9_resize.npz")
+    for name, (h, w, oh, ow) in CASES.items():
+        res = resize_bilinear_u8(image(name, h, w), oh, ow)
+        assert hashlib.sha256(res.tobytes()).digest() == g[f"{name}_sha"].tobytes(), name
+        assert (res[:24, :24] == g[f"{name}_corner"]).all() and (res[-8:, -8:] == g[f"{name}_tail"]).all()
+        for a, b in ((w, ow), (h, oh)):
+            ob, ok = coefficients(a, b)
+            pb, pk = resize_coefficients(a, b)
+            assert (ob == pb).all() and (ok == pk).all()
+    assert (resize_bilinear_u8(image("small", 37, 53), 24, 24) == g["small_full"]).all()
