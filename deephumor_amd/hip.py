@@ -79,6 +79,7 @@ SIGNATURES = {
     "dh_attn_cross_decode_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_attn_cross_prefill_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_conv2d_nhwc_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P],
+    "dh_conv2d_nhwc_bn_relu_maxpool": [_P, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_embed_rows": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_add_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "dh_attn_self_decode": [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
@@ -431,6 +432,19 @@ def conv2d_nhwc_bn_act(x, w, scale, shift, residual=None, relu=True, stride=1, p
     out = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
     _launch("dh_conv2d_nhwc_bn_act", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out),
             n, h, wd, cin, cout, ks, stride, pad, int(relu), _dt(x), _stream(), tag=f"{ks}x{ks}")
+    return out
+
+
+def conv2d_nhwc_bn_relu_maxpool(x, w, scale, shift, stride=2, pad=3):
+    """The ResNet stem in one launch: x [N,H,W,Cin] 16-bit (Cin % 8 == 0), w [Cout,KS,KS,Cin] -> pooled [N,Ho/2,Wo/2,Cout]."""
+    _dev(x, w, scale, shift)
+    n, h, wd, cin = x.shape
+    cout, ks, _, cin2 = w.shape
+    assert cin == cin2 and x.is_contiguous() and w.is_contiguous()
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (wd + 2 * pad - ks) // stride + 1
+    out = torch.empty((n, ho // 2, wo // 2, cout), dtype=x.dtype, device=x.device)
+    _launch("dh_conv2d_nhwc_bn_relu_maxpool", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), n, h, wd, cin, cout, ks,
+            stride, pad, _dt(x), _stream())
     return out
 
 

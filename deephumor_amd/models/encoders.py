@@ -6,6 +6,8 @@ parameter containers -- the arithmetic runs in ``libdeephumor_hip.so`` (``deephu
 batched over images.  Inference only: like the reference's ``generate`` callers
 (deephumor_demo.ipynb:1134-1141) the model must be in ``eval()`` mode.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -183,8 +185,14 @@ class ImageEncoder(_Planned, nn.Module):
                 packed = images.contiguous()              # already normalised + packed (experiments.inference.preprocess_images)
             else:
                 packed = hip.pack_nchw_to_nhwc8(images.float().contiguous(), out_dtype=plan["dtype"])
-            x = self._conv(packed, st, nhwc=True)
-            x = hip.maxpool3x3s2_nhwc(x)
+            ks, cout = st["w"].shape[1], st["w"].shape[0]
+            ho = (packed.shape[1] + 2 * st["pad"] - ks) // st["stride"] + 1
+            wo = (packed.shape[2] + 2 * st["pad"] - ks) // st["stride"] + 1
+            if ho % 2 == 0 and wo % 2 == 0 and cout <= 64 and not os.environ.get("DH_NO_STEM_POOL"):
+                # conv1 + bn1 + relu + maxpool in one launch: the un-pooled 112 x 112 x 64 activation never exists
+                x = hip.conv2d_nhwc_bn_relu_maxpool(packed, st["w"], st["scale"], st["shift"], st["stride"], st["pad"])
+            else:
+                x = hip.maxpool3x3s2_nhwc(self._conv(packed, st, nhwc=True))
         else:
             x = hip.maxpool3x3s2(self._conv(images.contiguous(), st))
         for blk in plan["blocks"]:

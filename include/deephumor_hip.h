@@ -62,6 +62,14 @@ int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* scale, cons
                           const void* residual, void* y, int N, int H, int W, int Cin, int Cout,
                           int KS, int stride, int pad, int relu, int dtype, void* stream);
 
+/* The ResNet stem in one launch (16-bit dtypes): conv + BatchNorm + ReLU + MaxPool2d(3, 2, 1) -- torchvision resnet children
+ * conv1, bn1, relu, maxpool (encoders.py:37-38).  A workgroup computes the 15 x 15 patch of convolution pixels under a 7 x 7
+ * block of pooled pixels and pools it in LDS: the 4x larger un-pooled activation (411 MB at 256 images) is neither written nor
+ * read back.  x NHWC [N,H,W,Cin] (Cin % 8 == 0: the packed image), w [Cout,KS,KS,Cin], y NHWC [N,Ho/2,Wo/2,Cout]; conv output
+ * Ho, Wo even; Cout <= 64.  Bit-identical to dh_conv2d_nhwc_bn_act + dh_maxpool3x3s2_nhwc (rounding is monotonic). */
+int dh_conv2d_nhwc_bn_relu_maxpool(const void* x, const void* w, const float* scale, const float* shift, void* y, int N,
+                                   int H, int W, int Cin, int Cout, int KS, int stride, int pad, int dtype, void* stream);
+
 /* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */
 int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const float* shift, void* y,

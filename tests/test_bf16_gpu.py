@@ -366,3 +366,20 @@ def test_linear_with_deferred_layernorm(hip, m):
     np.testing.assert_allclose(out3.float().cpu().numpy(), want3.numpy(), atol=6e-2 if HALF == torch.bfloat16 else 1.5e-2, rtol=2e-2)
     # plain form == dh_linear
     assert torch.equal(hip.linear_ln(a.cuda(), w2.cuda(), b2.cuda()), hip.linear(a.cuda(), w2.cuda(), b2.cuda()))
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 224, 224), (3, 64, 96), (1, 36, 28)])
+def test_stem_conv_with_fused_maxpool(hip, n, h, w):
+    """dh_conv2d_nhwc_bn_relu_maxpool == dh_conv2d_nhwc_bn_act + dh_maxpool3x3s2_nhwc bit for bit (partial 7 x 7 blocks at
+    the image edges included), and close to F.conv2d + max_pool2d in fp32."""
+    x = bf(rnd(n, h, w, 8, seed=41))
+    x[..., 3:] = 0
+    wgt = bf(rnd(64, 7, 7, 8, seed=42) * 0.08)
+    sc, sh = rnd(64, seed=43).abs() + 0.5, rnd(64, seed=44) * 0.3
+    fused = hip.conv2d_nhwc_bn_relu_maxpool(x.cuda(), wgt.cuda(), sc.cuda(), sh.cuda(), stride=2, pad=3)
+    conv = hip.conv2d_nhwc_bn_act(x.cuda(), wgt.cuda(), sc.cuda(), sh.cuda(), relu=True, stride=2, pad=3)
+    ref = hip.maxpool3x3s2_nhwc(conv)
+    assert tuple(fused.shape) == tuple(ref.shape) and torch.equal(fused, ref)
+    want = F.max_pool2d(torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), wgt.float().permute(0, 3, 1, 2), stride=2, padding=3)
+                                   * sc[None, :, None, None] + sh[None, :, None, None]), 3, 2, 1)
+    np.testing.assert_allclose(fused.float().cpu().permute(0, 3, 1, 2).numpy(), want.numpy(), atol=4e-2, rtol=2e-2)
