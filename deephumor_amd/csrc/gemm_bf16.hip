@@ -53,14 +53,17 @@ struct GemmBf16Params {
     float2* o_stats;                                   // out: partial statistics of the OUTPUT rows, [M][N / 64] (requires BN == 64)
 };
 
-// mean and rstd of a row from its nt <= 8 tile partials (each over 64 elements): Chan's parallel combination in a fixed order
-__device__ __forceinline__ void ln_combine(const float2* st, int nt, float eps, float& mu, float& rstd) {
+// mean and rstd of a row from its nt <= 8 tile partials (each over 64 elements): Chan's parallel combination in a fixed order.
+// Split in two so that the loads can be issued at the top of a kernel and the arithmetic (which waits for them) run in its
+// epilogue: called back to back they would put a full memory round trip in front of the first operand slab.
+__device__ __forceinline__ void ln_load(const float2* st, int nt, float4 (&raw)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) raw[t] = *reinterpret_cast<const float4*>(st + (2 * t < nt ? 2 * t : 0));   // 16-byte loads, clamped
+}
+__device__ __forceinline__ void ln_math(const float4 (&raw)[4], int nt, float eps, float& mu, float& rstd) {
     float2 v[8];
 #pragma unroll
-    for (int t = 0; t < 8; t += 2) {                    // 16-byte loads, clamped: all issued back to back
-        const float4 q = *reinterpret_cast<const float4*>(st + (t < nt ? t : 0));
-        v[t] = make_float2(q.x, q.y); v[t + 1] = make_float2(q.z, q.w);
-    }
+    for (int t = 0; t < 4; ++t) { v[2 * t] = make_float2(raw[t].x, raw[t].y); v[2 * t + 1] = make_float2(raw[t].z, raw[t].w); }
     float ms = 0.f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) ms += t < nt ? v[t].x : 0.f;
@@ -100,12 +103,13 @@ __device__ __forceinline__ void wait_vmcnt(int n) { wait_vmcnt_any(n); }
 
 // NS = LDS ring depth: slabs t+1 .. t+NS-1 are in flight (LDS-DMA) while slab t feeds the MFMAs.
 // NW waves per workgroup, arranged WAVES_M x (NW / WAVES_M) over the BM x BN block.
-// EXT: 0 = plain; 1 = deferred-LayerNorm forms (LNX); 2 = convolution + MaxPool2d(3, 2, 1) in one launch (POOL, the ResNet
+// EXT: 0 = plain; 1 = deferred LayerNorm on the A rows (a_stats); 3 = deferred LayerNorm on the residual rows and / or
+// statistics of the output rows (r_stats, o_stats); 2 = convolution + MaxPool2d(3, 2, 1) in one launch (POOL, the ResNet
 // stem): a workgroup's 256 GEMM rows are a 15 x 15 patch of convolution pixels whose BatchNorm + ReLU outputs stay in LDS and
 // leave the kernel as the 7 x 7 pooled pixels they cover -- the 4x larger un-pooled activation never goes to memory.
 template <typename OT, int BM, int BN, int WAVES_M, bool CONV, int NS, int NW = 4, int EXT = 0>
 __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
-    constexpr bool LNX = EXT == 1, POOL = EXT == 2;
+    constexpr bool AFX = EXT == 1, LNX = EXT == 3, POOL = EXT == 2;
     constexpr int NT = 64 * NW;
     constexpr int BK = 64;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, SLAB = A_BYTES + B_BYTES;
@@ -288,22 +292,44 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
             addv[j][0] = av.x; addv[j][1] = av.y; addv[j][2] = av.z; addv[j][3] = av.w;
         }
     }
-    // deferred LayerNorm on the A rows: this lane's rows' (mean, rstd) and its columns' folded-weight row sums
-    float a_mu[TM], a_rs[TM], csum[TN][4];
-    bool a_fold = false;
+    // deferred LayerNorm on the A rows: this lane's rows' statistics partials and its columns' folded-weight row sums are
+    // REQUESTED here, in front of the operand slabs; the arithmetic on them runs after the reduction
+    float4 a_raw[TM][4];
+    float csum[TN][4];
+    constexpr bool a_fold = AFX;
+    if constexpr (AFX) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = min(m0 + wm0 + 16 * i + l15, p.M - 1);
+            ln_load(p.a_stats + (size_t)m * p.a_nt, p.a_nt, a_raw[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn0 + 16 * j + 4 * lq;
+            const float4 c4 = n < p.N ? *reinterpret_cast<const float4*>(p.a_colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            csum[j][0] = c4.x; csum[j][1] = c4.y; csum[j][2] = c4.z; csum[j][3] = c4.w;
+        }
+    }
+    // residual path of the deferred-LayerNorm chain: residual chunk, its row's statistics partials, gamma / beta -- requested
+    // here as well (one thread = one 16-byte chunk of one row per epilogue iteration)
+    constexpr int CHUNKS = BN / 8;                        // 16-byte bf16 chunks per tile row
+    constexpr int EP_IT = (BM * CHUNKS + NT - 1) / NT;
+    uint4 rq[EP_IT];
+    float4 r_raw[EP_IT][4], rg[EP_IT][2], rb[EP_IT][2];
+    bool r_ln = false;
     if constexpr (LNX) {
-        a_fold = p.a_stats != nullptr;
-        if (a_fold) {
+        r_ln = p.r_stats != nullptr;
+        if (p.res) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = min(m0 + wm0 + 16 * i + l15, p.M - 1);
-                ln_combine(p.a_stats + (size_t)m * p.a_nt, p.a_nt, p.a_eps, a_mu[i], a_rs[i]);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn0 + 16 * j + 4 * lq;
-                const float4 c4 = n < p.N ? *reinterpret_cast<const float4*>(p.a_colsum + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-                csum[j][0] = c4.x; csum[j][1] = c4.y; csum[j][2] = c4.z; csum[j][3] = c4.w;
+            for (int it = 0; it < EP_IT; ++it) {
+                const int c = tid + it * NT, row = c / CHUNKS, ch = c - row * CHUNKS;
+                const int m = min(m0 + row, p.M - 1), n = min(n0 + ch * 8, p.N - 8);
+                rq[it] = *reinterpret_cast<const uint4*>(p.res + (size_t)m * p.ldres + n);
+                if (r_ln) {
+                    ln_load(p.r_stats + (size_t)m * p.r_nt, p.r_nt, r_raw[it]);
+                    rg[it][0] = *reinterpret_cast<const float4*>(p.r_gamma + n); rg[it][1] = *reinterpret_cast<const float4*>(p.r_gamma + n + 4);
+                    rb[it][0] = *reinterpret_cast<const float4*>(p.r_beta + n); rb[it][1] = *reinterpret_cast<const float4*>(p.r_beta + n + 4);
+                }
             }
         }
     }
@@ -383,33 +409,24 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
     // bf16 output with a residual: this thread's residual chunks (one 16-byte chunk per epilogue iteration) are requested
     // NOW, so they are in flight while the tile is staged through LDS -- loaded inside the loop below each of them
     // cost a full memory round trip (load, wait, add, store, next)
-    constexpr int CHUNKS = BN / 8;                        // 16-byte bf16 chunks per tile row
-    constexpr int EP_IT = (BM * CHUNKS + NT - 1) / NT;
     const bool fast = ((p.ldc & 7) == 0) && (!p.res || (p.ldres & 7) == 0);
-    uint4 rq[EP_IT];
-    float r_mu[EP_IT], r_rs[EP_IT];
-    float4 rg[EP_IT][2], rb[EP_IT][2];
-    bool r_ln = false;
-    if (!p.out_f32 && p.res && fast) {
+    float a_mu[TM], a_rs[TM], r_mu[EP_IT], r_rs[EP_IT];
+    if constexpr (AFX) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ln_math(a_raw[i], p.a_nt, p.a_eps, a_mu[i], a_rs[i]);
+    }
+    if constexpr (LNX) {
+        if (r_ln) {
+#pragma unroll
+            for (int it = 0; it < EP_IT; ++it) ln_math(r_raw[it], p.r_nt, p.r_eps, r_mu[it], r_rs[it]);
+        }
+    } else if (!p.out_f32 && p.res && fast) {
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) {
             const int c = tid + it * NT, row = c / CHUNKS, ch = c - row * CHUNKS;
             const int m = m0 + row, n = n0 + ch * 8;
             const bool ok = c < BM * CHUNKS && m < p.M && n + 8 <= p.N;
             rq[it] = *reinterpret_cast<const uint4*>(p.res + (ok ? (size_t)m * p.ldres + n : 0));
-        }
-        if constexpr (LNX) {
-            r_ln = p.r_stats != nullptr;
-            if (r_ln) {
-#pragma unroll
-                for (int it = 0; it < EP_IT; ++it) {
-                    const int c = tid + it * NT, row = c / CHUNKS, ch = c - row * CHUNKS;
-                    const int m = min(m0 + row, p.M - 1), n = min(n0 + ch * 8, p.N - 8);
-                    ln_combine(p.r_stats + (size_t)m * p.r_nt, p.r_nt, p.r_eps, r_mu[it], r_rs[it]);
-                    rg[it][0] = *reinterpret_cast<const float4*>(p.r_gamma + n); rg[it][1] = *reinterpret_cast<const float4*>(p.r_gamma + n + 4);
-                    rb[it][0] = *reinterpret_cast<const float4*>(p.r_beta + n); rb[it][1] = *reinterpret_cast<const float4*>(p.r_beta + n + 4);
-                }
-            }
         }
     }
     // Stage the fp32 tile in LDS, then finish rows with row-contiguous accesses.  Slot s of row m
@@ -422,7 +439,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         for (int j = 0; j < TN; ++j) {
             const int row = wm0 + 16 * i + l15, slot = (wn0 + 16 * j) / 4 + lq;
             float4 v;
-            if (LNX && a_fold) {        // LayerNorm of the A rows applied on the accumulators: rstd * (acc - mu * colsum) + bias'
+            if (a_fold) {               // LayerNorm of the A rows applied on the accumulators: rstd * (acc - mu * colsum) + bias'
                 v.x = fmaf(a_rs[i], fmaf(-a_mu[i], csum[j][0], acc[j][i][0]), addv[j][0]);
                 v.y = fmaf(a_rs[i], fmaf(-a_mu[i], csum[j][1], acc[j][i][1]), addv[j][1]);
                 v.z = fmaf(a_rs[i], fmaf(-a_mu[i], csum[j][2], acc[j][i][2]), addv[j][2]);
@@ -632,14 +649,17 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
     const int blocks = p.tiles_m * p.tiles_n;
     if (!CONV && (p.a_stats || p.r_stats || p.o_stats)) {       // deferred-LayerNorm forms: the 64 x 64 kernels, same ring choice
-        if (blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)
-            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 4, 4, 1>), dim3(blocks), dim3(256), 0, s, p);
-        else if (blocks <= 320)
-            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 8, 8, 1>), dim3(blocks), dim3(512), 0, s, p);
-        else if (blocks <= 768)
-            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 3, 4, 1>), dim3(blocks), dim3(256), 0, s, p);
-        else
-            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 2, 4, 1>), dim3(blocks), dim3(256), 0, s, p);
+#define DH_LN_LAUNCH(E)                                                                                                             \
+        if (blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)                                                         \
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 4, 4, E>), dim3(blocks), dim3(256), 0, s, p);                \
+        else if (blocks <= 320)                                                                                                     \
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 8, 8, E>), dim3(blocks), dim3(512), 0, s, p);                \
+        else if (blocks <= 768)                                                                                                     \
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 3, 4, E>), dim3(blocks), dim3(256), 0, s, p);                \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, false, 2, 4, E>), dim3(blocks), dim3(256), 0, s, p);
+        if (p.a_stats) { DH_LN_LAUNCH(1) } else { DH_LN_LAUNCH(3) }
+#undef DH_LN_LAUNCH
         return;
     }
     // ring depth (16 KB per slab) by workgroup count, so that all tiles are co-resident in ONE round where possible:
@@ -694,6 +714,7 @@ extern "C" int dh_linear_ln(const void* A, int lda, const void* W, int ldw, cons
                                 ln->r_tiles * 64 == N && ((uintptr_t)ln->r_stats % 16) == 0 && ((uintptr_t)ln->r_gamma % 16) == 0 &&
                                 ((uintptr_t)ln->r_beta % 16) == 0));
     DH_REQUIRE(!ln->o_stats || ((N % 64) == 0 && ((uintptr_t)ln->o_stats % 8) == 0));
+    DH_REQUIRE(!(ln->a_stats && (ln->r_stats || ln->o_stats)));      // one kernel flavour per launch (the chain never needs both)
     GemmBf16Params p{};
     p.A = (const uint16_t*)A; p.lda = lda; p.W = (const uint16_t*)W; p.ldw = ldw; p.bias = bias;
     p.res = (const uint16_t*)residual; p.ldres = ldres; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.relu = relu;
