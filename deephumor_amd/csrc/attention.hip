@@ -714,7 +714,7 @@ extern "C" int dh_attn_masked(const void* q, int ldq, const void* k, int ldk, co
 // Masked keys get -1e8 exactly as masked_fill does (transformers.py:110-111); keys >= S do not exist (weight 0).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_cross_pack_kernel(const T* __restrict__ kv, T* __restrict__ kp, T* __restrict__ vt,
-                                                               int S, int D, int H) {
+                                                               int S, int D, int H, int dperm) {
     // one workgroup per (image, head): stage the V head slice [S][64] in LDS, write K rows straight through and V transposed
     __shared__ uint16_t vs[64][64 + 2];
     const int img = blockIdx.x, h = blockIdx.y, tid = threadIdx.x;
@@ -728,6 +728,15 @@ __global__ __launch_bounds__(256) void attn_cross_pack_kernel(const T* __restric
             const uint16_t* row = src + (size_t)(img * S + key) * (2 * D) + h * 64 + ch * 8;
             val = *reinterpret_cast<const uint4*>(row);
             vv = *reinterpret_cast<const uint4*>(row + D);
+            if (dperm) {
+                // head-dim slots in the order a q row leaves the projection's MFMA accumulators (dh_attn_cross_qproj_decode):
+                // slot 32 kk + 8 lq + e holds dim 16 (2 kk + (e >> 2)) + 4 lq + (e & 3) -- two runs of 4 consecutive dims
+                const int kk = ch >> 2, lq4 = ch & 3;
+                const uint16_t* r0 = src + (size_t)(img * S + key) * (2 * D) + h * 64;
+                const uint2 lo = *reinterpret_cast<const uint2*>(r0 + 32 * kk + 4 * lq4);
+                const uint2 hi = *reinterpret_cast<const uint2*>(r0 + 32 * kk + 16 + 4 * lq4);
+                val = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            }
         }
         *reinterpret_cast<uint4*>(kd + key * 64 + ch * 8) = val;
         const uint16_t* pv = reinterpret_cast<const uint16_t*>(&vv);
@@ -743,55 +752,21 @@ __global__ __launch_bounds__(256) void attn_cross_pack_kernel(const T* __restric
     }
 }
 
-extern "C" int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img, int S, int D, int n_heads, int dtype,
+extern "C" int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img, int S, int D, int n_heads, int dperm, int dtype,
                                   void* stream) {
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(kv && kp && vt && n_img > 0 && S > 0 && S <= 64 && n_heads > 0 && D == 64 * n_heads);
     DH_REQUIRE(((uintptr_t)kv % 16) == 0 && ((uintptr_t)kp % 16) == 0 && ((uintptr_t)vt % 16) == 0);
     DhProfScope prof("dh_attn_cross_pack", 0.0, 2.0 * n_img * (2.0 * S * D + 2.0 * 64 * D), stream);
     DH_DISPATCH_16(dtype, hipLaunchKernelGGL(attn_cross_pack_kernel<T>, dim3(n_img, n_heads), dim3(256), 0, (hipStream_t)stream,
-                                             (const T*)kv, (T*)kp, (T*)vt, S, D, n_heads));
+                                             (const T*)kv, (T*)kp, (T*)vt, S, D, n_heads, dperm));
     DH_LAUNCH_CHECK();
 }
 
+// scores -> softmax -> P V of one (image, head) from preloaded fragments (shared by the two matrix-core kernels below)
 template <typename T>
-__global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ kp,
-                                                               const T* __restrict__ vt, const uint8_t* __restrict__ keymask,
-                                                               T* __restrict__ out, int n_img, int rows_per_img, int row_si, int S,
-                                                               int D, int H, float scale) {
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (wid >= n_img * H) return;                                  // wave-uniform
-    const int img = wid / H, h = wid - img * H;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const uint16_t* kb = reinterpret_cast<const uint16_t*>(kp) + ((size_t)img * H + h) * 4096;
-    const uint16_t* vb = reinterpret_cast<const uint16_t*>(vt) + ((size_t)img * H + h) * 4096;
-    // every load of the kernel up front: K / V^T fragments, the row's q fragments, the key-mask bytes of the lane's 16 keys
-    uint4 kf[4][2], vf[4][2], qf[2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
-            vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
-        }
-    const bool live = l15 < rows_per_img;
-    const size_t qrow = (size_t)img * row_si + (live ? l15 : 0);
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        const uint4 t = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(q) + qrow * ldq + h * 64 + 32 * kk + 8 * lq);
-        qf[kk] = live ? t : make_uint4(0u, 0u, 0u, 0u);
-    }
-    uint32_t mk[4];                                                 // mask bytes of keys 16j + 4lq .. + 3 (clamped reads)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t w = 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * j + 4 * lq + r;
-            w |= (uint32_t)(keymask[img * S + min(key, S - 1)] != 0) << (8 * r);
-        }
-        mk[j] = w;
-    }
+__device__ __forceinline__ void cross_core(const uint4 (&kf)[4][2], const uint4 (&vf)[4][2], const uint4 (&qf)[2], const uint32_t (&mk)[4],
+                                           int S, float scale, bool live, uint16_t* orow, int lq) {
     dh_f32x4 sacc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -832,7 +807,6 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const T* __restric
         }
         pf[kk] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    uint16_t* orow = reinterpret_cast<uint16_t*>(out) + qrow * D + h * 64;
 #pragma unroll
     for (int jd = 0; jd < 4; ++jd) {
         dh_f32x4 o = dh_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -847,32 +821,218 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const T* __restric
     }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const T* __restrict__ q, int ldq, const T* __restrict__ kp,
+                                                               const T* __restrict__ vt, const uint8_t* __restrict__ keymask,
+                                                               T* __restrict__ out, int n_img, int rows_per_img, int row_si, int S,
+                                                               int D, int H, float scale, int dperm) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wid >= n_img * H) return;                                  // wave-uniform
+    const int img = wid / H, h = wid - img * H;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const uint16_t* kb = reinterpret_cast<const uint16_t*>(kp) + ((size_t)img * H + h) * 4096;
+    const uint16_t* vb = reinterpret_cast<const uint16_t*>(vt) + ((size_t)img * H + h) * 4096;
+    // every load of the kernel up front: K / V^T fragments, the row's q fragments, the key-mask bytes of the lane's 16 keys
+    uint4 kf[4][2], vf[4][2], qf[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+            vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+        }
+    const bool live = l15 < rows_per_img;
+    const size_t qrow = (size_t)img * row_si + (live ? l15 : 0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        const uint16_t* qp = reinterpret_cast<const uint16_t*>(q) + qrow * ldq + h * 64;
+        uint4 t;
+        if (dperm) {            // K was packed with permuted head-dim slots: read q in the same slot order (two runs of 4 dims)
+            const uint2 lo = *reinterpret_cast<const uint2*>(qp + 32 * kk + 4 * lq), hi = *reinterpret_cast<const uint2*>(qp + 32 * kk + 16 + 4 * lq);
+            t = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        } else {
+            t = *reinterpret_cast<const uint4*>(qp + 32 * kk + 8 * lq);
+        }
+        qf[kk] = live ? t : make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t mk[4];                                                 // mask bytes of keys 16j + 4lq .. + 3 (clamped reads)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t w = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * j + 4 * lq + r;
+            w |= (uint32_t)(keymask[img * S + min(key, S - 1)] != 0) << (8 * r);
+        }
+        mk[j] = w;
+    }
+    uint16_t* orow = reinterpret_cast<uint16_t*>(out) + qrow * D + h * 64;
+    cross_core<T>(kf, vf, qf, mk, S, scale, live, orow, lq);
+}
+
+// ---- query projection + cross-attention in one launch (decode chain of the 16-bit Transformer decoder) -----------------------
+// enc_attn of a DecoderLayer (transformers.py:364 -> 97-127) for one position: q = fc_q(LN1(y)) and the attention over the
+// image's patches, without the [rows, D] q matrix ever going to memory and without a separate GEMM launch.
+// Workgroup = 8 waves = 8 images x ONE head.  The head's 64 rows of the (gamma-folded) fc_q weight -- 64 KB -- are staged once
+// per workgroup in LDS by LDS-DMA (XOR-swizzled 128-byte rows, 8 k-slabs); meanwhile every wave has already requested its own
+// image's K / V^T fragments (dh_attn_cross_pack, dperm = 1), its <= 16 pre-LayerNorm rows y as MFMA B fragments, their
+// LayerNorm statistics and the per-dim constants.  One wait + barrier, then per wave:
+//   qacc[m][d] = sum_k y[m][k] W'[d][k]            64 MFMAs (4 dim tiles x 16 k-steps), W' fragments from LDS
+//   q = rstd[m] * (qacc - mu[m] * colsum[d]) + bias'[d]      (deferred LayerNorm, dh_linear_ln's A-fold)
+//   the lane's 16 q values, rounded to the operand type, ARE its B operand for K q^T: K's head-dim slots were packed in
+//   exactly the order the accumulators hold them -- then scores / softmax / P V as in attn_cross_mfma_kernel.
+template <typename T>
+__global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restrict__ y, int ldy, const float2* __restrict__ stats, int nt,
+                                                                float eps, const T* __restrict__ wq, const float* __restrict__ bq,
+                                                                const float* __restrict__ csum, const T* __restrict__ kp,
+                                                                const T* __restrict__ vt, const uint8_t* __restrict__ keymask,
+                                                                T* __restrict__ out, int n_img, int rows_per_img, int S, int D, int H,
+                                                                float scale) {
+    __shared__ __attribute__((aligned(16))) unsigned char wlds[8 * 8192];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = blockIdx.y, img = blockIdx.x * 8 + wave;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int K = D, nslab = K / 64;                                // host: D % 64 == 0, D <= 512
+    // this wave's share of the weight slice: k-slabs wave, wave + 8, ... (8 pieces of 8 rows each)
+    {
+        const int lr = lane >> 3, lpos = lane & 7;
+        for (int sl = wave; sl < nslab; sl += 8)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                dh_lds_dma16(reinterpret_cast<const uint16_t*>(wq) + (size_t)(h * 64 + 8 * i + lr) * K + sl * 64 + (lpos ^ lr) * 8,
+                             wlds + sl * 8192 + i * 1024);
+    }
+    const bool have = img < n_img;                                  // wave-uniform; idle waves still join the barrier
+    const int im = have ? img : 0;
+    const bool live = have && l15 < rows_per_img;
+    const size_t row = (size_t)im * rows_per_img + (live ? l15 : 0);
+    const uint16_t* kb = reinterpret_cast<const uint16_t*>(kp) + ((size_t)im * H + h) * 4096;
+    const uint16_t* vb = reinterpret_cast<const uint16_t*>(vt) + ((size_t)im * H + h) * 4096;
+    uint4 kf[4][2], vf[4][2], yf[8][2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+            vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+        }
+    const uint16_t* yrow = reinterpret_cast<const uint16_t*>(y) + row * ldy;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const uint4 t = *reinterpret_cast<const uint4*>(yrow + min(sl, nslab - 1) * 64 + 32 * kk + 8 * lq);
+            yf[sl][kk] = live ? t : make_uint4(0u, 0u, 0u, 0u);
+        }
+    float4 raw[4], cs4[4], b4[4];
+    ln_load(stats + row * nt, nt, raw);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cs4[j] = *reinterpret_cast<const float4*>(csum + h * 64 + 16 * j + 4 * lq);
+        b4[j] = *reinterpret_cast<const float4*>(bq + h * 64 + 16 * j + 4 * lq);
+    }
+    uint32_t mk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t w = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = 16 * j + 4 * lq + r;
+            w |= (uint32_t)(keymask[im * S + min(key, S - 1)] != 0) << (8 * r);
+        }
+        mk[j] = w;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the weight pieces (LDS-DMA is invisible to the compiler's own waits)
+    __builtin_amdgcn_s_barrier();
+    if (!have) return;
+    dh_f32x4 qacc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qacc[j] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        if (sl < nslab) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int rr = 16 * j + l15;
+                    const uint4 wf = *reinterpret_cast<const uint4*>(wlds + sl * 8192 + rr * 128 + (((kk * 4 + lq) ^ (rr & 7)) << 4));
+                    qacc[j] = Op16<T>::mfma(wf, yf[sl][kk], qacc[j]);          // qacc[j][r] = q[m = l15][d = 16j + 4lq + r]
+                }
+        }
+    }
+    float mu, rstd;
+    ln_math(raw, nt, eps, mu, rstd);
+    uint4 qf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        uint32_t w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float qv[2];
+#pragma unroll
+            for (int z = 0; z < 2; ++z) {
+                const int e = 2 * u + z, j = 2 * kk + (e >> 2), r = e & 3;
+                const float c = r == 0 ? cs4[j].x : r == 1 ? cs4[j].y : r == 2 ? cs4[j].z : cs4[j].w;
+                const float b = r == 0 ? b4[j].x : r == 1 ? b4[j].y : r == 2 ? b4[j].z : b4[j].w;
+                qv[z] = fmaf(rstd, fmaf(-mu, c, qacc[j][r]), b);
+            }
+            w[u] = (uint32_t)Op16<T>::from_f32(qv[0]) | ((uint32_t)Op16<T>::from_f32(qv[1]) << 16);
+        }
+        qf[kk] = live ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint16_t* orow = reinterpret_cast<uint16_t*>(out) + row * D + h * 64;
+    cross_core<T>(kf, vf, qf, mk, S, scale, live, orow, lq);
+}
+
+extern "C" int dh_attn_cross_qproj_decode(const void* y, int ldy, const float* stats, int n_tiles, float eps, const void* wq_folded,
+                                          const float* bq_folded, const float* colsum, const void* kp_dperm, const void* vt,
+                                          const uint8_t* keymask, void* out, int n_img, int rows_per_img, int S, int D, int n_heads,
+                                          float scale, int dtype, void* stream) {
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(y && stats && wq_folded && bq_folded && colsum && kp_dperm && vt && keymask && out && n_img > 0);
+    DH_REQUIRE(rows_per_img > 0 && rows_per_img <= 16 && S > 0 && S <= 64 && n_heads > 0 && D == 64 * n_heads && D <= 512);
+    DH_REQUIRE(n_tiles * 64 == D && n_tiles >= 2 && (n_tiles % 2) == 0 && ldy >= D && (ldy % 8) == 0);
+    DH_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)stats % 16) == 0 && ((uintptr_t)wq_folded % 16) == 0 && ((uintptr_t)bq_folded % 16) == 0 &&
+               ((uintptr_t)colsum % 16) == 0 && ((uintptr_t)kp_dperm % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0);
+    const int rows = n_img * rows_per_img;
+    dh_prof_set_tag("qproj+attn");
+    DhProfScope prof("dh_attn_cross_decode", 2.0 * rows * D * D + 4.0 * rows * S * D,
+                     2.0 * (n_img * S * 2.0 * D + rows * 2.0 * D + (double)D * D), stream);
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL(attn_cross_qproj_kernel<T>, dim3(dh_cdiv(n_img, 8), n_heads), dim3(512), 0, (hipStream_t)stream,
+                                             (const T*)y, ldy, (const float2*)stats, n_tiles, eps, (const T*)wq_folded, bq_folded, colsum,
+                                             (const T*)kp_dperm, (const T*)vt, keymask, (T*)out, n_img, rows_per_img, S, D, n_heads, scale));
+    DH_LAUNCH_CHECK();
+}
+
 // q [n_img * row_si rows, ldq] (image i's rows start at row i * row_si; rows_per_img <= 16 of them are used), out likewise
 // [.., D]; kp / vt from dh_attn_cross_pack.
 static int launch_cross_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out, int n_img,
-                               int rows_per_img, int row_si, int S, int D, int n_heads, float scale, int dtype, hipStream_t s) {
+                               int rows_per_img, int row_si, int S, int D, int n_heads, float scale, int dperm, int dtype, hipStream_t s) {
     const int waves = n_img * n_heads;
     DH_DISPATCH_16(dtype, hipLaunchKernelGGL(attn_cross_mfma_kernel<T>, dim3(dh_cdiv(waves, 4)), dim3(256), 0, s, (const T*)q, ldq,
-                                             (const T*)kp, (const T*)vt, keymask, (T*)out, n_img, rows_per_img, row_si, S, D, n_heads, scale));
+                                             (const T*)kp, (const T*)vt, keymask, (T*)out, n_img, rows_per_img, row_si, S, D, n_heads, scale, dperm));
     return DH_OK;
 }
 
 extern "C" int dh_attn_cross_decode_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
-                                           int n_img, int rows_per_img, int S, int D, int n_heads, float scale, int dtype,
-                                           void* stream) {
+                                           int n_img, int rows_per_img, int S, int D, int n_heads, float scale, int dperm,
+                                           int dtype, void* stream) {
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(q && kp && vt && keymask && out && n_img > 0 && rows_per_img > 0 && rows_per_img <= 16);
     DH_REQUIRE(S > 0 && S <= 64 && n_heads > 0 && D == 64 * n_heads && ldq >= D && (ldq % 8) == 0);
     DH_REQUIRE(((uintptr_t)q % 16) == 0 && ((uintptr_t)kp % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0);
     DhProfScope prof("dh_attn_cross_decode", 4.0 * n_img * rows_per_img * S * D, 2.0 * n_img * (S * 2.0 * D + rows_per_img * 2.0 * D), stream);
-    const int rc = launch_cross_packed(q, ldq, kp, vt, keymask, out, n_img, rows_per_img, rows_per_img, S, D, n_heads, scale, dtype,
-                                       (hipStream_t)stream);
+    const int rc = launch_cross_packed(q, ldq, kp, vt, keymask, out, n_img, rows_per_img, rows_per_img, S, D, n_heads, scale, dperm,
+                                       dtype, (hipStream_t)stream);
     if (rc != DH_OK) return rc;
     DH_LAUNCH_CHECK();
 }
 
 extern "C" int dh_attn_cross_prefill_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
-                                            int n_img, int n_pos, int S, int D, int n_heads, float scale, int dtype, void* stream) {
+                                            int n_img, int n_pos, int S, int D, int n_heads, float scale, int dperm, int dtype,
+                                            void* stream) {
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(q && kp && vt && keymask && out && n_img > 0 && n_pos > 0 && S > 0 && S <= 64 && n_heads > 0 && D == 64 * n_heads);
     DH_REQUIRE(ldq >= D && (ldq % 8) == 0 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)out % 8) == 0);
@@ -881,7 +1041,7 @@ extern "C" int dh_attn_cross_prefill_packed(const void* q, int ldq, const void* 
         const int cnt = n_pos - t0 < 16 ? n_pos - t0 : 16;
         const char* qc = (const char*)q + (size_t)t0 * ldq * 2;
         char* oc = (char*)out + (size_t)t0 * D * 2;
-        const int rc = launch_cross_packed(qc, ldq, kp, vt, keymask, oc, n_img, cnt, n_pos, S, D, n_heads, scale, dtype, (hipStream_t)stream);
+        const int rc = launch_cross_packed(qc, ldq, kp, vt, keymask, oc, n_img, cnt, n_pos, S, D, n_heads, scale, dperm, dtype, (hipStream_t)stream);
         if (rc != DH_OK) return rc;
     }
     DH_LAUNCH_CHECK();

@@ -155,6 +155,34 @@ __device__ __forceinline__ float ldf(const bf16_t* p) { return (float)*p; }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
 
+// ---- deferred LayerNorm: per-(row, 64-column tile) partial statistics {mean, M2} -> the row's mean / rstd ------------------
+// mean and rstd of a row from its nt <= 8 tile partials (each over 64 elements): Chan's parallel combination in a fixed order.
+// Split in two so that the loads can be issued at the top of a kernel and the arithmetic (which waits for them) run in its
+// epilogue: called back to back they would put a full memory round trip in front of the first operand slab.
+__device__ __forceinline__ void ln_load(const float2* st, int nt, float4 (&raw)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) raw[t] = *reinterpret_cast<const float4*>(st + (2 * t < nt ? 2 * t : 0));   // 16-byte loads, clamped
+}
+__device__ __forceinline__ void ln_math(const float4 (&raw)[4], int nt, float eps, float& mu, float& rstd) {
+    float2 v[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { v[2 * t] = make_float2(raw[t].x, raw[t].y); v[2 * t + 1] = make_float2(raw[t].z, raw[t].w); }
+    float ms = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) ms += t < nt ? v[t].x : 0.f;
+    mu = ms / (float)nt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float d = v[t].x - mu;
+        m2 += t < nt ? fmaf(64.f * d, d, v[t].y) : 0.f;
+    }
+    rstd = 1.0f / sqrtf(m2 / (float)(nt * 64) + eps);
+}
+
+typedef const void __attribute__((address_space(1)))* gptr_t;
+typedef void __attribute__((address_space(3)))* lptr_t;
+
 #define DH_DISPATCH_T(dtype, ...)                                             \
     if ((dtype) == DH_F32) { using T = float; __VA_ARGS__; }                  \
     else if ((dtype) == DH_BF16) { using T = bf16_t; __VA_ARGS__; }           \

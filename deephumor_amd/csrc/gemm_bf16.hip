@@ -53,33 +53,6 @@ struct GemmBf16Params {
     float2* o_stats;                                   // out: partial statistics of the OUTPUT rows, [M][N / 64] (requires BN == 64)
 };
 
-// mean and rstd of a row from its nt <= 8 tile partials (each over 64 elements): Chan's parallel combination in a fixed order.
-// Split in two so that the loads can be issued at the top of a kernel and the arithmetic (which waits for them) run in its
-// epilogue: called back to back they would put a full memory round trip in front of the first operand slab.
-__device__ __forceinline__ void ln_load(const float2* st, int nt, float4 (&raw)[4]) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) raw[t] = *reinterpret_cast<const float4*>(st + (2 * t < nt ? 2 * t : 0));   // 16-byte loads, clamped
-}
-__device__ __forceinline__ void ln_math(const float4 (&raw)[4], int nt, float eps, float& mu, float& rstd) {
-    float2 v[8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) { v[2 * t] = make_float2(raw[t].x, raw[t].y); v[2 * t + 1] = make_float2(raw[t].z, raw[t].w); }
-    float ms = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) ms += t < nt ? v[t].x : 0.f;
-    mu = ms / (float)nt;
-    float m2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const float d = v[t].x - mu;
-        m2 += t < nt ? fmaf(64.f * d, d, v[t].y) : 0.f;
-    }
-    rstd = 1.0f / sqrtf(m2 / (float)(nt * 64) + eps);
-}
-
-typedef const void __attribute__((address_space(1)))* gptr_t;
-typedef void __attribute__((address_space(3)))* lptr_t;
-
 // wait until at most `n` of this wave's vector-memory operations (LDS-DMA included) are outstanding
 #define DH_VMCNT_CASE(x) case x: asm volatile("s_waitcnt vmcnt(" #x ")" ::: "memory"); break;
 __device__ __forceinline__ void wait_vmcnt_any(int n) {

@@ -12,7 +12,7 @@ static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const
                            int dt, void* stream) {
     if (L.kp && L.vt && DH_IS_16BIT(dt) && m->S <= 64 && m->D == 64 * m->n_heads && rows_per_img <= 16)
         return dh_attn_cross_decode_packed(q, m->D, L.kp, L.vt, m->keymask, att, n_img, rows_per_img, m->S, m->D, m->n_heads,
-                                           L.ea_scale, dt, stream);
+                                           L.ea_scale, L.kp_dperm, dt, stream);
     return dh_attn_cross_decode(q, m->D, L.kv, m->keymask, att, n_img, rows_per_img, m->S, m->D, m->n_heads, L.ea_scale, dt, stream);
 }
 
@@ -43,12 +43,17 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         const void* yin = sc->o; const float* st_in = sc->st1;               // rows entering the FFN block, LayerNorm pending
         const float *g_in = L.ln1_g, *b_in = L.ln1_b; float eps_in = L.ln1_eps;
         if (m->cross) {
-            // 3. q = LN1(Y1) Wq^T + bq
-            f = dh_ln_fold_t{};
-            f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
-            dh_prof_set_tag("proj");
-            DH_TRY(dh_linear_ln(sc->o, D, L.wq_f, D, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
-            DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
+            // 3. q = LN1(Y1) Wq^T + bq and the attention over the image's patches: ONE launch when K was packed for it
+            if (L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
+                DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
+                                                  n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
+            } else {
+                f = dh_ln_fold_t{};
+                f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
+                dh_prof_set_tag("proj");
+                DH_TRY(dh_linear_ln(sc->o, D, L.wq_f, D, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
+                DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
+            }
             // 4. Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2
             f = dh_ln_fold_t{};
             f.r_stats = sc->st1; f.r_tiles = nt; f.r_eps = L.ln1_eps; f.r_gamma = L.ln1_g; f.r_beta = L.ln1_b; f.o_stats = sc->st2;

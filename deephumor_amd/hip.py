@@ -25,7 +25,8 @@ class TrLayer(_c.Structure):
                                    "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b")]
                 + [(n, _F) for n in ("ln1_eps", "ln2_eps", "ln3_eps", "sa_scale", "ea_scale")] + [("_pad", _I)]
                 + [(n, _P) for n in ("kcache", "vcache", "kv")]
-                + [(n, _P) for n in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1", "kp", "vt")])
+                + [(n, _P) for n in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1", "kp", "vt")]
+                + [("kp_dperm", _I), ("_pad2", _I)])
 
 
 class TrModel(_c.Structure):
@@ -75,9 +76,10 @@ SIGNATURES = {
     "dh_label_mean": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "dh_linear_ln": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
-    "dh_attn_cross_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_attn_cross_decode_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
-    "dh_attn_cross_prefill_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "dh_attn_cross_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
+    "dh_attn_cross_qproj_decode": [_P, _I, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "dh_attn_cross_decode_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "dh_attn_cross_prefill_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dh_conv2d_nhwc_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "dh_conv2d_nhwc_bn_relu_maxpool": [_P, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_embed_rows": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
@@ -398,27 +400,36 @@ def linear_ln(a, w, bias, out=None, residual=None, relu=False, a_ln=None, r_ln=N
     return (out, stats) if want_stats else out
 
 
-def attn_cross_pack(kv, n_img, s, d, n_heads):
-    """kv [n_img*S, 2D] (16-bit) -> (kp, vt) [n_img, n_heads, 64, 64] each: the matrix-core cross-attention layout."""
+def attn_cross_pack(kv, n_img, s, d, n_heads, dperm=False):
+    """kv [n_img*S, 2D] (16-bit) -> (kp, vt) [n_img, n_heads, 64, 64] each: the matrix-core cross-attention layout
+    (``dperm``: K's head-dim slots permuted for ``attn_cross_qproj_decode``)."""
     _dev(kv)
     kp = torch.empty((n_img, n_heads, 64, 64), dtype=kv.dtype, device=kv.device)
     vt = torch.empty_like(kp)
-    _launch("dh_attn_cross_pack", _ptr(kv), _ptr(kp), _ptr(vt), n_img, s, d, n_heads, _dt(kv), _stream())
+    _launch("dh_attn_cross_pack", _ptr(kv), _ptr(kp), _ptr(vt), n_img, s, d, n_heads, int(dperm), _dt(kv), _stream())
     return kp, vt
 
 
-def attn_cross_decode_packed(q, kp, vt, keymask, out, n_img, rows_per_img, s, d, n_heads, scale):
-    _dev(q, kp, vt, keymask, out)
-    _launch("dh_attn_cross_decode_packed", _ptr(q), q.stride(0), _ptr(kp), _ptr(vt), _ptr(keymask), _ptr(out), n_img,
-            rows_per_img, s, d, n_heads, float(scale), _dt(q), _stream())
+def attn_cross_qproj_decode(y, stats, eps, wq_f, bq_f, colsum, kp_dperm, vt, keymask, out, n_img, rows_per_img, s, d, n_heads, scale):
+    """fc_q(LayerNorm(y)) + cross-attention in one launch (deferred-LayerNorm chain): see include/deephumor_hip.h."""
+    _dev(y, stats, wq_f, bq_f, colsum, kp_dperm, vt, keymask, out)
+    _launch("dh_attn_cross_qproj_decode", _ptr(y), y.stride(0), _ptr(stats), d // 64, float(eps), _ptr(wq_f), _ptr(bq_f), _ptr(colsum),
+            _ptr(kp_dperm), _ptr(vt), _ptr(keymask), _ptr(out), n_img, rows_per_img, s, d, n_heads, float(scale), _dt(y), _stream())
     return out
 
 
-def attn_cross_prefill_packed(q, kp, vt, keymask, n_img, n_pos, s, d, n_heads, scale):
+def attn_cross_decode_packed(q, kp, vt, keymask, out, n_img, rows_per_img, s, d, n_heads, scale, dperm=False):
+    _dev(q, kp, vt, keymask, out)
+    _launch("dh_attn_cross_decode_packed", _ptr(q), q.stride(0), _ptr(kp), _ptr(vt), _ptr(keymask), _ptr(out), n_img,
+            rows_per_img, s, d, n_heads, float(scale), int(dperm), _dt(q), _stream())
+    return out
+
+
+def attn_cross_prefill_packed(q, kp, vt, keymask, n_img, n_pos, s, d, n_heads, scale, dperm=False):
     _dev(q, kp, vt, keymask)
     out = torch.empty((n_img * n_pos, d), dtype=q.dtype, device=q.device)
     _launch("dh_attn_cross_prefill_packed", _ptr(q), q.stride(0), _ptr(kp), _ptr(vt), _ptr(keymask), _ptr(out), n_img, n_pos,
-            s, d, n_heads, float(scale), _dt(q), _stream())
+            s, d, n_heads, float(scale), int(dperm), _dt(q), _stream())
     return out
 
 

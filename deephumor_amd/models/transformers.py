@@ -232,7 +232,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             self.dtype = plan["dtype"]
             self.kc = torch.empty((nl, n_pos, self.rows_total, d), device=dev, dtype=self.dtype)
             self.vc = torch.empty((nl, n_pos, self.rows_total, d), device=dev, dtype=self.dtype)
-            self.kv, self.keymask, self.s, self.packed = None, None, 0, None
+            self.kv, self.keymask, self.s, self.packed, self.dperm = None, None, 0, None, False
             if enc_out is not None:
                 n, s, _ = enc_out.shape
                 flat = enc_out.to(self.dtype).contiguous().view(n * s, d)
@@ -241,8 +241,10 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv") for L in plan["layers"]]   # once per image
                 if (self.dtype in hip.HALF_DTYPES and s <= 64 and d == 64 * dec.n_heads and beam <= 16
                         and not os.environ.get("DH_NO_PACKED_CROSS")):
-                    # matrix-core cross-attention: K | V re-laid out per (image, head) in MFMA operand order, once per batch
-                    self.packed = [hip.attn_cross_pack(kv, n, s, d, dec.n_heads) for kv in self.kv]
+                    # matrix-core cross-attention: K | V re-laid out per (image, head) in MFMA operand order, once per batch; on the
+                    # deferred-LayerNorm chain additionally with K's head-dim slots permuted, so that fc_q runs inside the attention launch
+                    self.dperm = "wq_f" in plan["layers"][0] and d <= 512 and not os.environ.get("DH_NO_QPROJ_FUSION")
+                    self.packed = [hip.attn_cross_pack(kv, n, s, d, dec.n_heads, dperm=self.dperm) for kv in self.kv]
             self._scratch = {}
             self.pf = dec.layers[0].pf.fc_1.out_features
             self.d, self.dev = d, dev
@@ -260,7 +262,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     c.ln2_g, c.ln2_b, c.ln2_eps, c.ea_scale = P(L["ln2"][0]), P(L["ln2"][1]), L["ln2"][2], L["ea_scale"]
                     c.kv = P(self.kv[i])
                     if self.packed is not None:
-                        c.kp, c.vt = P(self.packed[i][0]), P(self.packed[i][1])
+                        c.kp, c.vt, c.kp_dperm = P(self.packed[i][0]), P(self.packed[i][1]), int(self.dperm)
                 for name in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1"):
                     if name in L:
                         setattr(c, name, P(L[name]))
@@ -381,8 +383,11 @@ class _IncrementalDecoder(_Planned, nn.Module):
         def cross(q, L):
             kv = hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv")
             if packed_ok:                                  # matrix-core cross-attention, 16 positions per launch
-                kp, vt = hip.attn_cross_pack(kv, bs, s_enc, d, nh)
-                return hip.attn_cross_prefill_packed(q, kp, vt, keymask, bs, seq, s_enc, d, nh, L["ea_scale"])
+                # (dperm: the head-dim slot order of the decode chain's fused fc_q + attention launch, so that teacher-forced
+                # logits and incremental decoding sum in the same order)
+                dperm = "wq_f" in L and not os.environ.get("DH_NO_QPROJ_FUSION")
+                kp, vt = hip.attn_cross_pack(kv, bs, s_enc, d, nh, dperm=dperm)
+                return hip.attn_cross_prefill_packed(q, kp, vt, keymask, bs, seq, s_enc, d, nh, L["ea_scale"], dperm=dperm)
             return hip.attn_cross_prefill(q, kv, keymask, bs, seq, s_enc, d, nh, L["ea_scale"])
 
         if "w1_f" in plan["layers"][0]:

@@ -222,14 +222,27 @@ int dh_attn_cross_decode(const void* q, int ldq, const void* kv, const uint8_t* 
 
 /* The same attention on the matrix cores (16-bit dtypes, head dim 64, S <= 64, rows_per_img <= 16).  dh_attn_cross_pack
  * re-lays kv out ONCE per batch and layer as kp [n_img][n_heads][64 keys][64] and vt [n_img][n_heads][64][64 key slots]
- * (V transposed, key slots permuted into MFMA operand order, keys >= S zero) -- 16 KB per (image, head).  One wave then
+ * (V transposed, key slots permuted into MFMA operand order, keys >= S zero) -- 16 KB per (image, head); dperm != 0
+ * additionally permutes K's head-dim slots for dh_attn_cross_qproj_decode; _decode_packed / _prefill_packed take the same flag
+ * and then read q in that slot order (same summation order as the fused kernel: prefill and decode agree bit for bit).  One wave then
  * handles one (image, head) straight from HBM: no LDS, no barrier, one memory round trip.  _prefill_packed: every
  * position of image n (rows n*n_pos + t), in chunks of 16 positions. */
-int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img, int S, int D, int n_heads, int dtype, void* stream);
+int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img, int S, int D, int n_heads, int dperm, int dtype, void* stream);
+
+/* enc_attn for one decode position WITH its query projection (transformers.py:364 -> 97-127: fc_q, energy, softmax, @v) in one
+ * launch, on the deferred-LayerNorm chain: y [rows, ldy] are the PRE-LayerNorm rows with partial statistics `stats`
+ * [rows][n_tiles][2] (dh_linear_ln's o_stats), wq_folded / bq_folded / colsum are fc_q with the LayerNorm's gamma / beta folded
+ * in (dh_ln_fold_t semantics).  kp_dperm: dh_attn_cross_pack(..., dperm = 1) -- K's head-dim slots in the order the projection's
+ * accumulators hold a q row, so q goes from the MFMA accumulators straight into the K q^T operand.  Workgroup = 8 images x one
+ * head (the head's 64 weight rows staged once in LDS); out [rows, D].  D <= 512, head dim 64, S <= 64, rows_per_img <= 16. */
+int dh_attn_cross_qproj_decode(const void* y, int ldy, const float* stats, int n_tiles, float eps, const void* wq_folded,
+                               const float* bq_folded, const float* colsum, const void* kp_dperm, const void* vt,
+                               const uint8_t* keymask, void* out, int n_img, int rows_per_img, int S, int D, int n_heads,
+                               float scale, int dtype, void* stream);
 int dh_attn_cross_decode_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
-                                int n_img, int rows_per_img, int S, int D, int n_heads, float scale, int dtype, void* stream);
+                                int n_img, int rows_per_img, int S, int D, int n_heads, float scale, int dperm, int dtype, void* stream);
 int dh_attn_cross_prefill_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
-                                 int n_img, int n_pos, int S, int D, int n_heads, float scale, int dtype, void* stream);
+                                 int n_img, int n_pos, int S, int D, int n_heads, float scale, int dperm, int dtype, void* stream);
 
 /* keymask[r] = any(enc_out[r, :] == 0)  (transformers.py:480-481).  enc_out [rows, D]. */
 int dh_enc_key_mask(const void* enc_out, uint8_t* keymask, int rows, int D, int dtype, void* stream);
@@ -374,6 +387,7 @@ typedef struct dh_tr_layer {
     const void *wqkv_f, *wq_f, *w1_f;
     const float *bqkv_f, *bq_f, *b1_f, *cs_qkv, *cs_q, *cs_1;
     const void *kp, *vt;                                    /* optional: kv re-laid out by dh_attn_cross_pack (matrix-core cross-attention) */
+    int kp_dperm, _pad2;                                    /* kp was packed with dperm = 1: the chain fuses fc_q into the attention launch */
 } dh_tr_layer_t;
 
 typedef struct dh_tr_model {

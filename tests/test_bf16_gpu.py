@@ -383,3 +383,41 @@ def test_stem_conv_with_fused_maxpool(hip, n, h, w):
     want = F.max_pool2d(torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), wgt.float().permute(0, 3, 1, 2), stride=2, padding=3)
                                    * sc[None, :, None, None] + sh[None, :, None, None]), 3, 2, 1)
     np.testing.assert_allclose(fused.float().cpu().permute(0, 3, 1, 2).numpy(), want.numpy(), atol=4e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("n_img,beam", [(3, 5), (8, 16), (11, 1), (17, 10)])
+def test_cross_attention_with_fused_query_projection(hip, n_img, beam):
+    """dh_attn_cross_qproj_decode (fc_q on the deferred-LayerNorm rows + attention, one launch, K head-dim slots permuted)
+    against the two-launch route (dh_linear_ln A-fold -> dh_attn_cross_decode_packed) and against fp32 math."""
+    d, h, s = 512, 8, 49
+    r = n_img * beam
+    g = torch.Generator().manual_seed(n_img * 31 + beam)
+    y = bf(torch.randn(r, d, generator=g) * 1.5 + 0.2)
+    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2
+    wq, bq = bf(torch.randn(d, d, generator=g) / d ** 0.5), torch.randn(d, generator=g) * 0.1
+    kv = bf(torch.randn(n_img * s, 2 * d, generator=g))
+    mask = torch.zeros(n_img * s, dtype=torch.uint8)
+    mask[7] = 1
+    t = y.float().view(r, -1, 64)
+    mean = t.mean(-1)
+    stats = torch.stack([mean, ((t - mean[..., None]) ** 2).sum(-1)], -1).contiguous()
+    wf = bf(wq.float() * gamma[None, :])
+    bfold = (bq + (wq.float() * beta[None, :]).sum(1)).contiguous()
+    colsum = wf.float().sum(1).contiguous()
+    kp1, vt = hip.attn_cross_pack(kv.cuda(), n_img, s, d, h, dperm=True)
+    out = torch.full((r, d), 3.0, device="cuda", dtype=HALF)
+    hip.attn_cross_qproj_decode(y.cuda(), stats.cuda(), 1e-5, wf.cuda(), bfold.cuda(), colsum.cuda(), kp1, vt, mask.cuda(), out,
+                                n_img, beam, s, d, h, 8.0)
+    q2 = hip.linear_ln(y.cuda(), wf.cuda(), bfold.cuda(), a_ln=(stats.cuda(), 1e-5, colsum.cuda()))
+    kp0, vt0 = hip.attn_cross_pack(kv.cuda(), n_img, s, d, h)
+    two = torch.empty_like(out)
+    hip.attn_cross_decode_packed(q2, kp0, vt0, mask.cuda(), two, n_img, beam, s, d, h, 8.0)
+    np.testing.assert_allclose(out.float().cpu().numpy(), two.float().cpu().numpy(), atol=3e-2, rtol=2e-2)
+    q32 = F.linear(F.layer_norm(y.float(), (d,), gamma, beta, 1e-5), wq.float(), bq)
+    for row in range(0, r, max(1, r // 7)):
+        i = row // beam
+        keys = kv.float()[i * s:(i + 1) * s, :d].reshape(s, h, 64)
+        vals = kv.float()[i * s:(i + 1) * s, d:].reshape(s, h, 64)
+        energy = (torch.einsum("hd,lhd->hl", q32[row].view(h, 64), keys) / 8.0).masked_fill(mask[i * s:(i + 1) * s].bool()[None], -1e8)
+        ref = torch.einsum("hl,lhd->hd", torch.softmax(energy, -1), vals).reshape(-1)
+        np.testing.assert_allclose(out[row].float().cpu().numpy(), ref.numpy(), atol=6e-2 if HALF == torch.bfloat16 else 1.5e-2, rtol=2e-2)
