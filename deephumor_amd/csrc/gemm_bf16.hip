@@ -598,13 +598,10 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
         // 8 waves (4 x 2, each 32 x 64) on the 128 x 128 tile, 2 workgroups per CU = 4 waves per SIMD: measured
         // 510 TF vs 450 TF with 4 waves per workgroup and 300 TF with one 4-wave workgroup and a deeper ring --
         // the MFMA pipe needs co-resident waves to cover each wave's LDS-read/barrier gaps
-        static const int ns128 = getenv("DH_GEMM128_NS") ? atoi(getenv("DH_GEMM128_NS")) : 2;
-        if (ns128 == 3)
-            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 3, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
-        else if (ns128 == 4)
-            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 4, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
-        else
-            hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
+        // (measured again in round 2 with the LDS ring really asynchronous: 3- / 4-slab rings at one workgroup per CU
+        //  3.6 vs 2.8 ms over the 1x1 convolutions; 256 x 128 tiles with a 3-slab ring 1.80 vs 1.54 ms over the 3x3 ones --
+        //  this one-barrier-per-slab loop needs the second co-resident workgroup)
+        hipLaunchKernelGGL((gemm_bf16_kernel<OT, 128, 128, 4, CONV, 2, 8>), dim3(p.tiles_m * p.tiles_n), dim3(512), 0, s, p);
         return;
     }
     if (p.N <= 64 && p.M >= 256 * 512 && !lnx) {
@@ -673,6 +670,13 @@ int dh_linear_bf16_impl(const void* A, int lda, const void* W, int ldw, const fl
     }
     DH_LAUNCH_CHECK();
 }
+
+
+// (Measured in round 2 and not kept: an output-projection GEMM in which a wave owns <= 16 rows and loads them straight from
+//  HBM / L2 into MFMA B fragments while the tile's 64 weight rows are staged once per workgroup in LDS -- the structure of
+//  dh_attn_cross_qproj_decode's projection part, 256 workgroups at M = 1280.  Bit-identical results, but 4.4 vs 3.9 ms over the
+//  projections of a C3 step and +1.6 ms on the step: fragment-shaped activation loads (20 live lanes x 16 B per instruction)
+//  cost more than the LDS-DMA bytes they save.)
 
 // dh_linear with deferred LayerNorm (include/deephumor_hip.h: dh_ln_fold_t)
 extern "C" int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldres,
@@ -1318,17 +1322,14 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         //  4-slab ring, the two wave halves one barrier apart -- 85 us with LDS-DMA, 170 us register-staged; with 64-byte
         //  row segments every 128-byte line is fetched twice.  scratch/dma_probe shows the LDS-DMA path itself sustains
         //  110-125 GB/s per CU against the ~46 GB/s this kernel draws: DESIGN.md section 9.)
-        static const int vns = getenv("DH_VOCAB_NS") ? atoi(getenv("DH_VOCAB_NS")) : 2;
-        if (vns == 3) {
-            DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 3, 128, 128, 4, 8>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0,
-                                                     (hipStream_t)stream, v));
-        } else if (vns == 256) {
+        // DH_VOCAB_TILE=256: the 256 x 256 kernel (vocab256_kernel).  With the 187 MB of fp32 logits to store both kernels take the
+        // same 86-89 us per launch (store-bound: the stores of a tile cannot overlap the next tile's MFMAs, vmcnt is in-order); where
+        // nothing is stored (dh_vocab_logprob) the bigger tile is the default.
+        static const int vns = getenv("DH_VOCAB_TILE") ? atoi(getenv("DH_VOCAB_TILE")) : 128;
+        if (vns == 256) {
             v.tiles_m = dh_cdiv(M, 256); v.tiles_n = dh_cdiv(V, 256);
             const int nt = v.tiles_m * v.tiles_n;
             DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab256_kernel<T>), dim3(nt < 256 ? nt : 256), dim3(512), 0, (hipStream_t)stream, v));
-        } else if (vns == 4) {
-            DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 4, 128, 128, 4, 8>), dim3(ntiles < 256 ? ntiles : 256), dim3(512), 0,
-                                                     (hipStream_t)stream, v));
         } else {
             DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0,
                                                      (hipStream_t)stream, v));
