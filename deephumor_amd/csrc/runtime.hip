@@ -3,9 +3,16 @@
 // block), FFN, add+LayerNorm] -> vocabulary GEMM), or of an LSTM time step, on the caller's stream.
 // They only sequence the C-ABI entry points above them -- no allocation, no synchronisation -- so the
 // host cost of a 6-layer decode position is one FFI crossing instead of ~70.
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 
+// dh_attn_self_qkv_decode replaces the QKV GEMM + self-attention pair of a decode position only below this many rows: at
+// 1280 rows (256 images x beam 5) it takes 30.5 us against 12.1 + 13.5 us for the pair (its attention part runs 8 waves per CU
+// instead of 40 and is latency-bound), measured per C3 step: 29.4 vs 28.1 ms.  DH_QKV_FUSION_MAX_ROWS overrides.
+#ifndef DH_QKV_FUSION_DEFAULT_MAX_ROWS
+#define DH_QKV_FUSION_DEFAULT_MAX_ROWS 0
+#endif
 #define DH_TRY(call) do { const int rc_ = (call); if (rc_ != DH_OK) return rc_; } while (0)
 
 static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* q, void* att, int n_img, int rows_per_img,
@@ -28,12 +35,21 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         const dh_tr_layer_t& L = m->layers[l];
         const dh_tr_layer_t* P = l > 0 ? &m->layers[l - 1] : nullptr;       // its LN3 is pending on X
         dh_ln_fold_t f{};
-        // 1. qkv = LN3_prev(X) Wqkv^T + b  (layer 0: X is the embedding, no LayerNorm in front)
-        if (P) { f.a_stats = sc->st0; f.a_tiles = nt; f.a_eps = P->ln3_eps; f.a_colsum = L.cs_qkv; }
-        dh_prof_set_tag("qkv");
-        DH_TRY(dh_linear_ln(sc->x, D, P ? L.wqkv_f : L.wqkv, D, P ? L.bqkv_f : L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
-        DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
-                                   row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
+        // 1. qkv = LN3_prev(X) Wqkv^T + b  (layer 0: X is the embedding, no LayerNorm in front) and the self-attention over the
+        //    row's history: ONE launch where the fused kernel applies (head dim 64, <= 6 rows per image, <= 40 positions)
+        static const int qkv_fusion_rows = getenv("DH_QKV_FUSION_MAX_ROWS") ? atoi(getenv("DH_QKV_FUSION_MAX_ROWS")) : DH_QKV_FUSION_DEFAULT_MAX_ROWS;
+        if (rows <= qkv_fusion_rows && D == 64 * m->n_heads && rows_per_img <= 6 && t <= 39) {
+            DH_TRY(dh_attn_self_qkv_decode(sc->x, D, P ? sc->st0 : nullptr, nt, P ? P->ln3_eps : 0.f, P ? L.cs_qkv : nullptr,
+                                           P ? L.wqkv_f : L.wqkv, P ? L.bqkv_f : L.bqkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld,
+                                           sc->att, n_img, rows_per_img, row_mult, rows_total, t, D, m->n_heads, L.sa_scale,
+                                           m->pad_index, dt, stream));
+        } else {
+            if (P) { f.a_stats = sc->st0; f.a_tiles = nt; f.a_eps = P->ln3_eps; f.a_colsum = L.cs_qkv; }
+            dh_prof_set_tag("qkv");
+            DH_TRY(dh_linear_ln(sc->x, D, P ? L.wqkv_f : L.wqkv, D, P ? L.bqkv_f : L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
+            DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
+                                       row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
+        }
         // 2. Y1 = LN3_prev(X) + att Wo^T + bo, statistics of Y1 -> st1
         f = dh_ln_fold_t{};
         if (P) { f.r_stats = sc->st0; f.r_tiles = nt; f.r_eps = P->ln3_eps; f.r_gamma = P->ln3_g; f.r_beta = P->ln3_b; }

@@ -86,6 +86,7 @@ SIGNATURES = {
     "dh_add_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
     "dh_attn_self_decode": [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dh_attn_cross_decode": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
+    "dh_attn_self_qkv_decode": [_P, _I, _P, _I, _F, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dh_enc_key_mask": [_P, _P, _I, _I, _I, _P],
     "dh_pad_mask": [_P, _P, _I, _I, _I, _c.c_longlong, _P],
     "dh_autoregressive_mask": [_P, _I, _I, _P],
@@ -484,6 +485,18 @@ def attn_self_decode(qkv, kcache, vcache, src, tokens, out, n_img, rows_per_img,
     _launch("dh_attn_self_decode", _ptr(qkv), _ptr(kcache), _ptr(vcache), _ptr(src), src.stride(0),
                                       _ptr(tokens), tokens.stride(0), _ptr(out), n_img, rows_per_img, row_mult,
                                       rows_total, t, d, n_heads, float(scale), pad_index, _dt(qkv), _stream())
+    return out
+
+
+def attn_self_qkv_decode(x, wqkv, bqkv, kcache, vcache, src, tokens, out, n_img, rows_per_img, row_mult, rows_total, t, d,
+                         n_heads, scale, pad_index, a_ln=None):
+    """QKV projection + self-attention + cache append in one launch; ``a_ln = (stats, eps, colsum)`` when ``x`` is pre-LayerNorm."""
+    _dev(x, wqkv, bqkv, kcache, vcache, src, tokens, out)
+    st, eps, cs = a_ln if a_ln is not None else (None, 0.0, None)
+    _launch("dh_attn_self_qkv_decode", _ptr(x), x.stride(0), _ptr(st), d // 64, float(eps), _ptr(cs), _ptr(wqkv), _ptr(bqkv),
+            _ptr(kcache), _ptr(vcache), _ptr(src), src.stride(0) if src is not None else 0, _ptr(tokens),
+            tokens.stride(0) if tokens is not None else 0, _ptr(out), n_img, rows_per_img, row_mult, rows_total, t, d, n_heads,
+            float(scale), pad_index, _dt(x), _stream())
     return out
 
 

@@ -212,6 +212,17 @@ int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, const int32
                         int row_mult, int rows_total, int t, int D, int n_heads, float scale,
                         int pad_index, int dtype, void* stream);
 
+/* The same self-attention WITH its QKV projection in one launch (16-bit dtypes; D = 64 * n_heads <= 512, t <= 39,
+ * rows_per_img <= 6): x [rows, ldx] are the layer's input rows -- plain (a_stats == NULL: layer 0, the embedding) or
+ * PRE-LayerNorm with partial statistics a_stats [rows][a_tiles][2] and wqkv / bqkv / colsum gamma- / beta-folded (dh_ln_fold_t
+ * semantics).  Workgroup = 8 images x one head; the head's q / k / v weight slices stream through LDS, q|k|v of the position
+ * never leave the chip except as the cache append.  Outputs (out, kcache, vcache) are bit-identical to dh_linear(_ln) into a
+ * [rows, 3D] buffer followed by dh_attn_self_decode. */
+int dh_attn_self_qkv_decode(const void* x, int ldx, const float* a_stats, int a_tiles, float a_eps, const float* colsum,
+                            const void* wqkv, const float* bqkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
+                            const int32_t* tokens, int tok_ld, void* out, int n_img, int rows_per_img, int row_mult,
+                            int rows_total, int t, int D, int n_heads, float scale, int pad_index, int dtype, void* stream);
+
 /* Single-position multi-head attention over the S image patches (transformers.py:364 -> 97-127).
  *   q [rows, ldq] (first D columns used), kv [n_img*S, 2*D] = fc_k | fc_v of enc_out (computed once
  *   per image), keymask [n_img*S] uint8 (1 = masked: some element of that enc_out row == 0,

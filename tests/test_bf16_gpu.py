@@ -421,3 +421,41 @@ def test_cross_attention_with_fused_query_projection(hip, n_img, beam):
         energy = (torch.einsum("hd,lhd->hl", q32[row].view(h, 64), keys) / 8.0).masked_fill(mask[i * s:(i + 1) * s].bool()[None], -1e8)
         ref = torch.einsum("hl,lhd->hd", torch.softmax(energy, -1), vals).reshape(-1)
         np.testing.assert_allclose(out[row].float().cpu().numpy(), ref.numpy(), atol=6e-2 if HALF == torch.bfloat16 else 1.5e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("n_img,beam,t,folded", [(3, 5, 0, False), (9, 5, 7, True), (8, 1, 3, True), (17, 6, 33, True), (2, 4, 39, False)])
+def test_self_attention_with_fused_qkv_projection(hip, n_img, beam, t, folded):
+    """dh_attn_self_qkv_decode (QKV projection + attention over the KV cache + cache append, one launch) against
+    dh_linear(_ln) -> dh_attn_self_decode: attention output and appended cache rows bit for bit."""
+    d, h, tmax = 512, 8, 40
+    r = n_img * beam
+    g = torch.Generator().manual_seed(n_img * 100 + t)
+    x = bf(torch.randn(r, d, generator=g) * 1.3 + 0.1)
+    w, b = bf(torch.randn(3 * d, d, generator=g) / d ** 0.5), torch.randn(3 * d, generator=g) * 0.1
+    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2
+    kc, vc = bf(torch.randn(tmax + 1, r, d, generator=g)), bf(torch.randn(tmax + 1, r, d, generator=g))
+    src = (torch.arange(r)[:, None] // beam * beam + torch.randint(0, beam, (r, tmax + 1), generator=g)).int()
+    tokens = torch.randint(0, 4, (r, tmax), generator=g, dtype=torch.int32)
+    a_ln = None
+    if folded:
+        tt = x.float().view(r, -1, 64)
+        mean = tt.mean(-1)
+        stats = torch.stack([mean, ((tt - mean[..., None]) ** 2).sum(-1)], -1).contiguous().cuda()
+        wf = bf(w.float() * gamma[None, :]).cuda()
+        bfold = (b + (w.float() * beta[None, :]).sum(1)).contiguous().cuda()
+        colsum = wf.float().sum(1).contiguous()
+        a_ln = (stats, 1e-5, colsum)
+    else:
+        wf, bfold = w.cuda(), b.cuda()
+    outs = []
+    for fused in (False, True):
+        kcd, vcd = kc.cuda().clone(), vc.cuda().clone()
+        out = torch.full((r, d), 5.0, device="cuda", dtype=HALF)
+        if fused:
+            hip.attn_self_qkv_decode(x.cuda(), wf, bfold, kcd, vcd, src.cuda(), tokens.cuda(), out, n_img, beam, 1, r, t, d, h, 8.0, 0, a_ln=a_ln)
+        else:
+            qkv = hip.linear_ln(x.cuda(), wf, bfold, a_ln=a_ln)
+            hip.attn_self_decode(qkv, kcd, vcd, src.cuda(), tokens.cuda(), out, n_img, beam, 1, r, t, d, h, 8.0, 0)
+        outs.append((out.cpu(), kcd[t].cpu(), vcd[t].cpu(), kcd[t + 1 if t < tmax else 0].cpu()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
