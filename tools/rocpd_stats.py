@@ -20,13 +20,50 @@ def load(path):
     return list(c.execute(q))
 
 
+def load_pmc(path):
+    """-> {counter name: {(kernel, workgroups, block): [values per dispatch]}} from a `rocprofv3 --pmc ... --kernel-trace` database."""
+    c = sqlite3.connect(path)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    pe = [t for t in tabs if t.startswith("rocpd_pmc_event")][0]
+    ip = [t for t in tabs if t.startswith("rocpd_info_pmc")][0]
+    q = (f"select i.name, s.kernel_name, d.grid_size_x * d.grid_size_y * d.grid_size_z / d.workgroup_size_x, d.workgroup_size_x, e.value "
+         f"from {pe} e join {ip} i on e.pmc_id = i.id join {kd} d on e.event_id = d.event_id join {ks} s on d.kernel_id = s.id")
+    out = defaultdict(lambda: defaultdict(list))
+    for cname, kname, wgs, blk, val in c.execute(q):
+        out[cname][(kname, wgs, blk)].append(val)
+    return out
+
+
+def main_pmc(a):
+    data = load_pmc(a.db)
+    rows = []
+    for cname, per in data.items():
+        for (kname, wgs, blk), vals in per.items():
+            rows.append(dict(counter=cname, name=kname, workgroups=wgs, block=blk, launches=len(vals), avg=sum(vals) / len(vals),
+                             total=sum(vals)))
+    rows.sort(key=lambda r: (r["counter"], -r["total"]))
+    if a.csv:
+        with open(a.csv, "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+    for r in rows[:a.top]:
+        nm = r["name"] if len(r["name"]) < 80 else r["name"][:77] + "..."
+        print(f"{r['counter']:28s} avg {r['avg']:14.1f}  x{r['launches']:<5} wg={r['workgroups']:<6} {nm}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("db")
+    ap.add_argument("--pmc", action="store_true", help="per-kernel averages of the hardware counters of a --pmc run")
     ap.add_argument("--by-grid", action="store_true")
     ap.add_argument("--csv")
     ap.add_argument("--top", type=int, default=40)
     a = ap.parse_args()
+    if a.pmc:
+        return main_pmc(a)
     rows = load(a.db)
     agg = defaultdict(list)
     for name, st, en, gx, gy, gz, wx, lds, vg, ag in rows:
