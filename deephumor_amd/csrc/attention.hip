@@ -888,12 +888,14 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
                                                                 const T* __restrict__ vt, const uint8_t* __restrict__ keymask,
                                                                 T* __restrict__ out, int n_img, int rows_per_img, int S, int D, int H,
                                                                 float scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char wlds[8 * 8192];
+    __shared__ __attribute__((aligned(16))) unsigned char wlds[8 * 8192 + 512];
+    float* cb = reinterpret_cast<float*>(wlds + 8 * 8192);          // colsum | bias of the head's 64 columns
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = blockIdx.y, img = blockIdx.x * 8 + wave;
     const int l15 = lane & 15, lq = lane >> 4;
     const int K = D, nslab = K / 64;                                // host: D % 64 == 0, D <= 512
+    if (threadIdx.x < 64) { cb[threadIdx.x] = csum[h * 64 + threadIdx.x]; cb[64 + threadIdx.x] = bq[h * 64 + threadIdx.x]; }
     // this wave's share of the weight slice: k-slabs wave, wave + 8, ... (8 pieces of 8 rows each)
     {
         const int lr = lane >> 3, lpos = lane & 7;
@@ -925,13 +927,8 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
             const uint4 t = *reinterpret_cast<const uint4*>(yrow + min(sl, nslab - 1) * 64 + 32 * kk + 8 * lq);
             yf[sl][kk] = live ? t : make_uint4(0u, 0u, 0u, 0u);
         }
-    float4 raw[4], cs4[4], b4[4];
+    float4 raw[4];
     ln_load(stats + row * nt, nt, raw);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        cs4[j] = *reinterpret_cast<const float4*>(csum + h * 64 + 16 * j + 4 * lq);
-        b4[j] = *reinterpret_cast<const float4*>(bq + h * 64 + 16 * j + 4 * lq);
-    }
     uint32_t mk[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -943,27 +940,41 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
         }
         mk[j] = w;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the weight pieces (LDS-DMA is invisible to the compiler's own waits)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // the weight pieces (LDS-DMA is invisible to the compiler's own waits)
     __builtin_amdgcn_s_barrier();
     if (!have) return;
     dh_f32x4 qacc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) qacc[j] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
+    // weight fragments of half-slab t + 1 are read while the 4 MFMAs of half-slab t run (two register sets)
+    uint4 wf[2][4];
+    auto read_w = [&](int buf, int t) {
 #pragma unroll
-    for (int sl = 0; sl < 8; ++sl) {
-        if (sl < nslab) {
+        for (int j = 0; j < 4; ++j) {
+            const int rr = 16 * j + l15;
+            wf[buf][j] = *reinterpret_cast<const uint4*>(wlds + (t >> 1) * 8192 + rr * 128 + ((((t & 1) * 4 + lq) ^ (rr & 7)) << 4));
+        }
+    };
+    read_w(0, 0);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+    for (int t = 0; t < 16; ++t) {
+        if (t < 2 * nslab) {
+            if (t + 1 < 2 * nslab) read_w((t + 1) & 1, t + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int rr = 16 * j + l15;
-                    const uint4 wf = *reinterpret_cast<const uint4*>(wlds + sl * 8192 + rr * 128 + (((kk * 4 + lq) ^ (rr & 7)) << 4));
-                    qacc[j] = Op16<T>::mfma(wf, yf[sl][kk], qacc[j]);          // qacc[j][r] = q[m = l15][d = 16j + 4lq + r]
-                }
+            for (int j = 0; j < 4; ++j)
+                qacc[j] = Op16<T>::mfma(wf[t & 1][j], yf[t >> 1][t & 1], qacc[j]);   // qacc[j][r] = q[m = l15][d = 16j + 4lq + r]
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     float mu, rstd;
     ln_math(raw, nt, eps, mu, rstd);
+    float4 cs4[4], b4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        cs4[j] = *reinterpret_cast<const float4*>(cb + 16 * j + 4 * lq);
+        b4[j] = *reinterpret_cast<const float4*>(cb + 64 + 16 * j + 4 * lq);
+    }
     uint4 qf[2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
