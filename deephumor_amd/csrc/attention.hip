@@ -895,7 +895,6 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
     const int h = blockIdx.y, img = blockIdx.x * 8 + wave;
     const int l15 = lane & 15, lq = lane >> 4;
     const int K = D, nslab = K / 64;                                // host: D % 64 == 0, D <= 512
-    if (threadIdx.x < 64) { cb[threadIdx.x] = csum[h * 64 + threadIdx.x]; cb[64 + threadIdx.x] = bq[h * 64 + threadIdx.x]; }
     // this wave's share of the weight slice: k-slabs wave, wave + 8, ... (8 pieces of 8 rows each)
     {
         const int lr = lane >> 3, lpos = lane & 7;
@@ -912,20 +911,16 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
     const uint16_t* kb = reinterpret_cast<const uint16_t*>(kp) + ((size_t)im * H + h) * 4096;
     const uint16_t* vb = reinterpret_cast<const uint16_t*>(vt) + ((size_t)im * H + h) * 4096;
     uint4 kf[4][2], vf[4][2], yf[8][2];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
-            vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
-        }
+    float cbv[2] = {0.f, 0.f};
+    if (threadIdx.x < 64) { cbv[0] = csum[h * 64 + threadIdx.x]; cbv[1] = bq[h * 64 + threadIdx.x]; }
     const uint16_t* yrow = reinterpret_cast<const uint16_t*>(y) + row * ldy;
 #pragma unroll
     for (int sl = 0; sl < 8; ++sl)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            const uint4 t = *reinterpret_cast<const uint4*>(yrow + min(sl, nslab - 1) * 64 + 32 * kk + 8 * lq);
-            yf[sl][kk] = live ? t : make_uint4(0u, 0u, 0u, 0u);
+            // lanes past the image's rows carry a copy of its row 0: every output row depends on its own input row only, and
+            // theirs are never stored (a select on the loaded value here would make the compiler drain the queue mid-issue)
+            yf[sl][kk] = *reinterpret_cast<const uint4*>(yrow + min(sl, nslab - 1) * 64 + 32 * kk + 8 * lq);
         }
     float4 raw[4];
     ln_load(stats + row * nt, nt, raw);
@@ -940,7 +935,19 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
         }
         mk[j] = w;
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");    // the weight pieces (LDS-DMA is invisible to the compiler's own waits)
+    // K and V last: vector-memory operations retire in order, so waiting until only these 16 loads are outstanding covers the
+    // weight pieces (issued first; LDS-DMA is invisible to the compiler's own waits) and leaves K / V in flight under the projection
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+            vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+    if (threadIdx.x < 64) { cb[threadIdx.x] = cbv[0]; cb[64 + threadIdx.x] = cbv[1]; }
+    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (!have) return;
     dh_f32x4 qacc[4];

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Reduce the per-kernel PMC CSVs of tools/collect_profiles.sh to profiles/r2/pmc_hbm_traffic.json, the file bench.py reads
+for `roofline.traffic` (rocprofv3 --pmc cannot run inside the bench process).
+
+traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE, both counters in KB: on gfx950 FETCH_SIZE tallies the 128-byte requests of
+wide coalesced reads at 64 bytes and has to be doubled, WRITE_SIZE is exact for 16-byte-per-lane stores
+(/opt/skills/guides/MI355X_MICROARCH.md, HBM section).  Separate passes per counter (they cannot share one on gfx950).
+
+    python tools/make_pmc_json.py profiles/r2 [commit]
+"""
+import csv
+import json
+import subprocess
+import sys
+from pathlib import Path
+
+# bench.py roofline key -> (workload, kernel-name fragment, workgroups or None, note)
+KEYS = [
+    ("c2", "dh_linear[vocab]{1280x36541x512}", "vocab_logits_kernel", 512,
+     "persistent 128x128-tile vocabulary GEMM + bias, fp32 logits out; fetch above W + A = other XCDs' L2 misses on W"),
+    ("c3", "dh_linear[vocab]{320x36541x512}", "vocab_logits_kernel", 512, "same kernel at M = 320 rows"),
+    ("c3", "dh_attn_self_decode", "attn_decode_reg_kernel", 2048,
+     "launch-weighted mean over the history depths of one sweep (2..22 keys per row)"),
+    ("c3", "dh_attn_cross_decode", "attn_cross_qproj_kernel", 256,
+     "fused fc_q + cross-attention launch: includes the 8 x 64 KB fc_q weight slices every workgroup stages"),
+]
+
+
+def rows(path):
+    with open(path) as f:
+        return list(csv.DictReader(f))
+
+
+def mean_kb(rs, frag, wgs):
+    sel = [r for r in rs if frag in r["name"] and (wgs is None or int(r["workgroups"]) == wgs)]
+    n = sum(int(r["launches"]) for r in sel)
+    return (sum(float(r["total"]) for r in sel) / n, n) if n else (None, 0)
+
+
+def main():
+    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r2")
+    commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(
+        ["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    out = {"commit": commit,
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace; traffic = "
+                     "(2 * FETCH_SIZE + WRITE_SIZE) KB * 1024 per launch (gfx950 FETCH_SIZE correction of the micro-arch guide)"}
+    for wl, key, frag, wgs, note in KEYS:
+        f, nf = mean_kb(rows(d / f"pmc_{wl}_FETCH_SIZE.csv"), frag, wgs)
+        w, nw = mean_kb(rows(d / f"pmc_{wl}_WRITE_SIZE.csv"), frag, wgs)
+        if f is None or w is None:
+            continue
+        out.setdefault(wl, {})[key] = {
+            "traffic_bytes_per_launch": (2 * f + w) * 1024, "fetch_size_kb_raw": f, "write_size_kb": w,
+            "launches_fetch_pass": nf, "launches_write_pass": nw, "note": note}
+    json.dump(out, open(d / "pmc_hbm_traffic.json", "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
