@@ -765,7 +765,7 @@ extern "C" int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img,
 
 // scores -> softmax -> P V of one (image, head) from preloaded fragments (shared by the two matrix-core kernels below)
 template <typename T>
-__device__ __forceinline__ void cross_core(const uint4 (&kf)[4][2], const uint4 (&vf)[4][2], const uint4 (&qf)[2], const uint32_t (&mk)[4],
+__device__ __forceinline__ void cross_core(const uint4 (&kf)[4][2], const uint4 (&vf)[4][2], const uint4 (&qf)[2], const uint64_t kbits,
                                            int S, float scale, bool live, uint16_t* orow, int lq) {
     dh_f32x4 sacc[4];
 #pragma unroll
@@ -781,7 +781,7 @@ __device__ __forceinline__ void cross_core(const uint4 (&kf)[4][2], const uint4 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int key = 16 * j + 4 * lq + r;
-            const bool masked = (mk[j] >> (8 * r)) & 0xFFu;
+            const bool masked = (kbits >> key) & 1ull;
             e[j][r] = key < S ? (masked ? -1e8f : sacc[j][r] / scale) : -INFINITY;
             mx = fmaxf(mx, e[j][r]);
         }
@@ -855,19 +855,9 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const T* __restric
         }
         qf[kk] = live ? t : make_uint4(0u, 0u, 0u, 0u);
     }
-    uint32_t mk[4];                                                 // mask bytes of keys 16j + 4lq .. + 3 (clamped reads)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t w = 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * j + 4 * lq + r;
-            w |= (uint32_t)(keymask[img * S + min(key, S - 1)] != 0) << (8 * r);
-        }
-        mk[j] = w;
-    }
+    const uint64_t kbits = __ballot(keymask[img * S + min(lane, S - 1)] != 0);     // bit key = that key is masked (one byte per lane)
     uint16_t* orow = reinterpret_cast<uint16_t*>(out) + qrow * D + h * 64;
-    cross_core<T>(kf, vf, qf, mk, S, scale, live, orow, lq);
+    cross_core<T>(kf, vf, qf, kbits, S, scale, live, orow, lq);
 }
 
 // ---- query projection + cross-attention in one launch (decode chain of the 16-bit Transformer decoder) -----------------------
@@ -924,17 +914,7 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
         }
     float4 raw[4];
     ln_load(stats + row * nt, nt, raw);
-    uint32_t mk[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t w = 0u;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = 16 * j + 4 * lq + r;
-            w |= (uint32_t)(keymask[im * S + min(key, S - 1)] != 0) << (8 * r);
-        }
-        mk[j] = w;
-    }
+    const uint8_t mbyte = keymask[im * S + min(lane, S - 1)];       // one byte per lane; balloted into a 64-bit key mask below
     // K and V last: vector-memory operations retire in order, so waiting until only these 16 loads are outstanding covers the
     // weight pieces (issued first; LDS-DMA is invisible to the compiler's own waits) and leaves K / V in flight under the projection
     __builtin_amdgcn_sched_barrier(0);
@@ -1001,7 +981,7 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
         qf[kk] = live ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
     }
     uint16_t* orow = reinterpret_cast<uint16_t*>(out) + row * D + h * 64;
-    cross_core<T>(kf, vf, qf, mk, S, scale, live, orow, lq);
+    cross_core<T>(kf, vf, qf, __ballot(mbyte != 0), S, scale, live, orow, lq);
 }
 
 extern "C" int dh_attn_cross_qproj_decode(const void* y, int ldy, const float* stats, int n_tiles, float eps, const void* wq_folded,
