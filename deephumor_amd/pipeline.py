@@ -13,6 +13,8 @@ so that the copy and the encoder of the next batch fill the CUs / the PCIe link 
 Captions are the ones ``generate_batch`` gives for the same ``seed`` / ``img0`` (the streams only reorder independent
 work).  Nothing here computes: every operation is a kernel of libdeephumor_hip.so or a copy.
 """
+import os
+
 import torch
 
 __all__ = ["CaptionPipeline"]
@@ -23,7 +25,9 @@ class CaptionPipeline:
         self.model, self.gen_kw, self.overlap = model, gen_kw, overlap
         self.dev = next(model.parameters()).device
         if overlap:
-            self.copy_s, self.enc_s, self.dec_s = (torch.cuda.Stream(device=self.dev) for _ in range(3))
+            # the decode chain's short launches go first whenever both streams have work ready
+            self.copy_s, self.enc_s = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
+            self.dec_s = torch.cuda.Stream(device=self.dev, priority=-1 if os.environ.get("DH_PIPE_NO_PRIO") is None else 0)
         else:
             self.copy_s = self.enc_s = self.dec_s = torch.cuda.current_stream(self.dev)
         self._dev_in = {}            # (slot, shape, dtype) -> device staging tensor (double-buffered)
