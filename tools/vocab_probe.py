@@ -1,0 +1,25 @@
+"""Developer probe: the classifier GEMM at the decode shape (1280 rows x 36541 tokens x 512) with and without the logits
+store (dh_vocab_logits vs dh_vocab_logprob), for the tile size selected by DH_VOCAB_TILE / DH_LOGPROB_TILE."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from deephumor_amd import hip
+hip.load()
+dev = "cuda"
+M, V, K = int(os.environ.get("KB_M", 1280)), int(os.environ.get("KB_V", 36541)), int(os.environ.get("KB_K", 512))
+DT = {"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("KB_DTYPE", "bf16")]
+a = [(torch.randn(M, K, device=dev)).to(DT) for _ in range(4)]
+w = (torch.randn(V, K, device=dev) * K ** -0.5).to(DT)
+b = torch.zeros(V, device=dev)
+ldl = (V + 3) // 4 * 4
+logits = torch.empty(M, ldl, device=dev)[:, :V]
+gm = torch.empty(M, hip.n_groups(V), device=dev)
+tg = torch.randint(0, V, (M,), device=dev)
+def timeit(fn, iters=40, warm=5):
+    for i in range(warm): fn(i)
+    torch.cuda.synchronize()
+    with hip.profile() as prof:
+        for i in range(iters): fn(i)
+        torch.cuda.synchronize()
+    return {k: round(v["ms"] / v["calls"] * 1e3, 1) for k, v in prof.summary().items()}
+print("logits ", os.environ.get("DH_VOCAB_TILE", "128"), timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, logits, gm)))
+print("logprob", os.environ.get("DH_LOGPROB_TILE", "auto"), timeit(lambda i: hip.vocab_logprob(a[i % 4], w, b, tg)))
