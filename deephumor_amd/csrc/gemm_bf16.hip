@@ -831,7 +831,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
     constexpr int TM = WM / 16, TN = WN / 16;
     constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW), G = IA + IB;
     constexpr int N_STORE_MAX = TM * TN + TM;                      // stores of one interior-tile epilogue, per wave
-    const int N_STORE = TM * TN + (p.gmax ? TM : 0);               // (group maxima are optional: plain fp32-output GEMM)
+    const int N_STORE = (p.C ? TM * TN : 0) + (p.gmax ? TM : 0);   // (group maxima are optional: plain fp32-output GEMM; so are the logits)
     static_assert((NS - 2) * G + N_STORE_MAX + 1 <= 63, "vmcnt encoding");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NS * SLAB + NW * 256];
     unsigned char* bias_lds = lds + NS * SLAB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * 256;   // wave-private
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
                     vb.x = acc[2 * h + 1][i][0] + b4[2 * h + 1].x; vb.y = acc[2 * h + 1][i][1] + b4[2 * h + 1].y;
                     vb.z = acc[2 * h + 1][i][2] + b4[2 * h + 1].z; vb.w = acc[2 * h + 1][i][3] + b4[2 * h + 1].w;
                     mxv = fmaxf(fmaxf(mxv, fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w))), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
-                    store_half_full_lines(r_even + 32 * h, p.ldc, va, vb, l15 & 1);
+                    if (p.C) store_half_full_lines(r_even + 32 * h, p.ldc, va, vb, l15 & 1);
                 }
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
                         if (n < p.N) {
                             const float v = acc[j][i][rr] + bj[rr];
                             mxv = fmaxf(mxv, v);
-                            if (m < p.M) p.C[(size_t)m * p.ldc + n] = v;
+                            if (m < p.M && p.C) p.C[(size_t)m * p.ldc + n] = v;
                         }
                     }
                 }
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(512, 1) void vocab256_kernel(VocabParams p) {
     constexpr int A_BYTES = BM * 128, SLAB = A_BYTES + BN * 128;          // 64 KB
     constexpr int TM = 8, TN = 4, G = 8;                                  // LDS-DMA pieces per wave per slab: 4 A + 4 B
     constexpr int N_STORE_MAX = TM * TN + TM;
-    const int N_STORE = TM * TN + (p.gmax ? TM : 0);
+    const int N_STORE = (p.C ? TM * TN : 0) + (p.gmax ? TM : 0);
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * SLAB + NW * 256];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(512, 1) void vocab256_kernel(VocabParams p) {
                     vb.x = acc[2 * h + 1][i][0] + b4[2 * h + 1].x; vb.y = acc[2 * h + 1][i][1] + b4[2 * h + 1].y;
                     vb.z = acc[2 * h + 1][i][2] + b4[2 * h + 1].z; vb.w = acc[2 * h + 1][i][3] + b4[2 * h + 1].w;
                     mxv = fmaxf(fmaxf(mxv, fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w))), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
-                    store_half_full_lines(r_even + 32 * h, p.ldc, va, vb, l15 & 1);
+                    if (p.C) store_half_full_lines(r_even + 32 * h, p.ldc, va, vb, l15 & 1);
                 }
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
                 mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
@@ -1265,7 +1265,7 @@ __global__ __launch_bounds__(512, 1) void vocab256_kernel(VocabParams p) {
                         if (n < p.N) {
                             const float v = acc[j][i][rr] + bj[rr];
                             mxv = fmaxf(mxv, v);
-                            if (m < p.M) p.C[(size_t)m * p.ldc + n] = v;
+                            if (m < p.M && p.C) p.C[(size_t)m * p.ldc + n] = v;
                         }
                     }
                 }
@@ -1324,13 +1324,14 @@ extern "C" int dh_conv1x1_dual_nhwc(const void* y, const void* x, const void* w,
 extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float* bias, float* logits, int ldl,
                                float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream) {
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
-    DH_REQUIRE(A && W && logits && group_max && M > 0 && V > 0 && K > 0 && ldl >= V && gm_ld >= 2 * dh_cdiv(V, 128));
+    DH_REQUIRE(A && W && group_max && M > 0 && V > 0 && K > 0 && (!logits || ldl >= V) && gm_ld >= 2 * dh_cdiv(V, 128));
+    DH_REQUIRE(logits || (K >= 128 && (K % 64) == 0));                  // group maxima only: the persistent kernels
     DH_REQUIRE((K % 8) == 0 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0);
     dh_prof_set_tag("vocab");
     dh_prof_set_dims(M, V, K);
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);
-    if ((ldl % 4) == 0 && ((uintptr_t)logits % 16) == 0 && K >= 128 && (K % 64) == 0) {
+    if ((!logits || ((ldl % 4) == 0 && ((uintptr_t)logits % 16) == 0)) && K >= 128 && (K % 64) == 0) {
         VocabParams v{};
         v.A = (const uint16_t*)A; v.lda = lda; v.W = (const uint16_t*)W; v.ldw = ldw; v.bias = bias;
         v.C = logits; v.ldc = ldl; v.gmax = group_max; v.gmax_ld = gm_ld; v.M = M; v.N = V; v.K = K;
@@ -1352,10 +1353,14 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         // same 86-89 us per launch (store-bound: the stores of a tile cannot overlap the next tile's MFMAs, vmcnt is in-order); where
         // nothing is stored (dh_vocab_logprob) the bigger tile is the default.
         static const int vns = getenv("DH_VOCAB_TILE") ? atoi(getenv("DH_VOCAB_TILE")) : 128;
-        if (vns == 256) {
+        static const int gns = getenv("DH_VOCAB_GMAX_TILE") ? atoi(getenv("DH_VOCAB_GMAX_TILE")) : 256;
+        if ((logits ? vns : gns) == 256 && (logits || M >= 512)) {
             v.tiles_m = dh_cdiv(M, 256); v.tiles_n = dh_cdiv(V, 256);
             const int nt = v.tiles_m * v.tiles_n;
             DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab256_kernel<T>), dim3(nt < 256 ? nt : 256), dim3(512), 0, (hipStream_t)stream, v));
+        } else if (vns == 1284) {       // 4 waves of 64 x 64 per 128 x 128 tile (less LDS read traffic per MFMA), 2 workgroups per CU
+            DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 2, 4>), dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0,
+                                                     (hipStream_t)stream, v));
         } else {
             DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0,
                                                      (hipStream_t)stream, v));

@@ -622,7 +622,8 @@ def vocab_logits(a, w, bias, logits, group_max):
     _dev(a, w, bias, logits, group_max)
     m, k = a.shape
     v = w.shape[0]
-    _launch("dh_vocab_logits", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(logits), logits.stride(0),
+    _launch("dh_vocab_logits", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(logits),
+            logits.stride(0) if logits is not None else 0,
             _ptr(group_max), group_max.stride(0), m, v, k, _dt(a), _stream())
 
 

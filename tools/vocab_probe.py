@@ -22,4 +22,5 @@ def timeit(fn, iters=40, warm=5):
         torch.cuda.synchronize()
     return {k: round(v["ms"] / v["calls"] * 1e3, 1) for k, v in prof.summary().items()}
 print("logits ", os.environ.get("DH_VOCAB_TILE", "128"), timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, logits, gm)))
+print("gmax   ", os.environ.get("DH_VOCAB_GMAX_TILE", "256"), timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, None, gm)))
 print("logprob", os.environ.get("DH_LOGPROB_TILE", "auto"), timeit(lambda i: hip.vocab_logprob(a[i % 4], w, b, tg)))
