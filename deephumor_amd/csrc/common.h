@@ -6,6 +6,7 @@
 
 #define DH_WAVE 64
 
+#define DH_TRY(call) do { const int rc_ = (call); if (rc_ != DH_OK) return rc_; } while (0)
 #define DH_REQUIRE(cond) do { if (!(cond)) return DH_ERR_BAD_ARG; } while (0)
 #define DH_LAUNCH_CHECK() do { return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH; } while (0)
 

@@ -13,7 +13,6 @@
 #ifndef DH_QKV_FUSION_DEFAULT_MAX_ROWS
 #define DH_QKV_FUSION_DEFAULT_MAX_ROWS 0
 #endif
-#define DH_TRY(call) do { const int rc_ = (call); if (rc_ != DH_OK) return rc_; } while (0)
 
 static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* q, void* att, int n_img, int rows_per_img,
                            int dt, void* stream) {
