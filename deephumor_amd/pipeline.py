@@ -25,9 +25,10 @@ class CaptionPipeline:
         self.model, self.gen_kw, self.overlap = model, gen_kw, overlap
         self.dev = next(model.parameters()).device
         if overlap:
-            # the decode chain's short launches go first whenever both streams have work ready
+            # (a high-priority decode stream -- DH_PIPE_PRIO=1 -- was measured: no gain, the encoder's workgroups hold the CUs
+            #  until they retire whatever the queue priority)
             self.copy_s, self.enc_s = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
-            self.dec_s = torch.cuda.Stream(device=self.dev, priority=-1 if os.environ.get("DH_PIPE_NO_PRIO") is None else 0)
+            self.dec_s = torch.cuda.Stream(device=self.dev, priority=-1 if os.environ.get("DH_PIPE_PRIO") else 0)
         else:
             self.copy_s = self.enc_s = self.dec_s = torch.cuda.current_stream(self.dev)
         self._dev_in = {}            # (slot, shape, dtype) -> device staging tensor (double-buffered)

@@ -18,7 +18,7 @@ from pathlib import Path
 KEYS = [
     ("c2", "dh_linear[vocab]{1280x36541x512}", "vocab_logits_kernel", 512,
      "persistent 128x128-tile vocabulary GEMM + bias, fp32 logits out; fetch above W + A = other XCDs' L2 misses on W"),
-    ("c3", "dh_linear[vocab]{320x36541x512}", "vocab_logits_kernel", 512, "same kernel at M = 320 rows"),
+    ("c3", "dh_linear[vocab]{1280x36541x512}", "vocab_logits_kernel", 512, "same kernel, same shape (256 images x 5 beams)"),
     ("c3", "dh_attn_self_decode", "attn_decode_reg_kernel", 2048,
      "launch-weighted mean over the history depths of one sweep (2..22 keys per row)"),
     ("c3", "dh_attn_cross_decode", "attn_cross_qproj_kernel", 256,
