@@ -34,7 +34,12 @@ struct LstmFusedParams {
 __device__ __forceinline__ void lf_wait_vmcnt(int n) {
     switch (n) {
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+        case 28: asm volatile("s_waitcnt vmcnt(28)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
@@ -48,11 +53,14 @@ __device__ __forceinline__ float lf_tanh(float x) {
     return copysignf(t, x);
 }
 
-template <typename OT, int NS>
+// BM = 64 (default): 64 x 64 tiles (640 workgroups at 1280 rows x 2048 gate columns, 2-3 per CU).  BM = 160 (opt-in, see the
+// entry point): 160 x 64 tiles, 80 x 32 per wave -- at 1280 rows exactly 256 workgroups, one per CU.
+template <typename OT, int NS, int BM = 64>
 __global__ __launch_bounds__(256) void lstm_layer_fused_kernel(LstmFusedParams p) {
-    constexpr int BM = 64, BN = 64, BK = 64, NW = 4, WAVES_M = 2;
+    constexpr int BN = 64, BK = 64, NW = 4, WAVES_M = 2;
     constexpr int A_BYTES = BM * 128, SLAB = A_BYTES + BN * 128;
-    constexpr int WM = 32, WN = 32, TM = 2, TN = 2;
+    constexpr int WM = BM / WAVES_M, WN = 32, TM = WM / 16, TN = 2;
+    static_assert(BM % (8 * NW) == 0 && WM % 16 == 0, "tile shape");
     constexpr int IA = BM / (8 * NW), IB = BN / (8 * NW), G = IA + IB;      // 2 + 2 LDS-DMA instructions per wave per slab
     __shared__ __attribute__((aligned(16))) unsigned char lds[NS * SLAB];
 
@@ -77,7 +85,7 @@ __global__ __launch_bounds__(256) void lstm_layer_fused_kernel(LstmFusedParams p
     bool a_ok[IA];
     // every index load of the kernel first (token ids and beam parents of the loader's rows, beam parents of the
     // epilogue's rows), at clamped rows and without branches: one memory round trip for all of them
-    constexpr int TM_ = 2;
+    constexpr int TM_ = TM;
     int tok_i[IA], hp_i[IA], hp_e[TM_];
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
@@ -227,12 +235,27 @@ extern "C" int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const
     p.W = (const uint16_t*)w_il; p.bias = b_il; p.rows = rows; p.row_mult = row_mult; p.E = E; p.Hh = Hh;
     p.tiles_m = dh_cdiv(rows, 64); p.tiles_n = dh_cdiv(4 * Hh, 64);
     const double K = E + Hh;
+    // 160-row tiles (DH_LSTM_BM=160; one full round of 256 workgroups at 1280 rows, 42 % less L2 -> LDS traffic on the busiest
+    // CU) are correct but measured SLOWER in the C2 step (1.33 vs 1.24 ms per step at any ring depth): one wave per SIMD hides
+    // less latency than the 2-3 co-resident 64 x 64 workgroups, so the small tile stays the default
+    static const int force_bm = getenv("DH_LSTM_BM") ? atoi(getenv("DH_LSTM_BM")) : 0;
+    const int blocks160 = dh_cdiv(rows, 160) * p.tiles_n;
+    const bool big = force_bm == 160;
     DhProfScope prof("dh_lstm_layer_fused", 2.0 * rows * 4 * Hh * K, 2.0 * (rows * K + 4.0 * Hh * K) + 12.0 * rows * Hh, stream);
     // ring depth by workgroup count so that all tiles are co-resident in ONE round where possible (16 KB per slab):
     // measured at 1280 rows x 2048 gate columns (640 workgroups): 4 slabs (2 per CU, 1.25 rounds) 20.7 / 24.3 us,
     // 3 slabs (3 per CU) 16.6 / 19.0 us, 2 slabs (5 per CU) 16.4 / 18.6 us  (E = 256 / 512)
     const int blocks = p.tiles_m * p.tiles_n;
     static const int force_ns = getenv("DH_LSTM_NS") ? atoi(getenv("DH_LSTM_NS")) : 0;
+    if (big) {
+        p.tiles_m = dh_cdiv(rows, 160);
+        DH_DISPATCH_16(dtype, {
+            if (force_ns == 3) hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 3, 160>), dim3(blocks160), dim3(256), 0, (hipStream_t)stream, p);
+            else if (force_ns == 5) hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 5, 160>), dim3(blocks160), dim3(256), 0, (hipStream_t)stream, p);
+            else hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 4, 160>), dim3(blocks160), dim3(256), 0, (hipStream_t)stream, p);
+        });
+        DH_LAUNCH_CHECK();
+    }
     DH_DISPATCH_16(dtype, {
         if (force_ns == 2 || (!force_ns && blocks > 768 && blocks <= 1280))
             hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
