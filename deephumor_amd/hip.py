@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 8
+ABI_VERSION = 9
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW, ERR_TOPK_GROUPS = 1, 2, 4, 8
 TOPK_SLOTS = 64
@@ -71,6 +71,7 @@ SIGNATURES = {
     "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_resize_u8_hwc": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -469,6 +470,33 @@ def conv2d_nhwc_bn_relu_maxpool(x, w, scale, shift, stride=2, pad=3):
     _launch("dh_conv2d_nhwc_bn_relu_maxpool", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), n, h, wd, cin, cout, ks,
             stride, pad, _dt(x), _stream())
     return out
+
+
+def stem_conv7_bn_relu_maxpool(x, wpk, scale, shift, out_dtype=None):
+    """The ResNet stem as a direct matrix-core convolution (conv 7x7/2/3 + BN + ReLU + maxpool 3/2/1, one launch).
+    x: fp32 NCHW [N,3,H,W] or 16-bit channels-last [N,H,W,8]; wpk [64,7,8,4] 16-bit (``pack_stem_weight``)."""
+    _dev(x, wpk, scale, shift)
+    assert x.is_contiguous() and wpk.is_contiguous() and tuple(wpk.shape) == (64, 7, 8, 4) and wpk.dtype in HALF_DTYPES
+    if x.dtype == torch.float32:
+        n, c, h, wd = x.shape
+        assert c == 3
+        fmt = 0
+    else:
+        n, h, wd, c = x.shape
+        assert c == 8 and x.dtype == wpk.dtype
+        fmt = 1
+    ho, wo = (h - 1) // 2 + 1, (wd - 1) // 2 + 1
+    out = torch.empty((n, ho // 2, wo // 2, 64), dtype=wpk.dtype if out_dtype is None else out_dtype, device=x.device)
+    _launch("dh_stem_conv7_bn_relu_maxpool", _ptr(x), fmt, _ptr(wpk), _ptr(scale), _ptr(shift), _ptr(out), n, h, wd, _dt(out), _stream())
+    return out
+
+
+def pack_stem_weight(w, dtype):
+    """Checkpoint stem weight [64,3,7,7] -> [64, 7 kh, 8 kw slots, 4 channels] (slot 7 / channel 3 zero) in ``dtype``."""
+    assert tuple(w.shape) == (64, 3, 7, 7)
+    out = torch.zeros((64, 7, 8, 4), dtype=dtype, device=w.device)
+    out[:, :, :7, :3] = w.detach().permute(0, 2, 3, 1).to(dtype)
+    return out.contiguous()
 
 
 def embed_rows(tok_emb, pos_emb, start_emb, tokens, x, rows, rows_per_img, row_mult, pos, scale):

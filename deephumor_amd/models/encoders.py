@@ -147,6 +147,9 @@ class ImageEncoder(_Planned, nn.Module):
 
         blocks = []
         stem = conv(self.resnet[0], self.resnet[1], True, stem=True)
+        c1 = self.resnet[0]
+        if bf16 and tuple(c1.weight.shape) == (64, 3, 7, 7) and c1.stride[0] == 2 and c1.padding[0] == 3:
+            stem["wpk"] = hip.pack_stem_weight(c1.weight, wdt)      # the direct-convolution stem kernel's weight layout
         for stage in list(self.resnet)[4:]:
             for blk in stage:
                 ent = dict(
@@ -181,7 +184,17 @@ class ImageEncoder(_Planned, nn.Module):
         nhwc = plan["bf16"]
         st = plan["stem"]
         if nhwc:
-            if images.dim() == 4 and images.shape[-1] == 8 and images.dtype == plan["dtype"]:
+            prepacked = images.dim() == 4 and images.shape[-1] == 8 and images.dtype == plan["dtype"]
+            h_in, w_in = (images.shape[1], images.shape[2]) if prepacked else (images.shape[2], images.shape[3])
+            direct = ("wpk" in st and h_in >= 2 and w_in >= 2 and ((h_in - 1) // 2 + 1) % 2 == 0 and ((w_in - 1) // 2 + 1) % 2 == 0
+                      and (prepacked or images.shape[1] == 3) and not os.environ.get("DH_NO_DIRECT_STEM"))
+            if direct:
+                # conv1 + bn1 + relu + maxpool as ONE direct-convolution launch that reads the caller's tensor as it is (fp32 NCHW
+                # or the preprocessing kernels' packed 16-bit layout): no packing launch, no im2col traffic, no un-pooled activation
+                src = images.contiguous() if prepacked else images.float().contiguous()
+                x = hip.stem_conv7_bn_relu_maxpool(src, st["wpk"], st["scale"], st["shift"])
+                return self._trunk(x, plan)
+            if prepacked:
                 packed = images.contiguous()              # already normalised + packed (experiments.inference.preprocess_images)
             else:
                 packed = hip.pack_nchw_to_nhwc8(images.float().contiguous(), out_dtype=plan["dtype"])
@@ -195,6 +208,11 @@ class ImageEncoder(_Planned, nn.Module):
                 x = hip.maxpool3x3s2_nhwc(self._conv(packed, st, nhwc=True))
         else:
             x = hip.maxpool3x3s2(self._conv(images.contiguous(), st))
+        return self._trunk(x, plan)
+
+    def _trunk(self, x, plan):
+        """layer1..layer4 on the pooled stem output."""
+        nhwc = plan["bf16"]
         for blk in plan["blocks"]:
             y = self._conv(self._conv(x, blk["c1"], nhwc=nhwc), blk["c2"], nhwc=nhwc)
             if blk["dual"] is not None:

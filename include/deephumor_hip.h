@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 8
+#define DH_ABI_VERSION 9
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -72,6 +72,17 @@ int dh_conv2d_nhwc_bn_act(const void* x, const void* w, const float* scale, cons
  * Ho, Wo even; Cout <= 64.  Bit-identical to dh_conv2d_nhwc_bn_act + dh_maxpool3x3s2_nhwc (rounding is monotonic). */
 int dh_conv2d_nhwc_bn_relu_maxpool(const void* x, const void* w, const float* scale, const float* shift, void* y, int N,
                                    int H, int W, int Cin, int Cout, int KS, int stride, int pad, int dtype, void* stream);
+
+/* The ResNet-50 stem as a DIRECT convolution on the matrix cores (16-bit dtypes): conv 7x7 / stride 2 / pad 3, 3 -> 64
+ * channels, + BatchNorm + ReLU + MaxPool2d(3, 2, 1) -- torchvision resnet children conv1, bn1, relu, maxpool
+ * (encoders.py:37-38) -- reading the caller's image as it is: x_fmt 0 = fp32 NCHW [N,3,H,W] (no packing launch in front),
+ * x_fmt 1 = 16-bit channels-last [N,H,W,8] (dh_normalize_pack_u8 / dh_pack_nchw_to_nhwc8; channels 0..2 used).  A workgroup
+ * loads the 35 x 36 input pixels under a 15 x 15 patch of convolution outputs once into LDS and forms the MFMA operands at
+ * ds_read time (one MFMA = one kernel row: K = 8 kw slots x 4 channels), so neither an im2col matrix nor the un-pooled
+ * activation ever exists.  w [64][7 kh][8 kw slots][4 channels] 16-bit (slot 7 and channel 3 zero; repacked once by the
+ * caller from the checkpoint's [64,3,7,7]), scale/shift fp32 [64], y channels-last [N, Ho/2, Wo/2, 64]; conv output Ho, Wo even. */
+int dh_stem_conv7_bn_relu_maxpool(const void* x, int x_fmt, const void* w, const float* scale, const float* shift, void* y,
+                                  int N, int H, int W, int dtype, void* stream);
 
 /* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */

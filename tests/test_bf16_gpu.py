@@ -440,6 +440,29 @@ def test_stem_conv_with_fused_maxpool(hip, n, h, w):
     np.testing.assert_allclose(fused.float().cpu().permute(0, 3, 1, 2).numpy(), want.numpy(), atol=4e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 224, 224), (3, 64, 96), (1, 36, 28), (1, 8, 4), (70, 60, 64)])
+def test_direct_stem_convolution(hip, n, h, w):
+    """dh_stem_conv7_bn_relu_maxpool (direct 7x7/2 convolution + BN + ReLU + maxpool, one launch) against fp32
+    F.conv2d + max_pool2d on the same 16-bit-rounded operands -- partial 7 x 7 pooled blocks at the image edges and more
+    patches than workgroups (the persistent loop) included -- and its two input formats against each other, bit for bit."""
+    x = bf(rnd(n, 3, h, w, seed=51)).float()                      # fp32 values that are exact in the 16-bit type
+    wgt = bf(rnd(64, 3, 7, 7, seed=52) * 0.08)
+    sc, sh = rnd(64, seed=53).abs() + 0.5, rnd(64, seed=54) * 0.3
+    wpk = hip.pack_stem_weight(wgt.cuda(), HALF)
+    assert torch.equal(wpk[:, :, :7, :3].cpu(), wgt.permute(0, 2, 3, 1)) and float(wpk[:, :, 7].abs().max()) == 0 and float(wpk[..., 3].abs().max()) == 0
+    got = hip.stem_conv7_bn_relu_maxpool(x.cuda(), wpk, sc.cuda(), sh.cuda())
+    want = F.max_pool2d(torch.relu(F.conv2d(x, wgt.float(), stride=2, padding=3) * sc[None, :, None, None] + sh[None, :, None, None]), 3, 2, 1)
+    assert tuple(got.shape) == (n, want.shape[2], want.shape[3], 64)
+    np.testing.assert_allclose(got.float().cpu().permute(0, 3, 1, 2).numpy(), want.numpy(), atol=4e-2 if HALF == torch.bfloat16 else 6e-3, rtol=2e-2 if HALF == torch.bfloat16 else 3e-3)
+    packed = hip.pack_nchw_to_nhwc8(x.cuda(), out_dtype=HALF)
+    assert torch.equal(hip.stem_conv7_bn_relu_maxpool(packed, wpk, sc.cuda(), sh.cuda()), got)
+    # against the implicit-GEMM stem (different summation order: close, not bit-equal)
+    w8 = torch.zeros(64, 7, 7, 8, dtype=HALF)
+    w8[..., :3] = wgt.permute(0, 2, 3, 1)
+    old = hip.conv2d_nhwc_bn_relu_maxpool(packed, w8.cuda(), sc.cuda(), sh.cuda(), stride=2, pad=3)
+    np.testing.assert_allclose(got.float().cpu().numpy(), old.float().cpu().numpy(), atol=4e-2 if HALF == torch.bfloat16 else 6e-3, rtol=2e-2)
+
+
 @pytest.mark.parametrize("n_img,beam", [(3, 5), (8, 16), (11, 1), (17, 10)])
 def test_cross_attention_with_fused_query_projection(hip, n_img, beam):
     """dh_attn_cross_qproj_decode (fc_q on the deferred-LayerNorm rows + attention, one launch, K head-dim slots permuted)
