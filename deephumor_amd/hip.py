@@ -71,6 +71,8 @@ SIGNATURES = {
     "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_conv3x3_direct_supported": [_I, _I, _I, _I],
+    "dh_conv3x3_direct_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -469,6 +471,28 @@ def conv2d_nhwc_bn_relu_maxpool(x, w, scale, shift, stride=2, pad=3):
     out = torch.empty((n, ho // 2, wo // 2, cout), dtype=x.dtype, device=x.device)
     _launch("dh_conv2d_nhwc_bn_relu_maxpool", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), n, h, wd, cin, cout, ks,
             stride, pad, _dt(x), _stream())
+    return out
+
+
+_c3_ok = {}
+
+
+def conv3x3_direct_supported(h, w, cin, cout):
+    key = (int(h), int(w), int(cin), int(cout))
+    if key not in _c3_ok:
+        _c3_ok[key] = bool(load().dh_conv3x3_direct_supported(*key))
+    return _c3_ok[key]
+
+
+def conv3x3_direct_nhwc(x, w, scale, shift):
+    """3x3 / stride 1 / pad 1 convolution + BN + ReLU as a direct matrix-core convolution (stage-1 / stage-2 bottleneck conv2)."""
+    _dev(x, w, scale, shift)
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    assert tuple(w.shape) == (cout, 3, 3, cin) and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
+    out = torch.empty((n, h, wd, cout), dtype=x.dtype, device=x.device)
+    _launch("dh_conv3x3_direct_nhwc", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), n, h, wd, cin, cout, 1, _dt(x), _stream(),
+            tag="3x3")
     return out
 
 

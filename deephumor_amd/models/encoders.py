@@ -174,6 +174,10 @@ class ImageEncoder(_Planned, nn.Module):
 
     @staticmethod
     def _conv(x, c, residual=None, nhwc=False):
+        if (nhwc and residual is None and c["relu"] and c["stride"] == 1 and c["pad"] == 1 and c["w"].shape[1] == 3
+                and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], x.shape[3], c["w"].shape[0])
+                and not os.environ.get("DH_NO_DIRECT_3X3")):
+            return hip.conv3x3_direct_nhwc(x, c["w"], c["scale"], c["shift"])      # patch-resident direct convolution (stages 1-2)
         fn = hip.conv2d_nhwc_bn_act if nhwc else hip.conv2d_bn_act
         return fn(x, c["w"], c["scale"], c["shift"], residual=residual, relu=c["relu"], stride=c["stride"], pad=c["pad"])
 

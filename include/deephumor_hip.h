@@ -84,6 +84,17 @@ int dh_conv2d_nhwc_bn_relu_maxpool(const void* x, const void* w, const float* sc
 int dh_stem_conv7_bn_relu_maxpool(const void* x, int x_fmt, const void* w, const float* scale, const float* shift, void* y,
                                   int N, int H, int W, int dtype, void* stream);
 
+/* 3x3 / stride 1 / pad 1 convolution + BatchNorm + ReLU as a DIRECT convolution on the matrix cores (16-bit dtypes,
+ * channels-last): the conv2 of the ResNet-50 bottlenecks of stages 1 and 2 (torchvision Bottleneck.conv2 / bn2 / relu).  A
+ * workgroup brings the (4 + 2) x (W + 2) input pixels under four output rows into LDS once and serves all nine taps from
+ * them; only the [Cout][64 k] weight slabs stream -- 3.5x less L2 -> LDS traffic per output pixel than the implicit GEMM of
+ * dh_conv2d_nhwc_bn_act, same contract: x [N,H,W,Cin], w [Cout,3,3,Cin], y [N,H,W,Cout], relu must be 1.  Supported shapes
+ * (dh_conv3x3_direct_supported != 0): H % 4 == 0 and (Cin = Cout = 64, W = 56) or (Cin = Cout = 128, W = 28); anything else
+ * returns DH_ERR_BAD_ARG and belongs to dh_conv2d_nhwc_bn_act. */
+int dh_conv3x3_direct_supported(int H, int W, int Cin, int Cout);
+int dh_conv3x3_direct_nhwc(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H,
+                           int W, int Cin, int Cout, int relu, int dtype, void* stream);
+
 /* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */
 int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const float* shift, void* y,

@@ -440,6 +440,23 @@ def test_stem_conv_with_fused_maxpool(hip, n, h, w):
     np.testing.assert_allclose(fused.float().cpu().permute(0, 3, 1, 2).numpy(), want.numpy(), atol=4e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("n,h,w,c", [(2, 56, 56, 64), (3, 8, 56, 64), (2, 28, 28, 128), (5, 4, 28, 128)])
+def test_direct_conv3x3(hip, n, h, w, c):
+    """dh_conv3x3_direct_nhwc (patch-resident direct convolution, stages 1-2 of the ResNet) against the implicit-GEMM
+    dh_conv2d_nhwc_bn_act and against fp32 F.conv2d on the same 16-bit operands."""
+    assert hip.conv3x3_direct_supported(h, w, c, c) and not hip.conv3x3_direct_supported(h, w + 4, c, c)
+    x = bf(rnd(n, h, w, c, seed=61))
+    wgt = bf(rnd(c, 3, 3, c, seed=62) * (9 * c) ** -0.5)
+    sc, sh = rnd(c, seed=63).abs() + 0.5, rnd(c, seed=64) * 0.3
+    got = hip.conv3x3_direct_nhwc(x.cuda(), wgt.cuda(), sc.cuda(), sh.cuda())
+    old = hip.conv2d_nhwc_bn_act(x.cuda(), wgt.cuda(), sc.cuda(), sh.cuda(), relu=True, stride=1, pad=1)
+    want = torch.relu(F.conv2d(x.float().permute(0, 3, 1, 2), wgt.float().permute(0, 3, 1, 2), padding=1) * sc[None, :, None, None]
+                      + sh[None, :, None, None]).permute(0, 2, 3, 1)
+    tol = dict(atol=3e-2, rtol=2e-2) if HALF == torch.bfloat16 else dict(atol=4e-3, rtol=3e-3)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), **tol)
+    np.testing.assert_allclose(got.float().cpu().numpy(), old.float().cpu().numpy(), **tol)
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 224, 224), (3, 64, 96), (1, 36, 28), (1, 8, 4), (70, 60, 64)])
 def test_direct_stem_convolution(hip, n, h, w):
     """dh_stem_conv7_bn_relu_maxpool (direct 7x7/2 convolution + BN + ReLU + maxpool, one launch) against fp32
