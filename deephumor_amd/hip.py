@@ -73,6 +73,7 @@ SIGNATURES = {
     "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv3x3_direct_supported": [_I, _I, _I, _I],
     "dh_conv3x3_direct_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dh_bottleneck_tail_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -493,6 +494,18 @@ def conv3x3_direct_nhwc(x, w, scale, shift):
     out = torch.empty((n, h, wd, cout), dtype=x.dtype, device=x.device)
     _launch("dh_conv3x3_direct_nhwc", _ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(out), n, h, wd, cin, cout, 1, _dt(x), _stream(),
             tag="3x3")
+    return out
+
+
+def bottleneck_tail_nhwc(y1, w2, scale2, shift2, w3, scale3, shift3, residual):
+    """relu(bn3(conv3_1x1(relu(bn2(conv2_3x3(y1))))) + residual) in one launch (shapes of ``conv3x3_direct_supported``)."""
+    _dev(y1, w2, scale2, shift2, w3, scale3, shift3, residual)
+    n, h, wd, c = y1.shape
+    assert tuple(w2.shape) == (c, 3, 3, c) and w3.shape[0] == 4 * c and w3.numel() == 4 * c * c and tuple(residual.shape) == (n, h, wd, 4 * c)
+    assert y1.is_contiguous() and w2.is_contiguous() and w3.is_contiguous() and residual.is_contiguous() and y1.dtype == w2.dtype == w3.dtype == residual.dtype
+    out = torch.empty_like(residual)
+    _launch("dh_bottleneck_tail_nhwc", _ptr(y1), _ptr(w2), _ptr(scale2), _ptr(shift2), _ptr(w3), _ptr(scale3), _ptr(shift3), _ptr(residual),
+            _ptr(out), n, h, wd, c, _dt(y1), _stream())
     return out
 
 

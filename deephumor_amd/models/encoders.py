@@ -218,6 +218,15 @@ class ImageEncoder(_Planned, nn.Module):
         """layer1..layer4 on the pooled stem output."""
         nhwc = plan["bf16"]
         for blk in plan["blocks"]:
+            c2, c3 = blk["c2"], blk["c3"]
+            if (nhwc and blk["dual"] is None and blk["down"] is None and c2["stride"] == 1 and c2["w"].shape[1] == 3
+                    and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], c2["w"].shape[3], c2["w"].shape[0])
+                    and c3["w"].shape[0] == 4 * c2["w"].shape[0] and not os.environ.get("DH_NO_FUSED_TAIL")
+                    and not os.environ.get("DH_NO_DIRECT_3X3")):
+                # conv2 + bn2 + relu + conv3 + bn3 + residual + relu in one launch: the conv2 output tile stays in LDS
+                y1 = self._conv(x, blk["c1"], nhwc=True)
+                x = hip.bottleneck_tail_nhwc(y1, c2["w"], c2["scale"], c2["shift"], c3["w"], c3["scale"], c3["shift"], x)
+                continue
             y = self._conv(self._conv(x, blk["c1"], nhwc=nhwc), blk["c2"], nhwc=nhwc)
             if blk["dual"] is not None:
                 d = blk["dual"]

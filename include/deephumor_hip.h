@@ -95,6 +95,16 @@ int dh_conv3x3_direct_supported(int H, int W, int Cin, int Cout);
 int dh_conv3x3_direct_nhwc(const void* x, const void* w, const float* scale, const float* shift, void* y, int N, int H,
                            int W, int Cin, int Cout, int relu, int dtype, void* stream);
 
+/* The tail of a ResNet bottleneck in ONE launch (16-bit dtypes, channels-last): out = relu(bn3(conv3(relu(bn2(conv2(y1))))) +
+ * residual), conv2 3x3 / stride 1 / pad 1 (C -> C), conv3 1x1 (C -> 4C) -- torchvision Bottleneck.forward from conv2 on
+ * (encoders.py:37-38,56).  conv2 runs as in dh_conv3x3_direct_nhwc; its output tile never leaves LDS: it is the activation
+ * operand of the 1x1 expansion, whose weights stream through the same LDS ring.  Bit-identical to dh_conv3x3_direct_nhwc
+ * followed by dh_conv2d_nhwc_bn_act(1x1, residual, relu).  Shapes as dh_conv3x3_direct_supported(H, W, C, C).
+ * y1 [N,H,W,C], w2 [C,3,3,C], w3 [4C,C], residual / out [N,H,W,4C], scale / shift fp32 per output channel. */
+int dh_bottleneck_tail_nhwc(const void* y1, const void* w2, const float* scale2, const float* shift2, const void* w3,
+                            const float* scale3, const float* shift3, const void* residual, void* out, int N, int H,
+                            int W, int C, int dtype, void* stream);
+
 /* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */
 int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const float* shift, void* y,

@@ -457,6 +457,28 @@ def test_direct_conv3x3(hip, n, h, w, c):
     np.testing.assert_allclose(got.float().cpu().numpy(), old.float().cpu().numpy(), **tol)
 
 
+@pytest.mark.parametrize("n,h,w,c", [(2, 56, 56, 64), (3, 8, 56, 64), (2, 28, 28, 128), (5, 4, 28, 128)])
+def test_fused_bottleneck_tail(hip, n, h, w, c):
+    """dh_bottleneck_tail_nhwc (3x3 conv2 + 1x1 conv3 + residual in one launch, the conv2 tile resident in LDS) against the
+    two-launch route, bit for bit, and against fp32 math."""
+    y1 = bf(rnd(n, h, w, c, seed=71)).cuda()
+    w2 = bf(rnd(c, 3, 3, c, seed=72) * (9 * c) ** -0.5).cuda()
+    w3 = bf(rnd(4 * c, 1, 1, c, seed=73) * c ** -0.5).cuda()
+    s2, h2 = (rnd(c, seed=74).abs() + 0.5).cuda(), (rnd(c, seed=75) * 0.3).cuda()
+    s3, h3 = (rnd(4 * c, seed=76).abs() + 0.5).cuda(), (rnd(4 * c, seed=77) * 0.3).cuda()
+    res = bf(rnd(n, h, w, 4 * c, seed=78)).cuda()
+    got = hip.bottleneck_tail_nhwc(y1, w2, s2, h2, w3, s3, h3, res)
+    y2 = hip.conv3x3_direct_nhwc(y1, w2, s2, h2)
+    two = hip.conv2d_nhwc_bn_act(y2, w3, s3, h3, residual=res, relu=True, stride=1, pad=0)
+    assert torch.equal(got, two)
+    y2f = torch.relu(F.conv2d(y1.float().cpu().permute(0, 3, 1, 2), w2.float().cpu().permute(0, 3, 1, 2), padding=1)
+                     * s2.cpu()[None, :, None, None] + h2.cpu()[None, :, None, None])
+    want = torch.relu(F.conv2d(bf(y2f).float(), w3.float().cpu().permute(0, 3, 1, 2)) * s3.cpu()[None, :, None, None]
+                      + h3.cpu()[None, :, None, None] + res.float().cpu().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    tol = dict(atol=6e-2, rtol=3e-2) if HALF == torch.bfloat16 else dict(atol=8e-3, rtol=4e-3)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), **tol)
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 224, 224), (3, 64, 96), (1, 36, 28), (1, 8, 4), (70, 60, 64)])
 def test_direct_stem_convolution(hip, n, h, w):
     """dh_stem_conv7_bn_relu_maxpool (direct 7x7/2 convolution + BN + ReLU + maxpool, one launch) against fp32
