@@ -123,24 +123,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, OCC) void vocab_dacc_kernel
             __builtin_amdgcn_s_barrier();
             const unsigned char* sa = lds + (g % NS) * SLAB;
             const unsigned char* sb = sa + A_BYTES;
-            // all fragments of the slab first (one LDS wait), the issue side inside that latency window, 32 MFMAs back to back,
-            // then the drain of the other accumulator set (the fragments are dead by then: their registers carry its temporaries)
-            uint4 fa[2][TM], fw[2][TN];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
+            // fragments per 32-deep k half (32 registers instead of 64: with two accumulator sets the wave is at the 256-register
+            // limit -- the all-fragments-first schedule of vocab_logits_kernel spills inside this loop and runs at half the speed)
+            uint4 fa[TM], fw[TN];
+            auto read_frags = [&](int kk) {
                 const int c = kk * 4 + lq;
 #pragma unroll
                 for (int i = 0; i < TM; ++i) {
                     const int rr = wm0 + i * 16 + l15;
-                    fa[kk][i] = *reinterpret_cast<const uint4*>(sa + rr * 128 + ((c ^ (rr & 7)) << 4));
+                    fa[i] = *reinterpret_cast<const uint4*>(sa + rr * 128 + ((c ^ (rr & 7)) << 4));
                 }
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
                     const int rr = wn0 + j * 16 + l15;
-                    fw[kk][j] = *reinterpret_cast<const uint4*>(sb + rr * 128 + ((c ^ (rr & 7)) << 4));
+                    fw[j] = *reinterpret_cast<const uint4*>(sb + rr * 128 + ((c ^ (rr & 7)) << 4));
                 }
-            }
+            };
+            read_frags(0);
             __builtin_amdgcn_sched_barrier(0);
+            // issue side of the slab, inside the LDS-read latency window: next slab's DMA, the bias strip, drained stores
 #pragma unroll
             for (int u = 0; u + 1 < NS - 1; ++u) mark[u] = mark[u + 1];
             if (ld_g < total) stage_next();
@@ -151,16 +152,21 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, OCC) void vocab_dacc_kernel
                 issued += 1;
                 bias_mark = issued;
             }
+            drain_some(accD, units_per_slab);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) accC[j][i] = Op16<OT>::mfma(fw[kk][j], fa[kk][i], accC[j][i]);
+                for (int i = 0; i < TM; ++i) accC[j][i] = Op16<OT>::mfma(fw[j], fa[i], accC[j][i]);
             __builtin_amdgcn_sched_barrier(0);
-            drain_some(accD, units_per_slab);
+            read_frags(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) accC[j][i] = Op16<OT>::mfma(fw[j], fa[i], accC[j][i]);
         }
         // the tile's bias strip has landed once everything issued up to it has
         wait_vmcnt_any(issued - bias_mark);
