@@ -1283,6 +1283,7 @@ __global__ __launch_bounds__(512, 1) void vocab256_kernel(VocabParams p) {
 }
 
 #include "vocab_dacc.h"
+#include "vocab_areg.h"
 
 // fp32-output dense GEMMs with many tiles (teacher-forced classifier: [bs*T, V] logits): the persistent kernel without
 // the group maxima (600 vs 385 TF for the one-tile-per-workgroup kernel with its LDS-staged fp32 epilogue).
@@ -1357,6 +1358,20 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         // nothing is stored (dh_vocab_logprob) the bigger tile is the default.
         static const int vns = getenv("DH_VOCAB_TILE") ? atoi(getenv("DH_VOCAB_TILE")) : 128;
         static const int gns = getenv("DH_VOCAB_GMAX_TILE") ? atoi(getenv("DH_VOCAB_GMAX_TILE")) : 256;
+        {   // A-stationary kernel: K = 512, row tiles of 128, groups of tiles_m workgroups per XCD (32 CUs each)
+            static const int areg = getenv("DH_VOCAB_AREG") ? atoi(getenv("DH_VOCAB_AREG")) : 0;
+            const int tm128 = dh_cdiv(M, 128), tn128 = dh_cdiv(V, 128);
+            if (areg && K == 512 && tm128 <= 32 && (32 / tm128) * tm128 >= 28 && tn128 >= 8 * (32 / tm128)) {
+                v.tiles_m = tm128; v.tiles_n = tn128;
+                if (areg == 2 && getenv("DH_AREG_SAMEPANEL")) v.tgt_logit = (float*)1;
+                static const int adbg = getenv("DH_AREG_DBG") ? atoi(getenv("DH_AREG_DBG")) : 0;
+                if (areg == 2 && adbg == 1) { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T, true, 1>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
+                else if (areg == 2 && adbg == 2) { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T, true, 2>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
+                else if (areg == 2) { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
+                else { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
+                DH_LAUNCH_CHECK();
+            }
+        }
         const int dsel = logits ? vns : gns;
         if ((dsel == 2561 || dsel == 1282 || dsel == 1281) && K / 64 > 3) {
             // deferred-store kernels: 2561 = 256 x 128 tiles (8 waves, 3-slab ring), 1282 = 128 x 256, 1281 = 128 x 128 (4 waves, 2 per CU)
@@ -1571,4 +1586,9 @@ extern "C" int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, 
     hipLaunchKernelGGL(lse_combine_kernel, dim3(dh_cdiv(M, 4)), dim3(256), 0, s, group_max, group_sum, gm_ld, 2 * dh_cdiv(V, 128),
                        target_logit, targets, V, logp, M);
     DH_LAUNCH_CHECK();
+}
+
+// developer instrumentation: per-workgroup phase cycle totals of the last vocab_areg_kernel<.., STAMP> launch (DH_VOCAB_AREG=2)
+extern "C" int dh_debug_areg_stamps(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dh_areg_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
 }
