@@ -1364,6 +1364,7 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
             if (areg && K == 512 && tm128 <= 32 && (32 / tm128) * tm128 >= 28 && tn128 >= 8 * (32 / tm128)) {
                 v.tiles_m = tm128; v.tiles_n = tn128;
                 if (areg == 2 && getenv("DH_AREG_SAMEPANEL")) v.tgt_logit = (float*)1;
+                if (areg == 2 && getenv("DH_AREG_SLABMAJOR")) v.gsum = (float*)1;
                 static const int adbg = getenv("DH_AREG_DBG") ? atoi(getenv("DH_AREG_DBG")) : 0;
                 if (areg == 2 && adbg == 1) { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T, true, 1>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
                 else if (areg == 2 && adbg == 2) { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T, true, 2>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }

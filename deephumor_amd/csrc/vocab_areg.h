@@ -70,7 +70,8 @@ __global__ __launch_bounds__(512, 1) void vocab_areg_kernel(VocabParams p) {
         const int tn = (STAMP && p.tgt_logit) ? 0 : grp + it * ngrp;      // (instrumentation: every workgroup streams panel 0 -> all L2 hits)
 #pragma unroll
         for (int i = 0; i < G; ++i)
-            b_off[i] = (unsigned)min(tn * BN + (wave * G + i) * 8 + lr, p.N - 1) * (unsigned)(p.ldw * 2) + swz * 16;
+            b_off[i] = (STAMP && p.gsum) ? (unsigned)min(tn * BN + (wave * G + i) * 8 + lr, p.N - 1) * 128u + swz * 16   // (timing probe: slab-major W)
+                                         : (unsigned)min(tn * BN + (wave * G + i) * 8 + lr, p.N - 1) * (unsigned)(p.ldw * 2) + swz * 16;
     };
     int issued = 0;
     int mark[NS];
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(512, 1) void vocab_areg_kernel(VocabParams p) {
     for (int b = 0; b < NS; ++b) mark[b] = 0;
     auto stage_into = [&](int buf) {                                // buf is a compile-time constant at every call site
         unsigned char* slab = lds + buf * SLAB;
-        const unsigned kb = (unsigned)ld_s * 128u;
+        const unsigned kb = (STAMP && p.gsum) ? (unsigned)ld_s * (unsigned)p.N * 128u : (unsigned)ld_s * 128u;
 #pragma unroll
         for (int i = 0; i < G; ++i) dh_lds_dma16_s(b_base + kb, b_off[i], slab + (wave * G + i) * 1024);
         issued += G;
