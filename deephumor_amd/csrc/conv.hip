@@ -335,11 +335,19 @@ __global__ __launch_bounds__(256) void avgpool_nhwc_kernel(const T* __restrict__
     float s[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) s[u] = 0.f;
-    for (int j = 0; j < HW; ++j) {
-        float v[8];
-        load16(x + ((size_t)n * HW + j) * C + cc * 8, v);
+    // eight positions per round, all requested before the first is used (a one-load-at-a-time loop is a chain of 49 memory
+    // round trips: 29 us per 256 images for 51 MB); same summation order as the plain loop
+    const T* src = x + (size_t)n * HW * C + cc * 8;
+    for (int j0 = 0; j0 < HW; j0 += 8) {
+        float v[8][8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s[u] += v[u];
+        for (int r = 0; r < 8; ++r) load16(src + (size_t)min(j0 + r, HW - 1) * C, v[r]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+            if (j0 + r < HW) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s[u] += v[r][u];
+            }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) s[u] /= (float)HW;

@@ -136,7 +136,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_direct_kernel(C3Params p) {
     int kh = 0, kw = 0, cbk = 0;                          // wave-uniform tap / channel-block counters
 #pragma unroll 1
     for (int t = 0; t < NSLAB; ++t) {
-        c3_wait_vmcnt((NSTREAM - 1 - t < NS - 2 ? NSTREAM - 1 - t : NS - 2) * G);   // slab t (and, at t = 0, the patch) has landed
+        // slab t (and, at t = 0, the patch) has landed.  Steady state: an immediate count; the run-time switch (a tree of taken
+        // scalar branches) only for the last slabs of the stream
+        if (__builtin_expect(NSTREAM - 1 - t >= NS - 2, 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * G) : "memory");
+        else c3_wait_vmcnt((NSTREAM - 1 - t) * G);
         __builtin_amdgcn_s_barrier();
         if (t + NS - 1 < NSTREAM) stage_w();
         const int tapoff = kh * PITCH + kw;

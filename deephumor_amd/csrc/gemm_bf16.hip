@@ -75,6 +75,18 @@ __device__ __forceinline__ void wait_vmcnt_any(int n) {
 
 __device__ __forceinline__ void wait_vmcnt(int n) { wait_vmcnt_any(n); }
 
+// The switch above costs a tree of ~6 scalar compares + TAKEN branches per call when `n` is a run-time value -- measured with
+// tools/probe/ta_probe: a bare LDS-DMA ring (2 pieces per wave per step, 8 deep, one barrier per step) streams 71.6 GB/s per CU
+// with an immediate s_waitcnt and 39.7 GB/s with the switch in front of it: several hundred cycles per K slab, as much as the
+// slab's MFMAs.  In steady state the count is a compile-time constant (the ring is full: NS - 2 slabs younger than the one
+// waited for); only the last NS - 2 slabs of the reduction need smaller counts.  HOT = that constant: one scalar compare and a
+// not-taken branch in the loop, the switch only in the tail.
+template <int HOT>
+__device__ __forceinline__ void wait_vmcnt_hot(int n) {
+    if (__builtin_expect(n == HOT, 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(HOT) : "memory");
+    else wait_vmcnt_any(n);
+}
+
 // NS = LDS ring depth: slabs t+1 .. t+NS-1 are in flight (LDS-DMA) while slab t feeds the MFMAs.
 // NW waves per workgroup, arranged WAVES_M x (NW / WAVES_M) over the BM x BN block.
 // EXT: 0 = plain; 1 = deferred LayerNorm on the A rows (a_stats); 3 = deferred LayerNorm on the residual rows and / or
@@ -314,8 +326,12 @@ __global__ __launch_bounds__(64 * NW) void gemm_bf16_kernel(GemmBf16Params p) {
         if (u < nslab) stage(u, u * BK);
     for (int t = 0; t < nslab; ++t) {
         // slab t has landed once at most min(NS-2, slabs issued after t) newer slabs are still outstanding
-        const int newer = min(NS - 2, nslab - 1 - t);
-        wait_vmcnt(newer * G);
+        if constexpr (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // two-slab ring: nothing younger than slab t is in flight
+        } else {
+            const int newer = min(NS - 2, nslab - 1 - t);
+            wait_vmcnt_hot<(NS - 2) * G>(newer * G);
+        }
         __builtin_amdgcn_s_barrier();                     // everyone's part of slab t landed; slab t-1 fully consumed
         if (t + NS - 1 < nslab) stage((t + NS - 1) % NS, (t + NS - 1) * BK);   // refill the buffer slab t-1 used
         const unsigned char* sa = lds + (t % NS) * SLAB;
@@ -919,7 +935,7 @@ __global__ __launch_bounds__(64 * NW, (NS * (BM + BN) * 128 <= 72 * 1024 ? 2 : 1
             int allow = min(NS - 2, total - 1 - g) * G;
             if (t <= NS - 2 && it > 0 && prev_full) allow += N_STORE;
             if (t >= 1 && t <= NS - 2) allow += 1;
-            wait_vmcnt_any(allow);
+            wait_vmcnt_hot<(NS - 2) * G>(allow);          // steady state inside a tile: the constant; tile starts / the tail: the switch
             __builtin_amdgcn_s_barrier();                 // slab g complete for every wave; slab g-1 fully consumed
             const unsigned char* sa = lds + (g % NS) * SLAB;
             const unsigned char* sb = sa + A_BYTES;
@@ -1142,7 +1158,7 @@ __global__ __launch_bounds__(512, 1) void vocab256_kernel(VocabParams p) {
             // -- the bias strip of this tile is issued below, after this wait
             int allow = 0;
             if (t == 0 && it > 0 && prev_full) allow = N_STORE;
-            wait_vmcnt_any(allow);
+            wait_vmcnt_hot<0>(allow);
             __builtin_amdgcn_s_barrier();
             const unsigned char* sa = lds + (g & 1) * SLAB;
             const unsigned char* sb = sa + A_BYTES;

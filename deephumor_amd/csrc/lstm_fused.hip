@@ -169,7 +169,12 @@ __global__ __launch_bounds__(256) void lstm_layer_fused_kernel(LstmFusedParams p
     for (int u = 0; u < NS - 1; ++u)
         if (u < nslab) stage(u, u * BK);
     for (int t = 0; t < nslab; ++t) {
-        lf_wait_vmcnt(min(NS - 2, nslab - 1 - t) * G);    // (the b4 / c0 loads are older than every slab)
+        {   // (the b4 / c0 loads are older than every slab)  steady state: an immediate; the run-time switch only in the K tail
+            // (a switch on a run-time count is a tree of taken scalar branches: gemm_bf16.hip, wait_vmcnt_hot)
+            const int newer = min(NS - 2, nslab - 1 - t);
+            if (__builtin_expect(newer == NS - 2, 1)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * G) : "memory");
+            else lf_wait_vmcnt(newer * G);
+        }
         __builtin_amdgcn_s_barrier();
         if (t + NS - 1 < nslab) stage((t + NS - 1) % NS, (t + NS - 1) * BK);
         const unsigned char* sa = lds + (t % NS) * SLAB;
