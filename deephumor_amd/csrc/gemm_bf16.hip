@@ -1379,13 +1379,7 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
             const int tm128 = dh_cdiv(M, 128), tn128 = dh_cdiv(V, 128);
             if (areg && K == 512 && tm128 <= 32 && (32 / tm128) * tm128 >= 28 && tn128 >= 8 * (32 / tm128)) {
                 v.tiles_m = tm128; v.tiles_n = tn128;
-                if (areg == 2 && getenv("DH_AREG_SAMEPANEL")) v.tgt_logit = (float*)1;
-                if (areg == 2 && getenv("DH_AREG_SLABMAJOR")) v.gsum = (float*)1;
-                static const int adbg = getenv("DH_AREG_DBG") ? atoi(getenv("DH_AREG_DBG")) : 0;
-                if (areg == 2 && adbg == 1) { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T, true, 1>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
-                else if (areg == 2 && adbg == 2) { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T, true, 2>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
-                else if (areg == 2) { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
-                else { DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, v)); }
+                DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, v));
                 DH_LAUNCH_CHECK();
             }
         }
@@ -1603,9 +1597,4 @@ extern "C" int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, 
     hipLaunchKernelGGL(lse_combine_kernel, dim3(dh_cdiv(M, 4)), dim3(256), 0, s, group_max, group_sum, gm_ld, 2 * dh_cdiv(V, 128),
                        target_logit, targets, V, logp, M);
     DH_LAUNCH_CHECK();
-}
-
-// developer instrumentation: per-workgroup phase cycle totals of the last vocab_areg_kernel<.., STAMP> launch (DH_VOCAB_AREG=2)
-extern "C" int dh_debug_areg_stamps(unsigned long long* out, int n) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(dh_areg_stamps), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
 }
