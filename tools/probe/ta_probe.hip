@@ -100,6 +100,60 @@ static void run_ring(const uint16_t* buf, int rows, int ld, uint32_t* sink) {
            bytes / (ms * 1e-3) / 256 / 1e9, bytes / (ms * 1e-3) / 1e12);
 }
 
+// ring + the rest of a GEMM slab step: READS ds_read_b128 of the landed slab and MFMAS v_mfma_f32_16x16x32_bf16 per wave per step
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int UN, int NS, int READS, int MFMAS, bool LGKM_WAIT>
+__global__ __launch_bounds__(512) void ring2(const uint16_t* buf, int rows, int ld, int iters, uint32_t* sink) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[128 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane >> 3, lpos = lane & 7;
+    int r0 = (blockIdx.x * 8 + wave) * 16;
+    const uint16_t* src = buf + (size_t)((r0 + lr) % (rows - 512)) * ld + lpos * 8;
+    auto stage = [&](int it) {
+#pragma unroll
+        for (int u = 0; u < UN; ++u)
+            lds_dma16(src + (size_t)((it * UN + u) % 64) * 8 * ld, lds + (((it % NS) * 8 + wave) * UN + u) % 128 * 1024);
+    };
+    f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    uint4 fr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fr[i] = make_uint4(lane + i, wave, i, 1);
+    for (int u = 0; u < NS - 1; ++u) stage(u);
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * UN) : "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* sb = lds + ((it % NS) * 16 * 1024) % (128 * 1024);
+#pragma unroll
+        for (int i = 0; i < READS; ++i)
+            fr[i & 7] = *reinterpret_cast<const uint4*>(sb + (((lane & 15) + 16 * (i & 3)) * 128 + (((lane >> 4) ^ (lane & 7)) << 4) + (i >> 2) * 8192) % (16 * 1024));
+        __builtin_amdgcn_sched_barrier(0);
+        stage(it + NS - 1);
+        if (LGKM_WAIT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MFMAS; ++i)
+            acc[i & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr[i & 7]), __builtin_bit_cast(bf16x8, fr[(i + 3) & 7]), acc[i & 3], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 123.25f) sink[0] = 1;
+}
+
+template <int UN, int NS, int READS, int MFMAS, bool LGKM_WAIT = true>
+static void run_ring2(const uint16_t* buf, int rows, int ld, uint32_t* sink) {
+    const int iters = 800;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((ring2<UN, NS, READS, MFMAS, LGKM_WAIT>), dim3(256), dim3(512), 0, 0, buf, rows, ld, iters, sink);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < 10; ++i) hipLaunchKernelGGL((ring2<UN, NS, READS, MFMAS, LGKM_WAIT>), dim3(256), dim3(512), 0, 0, buf, rows, ld, iters, sink);
+    (void)hipEventRecord(e1, 0); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    const double us_step = ms / 10 * 1e3 / iters;
+    printf("ring2: %d pieces + %2d LDS reads + %2d MFMAs per wave per step, %d-deep: %6.3f us per step (%4.0f cycles at 2.1 GHz; MFMA alone would need %4.0f)\n",
+           UN, READS, MFMAS, NS, us_step, us_step * 2100, MFMAS * 16.0 * 2);
+}
+
 template <int MODE, int UN>
 static void run(const uint16_t* buf, int rows, int ld, uint32_t* sink, const char* name) {
     const int iters = 200;
@@ -130,6 +184,9 @@ int main() {
     run_ring<1, 2, true>(buf, rows, ld, sink); run_ring<2, 2, true>(buf, rows, ld, sink); run_ring<4, 2, true>(buf, rows, ld, sink);
     run_ring<8, 2, true>(buf, rows, ld, sink);
     run_ring<1, 8, true>(buf, rows, ld, sink); run_ring<2, 8, true>(buf, rows, ld, sink); run_ring<4, 4, true>(buf, rows, ld, sink);
+    run_ring2<2, 8, 0, 0>(buf, rows, ld, sink); run_ring2<2, 8, 8, 0>(buf, rows, ld, sink); run_ring2<2, 8, 0, 16>(buf, rows, ld, sink);
+    run_ring2<2, 8, 8, 16>(buf, rows, ld, sink); run_ring2<0, 8, 8, 16>(buf, rows, ld, sink); run_ring2<0, 8, 0, 16>(buf, rows, ld, sink);
+    run_ring2<4, 2, 12, 16>(buf, rows, ld, sink); run_ring2<4, 4, 12, 16>(buf, rows, ld, sink); run_ring2<2, 8, 8, 32>(buf, rows, ld, sink);
     run_ring<2, 8, true, 1>(buf, rows, ld, sink); run_ring<2, 8, true, 2>(buf, rows, ld, sink);
     run_ring<2, 8, false>(buf, rows, ld, sink); run_ring<4, 4, false>(buf, rows, ld, sink); run_ring<2, 4, true>(buf, rows, ld, sink);
     return 0;
