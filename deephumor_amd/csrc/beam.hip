@@ -53,6 +53,13 @@ __device__ __forceinline__ void radix_pick_digit(const int* hist, int n_hist, in
     __syncthreads();
 }
 
+// lanes of one wave exchanging data through LDS without a workgroup barrier: keep the compiler from moving LDS accesses
+// across the hand-over (the hardware executes a wave's LDS operations in order)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ float block_reduce_256(float v, float* red, bool is_max) {
     const int tid = threadIdx.x;
     red[tid] = v;
@@ -207,6 +214,26 @@ __device__ void radix_row_candidates(const float* __restrict__ row, int V, int t
 // (about top_k..2*top_k values on real logits) is compacted into LDS and the exact threshold,
 // the survivors and the draws are computed there.  If more than CAP values pass the bound (flat / tied
 // logits) the kernel re-derives the exact candidate set in place with radix_row_candidates.
+// Picks handed from one workgroup to another inside a launch (fused beam step): stored / loaded with the sc1 bit (agent-scope
+// relaxed atomics) so they bypass the non-coherent per-XCD L2s; the ordering is the storing waves' vmcnt(0) + workgroup barrier
+// before the arrival counter's add and the reader's barrier after it (MI355X_MICROARCH "Correctness boundaries").  A full
+// agent-scope release fence instead (L2 write-back) in each of the 1,280 workgroups cost 19 us per step.
+__device__ __forceinline__ void pick_store(int32_t* pi, float* pv, size_t at, int32_t idx, float val, bool shared) {
+    if (shared) {
+        __hip_atomic_store(pi + at, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<int32_t*>(pv) + at, __builtin_bit_cast(int32_t, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        pi[at] = idx; pv[at] = val;
+    }
+}
+__device__ __forceinline__ int32_t pick_load_idx(const int32_t* pi, size_t at, bool shared) {
+    return shared ? __hip_atomic_load(pi + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pi[at];
+}
+__device__ __forceinline__ float pick_load_val(const float* pv, size_t at, bool shared) {
+    return shared ? __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int32_t*>(pv) + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                  : pv[at];
+}
+
 struct RowLds {
     int* idx_a; int* idx_b; float* val_a; float* val_b; float* qv; float* red; int* picks; int* s_cnt; uint32_t* s_thr;
 };
@@ -218,7 +245,7 @@ template <int NT>
 __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int rows_per_img, int beam, int top_k,
                                          float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
                                          const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
-                                         float* __restrict__ pick_val, int32_t* __restrict__ err) {
+                                         float* __restrict__ pick_val, int32_t* __restrict__ err, bool shared_picks = false) {
     const int tid = threadIdx.x;
     int* idx_a = L.idx_a; int* idx_b = L.idx_b; float* val_a = L.val_a; float* val_b = L.val_b;
     float* qv = L.qv; float* red = L.red; int* picks = L.picks;
@@ -248,7 +275,7 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
     const int n = s_cnt;
     if (n == 0) {
         if (tid == 0) atomicOr(err, DH_BEAM_ERR_ALL_FILTERED);
-        if (tid < beam) { pick_idx[(size_t)rc * beam + tid] = 0; pick_val[(size_t)rc * beam + tid] = 0.f; }
+        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f, shared_picks);
         return;
     }
     // deterministic order: sort survivors by token index
@@ -302,8 +329,7 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
         const float se = wave_sum(pi >= 0 ? expf(lv - mx) : 0.f);
         const float lse = logf(se);
         if (tid < beam) {
-            pick_idx[(size_t)rc * beam + tid] = pi >= 0 ? idx_a[pi] : 0;
-            pick_val[(size_t)rc * beam + tid] = pi >= 0 ? (lv - mx) - lse : -INFINITY;
+            pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, pi >= 0 ? idx_a[pi] : 0, pi >= 0 ? (lv - mx) - lse : -INFINITY, shared_picks);
         }
     }
 #undef s_cnt
@@ -370,26 +396,148 @@ __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
     row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err);
 }
 
+// ---- candidate draw of one image (used by beam_select_kernel and by the fused step below) ------------------------------------
+struct SelectParams {
+    const int32_t* pick_idx; const float* pick_val;
+    int32_t* tokens; int tok_ld; float* vals; uint8_t* ended; int32_t* src; int src_ld;
+    int32_t* parent; int32_t* hparent; uint8_t* done; int32_t* end_step;
+    int beam, first, first_sets_ended, write_pos, t, step_index, eos, img0;
+    float temperature; const float* noise; uint64_t seed; const uint64_t* seed_ptr;
+};
+
+// LDS scratch of one image's candidate draw: carved by the caller (its own arrays in beam_select_kernel, the dead candidate
+// buffers of the row kernel in the fused step)
+struct SelLds {
+    int32_t* stage;                                     // [beam][tok_ld] tokens, then [beam][t] ancestors
+    int* ctok; int* cpar; int* keep; float* cval; float* q; uint8_t* cend; int* s_n;
+};
+#define DH_SEL_STAGE_MAX 3072                           // ints available for `stage` in the fused step
+
+// The candidate draw + in-place rewrite of one image's beam state, executed by ONE wave (lane = 0..63); LDS hand-overs are
+// wave-local (wave_lds_sync), so the same body serves the stand-alone kernel and the tail of the fused row kernel.
+__device__ __forceinline__ void beam_select_image(const SelectParams& p, const int img, const int lane, const SelLds& L,
+                                                  const bool shared_picks = false) {
+    int32_t* stage = L.stage;
+    int* ctok = L.ctok; int* cpar = L.cpar; int* keep = L.keep; float* cval = L.cval; float* q = L.q; uint8_t* cend = L.cend;
+#define s_n (*L.s_n)
+    const int B = p.beam, base = img * B;
+    if (p.done[img]) return;
+
+    // candidate list in the reference's order: beam b contributes 1 candidate if it has ended, else B.
+    // Every lane derives the (short) offset table itself; candidates are then filled in parallel.
+    if (p.first) {
+        for (int j = lane; j < B; j += 64) {
+            const int tok = pick_load_idx(p.pick_idx, (size_t)img * B + j, shared_picks);
+            ctok[j] = tok; cval[j] = pick_load_val(p.pick_val, (size_t)img * B + j, shared_picks); cpar[j] = 0;
+            cend[j] = (uint8_t)(p.first_sets_ended && tok == p.eos);
+            keep[j] = j;
+        }
+        if (lane == 0) s_n = B;
+    } else {
+        int off[DH_BEAM_MAX_BEAMS + 1];
+        uint8_t was_ended[DH_BEAM_MAX_BEAMS];
+#pragma unroll
+        for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b) was_ended[b] = p.ended[base + min(b, B - 1)];   // one round trip for all
+        off[0] = 0;
+#pragma unroll
+        for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b)
+            off[b + 1] = off[b] + (b < B ? (was_ended[b] ? 1 : B) : 0);
+        const int total = off[B];
+        for (int c = lane; c < total; c += 64) {
+            int b = 0;
+#pragma unroll
+            for (int k = 1; k < DH_BEAM_MAX_BEAMS; ++k) b += (k < B && c >= off[k]);
+            const int j = c - off[b];
+            const bool was = p.ended[base + b] != 0;
+            const int tok = was ? 0 : pick_load_idx(p.pick_idx, (size_t)(base + b) * B + j, shared_picks);
+            ctok[c] = tok;
+            cval[c] = p.vals[base + b] + (was ? 0.f : pick_load_val(p.pick_val, (size_t)(base + b) * B + j, shared_picks));
+            cpar[c] = b;
+            cend[c] = (uint8_t)(was || tok == p.eos);
+        }
+        if (lane == 0) s_n = total;
+    }
+    wave_lds_sync();
+    const int n = s_n;
+    if (!p.first) {
+        // draw `beam` candidates without replacement from softmax(cand_val / T)
+        float m = -INFINITY;
+        for (int c = lane; c < n; c += 64) m = fmaxf(m, cval[c] / p.temperature);
+        m = wave_max(m);
+        float s = 0.f;
+        for (int c = lane; c < n; c += 64) { const float e = expf(cval[c] / p.temperature - m); q[c] = e; s += e; }
+        s = wave_sum(s);
+        for (int c = lane; c < n; c += 64) {
+            const float nz = p.noise ? p.noise[(size_t)img * B * B + c]
+                                     : philox_exp1(p.seed ^ (p.seed_ptr ? *p.seed_ptr : 0ull), (uint32_t)(p.img0 + img), (uint32_t)p.step_index, 1u, 0u, (uint32_t)c);
+            q[c] = (q[c] / s) / nz;
+        }
+        wave_lds_sync();
+        for (int c = lane; c < n; c += 64) {
+            const float me = q[c];
+            int r = 0;
+            for (int j = 0; j < n; ++j) r += (q[j] > me) || (q[j] == me && j < c);
+            if (r < B) keep[r] = c;
+        }
+    }
+    // stage the image's token rows and ancestor rows, then rewrite them in place
+    int32_t* tokbuf = stage;
+    int32_t* srcbuf = stage + (size_t)B * p.tok_ld;
+    for (int i = lane; i < B * p.tok_ld; i += 64) tokbuf[i] = p.tokens[(size_t)base * p.tok_ld + i];
+    if (p.src)
+        for (int b = 0; b < B; ++b)
+            for (int j = lane; j < p.t; j += 64) srcbuf[b * p.t + j] = p.src[(size_t)(base + b) * p.src_ld + j];
+    wave_lds_sync();
+    int all_ended = 1;
+    for (int b = 0; b < B; ++b) {
+        const int c = keep[b], par = cpar[c];
+        for (int i = lane; i < p.tok_ld; i += 64)
+            p.tokens[(size_t)(base + b) * p.tok_ld + i] = (i == p.write_pos) ? ctok[c] : tokbuf[par * p.tok_ld + i];
+        if (p.src) {
+            for (int j = lane; j < p.t; j += 64) p.src[(size_t)(base + b) * p.src_ld + j] = srcbuf[par * p.t + j];
+            if (lane == 0) p.src[(size_t)(base + b) * p.src_ld + p.t] = base + par;
+        }
+        if (lane == 0) {
+            p.vals[base + b] = cval[c];
+            p.ended[base + b] = cend[c];
+            p.parent[base + b] = base + par;
+            p.hparent[base + b] = base + c / B;        // rnn_models.py:135-137: dense B*B layout index
+        }
+        all_ended &= cend[c];
+    }
+    // the reference only tests all_ended() inside the token loop (rnn_models.py:131), never after the first draw
+    if (lane == 0 && all_ended && !p.first) { p.done[img] = 1; p.end_step[img] = p.step_index; }
+#undef s_n
+}
+
 // ---- group-max guided variant -----------------------------------------------------------------------------
 // The vocabulary GEMM (dh_vocab_logits) leaves, next to the logits, the maximum of every group of `gcols`
 // consecutive columns of each row.  The k-th largest GROUP maximum is a lower bound of the row's k-th largest
 // value (k groups hold a value >= it), and only groups whose maximum reaches that bound can contain one of the
 // top-k values: about top_k of the ~570 groups.  So this kernel reads ~9 % of the row instead of all of it.
-template <int NT>
+// FUSED: the workgroup that finishes an image's LAST row also runs that image's candidate draw (beam_select_image) -- one launch
+// per beam step instead of two.  Hand-over between workgroups (possibly on different XCDs, whose L2s are not coherent): every
+// row's picks are stored with sc1 stores and drained (vmcnt(0)), the workgroup's barrier, then one lane adds 1 to the image's
+// arrival counter (agent-scope atomic); the workgroup whose add returns rows_per_img - 1 is the last one: barrier, sc1 loads of
+// all rows' picks.  It resets the counter for the next step.
+template <int NT, bool FUSED = false>
 __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     const float* __restrict__ logits, int ldl, int V, const float* __restrict__ gmax, int gm_ld, int n_groups,
     int gcols, int rows_per_img, int beam, int top_k, float temperature, int unk, const float* __restrict__ noise,
     uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx, float* __restrict__ pick_val,
-    int32_t* __restrict__ err) {
+    int32_t* __restrict__ err, SelectParams sel = SelectParams{}, int32_t* __restrict__ arrive = nullptr) {
     constexpr int MAXG = 1024, GPT = MAXG / NT;       // group keys per thread, kept in registers
     __shared__ int glist[MAXG];
     __shared__ int hist[4][256];
     __shared__ uint32_t s_prefix, s_thr;
     __shared__ int s_k, s_cnt, s_ng, wtot[4];
-    __shared__ __attribute__((aligned(16))) int idx_a[CAP], idx_b[CAP];
-    __shared__ __attribute__((aligned(16))) float val_a[CAP], val_b[CAP], qv[CAP];
+    __shared__ __attribute__((aligned(16))) int32_t pool[5 * CAP];       // the five candidate buffers; dead after row_tail (FUSED reuses them)
+    int* const idx_a = pool; int* const idx_b = pool + CAP;
+    float* const val_a = reinterpret_cast<float*>(pool + 2 * CAP); float* const val_b = reinterpret_cast<float*>(pool + 3 * CAP);
+    float* const qv = reinterpret_cast<float*>(pool + 4 * CAP);
     __shared__ float red[NT];
     __shared__ int picks[DH_BEAM_MAX_BEAMS];
+    __shared__ int s_last;
     const int rc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (size_t)rc * ldl;
     uint32_t gk[GPT];
@@ -442,7 +590,24 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     __syncthreads();
     if (s_cnt > CAP) radix_row_candidates<NT>(row, V, top_k, &hist[0][0], &s_prefix, &s_k, &s_cnt, wtot, idx_a, val_a);
     const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
-    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err);
+    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err, FUSED);
+    if constexpr (FUSED) {
+        const int img = rc / rows_per_img;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 pick stores have been acknowledged
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(&arrive[img], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == rows_per_img - 1;
+            if (s_last) __hip_atomic_store(&arrive[img], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reset for the next step
+        }
+        __syncthreads();
+        if (s_last && wave == 0) {
+            const SelLds SL{pool, pool + DH_SEL_STAGE_MAX, pool + DH_SEL_STAGE_MAX + 256, pool + DH_SEL_STAGE_MAX + 512,
+                            reinterpret_cast<float*>(pool + DH_SEL_STAGE_MAX + 528), reinterpret_cast<float*>(pool + DH_SEL_STAGE_MAX + 784),
+                            reinterpret_cast<uint8_t*>(pool + DH_SEL_STAGE_MAX + 1040), pool + DH_SEL_STAGE_MAX + 1104};
+            beam_select_image(sel, img, lane, SL, true);
+        }
+    }
 }
 
 extern "C" int dh_beam_row_sample_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld,
@@ -478,12 +643,6 @@ extern "C" int dh_beam_row_sample_groups(const float* logits, int ldl, int V, co
 // DH_BEAM_ERR_TOPK_GROUPS and the caller repeats the step on the dense path.
 #define TOPK_CAND 512
 
-// lanes of one wave exchanging data through LDS without a workgroup barrier: keep the compiler from moving LDS accesses
-// across the hand-over (the hardware executes a wave's LDS operations in order)
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 
 // k-th largest of the keys a wave holds (E per lane, key 0 = absent), 1 <= k: the largest T with #(key >= T) >= k
 template <int E>
@@ -701,107 +860,15 @@ extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows,
 }
 
 // ------------------------------------------------------------------------------------------------
-struct SelectParams {
-    const int32_t* pick_idx; const float* pick_val;
-    int32_t* tokens; int tok_ld; float* vals; uint8_t* ended; int32_t* src; int src_ld;
-    int32_t* parent; int32_t* hparent; uint8_t* done; int32_t* end_step;
-    int beam, first, first_sets_ended, write_pos, t, step_index, eos, img0;
-    float temperature; const float* noise; uint64_t seed; const uint64_t* seed_ptr;
-};
 
 __global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
-    extern __shared__ int32_t stage[];                  // [beam][tok_ld] tokens, then [beam][t] ancestors
+    extern __shared__ int32_t stage[];
     __shared__ int ctok[256], cpar[256], keep[DH_BEAM_MAX_BEAMS];
     __shared__ float cval[256], q[256];
     __shared__ uint8_t cend[256];
     __shared__ int s_n;
-    const int img = blockIdx.x, lane = threadIdx.x, B = p.beam, base = img * B;
-    if (p.done[img]) return;
-
-    // candidate list in the reference's order: beam b contributes 1 candidate if it has ended, else B.
-    // Every lane derives the (short) offset table itself; candidates are then filled in parallel.
-    if (p.first) {
-        for (int j = lane; j < B; j += 64) {
-            const int tok = p.pick_idx[(size_t)img * B + j];
-            ctok[j] = tok; cval[j] = p.pick_val[(size_t)img * B + j]; cpar[j] = 0;
-            cend[j] = (uint8_t)(p.first_sets_ended && tok == p.eos);
-            keep[j] = j;
-        }
-        if (lane == 0) s_n = B;
-    } else {
-        int off[DH_BEAM_MAX_BEAMS + 1];
-        uint8_t was_ended[DH_BEAM_MAX_BEAMS];
-#pragma unroll
-        for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b) was_ended[b] = p.ended[base + min(b, B - 1)];   // one round trip for all
-        off[0] = 0;
-#pragma unroll
-        for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b)
-            off[b + 1] = off[b] + (b < B ? (was_ended[b] ? 1 : B) : 0);
-        const int total = off[B];
-        for (int c = lane; c < total; c += 64) {
-            int b = 0;
-#pragma unroll
-            for (int k = 1; k < DH_BEAM_MAX_BEAMS; ++k) b += (k < B && c >= off[k]);
-            const int j = c - off[b];
-            const bool was = p.ended[base + b] != 0;
-            const int tok = was ? 0 : p.pick_idx[(size_t)(base + b) * B + j];
-            ctok[c] = tok;
-            cval[c] = p.vals[base + b] + (was ? 0.f : p.pick_val[(size_t)(base + b) * B + j]);
-            cpar[c] = b;
-            cend[c] = (uint8_t)(was || tok == p.eos);
-        }
-        if (lane == 0) s_n = total;
-    }
-    __syncthreads();
-    const int n = s_n;
-    if (!p.first) {
-        // draw `beam` candidates without replacement from softmax(cand_val / T)
-        float m = -INFINITY;
-        for (int c = lane; c < n; c += 64) m = fmaxf(m, cval[c] / p.temperature);
-        m = wave_max(m);
-        float s = 0.f;
-        for (int c = lane; c < n; c += 64) { const float e = expf(cval[c] / p.temperature - m); q[c] = e; s += e; }
-        s = wave_sum(s);
-        for (int c = lane; c < n; c += 64) {
-            const float nz = p.noise ? p.noise[(size_t)img * B * B + c]
-                                     : philox_exp1(p.seed ^ (p.seed_ptr ? *p.seed_ptr : 0ull), (uint32_t)(p.img0 + img), (uint32_t)p.step_index, 1u, 0u, (uint32_t)c);
-            q[c] = (q[c] / s) / nz;
-        }
-        __syncthreads();
-        for (int c = lane; c < n; c += 64) {
-            const float me = q[c];
-            int r = 0;
-            for (int j = 0; j < n; ++j) r += (q[j] > me) || (q[j] == me && j < c);
-            if (r < B) keep[r] = c;
-        }
-    }
-    // stage the image's token rows and ancestor rows, then rewrite them in place
-    int32_t* tokbuf = stage;
-    int32_t* srcbuf = stage + (size_t)B * p.tok_ld;
-    for (int i = lane; i < B * p.tok_ld; i += 64) tokbuf[i] = p.tokens[(size_t)base * p.tok_ld + i];
-    if (p.src)
-        for (int b = 0; b < B; ++b)
-            for (int j = lane; j < p.t; j += 64) srcbuf[b * p.t + j] = p.src[(size_t)(base + b) * p.src_ld + j];
-    __syncthreads();
-    int all_ended = 1;
-    for (int b = 0; b < B; ++b) {
-        const int c = keep[b], par = cpar[c];
-        for (int i = lane; i < p.tok_ld; i += 64)
-            p.tokens[(size_t)(base + b) * p.tok_ld + i] = (i == p.write_pos) ? ctok[c] : tokbuf[par * p.tok_ld + i];
-        if (p.src) {
-            for (int j = lane; j < p.t; j += 64) p.src[(size_t)(base + b) * p.src_ld + j] = srcbuf[par * p.t + j];
-            if (lane == 0) p.src[(size_t)(base + b) * p.src_ld + p.t] = base + par;
-        }
-        if (lane == 0) {
-            p.vals[base + b] = cval[c];
-            p.ended[base + b] = cend[c];
-            p.parent[base + b] = base + par;
-            p.hparent[base + b] = base + c / B;        // rnn_models.py:135-137: dense B*B layout index
-        }
-        all_ended &= cend[c];
-    }
-    // the reference only tests all_ended() inside the token loop (rnn_models.py:131), never after the first draw
-    if (lane == 0 && all_ended && !p.first) { p.done[img] = 1; p.end_step[img] = p.step_index; }
+    const SelLds L{stage, ctok, cpar, keep, cval, q, cend, &s_n};
+    beam_select_image(p, blockIdx.x, threadIdx.x, L);
 }
 
 extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* tokens, int tok_ld,
@@ -818,6 +885,33 @@ extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, in
                    beam, first, first_sets_ended, write_pos, t, step_index, eos_index, img0, temperature, noise, seed, seed_ptr};
     const size_t lds = (size_t)beam * (tok_ld + (src ? t : 0)) * sizeof(int32_t);
     hipLaunchKernelGGL(beam_select_kernel, dim3(n_img), dim3(64), lds, (hipStream_t)stream, p);
+    DH_LAUNCH_CHECK();
+}
+
+// One beam step in ONE launch (16-bit paths): dh_beam_row_sample_groups for every row, and -- by the workgroup that finishes an
+// image's last row -- dh_beam_select for that image.  Same arguments as the two entry points; `arrive` = int32 [n_img], zero
+// before the first call (the kernel leaves it zero).  Returns DH_ERR_UNSUPPORTED when the image's token / ancestor rows do not
+// fit the row kernel's LDS (beam * (tok_ld + t) > 3072 ints): use the two launches then.
+extern "C" int dh_beam_step_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld, int n_groups,
+                                   int group_cols, int rows, int rows_per_img, int beam, int top_k, float temperature,
+                                   int unk_index, const float* row_noise, uint64_t seed, const uint64_t* seed_ptr, int img0,
+                                   int step, int32_t* pick_idx, float* pick_val, int32_t* err, int32_t* tokens, int tok_ld,
+                                   float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent, int32_t* hparent,
+                                   uint8_t* done, int32_t* end_step, int first, int first_sets_ended, int write_pos, int t,
+                                   int eos_index, const float* cand_noise, int32_t* arrive, void* stream) {
+    DH_REQUIRE(logits && group_max && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
+    DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
+    DH_REQUIRE(n_groups > 0 && n_groups <= 1024 && top_k <= n_groups && gm_ld >= n_groups && group_cols > 0 && group_cols <= 64 &&
+               (long long)n_groups * group_cols >= V);
+    DH_REQUIRE(tokens && vals && ended && parent && hparent && done && end_step && arrive && tok_ld > 0 && t >= 0 && (!src || src_ld > t));
+    DH_REQUIRE((rows % rows_per_img) == 0 && (first ? rows_per_img == 1 : rows_per_img == beam));
+    if ((long long)beam * (tok_ld + (src ? t : 0)) > DH_SEL_STAGE_MAX) return DH_ERR_UNSUPPORTED;
+    DhProfScope prof("dh_beam_step", 0.0, 0.0, stream);
+    SelectParams sp{pick_idx, pick_val, tokens, tok_ld, vals, ended, src, src_ld, parent, hparent, done, end_step,
+                    beam, first, first_sets_ended, write_pos, t, step, eos_index, img0, temperature, cand_noise, seed, seed_ptr};
+    hipLaunchKernelGGL((beam_row_sample_groups_kernel<256, true>), dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
+                       group_max, gm_ld, n_groups, group_cols, rows_per_img, beam, top_k, temperature, unk_index, row_noise,
+                       seed, seed_ptr, img0, step, pick_idx, pick_val, err, sp, arrive);
     DH_LAUNCH_CHECK();
 }
 

@@ -123,6 +123,8 @@ SIGNATURES = {
     "dh_vocab_sparse_logits": [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
     "dh_beam_row_sample_compact": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_vocab_topk_sample": [_P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _I, _F, _I, _P, _I, _U64, _P, _I, _I, _P, _P, _P, _I, _P],
+    "dh_beam_step_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P,
+                            _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_token_logprob": [_P, _I, _I, _P, _P, _I, _P],
     "dh_seq_perplexity": [_P, _P, _P, _P, _I, _I, _I, _P],
@@ -762,6 +764,21 @@ def beam_row_sample_groups(logits, v, group_max, rows, rows_per_img, beam, top_k
     _launch("dh_beam_row_sample_groups", _ptr(logits), logits.stride(0), v, _ptr(group_max), group_max.stride(0),
             n_groups(v), GROUP_COLS, rows, rows_per_img, beam, top_k, float(temperature), unk_index, _ptr(noise), seed,
             _ptr(seed_ptr), img0, step, _ptr(pick_idx), _ptr(pick_val), _ptr(err), _stream())
+
+
+SEL_STAGE_MAX = 3072      # ints of LDS the fused beam step has for an image's token + ancestor rows (DH_SEL_STAGE_MAX)
+
+
+def beam_step_groups(logits, v, group_max, rows, rows_per_img, beam, top_k, temperature, unk_index, row_noise, seed, img0, step,
+                     pick_idx, pick_val, err, tokens, vals, ended, src, parent, hparent, done, end_step, first, first_sets_ended,
+                     write_pos, t, eos_index, cand_noise, arrive, seed_ptr=None):
+    """``beam_row_sample_groups`` + ``beam_select`` as one launch (same results)."""
+    _dev(logits, group_max, row_noise, pick_idx, pick_val, err, tokens, vals, ended, src, parent, hparent, done, end_step, cand_noise, arrive)
+    _launch("dh_beam_step_groups", _ptr(logits), logits.stride(0), v, _ptr(group_max), group_max.stride(0), n_groups(v), GROUP_COLS,
+            rows, rows_per_img, beam, top_k, float(temperature), unk_index, _ptr(row_noise), seed, _ptr(seed_ptr), img0, step,
+            _ptr(pick_idx), _ptr(pick_val), _ptr(err), _ptr(tokens), tokens.stride(0), _ptr(vals), _ptr(ended), _ptr(src),
+            src.stride(0) if src is not None else 0, _ptr(parent), _ptr(hparent), _ptr(done), _ptr(end_step), int(first),
+            int(first_sets_ended), write_pos, t, eos_index, _ptr(cand_noise), _ptr(arrive), _stream())
 
 
 def beam_select(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, n_img, beam, first,

@@ -428,6 +428,20 @@ int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* toke
                    float temperature, int eos_index, const float* noise, uint64_t seed,
                    const uint64_t* seed_ptr, int img0, void* stream);
 
+/* One beam step in ONE launch (what dh_beam_row_sample_groups + dh_beam_select do in two): every row draws its picks, and the
+ * workgroup that finishes an image's LAST row runs that image's candidate draw and state rewrite (hand-over through an
+ * agent-scope release / acquire around an arrival counter: the rows of an image may run on different XCDs).  Arguments as in
+ * the two entry points (`step` is also the select's step_index); row_noise / cand_noise NULL -> Philox.  arrive: int32
+ * [n_img], zero before the first call; the kernel leaves it zero.  Returns DH_ERR_UNSUPPORTED when beam * (tok_ld + t) > 3072
+ * (the image's token / ancestor rows do not fit the row kernel's LDS): use the two launches then.  Results are identical. */
+int dh_beam_step_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld, int n_groups,
+                        int group_cols, int rows, int rows_per_img, int beam, int top_k, float temperature,
+                        int unk_index, const float* row_noise, uint64_t seed, const uint64_t* seed_ptr, int img0,
+                        int step, int32_t* pick_idx, float* pick_val, int32_t* err, int32_t* tokens, int tok_ld,
+                        float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent, int32_t* hparent,
+                        uint8_t* done, int32_t* end_step, int first, int first_sets_ended, int write_pos, int t,
+                        int eos_index, const float* cand_noise, int32_t* arrive, void* stream);
+
 /* Per image: final draw ind ~ softmax(vals/T) (k=1 -> arg-max of p/noise), copies
  * tokens[img*beam+ind, 0..len) to out[img, :] (rest = pad) and writes len, where
  * len = (done ? end_step + len_bias_done : full_len).  rnn_models.py:140-141; transformers.py:576-577.

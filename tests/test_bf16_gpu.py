@@ -457,6 +457,37 @@ def test_direct_conv3x3(hip, n, h, w, c):
     np.testing.assert_allclose(got.float().cpu().numpy(), old.float().cpu().numpy(), **tol)
 
 
+@pytest.mark.parametrize("n_img,beam,top_k,v,src_len", [(7, 5, 50, 36541, 0), (33, 10, 50, 5000, 9), (3, 16, 20, 1500, 6), (64, 1, 2, 700, 0)])
+def test_fused_beam_step_equals_two_launches(hip, n_img, beam, top_k, v, src_len):
+    """dh_beam_step_groups (row draw + candidate draw in one launch; the workgroup that finishes an image's last row runs the
+    candidate draw) leaves exactly the state dh_beam_row_sample_groups + dh_beam_select leave, step after step, with Philox
+    noise and with an early <eos> in play."""
+    from deephumor_amd.models.beam import BeamSearchHelper
+    g = torch.Generator().manual_seed(n_img * 100 + beam)
+    max_len = 9
+    mk = lambda: BeamSearchHelper(1.1, beam, top_k, 1, 3, "cuda", n_img=n_img, max_len=max_len, src_len=src_len, seed=77, img0=5)
+    a, b = mk(), mk()
+    a.fused_step, b.fused_step = True, False              # (the model path opts in with DH_FUSED_BEAM_STEP=1)
+    ng = hip.n_groups(v)
+    for step in range(5):
+        rows = n_img if step == 0 else n_img * beam
+        logits = torch.randn(rows, v, generator=g) * 3.0
+        logits[:, 3] += 4.0 if step >= 2 else -4.0                          # <eos> becomes likely from step 2 on
+        logits = logits.cuda()
+        pad = torch.full((rows, ng * 64 - v), float("-inf"), device="cuda")
+        gmax = torch.cat([logits, pad], 1).view(rows, ng, 64).max(-1).values.contiguous()
+        for h in (a, b):
+            h.step(logits, step == 0, step, step, step, first_sets_ended=True, group_max=gmax)
+        for name in ("tokens", "vals", "has_ended", "parent", "hparent", "done", "end_step", "pick_idx", "pick_val", "err", "src"):
+            x, y = getattr(a, name), getattr(b, name)
+            if x is not None:
+                if name.startswith("pick_"):
+                    x, y = x[:rows], y[:rows]                                   # the first step writes one row per image
+                assert torch.equal(x, y), (step, name)
+        assert int(a.arrive.abs().sum()) == 0
+    assert int(a.err.item()) == 0 and bool(a.has_ended.any())
+
+
 @pytest.mark.parametrize("n,h,w,c", [(2, 56, 56, 64), (3, 8, 56, 64), (2, 28, 28, 128), (5, 4, 28, 128)])
 def test_fused_bottleneck_tail(hip, n, h, w, c):
     """dh_bottleneck_tail_nhwc (3x3 conv2 + 1x1 conv3 + residual in one launch, the conv2 tile resident in LDS) against the
