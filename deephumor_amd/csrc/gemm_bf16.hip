@@ -1375,9 +1375,11 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         static const int vns = getenv("DH_VOCAB_TILE") ? atoi(getenv("DH_VOCAB_TILE")) : 128;
         static const int gns = getenv("DH_VOCAB_GMAX_TILE") ? atoi(getenv("DH_VOCAB_GMAX_TILE")) : 256;
         {   // A-stationary kernel: K = 512, row tiles of 128, groups of tiles_m workgroups per XCD (32 CUs each)
-            static const int areg = getenv("DH_VOCAB_AREG") ? atoi(getenv("DH_VOCAB_AREG")) : 0;
+            // default since round 2: in the C2 / C3 steps 3-5 % faster than the 128 x 128 kernel below (2.43 vs 2.49 ms and 2.81 vs 2.99 ms
+            // of classifier time per step, three alternating runs in one call); DH_VOCAB_AREG=0 restores the tile kernel
+            static const int areg = getenv("DH_VOCAB_AREG") ? atoi(getenv("DH_VOCAB_AREG")) : 1;
             const int tm128 = dh_cdiv(M, 128), tn128 = dh_cdiv(V, 128);
-            if (areg && K == 512 && tm128 <= 32 && (32 / tm128) * tm128 >= 28 && tn128 >= 8 * (32 / tm128)) {
+            if (areg && logits && K == 512 && tm128 <= 32 && (32 / tm128) * tm128 >= 28 && tn128 >= 8 * (32 / tm128)) {
                 v.tiles_m = tm128; v.tiles_n = tn128;
                 DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, v));
                 DH_LAUNCH_CHECK();

@@ -15,8 +15,12 @@
 //   * the tiles_m workgroups that share a W panel (same vocabulary rows, different row tiles) sit on the same XCD and walk the
 //     same sequence of panels, so a panel is fetched into that XCD's L2 once.
 // Same results as vocab_logits_kernel bit for bit (same MFMA chain per output: k ascending, one accumulator per output).
-// MEASURED (round 2, 1280 x 36541 x 512, same box): 78.9 us with the logits / 66.2 us group maxima only, against 80.5 / 63 us for the
-// default 128 x 128 kernel (57.4 us for the 256 x 256 kernel without logits) -- on par, so it stays opt-in (DH_VOCAB_AREG=1).
+// MEASURED (round 2, 1280 x 36541 x 512): stand-alone 76.8-79.5 us with the logits against 78.5-83.4 us for the 128 x 128 tile kernel
+// on the same boxes (66 vs 63 us group maxima only); in the C2 / C3 steps 2.43 vs 2.49 ms and 2.81 vs 2.99 ms of classifier time
+// per step (three alternating runs in one call) -- the default for K = 512 with the logits (DH_VOCAB_AREG=0: the tile kernel).
+// Without any epilogue the launch takes 55 us; the group-maxima epilogue adds 11 us and the logits stores another 13: every
+// vector-memory instruction (LDS-DMA piece or store) costs its wave ~100 cycles of issue next to running MFMAs, and nothing
+// overlaps a wave's epilogue but its SIMD partner, which is in its own epilogue at the same time.
 // History of this kernel: with `issued - mark` run-time counts in front of every s_waitcnt (a switch = a tree of taken scalar
 // branches) it took 91 / 75.5 us; immediates in steady state gave 79.6 / 66.6; two slabs per barrier changed nothing (78.9 / 66.2);
 // SIMD partners issuing their transfers at opposite ends of the MFMA block made it worse (86).  Phase stamps of the first version

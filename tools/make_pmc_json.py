@@ -16,9 +16,10 @@ from pathlib import Path
 
 # bench.py roofline key -> (workload, kernel-name fragment, workgroups or None, note)
 KEYS = [
-    ("c2", "dh_linear[vocab]{1280x36541x512}", "vocab_logits_kernel", 512,
-     "persistent 128x128-tile vocabulary GEMM + bias, fp32 logits out; fetch above W + A = other XCDs' L2 misses on W"),
-    ("c3", "dh_linear[vocab]{1280x36541x512}", "vocab_logits_kernel", 512, "same kernel, same shape (256 images x 5 beams)"),
+    ("c2", "dh_linear[vocab]{1280x36541x512}", "vocab_areg_kernel", 256,
+     "A-stationary persistent vocabulary GEMM + bias (activation fragments in registers, W-only LDS ring), fp32 logits out; "
+     "fetch above W + A = weight panels fetched by more than one XCD"),
+    ("c3", "dh_linear[vocab]{1280x36541x512}", "vocab_areg_kernel", 256, "same kernel, same shape (256 images x 5 beams)"),
     ("c3", "dh_attn_self_decode", "attn_decode_reg_kernel", 2048,
      "launch-weighted mean over the history depths of one sweep (2..22 keys per row)"),
     ("c3", "dh_attn_cross_decode", "attn_cross_qproj_kernel", 256,
