@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the image -> caption hot path on MI355X (contract: see the task brief / DESIGN.md section 6b).
 
-    python bench.py --gpus 1 --steps K --warmup W                 # one rank
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W                 # one rank, in-process
+    python bench.py --gpus N --steps K --warmup W                 # N > 1 without a launcher: starts its N ranks itself (child
+                                                                  # torch.distributed.run, before anything touches a GPU)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W     # the driver's form
 
 A "step" is one pass of the hot path over one batch of synthetic images that are already resident in HBM:
 ResNet-50 encoder -> decoder -> beam-search generate (beam=5, top_k=50, 32 tokens) for ``--batch`` images per rank,
@@ -433,7 +435,70 @@ def git_head():
         return None
 
 
-def main():
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """``python bench.py --gpus N`` without a launcher: THIS process (which has only imported torch -- no HIP call, no
+    ``torch.cuda.is_available()``) builds the library once, then starts ``python -m torch.distributed.run`` as a CHILD with one
+    rank per GPU, relays rank 0's JSON line as its own last stdout line and returns the child's exit code.  Nothing that has
+    touched a GPU ever re-execs, and the parent never initialises HIP."""
+    if not args.stub:
+        from deephumor_amd import _build
+        _build.build()                                    # ranks only load the prebuilt .so (no compile under the launcher)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               DH_BENCH_LAUNCHED_BY="bench.py self-launch (child torch.distributed.run)")
+    port = int(os.environ.get("MASTER_PORT", 0)) or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
+    line = None
+    for out in child.stdout:                              # the ranks' stderr passes straight through
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, flush=True)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 3
+        print(f"bench.py: {args.gpus} ranks exited 0 but rank 0 printed no result line", file=sys.stderr)
+    return rc
+
+
+def stub_workload(args, rank, world, dev):
+    """``--stub`` (tests/test_dist_cpu.py): the whole control flow of a multi-rank run -- launcher, process group, image shards,
+    barrier / K steps / barrier, MAX over ranks, one all_gather per step, rank 0's line -- with the model replaced by a pure
+    function of the GLOBAL image index, on CPU over gloo.  Its line says ``"data": "stub"``: it is never a measurement."""
+    from deephumor_amd.dist import gather_captions
+    n_local, n_total = args.batch, args.batch * world
+    idx = torch.arange(rank * n_local, (rank + 1) * n_local)
+    calls = []
+
+    def step(s):
+        calls.append(s)
+        time.sleep(0.01 * (rank + 1))
+        toks = (idx[:, None] * 10 + torch.arange(MAX_LEN)[None, :] + s) % 97
+        return gather_captions(toks, (idx % MAX_LEN) + 1, n_total)
+
+    for w in range(args.warmup):
+        step(-1 - w)
+    del calls[:]
+    dt, (toks, lens) = timed_region(step, args.steps, world, dev)
+    want = (torch.arange(n_total)[:, None] * 10 + torch.arange(MAX_LEN)[None, :] + args.steps - 1) % 97
+    return {"value": n_total * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "steps_run": calls,
+            "gathered": int(toks.shape[0]), "gather_in_global_order": bool(torch.equal(toks, want)),
+            "mean_caption_len": float(lens.float().mean())}
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -447,32 +512,53 @@ def main():
                     "profiler of the roofline line needs real launches, so the roofline then comes from the instrumented pass)")
     ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default=None,
                     help="storage/MFMA operand type of the measured path (BASELINE configs C2-C4: bf16, C5: fp16)")
-    args = ap.parse_args()
+    ap.add_argument("--stub", action="store_true", help="CPU/gloo control-flow test of the multi-rank path (model stubbed; not a measurement)")
+    args = ap.parse_args(argv)
     if args.dtype is None:
         args.dtype = "f16" if args.workload == "c5" else "bf16"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args, argv)                   # before anything touches a GPU
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world == 1 and args.gpus > 1:
-        sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU); see scripts/run_c4.sh")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        return 2
+    launched_by = os.environ.get("DH_BENCH_LAUNCHED_BY") or ("external launcher (torch.distributed.run env)" if "WORLD_SIZE" in os.environ
+                                                             else "in-process (single rank)")
+    if args.stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     n_ranks_seen = 1
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         n_ranks_seen = dist.get_world_size()
 
     def finish(line):
         line["n_ranks_seen"] = n_ranks_seen          # what the process group itself reports (RCCL saw N ranks)
+        line["ranks_launched_by"] = launched_by
         if rank == 0:
-            print(json.dumps(line))
+            print(json.dumps(line), flush=True)
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
             dist.destroy_process_group()
+        return 0
+
+    if args.stub:
+        res = stub_workload(args, rank, world, dev)
+        return finish(dict(res, metric="captions/sec (224x224, 32-tok, beam=5)", unit="captions/s", n_gpus=world, steps=args.steps,
+                           warmup=args.warmup, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="none", data="stub",
+                           config={"workload": "STUB: control flow only, no model, CPU/gloo"}))
 
     if args.workload.startswith("score-"):
         res = run_score(args, rank, world, dev, args.dtype, args.workload.split("-")[1])
@@ -509,8 +595,8 @@ def main():
         r3 = run_workload("c3", args, rank, world, dev, max(3, args.steps // 2), 1, with_cpu, args.dtype, main_line=False)
         r3.pop("encoder_layers", None)
         line["c3"] = dict(r3, workload=workload_name("c3") + ", same batch/beam settings", unit="captions/s")
-    finish(line)
+    return finish(line)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -114,3 +114,35 @@ def test_bench_timed_region_over_two_ranks():
             assert torch.equal(toks, want_t) and torch.equal(lens, want_l)  # whole batch, global order, on every rank
             assert dt >= 3 * 0.1 - 0.02                                     # max over ranks (rank 1 sleeps 0.1 s per step)
         assert abs(ret[0][0] - ret[1][0]) < 1e-9                            # one all-reduced number
+
+
+def test_bench_gpus_n_launches_its_own_ranks(monkeypatch, capfd):
+    """`python bench.py --gpus 2` with no launcher around it (WORLD_SIZE unset): main() spawns the ranks as a CHILD
+    torch.distributed.run before touching any GPU, relays rank 0's line and returns the child's rc.  Model stubbed
+    (--stub: CPU / gloo), everything else -- argument relay, rendezvous on 127.0.0.1, shards, timed_region, all_gather,
+    n_ranks_seen -- is the code the 8-GPU run takes."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "DH_BENCH_LAUNCHED_BY"):
+        monkeypatch.delenv(k, raising=False)
+    rc = bench.main(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "5", "--stub"])
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0, out
+    line = json.loads(out[-1])                                             # the LAST stdout line is the result line
+    assert line["n_gpus"] == 2 and line["n_ranks_seen"] == 2 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["ranks_launched_by"].startswith("bench.py self-launch")
+    assert line["steps_run"] == [0, 1, 2] and line["gathered"] == 10 and line["gather_in_global_order"]
+    assert line["data"] == "stub"                                          # can never be mistaken for a measurement
+    assert line["ms_per_step"] >= 20 - 2                                   # rank 1 sleeps 20 ms per step: MAX over ranks
+
+
+def test_bench_rejects_mismatched_world_size(monkeypatch, capfd):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setenv("RANK", "0")
+    assert bench.main(["--gpus", "2", "--stub"]) == 2
+    assert "WORLD_SIZE=4" in capfd.readouterr().err
