@@ -915,6 +915,170 @@ extern "C" int dh_beam_step_groups(const float* logits, int ldl, int V, const fl
     DH_LAUNCH_CHECK();
 }
 
+// ---- the reference's METHOD surface (deephumor/models/beam.py:32-108), one kernel per method ------------------------------------
+// BeamSearchHelper.filter_top_k / sample_k_indices / filter_by_indices / process_logits as the reference's own generate() loops
+// call them (rnn_models.py:87-128, transformers.py:532-569): host-driven, one image at a time, tensors of the reference's shapes
+// and dtypes (int64 indices, fp32 values, in-place -inf filter).  The batched decode engine above does not use them.
+
+__device__ __forceinline__ float key2f(uint32_t k) {           // inverse of f2key
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// beam.py:34-36: logits[logits < kth_largest] = -inf (strict: ties at the threshold stay), logits[:, unk] = -inf
+__global__ __launch_bounds__(256) void beam_filter_topk_kernel(float* __restrict__ logits, int ldl, int V, int top_k, int unk) {
+    __shared__ int hist[4 * 256];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_k, wtot[4];
+    const int tid = threadIdx.x, hw = tid >> 6;
+    float* row = logits + (size_t)blockIdx.x * ldl;
+    if (tid == 0) { s_prefix = 0u; s_k = top_k; }
+    uint32_t mask = 0u;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int i = tid; i < 1024; i += 256) hist[i] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix;
+        for (int i = tid; i < V; i += 256) {
+            const uint32_t key = f2key(row[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[hw * 256 + ((key >> shift) & 255u)], 1);
+        }
+        __syncthreads();
+        radix_pick_digit(hist, 4, shift, prefix, &s_prefix, &s_k, wtot);
+        mask |= 0xFFu << shift;
+    }
+    const float thr = key2f(s_prefix);                          // the k-th largest value of the row
+    for (int i = tid; i < V; i += 256)
+        if (row[i] < thr || i == unk) row[i] = -INFINITY;
+}
+
+// beam.py:39-48: p = softmax(x / T); torch.multinomial(p, k) without replacement == the k largest of p / Exp(1) noise, in
+// descending order (CPU torch).  k rounds of a block arg-max (ties -> lower index) over the whole row.
+__global__ __launch_bounds__(256) void beam_sample_k_kernel(const float* __restrict__ x, int ld, int V, int k, float temperature,
+                                                            const float* __restrict__ noise, int noise_ld, uint64_t seed,
+                                                            const uint64_t* __restrict__ seed_ptr, int stream_id, int draw,
+                                                            int64_t* __restrict__ out, int32_t* __restrict__ err) {
+    __shared__ float red[256];
+    __shared__ float rq[256];
+    __shared__ int ri[256];
+    __shared__ int picked[64];
+    const int tid = threadIdx.x, r = blockIdx.x;
+    const float* row = x + (size_t)r * ld;
+    float m = -INFINITY;
+    for (int i = tid; i < V; i += 256) m = fmaxf(m, row[i] / temperature);
+    m = block_reduce_256(m, red, true);
+    if (m == -INFINITY) {                                       // softmax of an all -inf row is NaN: torch raises
+        if (tid == 0) atomicOr(err, DH_BEAM_ERR_ALL_FILTERED);
+        for (int j = tid; j < k; j += 256) out[(size_t)r * k + j] = 0;
+        return;
+    }
+    float s = 0.f, cnt = 0.f;
+    for (int i = tid; i < V; i += 256) { const float e = expf(row[i] / temperature - m); s += e; cnt += e > 0.f ? 1.f : 0.f; }
+    s = block_reduce_256(s, red, false);
+    cnt = block_reduce_256(cnt, red, false);
+    if (tid == 0 && cnt < (float)k) atomicOr(err, DH_BEAM_ERR_TOO_FEW);      // "not enough non-negative category to sample"
+    const uint64_t sd = seed ^ (seed_ptr ? *seed_ptr : 0ull);
+    for (int round = 0; round < k; ++round) {
+        float bq = -1.f; int bi = 0x7FFFFFFF;
+        for (int i = tid; i < V; i += 256) {
+            bool taken = false;
+            for (int j = 0; j < round; ++j) taken |= picked[j] == i;
+            if (taken) continue;
+            const float nz = noise ? noise[(size_t)r * noise_ld + i] : philox_exp1(sd, (uint32_t)stream_id, (uint32_t)draw, 3u, (uint32_t)r, (uint32_t)i);
+            const float q = (expf(row[i] / temperature - m) / s) / nz;
+            if (q > bq) { bq = q; bi = i; }                     // ascending i: the first (lowest) index wins a tie
+        }
+        rq[tid] = bq; ri[tid] = bi;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                const float oq = rq[tid + st]; const int oi = ri[tid + st];
+                if (oq > rq[tid] || (oq == rq[tid] && oi < ri[tid])) { rq[tid] = oq; ri[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { picked[round] = ri[0]; out[(size_t)r * k + round] = ri[0] == 0x7FFFFFFF ? 0 : ri[0]; }
+        __syncthreads();
+    }
+}
+
+// beam.py:50-53: torch.gather(values, 1, indices)
+__global__ void beam_gather_kernel(const float* __restrict__ values, int ld, int V, const int64_t* __restrict__ indices, int k,
+                                   float* __restrict__ out, int total, int32_t* __restrict__ err) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int64_t i = indices[t];
+    if (i < 0 || i >= V) { if (err) atomicOr(err, DH_BEAM_ERR_OVERFLOW); out[t] = 0.f; return; }
+    out[t] = values[(size_t)(t / k) * ld + i];
+}
+
+// beam.py:78-106: log_softmax over each row's gathered picks, then the candidate expansion -- a live beam contributes `beam`
+// candidates, an ended one a single candidate with token 0 / score 0 -- with the new has_ended flags and the repeated sequences.
+__global__ __launch_bounds__(64) void beam_expand_kernel(const int64_t* __restrict__ ind, const float* __restrict__ gathered,
+                                                         const uint8_t* __restrict__ ended, const int64_t* __restrict__ seqs, int seq_len,
+                                                         const float* __restrict__ vals, int val_w, int n, int beam, int eos,
+                                                         int64_t* __restrict__ prev_seqs, float* __restrict__ prev_vals,
+                                                         int64_t* __restrict__ new_ind, float* __restrict__ new_val,
+                                                         uint8_t* __restrict__ new_ended) {
+    const int lane = threadIdx.x;
+    int total = 0;
+    for (int b = 0; b < n; ++b) total += ended[b] ? 1 : beam;
+    for (int c = lane; c < total; c += 64) {
+        int b = 0, off = 0;
+        for (;;) { const int w = ended[b] ? 1 : beam; if (c < off + w) break; off += w; ++b; }
+        const int j = c - off;
+        const bool was = ended[b] != 0;
+        float mx = -INFINITY;
+        for (int u = 0; u < beam; ++u) mx = fmaxf(mx, gathered[(size_t)b * beam + u]);
+        float se = 0.f;
+        for (int u = 0; u < beam; ++u) se += expf(gathered[(size_t)b * beam + u] - mx);
+        const int64_t tok = was ? 0 : ind[(size_t)b * beam + j];
+        new_ind[c] = tok;
+        new_val[c] = was ? 0.f : (gathered[(size_t)b * beam + j] - mx) - logf(se);
+        new_ended[c] = (uint8_t)(was || tok == eos);
+        for (int i = 0; i < seq_len; ++i) prev_seqs[(size_t)c * seq_len + i] = seqs[(size_t)b * seq_len + i];
+        for (int i = 0; i < val_w; ++i) prev_vals[(size_t)c * val_w + i] = vals[(size_t)b * val_w + i];
+    }
+}
+
+extern "C" int dh_beam_filter_top_k(float* logits, int ldl, int V, int rows, int top_k, int unk_index, void* stream) {
+    DH_REQUIRE(logits && rows > 0 && V > 0 && ldl >= V && top_k >= 1 && top_k <= V);
+    DhProfScope prof("dh_beam_filter_top_k", 0.0, 0.0, stream);
+    hipLaunchKernelGGL(beam_filter_topk_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V, top_k, unk_index);
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_beam_sample_k(const float* x, int ld, int V, int rows, int k, float temperature, const float* noise, int noise_ld,
+                                uint64_t seed, const uint64_t* seed_ptr, int stream_id, int draw, int64_t* out, int32_t* err,
+                                void* stream) {
+    DH_REQUIRE(x && out && err && rows > 0 && V > 0 && ld >= V && k >= 1 && k <= 64 && k <= V && temperature > 0.f);
+    DH_REQUIRE(!noise || noise_ld >= V);
+    DhProfScope prof("dh_beam_sample_k", 0.0, 0.0, stream);
+    hipLaunchKernelGGL(beam_sample_k_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, V, k, temperature, noise, noise_ld,
+                       seed, seed_ptr, stream_id, draw, out, err);
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_beam_gather(const float* values, int ld, int V, const int64_t* indices, int k, float* out, int rows, int32_t* err,
+                              void* stream) {
+    DH_REQUIRE(values && indices && out && rows > 0 && k > 0 && V > 0 && ld >= V);
+    DhProfScope prof("dh_beam_gather", 0.0, 0.0, stream);
+    const int total = rows * k;
+    hipLaunchKernelGGL(beam_gather_kernel, dim3(dh_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, values, ld, V, indices, k, out,
+                       total, err);
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_beam_expand(const int64_t* new_ind, const float* gathered, const uint8_t* ended, const int64_t* seqs, int seq_len,
+                              const float* vals, int val_width, int n_rows, int beam, int eos_index, int64_t* prev_seqs,
+                              float* prev_vals, int64_t* out_ind, float* out_val, uint8_t* out_ended, void* stream) {
+    DH_REQUIRE(new_ind && gathered && ended && seqs && vals && prev_seqs && prev_vals && out_ind && out_val && out_ended);
+    DH_REQUIRE(n_rows > 0 && n_rows <= 1024 && beam >= 1 && beam <= 64 && seq_len >= 0 && val_width >= 1);
+    DhProfScope prof("dh_beam_expand", 0.0, 0.0, stream);
+    hipLaunchKernelGGL(beam_expand_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, new_ind, gathered, ended, seqs, seq_len, vals,
+                       val_width, n_rows, beam, eos_index, prev_seqs, prev_vals, out_ind, out_val, out_ended);
+    DH_LAUNCH_CHECK();
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void beam_finalize_kernel(
     const int32_t* __restrict__ tokens, int tok_ld, const float* __restrict__ vals, const uint8_t* __restrict__ done,

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 9
+ABI_VERSION = 10
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW, ERR_TOPK_GROUPS = 1, 2, 4, 8
 TOPK_SLOTS = 64
@@ -135,6 +135,10 @@ SIGNATURES = {
     "dh_prof_get": [_I, _c.c_char_p, _I, _c.POINTER(_I), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
                     _c.POINTER(_c.c_double)],
     "dh_beam_finalize": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _U64, _P, _I, _P],
+    "dh_beam_filter_top_k": [_P, _I, _I, _I, _I, _I, _P],
+    "dh_beam_sample_k": [_P, _I, _I, _I, _I, _F, _P, _I, _U64, _P, _I, _I, _P, _P, _P],
+    "dh_beam_gather": [_P, _I, _I, _P, _I, _P, _I, _P, _P],
+    "dh_beam_expand": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
 }
 
 
@@ -789,6 +793,38 @@ def beam_select(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, d
                                  _ptr(hparent), _ptr(done), _ptr(end_step), n_img, beam, int(first),
                                  int(first_sets_ended), write_pos, t, step_index, float(temperature), eos_index,
                                  _ptr(noise), seed, _ptr(seed_ptr), img0, _stream())
+
+
+def beam_filter_top_k(logits, top_k, unk_index):
+    """beam.py:32-37 in place on fp32 ``logits [rows, V]`` (unit column stride; the row stride may exceed V)."""
+    _dev(logits)
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and logits.stride(1) == 1
+    _launch("dh_beam_filter_top_k", _ptr(logits), logits.stride(0), logits.shape[1], logits.shape[0], top_k, unk_index, _stream())
+
+
+def beam_sample_k(x, k, temperature, noise, seed, stream_id, draw, out, err, seed_ptr=None):
+    """beam.py:39-48: ``out [rows, k]`` int64 = multinomial(softmax(x / T), k) as an Exp(1) race."""
+    _dev(x, noise, out, err)
+    assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and out.dtype == torch.int64
+    _launch("dh_beam_sample_k", _ptr(x), x.stride(0), x.shape[1], x.shape[0], k, float(temperature), _ptr(noise),
+            0 if noise is None else noise.stride(0), seed, _ptr(seed_ptr), stream_id, draw, _ptr(out), _ptr(err), _stream())
+
+
+def beam_gather(values, indices, out, err=None):
+    """beam.py:50-53: ``out[r, j] = values[r, indices[r, j]]``."""
+    _dev(values, indices, out, err)
+    assert values.dtype == torch.float32 and values.stride(1) == 1 and indices.dtype == torch.int64 and indices.is_contiguous()
+    _launch("dh_beam_gather", _ptr(values), values.stride(0), values.shape[1], _ptr(indices), indices.shape[1], _ptr(out),
+            values.shape[0], _ptr(err), _stream())
+
+
+def beam_expand(new_ind, gathered, ended, seqs, vals, beam, eos_index, prev_seqs, prev_vals, out_ind, out_val, out_ended):
+    """beam.py:78-106 (log-softmax of the picks + candidate expansion by the has_ended flags)."""
+    _dev(new_ind, gathered, ended, seqs, vals, prev_seqs, prev_vals, out_ind, out_val, out_ended)
+    n = ended.shape[0]
+    _launch("dh_beam_expand", _ptr(new_ind), _ptr(gathered), _ptr(ended), _ptr(seqs), seqs.shape[1], _ptr(vals),
+            vals.numel() // n, n, beam, eos_index, _ptr(prev_seqs), _ptr(prev_vals), _ptr(out_ind), _ptr(out_val), _ptr(out_ended),
+            _stream())
 
 
 def beam_finalize(tokens, vals, done, end_step, out, out_len, n_img, beam, len_bias_done, full_len, pad_index,

@@ -48,7 +48,11 @@ class BeamSearchHelper:
         piece = lambda i: arena[offs[i]:offs[i] + words[i]]
         self.tokens = piece(0).view(r, max_len)
         self.vals = piece(1).view(torch.float32)
-        self.has_ended = piece(2).view(torch.uint8)[:r]
+        # engine state (uint8, all images).  `has_ended` starts as the SAME tensor; the reference-style method surface below
+        # (process_logits, or a caller assigning `helper.has_ended = ...` as rnn_models.py:103,126 do) rebinds only the public name
+        self._ended = piece(2).view(torch.uint8)[:r]
+        self.has_ended = self._ended
+        self._draws = 0                   # multinomial calls made through the method surface (Philox `draw` counter)
         self.parent, self.hparent = piece(3), piece(4)
         self.done = piece(5).view(torch.uint8)[:n_img]
         self.end_step, self.err = piece(6), piece(7)
@@ -94,7 +98,7 @@ class BeamSearchHelper:
             # 16-bit paths: row draw + candidate draw of the step in one launch
             hip.beam_step_groups(logits, v, group_max, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
                                  self._noise("row", step_index, (rows, v), logits.stride(0)), self.seed, self.img0, step_index,
-                                 self.pick_idx, self.pick_val, self.err, self.tokens, self.vals, self.has_ended, self.src,
+                                 self.pick_idx, self.pick_val, self.err, self.tokens, self.vals, self._ended, self.src,
                                  self.parent, self.hparent, self.done, self.end_step, first, first_sets_ended, write_pos, t,
                                  self.eos_index, None if first else self._noise("cand", step_index, (self.n_img, self.beam_size ** 2)),
                                  self.arrive, seed_ptr=self.seed_tensor)
@@ -109,7 +113,7 @@ class BeamSearchHelper:
                                 self._noise("row", step_index, (rows, v), logits.stride(0)), self.seed, self.img0, step_index,
                                 self.pick_idx, self.pick_val, self.err, seed_ptr=self.seed_tensor)
         noise = None if first else self._noise("cand", step_index, (self.n_img, self.beam_size ** 2))
-        hip.beam_select(self.pick_idx, self.pick_val, self.tokens, self.vals, self.has_ended, self.src,
+        hip.beam_select(self.pick_idx, self.pick_val, self.tokens, self.vals, self._ended, self.src,
                         self.parent, self.hparent, self.done, self.end_step, self.n_img, self.beam_size, first,
                         first_sets_ended, write_pos, t, step_index, self.temperature, self.eos_index, noise,
                         self.seed, self.img0, seed_ptr=self.seed_tensor)
@@ -143,12 +147,86 @@ class BeamSearchHelper:
         if code & hip.ERR_OVERFLOW:
             raise RuntimeError("more than 1024 logits of a row tie at its top-k threshold (DH_BEAM_MAX_SURVIVORS); "
                                "the reference would sample among all of them")
+        if code & hip.ERR_TOPK_GROUPS:
+            raise RuntimeError("logits-free classifier: more than 64 column groups or 512 logits reach a row's top-k bound "
+                               "(DH_BEAM_ERR_TOPK_GROUPS); repeat the step on the dense path (dh_vocab_logits + dh_beam_row_sample_groups)")
         if code & hip.ERR_TOO_FEW:
             raise RuntimeError("fewer positive-probability tokens than beams (top_k == beam_size with <unk> in the top-k)")
 
     def all_ended(self):
-        """Host-visible early-exit test (one sync; callers poll it sparsely, not per token)."""
+        """Host-visible early-exit test (one sync; callers poll it sparsely, not per token).  Engine use: every image's beams
+        have ended (`done`); method-surface use (beam.py:110-112): every flag of the caller-visible ``has_ended``."""
+        if self.has_ended is not self._ended:
+            return bool(self.has_ended.cpu().numpy().all())
         return bool(self.done.cpu().numpy().all())
+
+    # ---- the reference's method surface (beam.py:32-108): same names, argument meaning, shapes, dtypes and in-place behaviour,
+    # each method one HIP launch.  Host-driven like the reference's own loops (rnn_models.py:87-128, transformers.py:532-569):
+    # sample_k_indices reads the device error word (one sync per draw) so that it raises where torch.multinomial raises.
+    def _draw_noise(self, shape):
+        """Exp(1) noise of one multinomial call: the ``noise_source`` hook (``("multinomial", call number, shape)``) or Philox."""
+        self._draws += 1
+        if self.noise_source is None:
+            return None
+        t = self.noise_source("multinomial", self._draws - 1, shape)
+        return None if t is None else t.to(device=self.device, dtype=torch.float32).reshape(shape).contiguous()
+
+    def filter_top_k(self, logits):
+        """beam.py:32-37: IN PLACE -- entries strictly below the row's ``top_k``-th largest value and the ``unk`` column become
+        ``-inf`` (ties at the threshold stay); returns its argument."""
+        hip.beam_filter_top_k(logits, self.top_k, self.unk_index)
+        return logits
+
+    def sample_k_indices(self, logits, k=None):
+        """beam.py:39-48: ``torch.multinomial(softmax(logits / temperature), k)`` (no replacement) as an Exp(1) race on the
+        device; ``logits`` is ``[n, V]`` -> int64 ``[n, k]`` or 1-D ``[V]`` -> ``[k]`` (the candidate draws, rnn_models.py:120)."""
+        k = self.beam_size if k is None else int(k)
+        x = logits if logits.dim() == 2 else logits.reshape(1, -1)
+        if x.dtype != torch.float32 or x.stride(-1) != 1:
+            raise TypeError("sample_k_indices expects fp32 logits with unit column stride")
+        out = torch.empty((x.shape[0], k), dtype=torch.int64, device=x.device)
+        self.err.zero_()
+        hip.beam_sample_k(x, k, self.temperature, self._draw_noise(tuple(x.shape)), self.seed, self.img0, self._draws, out, self.err,
+                          seed_ptr=self.seed_tensor)
+        code = int(self.err.item())
+        if code & hip.ERR_TOO_FEW and not code & hip.ERR_ALL_FILTERED:
+            raise RuntimeError("invalid multinomial distribution (with replacement=False, not enough non-negative category to sample)")
+        self.raise_for(code)
+        return out if logits.dim() == 2 else out[0]
+
+    @staticmethod
+    def filter_by_indices(values, indices):
+        """beam.py:50-53: ``torch.gather(values, 1, indices)``."""
+        out = torch.empty(indices.shape, dtype=torch.float32, device=values.device)
+        hip.beam_gather(values, indices.contiguous(), out)
+        return out
+
+    def process_logits(self, logits, sample_seq, sample_val):
+        """beam.py:55-108.  ``logits [n, V]`` fp32 (filtered IN PLACE, as the reference does), ``sample_seq [n, L]`` int64,
+        ``sample_val [n]`` or ``[n, 1]``, ``self.has_ended [n]`` -> ``(prev_seqs, prev_vals), (new_ind, new_val)`` over the
+        ``n_cand = sum(1 if ended else beam_size)`` candidates; ``self.has_ended`` becomes the ``[n_cand]`` bool flags."""
+        b = self.beam_size
+        logits = self.filter_top_k(logits)
+        new_ind = self.sample_k_indices(logits, k=b)
+        gathered = self.filter_by_indices(logits, new_ind)
+        ended = self.has_ended
+        ended = ended.view(torch.uint8) if ended.dtype == torch.bool else ended.to(torch.uint8)
+        ended = ended.to(logits.device).contiguous()
+        n = ended.shape[0]
+        if logits.shape[0] != n or sample_seq.shape[0] != n:
+            raise IndexError(f"process_logits: {logits.shape[0]} logit rows / {sample_seq.shape[0]} sequences for {n} has_ended flags")
+        n_cand = int(sum(1 if e else b for e in ended.cpu().tolist()))
+        seqs = sample_seq.to(torch.int64).contiguous()
+        vals = sample_val.to(torch.float32).contiguous()
+        dev = logits.device
+        prev_seqs = torch.empty((n_cand, seqs.shape[1]), dtype=torch.int64, device=dev)
+        prev_vals = torch.empty((n_cand,) + tuple(vals.shape[1:]), dtype=torch.float32, device=dev)
+        out_ind = torch.empty((n_cand,), dtype=torch.int64, device=dev)
+        out_val = torch.empty((n_cand,), dtype=torch.float32, device=dev)
+        out_ended = torch.empty((n_cand,), dtype=torch.uint8, device=dev)
+        hip.beam_expand(new_ind, gathered, ended, seqs, vals, b, self.eos_index, prev_seqs, prev_vals, out_ind, out_val, out_ended)
+        self.has_ended = out_ended.view(torch.bool)
+        return (prev_seqs, prev_vals), (out_ind, out_val)
 
 
 def resolve_seed(seed, noise_source=None):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 9
+#define DH_ABI_VERSION 10
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -441,6 +441,33 @@ int dh_beam_step_groups(const float* logits, int ldl, int V, const float* group_
                         float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent, int32_t* hparent,
                         uint8_t* done, int32_t* end_step, int first, int first_sets_ended, int write_pos, int t,
                         int eos_index, const float* cand_noise, int32_t* arrive, void* stream);
+
+/* ---- BeamSearchHelper's METHOD surface (deephumor/models/beam.py:32-108), for callers that drive the helper the way the
+ * reference's own generate() loops do (rnn_models.py:87-128, transformers.py:532-569): one image, host-driven, tensors of the
+ * reference's shapes and dtypes.  The batched engine (dh_beam_row_sample / dh_beam_select above) does not need them. */
+
+/* filter_top_k (beam.py:32-37), IN PLACE like the reference: logits[r, c] = -inf where logits[r, c] < (top_k-th largest of row
+ * r) -- strict, ties at the threshold stay -- and at column unk_index.  logits fp32 [rows, ldl]. */
+int dh_beam_filter_top_k(float* logits, int ldl, int V, int rows, int top_k, int unk_index, void* stream);
+
+/* sample_k_indices (beam.py:39-48): out[r, 0..k) int64 = torch.multinomial(softmax(x[r] / temperature), k) without replacement
+ * == the k largest of p / Exp(1) noise in descending order (ties: lower index).  noise NULL -> Philox keyed by (seed ^
+ * *seed_ptr, stream_id, draw, row, index); else [rows, noise_ld] Exp(1) samples.  k <= 64.  err: DH_BEAM_ERR_ALL_FILTERED when a
+ * row is all -inf, DH_BEAM_ERR_TOO_FEW when it has fewer than k positive-probability entries (torch raises in both cases). */
+int dh_beam_sample_k(const float* x, int ld, int V, int rows, int k, float temperature, const float* noise, int noise_ld,
+                     uint64_t seed, const uint64_t* seed_ptr, int stream_id, int draw, int64_t* out, int32_t* err, void* stream);
+
+/* filter_by_indices (beam.py:50-53): out[r, j] = values[r, indices[r, j]] (torch.gather along dim 1); an index outside [0, V)
+ * ORs DH_BEAM_ERR_OVERFLOW into err (may be NULL) and gives 0. */
+int dh_beam_gather(const float* values, int ld, int V, const int64_t* indices, int k, float* out, int rows, int32_t* err,
+                   void* stream);
+
+/* The tail of process_logits (beam.py:78-106): new_val = log_softmax(gathered, -1); a live row contributes `beam` candidates, an
+ * ended row ONE with token 0 / score 0 (n_cand = sum over rows); out_ended = ended | (token == eos); prev_seqs / prev_vals =
+ * repeat_interleave of seqs [n_rows, seq_len] int64 / vals [n_rows, val_width] by the same counts.  Outputs sized n_cand. */
+int dh_beam_expand(const int64_t* new_ind, const float* gathered, const uint8_t* ended, const int64_t* seqs, int seq_len,
+                   const float* vals, int val_width, int n_rows, int beam, int eos_index, int64_t* prev_seqs, float* prev_vals,
+                   int64_t* out_ind, float* out_val, uint8_t* out_ended, void* stream);
 
 /* Per image: final draw ind ~ softmax(vals/T) (k=1 -> arg-max of p/noise), copies
  * tokens[img*beam+ind, 0..len) to out[img, :] (rest = pad) and writes len, where

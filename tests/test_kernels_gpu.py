@@ -419,3 +419,124 @@ def test_fused_normalize_pack_feeds_the_stem_identically():
             e1, s1 = m16.encoder(x32)
             e2, s2 = m16.encoder(packed)
         assert torch.equal(e1, e2) and torch.equal(s1, s2)
+
+
+# ------------------------------------------------------------------------------------------------
+# BeamSearchHelper's METHOD surface (reference beam.py:32-108), driven the way the reference drives it
+# ------------------------------------------------------------------------------------------------
+def _replay_noise(kind, call, shape):
+    """What torch.multinomial consumes from the CPU generator for a probability tensor of this shape."""
+    assert kind == "multinomial"
+    return torch.empty(shape).exponential_(1)
+
+
+def test_helper_methods_replay_reference_golden(hip):
+    """G4 (recorded from the REAL reference): filter_top_k unit vectors, then process_logits under torch.manual_seed(7) through
+    the METHODS -- ids / masks bit-exact, values <= 1e-6."""
+    from deephumor_amd.models import BeamSearchHelper
+    g = golden("g4_beam_helper.npz")
+    h = BeamSearchHelper(temperature=1.0, beam_size=3, top_k=4, device="cuda")
+    x = torch.from_numpy(g["filter_in"]).cuda()
+    out = h.filter_top_k(x)
+    assert out.data_ptr() == x.data_ptr()                                   # in place, like the reference (beam.py:36)
+    np.testing.assert_array_equal(x.cpu().numpy(), g["filter_out"])
+    h = BeamSearchHelper(temperature=0.7, beam_size=3, top_k=5, device="cuda", noise_source=_replay_noise)
+    h.has_ended = torch.tensor([False, True, False]).cuda()
+    logits = torch.from_numpy(g["pl_logits"]).cuda()
+    torch.manual_seed(7)
+    (ps, pv), (ni, nv) = h.process_logits(logits, torch.from_numpy(g["pl_seqs"]).cuda(), torch.from_numpy(g["pl_vals"]).cuda())
+    assert ps.dtype == torch.int64 and ni.dtype == torch.int64 and h.has_ended.dtype == torch.bool
+    np.testing.assert_array_equal(ps.cpu().numpy(), g["pl_prev_seqs"])
+    np.testing.assert_array_equal(ni.cpu().numpy(), g["pl_new_ind"])
+    np.testing.assert_array_equal(h.has_ended.cpu().numpy(), g["pl_has_ended"])
+    assert pv.shape == g["pl_prev_vals"].shape and nv.shape == g["pl_new_val"].shape
+    close(pv, torch.from_numpy(g["pl_prev_vals"]), atol=1e-6, rtol=0)
+    close(nv, torch.from_numpy(g["pl_new_val"]), atol=1e-6, rtol=0)
+    assert bool(torch.isinf(logits).any())                                  # process_logits filtered its argument in place
+    assert not h.all_ended()
+
+
+def test_helper_sample_k_and_gather(hip):
+    """sample_k_indices == torch.multinomial's race (2-D and the 1-D candidate form), golden mn_picks from the reference;
+    filter_by_indices == torch.gather; torch's error cases raise."""
+    from deephumor_amd.models import BeamSearchHelper
+    g = golden("g4_beam_helper.npz")
+    noise = torch.from_numpy(g["mn_noise"])
+    h = BeamSearchHelper(temperature=1.0, beam_size=4, top_k=50, device="cuda", noise_source=lambda k, c, s: noise)
+    # softmax(log p) == p up to rounding: the recorded picks come back
+    picks = h.sample_k_indices(torch.from_numpy(g["mn_p"]).log().cuda())
+    assert picks.dtype == torch.int64 and picks.cpu().tolist() == g["mn_picks"].tolist()
+    x = rnd(5, 36541, seed=3) * 3
+    x[0, 5:400] = float("-inf")
+    nz = torch.empty(5, 36541).exponential_(1, generator=torch.Generator().manual_seed(9))
+    h = BeamSearchHelper(temperature=1.3, beam_size=7, top_k=50, device="cuda", noise_source=lambda k, c, s: nz[:s[0]])
+    want = torch.topk(torch.softmax(x / 1.3, -1) / nz, 7, dim=-1).indices
+    got = h.sample_k_indices(x.cuda())
+    assert got.cpu().tolist() == want.tolist()
+    one = h.sample_k_indices(x[2].cuda(), k=3)                              # 1-D in -> 1-D out (rnn_models.py:120,140)
+    assert one.shape == (3,) and one.cpu().tolist() == torch.topk(torch.softmax(x[2] / 1.3, -1) / nz[0], 3).indices.tolist()
+    vals = BeamSearchHelper.filter_by_indices(x.cuda(), got)
+    assert torch.equal(vals.cpu(), torch.gather(x, 1, want))
+    # Philox mode: deterministic per (seed, draw), distinct, never a zero-probability entry
+    h = BeamSearchHelper(temperature=1.0, beam_size=5, top_k=50, device="cuda", seed=11)
+    a = h.sample_k_indices(x.cuda())
+    h2 = BeamSearchHelper(temperature=1.0, beam_size=5, top_k=50, device="cuda", seed=11)
+    assert torch.equal(a, h2.sample_k_indices(x.cuda())) and not torch.equal(a, h.sample_k_indices(x.cuda()))
+    assert all(len(set(r)) == 5 for r in a.cpu().tolist()) and not bool(((a[0] >= 5) & (a[0] < 400)).any())
+    with pytest.raises(RuntimeError):                                       # all -inf row: softmax is NaN, torch raises
+        h.sample_k_indices(torch.full((2, 30), float("-inf")).cuda())
+    few = torch.full((1, 30), float("-inf"))
+    few[0, 4:7] = 1.0
+    with pytest.raises(RuntimeError):                                       # 3 positive categories, 5 draws
+        h.sample_k_indices(few.cuda())
+
+
+@pytest.mark.parametrize("v,beam,top_k,temp,seed", [(1000, 3, 20, 1.3, 100), (71, 7, 50, 1.1, 5), (1000, 5, 5, 1.0, 3)])
+def test_helper_drives_reference_lstm_loop(hip, v, beam, top_k, temp, seed):
+    """The reference's own LSTMDecoder.generate loop (rnn_models.py:80-141) written against the helper's METHODS -- logits from
+    the oracle's LSTM on CPU, every helper call on the GPU -- reproduces the oracle's caption token for token under RNG replay
+    (incl. ended beams: EOS is made likely, and the h/c re-indexing uses the helper's filter indices)."""
+    import torch.nn.functional as Fn
+    from deephumor_amd.models import BeamSearchHelper
+    from helpers import synthetic_sd
+    from oracle import ref_path as R
+    sd, hp = synthetic_sd("CaptioningLSTM", v)
+    sd = dict(sd)
+    sd["decoder.classifier.bias"] = sd["decoder.classifier.bias"].clone()
+    sd["decoder.classifier.bias"][3] += 4.0                                 # beams end at different steps
+    p = "decoder"
+    emb_w, cls_w, cls_b = sd[p + ".embedding.weight"], sd[p + ".classifier.weight"], sd[p + ".classifier.bias"]
+    image_emb = rnd(1, 1, emb_w.shape[1], seed=seed)
+    max_len = 10
+    torch.manual_seed(seed)
+    want = R.lstm_decoder_generate(sd, p, image_emb, max_len=max_len, temperature=temp, beam_size=beam, top_k=top_k)
+
+    torch.manual_seed(seed)
+    helper = BeamSearchHelper(temperature=temp, beam_size=beam, top_k=top_k, eos_index=3, device="cuda", noise_source=_replay_noise)
+    out, (hh, cc) = R.lstm_run(sd, p + ".lstm", image_emb)
+    logits = Fn.linear(out[:, -1], cls_w, cls_b).cuda()
+    hh, cc = hh.repeat(1, beam, 1), cc.repeat(1, beam, 1)
+    logits = helper.filter_top_k(logits)
+    sample_ind = helper.sample_k_indices(logits, k=beam)
+    sample_val = helper.filter_by_indices(logits, sample_ind).log_softmax(-1)
+    sample_ind, sample_val = sample_ind.T, sample_val.T
+    sample_seq = sample_ind.clone()
+    helper.has_ended = (sample_ind == 3).view(-1)
+    for _ in range(sample_seq.size(1), max_len):
+        out, (hh, cc) = R.lstm_run(sd, p + ".lstm", emb_w[sample_ind.cpu()], (hh, cc))
+        logits = Fn.linear(out[:, -1], cls_w, cls_b).cuda()
+        (prev_seqs, prev_vals), (new_ind, new_val) = helper.process_logits(logits, sample_seq, sample_val)
+        cand_seq = torch.cat((prev_seqs, new_ind.unsqueeze(0).T), -1)
+        cand_val = prev_vals.flatten() + new_val
+        filter_ind = helper.sample_k_indices(cand_val, k=beam)
+        sample_val, sample_seq = cand_val[filter_ind], cand_seq[filter_ind]
+        sample_ind = sample_seq[:, -1].unsqueeze(-1)
+        helper.has_ended = helper.has_ended[filter_ind]
+        if helper.all_ended():
+            break
+        keep = filter_ind.cpu()
+        hh = torch.repeat_interleave(hh, beam, dim=1)[:, keep]
+        cc = torch.repeat_interleave(cc, beam, dim=1)[:, keep]
+    ind = helper.sample_k_indices(sample_val, k=1)
+    got = sample_seq[ind, :].squeeze()
+    assert got.cpu().tolist() == want.tolist()

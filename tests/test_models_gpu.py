@@ -28,7 +28,7 @@ def images():
 def test_native_library_is_loaded():
     from deephumor_amd import hip
     lib = hip.load()
-    assert lib.dh_abi_version() == 9
+    assert lib.dh_abi_version() == hip.ABI_VERSION
     with open("/proc/self/maps") as f:
         assert "libdeephumor_hip.so" in f.read()
 
