@@ -3,6 +3,7 @@ container.  TEST INFRASTRUCTURE ONLY; cannot run on the GPU box (no reference th
 needed there: the fixtures it writes are committed.
 
     python oracle/make_golden.py            # rewrites tests/golden/
+    python oracle/make_golden.py r3         # only the round-3 fixtures (g10 char-level, g11 demo decode settings)
 
 The reference imports torchvision (encoders.py:4), which is absent here, so
 ``oracle/_standin`` (our own ResNet-50 definition, torchvision naming) is put on ``sys.path``
@@ -32,6 +33,7 @@ OUT = os.path.join(ROOT, "tests", "golden")
 SEED = 1234
 V_SMALL = 1000
 V_WORD = 36541          # deephumor_demo.ipynb:524
+V_CHAR = 71             # char-level vocabulary of four of the eight released models (deephumor_demo.ipynb:1307-1309, 1393-1395)
 
 
 class _WithLabelsTransformer(torch.nn.Module):
@@ -148,6 +150,44 @@ def text_and_metric_goldens():
         json.dump(out, f, indent=1)
 
 
+def beam_ids(model, image, seed, **kw):
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        return model.generate(image, **kw).reshape(-1).numpy()
+
+
+def round3_goldens():
+    """G10: the char-level configuration (V = 71, captions of up to 127 tokens, beam 7 / top_k 50 / T 1.1 --
+    deephumor_demo.ipynb:1132, 1307-1309, 1393-1395): greedy ids + margins for 2 images, and the stochastic beam under
+    torch.manual_seed (RNG replay).  max_len = 127 because generate() needs max_len < the Transformer's 128 position slots.
+    G11: the demo's word-level decode settings at V = 36,541 (LSTM: beam 10, top_k 100, T 1.3 -- :1264-1266; Transformer:
+    beam 10, top_k 70, T 1.0 -- :1350-1352), stochastic beam under torch.manual_seed, max_len 12 to keep it small."""
+    torch.set_num_threads(8)
+    images = synth_images(2, seed=0)
+    for kind in ("CaptioningLSTM", "CaptioningTransformer"):
+        model = build(kind, V_CHAR)
+        rec = {}
+        for i in range(2):
+            ids, margins, top1 = greedy_with_margins(model, kind, images[i:i + 1], None, None, max_len=127)
+            rec[f"greedy_{i}"], rec[f"greedy_margin_{i}"], rec[f"greedy_top1_{i}"] = ids, margins, top1
+            rec[f"beam_{i}"] = beam_ids(model, images[i:i + 1], 200 + i, max_len=127, beam_size=7, top_k=50, temperature=1.1)
+        # <eos> made likely: beams end at different steps of a long caption (ended-beam bookkeeping over ~100 positions)
+        with torch.no_grad():
+            model.decoder.classifier.bias[3] += 2.5
+        rec["beam_eos_0"] = beam_ids(model, images[:1], 300, max_len=127, beam_size=7, top_k=50, temperature=1.1)
+        np.savez_compressed(os.path.join(OUT, f"g10_char_{kind}.npz"), **rec)
+        print(kind, "V=71 greedy0", rec["greedy_0"][:10], "len", len(rec["greedy_0"]), "min margin",
+              min(float(rec[f"greedy_margin_{i}"].min()) for i in range(2)), "beam lens", len(rec["beam_0"]), len(rec["beam_eos_0"]))
+    for kind, kw in (("CaptioningLSTM", dict(beam_size=10, top_k=100, temperature=1.3)),
+                     ("CaptioningTransformer", dict(beam_size=10, top_k=70, temperature=1.0))):
+        model = build(kind, V_WORD)
+        rec = {"beam_size": np.array(kw["beam_size"]), "top_k": np.array(kw["top_k"]), "temperature": np.float32(kw["temperature"])}
+        for i in range(2):
+            rec[f"beam_{i}"] = beam_ids(model, images[i:i + 1], 400 + i, max_len=12, **kw)
+        np.savez_compressed(os.path.join(OUT, f"g11_demo_{kind}.npz"), **rec)
+        print(kind, "V=36541 demo settings", kw, rec["beam_0"])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -262,10 +302,14 @@ def main():
     np.savez_compressed(os.path.join(OUT, "g4_beam_helper.npz"), **g4)
 
     text_and_metric_goldens()
+    round3_goldens()
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote", OUT)
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["r3"]:
+        round3_goldens()
+    else:
+        main()

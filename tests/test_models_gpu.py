@@ -298,3 +298,78 @@ def test_early_stop_gives_the_same_captions(kind, images):
         early = model.generate_batch(images.cuda(), early_stop_every=2, **kw)
     assert torch.equal(full[0], early[0]) and torch.equal(full[1], early[1])
     assert int(full[1].min()) < 32          # <eos> was sampled: images do finish before max_len
+
+
+def _replay_generate(model, image, seed, **kw):
+    """model.generate under torch.manual_seed(seed) with the kernels fed the CPU generator's Exp(1) noise in the reference's
+    draw order (the _Replay schedule above)."""
+    import deephumor_amd.models.beam as beam_mod
+    made = []
+    orig = beam_mod.BeamSearchHelper.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(self)
+
+    beam_mod.BeamSearchHelper.__init__ = spy
+    try:
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            return model.generate(image, noise_source=_Replay(lambda: made[-1]), **kw).reshape(-1).cpu().tolist()
+    finally:
+        beam_mod.BeamSearchHelper.__init__ = orig
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_char_level_configuration(kind):
+    """Char-level models (V = 71 < one 128-column GEMM tile, top_k 50 > the 2 column groups, 127-position histories;
+    deephumor_demo.ipynb:1307-1309, 1393-1395), goldens recorded from the reference: fp32 greedy ids bit-exact, stochastic beam
+    7 / top_k 50 / T 1.1 token for token under RNG replay (incl. beams ending at different steps); both 16-bit paths run the
+    same shapes, repeatably, and agree with fp32 on the first greedy token."""
+    g = golden(f"g10_char_{kind}.npz")
+    model, sd, _ = build(kind, v=71)
+    images = synth_images(2, seed=0)
+    with torch.no_grad():
+        toks, lens = model.generate_batch(images.cuda(), max_len=127, beam_size=1, top_k=1)
+    for i in range(2):
+        assert toks[i, :int(lens[i])].cpu().tolist() == g[f"greedy_{i}"].tolist(), (kind, i)
+    kw = dict(max_len=127, beam_size=7, top_k=50, temperature=1.1)
+    for i in range(2):
+        assert _replay_generate(model, images[i:i + 1].cuda(), 200 + i, **kw) == g[f"beam_{i}"].tolist(), (kind, i)
+    with torch.no_grad():
+        model.decoder.classifier.bias[3] += 2.5
+    assert _replay_generate(model, images[:1].cuda(), 300, **kw) == g["beam_eos_0"].tolist()
+    with torch.no_grad():
+        model.decoder.classifier.bias[3] -= 2.5
+    first = toks[:, 0].cpu().tolist()
+    for dt in (torch.bfloat16, torch.float16):
+        m16 = build(kind, v=71)[0].to(dt)
+        with torch.no_grad():
+            tg, lg = m16.generate_batch(images.cuda(), max_len=127, beam_size=1, top_k=1)
+            t1, l1 = m16.generate_batch(images.cuda(), seed=3, **kw)
+            t2, l2 = m16.generate_batch(images.cuda(), seed=3, **kw)
+        assert tg[:, 0].cpu().tolist() == first
+        assert torch.equal(t1, t2) and torch.equal(l1, l2) and tuple(t1.shape) == (2, 127)
+        assert int(t1.min()) >= 0 and int(t1.max()) < 71 and not bool((t1 == 1).any())
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_demo_decode_settings_word_vocab(kind):
+    """The notebook's word-level settings at V = 36,541 (LSTM beam 10 / top_k 100 / T 1.3, Transformer beam 10 / top_k 70 /
+    T 1.0: deephumor_demo.ipynb:1264-1266, 1350-1352): fp32 token for token under RNG replay; the 16-bit paths run them
+    (top_k above the 56 the group-guided sampler was tested with) repeatably, never sampling <unk>."""
+    g = golden(f"g11_demo_{kind}.npz")
+    model, _, _ = build(kind, v=36541)
+    images = synth_images(2, seed=0)
+    kw = dict(max_len=12, beam_size=int(g["beam_size"]), top_k=int(g["top_k"]), temperature=float(g["temperature"]))
+    for i in range(2):
+        assert _replay_generate(model, images[i:i + 1].cuda(), 400 + i, **kw) == g[f"beam_{i}"].tolist(), (kind, i)
+    with torch.no_grad():
+        want = model.generate_batch(images.cuda(), seed=9, **kw)
+    for dt in (torch.bfloat16, torch.float16):
+        m16 = build(kind, v=36541)[0].to(dt)
+        with torch.no_grad():
+            t1, l1 = m16.generate_batch(images.cuda(), seed=9, **kw)
+            t2, l2 = m16.generate_batch(images.cuda(), seed=9, **kw)
+        assert torch.equal(t1, t2) and torch.equal(l1, l2) and not bool((t1 == 1).any()) and int(t1.max()) < 36541
+        assert t1[:, 0].tolist() == want[0][:, 0].tolist() or dt == torch.bfloat16   # same Philox noise: fp16 keeps the first pick

@@ -121,3 +121,38 @@ def test_g3_word_vocab(kind, images):
     for i in range(2):
         ids = R.model_generate(kind, sd, hp, images[i:i + 1], max_len=32, beam_size=1, top_k=1)
         assert ids.reshape(-1).tolist() == g[f"greedy_{i}"].tolist()
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_g10_char_level(kind):
+    """Char-level configuration (V = 71, 127-token captions, beam 7 / top_k 50 / T 1.1: deephumor_demo.ipynb:1307-1309,
+    1393-1395): the oracle's greedy ids + margins and its stochastic beam under torch.manual_seed equal the reference's."""
+    g = golden(f"g10_char_{kind}.npz")
+    sd, hp = synthetic_sd(kind, v=71)
+    images = synth_images(2, seed=0)
+    trace = []
+    ids = R.model_generate(kind, sd, hp, images[:1], max_len=127, beam_size=1, top_k=1, trace=trace)
+    assert ids.reshape(-1).tolist() == g["greedy_0"].tolist()
+    margins = np.array([float(t["top2_val"][0, 0] - t["top2_val"][0, 1]) for t in trace])
+    np.testing.assert_allclose(margins, g["greedy_margin_0"], atol=1e-4)
+    if kind == "CaptioningLSTM":                  # (the Transformer oracle re-forwards 7 x 127 positions per token: one is enough here)
+        torch.manual_seed(201)
+        ids = R.model_generate(kind, sd, hp, images[1:2], max_len=127, beam_size=7, top_k=50, temperature=1.1)
+        assert ids.reshape(-1).tolist() == g["beam_1"].tolist()
+    sd["decoder.classifier.bias"] = sd["decoder.classifier.bias"].clone()
+    sd["decoder.classifier.bias"][3] += 2.5
+    torch.manual_seed(300)
+    ids = R.model_generate(kind, sd, hp, images[:1], max_len=127, beam_size=7, top_k=50, temperature=1.1)
+    assert ids.reshape(-1).tolist() == g["beam_eos_0"].tolist()
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_g11_demo_decode_settings(kind):
+    """The demo's word-level decode settings at V = 36,541 (deephumor_demo.ipynb:1264-1266, 1350-1352)."""
+    g = golden(f"g11_demo_{kind}.npz")
+    sd, hp = synthetic_sd(kind, v=36541)
+    images = synth_images(2, seed=0)
+    torch.manual_seed(400)
+    ids = R.model_generate(kind, sd, hp, images[:1], max_len=12, beam_size=int(g["beam_size"]), top_k=int(g["top_k"]),
+                           temperature=float(g["temperature"]))
+    assert ids.reshape(-1).tolist() == g["beam_0"].tolist()
