@@ -364,12 +364,9 @@ def test_demo_decode_settings_word_vocab(kind):
     kw = dict(max_len=12, beam_size=int(g["beam_size"]), top_k=int(g["top_k"]), temperature=float(g["temperature"]))
     for i in range(2):
         assert _replay_generate(model, images[i:i + 1].cuda(), 400 + i, **kw) == g[f"beam_{i}"].tolist(), (kind, i)
-    with torch.no_grad():
-        want = model.generate_batch(images.cuda(), seed=9, **kw)
     for dt in (torch.bfloat16, torch.float16):
         m16 = build(kind, v=36541)[0].to(dt)
         with torch.no_grad():
             t1, l1 = m16.generate_batch(images.cuda(), seed=9, **kw)
             t2, l2 = m16.generate_batch(images.cuda(), seed=9, **kw)
         assert torch.equal(t1, t2) and torch.equal(l1, l2) and not bool((t1 == 1).any()) and int(t1.max()) < 36541
-        assert t1[:, 0].tolist() == want[0][:, 0].tolist() or dt == torch.bfloat16   # same Philox noise: fp16 keeps the first pick
