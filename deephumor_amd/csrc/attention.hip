@@ -692,6 +692,7 @@ extern "C" int dh_attn_masked(const void* q, int ldq, const void* k, int ldk, co
     const int rows = bs * L, dh = D / n_heads;
     DhProfScope prof("dh_attn_masked", 4.0 * rows * L * D, 0.0, stream);
     const size_t lds = (size_t)4 * (dh + L) * sizeof(float);
+    if (lds > 64 * 1024) return DH_ERR_UNSUPPORTED;       // the default dynamic-LDS limit: L <= 4096 - dh (head dim 64: 4032 keys)
     DH_DISPATCH_T(dtype, hipLaunchKernelGGL(attn_masked_kernel<T>, dim3(dh_cdiv(rows, 4), n_heads), dim3(256), lds, (hipStream_t)stream,
                                             (const T*)q, ldq, (const T*)k, ldk, (const T*)v, ldv, mask, (T*)out, rows, L, D, dh, scale));
     DH_LAUNCH_CHECK();

@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(512, 1) void vocab256_kernel(VocabParams p) {
             read_a(0, 0);
             if (t == 0) {       // this wave's 64 bias values -> its LDS strip; older than this tile's later slabs, read in the epilogue
                 const int n = n0 + wn0 + lane;
-                dh_lds_dma4(p.bias + (p.bias && n < p.N ? n : 0), bias_lds);
+                dh_lds_dma4(p.bias ? p.bias + (n < p.N ? n : 0) : reinterpret_cast<const float*>(dh_zero_page), bias_lds);   // bias == NULL: the zero page, never address 0
             }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {

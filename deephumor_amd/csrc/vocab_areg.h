@@ -126,7 +126,7 @@ __global__ __launch_bounds__(512, 1) void vocab_areg_kernel(VocabParams p) {
             if (ld_it < my_tiles) stage_into((2 * st + NS - 1) % NS);
             if (st == 0) {
                 const int n = n0 + wn0 + lane;
-                dh_lds_dma4(p.bias + (p.bias && n < p.N ? n : 0), bias_lds);
+                dh_lds_dma4(p.bias ? p.bias + (n < p.N ? n : 0) : reinterpret_cast<const float*>(dh_zero_page), bias_lds);   // bias == NULL: the zero page, never address 0
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, OCC) void vocab_dacc_kernel
             mark[NS - 2] = issued;
             if (t == 0) {
                 const int n = n0 + wn0 + lane;
-                dh_lds_dma4(p.bias + (p.bias && n < p.N ? n : 0), bias_lds);
+                dh_lds_dma4(p.bias ? p.bias + (n < p.N ? n : 0) : reinterpret_cast<const float*>(dh_zero_page), bias_lds);   // bias == NULL: the zero page, never address 0
                 issued += 1;
                 bias_mark = issued;
             }

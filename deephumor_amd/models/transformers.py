@@ -210,12 +210,12 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=f(self.classifier.bias),
                     dtype=self.classifier.weight.dtype)
 
-    def _check_mode(self):
+    def _check_mode(self, cached=True):
         if self.training and self.dropout.p > 0:
             raise RuntimeError("deephumor_amd implements the inference path; call model.eval()")
         if self.pad_index is None:
             raise TypeError("pad_index=None is unusable in the reference too (transformers.py:451); pass an int")
-        if self.pad_index != 0:
+        if cached and self.pad_index != 0:
             # the reference compares the image slot's stand-in id 1 (transformers.py:474) and the 0/1 encoder-row flags
             # (:480-481) with pad_index: pad_index == 1 masks the image slot and inverts the encoder mask, any other
             # value disables the encoder mask.  The vocabulary fixes <pad> = 0 (data/vocab.py:5-12); the cached kernels
@@ -336,6 +336,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
         captioning models): the reference's own formulation on the module-API layers -- pad ``x`` / ``enc_out`` to a
         common length (:450-452), embeddings (:455-469), pad | causal input mask (:473-477), encoder-row mask
         (:480-481), layers, classifier."""
+        self._check_mode(cached=False)        # eval mode and an int pad_index; any pad_index value works on the module-API layers
         bs, dec_len = x.shape
         dt = self.classifier.weight.dtype
         seq = dec_len if enc_out is None else max(dec_len, enc_out.shape[1])

@@ -32,8 +32,9 @@ class CaptionPipeline:
         else:
             self.copy_s = self.enc_s = self.dec_s = torch.cuda.current_stream(self.dev)
         self._dev_in = {}            # (slot, shape, dtype) -> device staging tensor (double-buffered)
-        self._host_out = {}
+        self._host_out = {}          # (slot, shape) -> pinned (tokens, lengths) pair (double-buffered like _dev_in)
         self._slot = 0
+        self._out_slot = 0
 
     # -- stages ------------------------------------------------------------------------------------------------------
     def _stage(self, host_inputs):
@@ -41,9 +42,16 @@ class CaptionPipeline:
         tensors pass through."""
         slot, out = self._slot, []
         self._slot ^= 1
+        producer = torch.cuda.current_stream(self.dev)
+        if self.overlap and any(t.is_cuda for t in host_inputs):
+            # a device-resident input may still be being written on the caller's stream (e.g. by preprocess_images): the
+            # event recorded below must not fire before that work has finished
+            self.copy_s.wait_stream(producer)
         with torch.cuda.stream(self.copy_s):
             for j, t in enumerate(host_inputs):
                 if t.is_cuda:
+                    if self.overlap:
+                        t.record_stream(self.enc_s)
                     out.append(t)
                     continue
                 key = (slot, j, tuple(t.shape), t.dtype)
@@ -71,7 +79,8 @@ class CaptionPipeline:
             self.dec_s.wait_event(ev)
             toks, lens = self.model.decode(enc, seed=seed, img0=img0, **self.gen_kw)
             if to_host:
-                key = tuple(toks.shape)
+                key = (self._out_slot, tuple(toks.shape))
+                self._out_slot ^= 1
                 bufs = self._host_out.get(key)
                 if bufs is None:
                     bufs = self._host_out[key] = (torch.empty(toks.shape, dtype=toks.dtype).pin_memory(),
@@ -86,9 +95,10 @@ class CaptionPipeline:
     # -- driver ------------------------------------------------------------------------------------------------------
     def run(self, batches, seeds=None, img0=0, to_host=True):
         """``batches``: iterable of input tuples (``(images,)`` or ``(images, labels)``), host (ideally pinned) or device
-        tensors.  Yields ``(tokens, lengths)`` per batch, in order; with ``to_host`` they live in pinned host memory that
-        is reused two batches later -- consume or clone them before that.  All work of a batch has completed when it is
-        yielded."""
+        tensors.  Yields ``(tokens, lengths)`` per batch, in order; with ``to_host`` they live in one of TWO pinned host
+        buffer pairs used alternately: the pair yielded for batch i is overwritten by batch i+2's copy, so a result may be
+        kept across ONE further iteration, and ``list(pipe.run(...))`` must clone.  All work of a batch has completed
+        when it is yielded."""
         it = iter(batches)
         seeds = iter(seeds) if seeds is not None else None
         cur = next(it, None)

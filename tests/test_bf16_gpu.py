@@ -246,6 +246,21 @@ def test_logits_free_classifier_flags_tied_group_maxima(hip):
     assert int(err.item()) & hip.ERR_TOPK_GROUPS
 
 
+def test_vocab_logits_without_bias(hip):
+    """bias = NULL through every classifier kernel that stages a bias strip by LDS-DMA (A-stationary K = 512 default, the tile
+    kernel for K != 512, the group-maxima-only form): the strip comes from the zero page, never from address 0."""
+    for rows, v, k in ((1280, 4000, 512), (300, 1000, 256), (130, 36541, 512)):
+        a, w = bf(rnd(rows, k, seed=21)).cuda(), bf(rnd(v, k, seed=22) * 0.1).cuda()
+        ref = hip.linear(a, w, None, out_dtype=torch.float32)
+        logits = torch.full((rows, v), float("nan"), device="cuda")
+        gmax = torch.full((rows, hip.n_groups(v)), float("nan"), device="cuda")
+        hip.vocab_logits(a, w, None, logits, gmax)
+        assert torch.equal(logits, ref)
+        g2 = torch.full_like(gmax, float("nan"))
+        hip.vocab_logits(a, w, None, None, g2)
+        assert torch.equal(g2, gmax)
+
+
 def test_vocab_logits_full_size_repeatable(hip):
     """BASELINE-size classifier (1280 beam rows x 36,541 tokens, K = 512): the persistent kernel (several tiles per
     workgroup, ring never drained) against the one-tile-per-workgroup GEMM, bit for bit, over repeated launches."""
