@@ -22,7 +22,10 @@ What the line carries besides the contract fields:
                      warm-up + best of 3 (rank 0, N = 1 only)
   fp32_parity_path   captions/s of the fp32 path -- the one whose greedy ids are bit-exact vs the CPU reference
   host_inclusive     pinned host images in -> token ids in pinned host memory out: sequential, and software-pipelined
-                     (copy + encoder of batch i+1 on their own streams while batch i decodes; deephumor_amd/pipeline.py)
+                     (copy + encoder of batch i+1 on their own streams while batch i decodes; deephumor_amd/pipeline.py), for
+                     decoded uint8 HWC images (value_host_inclusive at the top level) and for the fp32 NCHW batch
+  precision_vs_fp32_hip   greedy token match / step-0 logit error of the bf16 AND fp16 paths against the fp32 HIP path over all
+                     bench images (what 16-bit storage costs; the table behind it: profiles/r3/precision_*.json)
 
 Only the ``cpu_baseline`` leg and the greedy parity check import ``oracle/``; the measured path is the HIP library only.
 """
@@ -42,6 +45,7 @@ sys.path.insert(0, ROOT)
 V_WORD = 36541          # deephumor_demo.ipynb:524
 MAX_LEN = 32            # deephumor_demo.ipynb:1127
 BEAM, TOP_K, TEMP = 5, 50, 1.0
+N_CHECK = 4             # images of the greedy parity check against the CPU oracle
 STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
@@ -213,6 +217,35 @@ def greedy_match(workload, model, sd, hp, n_check):
     return same / max(total, 1)
 
 
+def greedy_all(model, images, chunk=256):
+    """Greedy decode (beam 1, top_k 1) of every bench image: (tokens [N, 32], lengths [N], step-0 logits [N, V] fp32)."""
+    toks, lens, lg0 = [], [], []
+    with torch.no_grad():
+        for lo in range(0, images.shape[0], chunk):
+            cap = {}
+            t, l = model.generate_batch(images[lo:lo + chunk], max_len=MAX_LEN, beam_size=1, top_k=1,
+                                        logits_hook=lambda i, lg: cap.setdefault(i, lg.float().clone()))
+            toks.append(t), lens.append(l), lg0.append(cap[0][:t.shape[0]])
+    return torch.cat(toks), torch.cat(lens), torch.cat(lg0)
+
+
+def compare_greedy(ref, got):
+    """Token agreement of two greedy runs over the same images + the step-0 logit error (the perturbation that flips thin
+    arg-max margins; greedy decoding of synthetic random weights is chaotic: one flip changes the rest of the caption)."""
+    (rt, rl, r0), (gt, gl, g0) = ref, got
+    n, t = rt.shape
+    pos = torch.arange(t, device=rt.device)[None, :]
+    valid = pos < torch.maximum(rl, gl)[:, None]
+    same = (rt == gt) & valid & (pos < torch.minimum(rl, gl)[:, None])
+    first = torch.where(valid & ~same, pos, torch.full_like(pos, t)).min(1).values
+    d = (g0 - r0).abs()
+    top2 = torch.topk(r0, 2, dim=-1).values
+    return {"images": n, "token_match": float(same.sum() / valid.sum()), "captions_identical": float((first == t).float().mean()),
+            "mean_first_divergence_pos": float(first.float().mean()), "first_token_match": float((rt[:, 0] == gt[:, 0]).float().mean()),
+            "step0_logit_max_abs_err": float(d.max()), "step0_logit_mean_abs_err": float(d.mean()),
+            "step0_ref_margin_median": float((top2[:, 0] - top2[:, 1]).median())}
+
+
 # ---- the timed region ----------------------------------------------------------------------------------------------
 def timed_region(step_fn, steps, world, device):
     """Contract of the brief: barrier + device synchronize, EXACTLY ``steps`` calls of ``step_fn(s)``, device synchronize +
@@ -257,24 +290,39 @@ def timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=Non
     return dt, out[1], {}
 
 
-def host_inclusive(model, n_local, steps):
-    """Pinned host images -> token ids in pinned host memory (SURVEY 8(d)'s metric definition), sequential and pipelined."""
-    from deephumor_amd.pipeline import CaptionPipeline
+def synth_images_u8(n, seed=0):
+    """The synthetic bench images as DECODED pictures: uint8 [N, 224, 224, 3] whose ToTensor + Normalize image is the randn batch
+    quantised to the 8-bit grid (deephumor_demo.ipynb:565-567)."""
+    from deephumor_amd.experiments.inference import IMAGENET_MEAN, IMAGENET_STD
     from deephumor_amd.synth import synth_images
-    pinned = synth_images(n_local, seed=0).pin_memory()
+    x = synth_images(n, seed=seed)
+    m, s = torch.tensor(IMAGENET_MEAN)[None, :, None, None], torch.tensor(IMAGENET_STD)[None, :, None, None]
+    return ((x * s + m) * 255.0).round().clamp(0, 255).to(torch.uint8).permute(0, 2, 3, 1).contiguous()
+
+
+def host_inclusive(model, n_local, steps):
+    """Pinned host images -> token ids in pinned host memory (SURVEY 8(d)'s metric definition), sequential and pipelined, for the
+    two forms a caller can hand images over in: decoded uint8 HWC (38.5 MB per 256 images; ToTensor + Normalize on the device,
+    fused with the stem's input packing) and the reference's fp32 NCHW batch (154 MB)."""
+    from deephumor_amd.pipeline import CaptionPipeline, u8_preprocess
+    from deephumor_amd.synth import synth_images
     kw = dict(max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP)
     out = {}
-    for name, overlap in (("sequential", False), ("pipelined", True)):
-        pipe = CaptionPipeline(model, overlap=overlap, **kw)
-        for _ in pipe.run([(pinned,)] * 2, seeds=[1, 2]):
-            pass
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in pipe.run([(pinned,)] * steps, seeds=range(100, 100 + steps)):
-            pass
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        out[name] = {"value": n_local * steps / dt, "unit": "captions/s", "ms_per_step": dt / steps * 1e3}
+    for form, pinned, pre in (("u8_hwc", synth_images_u8(n_local, seed=0).pin_memory(), u8_preprocess(model)),
+                              ("f32_nchw", synth_images(n_local, seed=0).pin_memory(), None)):
+        res = {"host_bytes_per_step": pinned.numel() * pinned.element_size()}
+        for name, overlap in (("sequential", False), ("pipelined", True)):
+            pipe = CaptionPipeline(model, overlap=overlap, preprocess=pre, **kw)
+            for _ in pipe.run([(pinned,)] * 2, seeds=[1, 2]):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in pipe.run([(pinned,)] * steps, seeds=range(100, 100 + steps)):
+                pass
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res[name] = {"value": n_local * steps / dt, "unit": "captions/s", "ms_per_step": dt / steps * 1e3}
+        out[form] = res
     out["note"] = ("images start in pinned host memory, ids end in pinned host memory; pipelined = H2D copy and encoder of batch "
                    "i+1 on their own HIP streams while batch i decodes")
     return out
@@ -351,8 +399,9 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             del model
             torch.cuda.empty_cache()
             m32 = build_model(workload, dev, "f32")[0]
-        res["greedy_token_match_vs_cpu_ref"] = greedy_match(workload, m32, sd, hp, 2)
+        res["greedy_token_match_vs_cpu_ref"] = greedy_match(workload, m32, sd, hp, N_CHECK)
         if dtype != "f32":
+            ref = greedy_all(m32, images)                 # all bench images on the bit-exact path: the reference of `precision`
             with torch.no_grad():
                 one_step(m32, images, 0, n_total, seed=0)
                 t32, _, _ = timed_steps(m32, images, 0, n_local, n_total, 3, barrier)
@@ -360,8 +409,24 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                                        "note": "same step, fp32 storage + exact-fp32 arithmetic: the path whose greedy ids are bit-exact"}
             del m32
             torch.cuda.empty_cache()
-            model = build_model(workload, dev, dtype)[0]
-            res[f"greedy_token_match_{dtype}_vs_cpu_ref"] = greedy_match(workload, model, sd, hp, 2)
+            # what 16-bit storage costs in greedy tokens: both 16-bit paths against the fp32 HIP path (bit-exact vs the CPU
+            # oracle on the checked images above and on rows {0, 77, 255} in tests/test_fullsize_gpu.py) over ALL bench images
+            res["precision_vs_fp32_hip"] = {"reference": "fp32 HIP path, greedy (beam 1, top_k 1), all bench images",
+                                            "table": "profiles/r3/precision_c2.json, precision_c3.json (which tensor's precision buys what)"}
+            for dt in [dtype] + [d for d in ("bf16", "f16") if d != dtype]:
+                model = build_model(workload, dev, dt)[0]
+                res["precision_vs_fp32_hip"][dt] = compare_greedy(ref, greedy_all(model, images))
+                if dt == dtype:
+                    res[f"greedy_token_match_{dtype}_vs_cpu_ref"] = greedy_match(workload, model, sd, hp, N_CHECK)
+                else:
+                    with torch.no_grad():
+                        one_step(model, images, 0, n_total, seed=0)
+                        t16, _, _ = timed_steps(model, images, 0, n_local, n_total, 3, barrier)
+                    res[f"{dt}_path"] = {"value": n_total * 3 / t16, "unit": "captions/s", "ms_per_step": t16 / 3 * 1e3, "steps": 3}
+                del model
+                torch.cuda.empty_cache()
+            del ref
+            model = None
         res["cpu_baseline"] = cpu_baseline(workload, sd, hp)
         res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
     torch.cuda.empty_cache()
@@ -586,11 +651,20 @@ def main(argv=None):
                    "hipgraph": bool(args.graph), "commit": git_head()},
         "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"),
     }
-    for k in ("greedy_token_match_vs_cpu_ref", f"greedy_token_match_{args.dtype}_vs_cpu_ref", "speedup_vs_cpu", "mean_caption_len",
-              "fp32_parity_path", "host_inclusive", "hipgraph_replay", "kernel_breakdown_ms_per_step", "kernel_breakdown_note",
+    for k in ("greedy_token_match_vs_cpu_ref", f"greedy_token_match_{args.dtype}_vs_cpu_ref", "precision_vs_fp32_hip", "speedup_vs_cpu",
+              "mean_caption_len", "fp32_parity_path", "f16_path", "bf16_path", "host_inclusive", "hipgraph_replay", "kernel_breakdown_ms_per_step", "kernel_breakdown_note",
               "encoder_layers", "roofline_self_attention", "roofline_cross_attention", "roofline_decoder_attention_combined"):
         if k in res:
             line[k] = res[k]
+    hi = res.get("host_inclusive")
+    if hi:
+        # SURVEY 8(d)'s definition of the metric (images in host memory -> ids in host memory), next to `value` (inputs resident
+        # in HBM, as the bench contract prescribes): decoded uint8 images in pinned memory, copy + preprocessing + encoder of
+        # batch i+1 overlapped with the decode of batch i
+        line["value_host_inclusive"] = hi["u8_hwc"]["pipelined"]["value"]
+        line["value_host_inclusive_over_value"] = hi["u8_hwc"]["pipelined"]["value"] / res["value"]
+        line["value_host_inclusive_def"] = ("uint8 HWC 224x224 images in pinned host memory -> token ids in pinned host memory, pipelined "
+                                            "(CaptionPipeline + u8_preprocess); the fp32 NCHW form is under host_inclusive.f32_nchw")
     if args.workload == "both":
         r3 = run_workload("c3", args, rank, world, dev, max(3, args.steps // 2), 1, with_cpu, args.dtype, main_line=False)
         r3.pop("encoder_layers", None)

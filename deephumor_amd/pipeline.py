@@ -17,12 +17,29 @@ import os
 
 import torch
 
-__all__ = ["CaptionPipeline"]
+__all__ = ["CaptionPipeline", "u8_preprocess"]
+
+
+def u8_preprocess(model, size=(224, 224)):
+    """Input stage for DECODED images: ``uint8 [N, H, W, 3]`` (what an image decoder produces; 38.5 MB per 256 images at
+    224 x 224 instead of the 154 MB of the fp32 NCHW batch) -> what ``model.encode`` takes.  The notebook's transform
+    (Resize -> ToTensor -> Normalize, deephumor_demo.ipynb:565-567) runs on the device: for a 16-bit model the
+    normalised batch is written directly in the packed channels-last layout the stem kernel reads
+    (``dh_normalize_pack_u8``; no fp32 tensor exists), for the fp32 model it is the fp32 NCHW batch the reference's
+    encoders take.  Further inputs (labels) pass through."""
+    from .experiments.inference import preprocess_images
+    dtype = next(model.parameters()).dtype
+
+    def stage(images_u8, *rest):
+        return (preprocess_images(images_u8, size=size, dtype=dtype),) + rest
+    return stage
 
 
 class CaptionPipeline:
-    def __init__(self, model, overlap=True, **gen_kw):
-        self.model, self.gen_kw, self.overlap = model, gen_kw, overlap
+    def __init__(self, model, overlap=True, preprocess=None, **gen_kw):
+        """``preprocess``: optional callable mapping the staged device tensors of a batch to ``model.encode``'s inputs
+        (e.g. ``u8_preprocess(model)``); it runs on the encode stream in front of the encoder."""
+        self.model, self.gen_kw, self.overlap, self.preprocess = model, gen_kw, overlap, preprocess
         self.dev = next(model.parameters()).device
         if overlap:
             # (a high-priority decode stream -- DH_PIPE_PRIO=1 -- was measured: no gain, the encoder's workgroups hold the CUs
@@ -67,6 +84,8 @@ class CaptionPipeline:
     def _encode(self, staged, ev):
         with torch.cuda.stream(self.enc_s), torch.no_grad():
             self.enc_s.wait_event(ev)
+            if self.preprocess is not None:
+                staged = self.preprocess(*staged)
             enc = self.model.encode(*staged)
             done = torch.cuda.Event()
             done.record(self.enc_s)

@@ -370,3 +370,30 @@ def test_demo_decode_settings_word_vocab(kind):
             t1, l1 = m16.generate_batch(images.cuda(), seed=9, **kw)
             t2, l2 = m16.generate_batch(images.cuda(), seed=9, **kw)
         assert torch.equal(t1, t2) and torch.equal(l1, l2) and not bool((t1 == 1).any()) and int(t1.max()) < 36541
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_u8_pipeline_equals_fp32_image_path(dtype):
+    """Host-inclusive path for DECODED images (uint8 HWC in pinned memory -> CaptionPipeline with u8_preprocess -> ids in pinned
+    memory): the captions equal generate_batch on the fp32 NCHW batch the notebook's ToTensor + Normalize produces from the same
+    pixels -- on the fp32 model and on the bf16 model (whose stem reads the packed 16-bit layout instead of an fp32 tensor);
+    results of consecutive batches live in different pinned buffers (no aliasing across one iteration)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from deephumor_amd.experiments.inference import images_to_tensor
+    from deephumor_amd.pipeline import CaptionPipeline, u8_preprocess
+    model, _, _ = build("CaptioningLSTM")
+    model = model.to(dtype)
+    u8 = bench.synth_images_u8(6, seed=0)
+    batches = [(u8[:3].pin_memory(),), (u8[3:].pin_memory(),)]
+    kw = dict(max_len=12, beam_size=3, top_k=20, temperature=1.0)
+    with torch.no_grad():
+        want = [model.generate_batch(images_to_tensor(b[0].cuda()), seed=7 + i, **kw) for i, b in enumerate(batches)]
+    for overlap in (False, True):
+        pipe = CaptionPipeline(model, overlap=overlap, preprocess=u8_preprocess(model), **kw)
+        got = list(pipe.run(batches, seeds=[7, 8]))
+        assert got[0][0].data_ptr() != got[1][0].data_ptr() and not got[0][0].is_cuda
+        for (wt, wl), (gt, gl) in zip(want, got):
+            assert torch.equal(wt.cpu(), gt) and torch.equal(wl.cpu(), gl)
