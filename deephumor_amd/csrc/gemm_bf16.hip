@@ -1379,6 +1379,14 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
             // of classifier time per step, three alternating runs in one call); DH_VOCAB_AREG=0 restores the tile kernel
             static const int areg = getenv("DH_VOCAB_AREG") ? atoi(getenv("DH_VOCAB_AREG")) : 1;
             const int tm128 = dh_cdiv(M, 128), tn128 = dh_cdiv(V, 128);
+            // round 3: 256-row tiles (32 MFMAs per wave per slab instead of 16) when the rows fill them (DH_VOCAB_AREG=128: never)
+            const int tm256 = dh_cdiv(M, 256);
+            if (areg && areg != 128 && logits && K == 512 && M >= 512 && (M % 256) == 0 && ldl >= tn128 * 128 && tm256 <= 32 &&
+                (32 / tm256) * tm256 >= 28 && tn128 >= 8 * (32 / tm256)) {
+                v.tiles_m = tm256; v.tiles_n = tn128;
+                DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg256_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, v));
+                DH_LAUNCH_CHECK();
+            }
             if (areg && logits && K == 512 && tm128 <= 32 && (32 / tm128) * tm128 >= 28 && tn128 >= 8 * (32 / tm128)) {
                 v.tiles_m = tm128; v.tiles_n = tn128;
                 DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, v));

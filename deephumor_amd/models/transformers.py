@@ -464,7 +464,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             run = self._Run(self, plan, n, b, max_len + 1, None if enc_out is None else enc_out[lo:hi], dev)
             semb = start_emb[lo:hi]
             # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
-            logits = torch.empty((r, (self.num_tokens + 63) // 64 * 64), device=dev)[:, :self.num_tokens]
+            logits = torch.empty((r, (self.num_tokens + 127) // 128 * 128), device=dev)[:, :self.num_tokens]   # whole 128-column panels
             gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
                     if plan["dtype"] in hip.HALF_DTYPES else None)                   # column-group maxima (16-bit paths)
             gm = None if gmax is None else gmax[:n]

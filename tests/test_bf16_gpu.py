@@ -271,11 +271,35 @@ def test_vocab_logits_full_size_repeatable(hip):
     pad = torch.full((rows, ng * 64 - v), float("-inf"), device="cuda")
     want_g = torch.cat([ref, pad], 1).view(rows, ng, 64).max(-1).values
     for rep in range(6):
-        logits = torch.full((rows, (v + 63) // 64 * 64), float("nan"), device="cuda")[:, :v]
-        gmax = torch.full((rows, ng), float("nan"), device="cuda")
-        hip.vocab_logits(a, w, b, logits, gmax)
-        assert torch.equal(logits, ref), rep
-        assert torch.equal(gmax, want_g), rep
+        # row stride of whole 128-column panels (what the decoders allocate): the 256-row A-stationary kernel; a stride that ends
+        # inside the last panel: the 128-row kernel with its element-wise edge tiles
+        for ld in ((v + 127) // 128 * 128, (v + 63) // 64 * 64):
+            logits = torch.full((rows, ld), float("nan"), device="cuda")[:, :v]
+            gmax = torch.full((rows, ng), float("nan"), device="cuda")
+            hip.vocab_logits(a, w, b, logits, gmax)
+            assert torch.equal(logits, ref), (rep, ld)
+            assert torch.equal(gmax, want_g), (rep, ld)
+
+
+@pytest.mark.parametrize("rows,v", [(512, 5000), (768, 36541), (2560, 4100), (1280, 8192)])
+def test_vocab_logits_256_row_tiles(hip, rows, v):
+    """vocab_areg256_kernel (A-stationary, 256-row tiles, no edge path): bit-equal to dh_linear for row counts that are
+    multiples of 256, vocabularies that end inside a panel / inside a 64-column group (clamped weight rows must not disturb
+    the boundary group's maximum) and exact multiples of 128; padding columns of the row stride are the only bytes it may
+    write besides the logits."""
+    k = 512
+    a, w, b = bf(rnd(rows, k, seed=31)).cuda(), bf(rnd(v, k, seed=32) * 0.1).cuda(), rnd(v, seed=33).cuda()
+    ref = hip.linear(a, w, b, out_dtype=torch.float32)
+    ng = hip.n_groups(v)
+    pad = torch.full((rows, ng * 64 - v), float("-inf"), device="cuda")
+    want_g = torch.cat([ref, pad], 1).view(rows, ng, 64).max(-1).values
+    ld = (v + 127) // 128 * 128
+    buf = torch.full((rows + 1, ld), float("nan"), device="cuda")
+    gbuf = torch.full((rows + 1, ng + 3), float("nan"), device="cuda")       # (n_groups counts whole 128-column panels: a group past V holds -inf)
+    hip.vocab_logits(a, w, b, buf[:rows, :v], gbuf[:rows, :ng])
+    assert torch.equal(buf[:rows, :v], ref)
+    assert torch.equal(gbuf[:rows, :ng], want_g)
+    assert bool(torch.isnan(buf[rows]).all()) and bool(torch.isnan(gbuf[rows]).all()) and bool(torch.isnan(gbuf[:rows, ng:]).all())
 
 
 @pytest.mark.parametrize("rows,row_mult,e,hh,use_tokens,with_state", [

@@ -10,7 +10,7 @@ DT = {"bf16": torch.bfloat16, "f16": torch.float16}[os.environ.get("KB_DTYPE", "
 a = [(torch.randn(M, K, device=dev)).to(DT) for _ in range(4)]
 w = (torch.randn(V, K, device=dev) * K ** -0.5).to(DT)
 b = torch.zeros(V, device=dev)
-ldl = (V + 3) // 4 * 4
+ldl = (V + 127) // 128 * 128                       # whole 128-column panels, as the decoders allocate it
 logits = torch.empty(M, ldl, device=dev)[:, :V]
 gm = torch.empty(M, hip.n_groups(V), device=dev)
 tg = torch.randint(0, V, (M,), device=dev)
