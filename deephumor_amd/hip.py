@@ -74,6 +74,9 @@ SIGNATURES = {
     "dh_conv3x3_direct_supported": [_I, _I, _I, _I],
     "dh_conv3x3_direct_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_bottleneck_tail_s3_supported": [_I, _I, _I],
+    "dh_bottleneck_tail_s3_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_pack_mfma_fragments": [_P, _P, _I, _I, _P],
     "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
@@ -512,6 +515,37 @@ def bottleneck_tail_nhwc(y1, w2, scale2, shift2, w3, scale3, shift3, residual):
     out = torch.empty_like(residual)
     _launch("dh_bottleneck_tail_nhwc", _ptr(y1), _ptr(w2), _ptr(scale2), _ptr(shift2), _ptr(w3), _ptr(scale3), _ptr(shift3), _ptr(residual),
             _ptr(out), n, h, wd, c, _dt(y1), _stream())
+    return out
+
+
+def bottleneck_tail_s3_supported(h, w, c):
+    return bool(load().dh_bottleneck_tail_s3_supported(int(h), int(w), int(c)))
+
+
+def pack_mfma_fragments(w):
+    """16-bit weight matrix ``[R, K]`` (or a conv weight ``[Cout, kh, kw, Cin]`` viewed as ``[Cout, kh*kw*Cin]``) -> the
+    fragment-ordered copy the register-streaming kernels load (one coalesced 1 KB load per 16 rows x 32 k)."""
+    _dev(w)
+    assert w.dtype in HALF_DTYPES and w.is_contiguous()
+    r, k = w.shape[0], w.numel() // w.shape[0]
+    out = torch.empty((r * k,), dtype=w.dtype, device=w.device)
+    _launch("dh_pack_mfma_fragments", _ptr(w), _ptr(out), r, k, _stream())
+    return out
+
+
+def bottleneck_tail_s3_nhwc(y1, w2p, scale2, shift2, w3p=None, scale3=None, shift3=None, residual=None):
+    """Stage-3 bottleneck tail (14 x 14 x 256 -> 1024) in one launch on fragment-packed weights (``pack_mfma_fragments``);
+    ``w3p=None``: only relu(bn2(conv2_3x3(y1)))."""
+    _dev(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual)
+    n, h, wd, c = y1.shape
+    assert y1.is_contiguous() and w2p.numel() == 9 * c * c and y1.dtype == w2p.dtype
+    if w3p is None:
+        out = torch.empty_like(y1)
+    else:
+        assert w3p.numel() == 4 * c * c and tuple(residual.shape) == (n, h, wd, 4 * c) and residual.is_contiguous()
+        out = torch.empty_like(residual)
+    _launch("dh_bottleneck_tail_s3_nhwc", _ptr(y1), _ptr(w2p), _ptr(scale2), _ptr(shift2), _ptr(w3p), _ptr(scale3), _ptr(shift3),
+            _ptr(residual), _ptr(out), n, h, wd, c, _dt(y1), _stream())
     return out
 
 

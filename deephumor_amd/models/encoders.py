@@ -167,6 +167,12 @@ class ImageEncoder(_Planned, nn.Module):
                     if c3["w"].shape[-1] % 64 == 0 and dn["w"].shape[-1] % 64 == 0:
                         ent["dual"] = dict(w=w_cat.to(wdt).contiguous(), shift=(c3["shift"] + dn["shift"]).contiguous(),
                                            stride=dn["stride"])
+                if (bf16 and ent["down"] is None and ent["c2"]["stride"] == 1 and ent["c2"]["w"].shape[1] == 3
+                        and ent["c3"]["w"].shape[0] == 4 * ent["c2"]["w"].shape[0] and ent["c2"]["w"].shape[0] == ent["c2"]["w"].shape[3]
+                        and hip.bottleneck_tail_s3_supported(14, 14, ent["c2"]["w"].shape[0])):
+                    # stage-3 blocks: the fused tail streams the weights from L2 into registers in MFMA fragment order
+                    ent["w2p"] = hip.pack_mfma_fragments(ent["c2"]["w"])
+                    ent["w3p"] = hip.pack_mfma_fragments(ent["c3"]["w"].reshape(ent["c3"]["w"].shape[0], -1).contiguous())
                 blocks.append(ent)
         s, b = _bn_affine(self.bn)
         return dict(stem=stem, blocks=blocks, bn_scale=s, bn_shift=b, bf16=bf16, dtype=wdt,
@@ -219,6 +225,12 @@ class ImageEncoder(_Planned, nn.Module):
         nhwc = plan["bf16"]
         for blk in plan["blocks"]:
             c2, c3 = blk["c2"], blk["c3"]
+            if (nhwc and "w2p" in blk and hip.bottleneck_tail_s3_supported(x.shape[1], x.shape[2], c2["w"].shape[0])
+                    and not os.environ.get("DH_NO_FUSED_TAIL") and not os.environ.get("DH_NO_S3_TAIL")):
+                # stage 3 (14 x 14 x 256): one image per workgroup, patch-resident 3x3 + 1x1 expansion, weights register-streamed
+                y1 = self._conv(x, blk["c1"], nhwc=True)
+                x = hip.bottleneck_tail_s3_nhwc(y1, blk["w2p"], c2["scale"], c2["shift"], blk["w3p"], c3["scale"], c3["shift"], x)
+                continue
             if (nhwc and blk["dual"] is None and blk["down"] is None and c2["stride"] == 1 and c2["w"].shape[1] == 3
                     and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], c2["w"].shape[3], c2["w"].shape[0])
                     and c3["w"].shape[0] == 4 * c2["w"].shape[0] and not os.environ.get("DH_NO_FUSED_TAIL")

@@ -105,6 +105,20 @@ int dh_bottleneck_tail_nhwc(const void* y1, const void* w2, const float* scale2,
                             const float* scale3, const float* shift3, const void* residual, void* out, int N, int H,
                             int W, int C, int dtype, void* stream);
 
+/* The same bottleneck tail for STAGE 3 (H = W = 14, C = 256 -> 1024; torchvision layer3.1 .. layer3.5, reference encoders.py:37-38,56):
+ * one image per workgroup, patch-resident 3x3, the weights streamed from L2 straight into registers in MFMA fragment order --
+ * w2_packed / w3_packed = dh_pack_mfma_fragments of w2 viewed as [C][9 C] and of w3 [4C][C] (packed once per weight version).
+ * w3_packed == NULL (and residual == NULL): only conv2 + bn2 + relu, out = [N,14,14,C].  Bit-identical to the unfused pair of
+ * dh_conv2d_nhwc_bn_act launches. */
+int dh_bottleneck_tail_s3_supported(int H, int W, int C);
+int dh_bottleneck_tail_s3_nhwc(const void* y1, const void* w2_packed, const float* scale2, const float* shift2,
+                               const void* w3_packed, const float* scale3, const float* shift3, const void* residual,
+                               void* out, int N, int H, int W, int C, int dtype, void* stream);
+
+/* 16-bit weight matrix w [R][K] row-major -> MFMA operand fragments: out[((k / 32) * (R / 16) + r / 16) * 64 + lane] (16 bytes) = the 8
+ * values k = 32 s + 8 (lane >> 4) .. + 7 of row 16 rt + (lane & 15); R % 16 == 0, K % 32 == 0; out has R * K elements. */
+int dh_pack_mfma_fragments(const void* w, void* out, int R, int K, void* stream);
+
 /* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */
 int dh_stem_conv_nhwc(const float* x, const float* w, const float* scale, const float* shift, void* y,

@@ -549,6 +549,37 @@ def test_fused_bottleneck_tail(hip, n, h, w, c):
     np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), **tol)
 
 
+@pytest.mark.parametrize("n", [1, 3, 9])
+def test_stage3_bottleneck_tail(hip, n):
+    """dh_bottleneck_tail_s3_nhwc (14 x 14 x 256 -> 1024: one image per workgroup, patch-resident 3x3, weights streamed into
+    registers in MFMA fragment order, 1x1 expansion + residual in the same launch) against the two implicit-GEMM launches bit for
+    bit -- fused and conv2-only forms -- and against fp32 math; dh_pack_mfma_fragments against its definition."""
+    c, hw = 256, 14
+    y1 = bf(rnd(n, hw, hw, c, seed=81)).cuda()
+    w2 = bf(rnd(c, 3, 3, c, seed=82) * (9 * c) ** -0.5).cuda()
+    w3 = bf(rnd(4 * c, 1, 1, c, seed=83) * c ** -0.5).cuda()
+    s2, h2 = (rnd(c, seed=84).abs() + 0.5).cuda(), (rnd(c, seed=85) * 0.3).cuda()
+    s3, h3 = (rnd(4 * c, seed=86).abs() + 0.5).cuda(), (rnd(4 * c, seed=87) * 0.3).cuda()
+    res = bf(rnd(n, hw, hw, 4 * c, seed=88)).cuda()
+    w2p, w3p = hip.pack_mfma_fragments(w2), hip.pack_mfma_fragments(w3.reshape(4 * c, c).contiguous())
+    # fragment (s, rt, lane): 8 values k = 32 s + 8 (lane >> 4) .. of row 16 rt + (lane & 15)
+    k2 = 9 * c
+    want_p = w2.reshape(c // 16, 16, k2 // 32, 4, 8).permute(2, 0, 3, 1, 4).reshape(-1)
+    assert torch.equal(w2p, want_p)
+    y2_ref = hip.conv2d_nhwc_bn_act(y1, w2, s2, h2, relu=True, stride=1, pad=1)
+    y2 = hip.bottleneck_tail_s3_nhwc(y1, w2p, s2, h2)
+    assert torch.equal(y2, y2_ref)
+    got = hip.bottleneck_tail_s3_nhwc(y1, w2p, s2, h2, w3p, s3, h3, res)
+    two = hip.conv2d_nhwc_bn_act(y2_ref, w3, s3, h3, residual=res, relu=True, stride=1, pad=0)
+    assert torch.equal(got, two)
+    y2f = torch.relu(F.conv2d(y1.float().cpu().permute(0, 3, 1, 2), w2.float().cpu().permute(0, 3, 1, 2), padding=1)
+                     * s2.cpu()[None, :, None, None] + h2.cpu()[None, :, None, None])
+    want = torch.relu(F.conv2d(bf(y2f).float(), w3.float().cpu().permute(0, 3, 1, 2)) * s3.cpu()[None, :, None, None]
+                      + h3.cpu()[None, :, None, None] + res.float().cpu().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    tol = dict(atol=6e-2, rtol=3e-2) if HALF == torch.bfloat16 else dict(atol=8e-3, rtol=4e-3)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), **tol)
+
+
 @pytest.mark.parametrize("n,h,w", [(2, 224, 224), (3, 64, 96), (1, 36, 28), (1, 8, 4), (70, 60, 64)])
 def test_direct_stem_convolution(hip, n, h, w):
     """dh_stem_conv7_bn_relu_maxpool (direct 7x7/2 convolution + BN + ReLU + maxpool, one launch) against fp32
