@@ -176,6 +176,17 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
             const size_t so = (size_t)l * rows_total * Hh;
             const void* x = l == 0 ? img_emb : (const char*)sc->xcatl + (size_t)(l - 1) * rows * 2 * Hh * esz;
             void* dst = l + 1 < nl ? (void*)((char*)sc->xcatl + (size_t)l * rows * 2 * Hh * esz) : top;
+            const int El = l == 0 ? E : Hh;
+            // decode shapes: the step with the gate weights stationary in registers (DH_LSTM_WREG=0: the tile kernel)
+            static const int use_wreg = getenv("DH_LSTM_WREG") ? atoi(getenv("DH_LSTM_WREG")) : 1;
+            if (use_wreg && m->layers[l].w_pk && dh_lstm_layer_wreg_supported(El, Hh) && rows >= 256) {
+                DH_TRY(dh_lstm_layer_wreg(x, l == 0 ? E : 2 * Hh, l == 0 ? rows_per_img : 1, l == 0 ? m->emb : nullptr,
+                                          l == 0 ? tokens : nullptr, tok_ld, tok_pos, hr ? hr + so * esz : nullptr,
+                                          cr ? cr + so : nullptr, hparent, hw + so * esz, cw + so, dst,
+                                          l + 1 < nl ? 2 * Hh : top_ld, m->layers[l].w_pk, m->layers[l].b_il, rows, row_mult, El, Hh,
+                                          dt, stream));
+                continue;
+            }
             DH_TRY(dh_lstm_layer_fused(x, l == 0 ? E : 2 * Hh, l == 0 ? rows_per_img : 1, l == 0 ? m->emb : nullptr,
                                        l == 0 ? tokens : nullptr, tok_ld, tok_pos, hr ? hr + so * esz : nullptr,
                                        cr ? cr + so : nullptr, hparent, hw + so * esz, cw + so, dst,

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 10
+ABI_VERSION = 11
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW, ERR_TOPK_GROUPS = 1, 2, 4, 8
 TOPK_SLOTS = 64
@@ -53,7 +53,7 @@ class LnFold(_c.Structure):
 
 
 class LstmLayer(_c.Structure):
-    _fields_ = [("w", _P), ("b", _P), ("w_il", _P), ("b_il", _P)]
+    _fields_ = [("w", _P), ("b", _P), ("w_il", _P), ("b_il", _P), ("w_pk", _P)]
 
 
 class LstmModel(_c.Structure):
@@ -113,6 +113,8 @@ SIGNATURES = {
     "dh_attn_self_prefill": [_P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "dh_attn_cross_prefill": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_lstm_layer_fused": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_lstm_layer_wreg_supported": [_I, _I],
+    "dh_lstm_layer_wreg": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
                        _U64, _P, _I, _P],
@@ -940,6 +942,20 @@ def lstm_layer_fused(x_rows, x_div, emb, tokens, tok_pos, h_prev, c_prev, hparen
             _ptr(tokens), tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(h_prev), _ptr(c_prev),
             _ptr(hparent), _ptr(h_next), _ptr(c_next), _ptr(h_out), h_out.stride(0), _ptr(w_il), _ptr(b_il), rows,
             row_mult, e, hh, _dt(w_il), _stream())
+
+
+def lstm_layer_wreg_supported(e, hh):
+    return bool(load().dh_lstm_layer_wreg_supported(int(e), int(hh)))
+
+
+def lstm_layer_wreg(x_rows, x_div, emb, tokens, tok_pos, h_prev, c_prev, hparent, h_next, c_next, h_out, w_pk, b_il,
+                    rows, row_mult, e, hh):
+    """``lstm_layer_fused`` with the gate weights stationary in registers (``w_pk = pack_mfma_fragments(w_il)``)."""
+    _dev(h_next, c_next, h_out, w_pk, b_il)
+    _launch("dh_lstm_layer_wreg", _ptr(x_rows), x_rows.stride(0) if x_rows is not None else 0, x_div, _ptr(emb),
+            _ptr(tokens), tokens.stride(0) if tokens is not None else 0, tok_pos, _ptr(h_prev), _ptr(c_prev),
+            _ptr(hparent), _ptr(h_next), _ptr(c_next), _ptr(h_out), h_out.stride(0), _ptr(w_pk), _ptr(b_il), rows,
+            row_mult, e, hh, _dt(w_pk), _stream())
 
 
 def lstm_decode_step(model, scratch, img_emb, tokens, tok_pos, hparent, started, rows, rows_per_img, row_mult,

@@ -41,9 +41,11 @@ class LSTMDecoder(_Planned, nn.Module):
                 hh = self.lstm.hidden_size
                 w_il = w.view(4, hh, -1).permute(1, 0, 2).reshape(4 * hh, -1).contiguous()
                 b_il = b.view(4, hh).t().reshape(-1).contiguous()
+                # ... and that copy in MFMA fragment order for the register-stationary step (decode shapes)
+                w_pk = hip.pack_mfma_fragments(w_il) if hip.lstm_layer_wreg_supported(w.shape[1] - hh, hh) else None
             else:
-                w_il = b_il = None
-            layers.append((w, b, w_il, b_il))
+                w_il = b_il = w_pk = None
+            layers.append((w, b, w_il, b_il, w_pk))
         return dict(layers=layers, emb=self.embedding.weight.detach(),
                     cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach().float().contiguous(),
                     dtype=self.classifier.weight.dtype)
@@ -66,10 +68,12 @@ class LSTMDecoder(_Planned, nn.Module):
             self.started = 0                                                    # 0: zero state, then 1, 2, 1, 2, ...
             self._scratch = {}
             self.c_layers = (hip.LstmLayer * self.nl)()
-            for i, (w, b, w_il, b_il) in enumerate(plan["layers"]):
+            for i, (w, b, w_il, b_il, w_pk) in enumerate(plan["layers"]):
                 self.c_layers[i].w, self.c_layers[i].b = w.data_ptr(), b.data_ptr()
                 if w_il is not None:
                     self.c_layers[i].w_il, self.c_layers[i].b_il = w_il.data_ptr(), b_il.data_ptr()
+                if w_pk is not None:
+                    self.c_layers[i].w_pk = w_pk.data_ptr()
             m = self.c_model = hip.LstmModel()
             m.n_layers, m.E, m.Hh, m.V = self.nl, self.e, self.hh, dec.num_tokens
             m.dtype = {torch.float32: hip.F32, torch.bfloat16: hip.BF16, torch.float16: hip.F16}[self.dtype]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 10
+#define DH_ABI_VERSION 11
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -558,6 +558,7 @@ int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_tr_scratch_t
 typedef struct dh_lstm_layer {
     const void* w; const float* b;          /* [4Hh, in+Hh] = [W_ih|W_hh], b_ih+b_hh (PyTorch gate order i,f,g,o) */
     const void* w_il; const float* b_il;    /* optional (bf16): the same, gate-interleaved: row 4u+g = gate g of unit u */
+    const void* w_pk;                       /* optional: dh_pack_mfma_fragments(w_il) -- the register-stationary step (dh_lstm_layer_wreg) */
 } dh_lstm_layer_t;
 
 typedef struct dh_lstm_model {
@@ -580,6 +581,16 @@ int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const void* emb,
                         int tok_pos, const void* h_prev, const float* c_prev, const int32_t* hparent, void* h_next,
                         float* c_next, void* h_out, int ld_out, const void* w_il, const float* b_il, int rows,
                         int row_mult, int E, int Hh, int dtype, void* stream);
+
+/* The same step with the gate weights stationary in registers (decode shapes: E + Hh = 768 or 1024, E % 64 == 0, Hh % 32 == 0):
+ * a workgroup owns 128 gate rows x 80 activation rows, its waves load their weight fragments straight from L2 out of
+ * w_packed = dh_pack_mfma_fragments(w_il [4 Hh, E + Hh]); only the activation block crosses LDS.  Same arguments and results
+ * (bit-identical) as dh_lstm_layer_fused. */
+int dh_lstm_layer_wreg_supported(int E, int Hh);
+int dh_lstm_layer_wreg(const void* x_rows, int ldx, int x_div, const void* emb, const int32_t* tokens, int tok_ld,
+                       int tok_pos, const void* h_prev, const float* c_prev, const int32_t* hparent, void* h_next,
+                       float* c_next, void* h_out, int ld_out, const void* w_packed, const float* b_il, int rows,
+                       int row_mult, int E, int Hh, int dtype, void* stream);
 
 /* One LSTM time step for `rows` compact rows and, if logits != NULL, the classifier.  h_out (optional, row stride
  * ld_out) receives the top layer's h instead of scratch->hout.

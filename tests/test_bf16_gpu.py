@@ -343,6 +343,39 @@ def test_lstm_layer_fused_matches_cell_math(hip, rows, row_mult, e, hh, use_toke
         assert float(c_next.cpu()[1].min()) == 9.0
 
 
+@pytest.mark.parametrize("rows,row_mult,e,hh,use_tokens,with_state", [
+    (1280, 1, 256, 512, True, True), (1280, 1, 512, 512, False, True), (256, 5, 256, 512, False, False),
+    (333, 1, 512, 512, True, True), (77, 3, 256, 512, True, True)])
+def test_lstm_layer_wreg_equals_fused(hip, rows, row_mult, e, hh, use_tokens, with_state):
+    """dh_lstm_layer_wreg (gate weights stationary in registers, the whole [80 rows x K] activation block in LDS, one barrier) against
+    dh_lstm_layer_fused on the same operands: h / c / h_out bit for bit -- decode shapes (K = 768 and 1024), the zero-state first
+    step (256 compact rows, row_mult 5), row counts that do not fill the last 80-row block."""
+    g = torch.Generator().manual_seed(rows * 11 + e)
+    rows_total = rows * row_mult
+    w = bf(torch.randn(4 * hh, e + hh, generator=g) * 0.05)
+    b = torch.randn(4 * hh, generator=g) * 0.1
+    w_il = w.view(4, hh, -1).permute(1, 0, 2).reshape(4 * hh, -1).contiguous().cuda()
+    b_il = b.view(4, hh).t().reshape(-1).contiguous().cuda()
+    w_pk = hip.pack_mfma_fragments(w_il)
+    emb = bf(torch.randn(500, e, generator=g)).cuda()
+    tokens = torch.randint(0, 500, (rows_total, 6), generator=g, dtype=torch.int32).cuda()
+    x_rows = bf(torch.randn(rows, e, generator=g)).cuda()
+    h_prev = bf(torch.randn(rows_total, hh, generator=g) * 0.5).cuda()
+    c_prev = torch.randn(rows_total, hh, generator=g).cuda()
+    hparent = torch.randint(0, rows_total, (rows_total,), generator=g, dtype=torch.int32).cuda()
+    outs = []
+    for fn, wt in ((hip.lstm_layer_fused, w_il), (hip.lstm_layer_wreg, w_pk)):
+        h_next = torch.full((rows_total, hh), 9.0).to(HALF).cuda()
+        c_next = torch.full((rows_total, hh), 9.0).cuda()
+        h_out = torch.zeros(rows, hh + 8).to(HALF).cuda()[:, :hh]
+        fn(None if use_tokens else x_rows, 1, emb if use_tokens else None, tokens if use_tokens else None, 3,
+           h_prev if with_state else None, c_prev if with_state else None, hparent if with_state else None, h_next, c_next, h_out,
+           wt, b_il, rows, row_mult, e, hh)
+        outs.append((h_next, c_next, h_out.clone()))
+    for a, b_ in zip(outs[0], outs[1]):
+        assert torch.equal(a, b_)
+
+
 @pytest.mark.parametrize("rows,v", [(300, 36541), (1280, 36541), (37, 1000), (200, 4000)])
 def test_vocab_logprob_matches_log_softmax(hip, rows, v):
     """dh_vocab_logprob (log-sum-exp partials in the classifier GEMM epilogue, logits never written) against
