@@ -1298,7 +1298,6 @@ __global__ __launch_bounds__(512, 1) void vocab256_kernel(VocabParams p) {
     }
 }
 
-#include "vocab_dacc.h"
 #include "vocab_areg.h"
 
 // fp32-output dense GEMMs with many tiles (teacher-forced classifier: [bs*T, V] logits): the persistent kernel without
@@ -1392,20 +1391,6 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
                 DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, v));
                 DH_LAUNCH_CHECK();
             }
-        }
-        const int dsel = logits ? vns : gns;
-        if ((dsel == 2561 || dsel == 1282 || dsel == 1281) && K / 64 > 3) {
-            // deferred-store kernels: 2561 = 256 x 128 tiles (8 waves, 3-slab ring), 1282 = 128 x 256, 1281 = 128 x 128 (4 waves, 2 per CU)
-            const int bm = dsel == 2561 ? 256 : 128, bn = dsel == 1282 ? 256 : 128;
-            v.tiles_m = dh_cdiv(M, bm); v.tiles_n = dh_cdiv(V, bn);
-            const int nt = v.tiles_m * v.tiles_n;
-            hipStream_t s = (hipStream_t)stream;
-            DH_DISPATCH_16(dtype, {
-                if (dsel == 2561) hipLaunchKernelGGL((vocab_dacc_kernel<T, 4, 2, 3, 1>), dim3(nt < 256 ? nt : 256), dim3(512), 0, s, v);
-                else if (dsel == 1282) hipLaunchKernelGGL((vocab_dacc_kernel<T, 2, 4, 3, 1>), dim3(nt < 256 ? nt : 256), dim3(512), 0, s, v);
-                else hipLaunchKernelGGL((vocab_dacc_kernel<T, 2, 2, 2, 2>), dim3(nt < 512 ? nt : 512), dim3(256), 0, s, v);
-            });
-            DH_LAUNCH_CHECK();
         }
         if ((logits ? vns : gns) == 256 && (logits || M >= 512)) {
             v.tiles_m = dh_cdiv(M, 256); v.tiles_n = dh_cdiv(V, 256);

@@ -3,7 +3,7 @@ against the REAL reference (``/root/reference``, imported through the torchvisio
 and thread count, in the BUILD CONTAINER ("restatement-vs-reference timing ratio").
 TEST INFRASTRUCTURE ONLY; cannot run on the GPU box (no reference there).
 
-    python oracle/time_vs_reference.py      # writes profiles/r2/oracle_vs_reference_timing.json
+    python oracle/time_vs_reference.py      # writes profiles/r3/oracle_vs_reference_timing.json
 """
 import json
 import os
@@ -54,7 +54,7 @@ def main():
         out[kind] = {"reference_s_per_caption": round(t_ref, 3), "oracle_s_per_caption": round(t_orc, 3),
                      "oracle_over_reference": round(t_orc / t_ref, 3), "same_ids_under_same_seed": bool(torch.equal(a.reshape(-1), b.reshape(-1)))}
         print(kind, out[kind])
-    path = os.path.join(ROOT, "profiles", "r2", "oracle_vs_reference_timing.json")
+    path = os.path.join(ROOT, "profiles", "r3", "oracle_vs_reference_timing.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)

@@ -1,10 +1,10 @@
 #!/usr/bin/env bash
 # Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel traces and PMC passes of the bench workloads of THIS tree, reduced to
-# CSV summaries under gpurun_out/profiles_r2/ (copied to profiles/r2/ afterwards).  Counters in their own passes
+# CSV summaries under gpurun_out/profiles_${ROUND:-r3}/ (copied to profiles/<round>/ afterwards).  Counters in their own passes
 # (--pmc with --kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/profiles_r2
+OUT=$R/gpurun_out/profiles_${ROUND:-r3}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for wl in c2 c3; do
@@ -17,6 +17,11 @@ for wl in c2 c3; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d /tmp/pmc_${wl}_mfma -o p -- python3 $R/bench.py --workload $wl --steps 1 --warmup 1 --quick > /dev/null 2>&1
   python3 $R/tools/rocpd_stats.py /tmp/pmc_${wl}_mfma/p_results.db --pmc --top 0 --csv $OUT/pmc_${wl}_mfma.csv
 done
+# SQ-level PMC (wait / issue / LDS / MFMA counters) of the stand-alone probes: classifier, stage-3 bottleneck tail, LSTM step, decode GEMMs
+for pr in vocab_probe s3_probe lstm_probe kbench; do
+  bash $R/tools/pmc_sq.sh $pr $R/tools/$pr.py > /dev/null 2>&1
+done
+cp $R/gpurun_out/pmc_sq/*.csv $OUT/ 2>/dev/null
 python3 $R/bench.py > $OUT/bench_default_bf16.json 2> /dev/null
 python3 $R/bench.py --workload c5 --steps 5 > $OUT/bench_c5_f16.json 2> /dev/null
 python3 $R/bench.py --workload score-c2 --steps 3 > $OUT/bench_score_c2.json 2> /dev/null

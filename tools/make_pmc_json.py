@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Reduce the per-kernel PMC CSVs of tools/collect_profiles.sh to profiles/r2/pmc_hbm_traffic.json, the file bench.py reads
+"""Reduce the per-kernel PMC CSVs of tools/collect_profiles.sh to profiles/<round>/pmc_hbm_traffic.json, the file bench.py reads
 for `roofline.traffic` (rocprofv3 --pmc cannot run inside the bench process).
 
 traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE, both counters in KB: on gfx950 FETCH_SIZE tallies the 128-byte requests of
 wide coalesced reads at 64 bytes and has to be doubled, WRITE_SIZE is exact for 16-byte-per-lane stores
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section).  Separate passes per counter (they cannot share one on gfx950).
 
-    python tools/make_pmc_json.py profiles/r2 [commit]
+    python tools/make_pmc_json.py profiles/r3 [commit]
 """
 import csv
 import json
@@ -16,10 +16,10 @@ from pathlib import Path
 
 # bench.py roofline key -> (workload, kernel-name fragment, workgroups or None, note)
 KEYS = [
-    ("c2", "dh_linear[vocab]{1280x36541x512}", "vocab_areg_kernel", 256,
-     "A-stationary persistent vocabulary GEMM + bias (activation fragments in registers, W-only LDS ring), fp32 logits out; "
-     "fetch above W + A = weight panels fetched by more than one XCD"),
-    ("c3", "dh_linear[vocab]{1280x36541x512}", "vocab_areg_kernel", 256, "same kernel, same shape (256 images x 5 beams)"),
+    ("c2", "dh_linear[vocab]{1280x36541x512}", "vocab_areg256_kernel", 256,
+     "A-stationary persistent vocabulary GEMM + bias, 256-row tiles (activation fragments in registers, W-only LDS ring), fp32 logits "
+     "out into a row stride of whole 128-column panels; fetch above W + A = weight panels fetched by more than one XCD"),
+    ("c3", "dh_linear[vocab]{1280x36541x512}", "vocab_areg256_kernel", 256, "same kernel, same shape (256 images x 5 beams)"),
     ("c3", "dh_attn_self_decode", "attn_decode_reg_kernel", 2048,
      "launch-weighted mean over the history depths of one sweep (2..22 keys per row)"),
     ("c3", "dh_attn_cross_decode", "attn_cross_qproj_kernel", 256,
@@ -39,7 +39,7 @@ def mean_kb(rs, frag, wgs):
 
 
 def main():
-    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r2")
+    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r3")
     commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(
         ["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     out = {"commit": commit,
