@@ -410,6 +410,7 @@ struct SelectParams {
 struct SelLds {
     int32_t* stage;                                     // [beam][tok_ld] tokens, then [beam][t] ancestors
     int* ctok; int* cpar; int* keep; float* cval; float* q; uint8_t* cend; int* s_n;
+    int32_t* pki = nullptr; float* pkv = nullptr;       // optional [beam * beam]: the image's picks, brought in with the first round trip
 };
 #define DH_SEL_STAGE_MAX 3072                           // ints available for `stage` in the fused step
 
@@ -421,23 +422,46 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
     int* ctok = L.ctok; int* cpar = L.cpar; int* keep = L.keep; float* cval = L.cval; float* q = L.q; uint8_t* cend = L.cend;
 #define s_n (*L.s_n)
     const int B = p.beam, base = img * B;
-    if (p.done[img]) return;
+    // Stand-alone kernel (L.pki set): EVERYTHING the image needs -- its token rows, ancestor rows and all its picks -- is requested
+    // up front by LDS-DMA, next to the loads of done / ended / vals: ONE memory round trip instead of four dependent ones (done ->
+    // ended -> picks -> token rows), which were most of this 8 us kernel.
+    const bool pre = L.pki != nullptr && !shared_picks;
+    int32_t* const tokbuf0 = stage;
+    int32_t* const srcbuf0 = stage + (size_t)B * p.tok_ld;
+    if (pre) {
+        for (int i = lane; i < B * p.tok_ld; i += 64) dh_lds_dma4(p.tokens + (size_t)base * p.tok_ld + i, tokbuf0 + (i - lane));
+        if (p.src)
+            for (int b = 0; b < B; ++b)
+                for (int j = lane; j < p.t; j += 64) dh_lds_dma4(p.src + (size_t)(base + b) * p.src_ld + j, srcbuf0 + b * p.t + (j - lane));
+        const int npk = p.first ? B : B * B;
+        const size_t pk0 = p.first ? (size_t)img * B : (size_t)base * B;
+        for (int i = lane; i < npk; i += 64) {
+            dh_lds_dma4(p.pick_idx + pk0 + i, L.pki + (i - lane));
+            dh_lds_dma4(p.pick_val + pk0 + i, L.pkv + (i - lane));
+        }
+    }
+    const uint8_t is_done = p.done[img];
+    uint8_t was_ended[DH_BEAM_MAX_BEAMS];
+#pragma unroll
+    for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b) was_ended[b] = p.ended[base + min(b, B - 1)];   // one round trip for all
+    float val_b[DH_BEAM_MAX_BEAMS];
+#pragma unroll
+    for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b) val_b[b] = p.vals[base + min(b, B - 1)];
+    if (pre) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); wave_lds_sync(); }
+    if (is_done) return;
 
     // candidate list in the reference's order: beam b contributes 1 candidate if it has ended, else B.
     // Every lane derives the (short) offset table itself; candidates are then filled in parallel.
     if (p.first) {
         for (int j = lane; j < B; j += 64) {
-            const int tok = pick_load_idx(p.pick_idx, (size_t)img * B + j, shared_picks);
-            ctok[j] = tok; cval[j] = pick_load_val(p.pick_val, (size_t)img * B + j, shared_picks); cpar[j] = 0;
+            const int tok = pre ? L.pki[j] : pick_load_idx(p.pick_idx, (size_t)img * B + j, shared_picks);
+            ctok[j] = tok; cval[j] = pre ? L.pkv[j] : pick_load_val(p.pick_val, (size_t)img * B + j, shared_picks); cpar[j] = 0;
             cend[j] = (uint8_t)(p.first_sets_ended && tok == p.eos);
             keep[j] = j;
         }
         if (lane == 0) s_n = B;
     } else {
         int off[DH_BEAM_MAX_BEAMS + 1];
-        uint8_t was_ended[DH_BEAM_MAX_BEAMS];
-#pragma unroll
-        for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b) was_ended[b] = p.ended[base + min(b, B - 1)];   // one round trip for all
         off[0] = 0;
 #pragma unroll
         for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b)
@@ -448,10 +472,12 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
 #pragma unroll
             for (int k = 1; k < DH_BEAM_MAX_BEAMS; ++k) b += (k < B && c >= off[k]);
             const int j = c - off[b];
-            const bool was = p.ended[base + b] != 0;
-            const int tok = was ? 0 : pick_load_idx(p.pick_idx, (size_t)(base + b) * B + j, shared_picks);
+            bool was = false; float vb = 0.f;             // (static register indexing: b is a run-time value)
+#pragma unroll
+            for (int k = 0; k < DH_BEAM_MAX_BEAMS; ++k) if (k == b) { was = was_ended[k] != 0; vb = val_b[k]; }
+            const int tok = was ? 0 : (pre ? L.pki[b * B + j] : pick_load_idx(p.pick_idx, (size_t)(base + b) * B + j, shared_picks));
             ctok[c] = tok;
-            cval[c] = p.vals[base + b] + (was ? 0.f : pick_load_val(p.pick_val, (size_t)(base + b) * B + j, shared_picks));
+            cval[c] = vb + (was ? 0.f : (pre ? L.pkv[b * B + j] : pick_load_val(p.pick_val, (size_t)(base + b) * B + j, shared_picks)));
             cpar[c] = b;
             cend[c] = (uint8_t)(was || tok == p.eos);
         }
@@ -483,10 +509,12 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
     // stage the image's token rows and ancestor rows, then rewrite them in place
     int32_t* tokbuf = stage;
     int32_t* srcbuf = stage + (size_t)B * p.tok_ld;
-    for (int i = lane; i < B * p.tok_ld; i += 64) tokbuf[i] = p.tokens[(size_t)base * p.tok_ld + i];
-    if (p.src)
-        for (int b = 0; b < B; ++b)
-            for (int j = lane; j < p.t; j += 64) srcbuf[b * p.t + j] = p.src[(size_t)(base + b) * p.src_ld + j];
+    if (!pre) {
+        for (int i = lane; i < B * p.tok_ld; i += 64) tokbuf[i] = p.tokens[(size_t)base * p.tok_ld + i];
+        if (p.src)
+            for (int b = 0; b < B; ++b)
+                for (int j = lane; j < p.t; j += 64) srcbuf[b * p.t + j] = p.src[(size_t)(base + b) * p.src_ld + j];
+    }
     wave_lds_sync();
     int all_ended = 1;
     for (int b = 0; b < B; ++b) {
@@ -867,7 +895,9 @@ __global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
     __shared__ float cval[256], q[256];
     __shared__ uint8_t cend[256];
     __shared__ int s_n;
-    const SelLds L{stage, ctok, cpar, keep, cval, q, cend, &s_n};
+    __shared__ int32_t pki[DH_BEAM_MAX_BEAMS * DH_BEAM_MAX_BEAMS];
+    __shared__ float pkv[DH_BEAM_MAX_BEAMS * DH_BEAM_MAX_BEAMS];
+    const SelLds L{stage, ctok, cpar, keep, cval, q, cend, &s_n, pki, pkv};
     beam_select_image(p, blockIdx.x, threadIdx.x, L);
 }
 
