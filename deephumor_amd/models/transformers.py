@@ -215,12 +215,28 @@ class _IncrementalDecoder(_Planned, nn.Module):
             raise RuntimeError("deephumor_amd implements the inference path; call model.eval()")
         if self.pad_index is None:
             raise TypeError("pad_index=None is unusable in the reference too (transformers.py:451); pass an int")
-        if cached and self.pad_index != 0:
-            # the reference compares the image slot's stand-in id 1 (transformers.py:474) and the 0/1 encoder-row flags
-            # (:480-481) with pad_index: pad_index == 1 masks the image slot and inverts the encoder mask, any other
-            # value disables the encoder mask.  The vocabulary fixes <pad> = 0 (data/vocab.py:5-12); the cached kernels
-            # implement that case only.  (The module-API layers above take explicit masks and have no such limit.)
-            raise NotImplementedError("TransformerDecoder kernels implement pad_index == 0 (the vocabulary's <pad>)")
+        if cached and self.pad_index == 1:
+            # the reference compares the image slot's stand-in id 1 (transformers.py:474) and the 0/1 encoder-row flags (:480-481)
+            # with pad_index.  pad_index == 1 masks the image slot: at the first position EVERY key is then masked and the reference's
+            # softmax spreads uniformly over all seq_len positions, future <pad> rows included -- a row no longer depends only on
+            # rows <= it, which is what incremental (KV-cached) decoding rests on.  Every other value is supported: 0 (the
+            # vocabulary's <pad>, data/vocab.py:5-12) and >= 2 (see _enc_for_cross).  (The module-API layers take explicit masks.)
+            raise NotImplementedError("TransformerDecoder kernels do not implement pad_index == 1 (the image slot's stand-in id)")
+
+    def _enc_for_cross(self, enc_out, seq):
+        """Encoder rows and their key mask as the reference's forward sees them (transformers.py:450-452, 480-481).
+        ``pad_index == 0``: rows with a zero element are masked -- the zero rows the reference pads ``enc_out`` with up to ``seq`` are
+        masked too, so they need not exist.  ``pad_index >= 2``: the 0/1 row flags never equal it, NOTHING is masked, and once
+        ``seq`` exceeds the encoder length the padded zero rows are real keys (K = V = the projection biases): they are appended."""
+        n, s, d = enc_out.shape
+        if self.pad_index == 0:
+            flat = enc_out.contiguous().view(n * s, d)
+            return flat, s, hip.enc_key_mask(flat)
+        if seq > s:
+            padded = torch.zeros((n, seq, d), dtype=enc_out.dtype, device=enc_out.device)
+            padded[:, :s] = enc_out
+            enc_out, s = padded, seq
+        return enc_out.contiguous().view(n * s, d), s, torch.zeros((n * s,), dtype=torch.uint8, device=enc_out.device)
 
     class _Run:
         """KV cache + cross-attention operands + scratch for one batch, described to the native step
@@ -234,10 +250,9 @@ class _IncrementalDecoder(_Planned, nn.Module):
             self.vc = torch.empty((nl, n_pos, self.rows_total, d), device=dev, dtype=self.dtype)
             self.kv, self.keymask, self.s, self.packed, self.dperm = None, None, 0, None, False
             if enc_out is not None:
-                n, s, _ = enc_out.shape
-                flat = enc_out.to(self.dtype).contiguous().view(n * s, d)
+                n = enc_out.shape[0]
+                flat, s, self.keymask = dec._enc_for_cross(enc_out.to(self.dtype), n_pos)   # transformers.py:450-452, 480-481
                 self.s = s
-                self.keymask = hip.enc_key_mask(flat)                                   # transformers.py:480-481
                 self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv") for L in plan["layers"]]   # once per image
                 if (self.dtype in hip.HALF_DTYPES and s <= 64 and d == 64 * dec.n_heads and beam <= 16
                         and not os.environ.get("DH_NO_PACKED_CROSS")):
@@ -312,8 +327,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
         seq = dec_len if enc_out is None else max(dec_len, enc_out.shape[1])          # transformers.py:450
         if seq > self.pos_embedding.num_embeddings:
             raise IndexError("index out of range in self")                            # pos-embedding lookup
-        if num_positions is not None:                     # causal: positions >= num_positions cannot influence the rest
-            seq = max(1, min(seq, int(num_positions)))
+        if num_positions is not None and self.pad_index == 0:      # causal: positions >= num_positions cannot influence the rest
+            seq = max(1, min(seq, int(num_positions)))             # (pad_index >= 2: the padded encoder rows depend on the full length)
         tokens = torch.full((bs, max(seq - 1, 1)), self.pad_index, dtype=torch.int32, device=dev)
         ncopy = min(x.shape[1], tokens.shape[1])
         tokens[:, :ncopy] = x[:, :ncopy].to(torch.int32)
@@ -376,9 +391,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
         kv = keymask = None
         s_enc = 0
         if enc_out is not None:
-            s_enc = enc_out.shape[1]
-            flat = enc_out.to(dt).contiguous().view(bs * s_enc, d)
-            keymask = hip.enc_key_mask(flat)                                          # transformers.py:480-481
+            flat, s_enc, keymask = self._enc_for_cross(enc_out.to(dt), seq)            # transformers.py:450-452, 480-481
         packed_ok = dt in hip.HALF_DTYPES and 0 < s_enc <= 64
 
         def cross(q, L):

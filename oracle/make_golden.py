@@ -188,6 +188,32 @@ def round3_goldens():
         print(kind, "V=36541 demo settings", kw, rec["beam_0"])
 
 
+def pad_index_goldens():
+    """G12: a Transformer built with pad_index = 7 (transformers.py:393-394 accepts any value): the encoder-row mask then hides
+    nothing (the 0/1 row flags never equal 7, :480-481), <pad> positions are ids 7, an ended beam's 0 tokens are ordinary keys, and
+    once max_len + 1 exceeds the 49 image patches the zero rows the reference pads enc_out with (:452) take part in cross-attention
+    (K = V = the projection biases).  Greedy ids at max_len 32 (no padded rows) and 60 (12 padded rows), RNG-replay beam 3, and
+    teacher-forced logits on captions padded with 7."""
+    torch.set_num_threads(8)
+    images = synth_images(2, seed=0)
+    rec = {}
+    for kind in ("CaptioningTransformer", "CaptioningTransformerBase"):
+        model = load_synthetic({"CaptioningTransformer": CaptioningTransformer, "CaptioningTransformerBase": CaptioningTransformerBase}[kind](
+            V_SMALL, pad_index=7).eval(), seed=SEED)
+        with torch.no_grad():
+            for ml in (32, 60):
+                for i in range(2):
+                    rec[f"{kind}_greedy{ml}_{i}"] = model.generate(images[i:i + 1], max_len=ml, beam_size=1, top_k=1).reshape(-1).numpy()
+            rec[f"{kind}_beam_0"] = beam_ids(model, images[:1], 500, max_len=60, beam_size=3, top_k=20, temperature=1.3)
+            cap, lengths, _ = captions_and_lengths(V_SMALL)
+            cap = cap.clone()
+            cap[cap == 0] = 7
+            logits = model(images, cap[:2], lengths[:2])
+            rec[f"{kind}_forward_logits"] = logits.numpy()
+        print(kind, "pad_index=7", rec[f"{kind}_greedy60_0"][:8], len(rec[f"{kind}_greedy60_0"]), logits.shape)
+    np.savez_compressed(os.path.join(OUT, "g12_pad_index.npz"), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -303,6 +329,7 @@ def main():
 
     text_and_metric_goldens()
     round3_goldens()
+    pad_index_goldens()
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote", OUT)
@@ -311,5 +338,8 @@ def main():
 if __name__ == "__main__":
     if sys.argv[1:] == ["r3"]:
         round3_goldens()
+        pad_index_goldens()
+    elif sys.argv[1:] == ["pad"]:
+        pad_index_goldens()
     else:
         main()

@@ -280,7 +280,7 @@ def transformer_forward(sd, p, x, enc_out, start_emb, pad_index, n_heads):
     enc_mask = None
     if enc_out is not None:
         row_nonzero = (enc_out != 0.).all(dim=-1)                                    # :480
-        enc_mask = (~row_nonzero)[:, None, :].expand(bs, seq, seq)
+        enc_mask = (row_nonzero.long() == pad_index)[:, None, :].expand(bs, seq, seq)   # :481 get_pad_mask(x, enc_inp_mask, pad_index)
     n = 0
     while f"{p}.layers.{n}.self_attn.fc_q.weight" in sd:
         lp = f"{p}.layers.{n}"

@@ -397,3 +397,37 @@ def test_u8_pipeline_equals_fp32_image_path(dtype):
         assert got[0][0].data_ptr() != got[1][0].data_ptr() and not got[0][0].is_cuda
         for (wt, wl), (gt, gl) in zip(want, got):
             assert torch.equal(wt.cpu(), gt) and torch.equal(wl.cpu(), gl)
+
+
+@pytest.mark.parametrize("kind", ("CaptioningTransformer", "CaptioningTransformerBase"))
+def test_pad_index_other_than_zero(kind):
+    """``pad_index = 7`` (the reference's constructor accepts any value, transformers.py:393-394), goldens recorded from the reference:
+    fp32 greedy ids at max_len 32 and 60 (past 49 positions the reference's zero-padded encoder rows become real cross-attention keys),
+    RNG-replay beam 3, teacher-forced logits within 1e-3; the 16-bit path runs the same shapes; ``pad_index = 1`` raises."""
+    import deephumor_amd.models as M
+    g = golden("g12_pad_index.npz")
+    sd, hp = synthetic_sd(kind)
+    hp = dict(hp, pad_index=7)
+    model = getattr(M, kind)(**hp).eval()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    images = synth_images(2, seed=0)
+    for ml in (32, 60):
+        with torch.no_grad():
+            toks, lens = model.generate_batch(images.cuda(), max_len=ml, beam_size=1, top_k=1)
+        for i in range(2):
+            assert toks[i, :int(lens[i])].cpu().tolist() == g[f"{kind}_greedy{ml}_{i}"].tolist(), (kind, ml, i)
+            assert bool((toks[i, int(lens[i]):] == 7).all())                  # padded with pad_index
+    assert _replay_generate(model, images[:1].cuda(), 500, max_len=60, beam_size=3, top_k=20, temperature=1.3) == g[f"{kind}_beam_0"].tolist()
+    cap, lengths, _ = captions_and_lengths()
+    cap = cap.clone()
+    cap[cap == 0] = 7
+    with torch.no_grad():
+        out = model(images.cuda(), cap[:2].cuda(), lengths[:2])
+    np.testing.assert_allclose(out.cpu().numpy(), g[f"{kind}_forward_logits"], atol=LOGIT_TOL, rtol=0)
+    with torch.no_grad():
+        t16, l16 = model.bfloat16().generate_batch(images.cuda(), max_len=60, beam_size=3, top_k=20, seed=1)
+    assert tuple(t16.shape) == (2, 60) and int(t16.max()) < 1000
+    bad = getattr(M, kind)(**dict(hp, pad_index=1)).eval().cuda()
+    with pytest.raises(NotImplementedError):
+        bad.generate_batch(images.cuda(), max_len=8, beam_size=1, top_k=1)

@@ -156,3 +156,24 @@ def test_g11_demo_decode_settings(kind):
     ids = R.model_generate(kind, sd, hp, images[:1], max_len=12, beam_size=int(g["beam_size"]), top_k=int(g["top_k"]),
                            temperature=float(g["temperature"]))
     assert ids.reshape(-1).tolist() == g["beam_0"].tolist()
+
+
+@pytest.mark.parametrize("kind", ("CaptioningTransformer", "CaptioningTransformerBase"))
+def test_g12_pad_index(kind):
+    """pad_index = 7 (transformers.py:393-394 accepts any value): nothing of the encoder is masked, and past 49 positions the zero
+    rows the reference pads enc_out with are real keys -- greedy ids at max_len 32 / 60, RNG replay, teacher-forced logits."""
+    g = golden("g12_pad_index.npz")
+    sd, hp = synthetic_sd(kind)
+    hp = dict(hp, pad_index=7)
+    images = synth_images(2, seed=0)
+    for ml in (32, 60):
+        ids = R.model_generate(kind, sd, hp, images[:1], max_len=ml, beam_size=1, top_k=1)
+        assert ids.reshape(-1).tolist() == g[f"{kind}_greedy{ml}_0"].tolist()
+    torch.manual_seed(500)
+    ids = R.model_generate(kind, sd, hp, images[:1], max_len=60, beam_size=3, top_k=20, temperature=1.3)
+    assert ids.reshape(-1).tolist() == g[f"{kind}_beam_0"].tolist()
+    cap, lengths, _ = captions_and_lengths()
+    cap = cap.clone()
+    cap[cap == 0] = 7
+    out = R.model_forward(kind, sd, hp, images, cap[:2], lengths[:2])
+    np.testing.assert_allclose(out.numpy(), g[f"{kind}_forward_logits"], atol=2e-4, rtol=1e-5)
