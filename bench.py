@@ -321,7 +321,7 @@ def host_inclusive(model, n_local, steps):
                 pass
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            res[name] = {"value": n_local * steps / dt, "unit": "captions/s", "ms_per_step": dt / steps * 1e3}
+            res[name] = {"value": n_local * steps / dt, "unit": "captions/s", "ms_per_step": dt / steps * 1e3, "batches": steps}
         out[form] = res
     out["note"] = ("images start in pinned host memory, ids end in pinned host memory; pipelined = H2D copy and encoder of batch "
                    "i+1 on their own HIP streams while batch i decodes")
@@ -390,7 +390,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
         res["hipgraph_replay"] = {"value": n_total * steps / tg, "unit": "captions/s", "ms_per_step": tg / steps * 1e3}
     if world == 1 and not args.quick:
         with torch.no_grad():
-            res["host_inclusive"] = host_inclusive(model, n_local, max(3, steps // 2))
+            res["host_inclusive"] = host_inclusive(model, n_local, max(10, steps))    # enough batches for the pipeline's steady state
     if rank == 0 and with_cpu:
         # the parity gate is the fp32 path: bit-exact greedy ids vs the CPU reference path -- timed here too
         if dtype == "f32":

@@ -49,9 +49,10 @@ class CaptionPipeline:
         else:
             self.copy_s = self.enc_s = self.dec_s = torch.cuda.current_stream(self.dev)
         self._dev_in = {}            # (slot, shape, dtype) -> device staging tensor (double-buffered)
-        self._host_out = {}          # (slot, shape) -> pinned (tokens, lengths) pair (double-buffered like _dev_in)
+        self._host_out = {}          # (slot, shape) -> pinned (tokens, lengths) pair, three slots used in turn
         self._slot = 0
         self._out_slot = 0
+        self._slot_reader = {}       # staging slot -> event recorded after the encoder that read it
 
     # -- stages ------------------------------------------------------------------------------------------------------
     def _stage(self, host_inputs):
@@ -59,6 +60,9 @@ class CaptionPipeline:
         tensors pass through."""
         slot, out = self._slot, []
         self._slot ^= 1
+        self._last_slot = slot
+        if slot in self._slot_reader:                 # two batches may be in flight: the slot's previous reader must be done
+            self.copy_s.wait_event(self._slot_reader[slot])
         producer = torch.cuda.current_stream(self.dev)
         if self.overlap and any(t.is_cuda for t in host_inputs):
             # a device-resident input may still be being written on the caller's stream (e.g. by preprocess_images): the
@@ -89,6 +93,7 @@ class CaptionPipeline:
             enc = self.model.encode(*staged)
             done = torch.cuda.Event()
             done.record(self.enc_s)
+            self._slot_reader[self._last_slot] = done
         for t in enc:
             t.record_stream(self.dec_s)
         return enc, done
@@ -99,7 +104,7 @@ class CaptionPipeline:
             toks, lens = self.model.decode(enc, seed=seed, img0=img0, **self.gen_kw)
             if to_host:
                 key = (self._out_slot, tuple(toks.shape))
-                self._out_slot ^= 1
+                self._out_slot = (self._out_slot + 1) % 3
                 bufs = self._host_out.get(key)
                 if bufs is None:
                     bufs = self._host_out[key] = (torch.empty(toks.shape, dtype=toks.dtype).pin_memory(),
@@ -114,24 +119,31 @@ class CaptionPipeline:
     # -- driver ------------------------------------------------------------------------------------------------------
     def run(self, batches, seeds=None, img0=0, to_host=True):
         """``batches``: iterable of input tuples (``(images,)`` or ``(images, labels)``), host (ideally pinned) or device
-        tensors.  Yields ``(tokens, lengths)`` per batch, in order; with ``to_host`` they live in one of TWO pinned host
-        buffer pairs used alternately: the pair yielded for batch i is overwritten by batch i+2's copy, so a result may be
-        kept across ONE further iteration, and ``list(pipe.run(...))`` must clone.  All work of a batch has completed
-        when it is yielded."""
+        tensors.  Yields ``(tokens, lengths)`` per batch, in order; with ``to_host`` they live in one of THREE pinned host
+        buffer pairs used in turn.  The decode of batch i+1 is already queued when batch i is yielded (no host round trip between
+        two batches' decode loops), so the pair yielded for batch i is overwritten by batch i+3's copy, which is issued when batch
+        i+1 is yielded: a result may be kept across ONE further iteration, and ``list(pipe.run(...))`` must clone.  All work of a
+        batch has completed when it is yielded."""
         it = iter(batches)
         seeds = iter(seeds) if seeds is not None else None
         cur = next(it, None)
         if cur is None:
             return
         enc, ev = self._encode(*self._stage(cur))
+        pending = None
         while cur is not None:
             nxt = next(it, None)
             if nxt is not None:                      # issue the next batch's copy + encoder BEFORE this batch's decode
                 nxt_enc, nxt_ev = self._encode(*self._stage(nxt))
             seed = next(seeds) if seeds is not None else None
-            toks, lens, done = self._decode(enc, ev, seed, img0, to_host)
-            done.synchronize()
-            yield toks, lens
+            queued = self._decode(enc, ev, seed, img0, to_host)          # asynchronous
+            if pending is not None:                  # the PREVIOUS batch is handed over while this one decodes
+                pending[2].synchronize()
+                yield pending[0], pending[1]
+            pending = queued
             cur = nxt
             if nxt is not None:
                 enc, ev = nxt_enc, nxt_ev
+        if pending is not None:
+            pending[2].synchronize()
+            yield pending[0], pending[1]
