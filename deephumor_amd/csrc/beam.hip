@@ -654,217 +654,6 @@ extern "C" int dh_beam_row_sample_groups(const float* logits, int ldl, int V, co
     DH_LAUNCH_CHECK();
 }
 
-// ---- logits-free variant: candidate groups -> sparse classifier -> compact candidates -----------------------------------------
-// Only the top-k logits of a row matter to the draw, and the k-th largest GROUP maximum bounds them from below, so the [rows, V]
-// logits matrix (187 MB per position at 1,280 rows x 36,541 tokens) never has to exist:
-//   dh_vocab_logits(logits = NULL)  classifier GEMM, epilogue keeps only the maximum of every 64-column group
-//   beam_group_lists_kernel         per row (one wave): exact k-th largest group maximum = the bound; the k (+ ties) groups
-//                                   reaching it get the row's compact slots 0, 1, ... in group order; slot_map[row, g] = slot | 255
-//   vocab_sparse_kernel (gemm_bf16.hip)  per group: scans its slot_map column for the rows that listed it and computes the
-//                                   logits of its 64 columns for exactly those rows -- the same MFMA chain per output as the
-//                                   dense kernel, so bit-identical values
-//   beam_row_sample_compact_kernel  per row (one wave): values >= the bound out of its slots (they come out in token order),
-//                                   exact top-k threshold, softmax, Exp(1) race, log-softmax of the picks -- the arithmetic
-//                                   of row_tail, reduction order included, so the picks equal dh_beam_row_sample's bit for bit
-// No atomics, no barriers (single-wave kernels), nothing to reset between positions.  DH_TOPK_SLOTS slots per row: more
-// qualifying groups (exact ties of group maxima at the bound) or more than TOPK_CAND values >= the bound set
-// DH_BEAM_ERR_TOPK_GROUPS and the caller repeats the step on the dense path.
-#define TOPK_CAND 512
-
-
-// k-th largest of the keys a wave holds (E per lane, key 0 = absent), 1 <= k: the largest T with #(key >= T) >= k
-template <int E>
-__device__ __forceinline__ uint32_t wave_kth_largest(const uint32_t (&key)[E], int k) {
-    uint32_t t = 0u;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t c = t | (1u << bit);
-        int n = 0;
-#pragma unroll
-        for (int e = 0; e < E; ++e) n += key[e] >= c;
-        if (wave_sum_i(n) >= k) t = c;
-    }
-    return t;
-}
-
-__global__ __launch_bounds__(256) void beam_group_lists_kernel(const float* __restrict__ gmax, int gm_ld, int n_groups, int rows,
-                                                                int top_k, int32_t* __restrict__ cand_groups,
-                                                                int32_t* __restrict__ cand_n, uint32_t* __restrict__ cand_bound,
-                                                                uint8_t* __restrict__ slot_map, int sm_ld, int32_t* __restrict__ err) {
-    constexpr int E = 16;                                            // 1024 groups
-    const int rc = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (rc >= rows) return;                                          // wave-uniform
-    uint32_t key[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int g = lane + 64 * e;
-        const uint32_t k = f2key(gmax[(size_t)rc * gm_ld + min(g, n_groups - 1)]);      // clamped: all loads in flight together
-        key[e] = g < n_groups ? k : 0u;
-    }
-    const uint32_t bound = wave_kth_largest<E>(key, min(top_k, n_groups));
-    int base = 0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const int g = lane + 64 * e;
-        if (64 * e < n_groups) {                                     // wave-uniform
-            const bool q = key[e] >= bound && g < n_groups;
-            const uint64_t m = __ballot(q);
-            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            base += __popcll(m);
-            if (g < n_groups) slot_map[(size_t)rc * sm_ld + g] = (q && slot < DH_TOPK_SLOTS) ? (uint8_t)slot : (uint8_t)255;
-            if (q && slot < DH_TOPK_SLOTS) cand_groups[(size_t)rc * DH_TOPK_SLOTS + slot] = g;
-        }
-    }
-    if (lane == 0) {
-        if (base > DH_TOPK_SLOTS) atomicOr(err, DH_BEAM_ERR_TOPK_GROUPS);
-        cand_n[rc] = min(base, DH_TOPK_SLOTS);
-        cand_bound[rc] = bound;
-    }
-}
-
-__global__ __launch_bounds__(256) void beam_row_sample_compact_kernel(
-    const float* __restrict__ cand, const int32_t* __restrict__ cand_groups, const int32_t* __restrict__ cand_n,
-    const uint32_t* __restrict__ cand_bound, int V, int rows, int noise_ld, int rows_per_img, int beam, int top_k, float temperature,
-    int unk, const float* __restrict__ noise, uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step,
-    int32_t* __restrict__ pick_idx, float* __restrict__ pick_val, int32_t* __restrict__ err) {
-    constexpr int E = TOPK_CAND / 64;
-    __shared__ int s_ci[4][TOPK_CAND], s_si[4][TOPK_CAND];
-    __shared__ float s_cv[4][TOPK_CAND], s_sv[4][TOPK_CAND], s_q[4][TOPK_CAND];
-    __shared__ int s_pick[4][DH_BEAM_MAX_BEAMS];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rc = blockIdx.x * 4 + wv;
-    if (rc >= rows) return;                                          // wave-uniform; no block-level barrier below
-    int* ci = s_ci[wv]; int* si = s_si[wv]; float* cv = s_cv[wv]; float* sv = s_sv[wv]; float* qv = s_q[wv]; int* picks = s_pick[wv];
-    const int ng = cand_n[rc];
-    const uint32_t bound = cand_bound[rc];
-    const int my_g = cand_groups[(size_t)rc * DH_TOPK_SLOTS + lane];                   // slot `lane`'s group
-    const float* crow = cand + (size_t)rc * DH_TOPK_SLOTS * 64 + lane;
-    const uint64_t lt = (1ull << lane) - 1ull;
-    // candidates: values >= bound, slot by slot (groups ascending) and column by column: already in token order
-    int n0 = 0;
-    for (int q0 = 0; q0 < ng; q0 += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = crow[(size_t)min(q0 + u, ng - 1) * 64];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (q0 + u < ng) {                                       // wave-uniform
-                const int tok = __builtin_amdgcn_readlane(my_g, (q0 + u) & 63) * 64 + lane;
-                const bool take = tok < V && f2key(v[u]) >= bound;
-                const uint64_t m = __ballot(take);
-                const int p = n0 + __popcll(m & lt);
-                if (take && p < TOPK_CAND) { ci[p] = tok; cv[p] = v[u]; }
-                n0 += __popcll(m);
-            }
-        }
-    }
-    if (n0 > TOPK_CAND) { if (lane == 0) atomicOr(err, DH_BEAM_ERR_TOPK_GROUPS); n0 = TOPK_CAND; }
-    wave_lds_sync();
-    // exact k-th largest among the candidates, then the survivors (>= it, ties kept, unk dropped) -- still in token order
-    uint32_t key[E];
-#pragma unroll
-    for (int e = 0; e < E; ++e) key[e] = lane + 64 * e < n0 ? f2key(cv[lane + 64 * e]) : 0u;
-    const uint32_t thr = wave_kth_largest<E>(key, top_k);
-    int n = 0;
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if (64 * e < n0) {
-            const int i = lane + 64 * e;
-            const bool take = i < n0 && key[e] >= thr && ci[min(i, TOPK_CAND - 1)] != unk;
-            const uint64_t m = __ballot(take);
-            const int p = n + __popcll(m & lt);
-            if (take) { si[p] = ci[i]; sv[p] = cv[i]; }
-            n += __popcll(m);
-        }
-    }
-    wave_lds_sync();
-    if (n == 0) {
-        if (lane == 0) atomicOr(err, DH_BEAM_ERR_ALL_FILTERED);
-        if (lane < beam) { pick_idx[(size_t)rc * beam + lane] = 0; pick_val[(size_t)rc * beam + lane] = 0.f; }
-        return;
-    }
-    // softmax(filtered / T) with row_tail's reduction order: element i belongs to "thread" i % 256 of a 256-thread block --
-    // four 64-lane partial sums through wave_sum, added as ((w0 + w1) + w2) + w3
-    float m = -INFINITY;
-    for (int i = lane; i < n; i += 64) m = fmaxf(m, sv[i] / temperature);
-    m = wave_max(m);
-    float s = 0.f;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        float part = 0.f;
-        for (int i = 64 * c + lane; i < n; i += 256) { const float ex = expf(sv[i] / temperature - m); qv[i] = ex; part += ex; }
-        const float w = wave_sum(part);
-        s = c == 0 ? w : s + w;
-    }
-    const int img = rc / rows_per_img, rin = rc % rows_per_img;
-    for (int i = lane; i < n; i += 64) {
-        const float nz = noise ? noise[(size_t)rc * noise_ld + si[i]]
-                               : philox_exp1(seed ^ (seed_ptr ? *seed_ptr : 0ull), (uint32_t)(img0 + img), (uint32_t)step, 0u, (uint32_t)rin, (uint32_t)si[i]);
-        qv[i] = (qv[i] / s) / nz;
-    }
-    if (lane < DH_BEAM_MAX_BEAMS) picks[lane] = -1;
-    wave_lds_sync();
-    for (int i = lane; i < n; i += 64) {
-        const float me = qv[i];
-        int r = 0;
-        for (int j = 0; j < n; ++j) r += (qv[j] > me) || (qv[j] == me && j < i);
-        if (r < beam) picks[r] = i;
-    }
-    wave_lds_sync();
-    // log_softmax over the gathered (un-tempered) logits of the picks (beam.py:79): lane b owns pick b
-    if (lane == 0 && n < beam) atomicOr(err, DH_BEAM_ERR_TOO_FEW);
-    const int pi = lane < beam ? picks[lane] : -1;
-    const float lv = pi >= 0 ? sv[pi] : -INFINITY;
-    const float mx = wave_max(lv);
-    const float se = wave_sum(pi >= 0 ? expf(lv - mx) : 0.f);
-    const float lse = logf(se);
-    if (lane < beam) {
-        pick_idx[(size_t)rc * beam + lane] = pi >= 0 ? si[pi] : 0;
-        pick_val[(size_t)rc * beam + lane] = pi >= 0 ? (lv - mx) - lse : -INFINITY;
-    }
-}
-
-extern "C" int dh_beam_group_lists(const float* group_max, int gm_ld, int n_groups, int rows, int top_k, int32_t* cand_groups,
-                                   int32_t* cand_n, uint32_t* cand_bound, uint8_t* slot_map, int sm_ld, int32_t* err, void* stream) {
-    DH_REQUIRE(group_max && cand_groups && cand_n && cand_bound && slot_map && err && rows > 0);
-    DH_REQUIRE(n_groups > 0 && n_groups <= 1024 && gm_ld >= n_groups && sm_ld >= n_groups && top_k >= 1 && top_k <= n_groups &&
-               top_k <= DH_TOPK_SLOTS);
-    DhProfScope prof("dh_beam_group_lists", 0.0, 5.0 * rows * n_groups, stream);
-    hipLaunchKernelGGL(beam_group_lists_kernel, dim3(dh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, group_max, gm_ld, n_groups,
-                       rows, top_k, cand_groups, cand_n, cand_bound, slot_map, sm_ld, err);
-    DH_LAUNCH_CHECK();
-}
-
-extern "C" int dh_beam_row_sample_compact(const float* cand_logits, const int32_t* cand_groups, const int32_t* cand_n,
-                                          const uint32_t* cand_bound, int V, int rows, int rows_per_img, int beam, int top_k,
-                                          float temperature, int unk_index, const float* noise, int noise_ld, uint64_t seed,
-                                          const uint64_t* seed_ptr, int img0, int step, int32_t* pick_idx, float* pick_val,
-                                          int32_t* err, void* stream) {
-    DH_REQUIRE(cand_logits && cand_groups && cand_n && cand_bound && pick_idx && pick_val && err && rows > 0);
-    DH_REQUIRE(rows_per_img > 0 && V > 0 && (!noise || noise_ld >= V));
-    DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && top_k <= DH_TOPK_SLOTS && temperature > 0.f);
-    DhProfScope prof("dh_beam_row_sample", 0.0, 0.0, stream);
-    hipLaunchKernelGGL(beam_row_sample_compact_kernel, dim3(dh_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, cand_logits,
-                       cand_groups, cand_n, cand_bound, V, rows, noise_ld, rows_per_img, beam, top_k, temperature, unk_index, noise,
-                       seed, seed_ptr, img0, step, pick_idx, pick_val, err);
-    DH_LAUNCH_CHECK();
-}
-
-// classifier + row draw of one decode position without the logits matrix (the four launches above, one host call)
-extern "C" int dh_vocab_topk_sample(const void* A, int lda, const void* W, int ldw, const float* bias, int rows, int V, int K,
-                                    const dh_topk_scratch_t* sc, int rows_per_img, int beam, int top_k, float temperature,
-                                    int unk_index, const float* noise, int noise_ld, uint64_t seed, const uint64_t* seed_ptr,
-                                    int img0, int step, int32_t* pick_idx, float* pick_val, int32_t* err, int dtype, void* stream) {
-    DH_REQUIRE(sc && sc->group_max && sc->cand_logits && sc->slot_map && rows > 0 && rows <= sc->rows_cap);
-    const int n_groups = dh_cdiv(V, 64);
-    DH_TRY(dh_vocab_logits(A, lda, W, ldw, bias, nullptr, 0, sc->group_max, sc->gm_ld, rows, V, K, dtype, stream));
-    DH_TRY(dh_beam_group_lists(sc->group_max, sc->gm_ld, n_groups, rows, top_k, sc->cand_groups, sc->cand_n, sc->cand_bound,
-                               sc->slot_map, sc->sm_ld, err, stream));
-    DH_TRY(dh_vocab_sparse_logits(A, lda, W, ldw, bias, sc->slot_map, sc->sm_ld, rows, sc->cand_logits, n_groups, V, K, dtype, stream));
-    return dh_beam_row_sample_compact(sc->cand_logits, sc->cand_groups, sc->cand_n, sc->cand_bound, V, rows, rows_per_img, beam,
-                                      top_k, temperature, unk_index, noise, noise_ld, seed, seed_ptr, img0, step, pick_idx, pick_val,
-                                      err, stream);
-}
-
 extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,
                                   int top_k, float temperature, int unk_index, const float* noise,
                                   uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* pick_idx, float* pick_val,

@@ -1415,129 +1415,6 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
 }
 
 
-// ---- sparse classifier: the logits of one 64-column group for exactly the rows that listed it ---------------------------------
-// Third stage of dh_vocab_topk_sample (beam.hip).  Workgroup (g, y) = 8 waves.  It scans column g of slot_map (one byte per
-// row: the row's compact slot for this group, 255 = the row did not list it) into an LDS entry list, stages the group's
-// 64 x K weight slice once in LDS (8 KB per 64-deep k-slab, the XOR-swizzled 128-byte rows of the dense kernels), and then a
-// wave takes 16 entries at a time: lane (l15, lq) gathers the k-chunks of entry l15's activation row straight from global
-// memory as the MFMA's second operand and runs, per output, the dense kernel's chain acc = mfma(W frag, A frag, acc) over
-// k = 0, 32, 64, ...: the same instruction on the same operand slots in the same order, so cand[entry, c] is bit-identical to
-// the logit dh_vocab_logits would have stored.  y = 0 / 1 take alternate runs of 8 slices, so a group that nearly every
-// row lists (frequent tokens) is spread over 16 waves; a workgroup whose share of the list is empty leaves after the scan.
-template <typename T>
-__global__ __launch_bounds__(512) void vocab_sparse_kernel(const T* __restrict__ A, int lda, const T* __restrict__ W, int ldw,
-                                                            const float* __restrict__ bias, const uint8_t* __restrict__ slot_map,
-                                                            int sm_ld, int rows, float* __restrict__ cand, int V, int K) {
-    __shared__ __attribute__((aligned(16))) unsigned char wlds[8 * 8192];
-    __shared__ int elist[2048];
-    __shared__ int ccount[32];                                      // listed rows per 64-row chunk (rows <= 2048)
-    const int g = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // entry list in row order (both workgroups of a group must see the same list): chunk c = rows 64 c .. 64 c + 63 belongs to
-    // wave c % 8; counts -> barrier -> exclusive prefix -> ordered write
-    int slv[4];
-    uint64_t msk[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int r = (it * 8 + wave) * 64 + lane;
-        slv[it] = r < rows ? slot_map[(size_t)min(r, rows - 1) * sm_ld + g] : 255;
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        msk[it] = __ballot(slv[it] != 255);
-        if (lane == 0) ccount[it * 8 + wave] = __popcll(msk[it]);
-    }
-    __syncthreads();
-    int cnt = 0;
-    {
-        const int mine = lane < 32 ? ccount[lane] : 0;
-        int offs[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            const int v = __builtin_amdgcn_readlane(mine, c);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) offs[it] += c < it * 8 + wave ? v : 0;
-            cnt += v;
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it)
-            if (slv[it] != 255)
-                elist[offs[it] + __popcll(msk[it] & ((1ull << lane) - 1ull))] = ((it * 8 + wave) * 64 + lane) * DH_TOPK_SLOTS + slv[it];
-    }
-    __syncthreads();
-    const int first = blockIdx.y * 8 + wave;                        // this wave's slices: first, first + 16, ...
-    if (cnt <= blockIdx.y * 128) return;                            // block-uniform
-    const int nslab = K / 64;                                       // host: K % 64 == 0, K <= 512
-    {
-        const int lr = lane >> 3, lpos = lane & 7;
-        for (int sl = wave; sl < nslab; sl += 8)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int n = min(g * 64 + 8 * i + lr, V - 1);      // columns past V: finite garbage nobody reads
-                dh_lds_dma16(reinterpret_cast<const uint16_t*>(W) + (size_t)n * ldw + sl * 64 + (lpos ^ lr) * 8, wlds + sl * 8192 + i * 1024);
-            }
-    }
-    const int l15 = lane & 15, lq = lane >> 4;
-    float4 b4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = g * 64 + 16 * j + 4 * lq;
-        b4[j].x = bias ? bias[min(n, V - 1)] : 0.f; b4[j].y = bias ? bias[min(n + 1, V - 1)] : 0.f;
-        b4[j].z = bias ? bias[min(n + 2, V - 1)] : 0.f; b4[j].w = bias ? bias[min(n + 3, V - 1)] : 0.f;
-    }
-    // the first slice's activation fragments are requested before the wait for the weight slice
-    uint4 af[16];
-    int ent = 0;
-    bool valid = false;
-    auto gather = [&](int sidx) {
-        const int e = sidx * 16 + l15;
-        valid = e < cnt;
-        ent = elist[min(e, max(cnt - 1, 0))];
-        const uint16_t* arow = reinterpret_cast<const uint16_t*>(A) + (size_t)(ent / DH_TOPK_SLOTS) * lda;
-#pragma unroll
-        for (int t = 0; t < 16; ++t) af[t] = *reinterpret_cast<const uint4*>(arow + 32 * min(t, 2 * nslab - 1) + 8 * lq);
-    };
-    if (first * 16 < cnt) gather(first);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the weight pieces (LDS-DMA is invisible to the compiler's waits)
-    __builtin_amdgcn_s_barrier();
-    for (int sidx = first; sidx * 16 < cnt; sidx += 16) {
-        dh_f32x4 acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            if (t < 2 * nslab) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int rr = 16 * j + l15;
-                    const uint4 wf = *reinterpret_cast<const uint4*>(wlds + (t >> 1) * 8192 + rr * 128 + ((((t & 1) * 4 + lq) ^ (rr & 7)) << 4));
-                    acc[j] = Op16<T>::mfma(wf, af[t], acc[j]);      // acc[j][r] = logit[entry l15][column 16 j + 4 lq + r]
-                }
-            }
-        }
-        if (valid) {
-            float* dst = cand + (size_t)ent * 64 + 4 * lq;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                *reinterpret_cast<float4*>(dst + 16 * j) = make_float4(acc[j][0] + b4[j].x, acc[j][1] + b4[j].y, acc[j][2] + b4[j].z, acc[j][3] + b4[j].w);
-        }
-        if ((sidx + 16) * 16 < cnt) gather(sidx + 16);
-    }
-}
-
-extern "C" int dh_vocab_sparse_logits(const void* A, int lda, const void* W, int ldw, const float* bias, const uint8_t* slot_map,
-                                      int sm_ld, int rows, float* cand_logits, int n_groups, int V, int K, int dtype, void* stream) {
-    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
-    DH_REQUIRE(A && W && slot_map && cand_logits && n_groups > 0 && rows > 0 && rows <= 2048 && V > 0 && sm_ld >= n_groups);
-    DH_REQUIRE((long long)n_groups * 64 >= V && (K % 64) == 0 && K >= 128 && K <= 512 && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K);
-    DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)W % 16) == 0 && ((uintptr_t)cand_logits % 16) == 0);
-    dh_prof_set_tag("vocab-sparse");
-    DhProfScope prof("dh_linear", 0.0, 0.0, stream);
-    DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_sparse_kernel<T>), dim3(n_groups, rows > 128 ? 2 : 1), dim3(512), 0, (hipStream_t)stream,
-                                             (const T*)A, lda, (const T*)W, ldw, bias, slot_map, sm_ld, rows, cand_logits, V, K));
-    DH_LAUNCH_CHECK();
-}
 
 // ---- teacher-forced scoring without materialising the logits --------------------------------------------------------
 // logp[m] = log_softmax(A[m,:] W^T + bias)[targets[m]]: the classifier GEMM leaves per (row, 64-column group) the maximum

@@ -12,10 +12,9 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 11
+ABI_VERSION = 12
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
-ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW, ERR_TOPK_GROUPS = 1, 2, 4, 8
-TOPK_SLOTS = 64
+ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 16
 
 _c = ctypes
@@ -38,12 +37,6 @@ class TrModel(_c.Structure):
 
 class TrScratch(_c.Structure):
     _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2")]
-
-
-class TopkScratch(_c.Structure):
-    """``dh_topk_scratch_t``: buffers of the logits-free decode classifier (``vocab_topk_sample``)."""
-    _fields_ = [("group_max", _P), ("gm_ld", _I), ("cand_groups", _P), ("cand_n", _P), ("cand_bound", _P),
-                ("slot_map", _P), ("sm_ld", _I), ("cand_logits", _P), ("rows_cap", _I), ("_pad", _I)]
 
 
 class LnFold(_c.Structure):
@@ -124,10 +117,6 @@ SIGNATURES = {
                             _I, _P, _I, _P, _I, _P],
     "dh_vocab_logprob": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "dh_beam_group_lists": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P],
-    "dh_vocab_sparse_logits": [_P, _I, _P, _I, _P, _P, _I, _I, _P, _I, _I, _I, _I, _P],
-    "dh_beam_row_sample_compact": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _U64, _P, _I, _I, _P, _P, _P, _P],
-    "dh_vocab_topk_sample": [_P, _I, _P, _I, _P, _I, _I, _I, _P, _I, _I, _I, _F, _I, _P, _I, _U64, _P, _I, _I, _P, _P, _P, _I, _P],
     "dh_beam_step_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P,
                             _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
@@ -758,44 +747,6 @@ def vocab_logprob(a, w, bias, targets):
     _launch("dh_vocab_logprob", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(targets.contiguous()), _ptr(logp),
             _ptr(scratch[0]), _ptr(scratch[1]), _ptr(tgt), ng, m, v, k, _dt(a), _stream())
     return logp
-
-
-class TopkBuffers:
-    """Device buffers of the logits-free decode classifier for up to ``rows_cap`` rows of a ``v``-token vocabulary
-    (``dh_topk_scratch_t``): 64-column group maxima, per-row candidate-group lists, the row x group slot map and the compact
-    candidate logits (``rows_cap * 64 * 64`` fp32 = 21 MB at 1,280 rows, against 187 MB of full logits)."""
-
-    def __init__(self, rows_cap, v, device):
-        ng = (v + 63) // 64
-        i32 = dict(dtype=torch.int32, device=device)
-        self.rows_cap, self.v, self.n_groups = rows_cap, v, ng
-        self.group_max = torch.empty((rows_cap, n_groups(v)), device=device)
-        self.cand_groups = torch.zeros((rows_cap * TOPK_SLOTS,), **i32)
-        self.cand_n = torch.empty((rows_cap,), **i32)
-        self.cand_bound = torch.empty((rows_cap,), **i32)
-        self.slot_map = torch.empty((rows_cap, (ng + 63) // 64 * 64), dtype=torch.uint8, device=device)
-        self.cand_logits = torch.empty((rows_cap * TOPK_SLOTS * 64,), device=device)
-        self.struct = TopkScratch(self.group_max.data_ptr(), self.group_max.stride(0), self.cand_groups.data_ptr(),
-                                  self.cand_n.data_ptr(), self.cand_bound.data_ptr(), self.slot_map.data_ptr(),
-                                  self.slot_map.stride(0), self.cand_logits.data_ptr(), rows_cap, 0)
-
-
-def topk_supported(dtype, v, k, top_k, rows=1):
-    """Can ``vocab_topk_sample`` serve a classifier with ``k`` inputs over ``v`` tokens at this ``top_k``?"""
-    # (8 slots of headroom for group maxima that tie exactly at the bound; beyond that the step reports ERR_TOPK_GROUPS)
-    return (dtype in HALF_DTYPES and top_k is not None and 0 < top_k <= min(TOPK_SLOTS - 8, (v + 63) // 64) and (v + 63) // 64 <= 1024
-            and k % 64 == 0 and 128 <= k <= 512 and rows <= 2048)
-
-
-def vocab_topk_sample(a, w, bias, buf, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step,
-                      pick_idx, pick_val, err, seed_ptr=None):
-    """Classifier + per-row draw of one decode position without the logits matrix: see include/deephumor_hip.h."""
-    _dev(a, w, bias, noise, pick_idx, pick_val, err)
-    rows, k = a.shape
-    assert rows <= buf.rows_cap and w.shape[0] == buf.v
-    _launch("dh_vocab_topk_sample", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), rows, buf.v, k, _c.byref(buf.struct),
-            rows_per_img, beam, top_k, float(temperature), unk_index, _ptr(noise), noise.stride(0) if noise is not None else 0, seed,
-            _ptr(seed_ptr), img0, step, _ptr(pick_idx), _ptr(pick_val), _ptr(err), _dt(a), _stream())
 
 
 def beam_row_sample_groups(logits, v, group_max, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed,

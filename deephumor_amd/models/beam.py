@@ -147,9 +147,6 @@ class BeamSearchHelper:
         if code & hip.ERR_OVERFLOW:
             raise RuntimeError("more than 1024 logits of a row tie at its top-k threshold (DH_BEAM_MAX_SURVIVORS); "
                                "the reference would sample among all of them")
-        if code & hip.ERR_TOPK_GROUPS:
-            raise RuntimeError("logits-free classifier: more than 64 column groups or 512 logits reach a row's top-k bound "
-                               "(DH_BEAM_ERR_TOPK_GROUPS); repeat the step on the dense path (dh_vocab_logits + dh_beam_row_sample_groups)")
         if code & hip.ERR_TOO_FEW:
             raise RuntimeError("fewer positive-probability tokens than beams (top_k == beam_size with <unk> in the top-k)")
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 11
+#define DH_ABI_VERSION 12
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -36,10 +36,7 @@ enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weig
 /* device-side error bits OR-ed into the `err` word of the beam kernels */
 enum { DH_BEAM_ERR_ALL_FILTERED = 1,   /* every logit filtered (-inf): reference raises RuntimeError, beam.py:46 */
        DH_BEAM_ERR_OVERFLOW = 2,       /* more than DH_BEAM_MAX_SURVIVORS logits tie at the top-k threshold */
-       DH_BEAM_ERR_TOO_FEW = 4,        /* fewer positive-probability tokens than beams */
-       DH_BEAM_ERR_TOPK_GROUPS = 8 };  /* logits-free classifier only: more than DH_TOPK_SLOTS column groups reach the k-th
-                                          largest group maximum (exact ties) -- repeat the step with dh_vocab_logits */
-#define DH_TOPK_SLOTS 64                /* 64-logit slots per row of the compact candidate buffer (dh_vocab_topk_sample) */
+       DH_BEAM_ERR_TOO_FEW = 4 };      /* fewer positive-probability tokens than beams */
 #define DH_BEAM_MAX_SURVIVORS 1024
 #define DH_BEAM_MAX_BEAMS 16
 
@@ -224,7 +221,7 @@ int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bi
 /* Vocabulary projection feeding beam search (bf16 operands): logits [M,V] fp32 = A*W^T + bias, and
  * group_max[m, g] = max(logits[m, 64g .. 64g+63]) for g < 2*ceil(V/128) (row stride gm_ld) -- the pre-filter
  * dh_beam_row_sample_groups uses to read only the ~top_k column groups that can hold a top-k logit.
- * logits == NULL: only the group maxima are produced (K % 64 == 0, K >= 128) -- first stage of dh_vocab_topk_sample. */
+ * logits == NULL: only the group maxima are produced (K % 64 == 0, K >= 128) (teacher-forced scoring, probes). */
 int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float* bias, float* logits, int ldl,
                     float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream);
 
@@ -373,45 +370,6 @@ int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_p
 int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, const float* bias, const int64_t* targets, float* logp,
                      float* group_max, float* group_sum, float* target_logit, int gm_ld, int M, int V, int K, int dtype,
                      void* stream);
-
-/* ---- decode classifier without the [rows, V] logits matrix (16-bit dtypes) ----------------------------------------------------
- * The draw of beam.py:32-48 needs only a row's top-k logits, and the k-th largest of the row's 64-column GROUP maxima bounds
- * them from below: exactly the k (+ exact ties) groups reaching that bound can hold one.  So per position
- *   1. dh_vocab_logits(logits = NULL)      group maxima only (no 4*rows*V bytes of logits written or re-read);
- *   2. dh_beam_group_lists                 per row: bound = k-th largest group maximum (exact); the groups reaching it take
- *                                          the row's compact slots 0, 1, ... in group order -> cand_groups[row, slot],
- *                                          cand_n[row], cand_bound[row], slot_map[row, g] = slot (255: not listed);
- *   3. dh_vocab_sparse_logits              per group: cand_logits[row, slot, 0..63] = A[row] . W[64g + c] + bias for the rows
- *                                          whose slot_map lists g -- the same MFMA chain per output as dh_vocab_logits, i.e.
- *                                          bit-identical values;
- *   4. dh_beam_row_sample_compact          per row: picks exactly as dh_beam_row_sample on the full row (same reduction order).
- * dh_vocab_topk_sample issues the four.  A row with more than DH_TOPK_SLOTS qualifying groups (exact ties of group maxima at
- * the bound) or more than 512 logits >= its bound ORs DH_BEAM_ERR_TOPK_GROUPS into err (its picks are then undefined): the
- * caller repeats the step on dh_vocab_logits + dh_beam_row_sample_groups.
- * Requirements: top_k <= DH_TOPK_SLOTS, top_k <= ceil(V/64) <= 1024, K % 64 == 0, 128 <= K <= 512, rows <= min(rows_cap, 2048).
- * No atomics on global memory, nothing to reset between positions.  noise (tests only) is indexed [row * noise_ld + token]. */
-typedef struct dh_topk_scratch {
-    float* group_max; int gm_ld;            /* [rows_cap, gm_ld >= 2*ceil(V/128)] */
-    int32_t* cand_groups;                   /* [rows_cap * DH_TOPK_SLOTS] */
-    int32_t* cand_n;                        /* [rows_cap] */
-    uint32_t* cand_bound;                   /* [rows_cap] order-preserving key of the row's bound */
-    uint8_t* slot_map; int sm_ld;           /* [rows_cap, sm_ld >= ceil(V/64)] */
-    float* cand_logits;                     /* [rows_cap * DH_TOPK_SLOTS * 64] */
-    int rows_cap; int _pad;
-} dh_topk_scratch_t;
-int dh_beam_group_lists(const float* group_max, int gm_ld, int n_groups, int rows, int top_k, int32_t* cand_groups,
-                        int32_t* cand_n, uint32_t* cand_bound, uint8_t* slot_map, int sm_ld, int32_t* err, void* stream);
-int dh_vocab_sparse_logits(const void* A, int lda, const void* W, int ldw, const float* bias, const uint8_t* slot_map, int sm_ld,
-                           int rows, float* cand_logits, int n_groups, int V, int K, int dtype, void* stream);
-int dh_beam_row_sample_compact(const float* cand_logits, const int32_t* cand_groups, const int32_t* cand_n,
-                               const uint32_t* cand_bound, int V, int rows, int rows_per_img, int beam, int top_k,
-                               float temperature, int unk_index, const float* noise, int noise_ld, uint64_t seed,
-                               const uint64_t* seed_ptr, int img0, int step, int32_t* pick_idx, float* pick_val, int32_t* err,
-                               void* stream);
-int dh_vocab_topk_sample(const void* A, int lda, const void* W, int ldw, const float* bias, int rows, int V, int K,
-                         const dh_topk_scratch_t* scratch, int rows_per_img, int beam, int top_k, float temperature,
-                         int unk_index, const float* noise, int noise_ld, uint64_t seed, const uint64_t* seed_ptr, int img0,
-                         int step, int32_t* pick_idx, float* pick_val, int32_t* err, int dtype, void* stream);
 
 /* Same contract as dh_beam_row_sample, guided by the column-group maxima of dh_vocab_logits: the k-th largest
  * group maximum bounds the k-th largest logit from below, so only groups whose maximum reaches it are read. */

@@ -191,61 +191,6 @@ def test_vocab_logits_group_max_and_guided_sampling(hip, v, beam, top_k, rows, p
     np.testing.assert_allclose(out[0][1].numpy(), out[1][1].numpy(), atol=1e-6)
 
 
-@pytest.mark.parametrize("rows", [37, 300, 1280])
-@pytest.mark.parametrize("v,beam,top_k,k", [(36541, 5, 50, 512), (1000, 3, 16, 128), (4000, 7, 50, 256), (36541, 16, 56, 512)])
-def test_logits_free_classifier_matches_dense_path(hip, v, beam, top_k, k, rows):
-    """dh_vocab_topk_sample (group maxima -> candidate groups -> sparse classifier -> compact draw) never writes the
-    [rows, V] logits, and picks token for token, value for value, what dh_vocab_logits + the full-row sampler pick; the
-    compact candidate logits are bit-identical to the dense ones."""
-    a, w, b = bf(rnd(rows, k, seed=1)).cuda(), (bf(rnd(v, k, seed=2) * 0.12)).cuda(), rnd(v, seed=3).cuda()
-    logits = torch.empty(rows, (v + 63) // 64 * 64, device="cuda")[:, :v]
-    gmax = torch.empty((rows, hip.n_groups(v)), device="cuda")
-    hip.vocab_logits(a, w, b, logits, gmax)
-    noise = torch.ones(rows, logits.stride(0))
-    noise[:, :v] = torch.empty(rows, v).exponential_(1, generator=torch.Generator().manual_seed(5))
-    noise = noise.cuda()
-
-    def outs():
-        return (torch.empty(rows, beam, dtype=torch.int32, device="cuda"), torch.empty(rows, beam, device="cuda"),
-                torch.zeros(1, dtype=torch.int32, device="cuda"))
-    pi0, pv0, err0 = outs()
-    hip.beam_row_sample(logits, v, rows, 1, beam, top_k, 1.1, 1, noise, 0, 0, 0, pi0, pv0, err0)
-    buf = hip.TopkBuffers(rows + 3, v, "cuda")
-    assert hip.topk_supported(a.dtype, v, k, top_k)
-    for rep in range(2):                                   # (nothing to reset between positions)
-        pi1, pv1, err1 = outs()
-        hip.vocab_topk_sample(a, w, b, buf, 1, beam, top_k, 1.1, 1, noise, 0, 0, 0, pi1, pv1, err1)
-        assert int(err1.item()) == int(err0.item()) == 0
-        assert torch.equal(pi0, pi1)
-        assert torch.equal(pv0, pv1)
-    assert torch.equal(buf.group_max[:rows], gmax)
-    # every candidate slot holds the dense logits of its group
-    n = buf.cand_n[:rows].cpu().numpy()
-    assert (n >= min(top_k, buf.n_groups)).all() and (n <= hip.TOPK_SLOTS).all()
-    groups = buf.cand_groups.view(-1, hip.TOPK_SLOTS)[:rows].cpu().numpy()
-    cand = buf.cand_logits.view(-1, hip.TOPK_SLOTS, 64)[:rows].cpu().numpy()
-    dense = np.full((rows, buf.n_groups * 64), -np.inf, np.float32)
-    dense[:, :v] = logits.cpu().numpy()
-    for r in (0, rows // 2, rows - 1):
-        for sl in range(n[r]):
-            g = groups[r, sl]
-            width = min(64, v - g * 64)
-            assert np.array_equal(cand[r, sl, :width], dense[r, g * 64:g * 64 + width]), (r, sl, g)
-
-
-def test_logits_free_classifier_flags_tied_group_maxima(hip):
-    """More than DH_TOPK_SLOTS groups tying at the k-th largest group maximum cannot be served from the compact
-    buffer: the step reports DH_BEAM_ERR_TOPK_GROUPS (the caller repeats it on the dense path)."""
-    rows, v, k = 9, 36541, 512
-    a, w = bf(rnd(rows, k, seed=1)).cuda(), torch.zeros(v, k).to(HALF).cuda()
-    b = torch.full((v,), 0.25).cuda()
-    buf = hip.TopkBuffers(rows, v, "cuda")
-    pi, pv = torch.empty(rows, 5, dtype=torch.int32, device="cuda"), torch.empty(rows, 5, device="cuda")
-    err = torch.zeros(1, dtype=torch.int32, device="cuda")
-    hip.vocab_topk_sample(a, w, b, buf, 1, 5, 50, 1.0, 1, None, 0, 0, 0, pi, pv, err)
-    assert int(err.item()) & hip.ERR_TOPK_GROUPS
-
-
 def test_vocab_logits_without_bias(hip):
     """bias = NULL through every classifier kernel that stages a bias strip by LDS-DMA (A-stationary K = 512 default, the tile
     kernel for K != 512, the group-maxima-only form): the strip comes from the zero page, never from address 0."""
