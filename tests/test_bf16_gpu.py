@@ -527,6 +527,35 @@ def test_fused_bottleneck_tail(hip, n, h, w, c):
     np.testing.assert_allclose(got.float().cpu().numpy(), want.numpy(), **tol)
 
 
+@pytest.mark.parametrize("h,w", [(224, 224), (192, 256), (256, 256), (160, 224)])
+def test_encoder_16bit_other_image_sizes(h, w):
+    """The 16-bit encoder at image sizes where the shape-specialised kernels do NOT apply (stage 3 is not 14 x 14: no one-image
+    tail; stages 1-2 are not 56 / 28 wide: no patch-resident 3x3) falls back to the general kernels: embedding close to the fp32
+    path's, and at 224 x 224 identical with and without the specialised kernels switched off (they are bit-identical by design)."""
+    import os
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import synth_state_dict
+    enc = M.ImageEncoder(256, spatial_features=True).eval()
+    enc.load_state_dict(synth_state_dict(enc.state_dict(), seed=1234))
+    x = rnd(3, 3, h, w, seed=h + w).cuda()
+    with torch.no_grad():
+        emb32, sp32 = enc.cuda()(x)
+        e16 = enc.to(HALF)
+        emb16, sp16 = e16(x)
+        assert emb16.shape == emb32.shape and sp16.shape == sp32.shape == (3, (h // 32) * (w // 32), 256)
+        tol = 0.12 if HALF == torch.bfloat16 else 0.02
+        assert float((emb16.float() - emb32).abs().max()) < tol * max(1.0, float(emb32.abs().max()))
+        if (h, w) == (224, 224):
+            saved = {k: os.environ.get(k) for k in ("DH_NO_S3_TAIL", "DH_NO_FUSED_TAIL", "DH_NO_DIRECT_3X3")}
+            try:
+                os.environ.update(DH_NO_S3_TAIL="1", DH_NO_FUSED_TAIL="1", DH_NO_DIRECT_3X3="1")
+                emb_g, sp_g = e16(x)
+            finally:
+                for k, v in saved.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            assert torch.equal(emb_g, emb16) and torch.equal(sp_g, sp16)
+
+
 @pytest.mark.parametrize("n", [1, 3, 9])
 def test_stage3_bottleneck_tail(hip, n):
     """dh_bottleneck_tail_s3_nhwc (14 x 14 x 256 -> 1024: one image per workgroup, patch-resident 3x3, weights streamed into
