@@ -252,7 +252,9 @@ def timed_region(step_fn, steps, world, device):
     barrier, wall time = MAX over ranks (one all_reduce).  Returns ``(seconds, last result of step_fn)``.  Used by every
     workload; ``tests/test_dist_cpu.py`` drives it over gloo with a stubbed step."""
     import torch.distributed as dist
-    multi = world > 1 and dist.is_available() and dist.is_initialized()
+    # (a one-rank process group counts when DH_DIST_ALWAYS is set: --rccl-single runs the barriers / the max-reduction / the
+    #  all_gather on RCCL with one rank, the only RCCL run a one-GPU box allows)
+    multi = (world > 1 or os.environ.get("DH_DIST_ALWAYS", "0") not in ("", "0")) and dist.is_available() and dist.is_initialized()
     cuda = torch.device(device).type == "cuda"
 
     def fence():
@@ -577,6 +579,8 @@ def main(argv=None):
                     "profiler of the roofline line needs real launches, so the roofline then comes from the instrumented pass)")
     ap.add_argument("--dtype", choices=["bf16", "f16", "f32"], default=None,
                     help="storage/MFMA operand type of the measured path (BASELINE configs C2-C4: bf16, C5: fp16)")
+    ap.add_argument("--rccl-single", action="store_true", help="with --gpus 1: create the RCCL process group anyway (one rank) and run the "
+                    "barriers, the max-reduction and the per-batch all_gather of the N > 1 path through it")
     ap.add_argument("--stub", action="store_true", help="CPU/gloo control-flow test of the multi-rank path (model stubbed; not a measurement)")
     args = ap.parse_args(argv)
     if args.dtype is None:
@@ -598,7 +602,11 @@ def main(argv=None):
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     n_ranks_seen = 1
-    if world > 1:
+    single_pg = args.rccl_single and world == 1 and not args.stub
+    if single_pg:
+        os.environ["DH_DIST_ALWAYS"] = "1"
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or single_pg:
         import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -611,9 +619,15 @@ def main(argv=None):
     def finish(line):
         line["n_ranks_seen"] = n_ranks_seen          # what the process group itself reports (RCCL saw N ranks)
         line["ranks_launched_by"] = launched_by
+        if single_pg:
+            line["rccl_single_rank"] = "process group 'nccl' (RCCL) with one rank: barrier, all_reduce(MAX) and all_gather_into_tensor ran through it"
         if rank == 0:
+            # RCCL writes a version banner through C stdio at communicator creation; piped, that buffer would only be flushed at
+            # exit -- AFTER the JSON line.  Flush it first so that the JSON line is the last line of stdout.
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
             print(json.dumps(line), flush=True)
-        if world > 1:
+        if world > 1 or single_pg:
             import torch.distributed as dist
             dist.barrier()
             dist.destroy_process_group()

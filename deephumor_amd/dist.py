@@ -8,6 +8,8 @@ token ids and lengths (64 KB per rank at 256 x 32) -- never per decode step.  Th
 stochastic beam search is keyed by the GLOBAL image index (``img0``), so captions do not depend on
 the world size.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -22,11 +24,21 @@ def shard_range(n_total, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_captions(tokens, lengths, n_total, group=None):
+def _skip_collective(group, always):
+    """A single rank has nothing to exchange: the collective is skipped unless ``always`` (or ``DH_DIST_ALWAYS=1``) asks for it --
+    which is how the RCCL path is exercised on a one-GPU box (``bench.py --rccl-single``, ``tests/test_dist_gpu.py``)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return True
+    if always is None:
+        always = os.environ.get("DH_DIST_ALWAYS", "0") not in ("", "0")
+    return dist.get_world_size(group) == 1 and not always
+
+
+def gather_captions(tokens, lengths, n_total, group=None, always=None):
     """``tokens [n_local, T]`` int64, ``lengths [n_local]`` -> the full ``[n_total, T]`` / ``[n_total]``
     on every rank, in global image order.  One ``all_gather_into_tensor`` on shards padded to the
     largest shard (uneven shards differ by at most one image)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _skip_collective(group, always):
         return tokens, lengths
     world = dist.get_world_size(group)
     t = tokens.shape[1]
@@ -44,21 +56,21 @@ def gather_captions(tokens, lengths, n_total, group=None):
     return full[:, :t].contiguous(), full[:, t].contiguous()
 
 
-def generate_sharded(generate_fn, n_total, group=None):
+def generate_sharded(generate_fn, n_total, group=None, always=None):
     """Runs ``generate_fn(lo, hi) -> (tokens, lengths)`` on this rank's shard (``lo`` is the global
     index of its first image: pass it as ``img0``) and gathers the whole batch on every rank."""
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     lo, hi = shard_range(n_total, rank, world)
     tokens, lengths = generate_fn(lo, hi)
-    return gather_captions(tokens, lengths, n_total, group)
+    return gather_captions(tokens, lengths, n_total, group, always)
 
 
-def gather_rows(x, n_total, group=None):
+def gather_rows(x, n_total, group=None, always=None):
     """``x [n_local, ...]`` (any dtype: logits, log-probabilities, perplexities) -> ``[n_total, ...]`` on every
     rank in global row order: the north star's "all-gather of logits" -- one ``all_gather_into_tensor`` per call on
     shards padded to the largest one (contiguous ``shard_range`` shards)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if _skip_collective(group, always):
         return x
     world = dist.get_world_size(group)
     cap = -(-n_total // world)
@@ -73,11 +85,11 @@ def gather_rows(x, n_total, group=None):
     return torch.cat(rows, 0)
 
 
-def score_sharded(score_fn, n_total, group=None):
+def score_sharded(score_fn, n_total, group=None, always=None):
     """Teacher-forced scoring sharded by caption batch: ``score_fn(lo, hi) -> [hi - lo, ...]`` (e.g. per-caption
     perplexities from ``experiments.scoring.score_captions`` on captions ``lo..hi``) on this rank's contiguous
     shard, then one all-gather so that every rank holds all ``n_total`` rows."""
     rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
     world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
     lo, hi = shard_range(n_total, rank, world)
-    return gather_rows(score_fn(lo, hi), n_total, group)
+    return gather_rows(score_fn(lo, hi), n_total, group, always)

@@ -146,3 +146,23 @@ def test_bench_rejects_mismatched_world_size(monkeypatch, capfd):
     monkeypatch.setenv("RANK", "0")
     assert bench.main(["--gpus", "2", "--stub"]) == 2
     assert "WORLD_SIZE=4" in capfd.readouterr().err
+
+
+def _single_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1, timeout=datetime.timedelta(seconds=120))
+    calls = []
+    real = dist.all_gather_into_tensor
+    dist.all_gather_into_tensor = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    t0, l0 = generate_sharded(_fake_generate, 5)                       # one rank: nothing to exchange, no collective
+    n0 = len(calls)
+    t1, l1 = generate_sharded(_fake_generate, 5, always=True)          # the collective runs anyway (bench.py --rccl-single)
+    ret[0] = (n0, len(calls), torch.equal(t0, t1) and torch.equal(l0, l1))
+    dist.destroy_process_group()
+
+
+def test_single_rank_collective_only_on_request():
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_single_worker, args=(1, _free_port(), ret), nprocs=1, join=True)
+        assert ret[0] == (0, 1, True)

@@ -24,6 +24,7 @@ done
 cp $R/gpurun_out/pmc_sq/*.csv $OUT/ 2>/dev/null
 python3 $R/bench.py > $OUT/bench_default_bf16.json 2> /dev/null
 python3 $R/bench.py --workload c5 --steps 5 > $OUT/bench_c5_f16.json 2> /dev/null
+python3 $R/bench.py --workload c2 --steps 20 --warmup 5 --quick --rccl-single 2> /dev/null | tail -1 > $OUT/bench_c2_rccl_single_rank.json
 python3 $R/bench.py --workload score-c2 --steps 3 > $OUT/bench_score_c2.json 2> /dev/null
 python3 $R/bench.py --workload score-c3 --steps 3 > $OUT/bench_score_c3.json 2> /dev/null
 ls -la $OUT
