@@ -118,15 +118,21 @@ class BeamSearchHelper:
                         first_sets_ended, write_pos, t, step_index, self.temperature, self.eos_index, noise,
                         self.seed, self.img0, seed_ptr=self.seed_tensor)
 
-    def finalize(self, len_bias_done, full_len, pad_index=0, defer_check=False):
+    def finalize(self, len_bias_done, full_len, pad_index=0, defer_check=False, first_beam=False):
         """Final draw among the beams and output copy; returns (tokens int64 [n_img, max_len], lengths).
         ``defer_check``: skip the host read of the device error word (hipGraph capture) -- the caller checks
-        ``self.err`` after replay."""
+        ``self.err`` after replay.  ``first_beam``: no draw, beam 0 -- what the reference's final
+        ``sample_k_indices(sample_val, k=1)`` degenerates to when ``sample_val`` is still the ``[beam, 1]`` column of the
+        first step (rnn_models.py:93, 140-141: no decode step ran because the prefix already fills ``max_len - 1``)."""
         out = torch.empty((self.n_img, self.max_len), dtype=torch.int32, device=self.device)
         out_len = torch.empty((self.n_img,), dtype=torch.int32, device=self.device)
+        if first_beam:                 # the kernel's race p / noise with an infinite handicap on every beam but the first
+            noise = torch.full((self.n_img, self.beam_size), float("inf"), dtype=torch.float32, device=self.device)
+            noise[:, 0] = 1.0
+        else:
+            noise = self._noise("final", 0, (self.n_img, self.beam_size))
         hip.beam_finalize(self.tokens, self.vals, self.done, self.end_step, out, out_len, self.n_img, self.beam_size,
-                          len_bias_done, full_len, pad_index, self.temperature,
-                          self._noise("final", 0, (self.n_img, self.beam_size)), self.seed, self.img0,
+                          len_bias_done, full_len, pad_index, self.temperature, noise, self.seed, self.img0,
                           seed_ptr=self.seed_tensor)
         if defer_check:
             return out.long(), out_len.long(), self.err

@@ -131,7 +131,8 @@ class CaptioningLSTM(_CaptioningBase):
 
     def generate(self, image, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
-        return self._one(*self.generate_batch(image, caption, max_len, temperature, beam_size, top_k, eos_index, **kw))
+        return self.decoder.single_output(*self.generate_batch(image, caption, max_len, temperature, beam_size, top_k, eos_index, **kw),
+                                          caption, max_len, beam_size)
 
 
 class CaptioningLSTMWithLabels(_CaptioningBase):
@@ -160,8 +161,8 @@ class CaptioningLSTMWithLabels(_CaptioningBase):
 
     def generate(self, image, label, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):
-        return self._one(*self.generate_batch(image, label, caption, max_len, temperature, beam_size, top_k,
-                                              eos_index, **kw))
+        return self.decoder.single_output(*self.generate_batch(image, label, caption, max_len, temperature, beam_size, top_k,
+                                                               eos_index, **kw), caption, max_len, beam_size)
 
 
 class _TransformerHP:

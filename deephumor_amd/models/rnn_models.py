@@ -192,7 +192,8 @@ class LSTMDecoder(_Planned, nn.Module):
                 yield
                 if early_stop_every and (i - pos) % early_stop_every == 0 and bool(helper.done.all()):
                     break                                   # finished images are frozen by dh_beam_select: nothing left to do
-            return helper.finalize(len_bias_done=1, full_len=max_len, defer_check=defer_check)
+            # (no decode step when the prefix fills max_len - 1: the reference then returns beam 0 -- see finalize)
+            return helper.finalize(len_bias_done=1, full_len=max_len, defer_check=defer_check, first_beam=pos + 1 >= max_len)
 
         return run_interleaved(session, image_emb.shape[0], streams)
 
@@ -202,4 +203,14 @@ class LSTMDecoder(_Planned, nn.Module):
         1-D int64 token tensor."""
         toks, lens = self.generate_batch(image_emb, caption=caption, max_len=max_len, temperature=temperature,
                                          beam_size=beam_size, top_k=top_k, eos_index=eos_index, **kw)
-        return toks[0, :int(lens[0])].squeeze()
+        return self.single_output(toks, lens, caption, max_len, beam_size)
+
+    @staticmethod
+    def single_output(toks, lens, caption, max_len, beam_size):
+        """Row 0 of ``generate_batch``'s result in the shape the reference's single-image ``generate`` returns."""
+        seq = toks[0, :int(lens[0])]
+        if (0 if caption is None else caption.shape[1]) + 1 >= max_len:
+            # no decode step ran: the reference indexes ``sample_seq`` with the [beam, 1] result of its final draw on the
+            # [beam, 1] scores of the first step (rnn_models.py:140-141) and returns ``beam_size`` copies of beam 0's row
+            seq = seq.unsqueeze(0).repeat(beam_size, 1)
+        return seq.squeeze()

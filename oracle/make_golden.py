@@ -335,8 +335,34 @@ def main():
     print("wrote", OUT)
 
 
+def edge_goldens():
+    """G13: ``generate`` when the prefix already fills ``max_len - 1`` positions.  LSTMDecoder.generate's loop
+    (rnn_models.py:103) then runs zero times and the final draw (:140-141) is taken on the [beam, 1] scores of the first step:
+    a [beam, 1] index tensor of zeros, so ``sample_seq[ind, :].squeeze()`` is ``beam_size`` copies of beam 0's row -- a 2-D
+    result (1-D for beam_size = 1 or a single column).  The Transformer's loop (transformers.py:546) always runs once more
+    (its last step is discarded), so it returns the usual 1-D caption.  Found by tools/fuzz_generate.py."""
+    torch.set_num_threads(8)
+    images = synth_images(1, seed=0)
+    cap, _, _ = captions_and_lengths(V_SMALL)
+    rec = {}
+    for kind in ("CaptioningLSTM", "CaptioningTransformer"):
+        model = build(kind, V_SMALL)
+        for name, kw in (("prefix5_len6_beam3", dict(caption=cap[:1, :5], max_len=6, beam_size=3, top_k=20, temperature=1.3)),
+                         ("prefix5_len6_beam1", dict(caption=cap[:1, :5], max_len=6, beam_size=1, top_k=20, temperature=1.3)),
+                         ("noprefix_len1_beam3", dict(max_len=1, beam_size=3, top_k=20, temperature=1.3)),
+                         ("prefix1_len2_beam5", dict(caption=cap[:1, :1], max_len=2, beam_size=5, top_k=5, temperature=0.8))):
+            torch.manual_seed(600)
+            with torch.no_grad():
+                out = model.generate(images, **kw)
+            rec[f"{kind}_{name}"] = out.numpy()
+            print(kind, name, tuple(out.shape), out.reshape(-1)[:12].tolist())
+    np.savez_compressed(os.path.join(OUT, "g13_no_decode_step.npz"), **rec)
+
+
 if __name__ == "__main__":
-    if sys.argv[1:] == ["r3"]:
+    if sys.argv[1:] == ["edge"]:
+        edge_goldens()
+    elif sys.argv[1:] == ["r3"]:
         round3_goldens()
         pad_index_goldens()
     elif sys.argv[1:] == ["pad"]:

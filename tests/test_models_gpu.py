@@ -431,3 +431,41 @@ def test_pad_index_other_than_zero(kind):
     bad = getattr(M, kind)(**dict(hp, pad_index=1)).eval().cuda()
     with pytest.raises(NotImplementedError):
         bad.generate_batch(images.cuda(), max_len=8, beam_size=1, top_k=1)
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_no_decode_step_edge(kind):
+    """Prefix of max_len - 1 tokens (found by tools/fuzz_generate.py): the reference's LSTM ``generate`` returns beam_size copies of
+    beam 0's row, 2-D (rnn_models.py:103, 140-141); the Transformer its usual 1-D caption.  Shapes and ids vs the reference-recorded
+    G13, fp32 under RNG replay; ``generate_batch`` gives that row; the 16-bit path returns the same shapes."""
+    from test_oracle_golden import G13_CASES
+    import deephumor_amd.models.beam as beam_mod
+    g = golden("g13_no_decode_step.npz")
+    model, _, _ = build(kind)
+    images = synth_images(1, seed=0).cuda()
+    cap, _, _ = captions_and_lengths()
+    for name, kw in G13_CASES:
+        kw = dict(kw)
+        p = kw.pop("prefix")
+        kw["caption"] = cap[:1, :p].cuda() if p else None
+        made = []
+        orig = beam_mod.BeamSearchHelper.__init__
+
+        def spy(self, *a, **k):
+            orig(self, *a, **k)
+            made.append(self)
+
+        beam_mod.BeamSearchHelper.__init__ = spy
+        try:
+            torch.manual_seed(600)
+            with torch.no_grad():
+                ids = model.generate(images, noise_source=_Replay(lambda: made[-1]), **kw)
+        finally:
+            beam_mod.BeamSearchHelper.__init__ = orig
+        want = g[f"{kind}_{name}"]
+        assert tuple(ids.shape) == want.shape and ids.reshape(-1).cpu().tolist() == want.reshape(-1).tolist(), (kind, name)
+        with torch.no_grad():
+            toks, lens = model.generate_batch(images, seed=3, **kw)
+            half = build(kind)[0].to(torch.bfloat16).generate(images, seed=3, **kw)
+        assert int(lens[0]) == kw["max_len"] and tuple(toks.shape) == (1, kw["max_len"])
+        assert tuple(half.shape) == want.shape

@@ -177,3 +177,27 @@ def test_g12_pad_index(kind):
     cap[cap == 0] = 7
     out = R.model_forward(kind, sd, hp, images, cap[:2], lengths[:2])
     np.testing.assert_allclose(out.numpy(), g[f"{kind}_forward_logits"], atol=2e-4, rtol=1e-5)
+
+
+G13_CASES = (("prefix5_len6_beam3", dict(prefix=5, max_len=6, beam_size=3, top_k=20, temperature=1.3)),
+             ("prefix5_len6_beam1", dict(prefix=5, max_len=6, beam_size=1, top_k=20, temperature=1.3)),
+             ("noprefix_len1_beam3", dict(prefix=0, max_len=1, beam_size=3, top_k=20, temperature=1.3)),
+             ("prefix1_len2_beam5", dict(prefix=1, max_len=2, beam_size=5, top_k=5, temperature=0.8)))
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_g13_no_decode_step(kind):
+    """The prefix fills max_len - 1 positions: LSTMDecoder.generate's loop runs zero times and its final draw on the [beam, 1]
+    first-step scores returns beam_size COPIES of beam 0's row (rnn_models.py:103, 140-141) -- shapes and values recorded from
+    the reference; the Transformer runs its (discarded) extra step and returns the usual 1-D caption."""
+    g = golden("g13_no_decode_step.npz")
+    sd, hp = synthetic_sd(kind)
+    images = synth_images(1, seed=0)
+    cap, _, _ = captions_and_lengths()
+    for name, kw in G13_CASES:
+        kw = dict(kw)
+        p = kw.pop("prefix")
+        torch.manual_seed(600)
+        ids = R.model_generate(kind, sd, hp, images, caption=cap[:1, :p] if p else None, **kw)
+        want = g[f"{kind}_{name}"]
+        assert tuple(ids.shape) == want.shape and ids.reshape(-1).tolist() == want.reshape(-1).tolist(), (kind, name)

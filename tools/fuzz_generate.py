@@ -1,0 +1,126 @@
+"""Randomised parity sweep of the DECODERS' ``generate`` on the GPU box: random vocabulary sizes, widths, depths, beam sizes, top_k,
+temperatures, prefixes and encoder lengths -- fp32 HIP path against the oracle (``oracle/ref_path.py``), token for token, with the
+kernels fed the CPU generator's noise in the reference's draw order (the ``_Replay`` schedule of tests/test_models_gpu.py).
+TEST INFRASTRUCTURE (it imports the oracle); the fixed-seed cases that came out of it live in tests/.
+
+    python tools/fuzz_generate.py --trials 300 --seed 1 > gpurun_out/fuzz.jsonl
+"""
+import argparse
+import json
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from deephumor_amd.models import LSTMDecoder, SelfAttentionTransformerDecoder, TransformerDecoder    # noqa: E402
+from deephumor_amd.synth import synth_state_dict                                                       # noqa: E402
+import deephumor_amd.models.beam as beam_mod                                                           # noqa: E402
+from oracle import ref_path as R                                                                       # noqa: E402
+from test_models_gpu import _Replay                                                                    # noqa: E402
+
+
+def replay(fn, seed):
+    made = []
+    orig = beam_mod.BeamSearchHelper.__init__
+
+    def spy(self, *a, **k):
+        orig(self, *a, **k)
+        made.append(self)
+
+    beam_mod.BeamSearchHelper.__init__ = spy
+    try:
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            return fn(_Replay(lambda: made[-1])).reshape(-1).cpu().tolist()
+    finally:
+        beam_mod.BeamSearchHelper.__init__ = orig
+
+
+def one_trial(rng, idx):
+    kind = rng.choice(["lstm", "tfm", "tfm_self"])
+    v = rng.choice([rng.randint(5, 70), rng.randint(71, 700), rng.randint(701, 4000)])
+    beam = rng.choice([1, 2, 3, 5, 7, 10, 16, rng.randint(1, 16)])
+    beam = min(beam, v)
+    top_k = rng.randint(beam, min(v, rng.choice([beam, 20, 50, 100, 300])))
+    top_k = max(top_k, beam)
+    temp = rng.choice([1.0, 1.3, 0.7, rng.uniform(0.4, 2.5)])
+    max_len = rng.randint(2, 24)
+    prefix = rng.choice([0, 0, rng.randint(1, max(1, max_len - 1))])
+    prefix = min(prefix, max_len - 1)
+    logit_std = rng.choice([2.5, 1.0, 4.0])
+    cfg = dict(kind=kind, V=v, beam=beam, top_k=top_k, T=round(temp, 4), max_len=max_len, prefix=prefix, logit_std=logit_std)
+    g = torch.Generator().manual_seed(1000 + idx)
+    cap = torch.randint(4, v, (1, prefix), generator=g) if prefix and v > 4 else None
+    if kind == "lstm":
+        e, h, nl = 8 * rng.randint(1, 40), 8 * rng.randint(1, 72), rng.randint(1, 3)
+        cfg.update(emb=e, hidden=h, layers=nl)
+        dec = LSTMDecoder(v, emb_dim=e, hidden_size=h, num_layers=nl, dropout=0.0)
+    else:
+        heads = rng.choice([1, 2, 4, 8])
+        hid = heads * 8 * rng.randint(1, 8)
+        nl, pf = rng.randint(1, 3), 8 * rng.randint(1, 64)
+        pos = max(max_len, 64)
+        cfg.update(hid=hid, heads=heads, layers=nl, pf=pf)
+        cls = TransformerDecoder if kind == "tfm" else SelfAttentionTransformerDecoder
+        dec = cls(v, hid_dim=hid, n_layers=nl, n_heads=heads, pf_dim=pf, dropout=0.0, pad_index=0, max_len=pos)
+    sd = synth_state_dict(dec.state_dict(), seed=77 + idx, logit_std=logit_std)
+    dec.load_state_dict(sd)
+    dec = dec.cuda().eval()
+    osd = {"decoder." + k: t.clone() for k, t in sd.items()}
+    kw = dict(caption=cap, max_len=max_len, temperature=temp, beam_size=beam, top_k=top_k)
+    seed = 5000 + idx
+    if kind == "lstm":
+        emb = torch.randn(1, 1, cfg["emb"], generator=g)
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            want = R.lstm_decoder_generate(osd, "decoder", emb, **kw).reshape(-1).tolist()
+        capd = cap.cuda() if cap is not None else None
+        got = replay(lambda ns: dec.generate(emb.cuda(), **dict(kw, caption=capd), noise_source=ns), seed)
+    else:
+        start = torch.randn(1, cfg["hid"], generator=g)
+        s_len = rng.choice([49, 49, rng.randint(1, 60)])
+        enc = torch.randn(1, s_len, cfg["hid"], generator=g) if kind == "tfm" else None
+        cfg["enc_len"] = s_len if enc is not None else 0
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            want = R.transformer_generate(osd, "decoder", start, enc, 0, cfg["heads"], **kw).reshape(-1).tolist()
+        capd = cap.cuda() if cap is not None else None
+        if kind == "tfm":
+            got = replay(lambda ns: dec.generate(start.cuda(), enc.cuda(), **dict(kw, caption=capd), noise_source=ns), seed)
+        else:
+            got = replay(lambda ns: dec.generate(start.cuda(), **dict(kw, caption=capd), noise_source=ns), seed)
+    return cfg, want, got
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--first", type=int, default=0, help="index of the first trial (trial i depends only on (seed, i))")
+    args = ap.parse_args()
+    bad = 0
+    for i in range(args.first, args.first + args.trials):
+        rng = random.Random(args.seed * 100003 + i)
+        try:
+            cfg, want, got = one_trial(rng, i)
+        except Exception as e:                  # an unsupported shape must be a clean Python error, never a wrong answer
+            print(json.dumps({"i": i, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
+            bad += 1
+            continue
+        ok = want == got
+        bad += (not ok)
+        rec = {"i": i, "ok": ok, **cfg}
+        if not ok:
+            rec.update(want=want, got=got)
+        print(json.dumps(rec), flush=True)
+    print(json.dumps({"trials": args.trials, "mismatches_or_errors": bad}), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
