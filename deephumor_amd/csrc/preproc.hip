@@ -41,16 +41,25 @@ extern "C" int dh_resize_u8_hwc(const uint8_t* src, uint8_t* tmp, uint8_t* dst, 
     hipStream_t s = (hipStream_t)stream;
     auto grid = [](size_t total) { return (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536); };
     const uint8_t* cur = src;
-    if (Win != Wout) {            // horizontal pass first, 8-bit intermediate (Pillow's order)
-        uint8_t* out = Hin != Hout ? tmp : dst;
-        const size_t total = (size_t)N * Hin * Wout * C;
-        hipLaunchKernelGGL(resize_pass_kernel, dim3(grid(total)), dim3(256), 0, s, cur, out, bounds_x, kx, ksize_x, Win, Wout, C, (size_t)N * Hin);
+    int h_cur = Hin;
+    // PIL/Image.py, Image.resize: `if self.size[1] > self.size[0] * 100 and size[1] < self.size[1]` -- an image more than 100 x taller
+    // than wide whose height shrinks is resized VERTICALLY first (8-bit intermediate [N,Hout,Win,C]), everything else horizontally first
+    if (Hin > 100 * Win && Hout < Hin && Win != Wout) {
+        const size_t total = (size_t)N * Hout * Win * C;
+        hipLaunchKernelGGL(resize_pass_kernel, dim3(grid(total)), dim3(256), 0, s, cur, tmp, bounds_y, ky, ksize_y, Hin, Hout, Win * C, (size_t)N);
+        cur = tmp;
+        h_cur = Hout;
+    }
+    if (Win != Wout) {            // horizontal pass, 8-bit intermediate (Pillow's order)
+        uint8_t* out = h_cur != Hout ? tmp : dst;
+        const size_t total = (size_t)N * h_cur * Wout * C;
+        hipLaunchKernelGGL(resize_pass_kernel, dim3(grid(total)), dim3(256), 0, s, cur, out, bounds_x, kx, ksize_x, Win, Wout, C, (size_t)N * h_cur);
         cur = out;
     }
-    if (Hin != Hout) {
+    if (h_cur != Hout) {
         const size_t total = (size_t)N * Hout * Wout * C;
         hipLaunchKernelGGL(resize_pass_kernel, dim3(grid(total)), dim3(256), 0, s, cur, dst, bounds_y, ky, ksize_y, Hin, Hout, Wout * C, (size_t)N);
-    } else if (Win == Wout) {
+    } else if (Win == Wout && Hin == Hout) {
         if (hipMemcpyAsync(dst, src, (size_t)N * Hin * Win * C, hipMemcpyDeviceToDevice, s) != hipSuccess) return DH_ERR_LAUNCH;
     }
     DH_LAUNCH_CHECK();

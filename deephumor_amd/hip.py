@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 12
+ABI_VERSION = 13
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 16
@@ -867,7 +867,8 @@ def resize_u8_hwc(x, out_h, out_w, coeff_x, coeff_y):
     assert x.dtype == torch.uint8 and x.is_contiguous() and x.dim() == 4
     n, h, w, c = x.shape
     dst = torch.empty((n, out_h, out_w, c), dtype=torch.uint8, device=x.device)
-    tmp = torch.empty((n, h, out_w, c), dtype=torch.uint8, device=x.device) if (h != out_h and w != out_w) else None
+    tmp = (torch.empty((n * max(h * out_w, out_h * w) * c,), dtype=torch.uint8, device=x.device)      # either pass order (header)
+           if (h != out_h and w != out_w) else None)
     bx, kx = coeff_x if coeff_x is not None else (None, None)
     by, ky = coeff_y if coeff_y is not None else (None, None)
     _launch("dh_resize_u8_hwc", _ptr(x), _ptr(tmp), _ptr(dst), _ptr(bx), _ptr(kx), kx.shape[1] if kx is not None else 0,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 12
+#define DH_ABI_VERSION 13
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -140,7 +140,9 @@ int dh_normalize_u8_hwc(const uint8_t* x, const float* mean, const float* stdv, 
 
 /* transforms.Resize((Hout, Wout)) of the notebook's pipeline (deephumor_demo.ipynb:565) for decoded 8-bit images on device:
  * Pillow's antialiased BILINEAR resample, bit-exact (horizontal pass into the 8-bit intermediate `tmp` [N,Hin,Wout,C], then
- * vertical; 22-bit fixed-point weights, accumulator 2^21 + sum, result clip8(acc >> 22)).  bounds_* [n_out][2] = (first
+ * vertical -- except for images more than 100 x taller than wide whose height shrinks, which PIL/Image.py resizes vertically
+ * first: intermediate [N,Hout,Win,C]; `tmp` must hold N * max(Hin * Wout, Hout * Win) * C bytes; 22-bit fixed-point weights,
+ * accumulator 2^21 + sum, result clip8(acc >> 22)).  bounds_* [n_out][2] = (first
  * source index, count) and k* [n_out][ksize_*] int32 weights come from the host (Pillow's precompute_coeffs in double
  * precision: deephumor_amd.experiments.inference.resize_coefficients); a pass whose sizes agree is skipped.  C <= 8. */
 int dh_resize_u8_hwc(const uint8_t* src, uint8_t* tmp, uint8_t* dst, const int32_t* bounds_x, const int32_t* kx, int ksize_x,

@@ -10,7 +10,11 @@ from PIL import Image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = {"small": (37, 53, 24, 24), "down": (375, 500, 224, 224), "down_odd": (641, 479, 224, 224), "up": (100, 80, 224, 224),
-         "mixed": (300, 150, 224, 224), "same_w": (448, 224, 224, 224)}      # (H_in, W_in, H_out, W_out)
+         "mixed": (300, 150, 224, 224), "same_w": (448, 224, 224, 224),      # (H_in, W_in, H_out, W_out)
+         # more than 100 x taller than wide and shrinking in height: Image.resize goes vertical-first (PIL/Image.py); 801 / 800 x 8
+         # are the two sides of that boundary, tall_grow grows in height and stays horizontal-first
+         "tall_thin": (1275, 9, 224, 224), "tall_801": (801, 8, 50, 40), "tall_800": (800, 8, 50, 40),
+         "tall_wide_out": (1168, 11, 41, 205), "tall_grow": (350, 3, 351, 10), "tall_shrink": (350, 3, 349, 50)}
 
 
 def image(name, h, w):

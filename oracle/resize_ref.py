@@ -11,7 +11,10 @@ Pillow is a third-party dependency absent from /root/reference (requirements.txt
     weights triangle((x - center + 0.5) / max(scale, 1)) normalised to sum 1 (double precision);
   * fixed point: round-half-away weights at 22 fractional bits (PRECISION_BITS = 32 - 8 - 2), accumulator starts at 2^21,
     result = clip(acc >> 22, 0, 255);
-  * two passes, HORIZONTAL first, the intermediate image is 8-bit (rounded), then vertical.
+  * two passes, the intermediate image is 8-bit (rounded): HORIZONTAL first, then vertical -- except that ``Image.resize`` itself
+    (PIL/Image.py, Pillow >= 9.x incl. the 12.2.0 here: ``if self.size[1] > self.size[0] * 100 and size[1] < self.size[1]``) resizes an
+    image more than 100 times taller than wide whose height shrinks VERTICALLY first (two C-level resizes).  Found by
+    tools/fuzz_encoder.py; pinned by the ``tall_*`` cases of the golden (incl. both sides of the 100 x boundary).
 """
 import numpy as np
 
@@ -65,6 +68,9 @@ def _pass(img, bounds, kk, axis):
 def resize_bilinear_u8(img, out_h, out_w):
     """img uint8 [H, W, C] -> uint8 [out_h, out_w, C], bit-identical to PIL.Image.resize((out_w, out_h), BILINEAR)."""
     h, w = img.shape[:2]
+    if h > 100 * w and out_h < h:                   # PIL/Image.py, Image.resize: very tall images shrink vertically first
+        img = _pass(img, *coefficients(h, out_h), axis=0)
+        h = out_h
     if w != out_w:
         img = _pass(img, *coefficients(w, out_w), axis=1)
     if h != out_h:

@@ -1,0 +1,129 @@
+"""Randomised sweep of the decoders' teacher-forced ``forward`` and of ``generate_batch``'s batch invariance on the GPU box.
+
+Per trial, random decoder (as tools/fuzz_generate.py), random batch, ragged lengths, <pad>-filled captions:
+  * fp32 HIP ``forward`` vs the oracle: max |dlogit| (bar: 1e-3, the tolerance of tests/test_models_gpu.py);
+  * bf16 / fp16 ``forward`` vs the fp32 HIP logits: max |dlogit| relative to the logits' standard deviation (reported; widths are
+    multiples of 8 so the 16-bit kernels accept them);
+  * ``generate_batch`` of the whole batch vs one call per row with ``img0 = row`` under the same Philox seed (bit-equal ids), on fp32
+    and on bf16.
+TEST INFRASTRUCTURE (imports the oracle).
+
+    python tools/fuzz_forward.py --trials 200 --seed 1 > gpurun_out/fuzz_fwd.jsonl
+"""
+import argparse
+import json
+import os
+import random
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from deephumor_amd.models import LSTMDecoder, SelfAttentionTransformerDecoder, TransformerDecoder    # noqa: E402
+from deephumor_amd.synth import synth_state_dict                                                       # noqa: E402
+from oracle import ref_path as R                                                                       # noqa: E402
+
+
+def one_trial(rng, idx):
+    kind = rng.choice(["lstm", "tfm", "tfm_self"])
+    v = rng.choice([rng.randint(5, 70), rng.randint(71, 700), rng.randint(701, 4000)])
+    bs = rng.randint(1, 9)
+    cap_len = rng.randint(1, 30)
+    g = torch.Generator().manual_seed(2000 + idx)
+    cap = torch.randint(4, max(v, 5), (bs, cap_len), generator=g).clamp_(max=v - 1)
+    lengths = torch.tensor([rng.randint(1, cap_len + 1) for _ in range(bs)])
+    for b in range(bs):                                   # <pad> beyond each caption, as the reference's collate produces
+        cap[b, max(int(lengths[b]) - 1, 0):] = 0
+    cfg = dict(kind=kind, V=v, bs=bs, cap_len=cap_len, lengths=lengths.tolist())
+    if kind == "lstm":
+        e, h, nl = 8 * rng.randint(1, 40), 8 * rng.randint(1, 72), rng.randint(1, 3)
+        cfg.update(emb=e, hidden=h, layers=nl)
+        make = lambda: LSTMDecoder(v, emb_dim=e, hidden_size=h, num_layers=nl, dropout=0.0)
+        first = torch.randn(bs, e, generator=g)
+        enc = None
+    else:
+        heads = rng.choice([1, 2, 4, 8])
+        hid = heads * 8 * rng.randint(1, 8)
+        nl, pf = rng.randint(1, 3), 8 * rng.randint(1, 64)
+        cfg.update(hid=hid, heads=heads, layers=nl, pf=pf)
+        cls = TransformerDecoder if kind == "tfm" else SelfAttentionTransformerDecoder
+        make = lambda: cls(v, hid_dim=hid, n_layers=nl, n_heads=heads, pf_dim=pf, dropout=0.0, pad_index=0, max_len=64)
+        first = torch.randn(bs, hid, generator=g)
+        s_len = rng.choice([49, 49, rng.randint(1, 60)])
+        enc = torch.randn(bs, s_len, hid, generator=g) if kind == "tfm" else None
+        cfg["enc_len"] = s_len if enc is not None else 0
+    dec = make()
+    sd = synth_state_dict(dec.state_dict(), seed=99 + idx, logit_std=2.5)
+    dec.load_state_dict(sd)
+    osd = {"decoder." + k: t.clone() for k, t in sd.items()}
+    dec = dec.cuda().eval()
+    out = dict(cfg)
+    with torch.no_grad():
+        if kind == "lstm":
+            want = R.lstm_decoder_forward(osd, "decoder", first, cap, lengths)
+            run = lambda m, dt: m(first.cuda().to(dt), cap.cuda(), lengths)
+        elif kind == "tfm":
+            want = R.transformer_forward(osd, "decoder", cap, enc, first, 0, cfg["heads"])
+            run = lambda m, dt: m(cap.cuda(), enc.cuda().to(dt), first.cuda().to(dt))
+        else:
+            want = R.transformer_forward(osd, "decoder", cap, None, first, 0, cfg["heads"])
+            run = lambda m, dt: m(cap.cuda(), first.cuda().to(dt))
+        got = run(dec, torch.float32).float().cpu()
+        out["shape_ok"] = tuple(got.shape) == tuple(want.shape)
+        out["fp32_max_abs"] = float((got - want).abs().max()) if out["shape_ok"] else None
+        std = float(want.std())
+        for name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+            m16 = make()
+            m16.load_state_dict(sd)
+            m16 = m16.cuda().eval().to(dt)
+            g16 = run(m16, dt).float().cpu()
+            out[f"{name}_max_abs_over_std"] = float((g16 - got).abs().max()) / max(std, 1e-6)
+            if name == "bf16":
+                half = m16
+        # batch invariance of generate_batch under Philox (fp32 and bf16)
+        kw = dict(max_len=rng.randint(2, 12), beam_size=min(rng.choice([1, 3, 5, 10]), v), temperature=1.2, seed=7 + idx)
+        kw["top_k"] = min(v, max(kw["beam_size"] + 1, rng.choice([5, 20, 50])))
+        if kw["beam_size"] >= kw["top_k"]:
+            kw["beam_size"] = max(1, kw["top_k"] - 1)
+        out["gen"] = {k: kw[k] for k in ("max_len", "beam_size", "top_k")}
+        for name, m, dt in (("fp32", dec, torch.float32), ("bf16", half, torch.bfloat16)):
+            args = (first.cuda().to(dt),) if enc is None else (first.cuda().to(dt), enc.cuda().to(dt))
+            t_all, l_all = m.generate_batch(*args, **kw)
+            same = True
+            for b in range(bs):
+                a1 = tuple(a[b:b + 1] for a in args)
+                t1, l1 = m.generate_batch(*a1, img0=b, **kw)
+                same &= bool(torch.equal(t1[0], t_all[b]) and torch.equal(l1[0], l_all[b]))
+            out[f"batch_invariant_{name}"] = same
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--first", type=int, default=0)
+    args = ap.parse_args()
+    bad = 0
+    worst = {"fp32_max_abs": 0.0, "bf16_max_abs_over_std": 0.0, "f16_max_abs_over_std": 0.0}
+    for i in range(args.first, args.first + args.trials):
+        rng = random.Random(args.seed * 100003 + i)
+        try:
+            rec = one_trial(rng, i)
+        except Exception as e:
+            print(json.dumps({"i": i, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
+            bad += 1
+            continue
+        ok = rec["shape_ok"] and rec["fp32_max_abs"] < 1e-3 and rec["batch_invariant_fp32"] and rec["batch_invariant_bf16"]
+        bad += (not ok)
+        for k in worst:
+            worst[k] = max(worst[k], rec.get(k) or 0.0)
+        print(json.dumps(dict(i=i, ok=ok, **rec)), flush=True)
+    print(json.dumps({"trials": args.trials, "failures": bad, "worst": worst}), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
