@@ -1240,7 +1240,10 @@ __global__ __launch_bounds__(512, 1) void vocab256_kernel(VocabParams p) {
                 }
                 se += __shfl_xor(se, 16, 64);
                 se += __shfl_xor(se, 32, 64);
-                if (lq == 0 && m < p.M) {
+                // a 256-column tile spans four 64-column groups, the row holds 2 * ceil(V / 128) of them: when the last tile's second
+                // half lies past V its groups do not exist (written unguarded they landed in the NEXT row's first slots -- wrong
+                // scores for V % 256 in 1..128 and for V < 128; found by tools/fuzz_scoring.py)
+                if (lq == 0 && m < p.M && (n0 + wn0) / 64 < p.gmax_ld) {
                     p.gmax[(size_t)m * p.gmax_ld + (n0 + wn0) / 64] = mxv;
                     p.gsum[(size_t)m * p.gmax_ld + (n0 + wn0) / 64] = se;
                 }

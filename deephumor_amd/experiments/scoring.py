@@ -33,7 +33,8 @@ def score_captions(model, template_images, template_index, captions, lengths, la
             tgt = captions[lo:hi]                       # tokens + <eos>, zero padded (datasets.py:72-79, no <bos>)
             inp = tgt[:, :-1]                           # trainer.py:69-73: model(images, captions[:, :-1], lengths)
             dec = model.decoder
-            if feats.dtype in hip.HALF_DTYPES:
+            width = dec.classifier.in_features
+            if feats.dtype in hip.HALF_DTYPES and width % 64 == 0 and width >= 128:       # dh_vocab_logprob's contract; else the logits route
                 # bf16 path: hidden states -> fused classifier + log-softmax gather, the [rows, V] logits never exist
                 if hasattr(dec, "lstm"):
                     hidden, _, _ = dec.hidden_states(emb, inp, None)

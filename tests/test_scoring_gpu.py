@@ -83,3 +83,46 @@ def test_bf16_scoring_from_hidden_states_equals_logits_path(kind):
         want = sequence_perplexity(logits, caps.cuda(), lengths.cuda()).cpu()
     assert torch.allclose(got, want, rtol=2e-3), (got, want)
     assert torch.allclose(got, ref32, rtol=0.25), (got, ref32)
+
+
+@pytest.mark.parametrize("v", (9, 71, 125, 129, 1552, 3451, 36541 - 189 + 5))
+@pytest.mark.parametrize("dt", (torch.bfloat16, torch.float16))
+def test_vocab_logprob_any_vocabulary_size(v, dt):
+    """dh_vocab_logprob at 600 rows (the 256-column-tile form) for vocabularies whose last tile's second half lies past V
+    (V % 256 in 1..128, V < 128: the char-level V = 71) -- found by tools/fuzz_scoring.py: the tile's non-existent groups were
+    written into the next row's slots.  Against fp32 math on the same 16-bit operands, and equal to the 128-column-tile form
+    (fewer than 512 rows) on the rows both see."""
+    from deephumor_amd import hip
+    g = torch.Generator().manual_seed(v)
+    m, k = 600, 192
+    a = torch.randn(m, k, generator=g).to(dt)
+    w = (torch.randn(v, k, generator=g) * (2.5 / k ** 0.5)).to(dt)
+    b = torch.randn(v, generator=g) * 0.5
+    t = torch.randint(0, v, (m,), generator=g)
+    want = torch.nn.functional.linear(a.float(), w.float(), b).double().log_softmax(-1).gather(-1, t[:, None])[:, 0]
+    got = hip.vocab_logprob(a.cuda(), w.cuda(), b.cuda(), t.cuda()).double().cpu()
+    assert bool(torch.isfinite(got).all())
+    assert float((got - want).abs().max()) < (2e-2 if dt == torch.bfloat16 else 3e-3)
+    small = hip.vocab_logprob(a[:300].cuda(), w.cuda(), b.cuda(), t[:300].cuda()).double().cpu()
+    assert float((small - got[:300]).abs().max()) < 1e-5
+
+
+def test_bf16_scoring_falls_back_for_widths_outside_the_fused_kernels_contract():
+    """A 16-bit decoder whose classifier input is not a multiple of 64 (dh_vocab_logprob: K % 64 == 0, K >= 128) is scored
+    through its materialised logits instead of raising."""
+    import deephumor_amd.models as M
+    from deephumor_amd.experiments import score_captions
+    from deephumor_amd.synth import load_synthetic
+    model = load_synthetic(M.CaptioningLSTM(300, emb_dim=64, hidden_size=72, num_layers=1).eval(), seed=5).cuda()
+    templates = synth_images(2, seed=0).cuda()
+    g = torch.Generator().manual_seed(1)
+    caps = torch.randint(6, 300, (5, 8), generator=g)
+    lengths = torch.tensor([8, 4, 6, 8, 2])
+    for r, k in enumerate(lengths.tolist()):
+        caps[r, k - 1] = 3
+        caps[r, k:] = 0
+    tidx = torch.tensor([0, 1, 1, 0, 1]).cuda()
+    with torch.no_grad():
+        ref32 = score_captions(model, templates, tidx, caps.cuda(), lengths.cuda()).cpu()
+        got = score_captions(model.bfloat16(), templates, tidx, caps.cuda(), lengths.cuda()).cpu()
+    assert torch.allclose(got, ref32, rtol=0.25), (got, ref32)

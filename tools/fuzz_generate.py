@@ -94,7 +94,26 @@ def one_trial(rng, idx):
             got = replay(lambda ns: dec.generate(start.cuda(), enc.cuda(), **dict(kw, caption=capd), noise_source=ns), seed)
         else:
             got = replay(lambda ns: dec.generate(start.cuda(), **dict(kw, caption=capd), noise_source=ns), seed)
+    if HALF:
+        # the 16-bit paths on the same configuration: they must run, repeat exactly under the same Philox seed, and emit valid ids
+        # (in range, never <unk>, nothing but <pad> after the reported length)
+        first = (emb,) if kind == "lstm" else ((start, enc) if kind == "tfm" else (start,))
+        for dt in (torch.bfloat16, torch.float16):
+            m16 = dec.to(dt)
+            a16 = tuple(t.cuda().to(dt) for t in first)
+            with torch.no_grad():
+                t1, l1 = m16.generate_batch(*a16, **dict(kw, caption=capd), seed=seed)
+                t2, l2 = m16.generate_batch(*a16, **dict(kw, caption=capd), seed=seed)
+            n = int(l1[0])
+            body = t1[0, prefix:n]
+            ok16 = (torch.equal(t1, t2) and torch.equal(l1, l2) and 1 <= n <= max_len and int(t1.min()) >= 0 and int(t1.max()) < v
+                    and not bool((body == 1).any()) and not bool((t1[0, n:] != 0).any()))
+            cfg[f"ok_{str(dt)[6:]}"] = bool(ok16)
+        dec.float()
     return cfg, want, got
+
+
+HALF = False
 
 
 def main():
@@ -102,7 +121,10 @@ def main():
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--first", type=int, default=0, help="index of the first trial (trial i depends only on (seed, i))")
+    ap.add_argument("--half", action="store_true", help="also run the bf16 / fp16 paths on every configuration (validity + repeatability)")
     args = ap.parse_args()
+    global HALF
+    HALF = args.half
     bad = 0
     for i in range(args.first, args.first + args.trials):
         rng = random.Random(args.seed * 100003 + i)
@@ -112,7 +134,7 @@ def main():
             print(json.dumps({"i": i, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
             bad += 1
             continue
-        ok = want == got
+        ok = want == got and all(v for k, v in cfg.items() if k.startswith("ok_"))
         bad += (not ok)
         rec = {"i": i, "ok": ok, **cfg}
         if not ok:
