@@ -223,7 +223,9 @@ int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bi
 /* Vocabulary projection feeding beam search (bf16 operands): logits [M,V] fp32 = A*W^T + bias, and
  * group_max[m, g] = max(logits[m, 64g .. 64g+63]) for g < 2*ceil(V/128) (row stride gm_ld) -- the pre-filter
  * dh_beam_row_sample_groups uses to read only the ~top_k column groups that can hold a top-k logit.
- * logits == NULL: only the group maxima are produced (K % 64 == 0, K >= 128) (teacher-forced scoring, probes). */
+ * logits == NULL: only the group maxima are produced (K % 64 == 0, K >= 128) (teacher-forced scoring, probes).
+ * The padding of a logits row is SCRATCH: with ldl >= 128 * ceil(V / 128) the 256-row kernel stores whole 128-column panels, i.e.
+ * it writes columns V .. 128 * ceil(V / 128) - 1 of every row too (finite values, never read); nothing outside [M, ldl] is touched. */
 int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float* bias, float* logits, int ldl,
                     float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream);
 
