@@ -31,6 +31,9 @@ def one_trial(rng, idx):
     v = rng.choice([rng.randint(5, 70), rng.randint(71, 700), rng.randint(701, 4000)])
     bs = rng.randint(1, 9)
     cap_len = rng.randint(1, 30)
+    if BIG:                                               # the product's widths and many rows: the large-batch kernel variants
+        bs, cap_len = rng.randint(150, 1400), rng.randint(1, 10)
+        v = rng.choice([rng.randint(71, 3000), rng.randint(3001, 9000)])
     g = torch.Generator().manual_seed(2000 + idx)
     cap = torch.randint(4, max(v, 5), (bs, cap_len), generator=g).clamp_(max=v - 1)
     lengths = torch.tensor([rng.randint(1, cap_len + 1) for _ in range(bs)])
@@ -39,6 +42,8 @@ def one_trial(rng, idx):
     cfg = dict(kind=kind, V=v, bs=bs, cap_len=cap_len, lengths=lengths.tolist())
     if kind == "lstm":
         e, h, nl = 8 * rng.randint(1, 40), 8 * rng.randint(1, 72), rng.randint(1, 3)
+        if BIG:
+            e, h = rng.choice([256, 512]), 512
         cfg.update(emb=e, hidden=h, layers=nl)
         make = lambda: LSTMDecoder(v, emb_dim=e, hidden_size=h, num_layers=nl, dropout=0.0)
         first = torch.randn(bs, e, generator=g)
@@ -47,12 +52,19 @@ def one_trial(rng, idx):
         heads = rng.choice([1, 2, 4, 8])
         hid = heads * 8 * rng.randint(1, 8)
         nl, pf = rng.randint(1, 3), 8 * rng.randint(1, 64)
+        if BIG:
+            heads, hid, nl, pf = 8, 512, rng.randint(1, 2), rng.choice([2048, 1024])
         cfg.update(hid=hid, heads=heads, layers=nl, pf=pf)
         cls = TransformerDecoder if kind == "tfm" else SelfAttentionTransformerDecoder
         make = lambda: cls(v, hid_dim=hid, n_layers=nl, n_heads=heads, pf_dim=pf, dropout=0.0, pad_index=0, max_len=64)
         first = torch.randn(bs, hid, generator=g)
         s_len = rng.choice([49, 49, rng.randint(1, 60)])
         enc = torch.randn(bs, s_len, hid, generator=g) if kind == "tfm" else None
+        if enc is not None:
+            # keep |x| away from the fp16 underflow threshold (6e-8): the reference reads a row with ANY exactly-zero element as
+            # padding (transformers.py:480), so one element flushed to zero by the fp16 cast masks a real encoder position in the
+            # fp16 path only -- one image in ~1,000 at 49 x 512 features showed 0.2 sigma of logit error from that
+            enc = enc + 1e-3 * torch.sign(enc)
         cfg["enc_len"] = s_len if enc is not None else 0
     dec = make()
     sd = synth_state_dict(dec.state_dict(), seed=99 + idx, logit_std=2.5)
@@ -92,7 +104,7 @@ def one_trial(rng, idx):
             args = (first.cuda().to(dt),) if enc is None else (first.cuda().to(dt), enc.cuda().to(dt))
             t_all, l_all = m.generate_batch(*args, **kw)
             same = True
-            for b in range(bs):
+            for b in (range(bs) if bs <= 9 else rng.sample(range(bs), 3)):
                 a1 = tuple(a[b:b + 1] for a in args)
                 t1, l1 = m.generate_batch(*a1, img0=b, **kw)
                 same &= bool(torch.equal(t1[0], t_all[b]) and torch.equal(l1[0], l_all[b]))
@@ -100,12 +112,18 @@ def one_trial(rng, idx):
     return out
 
 
+BIG = False
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--big", action="store_true", help="the product's widths (512) and 150-1400 rows: the large-batch kernel variants")
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--first", type=int, default=0)
     args = ap.parse_args()
+    global BIG
+    BIG = args.big
     bad = 0
     worst = {"fp32_max_abs": 0.0, "bf16_max_abs_over_std": 0.0, "f16_max_abs_over_std": 0.0}
     for i in range(args.first, args.first + args.trials):
