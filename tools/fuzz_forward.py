@@ -109,6 +109,19 @@ def one_trial(rng, idx):
                 t1, l1 = m.generate_batch(*a1, img0=b, **kw)
                 same &= bool(torch.equal(t1[0], t_all[b]) and torch.equal(l1[0], l_all[b]))
             out[f"batch_invariant_{name}"] = same
+        if BIG:
+            # greedy decoding of the whole batch on the fp32 path: sampled rows against the oracle's single-image generate
+            gk = dict(max_len=rng.randint(2, 10), beam_size=1, top_k=1)
+            args = (first.cuda(),) if enc is None else (first.cuda(), enc.cuda())
+            t_all, l_all = dec.generate_batch(*args, **gk)
+            ok = True
+            for b in rng.sample(range(bs), 3):
+                if kind == "lstm":
+                    want_ids = R.lstm_decoder_generate(osd, "decoder", first[b:b + 1, None, :], **gk)
+                else:
+                    want_ids = R.transformer_generate(osd, "decoder", first[b:b + 1], None if enc is None else enc[b:b + 1], 0, cfg["heads"], **gk)
+                ok &= t_all[b, :int(l_all[b])].cpu().tolist() == want_ids.reshape(-1).tolist()
+            out["greedy_rows_equal_oracle"] = bool(ok)
     return out
 
 
@@ -134,7 +147,8 @@ def main():
             print(json.dumps({"i": i, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
             bad += 1
             continue
-        ok = rec["shape_ok"] and rec["fp32_max_abs"] < 1e-3 and rec["batch_invariant_fp32"] and rec["batch_invariant_bf16"]
+        ok = (rec["shape_ok"] and rec["fp32_max_abs"] < 1e-3 and rec["batch_invariant_fp32"] and rec["batch_invariant_bf16"]
+              and rec.get("greedy_rows_equal_oracle", True))
         bad += (not ok)
         for k in worst:
             worst[k] = max(worst[k], rec.get(k) or 0.0)
