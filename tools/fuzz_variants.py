@@ -1,0 +1,95 @@
+"""Randomised equivalence sweep of the ways one batch can be decoded on the GPU box: ``generate_batch`` against the same call with
+``streams`` = 2 / 3 (image sub-batches on concurrent HIP streams), ``early_stop_every`` (host-polled early exit), the captured-hipGraph
+replay (``generate_batch_graphed``, replayed with other images and seeds after capture), a 2-way split with ``img0``, and a
+``save`` / ``from_pretrained`` round trip of the model -- all five model classes, fp32 / bf16 / fp16, random batch sizes, decode
+settings, prefixes, EOS made likely so that images finish at different steps.  Everything must be bit-equal.  TEST INFRASTRUCTURE.
+
+    python tools/fuzz_variants.py --trials 60 > gpurun_out/fuzz_var.jsonl
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import tempfile
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import deephumor_amd.models as M                          # noqa: E402
+from deephumor_amd.synth import load_synthetic, synth_images           # noqa: E402
+
+KINDS = ("CaptioningLSTM", "CaptioningLSTMWithLabels", "CaptioningTransformerBase", "CaptioningTransformer", "CaptioningTransformerWithLabels")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--trials", type=int, default=40)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = random.Random(args.seed)
+    bad = 0
+    cache = {}
+    for t in range(args.trials):
+        kind = rng.choice([k for k in KINDS if hasattr(M, k)])
+        dt = rng.choice([torch.float32, torch.bfloat16, torch.float16])
+        v = rng.choice([71, 300, 1000])
+        key = (kind, dt, v)
+        if key not in cache:
+            m = load_synthetic(getattr(M, kind)(v).eval(), seed=1234)
+            with torch.no_grad():
+                m.decoder.classifier.bias[3] += rng.choice([0.0, 2.0, 4.0])        # <eos>: images end at different steps
+            cache[key] = m.cuda().to(dt)
+        model = cache[key]
+        n = rng.choice([1, 2, 5, rng.randint(3, 40)])
+        g = torch.Generator().manual_seed(800 + t)
+        images = synth_images(n, seed=t).cuda()
+        extra = (torch.randint(4, v, (n, rng.randint(1, 6)), generator=g).cuda(),) if "WithLabels" in kind else ()
+        beam = rng.choice([1, 3, 5, 10])
+        kw = dict(max_len=rng.randint(2, 14), beam_size=beam, top_k=max(beam + 1, rng.choice([5, 20, 50])), temperature=rng.choice([1.0, 1.3]))
+        kw["top_k"] = min(kw["top_k"], v)
+        if rng.random() < 0.3 and kw["max_len"] > 2:
+            kw["caption"] = torch.randint(4, v, (n, rng.randint(1, kw["max_len"] - 1)), generator=g).cuda()
+        seed = rng.randint(0, 10 ** 6)
+        rec = dict(t=t, kind=kind, dt=str(dt)[6:], V=v, N=n, **{k: (list(x.shape) if torch.is_tensor(x) else x) for k, x in kw.items()})
+        try:
+            with torch.no_grad():
+                base = model.generate_batch(images, *extra, seed=seed, **kw)
+                same = lambda r: bool(torch.equal(r[0], base[0]) and torch.equal(r[1], base[1]))
+                rec["streams"] = same(model.generate_batch(images, *extra, seed=seed, streams=rng.choice([2, 3]), **kw))
+                rec["early_stop"] = same(model.generate_batch(images, *extra, seed=seed, early_stop_every=rng.choice([1, 3]), **kw))
+                if n >= 2:
+                    h = rng.randint(1, n - 1)
+                    cap = kw.get("caption")
+                    k1 = dict(kw, caption=cap[:h]) if cap is not None else kw
+                    k2 = dict(kw, caption=cap[h:]) if cap is not None else kw
+                    a = model.generate_batch(images[:h], *(e[:h] for e in extra), seed=seed, img0=0, **k1)
+                    b = model.generate_batch(images[h:], *(e[h:] for e in extra), seed=seed, img0=h, **k2)
+                    rec["split"] = same((torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])))
+                if t % 3 == 0:
+                    g0 = model.generate_batch_graphed(images, *extra, seed=seed, **kw)               # capture
+                    other = synth_images(n, seed=t + 1000).cuda()
+                    g1 = model.generate_batch_graphed(other, *extra, seed=seed + 1, **kw)           # replay: other images, other seed
+                    want1 = model.generate_batch(other, *extra, seed=seed + 1, **kw)
+                    rec["graph"] = same(g0) and bool(torch.equal(g1[0], want1[0]) and torch.equal(g1[1], want1[1]))
+                    model.__dict__.pop("_graphs", None)                                             # graphs hold their activations
+                if t % 5 == 0:
+                    with tempfile.TemporaryDirectory() as d:
+                        path = os.path.join(d, "m.pth")
+                        model.save(path)
+                        again = type(model).from_pretrained(path).cuda().to(dt).eval()
+                    rec["reload"] = same(again.generate_batch(images, *extra, seed=seed, **kw))
+            ok = all(x for k, x in rec.items() if k in ("streams", "early_stop", "split", "graph", "reload"))
+        except Exception as e:
+            rec["error"], ok = f"{type(e).__name__}: {e}"[:300], False
+        rec["ok"] = bool(ok)
+        bad += (not ok)
+        print(json.dumps(rec), flush=True)
+    print(json.dumps({"trials": args.trials, "failures": bad}), flush=True)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
