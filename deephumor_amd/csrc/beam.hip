@@ -12,9 +12,12 @@
 
 #define CAP DH_BEAM_MAX_SURVIVORS
 
-// order-preserving float -> uint key (larger float <=> larger key)
+// order-preserving float -> uint key (larger float <=> larger key; -0.0 and +0.0 share ONE key, as they compare equal in the
+// reference's `logits < threshold` (beam.py:34): with distinct keys a row whose k-th largest logit is a zero dropped the zeros of the
+// other sign that torch keeps as ties -- found by tools/fuzz_sampler.py on quantised logits)
 __device__ __forceinline__ uint32_t f2key(float f) {
-    const uint32_t u = __float_as_uint(f);
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0u;
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 

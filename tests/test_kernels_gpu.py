@@ -540,3 +540,39 @@ def test_helper_drives_reference_lstm_loop(hip, v, beam, top_k, temp, seed):
     ind = helper.sample_k_indices(sample_val, k=1)
     got = sample_seq[ind, :].squeeze()
     assert got.cpu().tolist() == want.tolist()
+
+
+@pytest.mark.parametrize("v", (61, 5000))
+def test_row_samplers_treat_signed_zeros_as_ties(hip, v):
+    """A row whose top-k threshold is a zero: ``logits < threshold`` (beam.py:34) keeps the zeros of BOTH signs (-0.0 == +0.0); the
+    samplers' integer keys used to order -0.0 below +0.0 and dropped them (found by tools/fuzz_sampler.py)."""
+    g = torch.Generator().manual_seed(v)
+    rows, beam, top_k, temp = 4, 3, 10, 1.3
+    x = -1.0 - torch.rand(rows, v, generator=g)                       # everything else below zero
+    x[:, 2:10] = torch.arange(8, 0, -1).float()                       # eight values above
+    zeros = torch.tensor([0.0, -0.0, 0.0, -0.0, -0.0, 0.0])
+    cols = torch.tensor([11, 17, 23, 29, 40, 55])
+    x[:, cols] = zeros                                                # the 9th..14th largest: top_k = 10 cuts through them (at a +0.0 in key order)
+    noise = torch.empty(rows, v).exponential_(1, generator=g)
+    noise[:, cols[1]] = 1e-6                                          # a -0.0 tie must win the race
+    kept = x.clone()
+    kept[x < x.topk(top_k, dim=-1).values[:, -1:]] = float("-inf")
+    kept[:, 1] = float("-inf")
+    assert int(torch.isfinite(kept).sum(-1).min()) == 14             # 8 + all six zeros
+    want = torch.topk(torch.softmax(kept / temp, -1) / noise, beam, dim=-1).indices
+    assert bool((want[:, 0] == cols[1]).all())
+    ng = hip.n_groups(v)
+    pad = torch.full((rows, ng * 64), float("-inf"))
+    pad[:, :v] = x
+    gmax = pad.view(rows, ng, 64).max(-1).values.cuda()
+    for kind in ("full", "groups"):
+        if kind == "groups" and top_k > ng:
+            continue
+        pi = torch.empty((rows, beam), dtype=torch.int32, device="cuda")
+        pv = torch.empty((rows, beam), device="cuda")
+        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        if kind == "full":
+            hip.beam_row_sample(x.cuda(), v, rows, beam, beam, top_k, temp, 1, noise.cuda(), 0, 0, 0, pi, pv, err)
+        else:
+            hip.beam_row_sample_groups(x.cuda(), v, gmax, rows, beam, beam, top_k, temp, 1, noise.cuda(), 0, 0, 0, pi, pv, err)
+        assert int(err.item()) == 0 and pi.cpu().long().tolist() == want.tolist(), kind
