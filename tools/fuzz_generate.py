@@ -50,6 +50,11 @@ def one_trial(rng, idx):
     top_k = max(top_k, beam)
     temp = rng.choice([1.0, 1.3, 0.7, rng.uniform(0.4, 2.5)])
     max_len = rng.randint(2, 24)
+    if LONG:                                      # long captions: the long-history attention kernels, many ended-beam steps
+        max_len = rng.randint(100, 380)
+        v = rng.randint(5, 300)
+        beam = min(beam, 5, v)
+        top_k = max(beam, min(top_k, v))
     prefix = rng.choice([0, 0, rng.randint(1, max(1, max_len - 1))])
     prefix = min(prefix, max_len - 1)
     logit_std = rng.choice([2.5, 1.0, 4.0])
@@ -64,7 +69,10 @@ def one_trial(rng, idx):
         heads = rng.choice([1, 2, 4, 8])
         hid = heads * 8 * rng.randint(1, 8)
         nl, pf = rng.randint(1, 3), 8 * rng.randint(1, 64)
-        pos = max(max_len, 64)
+        pos = max(max_len + 1, 64)
+        if LONG:
+            heads = rng.choice([1, 2, 4]); hid = heads * 8 * rng.randint(1, 4); nl, pf = rng.randint(1, 2), 8 * rng.randint(1, 16)
+            cfg.update(hid=hid, heads=heads, layers=nl, pf=pf)
         cfg.update(hid=hid, heads=heads, layers=nl, pf=pf)
         cls = TransformerDecoder if kind == "tfm" else SelfAttentionTransformerDecoder
         dec = cls(v, hid_dim=hid, n_layers=nl, n_heads=heads, pf_dim=pf, dropout=0.0, pad_index=0, max_len=pos)
@@ -114,6 +122,7 @@ def one_trial(rng, idx):
 
 
 HALF = False
+LONG = False
 
 
 def main():
@@ -121,10 +130,11 @@ def main():
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--first", type=int, default=0, help="index of the first trial (trial i depends only on (seed, i))")
+    ap.add_argument("--long", action="store_true", help="captions of 100-380 positions on small decoders")
     ap.add_argument("--half", action="store_true", help="also run the bf16 / fp16 paths on every configuration (validity + repeatability)")
     args = ap.parse_args()
-    global HALF
-    HALF = args.half
+    global HALF, LONG
+    HALF, LONG = args.half, args.long
     bad = 0
     for i in range(args.first, args.first + args.trials):
         rng = random.Random(args.seed * 100003 + i)
