@@ -51,3 +51,26 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.dh_maxpool3x3s2(None, None, 1, 1, 4, 4, 7, None) == 2
     assert lib.dh_conv2d_bn_act(None, None, None, None, None, None, 1, 3, 8, 8, 8, 5, 5, 1, 0, 1, hip.F32, None) == 1
     assert lib.dh_beam_row_sample(None, 0, 10, 1, 1, 3, 2, 1.0, 1, None, 0, None, 0, 0, None, None, None, None) == 1
+
+
+def test_every_entry_point_rejects_all_zero_arguments():
+    """Argument contracts are checked before anything is launched: every compute entry point called with NULL pointers and zero
+    sizes returns an error code (no GPU needed, nothing is dereferenced)."""
+    import ctypes
+    from deephumor_amd import hip
+    lib = hip.load()
+    called = 0
+    for name, sig in hip.SIGNATURES.items():
+        if name == "dh_abi_version" or name.endswith("_supported") or name.startswith("dh_prof") or name == "dh_strerror":
+            continue
+        args = []
+        for t in sig:
+            if t in (ctypes.c_float, ctypes.c_double):
+                args.append(0.0)
+            elif isinstance(getattr(t, "_type_", None), type):            # POINTER(struct)
+                args.append(None)
+            else:
+                args.append(0)
+        assert getattr(lib, name)(*args) != 0, name
+        called += 1
+    assert called >= 55
