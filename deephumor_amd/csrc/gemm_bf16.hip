@@ -1383,11 +1383,29 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
             const int tm128 = dh_cdiv(M, 128), tn128 = dh_cdiv(V, 128);
             // round 3: 256-row tiles (32 MFMAs per wave per slab instead of 16) when the rows fill them (DH_VOCAB_AREG=128: never)
             const int tm256 = dh_cdiv(M, 256);
-            if (areg && areg != 128 && logits && K == 512 && M >= 512 && (M % 256) == 0 && ldl >= tn128 * 128 && tm256 <= 32 &&
-                (32 / tm256) * tm256 >= 28 && tn128 >= 8 * (32 / tm256)) {
-                v.tiles_m = tm256; v.tiles_n = tn128;
-                DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg256_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, v));
-                DH_LAUNCH_CHECK();
+            if (areg && areg != 128 && logits && K == 512 && M >= 512 && (M % 256) == 0 && ldl >= tn128 * 128) {
+                // a launch takes `t` row tiles with (32 / t) * t >= 28 of an XCD's 32 CUs busy (t = 1-8, 10, 14-16, 28-32) and
+                // 8 * (32 / t) column groups; more rows than that (batches of 1,024+ images on one GPU) go in several launches --
+                // the rows of a launch only share W, which L2 serves (batch 1,024: 0.24 -> of the tile kernel otherwise)
+                auto fits = [&](int t) { return t >= 1 && t <= 32 && (32 / t) * t >= 28 && tn128 >= 8 * (32 / t); };
+                int plan[64], np = 0, left = tm256;
+                while (left > 0 && np < 64) {
+                    int t = left < 32 ? left : 32;
+                    while (t > 0 && !(fits(t) && (left - t == 0 || left - t >= 2))) --t;   // (never leave a single 256-row tile: M >= 512)
+                    if (t == 0) break;
+                    plan[np++] = t; left -= t;
+                }
+                if (left == 0) {
+                    int row0 = 0;
+                    for (int i = 0; i < np; ++i) {
+                        VocabParams c = v;
+                        c.A = v.A + (size_t)row0 * lda; c.C = v.C + (size_t)row0 * ldl; c.gmax = v.gmax + (size_t)row0 * gm_ld;
+                        c.M = plan[i] * 256; c.tiles_m = plan[i]; c.tiles_n = tn128;
+                        DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_areg256_kernel<T>), dim3(256), dim3(512), 0, (hipStream_t)stream, c));
+                        row0 += plan[i] * 256;
+                    }
+                    DH_LAUNCH_CHECK();
+                }
             }
             if (areg && logits && K == 512 && tm128 <= 32 && (32 / tm128) * tm128 >= 28 && tn128 >= 8 * (32 / tm128)) {
                 v.tiles_m = tm128; v.tiles_n = tn128;

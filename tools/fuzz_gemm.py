@@ -88,7 +88,7 @@ def linear_trial(rng, idx):
 def vocab_trial(rng, idx):
     g = torch.Generator().manual_seed(30000 + idx)
     dt = rng.choice([torch.bfloat16, torch.float16])
-    m = rng.choice([rng.randint(1, 300), 256 * rng.randint(1, 8), 1280, rng.randint(301, 2600), 5 * rng.randint(1, 300)])
+    m = rng.choice([rng.randint(1, 300), 256 * rng.randint(1, 8), 1280, rng.randint(301, 2600), 5 * rng.randint(1, 300), 256 * rng.randint(9, 44)])
     v = rng.choice([rng.randint(2, 200), rng.randint(201, 3000), rng.randint(3001, 12000), rng.randint(12001, 40000), 36541])
     k = rng.choice([512, 512, 512, 256, 64 * rng.randint(2, 10)])
     while m * v > (1 << 26):
