@@ -48,8 +48,10 @@ class CaptionPipeline:
             self.dec_s = torch.cuda.Stream(device=self.dev, priority=-1 if os.environ.get("DH_PIPE_PRIO") else 0)
         else:
             self.copy_s = self.enc_s = self.dec_s = torch.cuda.current_stream(self.dev)
-        self._dev_in = {}            # (slot, shape, dtype) -> device staging tensor (double-buffered)
-        self._host_out = {}          # (slot, shape) -> pinned (tokens, lengths) pair, three slots used in turn
+        # staging buffers, ONE per (slot, input) / output slot: a batch of another shape replaces the slot's buffer (a service fed
+        # images of varying sizes would otherwise keep a device buffer per shape it has ever seen)
+        self._dev_in = {}            # (slot, input index) -> device staging tensor (double-buffered)
+        self._host_out = {}          # output slot -> pinned (tokens, lengths) pair, three slots used in turn
         self._slot = 0
         self._out_slot = 0
         self._slot_reader = {}       # staging slot -> event recorded after the encoder that read it
@@ -75,9 +77,12 @@ class CaptionPipeline:
                         t.record_stream(self.enc_s)
                     out.append(t)
                     continue
-                key = (slot, j, tuple(t.shape), t.dtype)
+                key = (slot, j)
                 buf = self._dev_in.get(key)
-                if buf is None:
+                if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+                    if buf is not None and self.overlap:          # the old buffer may still be read on the side streams
+                        buf.record_stream(self.copy_s)
+                        buf.record_stream(self.enc_s)
                     buf = self._dev_in[key] = torch.empty(t.shape, dtype=t.dtype, device=self.dev)
                 buf.copy_(t, non_blocking=True)
                 out.append(buf)
@@ -103,10 +108,10 @@ class CaptionPipeline:
             self.dec_s.wait_event(ev)
             toks, lens = self.model.decode(enc, seed=seed, img0=img0, **self.gen_kw)
             if to_host:
-                key = (self._out_slot, tuple(toks.shape))
+                key = self._out_slot
                 self._out_slot = (self._out_slot + 1) % 3
                 bufs = self._host_out.get(key)
-                if bufs is None:
+                if bufs is None or bufs[0].shape != toks.shape:    # (a replaced pinned pair stays alive while a consumer holds it)
                     bufs = self._host_out[key] = (torch.empty(toks.shape, dtype=toks.dtype).pin_memory(),
                                                   torch.empty(lens.shape, dtype=lens.dtype).pin_memory())
                 bufs[0].copy_(toks, non_blocking=True)
