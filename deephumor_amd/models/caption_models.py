@@ -51,6 +51,8 @@ class _CaptioningBase(nn.Module):
         ts = list(self.parameters()) + list(self.buffers())
         return tuple(t.data_ptr() for t in ts), tuple(t._version for t in ts)
 
+    MAX_GRAPHS = 4      # captured graphs kept per model (one per (input shapes, decode settings))
+
     def generate_batch_graphed(self, *inputs, seed=None, caption=None, **kw):
         """``generate_batch`` replayed from a captured hipGraph (torch.cuda.CUDAGraph on ROCm).
 
@@ -95,7 +97,11 @@ class _CaptioningBase(nn.Module):
                 out = run()
             sig = self._plan_signature()                  # (the warm-up built the plans)
             plans = [m._get_plan() for m in self.modules() if isinstance(m, _Planned)]     # outlive the graph
+            while len(cache) >= self.MAX_GRAPHS:          # every graph keeps its activations / KV cache allocated: oldest out
+                cache.pop(next(iter(cache)))
             state = cache[key] = (graph, static, scap, seed_t, out, sig, plans)
+        else:
+            cache[key] = cache.pop(key)                   # most recently used last
         graph, static, scap, seed_t, (toks, lens, err) = state[:5]
         for dst, src in zip(static, inputs):
             dst.copy_(src)
