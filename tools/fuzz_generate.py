@@ -144,7 +144,14 @@ def main():
             print(json.dumps({"i": i, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
             bad += 1
             continue
-        ok = want == got and all(v for k, v in cfg.items() if k.startswith("ok_"))
+        ok = want == got
+        if not ok and 3 in want and 3 in got:
+            # known, documented ("Candidates whose probability underflows"): same tokens up to <eos>, only the number of
+            # trailing <pad> zeros differs -- zero-probability candidates are drawn in torch.topk's tie order by the reference
+            e = want.index(3)
+            if want[:e + 1] == got[:e + 1] and not any(want[e + 1:]) and not any(got[e + 1:]):
+                ok, cfg["known"] = True, "trailing <pad> count differs (underflowed candidate probabilities)"
+        ok = ok and all(v for k, v in cfg.items() if k.startswith("ok_"))
         bad += (not ok)
         rec = {"i": i, "ok": ok, **cfg}
         if not ok:
