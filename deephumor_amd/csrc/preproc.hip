@@ -88,3 +88,26 @@ extern "C" int dh_normalize_pack_u8(const uint8_t* x, const float* mean, const f
                                              (T*)y, C, total));
     DH_LAUNCH_CHECK();
 }
+
+// fp32 -> 16-bit rows that keep a NON-ZERO value non-zero: round to nearest even, but a value that underflows to zero in the storage
+// type becomes the smallest subnormal of its sign (fp16: 6e-8; bf16 shares fp32's exponent range, so this only matters for fp32
+// subnormals).  For the encoder's spatial features on the fp16 path: the reference reads an encoder row with ANY exactly-zero element as
+// padding (transformers.py:480), and a feature below 3e-8 would otherwise mask a real image patch (one image in ~1,000).
+template <typename OT>
+__global__ __launch_bounds__(256) void round16_keep_nonzero_kernel(const float* __restrict__ x, uint16_t* __restrict__ y, size_t n) {
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256ull) {
+        const float f = x[i];
+        uint16_t h = Op16<OT>::from_f32(f);
+        if ((h & 0x7FFFu) == 0u && f != 0.f) h |= 1u;
+        y[i] = h;
+    }
+}
+
+extern "C" int dh_round16_keep_nonzero(const float* x, void* y, long long n, int dtype, void* stream) {
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(x && y && n > 0);
+    DhProfScope prof("dh_round16_keep_nonzero", 0.0, 6.0 * (double)n, stream);
+    const int grid = (int)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL((round16_keep_nonzero_kernel<T>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, (size_t)n));
+    DH_LAUNCH_CHECK();
+}

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 13
+ABI_VERSION = 14
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 16
@@ -64,6 +64,7 @@ SIGNATURES = {
     "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
     "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_round16_keep_nonzero": [_P, _P, _c.c_longlong, _I, _P],
     "dh_conv3x3_direct_supported": [_I, _I, _I, _I],
     "dh_conv3x3_direct_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -307,6 +308,15 @@ def pack_nchw_to_nhwc8(x, out_dtype=torch.bfloat16):
     assert x.dtype == torch.float32 and x.is_contiguous()
     out = torch.empty((n, h, w, 8), dtype=out_dtype, device=x.device)
     _launch("dh_pack_nchw_to_nhwc8", _ptr(x), _ptr(out), n, c, h, w, _dt(out), _stream())
+    return out
+
+
+def round16_keep_nonzero(x, out_dtype):
+    """fp32 tensor -> bf16 / fp16 tensor of the same shape, rounding to nearest even but never flushing a non-zero value to zero."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out_dtype in HALF_DTYPES
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _launch("dh_round16_keep_nonzero", _ptr(x), _ptr(out), x.numel(), _dt(out), _stream())
     return out
 
 

@@ -263,8 +263,14 @@ class ImageEncoder(_Planned, nn.Module):
             return emb
         if not plan["bf16"]:
             rows = hip.nchw_to_rows(feats)                                    # [N, k*k, 2048]
-        spatial = hip.linear(rows.reshape(-1, rows.shape[-1]), w, b).view(n, rows.shape[1], -1)
-        return emb, spatial
+        rows2 = rows.reshape(-1, rows.shape[-1])
+        if rows2.dtype == torch.float16:
+            # fp16 underflows below 3e-8 where fp32 / bf16 do not, and TransformerDecoder reads a row with any exactly-zero feature as
+            # padding (transformers.py:480): fp32 out of the GEMM, then a rounding that keeps non-zero values non-zero
+            spatial = hip.round16_keep_nonzero(hip.linear(rows2, w, b, out_dtype=torch.float32), torch.float16)
+        else:
+            spatial = hip.linear(rows2, w, b)
+        return emb, spatial.view(n, rows.shape[1], -1)
 
 
 class LabelEncoder(nn.Module):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 13
+#define DH_ABI_VERSION 14
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -137,6 +137,12 @@ int dh_pack_nchw_to_nhwc8(const float* x, void* y, int N, int C, int H, int W, i
  * torchvision ToTensor + Normalize (deephumor_demo.ipynb:566-567; the resize in front of it: dh_resize_u8_hwc). */
 int dh_normalize_u8_hwc(const uint8_t* x, const float* mean, const float* stdv, float* y, int N, int H, int W, int C,
                         void* stream);
+
+/* fp32 -> 16-bit (round to nearest even) that never turns a non-zero value into zero: a value that underflows in the storage type
+ * becomes the smallest subnormal of its sign.  ImageEncoder's spatial features on the fp16 path go through it, because
+ * TransformerDecoder reads an encoder row with any exactly-zero element as padding (reference transformers.py:480) and fp16
+ * underflows below 3e-8 where fp32 / bf16 do not. */
+int dh_round16_keep_nonzero(const float* x, void* y, long long n, int dtype, void* stream);
 
 /* transforms.Resize((Hout, Wout)) of the notebook's pipeline (deephumor_demo.ipynb:565) for decoded 8-bit images on device:
  * Pillow's antialiased BILINEAR resample, bit-exact (horizontal pass into the 8-bit intermediate `tmp` [N,Hin,Wout,C], then

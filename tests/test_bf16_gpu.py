@@ -684,3 +684,33 @@ def test_self_attention_with_fused_qkv_projection(hip, n_img, beam, t, folded):
         outs.append((out.cpu(), kcd[t].cpu(), vcd[t].cpu(), kcd[t + 1 if t < tmax else 0].cpu()))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
+
+
+def test_round16_keep_nonzero_and_fp16_spatial_features(hip):
+    """dh_round16_keep_nonzero: round to nearest even, but a non-zero fp32 value never becomes zero (smallest subnormal of its sign
+    instead); exact zeros stay zero.  ImageEncoder's fp16 spatial features go through it: the reference's zero-row test
+    (transformers.py:480) must not fire on a feature that merely underflowed in fp16."""
+    x = torch.tensor([0.0, -0.0, 1e-9, -1e-9, 2.9e-8, 3.1e-8, 1.0, -65504.0, 1e-40, 7.3])
+    y = hip.round16_keep_nonzero(x.cuda(), HALF).float().cpu()
+    want = x.to(HALF).float()
+    tiny = (want == 0) & (x != 0)
+    sub = 2.0 ** -24 if HALF == torch.float16 else 2.0 ** -133
+    assert bool((y[~tiny] == want[~tiny]).all()) and bool((y[tiny].abs() == sub).all()) and bool((torch.sign(y[tiny]) == torch.sign(x[tiny])).all())
+    big = torch.randn(100_003, generator=torch.Generator().manual_seed(1)) * 1e-7
+    yb = hip.round16_keep_nonzero(big.cuda(), HALF).float().cpu()
+    assert bool((yb != 0).all()) and float((yb - big).abs().max()) <= 6e-8
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import synth_state_dict
+    enc = M.ImageEncoder(256, spatial_features=True).eval()
+    enc.load_state_dict(synth_state_dict(enc.state_dict(), seed=1234))
+    calls = []
+    real = hip.round16_keep_nonzero
+    hip.round16_keep_nonzero = lambda t, dt: (calls.append(tuple(t.shape)), real(t, dt))[1]
+    try:
+        with torch.no_grad():
+            e16 = enc.cuda().to(HALF)
+            _, sp = e16(rnd(2, 3, 64, 64, seed=3).cuda())
+    finally:
+        hip.round16_keep_nonzero = real
+    assert sp.dtype == HALF and tuple(sp.shape) == (2, 4, 256)
+    assert calls == ([(8, 256)] if HALF == torch.float16 else [])       # the fp16 path rounds its spatial features through it
