@@ -435,7 +435,8 @@ int dh_beam_filter_top_k(float* logits, int ldl, int V, int rows, int top_k, int
 /* sample_k_indices (beam.py:39-48): out[r, 0..k) int64 = torch.multinomial(softmax(x[r] / temperature), k) without replacement
  * == the k largest of p / Exp(1) noise in descending order (ties: lower index).  noise NULL -> Philox keyed by (seed ^
  * *seed_ptr, stream_id, draw, row, index); else [rows, noise_ld] Exp(1) samples.  k <= 64.  err: DH_BEAM_ERR_ALL_FILTERED when a
- * row is all -inf, DH_BEAM_ERR_TOO_FEW when it has fewer than k positive-probability entries (torch raises in both cases). */
+ * row is all -inf, DH_BEAM_ERR_TOO_FEW when it has fewer than k positive-probability entries (informational: the zero-probability entries
+ * follow in index order, as current torch.multinomial returns them in an unspecified order; only the all -inf row is an error). */
 int dh_beam_sample_k(const float* x, int ld, int V, int rows, int k, float temperature, const float* noise, int noise_ld,
                      uint64_t seed, const uint64_t* seed_ptr, int stream_id, int draw, int64_t* out, int32_t* err, void* stream);
 

@@ -469,3 +469,32 @@ def test_no_decode_step_edge(kind):
             half = build(kind)[0].to(torch.bfloat16).generate(images, seed=3, **kw)
         assert int(lens[0]) == kw["max_len"] and tuple(toks.shape) == (1, kw["max_len"])
         assert tuple(half.shape) == want.shape
+
+
+@pytest.mark.parametrize("dec_kind", ("lstm", "tfm"))
+def test_beam_size_equal_to_vocabulary_matches_the_reference(dec_kind):
+    """beam_size == top_k == num_tokens: after <unk> is dropped fewer positive-probability tokens than beams remain.  Current
+    torch.multinomial (hence the reference) does not raise -- the last pick is a zero-probability token, a dead beam -- and neither does
+    the engine (dead beam = <pad> at -inf): the captions equal the oracle's token for token under RNG replay (twelve random cases
+    of tools/fuzz_generate.py; two of them pinned here)."""
+    from deephumor_amd.models import LSTMDecoder, SelfAttentionTransformerDecoder
+    from helpers import synth_state_dict
+    from oracle import ref_path as R
+    v, max_len, temp = 7, 9, 0.7
+    g = torch.Generator().manual_seed(29)
+    if dec_kind == "lstm":
+        dec = LSTMDecoder(v, emb_dim=112, hidden_size=408, num_layers=1, dropout=0.0)
+        first = torch.randn(1, 1, 112, generator=g)
+    else:
+        dec = SelfAttentionTransformerDecoder(v, hid_dim=16, n_layers=3, n_heads=1, pf_dim=32, dropout=0.0, pad_index=0, max_len=64)
+        first = torch.randn(1, 16, generator=g)
+    sd = synth_state_dict(dec.state_dict(), seed=106, logit_std=4.0)
+    dec.load_state_dict(sd)
+    osd = {"decoder." + k: t.clone() for k, t in sd.items()}
+    kw = dict(max_len=max_len, temperature=temp, beam_size=v, top_k=v)
+    torch.manual_seed(77)
+    with torch.no_grad():
+        want = (R.lstm_decoder_generate(osd, "decoder", first, **kw) if dec_kind == "lstm"
+                else R.transformer_generate(osd, "decoder", first, None, 0, 1, **kw)).reshape(-1).tolist()
+    got = _replay_generate(dec.cuda().eval(), first.cuda(), 77, **kw)
+    assert got == want

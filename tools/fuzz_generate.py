@@ -141,7 +141,13 @@ def main():
         try:
             cfg, want, got = one_trial(rng, i)
         except Exception as e:                  # an unsupported shape must be a clean Python error, never a wrong answer
-            print(json.dumps({"i": i, "error": f"{type(e).__name__}: {e}"[:400]}), flush=True)
+            msg = f"{type(e).__name__}: {e}"[:400]
+            if "probability tensor contains" in msg:
+                # every logit of a row filtered (<unk> the only top-k token): the reference raises this from torch.multinomial
+                # (the oracle, called first, did) -- the engine's own RuntimeError for it is covered by tests/test_kernels_gpu.py
+                print(json.dumps({"i": i, "ok": True, "reference_raises": msg}), flush=True)
+                continue
+            print(json.dumps({"i": i, "error": msg}), flush=True)
             bad += 1
             continue
         ok = want == got
