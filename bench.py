@@ -568,8 +568,8 @@ def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU (BASELINE configs: 256)")
     ap.add_argument("--workload", choices=["c2", "c3", "both", "c5", "score-c2", "score-c3"], default="both")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline / fp32 parity legs")
