@@ -77,6 +77,13 @@ __device__ __forceinline__ float block_reduce_256(float v, float* red, bool is_m
     return r;
 }
 
+template <int NT>
+__device__ __attribute__((noinline)) void row_overflow(const float* __restrict__ row, int V, uint32_t thr, int rc, int ldl, int rows_per_img, int beam,
+                             float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
+                             const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
+                             float* __restrict__ pick_val, float* sq, int* si, int* picks, bool shared_picks);
+__device__ __forceinline__ void pick_store(int32_t* pi, float* pv, size_t at, int32_t idx, float val, bool shared);
+
 __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
     float temperature, int unk, const float* __restrict__ noise, uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step,
@@ -120,7 +127,11 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     }
     __syncthreads();
     int n = s_cnt;
-    if (n > CAP) { if (tid == 0) atomicOr(err, DH_BEAM_ERR_OVERFLOW); n = CAP; }
+    if (n > CAP) {                   // more ties at the threshold than the candidate buffers hold: the draw over the row itself
+        row_overflow<256>(row, V, thr, rc, ldl, rows_per_img, beam, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val,
+                          qv, idx_b, picks, false);
+        return;
+    }
     if (n == 0) {
         if (tid == 0) atomicOr(err, DH_BEAM_ERR_ALL_FILTERED);
         if (tid < beam) { pick_idx[(size_t)rc * beam + tid] = 0; pick_val[(size_t)rc * beam + tid] = 0.f; }
@@ -235,6 +246,83 @@ __device__ __forceinline__ int32_t pick_load_idx(const int32_t* pi, size_t at, b
 __device__ __forceinline__ float pick_load_val(const float* pv, size_t at, bool shared) {
     return shared ? __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int32_t*>(pv) + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                   : pv[at];
+}
+
+// More than CAP logits of a row tie at (or exceed) its top-k threshold -- flat or constant logits -- so the survivors do not fit the
+// LDS candidate buffers: the draw runs over the ROW in global memory instead (beam.py:32-48 unchanged: every logit >= the threshold
+// survives, <unk> dropped, softmax / T, `beam` winners of p / Exp(1), ties to the lower index).  `beam` block-wide arg-max rounds over
+// V elements: slow and exact, for a case that trained models do not produce.  sq / si: NT floats / ints of LDS scratch.
+// Only the general kernel (beam_row_sample_kernel) carries it: inside the pre-filtered kernels of the hot path it cost 1-2 % of the C2 step
+// even as a never-taken call (registers 44 -> 88, scratch set-up), so those still flag DH_BEAM_ERR_OVERFLOW and the host repeats the batch
+// through dh_beam_row_sample_exact (deephumor_amd/models/beam.py).
+template <int NT>
+__device__ __attribute__((noinline)) void row_overflow(const float* __restrict__ row, int V, uint32_t thr, int rc, int ldl, int rows_per_img, int beam,
+                             float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
+                             const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
+                             float* __restrict__ pick_val, float* sq, int* si, int* picks, bool shared_picks) {
+    const int tid = threadIdx.x;
+    // (every loop rolled: this path must not raise the register count of the kernels that call it -- at 116 VGPRs instead of 44 the
+    //  group-guided sampler lost a wave of occupancy, its 1,280 workgroups no longer fitted the chip in one round: +9 us per launch)
+    float m = -INFINITY;
+#pragma unroll 1
+    for (int i = tid; i < V; i += NT) { const float v = row[i]; if (f2key(v) >= thr && i != unk) m = fmaxf(m, v / temperature); }
+    __syncthreads();
+    sq[tid] = m;
+    __syncthreads();
+#pragma unroll 1
+    for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) sq[tid] = fmaxf(sq[tid], sq[tid + st]); __syncthreads(); }
+    m = sq[0];
+    __syncthreads();
+    float part = 0.f;
+#pragma unroll 1
+    for (int i = tid; i < V; i += NT) { const float v = row[i]; if (f2key(v) >= thr && i != unk) part += expf(v / temperature - m); }
+    sq[tid] = part;
+    __syncthreads();
+#pragma unroll 1
+    for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) sq[tid] += sq[tid + st]; __syncthreads(); }
+    const float s = sq[0];
+    const int img = rc / rows_per_img, rin = rc % rows_per_img;
+    const uint64_t sd = seed ^ (seed_ptr ? *seed_ptr : 0ull);
+#pragma unroll 1
+    for (int round = 0; round < beam; ++round) {
+        float bq = -1.f; int bi = 0x7FFFFFFF;
+#pragma unroll 1
+        for (int i = tid; i < V; i += NT) {
+            const float v = row[i];
+            if (!(f2key(v) >= thr && i != unk)) continue;
+            bool taken = false;
+#pragma unroll 1
+            for (int j = 0; j < round; ++j) taken |= picks[j] == i;
+            if (taken) continue;
+            const float nz = noise ? noise[(size_t)rc * ldl + i] : philox_exp1(sd, (uint32_t)(img0 + img), (uint32_t)step, 0u, (uint32_t)rin, (uint32_t)i);
+            const float q = (expf(v / temperature - m) / s) / nz;
+            if (q > bq) { bq = q; bi = i; }             // ascending i: the first (lowest) index wins a tie
+        }
+        __syncthreads();
+        sq[tid] = bq; si[tid] = bi;
+        __syncthreads();
+#pragma unroll 1
+        for (int st = NT / 2; st > 0; st >>= 1) {
+            if (tid < st) {
+                const float oq = sq[tid + st]; const int oi = si[tid + st];
+                if (oq > sq[tid] || (oq == sq[tid] && oi < si[tid])) { sq[tid] = oq; si[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) picks[round] = si[0];
+        __syncthreads();
+    }
+    if (tid == 0) {                                    // log_softmax over the gathered (un-tempered) logits of the picks (beam.py:79)
+        float mx = -INFINITY;
+#pragma unroll 1
+        for (int b = 0; b < beam; ++b) mx = fmaxf(mx, row[picks[b]]);
+        float se = 0.f;
+#pragma unroll 1
+        for (int b = 0; b < beam; ++b) se += expf(row[picks[b]] - mx);
+        const float lse = logf(se);
+#pragma unroll 1
+        for (int b = 0; b < beam; ++b) pick_store(pick_idx, pick_val, (size_t)rc * beam + b, picks[b], (row[picks[b]] - mx) - lse, shared_picks);
+    }
 }
 
 struct RowLds {
@@ -676,6 +764,22 @@ extern "C" int dh_beam_row_sample(const float* logits, int ldl, int V, int rows,
                            rows_per_img, beam, top_k, temperature, unk_index, noise, seed, seed_ptr, img0, step, pick_idx,
                            pick_val, err);
 #undef DH_FAST
+    DH_LAUNCH_CHECK();
+}
+
+// dh_beam_row_sample on the general kernel only (4-pass radix select over the whole row; any top_k, any V; a row with more survivors than
+// DH_BEAM_MAX_SURVIVORS is drawn over the row itself instead of flagging DH_BEAM_ERR_OVERFLOW): the fall-back the host takes when a batch
+// flagged that overflow in the pre-filtered kernels.
+extern "C" int dh_beam_row_sample_exact(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,
+                                        int top_k, float temperature, int unk_index, const float* noise,
+                                        uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* pick_idx, float* pick_val,
+                                        int32_t* err, void* stream) {
+    DH_REQUIRE(logits && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
+    DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
+    DhProfScope prof("dh_beam_row_sample", 0.0, 0.0, stream);
+    hipLaunchKernelGGL(beam_row_sample_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
+                       rows_per_img, beam, top_k, temperature, unk_index, noise, seed, seed_ptr, img0, step, pick_idx,
+                       pick_val, err);
     DH_LAUNCH_CHECK();
 }
 

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 14
+ABI_VERSION = 15
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 16
@@ -110,6 +110,7 @@ SIGNATURES = {
     "dh_lstm_layer_wreg_supported": [_I, _I],
     "dh_lstm_layer_wreg": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
+    "dh_beam_row_sample_exact": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
                        _U64, _P, _I, _P],
     "dh_transformer_decode_position": [_c.POINTER(TrModel), _c.POINTER(TrScratch), _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
@@ -726,10 +727,12 @@ def lstm_cell(gates, c_cur, h_new, c_new, h_out, ld_out, rows, row_mult, hh):
 
 
 def beam_row_sample(logits, v, rows, rows_per_img, beam, top_k, temperature, unk_index, noise, seed, img0, step,
-                    pick_idx, pick_val, err, seed_ptr=None):
+                    pick_idx, pick_val, err, seed_ptr=None, exact=False):
+    """``exact``: the general kernel only (``dh_beam_row_sample_exact``): flat rows with more than 1,024 survivors are drawn over the
+    whole row instead of flagging ERR_OVERFLOW."""
     _dev(logits, noise, pick_idx, pick_val, err)
     assert logits.dtype == torch.float32
-    _launch("dh_beam_row_sample", _ptr(logits), logits.stride(0), v, rows, rows_per_img, beam, top_k,
+    _launch("dh_beam_row_sample_exact" if exact else "dh_beam_row_sample", _ptr(logits), logits.stride(0), v, rows, rows_per_img, beam, top_k,
                                      float(temperature), unk_index, _ptr(noise), seed, _ptr(seed_ptr), img0, step,
                                      _ptr(pick_idx), _ptr(pick_val), _ptr(err), _stream())
 

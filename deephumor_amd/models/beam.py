@@ -18,6 +18,11 @@ import torch
 from .. import hip
 
 
+class BeamOverflow(RuntimeError):
+    """A row had more logits at its top-k threshold than the pre-filtered samplers' candidate buffers hold (flat / constant logits):
+    the decoders catch this and repeat the batch with ``exact=True`` (the general sampler, which draws such rows over the whole row)."""
+
+
 class BeamSearchHelper:
     """Beam state for ``n_img`` images x ``beam_size`` beams.
 
@@ -26,8 +31,9 @@ class BeamSearchHelper:
     """
 
     def __init__(self, temperature=1.0, beam_size=10, top_k=50, unk_index=1, eos_index=3, device='cuda',
-                 n_img=1, max_len=25, src_len=0, seed=0, img0=0, noise_source=None, seed_tensor=None):
+                 n_img=1, max_len=25, src_len=0, seed=0, img0=0, noise_source=None, seed_tensor=None, exact=False):
         assert beam_size <= top_k, '`beam_size` should be less than `top_k`'          # beam.py:9
+        self.exact = bool(exact)          # row draws through the general sampler only (see BeamOverflow)
         if beam_size > hip.MAX_BEAMS:
             raise ValueError(f"beam_size <= {hip.MAX_BEAMS} supported")
         self.temperature, self.beam_size, self.top_k = float(temperature), int(beam_size), int(top_k)
@@ -94,6 +100,8 @@ class BeamSearchHelper:
         rpi = 1 if first else self.beam_size
         assert rows == self.n_img * rpi
         v = logits.shape[1]
+        if self.exact:
+            group_max = None              # the general sampler reads the whole row
         if group_max is not None and self.top_k <= hip.n_groups(v) and self.fused_step:
             # 16-bit paths: row draw + candidate draw of the step in one launch
             hip.beam_step_groups(logits, v, group_max, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
@@ -111,7 +119,7 @@ class BeamSearchHelper:
         else:
             hip.beam_row_sample(logits, v, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
                                 self._noise("row", step_index, (rows, v), logits.stride(0)), self.seed, self.img0, step_index,
-                                self.pick_idx, self.pick_val, self.err, seed_ptr=self.seed_tensor)
+                                self.pick_idx, self.pick_val, self.err, seed_ptr=self.seed_tensor, exact=self.exact)
         noise = None if first else self._noise("cand", step_index, (self.n_img, self.beam_size ** 2))
         hip.beam_select(self.pick_idx, self.pick_val, self.tokens, self.vals, self._ended, self.src,
                         self.parent, self.hparent, self.done, self.end_step, self.n_img, self.beam_size, first,
@@ -151,8 +159,7 @@ class BeamSearchHelper:
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0 "
                                "(every logit of a row was filtered: <unk> was the only top-k token)")
         if code & hip.ERR_OVERFLOW:
-            raise RuntimeError("more than 1024 logits of a row tie at its top-k threshold (DH_BEAM_MAX_SURVIVORS); "
-                               "the reference would sample among all of them")
+            raise BeamOverflow("more than 1024 logits of a row tie at its top-k threshold (DH_BEAM_MAX_SURVIVORS): repeat with exact=True")
         # hip.ERR_TOO_FEW (fewer positive-probability tokens than beams: top_k == beam_size with <unk> in the top-k, or
         # beam_size >= num_tokens) is NOT an error: torch.multinomial of the torch versions this was pinned against fills the
         # remaining slots with zero-probability tokens, the kernels with <pad> at score -inf -- a dead beam either way, which no

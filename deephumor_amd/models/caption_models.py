@@ -68,7 +68,7 @@ class _CaptioningBase(nn.Module):
         was captured with.  Every cached graph therefore records the models' plan signature and keeps the plans
         themselves alive; ``load_state_dict`` / ``.to()`` / in-place weight updates change the signature and the
         graph is re-captured instead of replayed against stale or freed memory."""
-        from .beam import BeamSearchHelper, resolve_seed
+        from .beam import BeamOverflow, BeamSearchHelper, resolve_seed
         seed = resolve_seed(seed)
         key = (tuple((tuple(t.shape), t.dtype) for t in inputs), None if caption is None else tuple(caption.shape),
                tuple(sorted(kw.items())), next(self.parameters()).dtype)
@@ -109,7 +109,10 @@ class _CaptioningBase(nn.Module):
             scap.copy_(caption)
         seed_t.fill_(int(seed))
         graph.replay()
-        BeamSearchHelper.raise_for(int(err.item()))
+        try:
+            BeamSearchHelper.raise_for(int(err.item()))
+        except BeamOverflow:              # flat logits: the captured chain cannot switch samplers -- this batch eagerly (it repeats itself exact)
+            return self.generate_batch(*inputs, caption=caption, seed=seed, **kw)
         return toks.clone(), lens.clone()
 
 

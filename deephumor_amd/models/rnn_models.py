@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamSearchHelper, resolve_seed, run_interleaved
+from .beam import BeamOverflow, BeamSearchHelper, resolve_seed, run_interleaved
 from .encoders import _Planned
 
 
@@ -141,7 +141,7 @@ class LSTMDecoder(_Planned, nn.Module):
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, seed=None, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
-                       defer_check=False, early_stop_every=0):
+                       defer_check=False, early_stop_every=0, exact=False):
         """Batched beam-search sampling for ``image_emb [N, 1, E]`` or ``[N, E]``.
 
         Returns ``(tokens int64 [N, max_len] zero-padded, lengths int64 [N])``; row ``i`` equals
@@ -149,7 +149,9 @@ class LSTMDecoder(_Planned, nn.Module):
         (rnn_models.py:48-143, incl. the hidden-state indexing at :135-137).  ``streams`` > 1 decodes
         that many image sub-batches concurrently on separate HIP streams (same captions).
         ``early_stop_every=k`` (> 0) checks every k steps whether every image has finished (the reference's
-        ``all_ended()`` break, rnn_models.py:131) and stops decoding then -- one host sync per check, same captions."""
+        ``all_ended()`` break, rnn_models.py:131) and stops decoding then -- one host sync per check, same captions.
+        ``exact=True`` draws every row through the general sampler from the start (what a batch is repeated with automatically
+        when flat logits overflow the pre-filtered samplers, see ``BeamOverflow``)."""
         self._check_mode()
         plan = self._get_plan()
         seed = resolve_seed(seed, noise_source)
@@ -160,7 +162,8 @@ class LSTMDecoder(_Planned, nn.Module):
             r = n * b
             dev = image_emb.device
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
-                                      max_len=max_len, seed=seed, img0=img0 + lo, noise_source=noise_source, seed_tensor=seed_tensor)
+                                      max_len=max_len, seed=seed, img0=img0 + lo, noise_source=noise_source, seed_tensor=seed_tensor,
+                                      exact=exact[0])
             pos = 0
             if caption is not None:
                 pos = caption.shape[1]
@@ -195,7 +198,14 @@ class LSTMDecoder(_Planned, nn.Module):
             # (no decode step when the prefix fills max_len - 1: the reference then returns beam 0 -- see finalize)
             return helper.finalize(len_bias_done=1, full_len=max_len, defer_check=defer_check, first_beam=pos + 1 >= max_len)
 
-        return run_interleaved(session, image_emb.shape[0], streams)
+        exact = [bool(exact)]
+        try:
+            return run_interleaved(session, image_emb.shape[0], streams)
+        except BeamOverflow:              # flat logits: more ties at a row's top-k threshold than the fast samplers hold -- once more,
+            if exact[0]:
+                raise
+            exact[0] = True               # every row draw through the general sampler (same seed: same captions where nothing overflowed)
+            return run_interleaved(session, image_emb.shape[0], streams)
 
     def generate(self, image_emb, caption=None, max_len=25,
                  temperature=1.0, beam_size=10, top_k=50, eos_index=3, **kw):

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamSearchHelper, resolve_seed, run_interleaved
+from .beam import BeamOverflow, BeamSearchHelper, resolve_seed, run_interleaved
 from .encoders import _Planned
 
 
@@ -452,7 +452,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
                         seed=None, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
-                        defer_check=False, early_stop_every=0):
+                        defer_check=False, early_stop_every=0, exact=False):
         self._check_mode()
         plan = self._get_plan()
         seed = resolve_seed(seed, noise_source)
@@ -467,7 +467,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             dev = start_emb.device
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
                                       max_len=max_len, src_len=max_len + 1, seed=seed, img0=img0 + lo,
-                                      noise_source=noise_source, seed_tensor=seed_tensor)
+                                      noise_source=noise_source, seed_tensor=seed_tensor, exact=exact[0])
             if self.pad_index != 0:
                 helper.tokens.fill_(self.pad_index)
             pos = 0
@@ -502,7 +502,14 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     break                                   # all_ended() break of the reference (transformers.py:585)
             return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index, defer_check=defer_check)
 
-        return run_interleaved(session, start_emb.shape[0], streams)
+        exact = [bool(exact)]
+        try:
+            return run_interleaved(session, start_emb.shape[0], streams)
+        except BeamOverflow:              # flat logits (see LSTMDecoder.generate_batch): once more through the general sampler
+            if exact[0]:
+                raise
+            exact[0] = True
+            return run_interleaved(session, start_emb.shape[0], streams)
 
 
 class TransformerDecoder(_IncrementalDecoder):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 14
+#define DH_ABI_VERSION 15
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -35,8 +35,10 @@ enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weig
 
 /* device-side error bits OR-ed into the `err` word of the beam kernels */
 enum { DH_BEAM_ERR_ALL_FILTERED = 1,   /* every logit filtered (-inf): reference raises RuntimeError, beam.py:46 */
-       DH_BEAM_ERR_OVERFLOW = 2,       /* more than DH_BEAM_MAX_SURVIVORS logits tie at the top-k threshold */
-       DH_BEAM_ERR_TOO_FEW = 4 };      /* fewer positive-probability tokens than beams */
+       DH_BEAM_ERR_OVERFLOW = 2,       /* more than DH_BEAM_MAX_SURVIVORS logits at a row's top-k threshold in a pre-filtered kernel: repeat
+                                          the step / batch with dh_beam_row_sample_exact (the models do) */
+       DH_BEAM_ERR_TOO_FEW = 4 };      /* informational: fewer positive-probability tokens than beams (dead beams, as torch's
+                                          zero-probability picks) */
 #define DH_BEAM_MAX_SURVIVORS 1024
 #define DH_BEAM_MAX_BEAMS 16
 
@@ -373,6 +375,14 @@ int dh_beam_row_sample(const float* logits, int ldl, int V, int rows, int rows_p
                        int top_k, float temperature, int unk_index, const float* noise,
                        uint64_t seed, const uint64_t* seed_ptr, int img0, int step, int32_t* pick_idx,
                        float* pick_val, int32_t* err, void* stream);
+
+/* dh_beam_row_sample on the general kernel only: any top_k / V, and a row with more than DH_BEAM_MAX_SURVIVORS logits at its top-k
+ * threshold (flat or constant logits: beam.py:34 keeps every tie) is drawn over the whole row instead of flagging
+ * DH_BEAM_ERR_OVERFLOW.  Slower; the models repeat a batch through it when the pre-filtered kernels flagged that overflow. */
+int dh_beam_row_sample_exact(const float* logits, int ldl, int V, int rows, int rows_per_img, int beam,
+                             int top_k, float temperature, int unk_index, const float* noise,
+                             uint64_t seed, const uint64_t* seed_ptr, int img0, int step, int32_t* pick_idx,
+                             float* pick_val, int32_t* err, void* stream);
 
 /* Teacher-forced scoring without materialising the logits (bf16): logp[m] = log_softmax(A[m,:] W^T + bias)[targets[m]]
  * (metrics.py:4-9 via F.cross_entropy).  group_max / group_sum [M, gm_ld >= 2*ceil(V/128)] and target_logit [M] are

@@ -576,3 +576,47 @@ def test_row_samplers_treat_signed_zeros_as_ties(hip, v):
         else:
             hip.beam_row_sample_groups(x.cuda(), v, gmax, rows, beam, beam, top_k, temp, 1, noise.cuda(), 0, 0, 0, pi, pv, err)
         assert int(err.item()) == 0 and pi.cpu().long().tolist() == want.tolist(), kind
+
+
+@pytest.mark.parametrize("v,top_k", [(5000, 50), (36541, 20), (1500, 300)])
+def test_row_samplers_on_flat_logits(hip, v, top_k):
+    """Constant logits: EVERY token ties at the top-k threshold and survives (beam.py:34 keeps ties), far more than the pre-filtered
+    samplers' 1,024-entry candidate buffers: those flag ERR_OVERFLOW, and dh_beam_row_sample_exact (what the models then repeat the
+    batch with) draws over the row itself -- the `beam` largest 1 / Exp(1) noise values (without <unk>), each with value log(1 / beam);
+    replayed noise and Philox."""
+    g = torch.Generator().manual_seed(v)
+    rows, beam, temp = 3, 5, 1.3
+    x = torch.full((rows, v), 0.25)
+    x[1, ::2] += 1.0                                                  # a row with two plateaus: the upper one (v / 2 tokens) is the top-k
+    noise = torch.empty(rows, v).exponential_(1, generator=g)
+    kept = x.clone()
+    kept[x < x.topk(top_k, dim=-1).values[:, -1:]] = float("-inf")
+    kept[:, 1] = float("-inf")
+    want = torch.topk(torch.softmax(kept / temp, -1) / noise, beam, dim=-1).indices
+    ng = hip.n_groups(v)
+    pad = torch.full((rows, ng * 64), float("-inf"))
+    pad[:, :v] = x
+    gmax = pad.view(rows, ng, 64).max(-1).values.cuda()
+
+    def run(kind, nz):
+        pi = torch.empty((rows, beam), dtype=torch.int32, device="cuda")
+        pv = torch.empty((rows, beam), device="cuda")
+        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        if kind == "groups":
+            hip.beam_row_sample_groups(x.cuda(), v, gmax, rows, beam, beam, top_k, temp, 1, nz, 5, 0, 2, pi, pv, err)
+        else:
+            hip.beam_row_sample(x.cuda(), v, rows, beam, beam, top_k, temp, 1, nz, 5, 0, 2, pi, pv, err, exact=kind == "exact")
+        return pi.cpu().long(), pv.cpu(), int(err.item())
+
+    fi, _, fe = run("fast", noise.cuda())          # top_k > 256 already dispatches to the general kernel: right answer, no flag
+    assert (fe & hip.ERR_OVERFLOW) if top_k <= 256 else (fe == 0 and fi.tolist() == want.tolist())
+    if top_k <= ng and top_k <= 256:
+        assert run("groups", noise.cuda())[2] & hip.ERR_OVERFLOW
+    for nz in (noise.cuda(), None):
+        got, pv, e = run("exact", nz)
+        assert e == 0
+        if nz is not None:
+            assert got.tolist() == want.tolist()
+        assert bool((got != 1).all()) and all(len(set(r)) == beam for r in got.tolist())
+        assert bool(torch.isfinite(kept.gather(1, got)).all())                          # only surviving tokens
+        close(pv, torch.full((rows, beam), float(np.log(1.0 / beam))), atol=1e-5, rtol=0)

@@ -498,3 +498,43 @@ def test_beam_size_equal_to_vocabulary_matches_the_reference(dec_kind):
                 else R.transformer_generate(osd, "decoder", first, None, 0, 1, **kw)).reshape(-1).tolist()
     got = _replay_generate(dec.cuda().eval(), first.cuda(), 77, **kw)
     assert got == want
+
+
+
+@pytest.mark.parametrize("dec_kind", ("lstm", "tfm"))
+def test_constant_logits_decode_like_the_reference(dec_kind):
+    """A classifier that outputs the same logit for every token (zero weights): all 3,000 tokens tie at every top-k threshold, which the
+    pre-filtered samplers cannot hold -- the decoders catch the overflow and repeat the batch through the general sampler.  Token for
+    token the oracle's caption under RNG replay (fp32); the 16-bit path runs, repeatably."""
+    from deephumor_amd.models import LSTMDecoder, SelfAttentionTransformerDecoder
+    from helpers import synth_state_dict
+    from oracle import ref_path as R
+    v = 3000
+    g = torch.Generator().manual_seed(3)
+    if dec_kind == "lstm":
+        dec = LSTMDecoder(v, emb_dim=32, hidden_size=64, num_layers=1, dropout=0.0)
+        first = torch.randn(1, 1, 32, generator=g)
+    else:
+        dec = SelfAttentionTransformerDecoder(v, hid_dim=64, n_layers=1, n_heads=1, pf_dim=64, dropout=0.0, pad_index=0, max_len=64)
+        first = torch.randn(1, 64, generator=g)
+    sd = synth_state_dict(dec.state_dict(), seed=9)
+    sd["classifier.weight"] = torch.zeros_like(sd["classifier.weight"])
+    sd["classifier.bias"] = torch.full_like(sd["classifier.bias"], 0.5)
+    dec.load_state_dict(sd)
+    osd = {"decoder." + k: t.clone() for k, t in sd.items()}
+    kw = dict(max_len=7, temperature=1.1, beam_size=3, top_k=20)
+    torch.manual_seed(5)
+    with torch.no_grad():
+        want = (R.lstm_decoder_generate(osd, "decoder", first, **kw) if dec_kind == "lstm"
+                else R.transformer_generate(osd, "decoder", first, None, 0, 1, **kw)).reshape(-1).tolist()
+    # (RNG replay draws from the CPU generator as it goes, so it cannot be repeated: the general sampler from the start)
+    assert _replay_generate(dec.cuda().eval(), first.cuda(), 5, exact=True, **kw) == want
+    with torch.no_grad():                                           # Philox noise: the automatic repeat == exact from the start
+        auto = dec.generate_batch(first.cuda().reshape(1, -1), seed=4, **kw)
+        forced = dec.generate_batch(first.cuda().reshape(1, -1), seed=4, exact=True, **kw)
+    assert torch.equal(auto[0], forced[0]) and torch.equal(auto[1], forced[1])
+    half = dec.to(torch.bfloat16)
+    with torch.no_grad():
+        a = half.generate_batch(first.cuda().to(torch.bfloat16).reshape(1, -1), seed=4, **kw)
+        b = half.generate_batch(first.cuda().to(torch.bfloat16).reshape(1, -1), seed=4, **kw)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and int(a[0].max()) < v and not bool((a[0] == 1).any())

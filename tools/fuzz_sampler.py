@@ -38,6 +38,11 @@ def one_trial(rng, idx):
         x = (x * q).round() / q                                   # exact ties, also at the top-k threshold
     if rng.random() < 0.25:
         x[torch.rand(rows, v, generator=g) < rng.choice([0.05, 0.6])] = float("-inf")
+    if rng.random() < 0.12:                                       # flat rows: (almost) every logit ties at the threshold -- more
+        flat = torch.rand(rows) < 0.7                             # survivors than the kernels' 1,024-entry candidate buffers when V allows
+        x[flat] = float(rng.choice([0.0, -3.5, 2.0]))
+        if rng.random() < 0.5:
+            x[flat, :: rng.randint(2, 9)] += 1.0                  # two plateaus
     if rng.random() < 0.25 and v > 1:
         x[:, 1] = x[torch.isfinite(x)].max() + 1.0                # <unk> on top
     rec = dict(V=v, beam=beam, n_img=n_img, first=first, top_k=top_k, T=round(temp, 4), ld=ld)
@@ -47,8 +52,9 @@ def one_trial(rng, idx):
     kept[x < kth] = float("-inf")
     kept[:, 1] = float("-inf")
     alive = torch.isfinite(kept).sum(-1)
-    if int(alive.min()) < beam or int(alive.max()) > 1024:
-        return dict(rec, ok=True, skipped="error case (too few / too many survivors)")
+    if int(alive.min()) < beam:
+        return dict(rec, ok=True, skipped="fewer survivors than beams (dead beams; covered by tools/fuzz_generate.py)")
+    rec["max_survivors"] = int(alive.max())
     noise = torch.empty(rows, v).exponential_(1, generator=g)
     want = torch.topk(torch.softmax(kept / temp, -1) / noise, beam, dim=-1).indices
     want_val = torch.gather(kept, 1, want)
@@ -67,11 +73,18 @@ def one_trial(rng, idx):
         pi = torch.full((rows, beam), -7, dtype=torch.int32, device="cuda")
         pv = torch.full((rows, beam), -7.0, device="cuda")
         err = torch.zeros(1, dtype=torch.int32, device="cuda")
-        if kind == "full":
-            hip.beam_row_sample(logits, v, rows, rpi, beam, top_k, temp, 1, nsrc, seed, 3, 5, pi, pv, err)
+        if kind == "full":      # more than 1,024 survivors: the general sampler (what the models repeat such a batch with)
+            hip.beam_row_sample(logits, v, rows, rpi, beam, top_k, temp, 1, nsrc, seed, 3, 5, pi, pv, err, exact=rec["max_survivors"] > 1024)
         else:
             hip.beam_row_sample_groups(logits, v, gmax, rows, rpi, beam, top_k, temp, 1, nsrc, seed, 3, 5, pi, pv, err)
         return pi.cpu().long(), pv.cpu(), int(err.item())
+
+    def run_fast_err():
+        pi = torch.full((rows, beam), -7, dtype=torch.int32, device="cuda")
+        pv = torch.full((rows, beam), -7.0, device="cuda")
+        err = torch.zeros(1, dtype=torch.int32, device="cuda")
+        hip.beam_row_sample(logits, v, rows, rpi, beam, top_k, temp, 1, nz, 0, 3, 5, pi, pv, err)
+        return int(err.item())
 
     fi, fv, fe = run("full", nz)
     rec["full_vs_torch"] = bool(torch.equal(fi, want) and fe == 0)
@@ -82,7 +95,11 @@ def one_trial(rng, idx):
         rec.update(err=fe, row=r, want=want[r].tolist(), got=fi[r].tolist(), q_want=[float(qq[j]) for j in want[r]],
                    q_got=[float(qq[j]) if 0 <= j < v else None for j in fi[r].tolist()], alive=int(alive[r]),
                    ties_at_threshold=int((x[r] == kth[r]).sum()))
-    if top_k <= ng:                                               # the engine's condition for the group-guided sampler
+    if rec["max_survivors"] > 1024:                               # the pre-filtered samplers must FLAG such rows (never answer wrongly)
+        if top_k <= 256 and v <= 65536:                           # (otherwise dh_beam_row_sample is the general kernel already)
+            rec["fast_flags_overflow"] = bool(run_fast_err() & hip.ERR_OVERFLOW)
+            ok = ok and rec["fast_flags_overflow"]
+    elif top_k <= ng:                                             # the engine's condition for the group-guided sampler
         gi, gv, ge = run("groups", nz)
         # (the two kernels sum the picks' log-softmax in different orders: values to 1e-6, ids exactly)
         rec["groups_vs_full"] = bool(torch.equal(gi, fi) and torch.allclose(gv, fv, atol=1e-6, rtol=1e-6) and ge == fe)
