@@ -22,6 +22,18 @@ static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const
     return dh_attn_cross_decode(q, m->D, L.kv, m->keymask, att, n_img, rows_per_img, m->S, m->D, m->n_heads, L.ea_scale, dt, stream);
 }
 
+// One GEMM of the deferred-LayerNorm chain: the register-stationary kernel (csrc/linear_wreg.hip; bit-identical results) when the
+// layer carries fragment-packed weights, the position has enough rows to fill the chip and the shape is one it takes; else the
+// tile kernels.  DH_DECODE_WREG=0 switches it off (A/B runs), DH_DECODE_WREG_MIN_ROWS moves the threshold.
+static int chain_linear(const void* A, int lda, const void* W, const void* W_pk, const float* bias, const void* res, int ldres, void* C,
+                        int ldc, int rows, int N, int K, int relu, const dh_ln_fold_t* f, int dt, void* stream) {
+    static const int use_wreg = getenv("DH_DECODE_WREG") ? atoi(getenv("DH_DECODE_WREG")) : 1;
+    static const int min_rows = getenv("DH_DECODE_WREG_MIN_ROWS") ? atoi(getenv("DH_DECODE_WREG_MIN_ROWS")) : 320;
+    if (use_wreg && W_pk && rows >= min_rows && dh_linear_ln_wreg_supported(N, K, res != nullptr) && (res == nullptr) == (f->o_stats == nullptr))
+        return dh_linear_ln_wreg(A, lda, W_pk, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
+    return dh_linear_ln(A, lda, W, K, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
+}
+
 // The decode position on the deferred-LayerNorm chain (16-bit dtypes): 8 launches per layer instead of 11.  The residual
 // stream is kept PRE-LayerNorm (buffers X = sc->x, Y1 = sc->o, Y2 = sc->y2 with partial statistics st0 / st1 / st2); every
 // LayerNorm is applied where its output is consumed: folded into the next projection (gamma in the weight, beta in the bias,
@@ -45,7 +57,7 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         } else {
             if (P) { f.a_stats = sc->st0; f.a_tiles = nt; f.a_eps = P->ln3_eps; f.a_colsum = L.cs_qkv; }
             dh_prof_set_tag("qkv");
-            DH_TRY(dh_linear_ln(sc->x, D, P ? L.wqkv_f : L.wqkv, D, P ? L.bqkv_f : L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
+            DH_TRY(chain_linear(sc->x, D, P ? L.wqkv_f : L.wqkv, L.wqkv_pk, P ? L.bqkv_f : L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
             DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
                                        row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
         }
@@ -54,7 +66,7 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         if (P) { f.r_stats = sc->st0; f.r_tiles = nt; f.r_eps = P->ln3_eps; f.r_gamma = P->ln3_g; f.r_beta = P->ln3_b; }
         f.o_stats = sc->st1;
         dh_prof_set_tag("proj");
-        DH_TRY(dh_linear_ln(sc->att, D, L.wo, D, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
+        DH_TRY(chain_linear(sc->att, D, L.wo, L.wo_pk, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
         const void* yin = sc->o; const float* st_in = sc->st1;               // rows entering the FFN block, LayerNorm pending
         const float *g_in = L.ln1_g, *b_in = L.ln1_b; float eps_in = L.ln1_eps;
         if (m->cross) {
@@ -73,19 +85,19 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
             f = dh_ln_fold_t{};
             f.r_stats = sc->st1; f.r_tiles = nt; f.r_eps = L.ln1_eps; f.r_gamma = L.ln1_g; f.r_beta = L.ln1_b; f.o_stats = sc->st2;
             dh_prof_set_tag("proj");
-            DH_TRY(dh_linear_ln(sc->att, D, L.weo, D, L.beo, sc->o, D, sc->y2, D, rows, D, D, 0, &f, dt, stream));
+            DH_TRY(chain_linear(sc->att, D, L.weo, L.weo_pk, L.beo, sc->o, D, sc->y2, D, rows, D, D, 0, &f, dt, stream));
             yin = sc->y2; st_in = sc->st2; g_in = L.ln2_g; b_in = L.ln2_b; eps_in = L.ln2_eps;
         }
         // 5. ff = relu(LN(Yin) W1^T + b1)
         f = dh_ln_fold_t{};
         f.a_stats = st_in; f.a_tiles = nt; f.a_eps = eps_in; f.a_colsum = L.cs_1;
         dh_prof_set_tag("ffn");
-        DH_TRY(dh_linear_ln(yin, D, L.w1_f, D, L.b1_f, nullptr, 0, sc->ff, PF, rows, PF, D, 1, &f, dt, stream));
+        DH_TRY(chain_linear(yin, D, L.w1_f, L.w1_pk, L.b1_f, nullptr, 0, sc->ff, PF, rows, PF, D, 1, &f, dt, stream));
         // 6. X = LN(Yin) + ff W2^T + b2, statistics -> st0  (LN3 of this layer now pending on X)
         f = dh_ln_fold_t{};
         f.r_stats = st_in; f.r_tiles = nt; f.r_eps = eps_in; f.r_gamma = g_in; f.r_beta = b_in; f.o_stats = sc->st0;
         dh_prof_set_tag("ffn");
-        DH_TRY(dh_linear_ln(sc->ff, PF, L.w2, PF, L.b2, yin, D, sc->x, D, rows, D, PF, 0, &f, dt, stream));
+        DH_TRY(chain_linear(sc->ff, PF, L.w2, L.w2_pk, L.b2, yin, D, sc->x, D, rows, D, PF, 0, &f, dt, stream));
     }
     const dh_tr_layer_t& Z = m->layers[m->n_layers - 1];
     return dh_add_layernorm(sc->x, nullptr, Z.ln3_g, Z.ln3_b, x_final, rows, D, Z.ln3_eps, dt, stream);

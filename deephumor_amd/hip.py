@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 15
+ABI_VERSION = 16
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 16
@@ -26,7 +26,8 @@ class TrLayer(_c.Structure):
                 + [(n, _F) for n in ("ln1_eps", "ln2_eps", "ln3_eps", "sa_scale", "ea_scale")] + [("_pad", _I)]
                 + [(n, _P) for n in ("kcache", "vcache", "kv")]
                 + [(n, _P) for n in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1", "kp", "vt")]
-                + [("kp_dperm", _I), ("_pad2", _I)])
+                + [("kp_dperm", _I), ("_pad2", _I)]
+                + [(n, _P) for n in ("wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk")])
 
 
 class TrModel(_c.Structure):
@@ -84,6 +85,8 @@ SIGNATURES = {
     "dh_label_mean": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "dh_linear_ln": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
+    "dh_linear_ln_wreg_supported": [_I, _I, _I],
+    "dh_linear_ln_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
     "dh_attn_cross_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dh_attn_cross_qproj_decode": [_P, _I, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_attn_cross_decode_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
@@ -425,6 +428,34 @@ def linear_ln(a, w, bias, out=None, residual=None, relu=False, a_ln=None, r_ln=N
             residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
             _dt(a), _stream(), tag=tag)
     return (out, stats) if want_stats else out
+
+
+def linear_ln_wreg_supported(n, k, with_residual_stats):
+    return bool(load().dh_linear_ln_wreg_supported(int(n), int(k), int(bool(with_residual_stats))))
+
+
+def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_ln=None, r_ln=None, tag=None):
+    """``dh_linear_ln_wreg``: ``linear_ln`` on ``w_packed = pack_mfma_fragments(w [n, k])`` -- the register-stationary decode
+    GEMM (bit-identical results).  With ``residual`` the partial statistics of the output rows are always produced and
+    returned: ``(out, stats)``."""
+    _dev(a, w_packed, bias, out, residual)
+    m, k = a.shape
+    assert a.dtype in HALF_DTYPES and a.dtype == w_packed.dtype and a.stride(1) == 1 and w_packed.numel() == n * k
+    if out is None:
+        out = torch.empty((m, n), dtype=a.dtype, device=a.device)
+    f = LnFold()
+    if a_ln is not None:
+        st, eps, colsum = a_ln
+        f.a_stats, f.a_tiles, f.a_eps, f.a_colsum = _ptr(st), k // 64, float(eps), _ptr(colsum)
+    if r_ln is not None:
+        st, eps, gamma, beta = r_ln
+        f.r_stats, f.r_tiles, f.r_eps, f.r_gamma, f.r_beta = _ptr(st), n // 64, float(eps), _ptr(gamma), _ptr(beta)
+    stats = torch.empty((m, n // 64, 2), dtype=torch.float32, device=a.device) if residual is not None else None
+    f.o_stats = _ptr(stats)
+    _launch("dh_linear_ln_wreg", _ptr(a), a.stride(0), _ptr(w_packed), _ptr(bias), _ptr(residual),
+            residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
+            _dt(a), _stream(), tag=tag)
+    return (out, stats) if residual is not None else out
 
 
 def attn_cross_pack(kv, n_img, s, d, n_heads, dperm=False):

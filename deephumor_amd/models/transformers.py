@@ -206,6 +206,14 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 if self._cross:
                     ent["wq_f"], ent["bq_f"], ent["cs_q"] = fold(ent["wq"], ent["bq"], ent["ln1"])
                 ent["w1_f"], ent["b1_f"], ent["cs_1"] = fold(ent["w1"], ent["b1"], ent["ln2"] if self._cross else ent["ln1"])
+            if torch.cuda.is_available() and self.classifier.weight.is_cuda and not os.environ.get("DH_NO_DECODE_WREG"):
+                # register-stationary decode GEMMs (dh_linear_ln_wreg): fragment-packed copies of the chain's weights, once per plan
+                d, pf = self.hid_dim, self.layers[0].pf.fc_1.out_features
+                for i, ent in enumerate(layers):
+                    for name, src, n, k, lnx in (("wqkv_pk", "wqkv_f" if i > 0 else "wqkv", 3 * d, d, False), ("wo_pk", "wo", d, d, True),
+                                                 ("weo_pk", "weo", d, d, True), ("w1_pk", "w1_f", pf, d, False), ("w2_pk", "w2", d, pf, True)):
+                        if src in ent and hip.linear_ln_wreg_supported(n, k, lnx):
+                            ent[name] = hip.pack_mfma_fragments(ent[src].contiguous())
         return dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
                     scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=f(self.classifier.bias),
                     dtype=self.classifier.weight.dtype)
@@ -278,7 +286,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     c.kv = P(self.kv[i])
                     if self.packed is not None:
                         c.kp, c.vt, c.kp_dperm = P(self.packed[i][0]), P(self.packed[i][1]), int(self.dperm)
-                for name in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1"):
+                for name in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1",
+                             "wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk"):
                     if name in L:
                         setattr(c, name, P(L[name]))
                 c.kcache, c.vcache = self.kc[i].data_ptr(), self.vc[i].data_ptr()

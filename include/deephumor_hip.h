@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 15
+#define DH_ABI_VERSION 16
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -227,6 +227,15 @@ typedef struct dh_ln_fold {
 } dh_ln_fold_t;
 int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bias, const void* residual, int ldres,
                  void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream);
+
+/* dh_linear_ln for the decode shapes with the weights stationary in registers (csrc/linear_wreg.hip; transformers.py:97,127,
+ * 162-163 applied to the rows of one position): w_packed = dh_pack_mfma_fragments(W [N, K]) replaces (W, ldw).  Two forms:
+ *   residual == NULL: optional ln->a_stats (deferred LayerNorm of the A rows), optional ReLU; K == 512, N % 128 == 0;
+ *   residual != NULL: ln->o_stats required, ln->r_stats optional; K == 512 or 2,048, N % 64 == 0.
+ * Results are bit-identical to dh_linear_ln on the unpacked weights.  _supported: 1 when (N, K, form) is taken. */
+int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats);
+int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
+                      void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream);
 
 /* Vocabulary projection feeding beam search (bf16 operands): logits [M,V] fp32 = A*W^T + bias, and
  * group_max[m, g] = max(logits[m, 64g .. 64g+63]) for g < 2*ceil(V/128) (row stride gm_ld) -- the pre-filter
@@ -508,6 +517,9 @@ typedef struct dh_tr_layer {
     const float *bqkv_f, *bq_f, *b1_f, *cs_qkv, *cs_q, *cs_1;
     const void *kp, *vt;                                    /* optional: kv re-laid out by dh_attn_cross_pack (matrix-core cross-attention) */
     int kp_dperm, _pad2;                                    /* kp was packed with dperm = 1: the chain fuses fc_q into the attention launch */
+    /* optional: dh_pack_mfma_fragments of (wqkv_f, or wqkv for layer 0), wo, weo, w1_f, w2 -- the register-stationary decode GEMMs
+     * (dh_linear_ln_wreg) for positions with many rows; NULL = the tile kernels */
+    const void *wqkv_pk, *wo_pk, *weo_pk, *w1_pk, *w2_pk;
 } dh_tr_layer_t;
 
 typedef struct dh_tr_model {

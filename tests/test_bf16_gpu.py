@@ -714,3 +714,57 @@ def test_round16_keep_nonzero_and_fp16_spatial_features(hip):
         hip.round16_keep_nonzero = real
     assert sp.dtype == HALF and tuple(sp.shape) == (2, 4, 256)
     assert calls == ([(8, 256)] if HALF == torch.float16 else [])       # the fp16 path rounds its spatial features through it
+
+
+@pytest.mark.parametrize("m", [1280, 37, 640, 3000, 81])
+def test_linear_ln_wreg_equals_tile_kernels(hip, m):
+    """dh_linear_ln_wreg (weights stationary in registers, one round of <= 256 workgroups) against dh_linear_ln's tile kernels on
+    the same operands: every form the decode chain uses (plain, deferred LayerNorm on the A rows + ReLU, residual +- its LayerNorm
+    + output statistics; K = 512 and 2,048), bit for bit -- outputs AND statistics."""
+    d, pf = 512, 2048
+    g = torch.Generator().manual_seed(m)
+    y = bf(torch.randn(m, d, generator=g) * 1.7 + 0.3).cuda()
+    stats = _tile_stats(y.float().cpu()).cuda()
+    gamma, beta = (torch.rand(d, generator=g) + 0.5).cuda(), (torch.randn(d, generator=g) * 0.2).cuda()
+    for n in (3 * d, pf, 128):
+        w = bf(torch.randn(n, d, generator=g) / d ** 0.5).cuda()
+        b, cs = (torch.randn(n, generator=g) * 0.1).cuda(), (torch.randn(n, generator=g)).cuda()
+        wp = hip.pack_mfma_fragments(w)
+        assert hip.linear_ln_wreg_supported(n, d, False)
+        for relu in (False, True):
+            assert torch.equal(hip.linear_ln_wreg(y, wp, n, b, relu=relu), hip.linear_ln(y, w, b, relu=relu))
+            assert torch.equal(hip.linear_ln_wreg(y, wp, n, b, relu=relu, a_ln=(stats, 1e-5, cs)),
+                               hip.linear_ln(y, w, b, relu=relu, a_ln=(stats, 1e-5, cs)))
+    for k in (d, pf):
+        a = bf(torch.randn(m, k, generator=g)).cuda()
+        w = bf(torch.randn(d, k, generator=g) / k ** 0.5).cuda()
+        b = (torch.randn(d, generator=g) * 0.1).cuda()
+        wp = hip.pack_mfma_fragments(w)
+        assert hip.linear_ln_wreg_supported(d, k, True)
+        for r_ln in (None, (stats, 1e-5, gamma, beta)):
+            got, gst = hip.linear_ln_wreg(a, wp, d, b, residual=y, r_ln=r_ln)
+            want, wst = hip.linear_ln(a, w, b, residual=y, r_ln=r_ln, want_stats=True)
+            assert torch.equal(got, want) and torch.equal(gst, wst)
+    assert not hip.linear_ln_wreg_supported(d, 256, False) and not hip.linear_ln_wreg_supported(96, d, True)
+
+
+@pytest.mark.parametrize("kind", ["CaptioningTransformer", "CaptioningTransformerBase"])
+def test_decode_chain_wreg_equals_tile_chain(kind, monkeypatch):
+    """The decode chain on the register-stationary GEMMs against the same chain on the tile kernels (plan built with
+    DH_NO_DECODE_WREG): 64 images x beam 5 (320 rows: the wreg threshold) -- same tokens, same lengths, bit for bit."""
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import synth_state_dict
+    model = getattr(M, kind)(1000, hid_dim=512, n_layers=2).eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=4321))
+    model = model.to(HALF).cuda()
+    imgs = synth_images(64, seed=11).cuda()
+    with torch.no_grad():
+        t1, l1 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
+        assert "wo_pk" in model.decoder._get_plan()["layers"][0]
+        monkeypatch.setenv("DH_NO_DECODE_WREG", "1")
+        model.decoder._drop_plan()
+        assert "wo_pk" not in model.decoder._get_plan()["layers"][0]
+        t2, l2 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
+        monkeypatch.delenv("DH_NO_DECODE_WREG")
+        model.decoder._drop_plan()
+    assert torch.equal(t1, t2) and torch.equal(l1, l2)

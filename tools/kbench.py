@@ -49,6 +49,9 @@ def main():
         res[f"{name}:linear_ln(plain)"] = timeit(lambda i: hip.linear_ln(a[i % 6], w[i % 6], b, out=out))
         if k == D:
             res[f"{name}:linear_ln(a_ln)"] = timeit(lambda i: hip.linear_ln(a[i % 6], w[i % 6], b, out=out, a_ln=(st[i % 6], 1e-5, cs)))
+            if hip.linear_ln_wreg_supported(n, k, False):
+                wp = [hip.pack_mfma_fragments(t) for t in w]
+                res[f"{name}:WREG(a_ln)"] = timeit(lambda i: hip.linear_ln_wreg(a[i % 6], wp[i % 6], n, b, out=out, a_ln=(st[i % 6], 1e-5, cs), relu=(name == "ffn1")))
         if n == D:
             res[f"{name}:linear(+res)"] = timeit(lambda i: hip.linear(a[i % 6], w[i % 6], b, out=out, residual=x[(i + 1) % 6]))
             stats_out = torch.empty(R, 8, 2, device=dev)
@@ -60,6 +63,9 @@ def main():
                 hip._launch("dh_linear_ln", a[i % 6].data_ptr(), k, w[i % 6].data_ptr(), k, b.data_ptr(), x[(i + 1) % 6].data_ptr(), D,
                             out.data_ptr(), n, R, n, k, 0, hip._c.byref(fl), hip._dt(out), hip._stream())
             res[f"{name}:linear_ln(r_ln+stats)"] = timeit(f)
+            wp2 = [hip.pack_mfma_fragments(t) for t in w]
+            res[f"{name}:WREG(r_ln+stats)"] = timeit(lambda i: hip.linear_ln_wreg(a[i % 6], wp2[i % 6], n, b, out=out, residual=x[(i + 1) % 6],
+                                                                                  r_ln=(st[i % 6], 1e-5, gamma, beta)))
     # padded row strides (power-of-two row strides of 1 KB / 4 KB put the 8 rows of an LDS-DMA piece on few L2 channels?)
     for name, n, k in (("proj", D, D), ("ffn2", D, PF), ("ffn1", PF, D)):
         for pad in (0, 64, 32):
