@@ -48,9 +48,10 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_wreg_kernel(LwParams p) {
     constexpr int WIN_SLABS = 65536 / SLABB, WIN = WIN_SLABS * SLABB, NWIN = (NSLAB + WIN_SLABS - 1) / WIN_SLABS;
     constexpr int PF = 3;                              // LDS fragment reads this many MFMAs ahead
     constexpr int CHUNKS = BN / 8, SLOTS = BN / 4, EP_IT = (RL * CHUNKS + NT - 1) / NT;
-    static_assert(RL % 8 == 0 && NSLAB * SLABB <= 163840 && RL * BN * 4 <= NSLAB * SLABB, "LDS budget");
+    static_assert(RL % 8 == 0 && RL <= NT && NSLAB * SLABB + (LNX == 0 ? RL * 8 : 0) <= 163840 && RL * BN * 4 <= NSLAB * SLABB, "LDS budget");
     static_assert((NSLAB * RG) % NW == 0, "pieces per wave");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLAB * SLABB];
+    constexpr int STAT_BYTES = LNX == 0 ? RL * 8 : 0;  // (mean, rstd) of the block's rows (deferred LayerNorm of the A rows)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLAB * SLABB + STAT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4, lr = lane >> 3, lpos = lane & 7;
@@ -66,13 +67,15 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_wreg_kernel(LwParams p) {
 
     // ---- epilogue operands: requested BEFORE the LDS-DMA transfers (ordinary loads the compiler counts; vmcnt retires in order) -------
     const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + 16 * wave + 4 * lq);
-    float4 a_raw[TM][4];
+    // deferred LayerNorm of the A rows: thread r < RL fetches the statistics partials of block row r (64 contiguous bytes per row:
+    // 4 coalesced instructions per wave) and leaves (mean, rstd) in LDS for the lanes whose accumulators hold that row -- fetched per
+    // accumulator lane instead, they are 4 TM scattered loads per wave, as many vector-memory instructions as the operands themselves
+    float4 a_raw[4];
     float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool a_ln = LNX == 0 && p.a_stats != nullptr;
     if (LNX == 0) {
         if (a_ln) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) ln_load(p.a_stats + (size_t)min(m0 + 16 * i + l15, p.M - 1) * p.a_nt, p.a_nt, a_raw[i]);
+            if (tid < RL) ln_load(p.a_stats + (size_t)min(m0 + tid, p.M - 1) * p.a_nt, p.a_nt, a_raw);
             cs4 = *reinterpret_cast<const float4*>(p.a_colsum + n0 + 16 * wave + 4 * lq);
         }
     }
@@ -120,15 +123,24 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_wreg_kernel(LwParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces, fragments and operands have landed
     // statistics -> mean / rstd now (frees the raw partials' registers before the MFMA loop)
     float a_mu[TM], a_rs[TM], r_mu[EP_IT], r_rs[EP_IT];
-    if (a_ln) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) ln_math(a_raw[i], p.a_nt, p.a_eps, a_mu[i], a_rs[i]);
+    float2* row_stat = reinterpret_cast<float2*>(lds + NSLAB * SLABB);
+    if (a_ln && tid < RL) {
+        float mu, rs;
+        ln_math(a_raw, p.a_nt, p.a_eps, mu, rs);
+        row_stat[tid] = make_float2(mu, rs);
     }
     if (r_ln) {
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) ln_math(r_raw[it], p.r_nt, p.r_eps, r_mu[it], r_rs[it]);
     }
     __syncthreads();
+    if (a_ln) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float2 ms = row_stat[min(16 * i + l15, RL - 1)];
+            a_mu[i] = ms.x; a_rs[i] = ms.y;
+        }
+    }
 
     // ---- TM row tiles x KF k-steps; fragment reads PF steps ahead of their MFMAs ---------------------------------------------------------
     dh_f32x4 acc[TM];

@@ -208,10 +208,10 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 ent["w1_f"], ent["b1_f"], ent["cs_1"] = fold(ent["w1"], ent["b1"], ent["ln2"] if self._cross else ent["ln1"])
             if torch.cuda.is_available() and self.classifier.weight.is_cuda and not os.environ.get("DH_NO_DECODE_WREG"):
                 # register-stationary decode GEMMs (dh_linear_ln_wreg): fragment-packed copies of the chain's weights, once per plan
-                d, pf = self.hid_dim, self.layers[0].pf.fc_1.out_features
+                hd, pf = self.hid_dim, self.layers[0].pf.fc_1.out_features
                 for i, ent in enumerate(layers):
-                    for name, src, n, k, lnx in (("wqkv_pk", "wqkv_f" if i > 0 else "wqkv", 3 * d, d, False), ("wo_pk", "wo", d, d, True),
-                                                 ("weo_pk", "weo", d, d, True), ("w1_pk", "w1_f", pf, d, False), ("w2_pk", "w2", d, pf, True)):
+                    for name, src, n, k, lnx in (("wqkv_pk", "wqkv_f" if i > 0 else "wqkv", 3 * hd, hd, False), ("wo_pk", "wo", hd, hd, True),
+                                                 ("weo_pk", "weo", hd, hd, True), ("w1_pk", "w1_f", pf, hd, False), ("w2_pk", "w2", hd, pf, True)):
                         if src in ent and hip.linear_ln_wreg_supported(n, k, lnx):
                             ent[name] = hip.pack_mfma_fragments(ent[src].contiguous())
         return dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
