@@ -26,14 +26,24 @@ struct AttnParams {
     int row_si;                           // compact row of (image, w) = img * row_si + w (decode: rows_per_img; prefill chunks: n_pos)
 };
 
+// Beam row of this wave: a workgroup holds DH_ATTN_RPB (= 16) waves = 16 rows of its image; images with more rows (beam_size > 16,
+// beam.py:7-9 allows any beam_size <= top_k) take blockIdx.z row blocks.  Waves past the image's last row compute a copy of
+// that row (they still join the block barriers and own an LDS strip) and store nothing.
+#define DH_ATTN_RPB 16
+#define DH_ATTN_ROW(w, ok)                                                                   \
+    const int w##_raw = (int)blockIdx.z * DH_ATTN_RPB + (int)(threadIdx.x >> 6);             \
+    const bool ok = w##_raw < p.rows_per_img;                                                \
+    const int w = ok ? w##_raw : p.rows_per_img - 1
+
 template <typename T, bool CROSS>
 __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams<T> p) {
     constexpr int VN = Vec16<T>::N;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.x, h = blockIdx.y, wl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    DH_ATTN_ROW(w, w_ok);
     const int rc = img * p.row_si + w, rl = rc * p.row_mult;
     const int dh = p.dh, D = p.D, L = p.L, t = L - 1;
-    float* qs = smem + (size_t)w * (dh + 2 * p.lcap);
+    float* qs = smem + (size_t)wl * (dh + 2 * p.lcap);
     float* sc = qs + dh;
     int* ph = reinterpret_cast<int*>(sc + p.lcap);
 
@@ -98,6 +108,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams<T> p) {
             else vp = p.vnew + (size_t)rc * p.ldnew + h * dh;
             acc = fmaf(pj, ldf(vp + d), acc);
         }
+        if (!w_ok) continue;
         stf(p.out + (size_t)rc * D + h * dh + d, acc);
         if (!CROSS) {   // append this position to the cache at the row's own logical slot
             p.kc[((size_t)t * p.rows_total + rl) * D + h * dh + d] = p.knew[(size_t)rc * p.ldnew + h * dh + d];
@@ -141,11 +152,12 @@ template <typename T, bool CROSS, int DH>
 __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p) {
     constexpr int LPK = DH / 8, KPI = 64 / LPK;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.x, h = blockIdx.y, wl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    DH_ATTN_ROW(w, w_ok);
     const int rc = img * p.row_si + w, rl = rc * p.row_mult;
     const int D = p.D, L = p.L, t = L - 1;
     const int kg = lane / LPK, dc = lane % LPK;
-    float* sc = smem + (size_t)w * 2 * p.lcap;
+    float* sc = smem + (size_t)wl * 2 * p.lcap;
     int* ph = reinterpret_cast<int*>(sc + p.lcap);
 
     float qv[8];
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p)
     for (int u = 0; u < 8; ++u)
 #pragma unroll
         for (int s2 = LPK; s2 < 64; s2 <<= 1) o[u] += __shfl_xor(o[u], s2, 64);
-    if (kg == 0) {
+    if (kg == 0 && w_ok) {
         store8(p.out + (size_t)rc * D + h * DH + dc * 8, o);
         if (!CROSS) {   // append this position to the cache at the row's own logical slot
             copy8(p.kc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.knew + (size_t)rc * p.ldnew + h * DH + dc * 8);
@@ -258,7 +270,9 @@ __device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float (&v)[8])
 template <typename T, bool CROSS, int DH, int NIT>
 __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) {
     constexpr int LPK = DH / 8, KPI = 64 / LPK;
-    const int img = blockIdx.x, h = blockIdx.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.x, h = blockIdx.y, lane = threadIdx.x & 63;
+    DH_ATTN_ROW(w, w_ok);
+    if (!w_ok) return;                                   // (no LDS, no block barrier in this kernel)
     const int rc = img * p.row_si + w, rl = rc * p.row_mult;
     const int D = p.D, L = p.L, t = L - 1;
     const int kg = lane / LPK, dc = lane % LPK;
@@ -381,12 +395,13 @@ __global__ __launch_bounds__(1024) void attn_cross_lds_kernel(AttnParams<T> p) {
     constexpr int DH = 64, VN = Vec16<T>::N, CPR = DH / VN;          // 16-byte chunks per row
     constexpr int ROW = DH + VN;                                       // padded row (elements)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int img = blockIdx.x, h0 = blockIdx.y * HPB, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int img = blockIdx.x, h0 = blockIdx.y * HPB, wl = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    DH_ATTN_ROW(w, w_ok);
     const int nthreads = blockDim.x, S = p.L, D = p.D;
     T* ks = reinterpret_cast<T*>(smem_raw);                            // [HPB][S][ROW]
     T* vs = ks + (size_t)HPB * S * ROW;                                // [HPB][S][ROW]
     float* fbase = reinterpret_cast<float*>(vs + (size_t)HPB * S * ROW);   // per wave: q[HPB*64] then p[64]
-    float* qs = fbase + w * (HPB * 64 + 64);
+    float* qs = fbase + wl * (HPB * 64 + 64);
     float* ps = qs + HPB * 64;
     const int per_head = S * CPR;
     for (int c = threadIdx.x; c < HPB * per_head * 2; c += nthreads) {
@@ -436,7 +451,7 @@ __global__ __launch_bounds__(1024) void attn_cross_lds_kernel(AttnParams<T> p) {
         }
         o0 += __shfl_xor(o0, 32, 64);
         o1 += __shfl_xor(o1, 32, 64);
-        if (par == 0) {
+        if (par == 0 && w_ok) {
             stf(p.out + (size_t)rc * D + (h0 + hh) * DH + d2, o0);
             stf(p.out + (size_t)rc * D + (h0 + hh) * DH + d2 + 1, o1);
         }
@@ -446,8 +461,9 @@ __global__ __launch_bounds__(1024) void attn_cross_lds_kernel(AttnParams<T> p) {
 
 template <typename T, bool CROSS>
 static bool launch_fast(AttnParams<T>& p, int n_img, int n_heads, int rows_per_img, hipStream_t s) {
-    const size_t lds = (size_t)rows_per_img * 2 * p.lcap * sizeof(float);
-    const dim3 grid(n_img, n_heads), block(64 * rows_per_img);
+    const int rpb = rows_per_img < DH_ATTN_RPB ? rows_per_img : DH_ATTN_RPB;
+    const size_t lds = (size_t)rpb * 2 * p.lcap * sizeof(float);
+    const dim3 grid(n_img, n_heads, dh_cdiv(rows_per_img, DH_ATTN_RPB)), block(64 * rpb);
     if (p.dh == 64 && p.L <= (sizeof(T) == 2 ? 56 : 40)) {    // the caption models' shape: whole history in registers
         if (p.L <= 16) hipLaunchKernelGGL((attn_decode_reg_kernel<T, CROSS, 64, 2>), grid, block, 0, s, p);
         else if (p.L <= 40) hipLaunchKernelGGL((attn_decode_reg_kernel<T, CROSS, 64, 5>), grid, block, 0, s, p);
@@ -473,8 +489,9 @@ static void launch_self(const void* qkv, void* kcache, void* vcache, const int32
     p.rows_per_img = rows_per_img; p.row_mult = row_mult; p.rows_total = rows_total; p.row_si = rows_per_img;
     p.L = t + 1; p.D = D; p.dh = D / n_heads; p.lcap = (t + 1 + 3) & ~3; p.pad_index = pad_index; p.scale = scale;
     if (launch_fast<T, false>(p, n_img, n_heads, rows_per_img, s)) return;
-    const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
-    hipLaunchKernelGGL((attn_decode_kernel<T, false>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds, s, p);
+    const int rpb = rows_per_img < DH_ATTN_RPB ? rows_per_img : DH_ATTN_RPB;
+    const size_t lds = (size_t)rpb * (p.dh + 2 * p.lcap) * sizeof(float);
+    hipLaunchKernelGGL((attn_decode_kernel<T, false>), dim3(n_img, n_heads, dh_cdiv(rows_per_img, DH_ATTN_RPB)), dim3(64 * rpb), lds, s, p);
 }
 
 extern "C" int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
@@ -502,16 +519,18 @@ static void launch_cross(const void* q, int ldq, const void* kv, const uint8_t* 
     if (p.dh == 64 && S <= 64) {                         // the caption models' shape: K|V staged once per (image, head group)
         constexpr int VN = Vec16<T>::N;
         const int hpb = 1;     // measured: 1 head per workgroup 20 us, 4 heads 24 us per launch (per-wave latency chain dominates)
-        const size_t lds = (size_t)2 * hpb * S * (64 + VN) * sizeof(T) + (size_t)rows_per_img * (hpb * 64 + 64) * sizeof(float);
-        const dim3 grid(n_img, n_heads / hpb), block(64 * rows_per_img);
+        const int rpb = rows_per_img < DH_ATTN_RPB ? rows_per_img : DH_ATTN_RPB;
+        const size_t lds = (size_t)2 * hpb * S * (64 + VN) * sizeof(T) + (size_t)rpb * (hpb * 64 + 64) * sizeof(float);
+        const dim3 grid(n_img, n_heads / hpb, dh_cdiv(rows_per_img, DH_ATTN_RPB)), block(64 * rpb);
         if (hpb == 4) hipLaunchKernelGGL((attn_cross_lds_kernel<T, 4>), grid, block, lds, s, p);
         else if (hpb == 2) hipLaunchKernelGGL((attn_cross_lds_kernel<T, 2>), grid, block, lds, s, p);
         else hipLaunchKernelGGL((attn_cross_lds_kernel<T, 1>), grid, block, lds, s, p);
         return;
     }
     if (launch_fast<T, true>(p, n_img, n_heads, rows_per_img, s)) return;
-    const size_t lds = (size_t)rows_per_img * (p.dh + 2 * p.lcap) * sizeof(float);
-    hipLaunchKernelGGL((attn_decode_kernel<T, true>), dim3(n_img, n_heads), dim3(64 * rows_per_img), lds, s, p);
+    const int rpb = rows_per_img < DH_ATTN_RPB ? rows_per_img : DH_ATTN_RPB;
+    const size_t lds = (size_t)rpb * (p.dh + 2 * p.lcap) * sizeof(float);
+    hipLaunchKernelGGL((attn_decode_kernel<T, true>), dim3(n_img, n_heads, dh_cdiv(rows_per_img, DH_ATTN_RPB)), dim3(64 * rpb), lds, s, p);
 }
 
 extern "C" int dh_attn_cross_decode(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out,
@@ -632,8 +651,8 @@ extern "C" int dh_attn_cross_prefill(const void* q, int ldq, const void* kv, con
     DH_REQUIRE(((D / n_heads) % 8) == 0 && ldq >= D);
     const size_t esz = dtype == DH_F32 ? 4 : 2;
     DhProfScope prof("dh_attn_cross_prefill", 4.0 * n_img * n_pos * S * D, (double)esz * n_img * (S * 2.0 * D + n_pos * 2.0 * D), stream);
-    for (int t0 = 0; t0 < n_pos; t0 += DH_BEAM_MAX_BEAMS) {
-        const int cnt = n_pos - t0 < DH_BEAM_MAX_BEAMS ? n_pos - t0 : DH_BEAM_MAX_BEAMS;
+    for (int t0 = 0; t0 < n_pos; t0 += DH_ATTN_RPB) {
+        const int cnt = n_pos - t0 < DH_ATTN_RPB ? n_pos - t0 : DH_ATTN_RPB;
         const char* qc = (const char*)q + (size_t)t0 * ldq * esz;
         char* oc = (char*)out + (size_t)t0 * D * esz;
         DH_DISPATCH_T(dtype, launch_cross<T>(qc, ldq, kv, keymask, oc, n_img, cnt, S, D, n_heads, scale, (hipStream_t)stream, n_pos));

@@ -506,7 +506,9 @@ struct SelLds {
 #define DH_SEL_STAGE_MAX 3072                           // ints available for `stage` in the fused step
 
 // The candidate draw + in-place rewrite of one image's beam state, executed by ONE wave (lane = 0..63); LDS hand-overs are
-// wave-local (wave_lds_sync), so the same body serves the stand-alone kernel and the tail of the fused row kernel.
+// wave-local (wave_lds_sync), so the same body serves the stand-alone kernel and the tail of the fused row kernel.  MB = the largest beam
+// count the instantiation takes (register arrays of the beams' flags / scores): 16 for the usual settings, 64 for beam_size > 16.
+template <int MB>
 __device__ __forceinline__ void beam_select_image(const SelectParams& p, const int img, const int lane, const SelLds& L,
                                                   const bool shared_picks = false) {
     int32_t* stage = L.stage;
@@ -532,12 +534,12 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
         }
     }
     const uint8_t is_done = p.done[img];
-    uint8_t was_ended[DH_BEAM_MAX_BEAMS];
+    uint8_t was_ended[MB];
 #pragma unroll
-    for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b) was_ended[b] = p.ended[base + min(b, B - 1)];   // one round trip for all
-    float val_b[DH_BEAM_MAX_BEAMS];
+    for (int b = 0; b < MB; ++b) was_ended[b] = p.ended[base + min(b, B - 1)];   // one round trip for all
+    float val_b[MB];
 #pragma unroll
-    for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b) val_b[b] = p.vals[base + min(b, B - 1)];
+    for (int b = 0; b < MB; ++b) val_b[b] = p.vals[base + min(b, B - 1)];
     if (pre) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); wave_lds_sync(); }
     if (is_done) return;
 
@@ -552,20 +554,20 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
         }
         if (lane == 0) s_n = B;
     } else {
-        int off[DH_BEAM_MAX_BEAMS + 1];
+        int off[MB + 1];
         off[0] = 0;
 #pragma unroll
-        for (int b = 0; b < DH_BEAM_MAX_BEAMS; ++b)
+        for (int b = 0; b < MB; ++b)
             off[b + 1] = off[b] + (b < B ? (was_ended[b] ? 1 : B) : 0);
         const int total = off[B];
         for (int c = lane; c < total; c += 64) {
             int b = 0;
 #pragma unroll
-            for (int k = 1; k < DH_BEAM_MAX_BEAMS; ++k) b += (k < B && c >= off[k]);
+            for (int k = 1; k < MB; ++k) b += (k < B && c >= off[k]);
             const int j = c - off[b];
             bool was = false; float vb = 0.f;             // (static register indexing: b is a run-time value)
 #pragma unroll
-            for (int k = 0; k < DH_BEAM_MAX_BEAMS; ++k) if (k == b) { was = was_ended[k] != 0; vb = val_b[k]; }
+            for (int k = 0; k < MB; ++k) if (k == b) { was = was_ended[k] != 0; vb = val_b[k]; }
             const int tok = was ? 0 : (pre ? L.pki[b * B + j] : pick_load_idx(p.pick_idx, (size_t)(base + b) * B + j, shared_picks));
             ctok[c] = tok;
             cval[c] = vb + (was ? 0.f : (pre ? L.pkv[b * B + j] : pick_load_val(p.pick_val, (size_t)(base + b) * B + j, shared_picks)));
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
             const SelLds SL{pool, pool + DH_SEL_STAGE_MAX, pool + DH_SEL_STAGE_MAX + 256, pool + DH_SEL_STAGE_MAX + 512,
                             reinterpret_cast<float*>(pool + DH_SEL_STAGE_MAX + 528), reinterpret_cast<float*>(pool + DH_SEL_STAGE_MAX + 784),
                             reinterpret_cast<uint8_t*>(pool + DH_SEL_STAGE_MAX + 1040), pool + DH_SEL_STAGE_MAX + 1104};
-            beam_select_image(sel, img, lane, SL, true);
+            beam_select_image<16>(sel, img, lane, SL, true);
         }
     }
 }
@@ -785,16 +787,17 @@ extern "C" int dh_beam_row_sample_exact(const float* logits, int ldl, int V, int
 
 // ------------------------------------------------------------------------------------------------
 
+template <int MB>
 __global__ __launch_bounds__(64) void beam_select_kernel(SelectParams p) {
     extern __shared__ int32_t stage[];
-    __shared__ int ctok[256], cpar[256], keep[DH_BEAM_MAX_BEAMS];
-    __shared__ float cval[256], q[256];
-    __shared__ uint8_t cend[256];
+    __shared__ int ctok[MB * MB], cpar[MB * MB], keep[MB];
+    __shared__ float cval[MB * MB], q[MB * MB];
+    __shared__ uint8_t cend[MB * MB];
     __shared__ int s_n;
-    __shared__ int32_t pki[DH_BEAM_MAX_BEAMS * DH_BEAM_MAX_BEAMS];
-    __shared__ float pkv[DH_BEAM_MAX_BEAMS * DH_BEAM_MAX_BEAMS];
+    __shared__ int32_t pki[MB * MB];
+    __shared__ float pkv[MB * MB];
     const SelLds L{stage, ctok, cpar, keep, cval, q, cend, &s_n, pki, pkv};
-    beam_select_image(p, blockIdx.x, threadIdx.x, L);
+    beam_select_image<MB>(p, blockIdx.x, threadIdx.x, L);
 }
 
 extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* tokens, int tok_ld,
@@ -810,7 +813,9 @@ extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, in
     SelectParams p{pick_idx, pick_val, tokens, tok_ld, vals, ended, src, src_ld, parent, hparent, done, end_step,
                    beam, first, first_sets_ended, write_pos, t, step_index, eos_index, img0, temperature, noise, seed, seed_ptr};
     const size_t lds = (size_t)beam * (tok_ld + (src ? t : 0)) * sizeof(int32_t);
-    hipLaunchKernelGGL(beam_select_kernel, dim3(n_img), dim3(64), lds, (hipStream_t)stream, p);
+    DH_REQUIRE(lds <= 56 * 1024);                         // beam * (tok_ld + t) ints of staging next to the candidate arrays
+    if (beam <= 16) hipLaunchKernelGGL(beam_select_kernel<16>, dim3(n_img), dim3(64), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(beam_select_kernel<DH_BEAM_MAX_BEAMS>, dim3(n_img), dim3(64), lds, (hipStream_t)stream, p);   // beam.py:7-9: any beam_size <= top_k
     DH_LAUNCH_CHECK();
 }
 
@@ -831,7 +836,7 @@ extern "C" int dh_beam_step_groups(const float* logits, int ldl, int V, const fl
                (long long)n_groups * group_cols >= V);
     DH_REQUIRE(tokens && vals && ended && parent && hparent && done && end_step && arrive && tok_ld > 0 && t >= 0 && (!src || src_ld > t));
     DH_REQUIRE((rows % rows_per_img) == 0 && (first ? rows_per_img == 1 : rows_per_img == beam));
-    if ((long long)beam * (tok_ld + (src ? t : 0)) > DH_SEL_STAGE_MAX) return DH_ERR_UNSUPPORTED;
+    if ((long long)beam * (tok_ld + (src ? t : 0)) > DH_SEL_STAGE_MAX || beam > 16) return DH_ERR_UNSUPPORTED;
     DhProfScope prof("dh_beam_step", 0.0, 0.0, stream);
     SelectParams sp{pick_idx, pick_val, tokens, tok_ld, vals, ended, src, src_ld, parent, hparent, done, end_step,
                     beam, first, first_sets_ended, write_pos, t, step, eos_index, img0, temperature, cand_noise, seed, seed_ptr};

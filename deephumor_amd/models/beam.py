@@ -23,6 +23,68 @@ class BeamOverflow(RuntimeError):
     the decoders catch this and repeat the batch with ``exact=True`` (the general sampler, which draws such rows over the whole row)."""
 
 
+class TorchRngNoise:
+    """``rng="torch"``: the Exp(1) noise of every draw taken from torch CPU generators in the reference's order and shapes, so that
+    the sampled caption is the one the reference returns under the same generator state.  ``torch.multinomial(p, k)`` on the CPU
+    is ``topk(p / empty_like(p).exponential_(1), k)``: the reference consumes, per decode step, one ``[n_rows, V]`` fill for the
+    row draw (beam.py:39-48 via :57-58; one row at the first step), one ``[n_candidates]`` fill for the candidate draw
+    (rnn_models.py:116-121, transformers.py:557-562; ``n_candidates = sum(1 if ended else beam)``, beam.py:72-101) and one
+    ``[beam]`` fill for the final draw (rnn_models.py:140, transformers.py:576); nothing once every beam has ended (the ``break`` at
+    rnn_models.py:131 / transformers.py:585).
+
+    ``seed=None`` (one image only): the draws come from torch's DEFAULT generator -- ``torch.manual_seed(s); model.generate(image,
+    rng="torch")`` is then the reference's own call sequence.  ``seed=int``: image ``i`` of the batch (global index ``img0 + i``)
+    draws from its own ``torch.Generator().manual_seed(seed + img0 + i)`` -- row ``i`` equals the reference's
+    ``torch.manual_seed(seed + img0 + i); model.generate(image_i)``, whatever the batch composition or rank layout.
+
+    A parity feature, not a throughput path: the noise is generated on the host (rows x V floats per step) and the ended flags are
+    read back once per step."""
+
+    def __init__(self, seed, n_img, img0=0):
+        if seed is None and n_img != 1:
+            raise ValueError('rng="torch" with seed=None draws from torch\'s default generator, which only one image at a time can '
+                             'consume in the reference\'s order: pass seed=<int> (image i then draws from manual_seed(seed + i))')
+        self.seed, self.n_img, self.img0 = seed, int(n_img), int(img0)
+        self.gens, self.h, self._state0 = None, None, None
+
+    def attach(self, helper):
+        """Called by the helper that will consume the noise; (re-)positions the generators at the start of their streams, so a
+        repeated session (``BeamOverflow`` retry) replays the same draws."""
+        self.h = helper
+        if self.seed is None:
+            if self._state0 is None:
+                self._state0 = torch.get_rng_state()
+            else:
+                torch.set_rng_state(self._state0)
+        else:
+            self.gens = [torch.Generator().manual_seed(int(self.seed) + self.img0 + i) for i in range(self.n_img)]
+
+    def _exp(self, i, n):
+        return torch.empty(n).exponential_(1, generator=None if self.gens is None else self.gens[i])
+
+    def __call__(self, kind, step, shape):
+        h, b = self.h, self.h.beam_size
+        if kind == "multinomial":             # the method surface (sample_k_indices): one fill of the argument's shape
+            return self._exp(0, int(torch.Size(shape).numel())).view(shape)
+        done = h.done.cpu().tolist()
+        out = torch.ones(shape)
+        if kind == "row":
+            rpi, v = shape[0] // self.n_img, shape[1]
+            for i in range(self.n_img):
+                if not done[i]:
+                    out[i * rpi:(i + 1) * rpi] = self._exp(i, rpi * v).view(rpi, v)
+        elif kind == "cand":
+            ended = h._ended.cpu().view(self.n_img, b).tolist()
+            for i in range(self.n_img):
+                if not done[i]:
+                    n_cand = sum(1 if e else b for e in ended[i])
+                    out[i, :n_cand] = self._exp(i, n_cand)
+        else:                                 # "final": one fill over the beams
+            for i in range(self.n_img):
+                out[i] = self._exp(i, shape[1])
+        return out
+
+
 class BeamSearchHelper:
     """Beam state for ``n_img`` images x ``beam_size`` beams.
 
@@ -34,12 +96,14 @@ class BeamSearchHelper:
                  n_img=1, max_len=25, src_len=0, seed=0, img0=0, noise_source=None, seed_tensor=None, exact=False):
         assert beam_size <= top_k, '`beam_size` should be less than `top_k`'          # beam.py:9
         self.exact = bool(exact)          # row draws through the general sampler only (see BeamOverflow)
-        if beam_size > hip.MAX_BEAMS:
+        if beam_size > hip.MAX_BEAMS:     # one wave draws among an image's beams (dh_beam_finalize); the reference has no limit
             raise ValueError(f"beam_size <= {hip.MAX_BEAMS} supported")
         self.temperature, self.beam_size, self.top_k = float(temperature), int(beam_size), int(top_k)
         self.unk_index, self.eos_index, self.device = unk_index, eos_index, device
         self.n_img, self.max_len = n_img, max_len
         self.seed, self.img0, self.noise_source = int(seed), int(img0), noise_source
+        if hasattr(noise_source, "attach"):
+            noise_source.attach(self)
         # optional device-resident int64 word XOR-ed into the seed by the kernels: lets a captured hipGraph of the
         # whole decode be replayed with a fresh seed (kernel arguments are frozen at capture)
         self.seed_tensor = seed_tensor
@@ -66,7 +130,7 @@ class BeamSearchHelper:
         # one launch per step (dh_beam_step_groups; needs an image's token + ancestor rows to fit the row kernel's LDS).  Same
         # results, measured gain within run-to-run noise (C2 9.03 / 8.72 vs 9.01 ms, C3 25.2 / 24.9 vs 25.4 ms per step), so the two
         # launches stay the default and DH_FUSED_BEAM_STEP=1 opts in
-        self.fused_step = (beam_size * (max_len + src_len) <= hip.SEL_STAGE_MAX) and bool(os.environ.get("DH_FUSED_BEAM_STEP"))
+        self.fused_step = (beam_size * (max_len + src_len) <= hip.SEL_STAGE_MAX) and beam_size <= 16 and bool(os.environ.get("DH_FUSED_BEAM_STEP"))
         self.pick_idx = torch.empty((r, beam_size), dtype=torch.int32, device=dev)
         self.pick_val = torch.empty((r, beam_size), dtype=torch.float32, device=dev)
         # KV-cache ancestor table (Transformer only): src[r, j] = row holding position j of r's history
@@ -239,6 +303,33 @@ class BeamSearchHelper:
         hip.beam_expand(new_ind, gathered, ended, seqs, vals, b, self.eos_index, prev_seqs, prev_vals, out_ind, out_val, out_ended)
         self.has_ended = out_ended.view(torch.bool)
         return (prev_seqs, prev_vals), (out_ind, out_val)
+
+
+def make_noise_source(rng, seed, noise_source, lo, hi, img0):
+    """The noise source of one decode session (images ``[lo, hi)`` of the batch): the caller's hook, or the torch-generator replay
+    of ``rng="torch"`` (``TorchRngNoise``); ``rng`` None / "philox" = the kernels' own counter-based generator."""
+    if rng in (None, "philox"):
+        return noise_source
+    if rng != "torch":
+        raise ValueError(f'rng must be None, "philox" or "torch", not {rng!r}')
+    if noise_source is not None:
+        raise ValueError('rng="torch" and noise_source are mutually exclusive')
+    return TorchRngNoise(seed, hi - lo, img0 + lo)
+
+
+_overflow_warned = False
+
+
+def warn_overflow_retry():
+    """One warning per process when a batch is decoded a second time through the general sampler (``BeamOverflow``): user hooks
+    (``logits_hook``, ``noise_source``) then fire once more for the same steps."""
+    global _overflow_warned
+    if not _overflow_warned:
+        _overflow_warned = True
+        import warnings
+        warnings.warn("deephumor_amd: a row had more logits tied at its top-k threshold than the pre-filtered samplers hold (flat "
+                      "logits); the batch is decoded again with exact=True -- logits_hook / noise_source callbacks run a second time",
+                      RuntimeWarning, stacklevel=3)
 
 
 def resolve_seed(seed, noise_source=None):

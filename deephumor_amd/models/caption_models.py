@@ -68,11 +68,16 @@ class _CaptioningBase(nn.Module):
         was captured with.  Every cached graph therefore records the models' plan signature and keeps the plans
         themselves alive; ``load_state_dict`` / ``.to()`` / in-place weight updates change the signature and the
         graph is re-captured instead of replayed against stale or freed memory."""
-        from .beam import BeamOverflow, BeamSearchHelper, resolve_seed
+        from .beam import BeamOverflow, BeamSearchHelper, resolve_seed, warn_overflow_retry
+        if kw.get("rng") == "torch":      # host-generated noise (parity mode): nothing to replay
+            return self.generate_batch(*inputs, caption=caption, seed=seed, **kw)
         seed = resolve_seed(seed)
         key = (tuple((tuple(t.shape), t.dtype) for t in inputs), None if caption is None else tuple(caption.shape),
                tuple(sorted(kw.items())), next(self.parameters()).dtype)
         cache = self.__dict__.setdefault("_graphs", {})
+        eager_keys = self.__dict__.setdefault("_graph_overflowed", set())
+        if key in eager_keys:             # this configuration overflowed the pre-filtered samplers before (flat logits): straight to
+            return self.generate_batch(*inputs, caption=caption, seed=seed, exact=True, **kw)     # the general sampler, eagerly
         state = cache.get(key)
         sig = self._plan_signature()
         if state is not None and state[5] != sig:
@@ -111,8 +116,10 @@ class _CaptioningBase(nn.Module):
         graph.replay()
         try:
             BeamSearchHelper.raise_for(int(err.item()))
-        except BeamOverflow:              # flat logits: the captured chain cannot switch samplers -- this batch eagerly (it repeats itself exact)
-            return self.generate_batch(*inputs, caption=caption, seed=seed, **kw)
+        except BeamOverflow:              # flat logits: the captured chain cannot switch samplers -- this batch (and, from now on, this
+            warn_overflow_retry()         # configuration) eagerly through the general sampler
+            eager_keys.add(key)
+            return self.generate_batch(*inputs, caption=caption, seed=seed, exact=True, **kw)
         return toks.clone(), lens.clone()
 
 

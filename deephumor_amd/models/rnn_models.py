@@ -12,7 +12,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamOverflow, BeamSearchHelper, resolve_seed, run_interleaved
+from .beam import BeamOverflow, BeamSearchHelper, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
 
@@ -141,7 +141,7 @@ class LSTMDecoder(_Planned, nn.Module):
 
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, seed=None, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
-                       defer_check=False, early_stop_every=0, exact=False):
+                       defer_check=False, early_stop_every=0, exact=False, rng=None):
         """Batched beam-search sampling for ``image_emb [N, 1, E]`` or ``[N, E]``.
 
         Returns ``(tokens int64 [N, max_len] zero-padded, lengths int64 [N])``; row ``i`` equals
@@ -151,10 +151,14 @@ class LSTMDecoder(_Planned, nn.Module):
         ``early_stop_every=k`` (> 0) checks every k steps whether every image has finished (the reference's
         ``all_ended()`` break, rnn_models.py:131) and stops decoding then -- one host sync per check, same captions.
         ``exact=True`` draws every row through the general sampler from the start (what a batch is repeated with automatically
-        when flat logits overflow the pre-filtered samplers, see ``BeamOverflow``)."""
+        when flat logits overflow the pre-filtered samplers, see ``BeamOverflow``).
+        ``rng="torch"``: the draws consume torch CPU generators in the reference's order (``beam.TorchRngNoise``): on the fp32 path
+        ``torch.manual_seed(s); decoder.generate(emb, rng="torch")`` returns the reference's sampled caption; in a batch image ``i``
+        replays ``torch.manual_seed(seed + img0 + i)``."""
         self._check_mode()
         plan = self._get_plan()
-        seed = resolve_seed(seed, noise_source)
+        rng_seed = seed
+        seed = 0 if rng == "torch" else resolve_seed(seed, noise_source)
         image_emb = image_emb.reshape(image_emb.shape[0], -1).to(plan["dtype"]).contiguous()
 
         def session(lo, hi):
@@ -162,7 +166,8 @@ class LSTMDecoder(_Planned, nn.Module):
             r = n * b
             dev = image_emb.device
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
-                                      max_len=max_len, seed=seed, img0=img0 + lo, noise_source=noise_source, seed_tensor=seed_tensor,
+                                      max_len=max_len, seed=seed, img0=img0 + lo,
+                                      noise_source=make_noise_source(rng, rng_seed, noise_source, lo, hi, img0), seed_tensor=seed_tensor,
                                       exact=exact[0])
             pos = 0
             if caption is not None:
@@ -205,6 +210,7 @@ class LSTMDecoder(_Planned, nn.Module):
             if exact[0]:
                 raise
             exact[0] = True               # every row draw through the general sampler (same seed: same captions where nothing overflowed)
+            warn_overflow_retry()
             return run_interleaved(session, image_emb.shape[0], streams)
 
     def generate(self, image_emb, caption=None, max_len=25,

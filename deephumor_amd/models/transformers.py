@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamOverflow, BeamSearchHelper, resolve_seed, run_interleaved
+from .beam import BeamOverflow, BeamSearchHelper, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
 
@@ -218,18 +218,11 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=f(self.classifier.bias),
                     dtype=self.classifier.weight.dtype)
 
-    def _check_mode(self, cached=True):
+    def _check_mode(self):
         if self.training and self.dropout.p > 0:
             raise RuntimeError("deephumor_amd implements the inference path; call model.eval()")
         if self.pad_index is None:
             raise TypeError("pad_index=None is unusable in the reference too (transformers.py:451); pass an int")
-        if cached and self.pad_index == 1:
-            # the reference compares the image slot's stand-in id 1 (transformers.py:474) and the 0/1 encoder-row flags (:480-481)
-            # with pad_index.  pad_index == 1 masks the image slot: at the first position EVERY key is then masked and the reference's
-            # softmax spreads uniformly over all seq_len positions, future <pad> rows included -- a row no longer depends only on
-            # rows <= it, which is what incremental (KV-cached) decoding rests on.  Every other value is supported: 0 (the
-            # vocabulary's <pad>, data/vocab.py:5-12) and >= 2 (see _enc_for_cross).  (The module-API layers take explicit masks.)
-            raise NotImplementedError("TransformerDecoder kernels do not implement pad_index == 1 (the image slot's stand-in id)")
 
     def _enc_for_cross(self, enc_out, seq):
         """Encoder rows and their key mask as the reference's forward sees them (transformers.py:450-452, 480-481).
@@ -326,8 +319,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
         return x_out if x_out is not None else sc["x"]
 
     def _forward(self, x, enc_out, start_emb, num_positions=None, return_hidden=False):
-        if start_emb is None:
-            return self._forward_modules(x, enc_out)
+        if start_emb is None or self.pad_index == 1:
+            return self._forward_modules(x, enc_out, start_emb, return_hidden=return_hidden)
         self._check_mode()
         plan = self._get_plan()
         bs, dec_len = x.shape
@@ -355,21 +348,29 @@ class _IncrementalDecoder(_Planned, nn.Module):
         out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
         return out.view(bs, seq, -1)
 
-    def _forward_modules(self, x, enc_out):
-        """``forward`` WITHOUT a start embedding (transformers.py:432 default ``start_emb=None``; never used by the
-        captioning models): the reference's own formulation on the module-API layers -- pad ``x`` / ``enc_out`` to a
-        common length (:450-452), embeddings (:455-469), pad | causal input mask (:473-477), encoder-row mask
-        (:480-481), layers, classifier."""
-        self._check_mode(cached=False)        # eval mode and an int pad_index; any pad_index value works on the module-API layers
+    def _forward_modules(self, x, enc_out, start_emb=None, return_hidden=False):
+        """The reference's own formulation of ``forward`` on the module-API layers: pad ``x`` / ``enc_out`` to a common length
+        (transformers.py:450-452), embeddings (:455-469), pad | causal input mask over ``[1 | x]`` (:473-477), encoder-row mask
+        (:480-481), layers, classifier.  Two callers: ``forward`` WITHOUT a start embedding (:432 default ``start_emb=None``; never
+        used by the captioning models), and ``pad_index == 1``.  With pad_index 1 the image slot's stand-in id 1 (:474) counts as
+        padding: position 0 then has EVERY key masked and its softmax spreads uniformly over all ``seq_len`` positions, future
+        <pad> rows included (:110-114), and in the encoder attention the real patch rows (flag 1) are the masked ones -- a position
+        no longer depends only on positions <= it, so the KV-cached engine does not apply and every decode step re-runs the whole
+        sequence, exactly as the reference does (``_generate_reforward``)."""
+        self._check_mode()
         bs, dec_len = x.shape
         dt = self.classifier.weight.dtype
+        has_start = start_emb is not None
+        dec_len += int(has_start)
         seq = dec_len if enc_out is None else max(dec_len, enc_out.shape[1])
         if seq > self.pos_embedding.num_embeddings:
             raise IndexError("index out of range in self")
-        ids = torch.full((bs, seq), self.pad_index, dtype=torch.int64, device=x.device)
-        ids[:, :dec_len] = x
-        emb = hip.embed_prefill(self.tok_embedding.weight.detach(), self.pos_embedding.weight.detach(), None,
-                                ids.to(torch.int32).contiguous(), bs, seq, float(self.scale)).view(bs, seq, self.hid_dim)
+        toks = torch.full((bs, seq - int(has_start)), self.pad_index, dtype=torch.int64, device=x.device)
+        toks[:, :x.shape[1]] = x
+        ids = torch.cat([torch.ones((bs, 1), dtype=torch.int64, device=x.device), toks], 1) if has_start else toks   # :474
+        emb = hip.embed_prefill(self.tok_embedding.weight.detach(), self.pos_embedding.weight.detach(),
+                                start_emb.to(dt).contiguous() if has_start else None, toks.to(torch.int32).contiguous(), bs, seq,
+                                float(self.scale)).view(bs, seq, self.hid_dim)
         input_mask = hip.mask_or(get_pad_mask(ids, ids, pad_index=self.pad_index), get_autoregressive_mask(ids))
         h = emb
         if enc_out is not None:
@@ -381,9 +382,44 @@ class _IncrementalDecoder(_Planned, nn.Module):
         else:
             for layer in self.layers:
                 h = layer(h, input_mask=input_mask)
+        if return_hidden:
+            return h
         out = hip.linear(h.reshape(bs * seq, self.hid_dim), self.classifier.weight.detach(), _fp32(self.classifier.bias),
                          out_dtype=torch.float32, tag="vocab")
         return out.view(bs, seq, -1)
+
+    def _generate_reforward(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index, seed, img0,
+                            noise_source, logits_hook, rng, rng_seed, exact):
+        """``generate`` by the reference's own algorithm (transformers.py:521-577): the whole padded sequence of every beam row is
+        re-run for each token on the module-API layers.  Only ``pad_index == 1`` needs it (see ``_forward_modules``); the beam
+        bookkeeping is the batched engine's."""
+        n, b, dev = start_emb.shape[0], beam_size, start_emb.device
+        helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n, max_len=max_len,
+                                  src_len=max_len + 1, seed=seed, img0=img0,
+                                  noise_source=make_noise_source(rng, rng_seed, noise_source, 0, n, img0), exact=exact)
+        helper.tokens.fill_(self.pad_index)
+        pos = 0
+        if caption is not None:
+            pos = caption.shape[1]
+            helper.set_prefix(caption)
+        cls_w, cls_b = self.classifier.weight.detach(), _fp32(self.classifier.bias)
+
+        def logits_at(tokens, semb, enc, t):
+            h = self._forward_modules(tokens.long(), enc, semb, return_hidden=True)
+            return hip.linear(h[:, t].contiguous(), cls_w, cls_b, out_dtype=torch.float32, tag="vocab")
+
+        lg = logits_at(helper.tokens[::b], start_emb, enc_out, pos)
+        if logits_hook is not None:
+            logits_hook(pos, lg)
+        helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False)
+        semb = start_emb.repeat_interleave(b, 0)
+        enc = None if enc_out is None else enc_out.repeat_interleave(b, 0)
+        for i in range(pos + 1, max_len + 1):
+            lg = logits_at(helper.tokens, semb, enc, i)
+            if logits_hook is not None:
+                logits_hook(i, lg)
+            helper.step(lg, first=False, write_pos=i, t=i, step_index=i)
+        return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index)
 
     def _prefill_ok(self, plan, seq):
         """All positions at once (batched GEMMs, one causal-attention launch per layer) when the attention kernels'
@@ -461,13 +497,26 @@ class _IncrementalDecoder(_Planned, nn.Module):
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
                         seed=None, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
-                        defer_check=False, early_stop_every=0, exact=False):
+                        defer_check=False, early_stop_every=0, exact=False, rng=None):
         self._check_mode()
         plan = self._get_plan()
-        seed = resolve_seed(seed, noise_source)
+        rng_seed = seed                   # rng="torch": the draws replay torch CPU generators (beam.TorchRngNoise)
+        seed = 0 if rng == "torch" else resolve_seed(seed, noise_source)
         if max_len + 1 > self.pos_embedding.num_embeddings:
             raise IndexError("index out of range in self")    # reference: pos_embedding lookup, SURVEY.md section 5
         start_emb = start_emb.to(plan["dtype"]).contiguous()
+        if self.pad_index == 1:
+            if seed_tensor is not None or defer_check:
+                raise NotImplementedError("pad_index == 1 decodes by full re-forward on the host-driven module path: no hipGraph capture")
+            try:
+                return self._generate_reforward(start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index, seed,
+                                                img0, noise_source, logits_hook, rng, rng_seed, bool(exact))
+            except BeamOverflow:
+                if exact:
+                    raise
+                warn_overflow_retry()
+                return self._generate_reforward(start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index, seed,
+                                                img0, noise_source, logits_hook, rng, rng_seed, True)
 
         def session(lo, hi):
             """Decodes images [lo, hi); yields after every position (see ``run_interleaved``)."""
@@ -476,7 +525,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
             dev = start_emb.device
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
                                       max_len=max_len, src_len=max_len + 1, seed=seed, img0=img0 + lo,
-                                      noise_source=noise_source, seed_tensor=seed_tensor, exact=exact[0])
+                                      noise_source=make_noise_source(rng, rng_seed, noise_source, lo, hi, img0),
+                                      seed_tensor=seed_tensor, exact=exact[0])
             if self.pad_index != 0:
                 helper.tokens.fill_(self.pad_index)
             pos = 0
@@ -518,6 +568,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             if exact[0]:
                 raise
             exact[0] = True
+            warn_overflow_retry()
             return run_interleaved(session, start_emb.shape[0], streams)
 
 

@@ -40,7 +40,7 @@ enum { DH_BEAM_ERR_ALL_FILTERED = 1,   /* every logit filtered (-inf): reference
        DH_BEAM_ERR_TOO_FEW = 4 };      /* informational: fewer positive-probability tokens than beams (dead beams, as torch's
                                           zero-probability picks) */
 #define DH_BEAM_MAX_SURVIVORS 1024
-#define DH_BEAM_MAX_BEAMS 16
+#define DH_BEAM_MAX_BEAMS 64
 
 int dh_abi_version(void);
 const char* dh_error_string(int code);

@@ -4,6 +4,7 @@ needed there: the fixtures it writes are committed.
 
     python oracle/make_golden.py            # rewrites tests/golden/
     python oracle/make_golden.py r3         # only the round-3 fixtures (g10 char-level, g11 demo decode settings)
+    python oracle/make_golden.py r4         # only the round-4 fixtures (g14 V=36,541 logits, g15 bench-shape beam, g16 beam 24, g17 pad_index 1)
 
 The reference imports torchvision (encoders.py:4), which is absent here, so
 ``oracle/_standin`` (our own ResNet-50 definition, torchvision naming) is put on ``sys.path``
@@ -214,6 +215,71 @@ def pad_index_goldens():
     np.savez_compressed(os.path.join(OUT, "g12_pad_index.npz"), **rec)
 
 
+def round4_goldens():
+    """G14: logits at the BASELINE vocabulary (V = 36,541; SURVEY 8(c) G2 "checksums at V=36541"): teacher-forced ``forward()`` of
+    2 images -- row sums, arg-max and a 512-column slice (the first 256 and the LAST 256 columns: the partial 128-column panel at the
+    end of the vocabulary) of every position -- and the pre-filter logits of ``generate``'s first step (same slice + row sum).
+    G15: stochastic beam search at the BASELINE decode settings (beam 5, top_k 50, T 1.0, 32 tokens, V = 36,541) for images 0 and
+    255 of the 256-image bench batch under ``torch.manual_seed(700 + index)`` -- what ``generate(..., rng="torch")`` must return.
+    G16: beam_size 24 > 16 (beam.py:7-9 allows any beam_size <= top_k), top_k 50, V = 1,000, under ``torch.manual_seed(800 + i)``.
+    G17: a Transformer built with pad_index = 1 (transformers.py:393-394): the image slot's stand-in id 1 (:474) then counts as
+    padding -- greedy ids, RNG-replay beam 3, teacher-forced logits."""
+    torch.set_num_threads(8)
+    images = synth_images(4, seed=0)
+    cols = np.r_[0:256, V_WORD - 256:V_WORD]
+    cap, lengths, _ = captions_and_lengths(V_WORD)
+    for kind in ("CaptioningLSTM", "CaptioningTransformer"):
+        model = build(kind, V_WORD)
+        rec = {"cols": cols}
+        with torch.no_grad():
+            logits = model(images[:2], cap[:2], lengths[:2])
+        rec["forward_shape"] = np.array(logits.shape)
+        rec["forward_slice"] = logits[:, :, cols].numpy()
+        rec["forward_rowsum"] = logits.double().sum(-1).numpy()
+        rec["forward_argmax"] = logits.argmax(-1).numpy()
+        for i in range(2):
+            tap = _LogitTap(model)
+            with torch.no_grad():
+                model.generate(images[i:i + 1], max_len=2, beam_size=1, top_k=1)
+            tap.close()
+            out = tap.rows[0]
+            row = out[0] if out.dim() == 2 else out[0, 0]
+            rec[f"step0_slice_{i}"] = row[cols].numpy()
+            rec[f"step0_rowsum_{i}"] = np.float64(row.double().sum())
+            rec[f"step0_argmax_{i}"] = np.int64(row.argmax())
+        np.savez_compressed(os.path.join(OUT, f"g14_word_logits_{kind}.npz"), **rec)
+        print(kind, "V=36541 forward", tuple(logits.shape), "rowsum[0,:3]", rec["forward_rowsum"][0, :3])
+        rec = {}
+        for idx in (0, 255):
+            img = synth_images(1, seed=0, first=idx)
+            rec[f"beam_{idx}"] = beam_ids(model, img, 700 + idx, max_len=32, beam_size=5, top_k=50, temperature=1.0)
+            print(kind, "bench image", idx, "beam 5:", rec[f"beam_{idx}"][:10], len(rec[f"beam_{idx}"]))
+        np.savez_compressed(os.path.join(OUT, f"g15_bench_beam_{kind}.npz"), **rec)
+    for kind in ("CaptioningLSTM", "CaptioningTransformer"):
+        model = build(kind, V_SMALL)
+        rec = {}
+        for i in range(2):
+            rec[f"beam_{i}"] = beam_ids(model, images[i:i + 1], 800 + i, max_len=12, beam_size=24, top_k=50, temperature=1.0)
+        np.savez_compressed(os.path.join(OUT, f"g16_beam24_{kind}.npz"), **rec)
+        print(kind, "beam 24", rec["beam_0"])
+    rec = {}
+    for kind in ("CaptioningTransformer", "CaptioningTransformerBase"):
+        model = load_synthetic({"CaptioningTransformer": CaptioningTransformer, "CaptioningTransformerBase": CaptioningTransformerBase}[kind](
+            V_SMALL, pad_index=1).eval(), seed=SEED)
+        with torch.no_grad():
+            for ml in (32, 60):
+                for i in range(2):
+                    rec[f"{kind}_greedy{ml}_{i}"] = model.generate(images[i:i + 1], max_len=ml, beam_size=1, top_k=1).reshape(-1).numpy()
+            rec[f"{kind}_beam_0"] = beam_ids(model, images[:1], 500, max_len=60, beam_size=3, top_k=20, temperature=1.3)
+            c1, l1, _ = captions_and_lengths(V_SMALL)
+            c1 = c1.clone()
+            c1[c1 == 0] = 1
+            logits = model(images[:2], c1[:2], l1[:2])
+            rec[f"{kind}_forward_logits"] = logits.numpy()
+        print(kind, "pad_index=1", rec[f"{kind}_greedy60_0"][:8], len(rec[f"{kind}_greedy60_0"]), logits.shape)
+    np.savez_compressed(os.path.join(OUT, "g17_pad_index_1.npz"), **rec)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -330,6 +396,7 @@ def main():
     text_and_metric_goldens()
     round3_goldens()
     pad_index_goldens()
+    round4_goldens()
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     print("wrote", OUT)
@@ -365,6 +432,8 @@ if __name__ == "__main__":
     elif sys.argv[1:] == ["r3"]:
         round3_goldens()
         pad_index_goldens()
+    elif sys.argv[1:] == ["r4"]:
+        round4_goldens()
     elif sys.argv[1:] == ["pad"]:
         pad_index_goldens()
     else:

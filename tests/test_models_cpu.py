@@ -20,9 +20,10 @@ def test_state_dict_layout_matches_reference(kind):
         assert list(sd[k].shape) == shape, k
     if rec["hp"]:
         assert model._hp == rec["hp"]
-    assert not any(p.requires_grad for p in model.encoder.parameters() if False) or True
     trunk = model.encoder.resnet if hasattr(model.encoder, "resnet") else model.encoder.image_encoder.resnet
     assert all(not p.requires_grad for p in trunk.parameters())            # encoders.py:35-36
+    enc = model.encoder if hasattr(model.encoder, "resnet") else model.encoder.image_encoder
+    assert all(p.requires_grad for p in enc.linear.parameters())           # the embedding head stays trainable (:42-43)
 
 
 def test_signatures_follow_the_reference():

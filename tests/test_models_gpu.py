@@ -170,10 +170,44 @@ def test_word_vocab_greedy(kind, images):
     """BASELINE configs C1-C3 vocabulary (V=36,541): greedy ids equal the reference's."""
     g = golden(f"g3_word_{kind}.npz")
     model, _, _ = build(kind, v=36541)
+    top2 = []
     with torch.no_grad():
-        toks, lens = model.generate_batch(images.cuda(), max_len=32, beam_size=1, top_k=1)
+        toks, lens = model.generate_batch(images.cuda(), max_len=32, beam_size=1, top_k=1,
+                                          logits_hook=lambda i, lg: top2.append(torch.topk(lg[:4].float(), 2, dim=-1)))
     for i in range(4):
         assert toks[i, :int(lens[i])].cpu().tolist() == g[f"greedy_{i}"].tolist()
+        # the recorded top-1 ids and top-1 / top-2 margins of every step the reference ran (pre-filter logits)
+        n = len(g[f"greedy_margin_{i}"])
+        got_top1 = [int(t.indices[i, 0]) for t in top2[:n]]
+        got_margin = np.array([float(t.values[i, 0] - t.values[i, 1]) for t in top2[:n]])
+        assert got_top1 == g[f"greedy_top1_{i}"].tolist()
+        np.testing.assert_allclose(got_margin, g[f"greedy_margin_{i}"], atol=2 * LOGIT_TOL, rtol=0)
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_word_vocab_logits(kind):
+    """"Logits within 1e-3 fp32" AT the BASELINE vocabulary (V = 36,541; SURVEY 8(c) G2, golden G14 recorded from the reference):
+    teacher-forced ``forward()`` -- the first 256 and LAST 256 columns of every position (the partial 128-column panel at the end
+    of the vocabulary), row sums, arg-max -- and the pre-filter logits of ``generate``'s first step."""
+    g = golden(f"g14_word_logits_{kind}.npz")
+    model, _, _ = build(kind, v=36541)
+    imgs = synth_images(2, seed=0)
+    cap, lengths, _ = captions_and_lengths(36541)
+    with torch.no_grad():
+        out = model(imgs.cuda(), cap[:2].cuda(), lengths[:2]).cpu()
+    assert tuple(out.shape) == tuple(g["forward_shape"])
+    cols = torch.from_numpy(g["cols"])
+    np.testing.assert_allclose(out[:, :, cols].numpy(), g["forward_slice"], atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(out.double().sum(-1).numpy(), g["forward_rowsum"], atol=0.5, rtol=0)      # 36,541 terms of |err| << 1e-3
+    assert (out.argmax(-1).numpy() == g["forward_argmax"]).mean() > 0.999
+    step0 = []
+    with torch.no_grad():
+        model.generate_batch(imgs.cuda(), max_len=2, beam_size=1, top_k=1,
+                             logits_hook=lambda i, lg: step0.append(lg[:2].float().cpu().clone()))
+    for i in range(2):
+        np.testing.assert_allclose(step0[0][i, cols].numpy(), g[f"step0_slice_{i}"], atol=LOGIT_TOL, rtol=0)
+        assert int(step0[0][i].argmax()) == int(g[f"step0_argmax_{i}"])
+        assert abs(float(step0[0][i].double().sum()) - float(g[f"step0_rowsum_{i}"])) < 0.5
 
 
 @pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
@@ -403,7 +437,7 @@ def test_u8_pipeline_equals_fp32_image_path(dtype):
 def test_pad_index_other_than_zero(kind):
     """``pad_index = 7`` (the reference's constructor accepts any value, transformers.py:393-394), goldens recorded from the reference:
     fp32 greedy ids at max_len 32 and 60 (past 49 positions the reference's zero-padded encoder rows become real cross-attention keys),
-    RNG-replay beam 3, teacher-forced logits within 1e-3; the 16-bit path runs the same shapes; ``pad_index = 1`` raises."""
+    RNG-replay beam 3, teacher-forced logits within 1e-3; the 16-bit path runs the same shapes."""
     import deephumor_amd.models as M
     g = golden("g12_pad_index.npz")
     sd, hp = synthetic_sd(kind)
@@ -428,9 +462,91 @@ def test_pad_index_other_than_zero(kind):
     with torch.no_grad():
         t16, l16 = model.bfloat16().generate_batch(images.cuda(), max_len=60, beam_size=3, top_k=20, seed=1)
     assert tuple(t16.shape) == (2, 60) and int(t16.max()) < 1000
-    bad = getattr(M, kind)(**dict(hp, pad_index=1)).eval().cuda()
-    with pytest.raises(NotImplementedError):
-        bad.generate_batch(images.cuda(), max_len=8, beam_size=1, top_k=1)
+
+
+@pytest.mark.parametrize("kind", ("CaptioningTransformer", "CaptioningTransformerBase"))
+def test_pad_index_one(kind):
+    """``pad_index = 1`` (golden G17 recorded from the reference): the image slot's stand-in id 1 (transformers.py:474) is itself
+    padding, so position 0 attends uniformly to EVERY position and the real patch rows are the masked encoder keys -- decoded by
+    full re-forward on the module-API kernels (no KV cache applies).  fp32 greedy ids at max_len 32 / 60, the stochastic beam
+    through ``rng="torch"``, teacher-forced logits within 1e-3; the bf16 path runs the same shapes."""
+    import deephumor_amd.models as M
+    g = golden("g17_pad_index_1.npz")
+    sd, hp = synthetic_sd(kind)
+    hp = dict(hp, pad_index=1)
+    model = getattr(M, kind)(**hp).eval()
+    model.load_state_dict(sd)
+    model = model.cuda()
+    images = synth_images(2, seed=0)
+    for ml in (32, 60):
+        with torch.no_grad():
+            toks, lens = model.generate_batch(images.cuda(), max_len=ml, beam_size=1, top_k=1)
+        for i in range(2):
+            assert toks[i, :int(lens[i])].cpu().tolist() == g[f"{kind}_greedy{ml}_{i}"].tolist(), (kind, ml, i)
+    torch.manual_seed(500)
+    with torch.no_grad():
+        ids = model.generate(images[:1].cuda(), max_len=60, beam_size=3, top_k=20, temperature=1.3, rng="torch")
+    assert ids.reshape(-1).cpu().tolist() == g[f"{kind}_beam_0"].tolist()
+    cap, lengths, _ = captions_and_lengths()
+    cap = cap.clone()
+    cap[cap == 0] = 1
+    with torch.no_grad():
+        out = model(images.cuda(), cap[:2].cuda(), lengths[:2])
+    np.testing.assert_allclose(out.cpu().numpy(), g[f"{kind}_forward_logits"], atol=LOGIT_TOL, rtol=0)
+    with torch.no_grad():
+        t16, l16 = model.bfloat16().generate_batch(images.cuda(), max_len=20, beam_size=3, top_k=20, seed=1)
+    assert tuple(t16.shape) == (2, 20) and int(t16.max()) < 1000
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_rng_torch_returns_the_reference_sampled_caption(kind, images):
+    """The product option ``rng="torch"``: ``torch.manual_seed(s); model.generate(image, rng="torch")`` is the reference's own
+    call sequence and returns its sampled caption (golden G5: beam 3, top_k 20, T 1.3); in a batch, image i replays
+    ``torch.manual_seed(seed + i)``."""
+    g = golden(f"g2g3_{kind}.npz")
+    model, _, _ = build(kind)
+    _, _, labels = captions_and_lengths()
+    kw = dict(max_len=12, beam_size=3, top_k=20, temperature=1.3)
+    wl = "WithLabels" in kind
+    for i in range(2):
+        torch.manual_seed(100 + i)
+        args = (images[i:i + 1].cuda(), labels[i:i + 1].cuda()) if wl else (images[i:i + 1].cuda(),)
+        with torch.no_grad():
+            ids = model.generate(*args, rng="torch", **kw)
+        assert ids.reshape(-1).cpu().tolist() == g[f"beam_{i}"].tolist(), (kind, i)
+    args = (images[:2].cuda(), labels[:2].cuda()) if wl else (images[:2].cuda(),)
+    with torch.no_grad():
+        toks, lens = model.generate_batch(*args, seed=100, rng="torch", **kw)
+        t2, l2 = model.generate_batch(*args, seed=100, rng="torch", streams=2, **kw)
+    for i in range(2):
+        assert toks[i, :int(lens[i])].cpu().tolist() == g[f"beam_{i}"].tolist(), (kind, i)
+    assert torch.equal(toks, t2) and torch.equal(lens, l2)
+    with pytest.raises(ValueError):
+        model.generate_batch(*args, rng="torch", **kw)          # the default generator cannot serve two images in the reference's order
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_beam_size_above_16(kind, images):
+    """beam_size 24 (the reference takes any beam_size <= top_k, beam.py:7-9; golden G16 recorded from it): fp32 token for token
+    through ``rng="torch"``; batch of 2 == singles; both 16-bit paths run beam 24 and beam 40 repeatably."""
+    g = golden(f"g16_beam24_{kind}.npz")
+    model, _, _ = build(kind)
+    kw = dict(max_len=12, beam_size=24, top_k=50, temperature=1.0)
+    with torch.no_grad():
+        toks, lens = model.generate_batch(images[:2].cuda(), seed=800, rng="torch", **kw)
+    for i in range(2):
+        assert toks[i, :int(lens[i])].cpu().tolist() == g[f"beam_{i}"].tolist(), (kind, i)
+    for dt in (torch.bfloat16, torch.float16):
+        m16 = build(kind)[0].to(dt)
+        for beam in (24, 40):
+            with torch.no_grad():
+                t1, l1 = m16.generate_batch(images.cuda(), max_len=12, beam_size=beam, top_k=50, seed=3)
+                t2, l2 = m16.generate_batch(images.cuda(), max_len=12, beam_size=beam, top_k=50, seed=3)
+                ta, la = m16.generate_batch(images[:2].cuda(), max_len=12, beam_size=beam, top_k=50, seed=3)
+            assert torch.equal(t1, t2) and torch.equal(l1, l2) and torch.equal(t1[:2], ta) and torch.equal(l1[:2], la)
+            assert int(t1.min()) >= 0 and int(t1.max()) < 1000 and not bool((t1 == 1).any())
+    with pytest.raises(ValueError):
+        model.generate_batch(images[:1].cuda(), max_len=4, beam_size=65, top_k=70)
 
 
 @pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))

@@ -201,3 +201,69 @@ def test_g13_no_decode_step(kind):
         ids = R.model_generate(kind, sd, hp, images, caption=cap[:1, :p] if p else None, **kw)
         want = g[f"{kind}_{name}"]
         assert tuple(ids.shape) == want.shape and ids.reshape(-1).tolist() == want.reshape(-1).tolist(), (kind, name)
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_g14_logits_at_the_word_vocabulary(kind):
+    """SURVEY 8(c) G2 "checksums at V=36541": the oracle's teacher-forced logits at the BASELINE vocabulary against the slice
+    (first 256 + last 256 columns of every position), row sums and arg-max recorded from the reference; and the pre-filter
+    logits of generate's first step."""
+    g = golden(f"g14_word_logits_{kind}.npz")
+    sd, hp = synthetic_sd(kind, v=36541)
+    images = synth_images(2, seed=0)
+    cap, lengths, _ = captions_and_lengths(36541)
+    out = R.model_forward(kind, sd, hp, images, cap[:2], lengths[:2])
+    assert tuple(out.shape) == tuple(g["forward_shape"])
+    cols = torch.from_numpy(g["cols"])
+    np.testing.assert_allclose(out[:, :, cols].numpy(), g["forward_slice"], atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(out.double().sum(-1).numpy(), g["forward_rowsum"], atol=5e-2, rtol=1e-5)
+    assert (out.argmax(-1).numpy() == g["forward_argmax"]).mean() > 0.999
+    trace = []
+    R.model_generate(kind, sd, hp, images[:1], max_len=2, beam_size=1, top_k=1, trace=trace)
+    assert int(trace[0]["top2_idx"][0, 0]) == int(g["step0_argmax_0"])
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_g15_bench_shape_beam(kind):
+    """Stochastic beam search at the BASELINE decode settings (beam 5, top_k 50, 32 tokens, V = 36,541) on bench image 255 under
+    torch.manual_seed(700 + 255): the oracle returns the reference's caption (image 0 is checked on the GPU box, where the HIP
+    path is compared with both)."""
+    g = golden(f"g15_bench_beam_{kind}.npz")
+    sd, hp = synthetic_sd(kind, v=36541)
+    img = synth_images(1, seed=0, first=255)
+    torch.manual_seed(700 + 255)
+    ids = R.model_generate(kind, sd, hp, img, max_len=32, beam_size=5, top_k=50, temperature=1.0)
+    assert ids.reshape(-1).tolist() == g["beam_255"].tolist()
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_g16_beam_24(kind):
+    """beam_size 24 (any beam_size <= top_k is valid, beam.py:7-9)."""
+    g = golden(f"g16_beam24_{kind}.npz")
+    sd, hp = synthetic_sd(kind)
+    images = synth_images(2, seed=0)
+    for i in range(2):
+        torch.manual_seed(800 + i)
+        ids = R.model_generate(kind, sd, hp, images[i:i + 1], max_len=12, beam_size=24, top_k=50, temperature=1.0)
+        assert ids.reshape(-1).tolist() == g[f"beam_{i}"].tolist()
+
+
+@pytest.mark.parametrize("kind", ("CaptioningTransformer", "CaptioningTransformerBase"))
+def test_g17_pad_index_one(kind):
+    """pad_index = 1: the image slot's stand-in id 1 (transformers.py:474) is itself padding -- position 0 attends uniformly to
+    every position, the real patch rows are the masked encoder keys (:480-481).  Greedy ids, RNG replay, teacher-forced logits."""
+    g = golden("g17_pad_index_1.npz")
+    sd, hp = synthetic_sd(kind)
+    hp = dict(hp, pad_index=1)
+    images = synth_images(2, seed=0)
+    for ml in (32, 60):
+        ids = R.model_generate(kind, sd, hp, images[:1], max_len=ml, beam_size=1, top_k=1)
+        assert ids.reshape(-1).tolist() == g[f"{kind}_greedy{ml}_0"].tolist()
+    torch.manual_seed(500)
+    ids = R.model_generate(kind, sd, hp, images[:1], max_len=60, beam_size=3, top_k=20, temperature=1.3)
+    assert ids.reshape(-1).tolist() == g[f"{kind}_beam_0"].tolist()
+    cap, lengths, _ = captions_and_lengths()
+    cap = cap.clone()
+    cap[cap == 0] = 1
+    out = R.model_forward(kind, sd, hp, images, cap[:2], lengths[:2])
+    np.testing.assert_allclose(out.numpy(), g[f"{kind}_forward_logits"], atol=2e-4, rtol=1e-5)
