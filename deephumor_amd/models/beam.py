@@ -23,6 +23,54 @@ class BeamOverflow(RuntimeError):
     the decoders catch this and repeat the batch with ``exact=True`` (the general sampler, which draws such rows over the whole row)."""
 
 
+class _TorchCpuStream:
+    """Replica of the stream a seeded ``torch.Generator`` (CPU) feeds ``Tensor.exponential_`` with, generated with numpy so that a
+    batch's images can be filled on a thread pool (torch fills serially under the GIL, ~27 ns per value: 256 images x 5 rows x
+    36,541 values take 1.2 s per decode step).  What the pinned torch (2.x CPU, ``exponential_kernel_default``) does per element:
+    two mt19937 draws -> ``random64`` (first draw = high word) -> ``u = (x & (2^53 - 1)) * 2^-53`` -> ``-log1p(-u)`` in double ->
+    cast to the tensor's type (ATen/core/TransformationHelper.h:144, DistributionTemplates.h); ``manual_seed(s)`` is mt19937's
+    standard ``init_genrand(s & 0xffffffff)``.  numpy's ``log1p`` is not glibc's (1 ulp of a double apart on ~7 % of the inputs),
+    which would change the float32 result when the double lies within a few ulps of a float32 rounding boundary (~2^-26 of the
+    samples): exactly those samples are recomputed with ``math.log1p`` (the C library's).  ``self_check`` compares a long fill
+    against torch itself; ``TorchRngNoise`` falls back to torch's own fill if it ever fails (another torch build)."""
+
+    _ok = None
+
+    def __init__(self, seed):
+        import numpy as np
+        key = np.empty(624, dtype=np.uint64)
+        s = int(seed) & 0xFFFFFFFF
+        key[0] = s
+        for j in range(1, 624):
+            s = (1812433253 * (s ^ (s >> 30)) + j) & 0xFFFFFFFF
+            key[j] = s
+        self.bg = np.random.MT19937()
+        self.bg.state = {"bit_generator": "MT19937", "state": {"key": key.astype(np.uint32), "pos": 624}}
+
+    def exponential(self, n):
+        """The next ``n`` values of ``torch.empty(n).exponential_(1, generator=g)`` as a float32 numpy array."""
+        import math
+        import numpy as np
+        raw = self.bg.random_raw(2 * n)
+        x = ((raw[0::2] << np.uint64(32)) | raw[1::2]) & np.uint64((1 << 53) - 1)
+        u = x.astype(np.float64) * (2.0 ** -53)
+        y = -np.log1p(-u)
+        out = y.astype(np.float32)
+        frac = (y.view(np.uint64) & np.uint64(0x1FFFFFFF)).astype(np.int64)      # the 29 bits float32 rounds away
+        for i in np.nonzero(np.abs(frac - 0x10000000) <= 16)[0].tolist():
+            out[i] = np.float32(-math.log1p(-float(u[i])))
+        return out
+
+    @classmethod
+    def self_check(cls):
+        if cls._ok is None:
+            g = torch.Generator().manual_seed(20240229)
+            mine = cls(20240229)
+            cls._ok = all(bool((torch.empty(n).exponential_(1, generator=g).numpy() == mine.exponential(n)).all())
+                          for n in (7, 200000, 36541))
+        return cls._ok
+
+
 class TorchRngNoise:
     """``rng="torch"``: the Exp(1) noise of every draw taken from torch CPU generators in the reference's order and shapes, so that
     the sampled caption is the one the reference returns under the same generator state.  ``torch.multinomial(p, k)`` on the CPU
@@ -56,11 +104,29 @@ class TorchRngNoise:
                 self._state0 = torch.get_rng_state()
             else:
                 torch.set_rng_state(self._state0)
+        elif self.n_img >= 8 and _TorchCpuStream.self_check():
+            self.gens = [_TorchCpuStream(int(self.seed) + self.img0 + i) for i in range(self.n_img)]     # thread-parallel fills
         else:
             self.gens = [torch.Generator().manual_seed(int(self.seed) + self.img0 + i) for i in range(self.n_img)]
 
     def _exp(self, i, n):
-        return torch.empty(n).exponential_(1, generator=None if self.gens is None else self.gens[i])
+        g = None if self.gens is None else self.gens[i]
+        if isinstance(g, _TorchCpuStream):
+            return torch.from_numpy(g.exponential(n))
+        return torch.empty(n).exponential_(1, generator=g)
+
+    def _each_image(self, fn, todo):
+        """``fn(i)`` for every image of ``todo``: the images' generators are independent, so a batch fills its [rows, V] noise on a
+        thread pool (``exponential_`` releases the GIL; one generator is only ever touched by one task at a time)."""
+        if self.gens is None or len(todo) < 8:
+            for i in todo:
+                fn(i)
+            return
+        pool = self.__dict__.get("_pool")
+        if pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = self._pool = ThreadPoolExecutor(max_workers=max(1, min(32, (os.cpu_count() or 8) - 1)))
+        list(pool.map(fn, todo))
 
     def __call__(self, kind, step, shape):
         h, b = self.h, self.h.beam_size
@@ -70,9 +136,10 @@ class TorchRngNoise:
         out = torch.ones(shape)
         if kind == "row":
             rpi, v = shape[0] // self.n_img, shape[1]
-            for i in range(self.n_img):
-                if not done[i]:
-                    out[i * rpi:(i + 1) * rpi] = self._exp(i, rpi * v).view(rpi, v)
+
+            def fill(i):
+                out[i * rpi:(i + 1) * rpi] = self._exp(i, rpi * v).view(rpi, v)
+            self._each_image(fill, [i for i in range(self.n_img) if not done[i]])
         elif kind == "cand":
             ended = h._ended.cpu().view(self.n_img, b).tolist()
             for i in range(self.n_img):

@@ -96,3 +96,28 @@ def test_product_never_imports_the_oracle():
                 for line in src.splitlines():
                     if line.lstrip().startswith(("import ", "from ")):
                         assert "oracle" not in line, (f, line)
+
+
+def test_torch_cpu_stream_replica_is_bit_equal_to_torch():
+    """rng="torch" fills a batch's noise from a numpy replica of the seeded torch CPU generator's ``exponential_`` stream (thread
+    parallel over the images): value for value what torch itself draws, across consecutive fills of different lengths."""
+    from deephumor_amd.models.beam import TorchRngNoise, _TorchCpuStream
+    assert _TorchCpuStream.self_check()
+    for seed in (0, 700, 955, 2 ** 33 + 5):
+        g, mine = torch.Generator().manual_seed(seed), _TorchCpuStream(seed)
+        for n in (5, 5 * 36541, 24, 300000):
+            assert bool((torch.empty(n).exponential_(1, generator=g).numpy() == mine.exponential(n)).all()), (seed, n)
+
+    class _H:
+        beam_size = 3
+        done = torch.zeros(8, dtype=torch.uint8)
+        _ended = torch.tensor([0, 1, 0] * 8, dtype=torch.uint8)
+    src = TorchRngNoise(100, 8, img0=2)
+    src.attach(_H())
+    gens = [torch.Generator().manual_seed(102 + i) for i in range(8)]
+    row = src("row", 0, (24, 501))
+    want = torch.cat([torch.empty(3 * 501).exponential_(1, generator=g).view(3, 501) for g in gens])
+    assert torch.equal(row, want)
+    cand = src("cand", 0, (8, 9))
+    for i, g in enumerate(gens):                  # 3 + 1 + 3 candidates (beam.py:72-101), the rest of the row untouched
+        assert torch.equal(cand[i, :7], torch.empty(7).exponential_(1, generator=g)) and bool((cand[i, 7:] == 1).all())
