@@ -50,10 +50,11 @@ STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
 PEAK_16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r3", "pmc_hbm_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r4", "pmc_hbm_traffic.json")
 TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 _SD_CACHE = {}
+RANK_TIMES = []         # wall time of the last timed region on every rank (seconds), filled by timed_region
 
 
 def build_model(workload, dev, dtype="bf16"):
@@ -130,7 +131,7 @@ def attach_traffic(rl, workload, dtype):
         if ent:
             rl["traffic"] = ent["traffic_bytes_per_launch"]
             rl["traffic_over_algorithmic"] = ent["traffic_bytes_per_launch"] / rl["algorithmic_bytes_per_launch"]
-            rl["traffic_source"] = f"profiles/r3/pmc_hbm_traffic.json @ {pmc.get('commit', '?')} ({ent.get('note', '')})"
+            rl["traffic_source"] = f"profiles/r4/pmc_hbm_traffic.json @ {pmc.get('commit', '?')} ({ent.get('note', '')})"
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return rl
@@ -224,7 +225,7 @@ def greedy_all(model, images, chunk=256):
         for lo in range(0, images.shape[0], chunk):
             cap = {}
             t, l = model.generate_batch(images[lo:lo + chunk], max_len=MAX_LEN, beam_size=1, top_k=1,
-                                        logits_hook=lambda i, lg: cap.setdefault(i, lg.float().clone()))
+                                        logits_hook=lambda i, lg: cap.__setitem__(0, lg.float().clone()) if i == 0 else None)
             toks.append(t), lens.append(l), lg0.append(cap[0][:t.shape[0]])
     return torch.cat(toks), torch.cat(lens), torch.cat(lg0)
 
@@ -272,20 +273,27 @@ def timed_region(step_fn, steps, world, device):
         out = step_fn(s)
     fence()
     dt = time.perf_counter() - t0
+    RANK_TIMES[:] = [dt]
     if multi:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # one extra all_gather of a float: every rank's own wall time, so the line shows skew between ranks next to the MAX
+        mine = torch.tensor([dt], dtype=torch.float64, device=device)
+        every = torch.empty((dist.get_world_size(),), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(every, mine)
+        RANK_TIMES[:] = [float(x) for x in every.cpu().tolist()]
+        dt = max(RANK_TIMES)
     return dt, out
 
 
 # ---- legs on the GPU ----------------------------------------------------------------------------------------------
-def timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=None, graph=False):
+def timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=None, graph=False, stride=1):
     from deephumor_amd import hip
     world = n_total // n_local
     step = lambda s: one_step(model, images, rank * n_local, n_total, seed=100 + s, graph=graph)
     if watch:
-        with hip.profile(watch=watch) as prof:
+        # HIP events around the launches of the roofline kernel INSIDE the timed region.  Each event pair costs ~5 us of stream
+        # time: a key launched hundreds of times per step (the C3 decode GEMMs: 192-576) is sampled every `stride`-th launch so
+        # that the instrumentation stays below ~0.2 ms per step (an unbiased sample of the same launches)
+        with hip.profile(watch=watch, stride=stride) as prof:
             dt, out = timed_region(step, steps, world, images.device)
         return dt, out[1], prof.summary()
     dt, out = timed_region(step, steps, world, images.device)
@@ -345,6 +353,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
         torch.cuda.synchronize()
 
     graph = args.graph
+    stride = 1
     with torch.no_grad():
         # untimed: a cold pass (code-object loading, allocator growth), then one fully instrumented pass (HIP events around
         # every launch made through the library) for the per-kernel breakdown and the choice of the roofline kernel
@@ -357,7 +366,8 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             one_step(model, images, rank * n_local, n_total, seed=w, graph=graph)
         if main_line and not graph:
             # timed region: events only around the launches of the dominant key (a few dozen pairs per step)
-            dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch={dominant})
+            stride = max(1, breakdown[dominant]["calls"] // 32)
+            dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch={dominant}, stride=stride)
         else:
             dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, graph=graph)
     res = {"value": n_total * steps / dt, "ms_per_step": dt / steps * 1e3,
@@ -368,10 +378,12 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
         by_entry[base] = by_entry.get(base, 0.0) + v["ms"]
     res["kernel_breakdown_ms_per_step"] = {k: round(v, 3) for k, v in sorted(by_entry.items(), key=lambda kv: -kv[1])}
     res["kernel_breakdown_note"] = ("untimed pass with HIP events around every launch: the events add ~15 % to a chain of "
-                                    "small launches; per-kernel shares of the clean run: profiles/r3/*_kernel_stats.csv (rocprofv3)")
+                                    "small launches; per-kernel shares of the clean run: profiles/r4/*_kernel_stats.csv (rocprofv3)")
     src = summary if dominant in summary else breakdown
     res["roofline"] = attach_traffic(price(dominant, src[dominant], dtype), workload, dtype)
-    res["roofline"]["measured"] = "timed region, every launch" if dominant in summary else "instrumented pass"
+    res["roofline"]["measured"] = ((f"timed region, every {stride}th launch" if main_line and not graph and stride > 1 else "timed region, every launch")
+                                   if dominant in summary else "instrumented pass")
+    res["per_rank_ms_per_step"] = {"min": min(RANK_TIMES) / steps * 1e3, "max": max(RANK_TIMES) / steps * 1e3, "ranks": len(RANK_TIMES)}
     res["encoder_layers"] = encoder_table(breakdown, dtype)
     if workload in ("c3", "c5"):
         for name, entry in (("roofline_self_attention", "dh_attn_self_decode"), ("roofline_cross_attention", "dh_attn_cross_decode")):
@@ -385,7 +397,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             tot_s = (sa["avg_launch_us"] * sa["launches"] + ca["avg_launch_us"] * ca["launches"]) * 1e-6
             res["roofline_decoder_attention_combined"] = {"bound": "hbm", "achieved": tot_b / tot_s / 1e9, "peak": PEAK_HBM_GBS,
                                                           "unit": "GB/s", "frac": tot_b / tot_s / 1e9 / PEAK_HBM_GBS}
-    if main_line and world == 1 and not graph:
+    if world == 1 and not graph:
         with torch.no_grad():
             one_step(model, images, 0, n_total, seed=1, graph=True)
             tg, _, _ = timed_steps(model, images, 0, n_local, n_total, steps, barrier, graph=True)
@@ -414,7 +426,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             # what 16-bit storage costs in greedy tokens: both 16-bit paths against the fp32 HIP path (bit-exact vs the CPU
             # oracle on the checked images above and on rows {0, 77, 255} in tests/test_fullsize_gpu.py) over ALL bench images
             res["precision_vs_fp32_hip"] = {"reference": "fp32 HIP path, greedy (beam 1, top_k 1), all bench images",
-                                            "table": "profiles/r3/precision_c2.json, precision_c3.json (which tensor's precision buys what)"}
+                                            "table": "profiles/r3/precision_c2.json, precision_c3.json (which tensor's precision buys what; round 3)"}
             for dt in [dtype] + [d for d in ("bf16", "f16") if d != dtype]:
                 model = build_model(workload, dev, dt)[0]
                 res["precision_vs_fp32_hip"][dt] = compare_greedy(ref, greedy_all(model, images))
@@ -496,9 +508,18 @@ def run_score(args, rank, world, dev, dtype, kind):
 
 
 def git_head():
+    """Commit of the tree being measured: from git where the checkout has one, else the stamp ``deephumor_amd/_build.py`` left next
+    to the library when it was built (the GPU box receives a snapshot without ``.git``)."""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+        out = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+        if out:
+            return out
     except Exception:
+        pass
+    try:
+        with open(os.path.join(ROOT, "deephumor_amd", "lib", "BUILD_COMMIT")) as f:
+            return f.read().strip() or None
+    except OSError:
         return None
 
 
@@ -560,6 +581,7 @@ def stub_workload(args, rank, world, dev):
     dt, (toks, lens) = timed_region(step, args.steps, world, dev)
     want = (torch.arange(n_total)[:, None] * 10 + torch.arange(MAX_LEN)[None, :] + args.steps - 1) % 97
     return {"value": n_total * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "steps_run": calls,
+            "per_rank_ms_per_step": {"min": min(RANK_TIMES) / args.steps * 1e3, "max": max(RANK_TIMES) / args.steps * 1e3, "ranks": len(RANK_TIMES)},
             "gathered": int(toks.shape[0]), "gather_in_global_order": bool(torch.equal(toks, want)),
             "mean_caption_len": float(lens.float().mean())}
 
@@ -605,7 +627,7 @@ def main(argv=None):
     single_pg = args.rccl_single and world == 1 and not args.stub
     if single_pg:
         os.environ["DH_DIST_ALWAYS"] = "1"
-        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
     if world > 1 or single_pg:
         import datetime
         import torch.distributed as dist
@@ -670,6 +692,21 @@ def main(argv=None):
               "encoder_layers", "roofline_self_attention", "roofline_cross_attention", "roofline_decoder_attention_combined"):
         if k in res:
             line[k] = res[k]
+    for k in ("per_rank_ms_per_step",):
+        if k in res:
+            line[k] = res[k]
+    # the second half of the metric ("greedy-decode token match vs CPU ref") next to `value`: the fp32 path's match against the CPU
+    # oracle (bit-exact: 1.0), and what each 16-bit storage type keeps of the fp32 path's greedy tokens over all bench images
+    pv = res.get("precision_vs_fp32_hip")
+    if pv:
+        line["greedy_token_match_vs_fp32_hip"] = {dt: pv[dt]["token_match"] for dt in ("bf16", "f16") if dt in pv}
+        line["greedy_captions_identical_vs_fp32_hip"] = {dt: pv[dt]["captions_identical"] for dt in ("bf16", "f16") if dt in pv}
+    for dt in ("bf16", "f16"):
+        if f"{dt}_path" in res:
+            line[f"value_{dt}"] = res[f"{dt}_path"]["value"]
+    line[f"value_{args.dtype}"] = res["value"]
+    if "hipgraph_replay" in res:
+        line["value_hipgraph_replay"] = res["hipgraph_replay"]["value"]
     hi = res.get("host_inclusive")
     if hi:
         # SURVEY 8(d)'s definition of the metric (images in host memory -> ids in host memory), next to `value` (inputs resident

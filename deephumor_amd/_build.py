@@ -62,7 +62,24 @@ def _build_locked(verbose):
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{res.stdout.decode()}")
     os.replace(tmp, LIB_PATH)
+    _stamp_commit()
     return LIB_PATH
+
+
+def _stamp_commit():
+    """Leaves the commit (+ "-dirty") of the tree the library was built from next to it: the GPU box gets a snapshot without
+    ``.git``, and bench.py records this stamp in its line instead."""
+    root = os.path.dirname(HERE)
+    try:
+        head = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+        if not head:
+            return
+        dirty = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True,
+                               timeout=10).stdout.strip()
+        with open(os.path.join(LIB_DIR, "BUILD_COMMIT"), "w") as f:
+            f.write(head + ("-dirty" if dirty else "") + "\n")
+    except Exception:
+        pass
 
 
 if __name__ == "__main__":

@@ -12,6 +12,45 @@
 #include "common.h"
 #include "prof.h"
 
+// Softmax arithmetic.  fp32 path: the reference's exact formulation -- energy / scale (transformers.py:106), expf, e / sum as
+// torch.softmax (:114) -- its greedy ids are bit-exact against the CPU reference.  16-bit paths: the hardware reciprocal and
+// exp2 (1 ulp of fp32 each; the attention output is rounded to 8 / 11 significant bits anyway): the exact division and expf are
+// ~10 and ~15 VALU instructions each, 48 of them per lane on a wave that runs alone on its SIMD.  One definition for every
+// kernel, so fused and unfused forms stay bit-identical to each other.
+template <typename T> struct SmMath {
+    static __device__ __forceinline__ float div(float a, float b) { return a / b; }
+    static __device__ __forceinline__ float exp(float x) { return expf(x); }
+};
+struct SmFast {
+    static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+    static __device__ __forceinline__ float exp(float x) { return __expf(x); }
+};
+template <> struct SmMath<bf16_t> : SmFast {};
+template <> struct SmMath<f16_t> : SmFast {};
+
+// max / sum over the four lanes {l, l ^ 16, l ^ 32, l ^ 48} (the lanes sharing an MFMA accumulator row) without the LDS crossbar:
+// gfx950's v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane halves between two registers (x, x) -> (lower copies, upper
+// copies); __shfl_xor is a ds_bpermute round trip (~100 cycles + a wait) each
+__device__ __forceinline__ float quad_rows_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float quad_rows_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// sum over the 8 key slots of a (key slot, 8-dim chunk) lane layout with 8 chunk lanes per key (lanes l, l ^ 8, l ^ 16, ..., l ^ 56), in
+// the order the xor-shuffle tree takes them: DPP row_ror:8 (lane ^ 8 inside a 16-lane row), then the row swaps above
+__device__ __forceinline__ float key_slots_sum8(float v) {
+    v += dpp_get<0x128>(v);
+    return quad_rows_sum(v);
+}
+
 template <typename T>
 struct AttnParams {
     const T* q; int ldq;                  // query rows (compact)
@@ -81,7 +120,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams<T> p) {
                     a2 = fmaf(kk[u + 2], qq.z, a2); a3 = fmaf(kk[u + 3], qq.w, a3);
                 }
             }
-            e = ((a0 + a1) + (a2 + a3)) / p.scale;
+            e = SmMath<T>::div((a0 + a1) + (a2 + a3), p.scale);
         }
         sc[j] = e;
         mx = fmaxf(mx, e);
@@ -89,12 +128,12 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams<T> p) {
     mx = wave_max(mx);
     float sum = 0.f;
     for (int j = lane; j < L; j += 64) {
-        const float e = expf(sc[j] - mx);
+        const float e = SmMath<T>::exp(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
     sum = wave_sum(sum);
-    for (int j = lane; j < L; j += 64) sc[j] = sc[j] / sum;     // attention weights, as torch.softmax
+    for (int j = lane; j < L; j += 64) sc[j] = SmMath<T>::div(sc[j], sum);     // attention weights, as torch.softmax
     __syncthreads();
 
     for (int d = lane; d < dh; d += 64) {
@@ -190,7 +229,7 @@ __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p)
             for (int u = 0; u < 8; ++u) a = fmaf(kk[u], qv[u], a);
 #pragma unroll
             for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
-            e = masked ? -1e8f : a / p.scale;
+            e = masked ? -1e8f : SmMath<T>::div(a, p.scale);
             if (dc == 0) { sc[j] = e; if (!CROSS) ph[j] = phys; }
         }
         mx = fmaxf(mx, e);
@@ -199,12 +238,12 @@ __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p)
     __syncthreads();
     float sum = 0.f;
     for (int j = lane; j < L; j += 64) {
-        const float e = expf(sc[j] - mx);
+        const float e = SmMath<T>::exp(sc[j] - mx);
         sc[j] = e;
         sum += e;
     }
     sum = wave_sum(sum);
-    for (int j = lane; j < L; j += 64) sc[j] = sc[j] / sum;     // attention weights, as torch.softmax
+    for (int j = lane; j < L; j += 64) sc[j] = SmMath<T>::div(sc[j], sum);     // attention weights, as torch.softmax
     __syncthreads();
 
     float o[8];
@@ -227,8 +266,13 @@ __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p)
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
+        {
+            if constexpr (LPK == 8) o[u] = key_slots_sum8(o[u]);
+            else {
 #pragma unroll
-        for (int s2 = LPK; s2 < 64; s2 <<= 1) o[u] += __shfl_xor(o[u], s2, 64);
+                for (int s2 = LPK; s2 < 64; s2 <<= 1) o[u] += __shfl_xor(o[u], s2, 64);
+            }
+        }
     if (kg == 0 && w_ok) {
         store8(p.out + (size_t)rc * D + h * DH + dc * 8, o);
         if (!CROSS) {   // append this position to the cache at the row's own logical slot
@@ -344,7 +388,7 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
 #pragma unroll
                 for (int o = 1; o < LPK; o <<= 1) a += __shfl_xor(a, o, 64);
             }
-            e[it] = masked[it] ? -1e8f : a / p.scale;
+            e[it] = masked[it] ? -1e8f : SmMath<T>::div(a, p.scale);
         }
         mx = fmaxf(mx, e[it]);
     }
@@ -352,7 +396,7 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
     float sum = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        e[it] = live[it] ? expf(e[it] - mx) : 0.f;
+        e[it] = live[it] ? SmMath<T>::exp(e[it] - mx) : 0.f;
         sum += e[it];
     }
     // every chunk lane holds its key's e: the wave sum counts each key LPK times
@@ -365,15 +409,20 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
         if (live[it]) {
             float vv[8];
             raw_unpack(vr[it], vv);
-            const float pj = e[it] / sum;                                             // attention weight, as torch.softmax
+            const float pj = SmMath<T>::div(e[it], sum);                                             // attention weight, as torch.softmax
 #pragma unroll
             for (int u = 0; u < 8; ++u) o8[u] = fmaf(pj, vv[u], o8[u]);
         }
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
+        {
+            if constexpr (LPK == 8) o8[u] = key_slots_sum8(o8[u]);
+            else {
 #pragma unroll
-        for (int s2 = LPK; s2 < 64; s2 <<= 1) o8[u] += __shfl_xor(o8[u], s2, 64);
+                for (int s2 = LPK; s2 < 64; s2 <<= 1) o8[u] += __shfl_xor(o8[u], s2, 64);
+            }
+        }
     if (kg == 0) {
         store8(p.out + (size_t)rc * D + h * DH + dc * 8, o8);
         if (!CROSS) {
@@ -434,12 +483,12 @@ __global__ __launch_bounds__(1024) void attn_cross_lds_kernel(AttnParams<T> p) {
                     a2 = fmaf(kk[u + 2], qq.z, a2); a3 = fmaf(kk[u + 3], qq.w, a3);
                 }
             }
-            e = masked ? -1e8f : ((a0 + a1) + (a2 + a3)) / p.scale;
+            e = masked ? -1e8f : SmMath<T>::div((a0 + a1) + (a2 + a3), p.scale);
         }
         const float mx = wave_max(e);
-        const float ex = lane < S ? expf(e - mx) : 0.f;
+        const float ex = lane < S ? SmMath<T>::exp(e - mx) : 0.f;
         const float sum = wave_sum(ex);
-        ps[lane] = ex / sum;                                           // attention weights, as torch.softmax
+        ps[lane] = SmMath<T>::div(ex, sum);                                           // attention weights, as torch.softmax
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");         // ps is wave-private: order write -> reads
         // PV: lane l -> dims 2*(l&31), +1 ; half-wave (l>>5) takes keys of its parity
         float o0 = 0.f, o1 = 0.f;
@@ -592,14 +641,14 @@ __global__ __launch_bounds__(256) void attn_self_prefill_kernel(const T* __restr
 #pragma unroll
         for (int u = 0; u < 8; ++u) a = fmaf(kk[u], qv[u], a);
         a = sum8(a);
-        e[it] = !live[it] ? -INFINITY : (masked[it] ? -1e8f : a / scale);
+        e[it] = !live[it] ? -INFINITY : (masked[it] ? -1e8f : SmMath<T>::div(a, scale));
         mx = fmaxf(mx, e[it]);
     }
     mx = wave_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        e[it] = live[it] ? expf(e[it] - mx) : 0.f;
+        e[it] = live[it] ? SmMath<T>::exp(e[it] - mx) : 0.f;
         sum += e[it];
     }
     sum = wave_sum(sum) / (float)LPK;
@@ -610,14 +659,19 @@ __global__ __launch_bounds__(256) void attn_self_prefill_kernel(const T* __restr
     for (int it = 0; it < NIT; ++it) {
         float vv[8];
         raw_unpack(vr[it], vv);
-        const float pj = e[it] / sum;
+        const float pj = SmMath<T>::div(e[it], sum);
 #pragma unroll
         for (int u = 0; u < 8; ++u) o8[u] = fmaf(pj, vv[u], o8[u]);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u)
+        {
+            if constexpr (LPK == 8) o8[u] = key_slots_sum8(o8[u]);
+            else {
 #pragma unroll
-        for (int s2 = LPK; s2 < 64; s2 <<= 1) o8[u] += __shfl_xor(o8[u], s2, 64);
+                for (int s2 = LPK; s2 < 64; s2 <<= 1) o8[u] += __shfl_xor(o8[u], s2, 64);
+            }
+        }
     if (kg == 0) store8(out + (size_t)rc * D + h * DH + dc * 8, o8);
 }
 
@@ -802,18 +856,16 @@ __device__ __forceinline__ void cross_core(const uint4 (&kf)[4][2], const uint4 
         for (int r = 0; r < 4; ++r) {
             const int key = 16 * j + 4 * lq + r;
             const bool masked = (kbits >> key) & 1ull;
-            e[j][r] = key < S ? (masked ? -1e8f : sacc[j][r] / scale) : -INFINITY;
+            e[j][r] = key < S ? (masked ? -1e8f : SmMath<T>::div(sacc[j][r], scale)) : -INFINITY;
             mx = fmaxf(mx, e[j][r]);
         }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = quad_rows_max(mx);
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { e[j][r] = expf(e[j][r] - mx); sum += e[j][r]; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+        for (int r = 0; r < 4; ++r) { e[j][r] = SmMath<T>::exp(e[j][r] - mx); sum += e[j][r]; }
+    sum = quad_rows_sum(sum);
     // the lane's own 16 weights, rounded to the operand type, in key-slot order: k-step kk, element e <-> (j = 2kk + (e >> 2), r = e & 3)
     uint4 pf[2];
 #pragma unroll
@@ -822,7 +874,7 @@ __device__ __forceinline__ void cross_core(const uint4 (&kf)[4][2], const uint4 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e0 = 2 * u, e1 = 2 * u + 1;
-            const float p0 = e[2 * kk + (e0 >> 2)][e0 & 3] / sum, p1 = e[2 * kk + (e1 >> 2)][e1 & 3] / sum;   // as torch.softmax
+            const float p0 = SmMath<T>::div(e[2 * kk + (e0 >> 2)][e0 & 3], sum), p1 = SmMath<T>::div(e[2 * kk + (e1 >> 2)][e1 & 3], sum);   // as torch.softmax
             w[u] = (uint32_t)Op16<T>::from_f32(p0) | ((uint32_t)Op16<T>::from_f32(p1) << 16);
         }
         pf[kk] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -1198,7 +1250,7 @@ __global__ __launch_bounds__(512) void attn_self_qkv_kernel(SelfQkvParams p) {
                         for (int u = 0; u < 8; ++u) a = fmaf(kk8[u], qv[u], a);
                         a = sum8(a);
                         const bool masked = (j >= 1) && p.tokens && (aux[b][it] == p.pad_index);
-                        e[it] = masked ? -1e8f : a / p.scale;
+                        e[it] = masked ? -1e8f : SmMath<T>::div(a, p.scale);
                     }
                     mx = fmaxf(mx, e[it]);
                 }
@@ -1206,7 +1258,7 @@ __global__ __launch_bounds__(512) void attn_self_qkv_kernel(SelfQkvParams p) {
                 float sum = 0.f;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) {
-                    e[it] = (it * KPI + kg < L) ? expf(e[it] - mx) : 0.f;
+                    e[it] = (it * KPI + kg < L) ? SmMath<T>::exp(e[it] - mx) : 0.f;
                     sum += e[it];
                 }
                 sum = wave_sum(sum) / 8.0f;
@@ -1218,15 +1270,14 @@ __global__ __launch_bounds__(512) void attn_self_qkv_kernel(SelfQkvParams p) {
                     if (it * KPI + kg < L) {
                         float vv[8];
                         raw_unpack(vr[b][it], vv);
-                        const float pj = e[it] / sum;
+                        const float pj = SmMath<T>::div(e[it], sum);
 #pragma unroll
                         for (int u = 0; u < 8; ++u) o8[u] = fmaf(pj, vv[u], o8[u]);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-#pragma unroll
-                    for (int s2 = 8; s2 < 64; s2 <<= 1) o8[u] += __shfl_xor(o8[u], s2, 64);
+                    o8[u] = key_slots_sum8(o8[u]);
                 if (kg == 0) {
                     store8(reinterpret_cast<T*>(p.out) + rc * D + h * 64 + dc * 8, o8);
                     copy8(reinterpret_cast<T*>(p.kc) + ((size_t)t * p.rows_total + rl) * D + h * 64 + dc * 8, sq + mm * 192 + 64 + dc * 8);

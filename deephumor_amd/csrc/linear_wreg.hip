@@ -262,7 +262,7 @@ int pick_xn(int tiles_m, int tiles_n, double w_block_bytes, double a_block_bytes
 // K = 2,048 with residual + statistics (the position-wise feed-forward's second layer)
 extern "C" int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats) {
     if (with_residual_stats) return (K == 512 || K == 2048) && (N % 64) == 0;
-    return K == 512 && (N % 128) == 0;
+    return K == 512 && (N % 64) == 0;
 }
 
 // dh_linear_ln with `w_packed` = dh_pack_mfma_fragments(W [N, K]) in place of W; same arguments, restrictions as above:
@@ -301,6 +301,13 @@ extern "C" int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, c
             if (K == 512) hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 1, 1>), grid, dim3(256), 0, s, p);
             else hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 4, 1>), grid, dim3(256), 0, s, p);
         });
+        DH_LAUNCH_CHECK();
+    }
+    if ((N % 128) != 0 || (long long)dh_cdiv(M, 40) * (N / 64) <= 256) {
+        // narrow outputs (the cross-attention query projection, N = D = 512): 64-column x 40-row blocks, 4 waves, as the residual form
+        p.tiles_n = N / 64; p.tiles_m = dh_cdiv(M, 40);
+        p.xn = pick_xn(p.tiles_m, p.tiles_n, 64.0 * K * 2, 40.0 * K * 2);
+        DH_DISPATCH_16(dtype, hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 1, 0>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p));
         DH_LAUNCH_CHECK();
     }
     p.tiles_n = N / 128;

@@ -71,14 +71,16 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         const float *g_in = L.ln1_g, *b_in = L.ln1_b; float eps_in = L.ln1_eps;
         if (m->cross) {
             // 3. q = LN1(Y1) Wq^T + bq and the attention over the image's patches: ONE launch when K was packed for it
-            if (L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
+            // DH_CROSS_QPROJ=0: fc_q as its own (register-stationary) GEMM, then the packed attention -- A/B of the fused launch
+            static const int fused_qproj = getenv("DH_CROSS_QPROJ") ? atoi(getenv("DH_CROSS_QPROJ")) : 1;
+            if (fused_qproj && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
                 DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
                                                   n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
             } else {
                 f = dh_ln_fold_t{};
                 f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
                 dh_prof_set_tag("proj");
-                DH_TRY(dh_linear_ln(sc->o, D, L.wq_f, D, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
+                DH_TRY(chain_linear(sc->o, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
                 DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
             }
             // 4. Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2

@@ -27,7 +27,7 @@ class TrLayer(_c.Structure):
                 + [(n, _P) for n in ("kcache", "vcache", "kv")]
                 + [(n, _P) for n in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1", "kp", "vt")]
                 + [("kp_dperm", _I), ("_pad2", _I)]
-                + [(n, _P) for n in ("wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk")])
+                + [(n, _P) for n in ("wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk")])
 
 
 class TrModel(_c.Structure):

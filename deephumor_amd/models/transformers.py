@@ -211,7 +211,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 hd, pf = self.hid_dim, self.layers[0].pf.fc_1.out_features
                 for i, ent in enumerate(layers):
                     for name, src, n, k, lnx in (("wqkv_pk", "wqkv_f" if i > 0 else "wqkv", 3 * hd, hd, False), ("wo_pk", "wo", hd, hd, True),
-                                                 ("weo_pk", "weo", hd, hd, True), ("w1_pk", "w1_f", pf, hd, False), ("w2_pk", "w2", hd, pf, True)):
+                                                 ("weo_pk", "weo", hd, hd, True), ("w1_pk", "w1_f", pf, hd, False), ("w2_pk", "w2", hd, pf, True),
+                                                 ("wq_pk", "wq_f", hd, hd, False)):
                         if src in ent and hip.linear_ln_wreg_supported(n, k, lnx):
                             ent[name] = hip.pack_mfma_fragments(ent[src].contiguous())
         return dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
@@ -280,7 +281,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     if self.packed is not None:
                         c.kp, c.vt, c.kp_dperm = P(self.packed[i][0]), P(self.packed[i][1]), int(self.dperm)
                 for name in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1",
-                             "wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk"):
+                             "wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk"):
                     if name in L:
                         setattr(c, name, P(L[name]))
                 c.kcache, c.vcache = self.kc[i].data_ptr(), self.vc[i].data_ptr()

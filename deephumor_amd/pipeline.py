@@ -55,6 +55,9 @@ class CaptionPipeline:
         self._slot = 0
         self._out_slot = 0
         self._slot_reader = {}       # staging slot -> event recorded after the encoder that read it
+        # decode is queued without a host read of the beam engine's error word (examined at hand-over); decoders that cannot defer it
+        # (pad_index == 1: host-driven full re-forward) decode synchronously
+        self._async = getattr(getattr(model, "decoder", None), "pad_index", 0) != 1
 
     # -- stages ------------------------------------------------------------------------------------------------------
     def _stage(self, host_inputs):
@@ -104,51 +107,103 @@ class CaptionPipeline:
         return enc, done
 
     def _decode(self, enc, ev, seed, img0, to_host):
+        """Queues the decode of one batch on the decode stream and returns WITHOUT waiting for it: the beam engine's error word is
+        not read here (``defer_check``) but copied to pinned memory behind the token ids and examined by ``_finish`` once the
+        batch's event has fired."""
+        from .models.beam import resolve_seed
+        if self.gen_kw.get("rng") != "torch":
+            seed = resolve_seed(seed)                 # fixed now: a repeated decode (BeamOverflow) must draw the same noise
         with torch.cuda.stream(self.dec_s), torch.no_grad():
             self.dec_s.wait_event(ev)
-            toks, lens = self.model.decode(enc, seed=seed, img0=img0, **self.gen_kw)
+            res = self.model.decode(enc, seed=seed, img0=img0, defer_check=self._async, **self.gen_kw)
+            toks, lens = res[0], res[1]
+            err_host = None
+            if len(res) > 2:
+                err_host = torch.empty((1,), dtype=torch.int32).pin_memory()
+                err_host.copy_(res[2].view(-1)[:1], non_blocking=True)
             if to_host:
-                key = self._out_slot
-                self._out_slot = (self._out_slot + 1) % 3
-                bufs = self._host_out.get(key)
-                if bufs is None or bufs[0].shape != toks.shape:    # (a replaced pinned pair stays alive while a consumer holds it)
-                    bufs = self._host_out[key] = (torch.empty(toks.shape, dtype=toks.dtype).pin_memory(),
-                                                  torch.empty(lens.shape, dtype=lens.dtype).pin_memory())
-                bufs[0].copy_(toks, non_blocking=True)
-                bufs[1].copy_(lens, non_blocking=True)
-                toks, lens = bufs
+                toks, lens = self._to_host(toks, lens)
             done = torch.cuda.Event()
             done.record(self.dec_s)
-        return toks, lens, done
+        return dict(toks=toks, lens=lens, done=done, err=err_host, redo=(enc, seed, img0, to_host))
+
+    def _to_host(self, toks, lens):
+        key = self._out_slot
+        self._out_slot = (self._out_slot + 1) % 3
+        bufs = self._host_out.get(key)
+        if bufs is None or bufs[0].shape != toks.shape:    # (a replaced pinned pair stays alive while a consumer holds it)
+            bufs = self._host_out[key] = (torch.empty(toks.shape, dtype=toks.dtype).pin_memory(),
+                                          torch.empty(lens.shape, dtype=lens.dtype).pin_memory())
+        bufs[0].copy_(toks, non_blocking=True)
+        bufs[1].copy_(lens, non_blocking=True)
+        return bufs
+
+    def _finish(self, q):
+        """Waits for a queued batch and returns its ``(tokens, lengths)``; reads the deferred error word: flat logits that
+        overflowed the pre-filtered samplers (``BeamOverflow``) repeat this batch through the general sampler, anything else raises
+        as ``generate_batch`` does."""
+        from .models.beam import BeamOverflow, BeamSearchHelper, warn_overflow_retry
+        q["done"].synchronize()
+        if q["err"] is not None:
+            try:
+                BeamSearchHelper.raise_for(int(q["err"][0]))
+            except BeamOverflow:
+                warn_overflow_retry()
+                enc, seed, img0, to_host = q["redo"]
+                with torch.cuda.stream(self.dec_s), torch.no_grad():
+                    toks, lens = self.model.decode(enc, seed=seed, img0=img0, exact=True, **self.gen_kw)
+                    if to_host:
+                        toks, lens = self._to_host(toks, lens)
+                self.dec_s.synchronize()
+                return toks, lens
+        return q["toks"], q["lens"]
 
     # -- driver ------------------------------------------------------------------------------------------------------
-    def run(self, batches, seeds=None, img0=0, to_host=True):
+    def run(self, batches, seeds=None, img0=0, to_host=True, low_latency=False):
         """``batches``: iterable of input tuples (``(images,)`` or ``(images, labels)``), host (ideally pinned) or device
         tensors.  Yields ``(tokens, lengths)`` per batch, in order; with ``to_host`` they live in one of THREE pinned host
-        buffer pairs used in turn.  The decode of batch i+1 is already queued when batch i is yielded (no host round trip between
-        two batches' decode loops), so the pair yielded for batch i is overwritten by batch i+3's copy, which is issued when batch
-        i+1 is yielded: a result may be kept across ONE further iteration, and ``list(pipe.run(...))`` must clone.  All work of a
-        batch has completed when it is yielded."""
+        buffer pairs used in turn, so a result may be kept across ONE further iteration and ``list(pipe.run(...))`` must clone.
+        All work of a batch has completed when it is yielded.
+
+        Decoding is queued asynchronously (the beam engine's error word is examined only when the batch is handed over), in one of
+        two schedules:
+
+        * default (throughput): batch i is handed over while batch i+1 decodes -- its decode loop is queued right behind batch i's,
+          with no host round trip in between -- and the copy + encoder of batch i+2 are already issued; the hand-over of batch i
+          therefore happens after batch i+2 has been FETCHED from ``batches``;
+        * ``low_latency=True`` (a service whose iterator blocks until the next request arrives): batch i is handed over as soon as
+          it has finished, before anything further is fetched; only the copy + encoder of the already-fetched batch i+1 overlap its
+          decode."""
         it = iter(batches)
         seeds = iter(seeds) if seeds is not None else None
         cur = next(it, None)
         if cur is None:
             return
         enc, ev = self._encode(*self._stage(cur))
+        if low_latency:
+            nxt = next(it, None)
+            while cur is not None:
+                if nxt is not None:
+                    nxt_enc, nxt_ev = self._encode(*self._stage(nxt))
+                queued = self._decode(enc, ev, next(seeds) if seeds is not None else None, img0, to_host)
+                yield self._finish(queued)            # nothing finished is withheld while the iterator blocks
+                cur = nxt
+                if nxt is not None:
+                    enc, ev = nxt_enc, nxt_ev
+                    nxt = next(it, None)
+            return
         pending = None
         while cur is not None:
             nxt = next(it, None)
             if nxt is not None:                      # issue the next batch's copy + encoder BEFORE this batch's decode
                 nxt_enc, nxt_ev = self._encode(*self._stage(nxt))
             seed = next(seeds) if seeds is not None else None
-            queued = self._decode(enc, ev, seed, img0, to_host)          # asynchronous
+            queued = self._decode(enc, ev, seed, img0, to_host)          # asynchronous: returns once the launches are queued
             if pending is not None:                  # the PREVIOUS batch is handed over while this one decodes
-                pending[2].synchronize()
-                yield pending[0], pending[1]
+                yield self._finish(pending)
             pending = queued
             cur = nxt
             if nxt is not None:
                 enc, ev = nxt_enc, nxt_ev
         if pending is not None:
-            pending[2].synchronize()
-            yield pending[0], pending[1]
+            yield self._finish(pending)

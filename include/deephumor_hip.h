@@ -230,7 +230,7 @@ int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bi
 
 /* dh_linear_ln for the decode shapes with the weights stationary in registers (csrc/linear_wreg.hip; transformers.py:97,127,
  * 162-163 applied to the rows of one position): w_packed = dh_pack_mfma_fragments(W [N, K]) replaces (W, ldw).  Two forms:
- *   residual == NULL: optional ln->a_stats (deferred LayerNorm of the A rows), optional ReLU; K == 512, N % 128 == 0;
+ *   residual == NULL: optional ln->a_stats (deferred LayerNorm of the A rows), optional ReLU; K == 512, N % 64 == 0;
  *   residual != NULL: ln->o_stats required, ln->r_stats optional; K == 512 or 2,048, N % 64 == 0.
  * Results are bit-identical to dh_linear_ln on the unpacked weights.  _supported: 1 when (N, K, form) is taken. */
 int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats);
@@ -520,6 +520,7 @@ typedef struct dh_tr_layer {
     /* optional: dh_pack_mfma_fragments of (wqkv_f, or wqkv for layer 0), wo, weo, w1_f, w2 -- the register-stationary decode GEMMs
      * (dh_linear_ln_wreg) for positions with many rows; NULL = the tile kernels */
     const void *wqkv_pk, *wo_pk, *weo_pk, *w1_pk, *w2_pk;
+    const void* wq_pk;                                      /* optional: dh_pack_mfma_fragments(wq_f): fc_q as its own register-stationary GEMM in front of the packed cross-attention */
 } dh_tr_layer_t;
 
 typedef struct dh_tr_model {

@@ -726,7 +726,7 @@ def test_linear_ln_wreg_equals_tile_kernels(hip, m):
     y = bf(torch.randn(m, d, generator=g) * 1.7 + 0.3).cuda()
     stats = _tile_stats(y.float().cpu()).cuda()
     gamma, beta = (torch.rand(d, generator=g) + 0.5).cuda(), (torch.randn(d, generator=g) * 0.2).cuda()
-    for n in (3 * d, pf, 128):
+    for n in (3 * d, pf, 128, d, 192):
         w = bf(torch.randn(n, d, generator=g) / d ** 0.5).cuda()
         b, cs = (torch.randn(n, generator=g) * 0.1).cuda(), (torch.randn(n, generator=g)).cuda()
         wp = hip.pack_mfma_fragments(w)

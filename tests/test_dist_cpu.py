@@ -4,6 +4,8 @@ import datetime
 import os
 import socket
 
+import pytest
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -113,7 +115,7 @@ def test_bench_timed_region_over_two_ranks():
             assert calls == [0, 1, 2] and seen == 2                         # EXACTLY K steps on every rank
             assert torch.equal(toks, want_t) and torch.equal(lens, want_l)  # whole batch, global order, on every rank
             assert dt >= 3 * 0.1 - 0.02                                     # max over ranks (rank 1 sleeps 0.1 s per step)
-        assert abs(ret[0][0] - ret[1][0]) < 1e-9                            # one all-reduced number
+        assert abs(ret[0][0] - ret[1][0]) < 1e-9                            # the same number on every rank
 
 
 def test_bench_gpus_n_launches_its_own_ranks(monkeypatch, capfd):
@@ -136,6 +138,8 @@ def test_bench_gpus_n_launches_its_own_ranks(monkeypatch, capfd):
     assert line["steps_run"] == [0, 1, 2] and line["gathered"] == 10 and line["gather_in_global_order"]
     assert line["data"] == "stub"                                          # can never be mistaken for a measurement
     assert line["ms_per_step"] >= 20 - 2                                   # rank 1 sleeps 20 ms per step: MAX over ranks
+    pr = line["per_rank_ms_per_step"]                                      # every rank's own time (one all_gather of a float): the skew is visible
+    assert pr["ranks"] == 2 and pr["max"] == pytest.approx(line["ms_per_step"]) and pr["min"] <= pr["max"]
 
 
 def test_bench_rejects_mismatched_world_size(monkeypatch, capfd):

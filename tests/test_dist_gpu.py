@@ -15,7 +15,11 @@ CHILD = r"""
 import datetime, json, os, sys
 sys.path.insert(0, %(root)r)
 import torch, torch.distributed as dist
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+import socket
+with socket.socket() as _s:                      # a free port per run: two concurrent runs on one box must not collide
+    _s.bind(("127.0.0.1", 0))
+    _port = _s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(_port))
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
@@ -34,7 +38,8 @@ import bench
 os.environ["DH_DIST_ALWAYS"] = "1"
 dt, out = bench.timed_region(lambda s: s + 1, 3, 1, dev)
 print("RESULT " + json.dumps({"backend": dist.get_backend(), "ids": bool(torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])),
-                              "rows": bool(torch.equal(rows, back)), "timed_out": out, "dt_ok": dt > 0}))
+                              "rows": bool(torch.equal(rows, back)), "timed_out": out, "dt_ok": dt > 0,
+                              "rank_times": len(bench.RANK_TIMES) == 1 and abs(bench.RANK_TIMES[0] - dt) < 1e-9}))
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -45,7 +50,7 @@ def test_sharded_generate_through_one_rank_rccl():
     assert p.returncode == 0, p.stderr[-2000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
     res = json.loads(line[7:])
-    assert res == {"backend": "nccl", "ids": True, "rows": True, "timed_out": 3, "dt_ok": True}
+    assert res == {"backend": "nccl", "ids": True, "rows": True, "timed_out": 3, "dt_ok": True, "rank_times": True}
 
 
 def test_bench_rccl_single_line():
@@ -54,3 +59,4 @@ def test_bench_rccl_single_line():
     assert p.returncode == 0, p.stderr[-2000:]
     line = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])      # the LAST stdout line (RCCL's banner must not follow it)
     assert line["n_ranks_seen"] == 1 and "rccl_single_rank" in line and line["value"] > 0
+    assert line["per_rank_ms_per_step"]["ranks"] == 1 and line["per_rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"])

@@ -1,0 +1,33 @@
+"""One fixed seed of every randomised sweep of tools/ (``tools/fuzz_all.sh`` runs them at ~20x these trial counts; the summary
+lines of a full run are committed under profiles/r4/fuzz_summary.txt) inside ``-m gpu``: a regression in any swept entry point --
+generate / forward against the CPU oracle on random model shapes, the samplers, the scorer, the GEMM / convolution / encoder
+kernels against fp32 references, the BeamSearchHelper method surface, the pipeline, the kernel variants -- turns the driver's
+run red.  Each tool prints one JSON record per trial and a last summary line; the bar is zero failing trials."""
+import importlib
+import json
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 11
+
+SWEEPS = [("fuzz_generate", 12, ["--half"]), ("fuzz_generate", 2, ["--long"]), ("fuzz_forward", 12, []), ("fuzz_forward", 2, ["--big"]),
+          ("fuzz_encoder", 4, []), ("fuzz_beam_methods", 15, []), ("fuzz_sampler", 25, []), ("fuzz_scoring", 15, []),
+          ("fuzz_gemm", 15, []), ("fuzz_conv", 8, []), ("fuzz_pipeline", 6, []), ("fuzz_variants", 6, [])]
+
+
+@pytest.mark.parametrize("tool,trials,extra", SWEEPS, ids=[t + "".join(e) for t, _, e in SWEEPS])
+def test_one_seed_of_the_sweep(tool, trials, extra, capsys):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ROOT)
+    mod = importlib.import_module(tool)
+    rc = mod.main(["--trials", str(trials), "--seed", str(SEED)] + extra)
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    summary = json.loads(lines[-1])
+    failed = [l for l in lines[:-1] if '"ok": true' not in l and "fewer positive" not in l]
+    assert rc == 0 and summary["trials"] == trials, summary
+    assert summary.get("failures", 0) + summary.get("mismatches_or_errors", 0) == 0, (summary, failed[:3])

@@ -433,6 +433,41 @@ def test_u8_pipeline_equals_fp32_image_path(dtype):
             assert torch.equal(wt.cpu(), gt) and torch.equal(wl.cpu(), gl)
 
 
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_pipeline_schedules_and_deferred_error_word(kind):
+    """CaptionPipeline queues decodes asynchronously (the beam engine's error word is read at hand-over): four batches
+    give ``generate_batch``'s captions in both schedules; in the default schedule result i is handed over once batch i+2 has been
+    fetched, with ``low_latency=True`` before anything beyond batch i+1 is fetched; flat logits (BeamOverflow, detected at
+    hand-over) still give the exact sampler's captions."""
+    from deephumor_amd.pipeline import CaptionPipeline
+    model, _, _ = build(kind)
+    model = model.bfloat16()
+    imgs = synth_images(8, seed=3)
+    batches = [(imgs[2 * i:2 * i + 2].pin_memory(),) for i in range(4)]
+    kw = dict(max_len=10, beam_size=3, top_k=20, temperature=1.0)
+    with torch.no_grad():
+        want = [model.generate_batch(b[0].cuda(), seed=20 + i, **kw) for i, b in enumerate(batches)]
+    for low_latency, ahead in ((False, 2), (True, 1)):
+        fetched = []
+
+        def feed():
+            for i, b in enumerate(batches):
+                fetched.append(i)
+                yield b
+        pipe = CaptionPipeline(model, **kw)
+        for i, (gt, gl) in enumerate(pipe.run(feed(), seeds=[20, 21, 22, 23], low_latency=low_latency)):
+            assert max(fetched) == min(i + ahead, 3), (low_latency, i, fetched)
+            assert torch.equal(want[i][0].cpu(), gt) and torch.equal(want[i][1].cpu(), gl)
+    # flat logits: every row ties at its top-k threshold -> the pre-filtered samplers overflow; the pipeline repeats the batch exact
+    with torch.no_grad():
+        model.decoder.classifier.weight.zero_()
+        model.decoder.classifier.bias.zero_()
+        flat = model.generate_batch(batches[0][0].cuda(), seed=5, max_len=6, beam_size=3, top_k=20)
+        pipe = CaptionPipeline(model, max_len=6, beam_size=3, top_k=20)
+        got = [(t.clone(), l.clone()) for t, l in pipe.run(batches[:2], seeds=[5, 6])]
+    assert torch.equal(flat[0].cpu(), got[0][0]) and torch.equal(flat[1].cpu(), got[0][1])
+
+
 @pytest.mark.parametrize("kind", ("CaptioningTransformer", "CaptioningTransformerBase"))
 def test_pad_index_other_than_zero(kind):
     """``pad_index = 7`` (the reference's constructor accepts any value, transformers.py:393-394), goldens recorded from the reference:

@@ -94,11 +94,11 @@ def one_trial(rng, idx):
     return rec
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     bad = 0
     for i in range(args.trials):
         rng = random.Random(args.seed * 100003 + i)

@@ -158,12 +158,12 @@ def fp32_trial(rng, idx):
                 ok=bool(err <= 2e-4 * max(1.0, float(want.abs().max())) and check()))
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", default=None)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     torch.backends.cudnn.allow_tf32 = False
     bad = 0
     for i in range(args.trials):

@@ -89,12 +89,12 @@ def encoder_trial(rng, idx):
     return rec
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", choices=["resize", "encoder"], default=None)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     bad, worst = 0, {}
     for i in range(args.trials):
         for fn in (resize_trial, encoder_trial):

@@ -128,13 +128,13 @@ def one_trial(rng, idx):
 BIG = False
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", action="store_true", help="the product's widths (512) and 150-1400 rows: the large-batch kernel variants")
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--first", type=int, default=0)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     global BIG
     BIG = args.big
     bad = 0

@@ -118,12 +118,12 @@ def vocab_trial(rng, idx):
     return rec
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--only", choices=["linear", "vocab"], default=None)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     bad = 0
     for i in range(args.trials):
         for fn in (linear_trial, vocab_trial):

@@ -144,14 +144,14 @@ HALF = False
 LONG = False
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--first", type=int, default=0, help="index of the first trial (trial i depends only on (seed, i))")
     ap.add_argument("--long", action="store_true", help="captions of 100-380 positions on small decoders")
     ap.add_argument("--half", action="store_true", help="also run the bf16 / fp16 paths on every configuration (validity + repeatability)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     global HALF, LONG
     HALF, LONG = args.half, args.long
     bad = 0

@@ -22,11 +22,11 @@ from deephumor_amd.pipeline import CaptionPipeline, u8_preprocess          # noq
 from deephumor_amd.synth import load_synthetic                             # noqa: E402
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=30)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = random.Random(args.seed)
     models = {}
     for kind in ("CaptioningLSTM", "CaptioningTransformer"):

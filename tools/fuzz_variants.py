@@ -24,11 +24,11 @@ from deephumor_amd.synth import load_synthetic, synth_images           # noqa: E
 KINDS = ("CaptioningLSTM", "CaptioningLSTMWithLabels", "CaptioningTransformerBase", "CaptioningTransformer", "CaptioningTransformerWithLabels")
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=40)
     ap.add_argument("--seed", type=int, default=1)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     rng = random.Random(args.seed)
     bad = 0
     cache = {}

@@ -61,10 +61,18 @@ def main():
     ap.add_argument("--by-grid", action="store_true")
     ap.add_argument("--csv")
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--sequence", type=int, default=0, help="also print the LAST N dispatches in launch order (name, workgroups, us, gap to the previous one)")
     a = ap.parse_args()
     if a.pmc:
         return main_pmc(a)
     rows = load(a.db)
+    if a.sequence:
+        seq = rows[-a.sequence:]
+        for i, (name, st, en, gx, gy, gz, wx, lds, vg, ag) in enumerate(seq):
+            gap = (st - seq[i - 1][2]) / 1e3 if i else 0.0
+            short = name.split("(")[0]
+            short = short if len(short) < 70 else short[:67] + "..."
+            print(f"SEQ {i:5d} {(en - st) / 1e3:8.2f} us  gap {gap:7.2f}  wg={gx * gy * gz // max(wx, 1):<6} {short}")
     agg = defaultdict(list)
     for name, st, en, gx, gy, gz, wx, lds, vg, ag in rows:
         key = (name, gx * gy * gz // max(wx, 1), wx, lds) if a.by_grid else (name,)
