@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEED = 11
 
-SWEEPS = [("fuzz_generate", 12, ["--half"]), ("fuzz_generate", 2, ["--long"]), ("fuzz_forward", 12, []), ("fuzz_forward", 2, ["--big"]),
+SWEEPS = [("fuzz_generate", 12, ["--half"]), ("fuzz_generate", 2, ["--long"]), ("fuzz_generate", 8, ["--r4", "--half"]), ("fuzz_forward", 12, []), ("fuzz_forward", 2, ["--big"]),
           ("fuzz_encoder", 4, []), ("fuzz_beam_methods", 15, []), ("fuzz_sampler", 25, []), ("fuzz_scoring", 15, []),
           ("fuzz_gemm", 15, []), ("fuzz_conv", 8, []), ("fuzz_pipeline", 6, []), ("fuzz_variants", 6, [])]
 

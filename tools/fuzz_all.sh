@@ -17,6 +17,7 @@ run() {   # name, trials, extra args...
 }
 run fuzz_generate 250 --half
 run fuzz_generate 25 --long
+run fuzz_generate 120 --r4 --half
 run fuzz_forward 250
 run fuzz_forward 40 --big
 run fuzz_encoder 80

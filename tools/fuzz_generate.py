@@ -42,6 +42,10 @@ R.BeamBook.draw = _counting_draw
 
 
 def replay(fn, seed):
+    if R4:                                        # the product option: the draws consume torch's default generator in the reference's order
+        torch.manual_seed(seed)
+        with torch.no_grad():
+            return fn(None).reshape(-1).cpu().tolist()
     made = []
     orig = beam_mod.BeamSearchHelper.__init__
 
@@ -72,12 +76,23 @@ def one_trial(rng, idx):
         v = rng.randint(5, 300)
         beam = min(beam, 5, v)
         top_k = max(beam, min(top_k, v))
+    pad_index = 0
+    if R4:                                        # round 4: beam_size > 16 (any beam_size <= top_k is valid), pad_index 1 / 7, the product's rng="torch"
+        v = max(v, 70)
+        beam = rng.choice([17, 24, 33, 48, rng.randint(17, 64)])
+        top_k = rng.randint(beam, min(v, rng.choice([beam, 64, 100, 300])))
+        top_k = max(top_k, beam)
+        max_len = rng.randint(2, 14)
+        pad_index = rng.choice([0, 1, 1, 7])
     prefix = rng.choice([0, 0, rng.randint(1, max(1, max_len - 1))])
     prefix = min(prefix, max_len - 1)
     logit_std = rng.choice([2.5, 1.0, 4.0])
     cfg = dict(kind=kind, V=v, beam=beam, top_k=top_k, T=round(temp, 4), max_len=max_len, prefix=prefix, logit_std=logit_std)
+    if R4 and kind != "lstm":
+        cfg["pad_index"] = pad_index
     g = torch.Generator().manual_seed(1000 + idx)
-    cap = torch.randint(4, v, (1, prefix), generator=g) if prefix and v > 4 else None
+    lo = 8 if R4 else 4                           # (round-4 trials keep the prefix clear of the pad_index values under test)
+    cap = torch.randint(lo, v, (1, prefix), generator=g) if prefix and v > lo else None
     if kind == "lstm":
         e, h, nl = 8 * rng.randint(1, 40), 8 * rng.randint(1, 72), rng.randint(1, 3)
         cfg.update(emb=e, hidden=h, layers=nl)
@@ -92,7 +107,7 @@ def one_trial(rng, idx):
             cfg.update(hid=hid, heads=heads, layers=nl, pf=pf)
         cfg.update(hid=hid, heads=heads, layers=nl, pf=pf)
         cls = TransformerDecoder if kind == "tfm" else SelfAttentionTransformerDecoder
-        dec = cls(v, hid_dim=hid, n_layers=nl, n_heads=heads, pf_dim=pf, dropout=0.0, pad_index=0, max_len=pos)
+        dec = cls(v, hid_dim=hid, n_layers=nl, n_heads=heads, pf_dim=pf, dropout=0.0, pad_index=pad_index, max_len=pos)
     sd = synth_state_dict(dec.state_dict(), seed=77 + idx, logit_std=logit_std)
     dec.load_state_dict(sd)
     dec = dec.cuda().eval()
@@ -106,7 +121,7 @@ def one_trial(rng, idx):
         with torch.no_grad():
             want = R.lstm_decoder_generate(osd, "decoder", emb, **kw).reshape(-1).tolist()
         capd = cap.cuda() if cap is not None else None
-        got = replay(lambda ns: dec.generate(emb.cuda(), **dict(kw, caption=capd), noise_source=ns), seed)
+        got = replay(lambda ns: dec.generate(emb.cuda(), **dict(kw, caption=capd), **({'rng': 'torch'} if ns is None else {'noise_source': ns})), seed)
     else:
         start = torch.randn(1, cfg["hid"], generator=g)
         s_len = rng.choice([49, 49, rng.randint(1, 60)])
@@ -114,12 +129,12 @@ def one_trial(rng, idx):
         cfg["enc_len"] = s_len if enc is not None else 0
         torch.manual_seed(seed)
         with torch.no_grad():
-            want = R.transformer_generate(osd, "decoder", start, enc, 0, cfg["heads"], **kw).reshape(-1).tolist()
+            want = R.transformer_generate(osd, "decoder", start, enc, pad_index, cfg["heads"], **kw).reshape(-1).tolist()
         capd = cap.cuda() if cap is not None else None
         if kind == "tfm":
-            got = replay(lambda ns: dec.generate(start.cuda(), enc.cuda(), **dict(kw, caption=capd), noise_source=ns), seed)
+            got = replay(lambda ns: dec.generate(start.cuda(), enc.cuda(), **dict(kw, caption=capd), **({'rng': 'torch'} if ns is None else {'noise_source': ns})), seed)
         else:
-            got = replay(lambda ns: dec.generate(start.cuda(), **dict(kw, caption=capd), noise_source=ns), seed)
+            got = replay(lambda ns: dec.generate(start.cuda(), **dict(kw, caption=capd), **({'rng': 'torch'} if ns is None else {'noise_source': ns})), seed)
     cfg["undefined_candidate_draws"] = UNDEFINED_DRAWS[0]
     if HALF:
         # the 16-bit paths on the same configuration: they must run, repeat exactly under the same Philox seed, and emit valid ids
@@ -142,6 +157,7 @@ def one_trial(rng, idx):
 
 HALF = False
 LONG = False
+R4 = False
 
 
 def main(argv=None):
@@ -151,9 +167,10 @@ def main(argv=None):
     ap.add_argument("--first", type=int, default=0, help="index of the first trial (trial i depends only on (seed, i))")
     ap.add_argument("--long", action="store_true", help="captions of 100-380 positions on small decoders")
     ap.add_argument("--half", action="store_true", help="also run the bf16 / fp16 paths on every configuration (validity + repeatability)")
+    ap.add_argument("--r4", action="store_true", help="beam_size 17-64, pad_index in {0, 1, 7}, draws through the product's rng=\"torch\"")
     args = ap.parse_args(argv)
-    global HALF, LONG
-    HALF, LONG = args.half, args.long
+    global HALF, LONG, R4
+    HALF, LONG, R4 = args.half, args.long, args.r4
     bad = 0
     for i in range(args.first, args.first + args.trials):
         rng = random.Random(args.seed * 100003 + i)
