@@ -31,9 +31,6 @@ struct LwParams {
     const float2* a_stats; int a_nt; float a_eps; const float* a_colsum;
     const float2* r_stats; int r_nt; float r_eps; const float* r_gamma; const float* r_beta;
     float2* o_stats;
-    // data-flow hand-over between the two phases of dh_ffn_wreg (one launch): arrive[g] counts the producer workgroups of row group g that
-    // have finished, depart[g] the consumer workgroups that have seen it complete (the last one re-arms both counters)
-    int* arrive; int* depart; int grp_div, need, consumers;
 };
 
 // global -> LDS, 16 bytes per lane: wave-uniform base (SGPR pair) + per-lane byte offset
@@ -42,51 +39,44 @@ __device__ __forceinline__ void lw_dma16(const void* base, unsigned off, void* l
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m), "v"(off), "s"(base) : "memory");
 }
 
-// NW waves (CT 16-column tiles each), RL activation rows in LDS, KQ = K / 512, LNX: 0 = (deferred LayerNorm on the A rows |
-// plain) + optional ReLU; 1 = residual (optionally pre-LayerNorm) + statistics of the output rows.
-// SYNC (dh_ffn_wreg, two GEMMs in one launch): 1 = producer -- after its stores are visible device-wide it adds 1 to arrive[row group];
-// 2 = consumer -- requests everything that does not depend on the producer (residual rows, statistics, its weight fragments) FIRST, then
-// waits until arrive[row group] == need, and only then stages its activation block.
-template <typename OT, int NW, int CT, int RL, int KQ, int LNX, int SYNC>
-__device__ __forceinline__ void lw_body(const LwParams& p, unsigned char* lds, const int bid) {
-    constexpr int NT = 64 * NW, BN = 16 * NW * CT, TM = (RL + 15) / 16, RG = RL / 8, NSLAB = 8 * KQ, SLABB = RL * 128;
+// NW waves (16 output columns each), RL activation rows in LDS, KQ = K / 512, LNX: 0 = (deferred LayerNorm on the A rows |
+// plain) + optional ReLU; 1 = residual (optionally pre-LayerNorm) + statistics of the output rows
+template <typename OT, int NW, int RL, int KQ, int LNX>
+__global__ __launch_bounds__(64 * NW, 1) void linear_wreg_kernel(LwParams p) {
+    constexpr int NT = 64 * NW, BN = 16 * NW, TM = (RL + 15) / 16, RG = RL / 8, NSLAB = 8 * KQ, SLABB = RL * 128;
     constexpr int KF = 16 * KQ;                         // 32-k fragments per wave
     constexpr int WIN_SLABS = 65536 / SLABB, WIN = WIN_SLABS * SLABB, NWIN = (NSLAB + WIN_SLABS - 1) / WIN_SLABS;
     constexpr int PF = 3;                              // LDS fragment reads this many MFMAs ahead
     constexpr int CHUNKS = BN / 8, SLOTS = BN / 4, EP_IT = (RL * CHUNKS + NT - 1) / NT;
     static_assert(RL % 8 == 0 && RL <= NT && NSLAB * SLABB + (LNX == 0 ? RL * 8 : 0) <= 163840 && RL * BN * 4 <= NSLAB * SLABB, "LDS budget");
-    static_assert(SYNC == 0 || (SYNC == 1 && LNX == 0) || (SYNC == 2 && LNX == 1), "producer = fc_1 form, consumer = fc_2 form");
     static_assert((NSLAB * RG) % NW == 0, "pieces per wave");
+    constexpr int STAT_BYTES = LNX == 0 ? RL * 8 : 0;  // (mean, rstd) of the block's rows (deferred LayerNorm of the A rows)
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLAB * SLABB + STAT_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4, lr = lane >> 3, lpos = lane & 7;
     int cb, rb;
-    if (p.xn) {                                        // XCD x = block % 8 owns column group x % xn, row group x / xn
-        const int xcd = bid & 7, idx = bid >> 3;
+    if (p.xn) {                                        // XCD x = blockIdx % 8 owns column group x % xn, row group x / xn
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         const int cpg = p.tiles_n / p.xn, rpg = p.tiles_m / (8 / p.xn);
         cb = (xcd % p.xn) * cpg + idx % cpg; rb = (xcd / p.xn) * rpg + idx / cpg;
     } else {
-        cb = bid % p.tiles_n; rb = bid / p.tiles_n;
+        cb = blockIdx.x % p.tiles_n; rb = blockIdx.x / p.tiles_n;
     }
     const int m0 = rb * RL, n0 = cb * BN;
 
     // ---- epilogue operands: requested BEFORE the LDS-DMA transfers (ordinary loads the compiler counts; vmcnt retires in order) -------
-    float4 b4[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) b4[c] = *reinterpret_cast<const float4*>(p.bias + n0 + 16 * (wave * CT + c) + 4 * lq);
+    const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n0 + 16 * wave + 4 * lq);
     // deferred LayerNorm of the A rows: thread r < RL fetches the statistics partials of block row r (64 contiguous bytes per row:
     // 4 coalesced instructions per wave) and leaves (mean, rstd) in LDS for the lanes whose accumulators hold that row -- fetched per
     // accumulator lane instead, they are 4 TM scattered loads per wave, as many vector-memory instructions as the operands themselves
     float4 a_raw[4];
-    float4 cs4[CT];
-#pragma unroll
-    for (int c = 0; c < CT; ++c) cs4[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const bool a_ln = LNX == 0 && p.a_stats != nullptr;
     if (LNX == 0) {
         if (a_ln) {
             if (tid < RL) ln_load(p.a_stats + (size_t)min(m0 + tid, p.M - 1) * p.a_nt, p.a_nt, a_raw);
-#pragma unroll
-            for (int c = 0; c < CT; ++c) cs4[c] = *reinterpret_cast<const float4*>(p.a_colsum + n0 + 16 * (wave * CT + c) + 4 * lq);
+            cs4 = *reinterpret_cast<const float4*>(p.a_colsum + n0 + 16 * wave + 4 * lq);
         }
     }
     uint4 rq[EP_IT];
@@ -105,19 +95,8 @@ __device__ __forceinline__ void lw_body(const LwParams& p, unsigned char* lds, c
             }
         }
     }
-    // ---- this wave's 16 CT weight rows x all K: CT x KF fragments of 1 KB, straight into registers ----------------------------------------
-    uint4 wf[CT][KF];
-    auto load_w = [&]() {
-        const size_t fstep = (size_t)(p.N / 16) * 64;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-            const uint4* wsrc = p.wp + ((size_t)(n0 / 16 + wave * CT + c)) * 64 + lane;
-#pragma unroll
-            for (int f = 0; f < KF; ++f) wf[c][f] = wsrc[(size_t)f * fstep];
-        }
-    };
     // ---- the activation block: slab s = k 64 s .. + 63 of all RL rows, piece = 8 rows x 128 bytes; wave w stages slabs w, w + NW, ... ----
-    auto stage_a = [&]() {
+    {
         unsigned ro[RG];                               // byte offsets of this lane's source chunk in the rows of each 8-row group
         const unsigned swz = (unsigned)((lpos ^ lr) << 4);     // source chunk of LDS slot lpos in a row with (row & 7) == lr
 #pragma unroll
@@ -132,31 +111,14 @@ __device__ __forceinline__ void lw_body(const LwParams& p, unsigned char* lds, c
                 for (int g = 0; g < RG; ++g) lw_dma16(p.A, ro[g] + 128u * s, dst + g * 1024);
             }
         }
-    };
-    if constexpr (SYNC == 2) {
-        load_w();
-        // the producer phase's rows of this block: wait (one lane polls; bounded, so that a fault cannot hang the GPU), then make them visible
-        const int grp = rb / p.grp_div;
-        if (tid == 0) {
-            for (int spin = 0; spin < (1 << 24); ++spin) {
-                if (__hip_atomic_load(p.arrive + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= p.need) break;
-                __builtin_amdgcn_s_sleep(1);
-            }
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        stage_a();
-        if (tid == 0) {                                // the last consumer of the group re-arms the counters for the next launch
-            const int old = __hip_atomic_fetch_add(p.depart + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int blocks_in_grp = min(p.grp_div, p.tiles_m - grp * p.grp_div);
-            if (old == p.consumers * blocks_in_grp - 1) {
-                __hip_atomic_store(p.depart + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(p.arrive + grp, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    } else {
-        stage_a();                                     // (LDS-DMA first: every ordinary load whose wait the compiler counts is younger)
-        load_w();
+    }
+    // ---- this wave's 16 weight rows x all K: KF fragments of 1 KB, straight into registers ----------------------------------------------
+    uint4 wf[KF];
+    {
+        const uint4* wsrc = p.wp + ((size_t)(n0 / 16 + wave)) * 64 + lane;
+        const size_t fstep = (size_t)(p.N / 16) * 64;
+#pragma unroll
+        for (int f = 0; f < KF; ++f) wf[f] = wsrc[(size_t)f * fstep];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces, fragments and operands have landed
     // statistics -> mean / rstd now (frees the raw partials' registers before the MFMA loop)
@@ -181,11 +143,9 @@ __device__ __forceinline__ void lw_body(const LwParams& p, unsigned char* lds, c
     }
 
     // ---- TM row tiles x KF k-steps; fragment reads PF steps ahead of their MFMAs ---------------------------------------------------------
-    dh_f32x4 acc[CT][TM];
+    dh_f32x4 acc[TM];
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[c][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TM; ++i) acc[i] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
     // LDS read bases: (k half) x (64 KB window) [x last-tile variant]; row 16 i + l15 has (row & 7) == (l15 & 7).  With RL % 16 == 8 the
     // upper half of the last tile does not exist: those lanes re-read the lower half's rows (same row & 7), their outputs are dropped
     constexpr bool PARTIAL = (RL % 16) != 0;
@@ -212,31 +172,28 @@ __device__ __forceinline__ void lw_body(const LwParams& p, unsigned char* lds, c
     for (int t = 0; t < KF * TM; ++t) {
         const int f = t / TM, i = t - f * TM;
         if (t + PF < KF * TM) rd(t + PF);
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[c][i] = Op16<OT>::mfma(wf[c][f], fa[t % (PF + 1)], acc[c][i]);
+        acc[i] = Op16<OT>::mfma(wf[f], fa[t % (PF + 1)], acc[i]);
         __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();                                   // every wave is done reading the block: LDS is free for the epilogue
 
-    // ---- epilogue: acc[c][i][r] = C[m0 + 16 i + l15][n0 + 16 (wave CT + c) + 4 lq + r], staged as fp32 rows (XOR-swizzled 16-byte slots) ----
+    // ---- epilogue: acc[i][r] = C[m0 + 16 i + l15][n0 + 16 wave + 4 lq + r], staged as fp32 rows (XOR-swizzled 16-byte slots) --------------
     float* ep = reinterpret_cast<float*>(lds);
 #pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int row = 16 * i + l15, slot = 4 * (wave * CT + c) + lq;
-            if (PARTIAL && row >= RL) continue;
-            float4 v;
-            if (a_ln) {                                // rstd * (acc - mu * colsum) + bias'
-                v.x = fmaf(a_rs[i], fmaf(-a_mu[i], cs4[c].x, acc[c][i][0]), b4[c].x);
-                v.y = fmaf(a_rs[i], fmaf(-a_mu[i], cs4[c].y, acc[c][i][1]), b4[c].y);
-                v.z = fmaf(a_rs[i], fmaf(-a_mu[i], cs4[c].z, acc[c][i][2]), b4[c].z);
-                v.w = fmaf(a_rs[i], fmaf(-a_mu[i], cs4[c].w, acc[c][i][3]), b4[c].w);
-            } else {
-                v.x = acc[c][i][0] + b4[c].x; v.y = acc[c][i][1] + b4[c].y; v.z = acc[c][i][2] + b4[c].z; v.w = acc[c][i][3] + b4[c].w;
-            }
-            *reinterpret_cast<float4*>(ep + row * BN + ((slot ^ (row & (SLOTS - 1))) << 2)) = v;
+    for (int i = 0; i < TM; ++i) {
+        const int row = 16 * i + l15, slot = 4 * wave + lq;
+        if (PARTIAL && row >= RL) continue;
+        float4 v;
+        if (a_ln) {                                    // rstd * (acc - mu * colsum) + bias'
+            v.x = fmaf(a_rs[i], fmaf(-a_mu[i], cs4.x, acc[i][0]), b4.x);
+            v.y = fmaf(a_rs[i], fmaf(-a_mu[i], cs4.y, acc[i][1]), b4.y);
+            v.z = fmaf(a_rs[i], fmaf(-a_mu[i], cs4.z, acc[i][2]), b4.z);
+            v.w = fmaf(a_rs[i], fmaf(-a_mu[i], cs4.w, acc[i][3]), b4.w);
+        } else {
+            v.x = acc[i][0] + b4.x; v.y = acc[i][1] + b4.y; v.z = acc[i][2] + b4.z; v.w = acc[i][3] + b4.w;
         }
+        *reinterpret_cast<float4*>(ep + row * BN + ((slot ^ (row & (SLOTS - 1))) << 2)) = v;
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < EP_IT; ++it) {
@@ -286,36 +243,6 @@ __device__ __forceinline__ void lw_body(const LwParams& p, unsigned char* lds, c
             }
         }
     }
-    if constexpr (SYNC == 1) {
-        // this workgroup's rows are written: write them back from this XCD's L2 (release, agent scope -- the consumer may run on another
-        // XCD, whose L2 is not coherent with this one), then count the workgroup in
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(p.arrive + rb / p.grp_div, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
-template <int RL, int KQ, int LNX> constexpr int lw_lds_bytes() { return 8 * KQ * RL * 128 + (LNX == 0 ? RL * 8 : 0); }
-
-template <typename OT, int NW, int CT, int RL, int KQ, int LNX>
-__global__ __launch_bounds__(64 * NW, 1) void linear_wreg_kernel(LwParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[lw_lds_bytes<RL, KQ, LNX>()];
-    lw_body<OT, NW, CT, RL, KQ, LNX, 0>(p, lds, blockIdx.x);
-}
-
-// The position-wise feed-forward layer (transformers.py:162-163: fc_2(relu(fc_1(x)))) as ONE launch of two phases with a data-flow
-// hand-over instead of a kernel boundary: workgroups [0, n1) are fc_1 (128 columns x 80 rows, 4 waves x 2 column tiles), workgroups
-// [n1, n1 + n2) are fc_2 (64 columns x 40 rows, K = 2,048).  A fc_2 workgroup first requests its 256 KB of weight fragments, its
-// residual rows and their statistics -- none of which depend on fc_1 -- and only then waits for the 16 fc_1 workgroups of its 80-row
-// group.  The hardware hands a grid's workgroups to each XCD in index order, so every fc_1 workgroup is resident or finished before
-// the first fc_2 workgroup starts; fc_1 workgroups never wait: the wait cannot deadlock (and is bounded anyway).  In a chain of
-// dependent launches a kernel boundary costs ~8 us on this part (drain, write-back, launch, cold caches, first operand round trip);
-// here fc_2's prologue overlaps fc_1's tail.
-template <typename OT>
-__global__ __launch_bounds__(256, 1) void ffn_wreg_kernel(LwParams p1, LwParams p2, int n1) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds[lw_lds_bytes<40, 4, 1>()];
-    if ((int)blockIdx.x < n1) lw_body<OT, 4, 2, 80, 1, 0, 1>(p1, lds, blockIdx.x);
-    else lw_body<OT, 4, 1, 40, 4, 1, 2>(p2, lds, (int)blockIdx.x - n1);
 }
 
 // XCD column groups: the divisor xn of 8 (tiles_n % xn == 0, tiles_m % (8 / xn) == 0) with the fewest operand bytes per XCD; 0 = none fits
@@ -371,8 +298,8 @@ extern "C" int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, c
         p.xn = pick_xn(p.tiles_m, p.tiles_n, 64.0 * K * 2, 40.0 * K * 2);
         const dim3 grid(p.tiles_m * p.tiles_n);
         DH_DISPATCH_16(dtype, {
-            if (K == 512) hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 1, 40, 1, 1>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 1, 40, 4, 1>), grid, dim3(256), 0, s, p);
+            if (K == 512) hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 1, 1>), grid, dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 4, 1>), grid, dim3(256), 0, s, p);
         });
         DH_LAUNCH_CHECK();
     }
@@ -380,7 +307,7 @@ extern "C" int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, c
         // narrow outputs (the cross-attention query projection, N = D = 512): 64-column x 40-row blocks, 4 waves, as the residual form
         p.tiles_n = N / 64; p.tiles_m = dh_cdiv(M, 40);
         p.xn = pick_xn(p.tiles_m, p.tiles_n, 64.0 * K * 2, 40.0 * K * 2);
-        DH_DISPATCH_16(dtype, hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 1, 40, 1, 0>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p));
+        DH_DISPATCH_16(dtype, hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 1, 0>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p));
         DH_LAUNCH_CHECK();
     }
     p.tiles_n = N / 128;
@@ -390,53 +317,8 @@ extern "C" int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, c
     p.xn = pick_xn(p.tiles_m, p.tiles_n, 128.0 * K * 2, (rl64 ? 64.0 : 80.0) * K * 2);
     const dim3 grid(p.tiles_m * p.tiles_n);
     DH_DISPATCH_16(dtype, {
-        if (rl64) hipLaunchKernelGGL((linear_wreg_kernel<T, 8, 1, 64, 1, 0>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((linear_wreg_kernel<T, 8, 1, 80, 1, 0>), grid, dim3(512), 0, s, p);
+        if (rl64) hipLaunchKernelGGL((linear_wreg_kernel<T, 8, 64, 1, 0>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((linear_wreg_kernel<T, 8, 80, 1, 0>), grid, dim3(512), 0, s, p);
     });
-    DH_LAUNCH_CHECK();
-}
-
-// fc_2(relu(fc_1(LN(x)))) + residual of one decode position in ONE launch (see ffn_wreg_kernel): dh_linear_ln_wreg(x, w1_packed, ...,
-// relu, ln1 -> ff) followed by dh_linear_ln_wreg(ff, w2_packed, ..., residual, ln2 -> out), bit-identical to the two calls.
-// ln1: a_stats form (or no LayerNorm); ln2: residual form with o_stats.  D == 512, PF == 2,048.  sync = int32 [2 * ceil(M / 80)],
-// zero before the first call (the kernel leaves it zero).
-extern "C" int dh_ffn_wreg_supported(int D, int PF) { return D == 512 && PF == 2048; }
-
-extern "C" int dh_ffn_wreg(const void* x, int ldx, const void* w1_packed, const float* b1, const dh_ln_fold_t* ln1, void* ff, int ldff,
-                           const void* w2_packed, const float* b2, const void* residual, int ldres, const dh_ln_fold_t* ln2, void* out,
-                           int ldo, int M, int D, int PF, int32_t* sync, int dtype, void* stream) {
-    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
-    DH_REQUIRE(x && w1_packed && b1 && ln1 && ff && w2_packed && b2 && residual && ln2 && out && sync && M > 0 && dh_ffn_wreg_supported(D, PF));
-    DH_REQUIRE((ldx % 8) == 0 && ldx >= D && (ldff % 8) == 0 && ldff >= PF && (ldres % 8) == 0 && ldres >= D && (ldo % 8) == 0 && ldo >= D);
-    DH_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w1_packed % 16) == 0 && ((uintptr_t)w2_packed % 16) == 0 && ((uintptr_t)ff % 16) == 0 &&
-               ((uintptr_t)out % 16) == 0 && ((uintptr_t)residual % 16) == 0 && ((uintptr_t)b1 % 16) == 0 && ((uintptr_t)b2 % 16) == 0);
-    DH_REQUIRE((unsigned long long)M * (unsigned)ldff * 2ull < (1ull << 32) && (unsigned long long)M * (unsigned)ldx * 2ull < (1ull << 32));
-    DH_REQUIRE(!ln1->o_stats && !ln1->r_stats && ln2->o_stats && !ln2->a_stats && ((uintptr_t)ln2->o_stats % 8) == 0);
-    DH_REQUIRE(!ln1->a_stats || (ln1->a_colsum && ln1->a_tiles == 8 && ((uintptr_t)ln1->a_stats % 16) == 0 && ((uintptr_t)ln1->a_colsum % 16) == 0));
-    DH_REQUIRE(!ln2->r_stats || (ln2->r_gamma && ln2->r_beta && ln2->r_tiles == 8 && ((uintptr_t)ln2->r_stats % 16) == 0 &&
-                                 ((uintptr_t)ln2->r_gamma % 16) == 0 && ((uintptr_t)ln2->r_beta % 16) == 0));
-    LwParams p1{}, p2{};
-    p1.A = (const uint16_t*)x; p1.lda = ldx; p1.wp = (const uint4*)w1_packed; p1.bias = b1; p1.C = (uint16_t*)ff; p1.ldc = ldff;
-    p1.M = M; p1.N = PF; p1.relu = 1;
-    p1.a_stats = (const float2*)ln1->a_stats; p1.a_nt = ln1->a_tiles; p1.a_eps = ln1->a_eps; p1.a_colsum = ln1->a_colsum;
-    p1.tiles_n = PF / 128; p1.tiles_m = dh_cdiv(M, 80);
-    p1.xn = pick_xn(p1.tiles_m, p1.tiles_n, 128.0 * D * 2, 80.0 * D * 2);
-    p2.A = (const uint16_t*)ff; p2.lda = ldff; p2.wp = (const uint4*)w2_packed; p2.bias = b2; p2.res = (const uint16_t*)residual; p2.ldres = ldres;
-    p2.C = (uint16_t*)out; p2.ldc = ldo; p2.M = M; p2.N = D;
-    p2.r_stats = (const float2*)ln2->r_stats; p2.r_nt = ln2->r_tiles; p2.r_eps = ln2->r_eps; p2.r_gamma = ln2->r_gamma; p2.r_beta = ln2->r_beta;
-    p2.o_stats = (float2*)ln2->o_stats;
-    p2.tiles_n = D / 64; p2.tiles_m = dh_cdiv(M, 40);
-    p2.xn = pick_xn(p2.tiles_m, p2.tiles_n, 64.0 * PF * 2, 40.0 * PF * 2);
-    // hand-over: row group g = 80-row block g of fc_1 (16 producer workgroups) = 40-row blocks 2g, 2g + 1 of fc_2 (8 consumers each)
-    p1.arrive = p2.arrive = sync; p1.depart = p2.depart = sync + p1.tiles_m;
-    p1.grp_div = 1; p2.grp_div = 2; p2.need = p1.tiles_n;
-    p2.consumers = 0;                                   // per group below: the last group may hold ONE 40-row block
-    // (consumers differ for the last group when M % 80 is in 1..40: handled in the kernel through tiles_m)
-    const int n1 = p1.tiles_m * p1.tiles_n, n2 = p2.tiles_m * p2.tiles_n;
-    p2.consumers = p2.tiles_n;                          // per 40-row block; the kernel multiplies by the group's block count
-    dh_prof_set_tag("ffn");
-    dh_prof_set_dims(M, PF + D, D);
-    DhProfScope prof("dh_ffn", 4.0 * M * D * PF, 2.0 * ((double)M * D * 3 + 2.0 * D * PF + 2.0 * M * PF), stream);
-    DH_DISPATCH_16(dtype, hipLaunchKernelGGL((ffn_wreg_kernel<T>), dim3(n1 + n2), dim3(256), 0, (hipStream_t)stream, p1, p2, n1));
     DH_LAUNCH_CHECK();
 }

@@ -90,17 +90,6 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
             DH_TRY(chain_linear(sc->att, D, L.weo, L.weo_pk, L.beo, sc->o, D, sc->y2, D, rows, D, D, 0, &f, dt, stream));
             yin = sc->y2; st_in = sc->st2; g_in = L.ln2_g; b_in = L.ln2_b; eps_in = L.ln2_eps;
         }
-        // 5 + 6 in ONE launch (data-flow hand-over between fc_1 and fc_2, csrc/linear_wreg.hip) when the layer carries the packed weights
-        static const int ffn_fused = getenv("DH_FFN_FUSED") ? atoi(getenv("DH_FFN_FUSED")) : 1;
-        static const int ffn_min_rows = getenv("DH_DECODE_WREG_MIN_ROWS") ? atoi(getenv("DH_DECODE_WREG_MIN_ROWS")) : 320;
-        if (ffn_fused && L.w1_pk && L.w2_pk && sc->ffn_sync && rows >= ffn_min_rows && dh_ffn_wreg_supported(D, PF) &&
-            !(getenv("DH_DECODE_WREG") && atoi(getenv("DH_DECODE_WREG")) == 0)) {
-            dh_ln_fold_t f1{}, f2{};
-            f1.a_stats = st_in; f1.a_tiles = nt; f1.a_eps = eps_in; f1.a_colsum = L.cs_1;
-            f2.r_stats = st_in; f2.r_tiles = nt; f2.r_eps = eps_in; f2.r_gamma = g_in; f2.r_beta = b_in; f2.o_stats = sc->st0;
-            DH_TRY(dh_ffn_wreg(yin, D, L.w1_pk, L.b1_f, &f1, sc->ff, PF, L.w2_pk, L.b2, yin, D, &f2, sc->x, D, rows, D, PF, sc->ffn_sync, dt, stream));
-            continue;
-        }
         // 5. ff = relu(LN(Yin) W1^T + b1)
         f = dh_ln_fold_t{};
         f.a_stats = st_in; f.a_tiles = nt; f.a_eps = eps_in; f.a_colsum = L.cs_1;

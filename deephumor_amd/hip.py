@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 17
+ABI_VERSION = 16
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -37,7 +37,7 @@ class TrModel(_c.Structure):
 
 
 class TrScratch(_c.Structure):
-    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2", "ffn_sync")]
+    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2")]
 
 
 class LnFold(_c.Structure):
@@ -86,8 +86,6 @@ SIGNATURES = {
     "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "dh_linear_ln": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
     "dh_linear_ln_wreg_supported": [_I, _I, _I],
-    "dh_ffn_wreg_supported": [_I, _I],
-    "dh_ffn_wreg": [_P, _I, _P, _P, _c.POINTER(LnFold), _P, _I, _P, _P, _P, _I, _c.POINTER(LnFold), _P, _I, _I, _I, _I, _P, _I, _P],
     "dh_linear_ln_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
     "dh_attn_cross_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dh_attn_cross_qproj_decode": [_P, _I, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
@@ -458,32 +456,6 @@ def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_
             residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
             _dt(a), _stream(), tag=tag)
     return (out, stats) if residual is not None else out
-
-
-def ffn_wreg_supported(d, pf):
-    return bool(load().dh_ffn_wreg_supported(int(d), int(pf)))
-
-
-def ffn_wreg(x, w1_packed, b1, w2_packed, b2, residual, sync, a_ln=None, r_ln=None, tag=None):
-    """``dh_ffn_wreg``: ``fc_2(relu(fc_1(LN(x)))) + LN(residual)`` of one decode position in one launch (two phases with a data-flow
-    hand-over).  Returns ``(out [M, D], stats [M, D/64, 2], ff [M, PF])``; ``sync`` = zeroed int32 ``[2 * ceil(M / 80)]``."""
-    _dev(x, w1_packed, b1, w2_packed, b2, residual, sync)
-    m, d = x.shape
-    pf = b1.shape[0]
-    ff = torch.empty((m, pf), dtype=x.dtype, device=x.device)
-    out = torch.empty((m, d), dtype=x.dtype, device=x.device)
-    stats = torch.empty((m, d // 64, 2), dtype=torch.float32, device=x.device)
-    f1, f2 = LnFold(), LnFold()
-    if a_ln is not None:
-        st, eps, colsum = a_ln
-        f1.a_stats, f1.a_tiles, f1.a_eps, f1.a_colsum = _ptr(st), d // 64, float(eps), _ptr(colsum)
-    if r_ln is not None:
-        st, eps, gamma, beta = r_ln
-        f2.r_stats, f2.r_tiles, f2.r_eps, f2.r_gamma, f2.r_beta = _ptr(st), d // 64, float(eps), _ptr(gamma), _ptr(beta)
-    f2.o_stats = _ptr(stats)
-    _launch("dh_ffn_wreg", _ptr(x), x.stride(0), _ptr(w1_packed), _ptr(b1), _c.byref(f1), _ptr(ff), ff.stride(0), _ptr(w2_packed), _ptr(b2),
-            _ptr(residual), residual.stride(0), _c.byref(f2), _ptr(out), out.stride(0), m, d, pf, _ptr(sync), _dt(x), _stream(), tag=tag)
-    return out, stats, ff
 
 
 def attn_cross_pack(kv, n_img, s, d, n_heads, dperm=False):

@@ -303,8 +303,6 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     bufs["y2"] = e(rows, self.d)
                     for k in ("st0", "st1", "st2"):
                         bufs[k] = torch.empty((rows, self.d // 64, 2), device=self.dev, dtype=torch.float32)
-                    if hip.ffn_wreg_supported(self.d, self.pf):      # hand-over counters of dh_ffn_wreg (the kernel leaves them zero)
-                        bufs["ffn_sync"] = torch.zeros((2 * ((rows + 79) // 80),), device=self.dev, dtype=torch.int32)
                 c = hip.TrScratch()
                 for k, v in bufs.items():
                     setattr(c, k, v.data_ptr())

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 17
+#define DH_ABI_VERSION 16
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -234,15 +234,6 @@ int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bi
  *   residual != NULL: ln->o_stats required, ln->r_stats optional; K == 512 or 2,048, N % 64 == 0.
  * Results are bit-identical to dh_linear_ln on the unpacked weights.  _supported: 1 when (N, K, form) is taken. */
 int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats);
-/* The position-wise feed-forward layer of one decode position (transformers.py:162-163, :372-375) in ONE launch: phase 1 =
- * dh_linear_ln_wreg(x, w1_packed, b1, relu, ln1 -> ff), phase 2 = dh_linear_ln_wreg(ff, w2_packed, b2, residual, ln2 -> out); the phase-2
- * workgroups prefetch their weights and wait for the phase-1 workgroups of their rows through device-scope counters instead of a kernel
- * boundary (csrc/linear_wreg.hip).  Bit-identical to the two calls.  D == 512, PF == 2,048 (_supported).  sync: int32
- * [2 * ceil(M / 80)], zero before the first call; the kernel leaves it zero. */
-int dh_ffn_wreg_supported(int D, int PF);
-int dh_ffn_wreg(const void* x, int ldx, const void* w1_packed, const float* b1, const dh_ln_fold_t* ln1, void* ff, int ldff,
-                const void* w2_packed, const float* b2, const void* residual, int ldres, const dh_ln_fold_t* ln2, void* out, int ldo,
-                int M, int D, int PF, int32_t* sync, int dtype, void* stream);
 int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
                       void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream);
 
@@ -545,7 +536,6 @@ typedef struct dh_tr_scratch {
     void *x, *qkv, *att, *o, *q, *ff;       /* [rows, D|3D|D|D|D|PF] */
     void* y2;                               /* [rows, D]      second pre-LayerNorm row buffer of the deferred chain (or NULL) */
     float *st0, *st1, *st2;                 /* [rows, D/64, 2] partial LayerNorm statistics of x / o / y2 (or NULL) */
-    int32_t* ffn_sync;                      /* optional: int32 [2 * ceil(rows / 80)], zeroed once -- enables dh_ffn_wreg (one launch per FFN) */
 } dh_tr_scratch_t;
 
 /* Hidden state of position t for n_img*rows_per_img compact rows; x_out (optional, [rows,D]) receives the

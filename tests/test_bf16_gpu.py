@@ -768,27 +768,3 @@ def test_decode_chain_wreg_equals_tile_chain(kind, monkeypatch):
         monkeypatch.delenv("DH_NO_DECODE_WREG")
         model.decoder._drop_plan()
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
-
-
-@pytest.mark.parametrize("m", [1280, 37, 81, 640, 3000])
-def test_ffn_wreg_one_launch_equals_two(hip, m):
-    """dh_ffn_wreg (fc_1 and fc_2 of a position as two phases of ONE launch, handed over through device-scope counters) against
-    the two dh_linear_ln_wreg launches: outputs, statistics and the intermediate ff rows bit for bit -- with and without the
-    LayerNorm folds, three launches in a row on the same counters (the last consumer of a row group re-arms them)."""
-    d, pf = 512, 2048
-    g = torch.Generator().manual_seed(m)
-    y = bf(torch.randn(m, d, generator=g) * 1.7 + 0.3).cuda()
-    stats = _tile_stats(y.float().cpu()).cuda()
-    gamma, beta = (torch.rand(d, generator=g) + 0.5).cuda(), (torch.randn(d, generator=g) * 0.2).cuda()
-    w1, w2 = bf(torch.randn(pf, d, generator=g) / d ** 0.5).cuda(), bf(torch.randn(d, pf, generator=g) / pf ** 0.5).cuda()
-    b1, b2, cs = (torch.randn(pf, generator=g) * 0.1).cuda(), (torch.randn(d, generator=g) * 0.1).cuda(), torch.randn(pf, generator=g).cuda()
-    w1p, w2p = hip.pack_mfma_fragments(w1), hip.pack_mfma_fragments(w2)
-    sync = torch.zeros(2 * ((m + 79) // 80), dtype=torch.int32, device="cuda")
-    assert hip.ffn_wreg_supported(d, pf) and not hip.ffn_wreg_supported(256, 1024)
-    for rep in range(3):
-        for a_ln, r_ln in ((None, None), ((stats, 1e-5, cs), (stats, 1e-5, gamma, beta))):
-            ff = hip.linear_ln_wreg(y, w1p, pf, b1, relu=True, a_ln=a_ln)
-            want, wst = hip.linear_ln_wreg(ff, w2p, d, b2, residual=y, r_ln=r_ln)
-            out, st, ff2 = hip.ffn_wreg(y, w1p, b1, w2p, b2, y, sync, a_ln=a_ln, r_ln=r_ln)
-            assert torch.equal(ff2, ff) and torch.equal(out, want) and torch.equal(st, wst), (m, rep)
-            assert int(sync.abs().sum()) == 0                      # re-armed
