@@ -910,7 +910,9 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const T* __restric
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+            // key rows >= S are padding whose scores are replaced by -inf: those lanes re-read row S - 1 (a line the wave fetches
+            // anyway) instead of pulling the 64 - S zero rows of every (image, head) from HBM (15 of 64 rows at S = 49)
+            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + min(16 * j + l15, S - 1) * 64 + 32 * kk + 8 * lq);
             vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
         }
     const bool live = l15 < rows_per_img;
@@ -994,7 +996,9 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
     for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
+            // key rows >= S are padding whose scores are replaced by -inf: those lanes re-read row S - 1 (a line the wave fetches
+            // anyway) instead of pulling the 64 - S zero rows of every (image, head) from HBM (15 of 64 rows at S = 49)
+            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + min(16 * j + l15, S - 1) * 64 + 32 * kk + 8 * lq);
             vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
         }
     __builtin_amdgcn_sched_barrier(0);

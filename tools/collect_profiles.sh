@@ -1,10 +1,10 @@
 #!/usr/bin/env bash
 # Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel traces and PMC passes of the bench workloads of THIS tree, reduced to
-# CSV summaries under gpurun_out/profiles_${ROUND:-r3}/ (copied to profiles/<round>/ afterwards).  Counters in their own passes
+# CSV summaries under gpurun_out/profiles_${ROUND:-r4}/ (copied to profiles/<round>/ afterwards).  Counters in their own passes
 # (--pmc with --kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/profiles_${ROUND:-r3}
+OUT=$R/gpurun_out/profiles_${ROUND:-r4}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for wl in c2 c3; do
@@ -22,6 +22,8 @@ for pr in vocab_probe s3_probe lstm_probe kbench; do
   bash $R/tools/pmc_sq.sh $pr $R/tools/$pr.py > /dev/null 2>&1
 done
 cp $R/gpurun_out/pmc_sq/*.csv $OUT/ 2>/dev/null
+python3 $R/tools/make_pmc_json.py $OUT "$(cat $R/deephumor_amd/lib/BUILD_COMMIT 2>/dev/null || echo unknown)" > /dev/null 2>&1
+mkdir -p $R/profiles/${ROUND:-r4} && cp $OUT/pmc_hbm_traffic.json $R/profiles/${ROUND:-r4}/pmc_hbm_traffic.json   # bench.py reads it for roofline.traffic
 python3 $R/bench.py > $OUT/bench_default_bf16.json 2> /dev/null
 python3 $R/bench.py --workload c5 --steps 5 > $OUT/bench_c5_f16.json 2> /dev/null
 python3 $R/bench.py --workload c2 --steps 20 --warmup 5 --quick --rccl-single 2> /dev/null | tail -1 > $OUT/bench_c2_rccl_single_rank.json

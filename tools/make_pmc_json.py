@@ -6,7 +6,7 @@ traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE, both counters in KB: on gfx950
 wide coalesced reads at 64 bytes and has to be doubled, WRITE_SIZE is exact for 16-byte-per-lane stores
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section).  Separate passes per counter (they cannot share one on gfx950).
 
-    python tools/make_pmc_json.py profiles/r3 [commit]
+    python tools/make_pmc_json.py profiles/r4 [commit]
 """
 import csv
 import json
@@ -24,6 +24,12 @@ KEYS = [
      "launch-weighted mean over the history depths of one sweep (2..22 keys per row)"),
     ("c3", "dh_attn_cross_decode", "attn_cross_qproj_kernel", 256,
      "fused fc_q + cross-attention launch: includes the 8 x 64 KB fc_q weight slices every workgroup stages"),
+    ("c3", "dh_attn_cross_decode[qproj+attn]", "attn_cross_qproj_kernel", 256,
+     "the same launch under its full profiler key (C3's dominant launch key since round 4)"),
+    ("c3", "dh_linear[ffn]{1280x512x2048}", "linear_wreg_kernelIDF16bLi4ELi1ELi40ELi4ELi1E", 256,
+     "fc_2 of the feed-forward layer on the register-stationary kernel (64 columns x 40 rows per workgroup, K = 2,048)"),
+    ("c3", "dh_linear[ffn]{1280x2048x512}", "linear_wreg_kernelIDF16bLi8ELi1ELi80ELi1ELi0E", 256,
+     "fc_1 of the feed-forward layer on the register-stationary kernel (128 columns x 80 rows per workgroup)"),
 ]
 
 
@@ -39,7 +45,7 @@ def mean_kb(rs, frag, wgs):
 
 
 def main():
-    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r3")
+    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r4")
     commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(
         ["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     out = {"commit": commit,
