@@ -42,16 +42,15 @@ __device__ __forceinline__ void lw_dma16(const void* base, unsigned off, void* l
 // NW waves (16 output columns each), RL activation rows in LDS, KQ = K / 512, LNX: 0 = (deferred LayerNorm on the A rows |
 // plain) + optional ReLU; 1 = residual (optionally pre-LayerNorm) + statistics of the output rows
 template <typename OT, int NW, int RL, int KQ, int LNX>
-__global__ __launch_bounds__(64 * NW, 1) void linear_wreg_kernel(LwParams p) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void linear_wreg_kernel(LwParams p) {
     constexpr int NT = 64 * NW, BN = 16 * NW, TM = (RL + 15) / 16, RG = RL / 8, NSLAB = 8 * KQ, SLABB = RL * 128;
     constexpr int KF = 16 * KQ;                         // 32-k fragments per wave
     constexpr int WIN_SLABS = 65536 / SLABB, WIN = WIN_SLABS * SLABB, NWIN = (NSLAB + WIN_SLABS - 1) / WIN_SLABS;
     constexpr int PF = 3;                              // LDS fragment reads this many MFMAs ahead
     constexpr int CHUNKS = BN / 8, SLOTS = BN / 4, EP_IT = (RL * CHUNKS + NT - 1) / NT;
-    static_assert(RL % 8 == 0 && RL <= NT && NSLAB * SLABB + (LNX == 0 ? RL * 8 : 0) <= 163840 && RL * BN * 4 <= NSLAB * SLABB, "LDS budget");
+    static_assert(RL % 8 == 0 && RL <= NT && NSLAB * SLABB <= 163840 && RL * BN * 4 + RL * 8 <= NSLAB * SLABB, "LDS budget");
     static_assert((NSLAB * RG) % NW == 0, "pieces per wave");
-    constexpr int STAT_BYTES = LNX == 0 ? RL * 8 : 0;  // (mean, rstd) of the block's rows (deferred LayerNorm of the A rows)
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLAB * SLABB + STAT_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NSLAB * SLABB];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4, lr = lane >> 3, lpos = lane & 7;
@@ -123,24 +122,13 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_wreg_kernel(LwParams p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces, fragments and operands have landed
     // statistics -> mean / rstd now (frees the raw partials' registers before the MFMA loop)
     float a_mu[TM], a_rs[TM], r_mu[EP_IT], r_rs[EP_IT];
-    float2* row_stat = reinterpret_cast<float2*>(lds + NSLAB * SLABB);
-    if (a_ln && tid < RL) {
-        float mu, rs;
-        ln_math(a_raw, p.a_nt, p.a_eps, mu, rs);
-        row_stat[tid] = make_float2(mu, rs);
-    }
+    float2 my_stat = make_float2(0.f, 1.f);            // (mean, rstd) of block row `tid`: handed to the accumulator lanes in the epilogue
+    if (a_ln && tid < RL) ln_math(a_raw, p.a_nt, p.a_eps, my_stat.x, my_stat.y);
     if (r_ln) {
 #pragma unroll
         for (int it = 0; it < EP_IT; ++it) ln_math(r_raw[it], p.r_nt, p.r_eps, r_mu[it], r_rs[it]);
     }
     __syncthreads();
-    if (a_ln) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const float2 ms = row_stat[min(16 * i + l15, RL - 1)];
-            a_mu[i] = ms.x; a_rs[i] = ms.y;
-        }
-    }
 
     // ---- TM row tiles x KF k-steps; fragment reads PF steps ahead of their MFMAs ---------------------------------------------------------
     dh_f32x4 acc[TM];
@@ -179,6 +167,18 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_wreg_kernel(LwParams p) {
 
     // ---- epilogue: acc[i][r] = C[m0 + 16 i + l15][n0 + 16 wave + 4 lq + r], staged as fp32 rows (XOR-swizzled 16-byte slots) --------------
     float* ep = reinterpret_cast<float*>(lds);
+    if (a_ln) {
+        // the block rows' (mean, rstd) through the LDS the operands have left (behind the staging tile): the activation block fills the
+        // kernel's whole allocation, which keeps TWO 80-row workgroups per CU possible (2 x 80 KB)
+        float2* row_stat = reinterpret_cast<float2*>(lds + RL * BN * 4);
+        if (tid < RL) row_stat[tid] = my_stat;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float2 ms = row_stat[min(16 * i + l15, RL - 1)];
+            a_mu[i] = ms.x; a_rs[i] = ms.y;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = 16 * i + l15, slot = 4 * wave + lq;
@@ -263,6 +263,23 @@ int pick_xn(int tiles_m, int tiles_n, double w_block_bytes, double a_block_bytes
 extern "C" int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats) {
     if (with_residual_stats) return (K == 512 || K == 2048) && (N % 64) == 0;
     return K == 512 && (N % 64) == 0;
+}
+
+// Fraction of the resident workgroup slots the launch keeps busy when it needs more than one residency round (1.0 when everything
+// is co-resident): the callers prefer the tile kernels below ~0.85 (e.g. 3,000 rows: fc_2 = 600 workgroups at one per CU = 3 rounds
+// for 2.34 rounds of work).  Slots per CU: K = 2,048 one (160 KB LDS); the 4-wave 40 KB forms three; the 8-wave forms two.
+extern "C" double dh_linear_ln_wreg_occupancy(int M, int N, int K, int with_residual_stats) {
+    if (!dh_linear_ln_wreg_supported(N, K, with_residual_stats) || M <= 0) return 0.0;
+    long long wgs, cap;
+    if (with_residual_stats || (N % 128) != 0 || (long long)dh_cdiv(M, 40) * (N / 64) <= 256) {
+        wgs = (long long)dh_cdiv(M, 40) * (N / 64); cap = K == 2048 ? 256 : 768;
+    } else {
+        const bool rl64 = dh_cdiv(M, 64) * (N / 128) <= 256;
+        wgs = (long long)dh_cdiv(M, rl64 ? 64 : 80) * (N / 128); cap = 512;
+    }
+    if (wgs <= cap) return 1.0;
+    const long long rounds = (wgs + cap - 1) / cap;
+    return (double)wgs / (double)(rounds * cap);
 }
 
 // dh_linear_ln with `w_packed` = dh_pack_mfma_fragments(W [N, K]) in place of W; same arguments, restrictions as above:

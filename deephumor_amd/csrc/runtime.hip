@@ -29,7 +29,8 @@ static int chain_linear(const void* A, int lda, const void* W, const void* W_pk,
                         int ldc, int rows, int N, int K, int relu, const dh_ln_fold_t* f, int dt, void* stream) {
     static const int use_wreg = getenv("DH_DECODE_WREG") ? atoi(getenv("DH_DECODE_WREG")) : 1;
     static const int min_rows = getenv("DH_DECODE_WREG_MIN_ROWS") ? atoi(getenv("DH_DECODE_WREG_MIN_ROWS")) : 320;
-    if (use_wreg && W_pk && rows >= min_rows && dh_linear_ln_wreg_supported(N, K, res != nullptr) && (res == nullptr) == (f->o_stats == nullptr))
+    if (use_wreg && W_pk && rows >= min_rows && (res == nullptr) == (f->o_stats == nullptr) &&
+        dh_linear_ln_wreg_occupancy(rows, N, K, res != nullptr) >= 0.85)
         return dh_linear_ln_wreg(A, lda, W_pk, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
     return dh_linear_ln(A, lda, W, K, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
 }

@@ -234,6 +234,9 @@ int dh_linear_ln(const void* A, int lda, const void* W, int ldw, const float* bi
  *   residual != NULL: ln->o_stats required, ln->r_stats optional; K == 512 or 2,048, N % 64 == 0.
  * Results are bit-identical to dh_linear_ln on the unpacked weights.  _supported: 1 when (N, K, form) is taken. */
 int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats);
+/* 0.0 = shape not taken; else the fraction of resident workgroup slots the launch keeps busy over its residency rounds (1.0: one round):
+ * the decode driver uses the register-stationary kernel at >= 0.85 and the tile kernels otherwise. */
+double dh_linear_ln_wreg_occupancy(int M, int N, int K, int with_residual_stats);
 int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
                       void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream);
 

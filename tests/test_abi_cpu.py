@@ -11,7 +11,7 @@ def _prototypes():
     text = open(os.path.join(ROOT, "include", "deephumor_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     protos = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(dh_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|double|const char\*)\s+(dh_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = m.group(2).strip()
         protos[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return protos
