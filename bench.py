@@ -405,6 +405,20 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
     if world == 1 and not args.quick:
         with torch.no_grad():
             res["host_inclusive"] = host_inclusive(model, n_local, max(10, steps))    # enough batches for the pipeline's steady state
+            # the same device-resident batches as `value`, but as a STREAM of batches through CaptionPipeline: the encoder of batch
+            # i+1 runs on its own HIP stream while batch i decodes (reported next to `value`, which times one batch at a time)
+            from deephumor_amd.pipeline import CaptionPipeline
+            pipe = CaptionPipeline(model, overlap=True, max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP)
+            nb = max(10, steps)
+            for _ in pipe.run([(images,)] * 2, seeds=[1, 2], to_host=False):
+                pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in pipe.run([(images,)] * nb, seeds=range(100, 100 + nb), to_host=False):
+                pass
+            torch.cuda.synchronize()
+            tp = time.perf_counter() - t0
+            res["pipelined_device_resident"] = {"value": n_local * nb / tp, "unit": "captions/s", "ms_per_step": tp / nb * 1e3, "batches": nb}
     if rank == 0 and with_cpu:
         # the parity gate is the fp32 path: bit-exact greedy ids vs the CPU reference path -- timed here too
         if dtype == "f32":
@@ -687,7 +701,7 @@ def main(argv=None):
                    "hipgraph": bool(args.graph), "commit": git_head()},
         "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"),
     }
-    for k in ("greedy_token_match_vs_cpu_ref", f"greedy_token_match_{args.dtype}_vs_cpu_ref", "precision_vs_fp32_hip", "speedup_vs_cpu",
+    for k in ("greedy_token_match_vs_cpu_ref", f"greedy_token_match_{args.dtype}_vs_cpu_ref", "precision_vs_fp32_hip", "speedup_vs_cpu", "pipelined_device_resident",
               "mean_caption_len", "fp32_parity_path", "f16_path", "bf16_path", "host_inclusive", "hipgraph_replay", "kernel_breakdown_ms_per_step", "kernel_breakdown_note",
               "encoder_layers", "roofline_self_attention", "roofline_cross_attention", "roofline_decoder_attention_combined"):
         if k in res:
