@@ -838,11 +838,9 @@ extern "C" int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img,
 }
 
 // scores -> softmax -> P V of one (image, head) from preloaded fragments (shared by the two matrix-core kernels below)
-// `store(jd, pk)`: the 4 output values (two packed words) of head dims 16 jd + 4 lq .. + 3 of row l15 -- to the caller's row in
-// global memory (cross_core) or into an LDS operand tile (attn_block_kernel)
-template <typename T, typename Store>
-__device__ __forceinline__ void cross_core_f(const uint4 (&kf)[4][2], const uint4 (&vf)[4][2], const uint4 (&qf)[2], const uint64_t kbits,
-                                             int S, float scale, int lq, Store store) {
+template <typename T>
+__device__ __forceinline__ void cross_core(const uint4 (&kf)[4][2], const uint4 (&vf)[4][2], const uint4 (&qf)[2], const uint64_t kbits,
+                                           int S, float scale, bool live, uint16_t* orow, int lq) {
     dh_f32x4 sacc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -886,19 +884,13 @@ __device__ __forceinline__ void cross_core_f(const uint4 (&kf)[4][2], const uint
         dh_f32x4 o = dh_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) o = Op16<T>::mfma(vf[jd][kk], pf[kk], o);                 // out[m = l15][d = 16jd + 4lq + r]
-        uint2 pk;
-        pk.x = (uint32_t)Op16<T>::from_f32(o[0]) | ((uint32_t)Op16<T>::from_f32(o[1]) << 16);
-        pk.y = (uint32_t)Op16<T>::from_f32(o[2]) | ((uint32_t)Op16<T>::from_f32(o[3]) << 16);
-        store(jd, pk);
+        if (live) {
+            uint2 pk;
+            pk.x = (uint32_t)Op16<T>::from_f32(o[0]) | ((uint32_t)Op16<T>::from_f32(o[1]) << 16);
+            pk.y = (uint32_t)Op16<T>::from_f32(o[2]) | ((uint32_t)Op16<T>::from_f32(o[3]) << 16);
+            *reinterpret_cast<uint2*>(orow + 16 * jd + 4 * lq) = pk;
+        }
     }
-}
-
-template <typename T>
-__device__ __forceinline__ void cross_core(const uint4 (&kf)[4][2], const uint4 (&vf)[4][2], const uint4 (&qf)[2], const uint64_t kbits,
-                                           int S, float scale, bool live, uint16_t* orow, int lq) {
-    cross_core_f<T>(kf, vf, qf, kbits, S, scale, lq, [&](int jd, uint2 pk) {
-        if (live) *reinterpret_cast<uint2*>(orow + 16 * jd + 4 * lq) = pk;
-    });
 }
 
 template <typename T>
@@ -1372,437 +1364,5 @@ extern "C" int dh_attn_cross_prefill_packed(const void* q, int ldq, const void* 
         const int rc = launch_cross_packed(qc, ldq, kp, vt, keymask, oc, n_img, cnt, n_pos, S, D, n_heads, scale, dperm, dtype, (hipStream_t)stream);
         if (rc != DH_OK) return rc;
     }
-    DH_LAUNCH_CHECK();
-}
-
-
-// ---- the attention half of a decoder layer for one decode position in ONE launch (16-bit decode chain) -----------------------------
-// self_attn -> fc_o + residual (+ LayerNorm statistics) -> [fc_q -> enc_attn -> enc fc_o + residual (+ statistics)] of DecoderLayer /
-// SelfAttentionDecoderLayer (transformers.py:356-368, :625-629) for the rows of ONE image per workgroup.
-//
-// Why: in the chain of dependent launches a kernel costs ~8 us before it does anything (launch, drain, write-back / invalidate, the first
-// cold operand round trip: DESIGN.md section 11), and these five launches were 39 us per layer for ~14 us of work.  Fusing GEMMs across
-// WORKGROUPS loses (a seam inside a launch costs more than a kernel boundary, section 11); so the rows are fused instead: a workgroup owns
-// ALL 512 columns of its image's <= 8 rows, which makes every step row-local -- attention, projection, residual, LayerNorm statistics --
-// at the price of every workgroup streaming the three 512 x 512 weight matrices itself.  That price was measured first
-// (tools/probe/wstream_probe.hip): 256 workgroups pulling the SAME fragment-packed 0.5 / 1.0 / 1.5 MB out of L2 into registers with an
-// MFMA per fragment take 6.1 / 9.9 / 14.3 us per launch (2.9 us of that is the launch) -- ~55 B/clk per CU.
-//
-// Workgroup = image, 8 waves.  Wave w is HEAD w in the attention steps and COLUMNS 64 w .. 64 w + 63 in the projections (the same 64
-// columns: the head's slice), so a head's attention output and its q never leave the wave that needs them next except through the
-// [16 rows x 512] operand tiles in LDS (MFMA B-operand slab layout, XOR-swizzled, as linear_wreg.hip stages them):
-//   1. self-attention of head w for every row of the image: attn_decode_reg_kernel's lane layout (8 key slots x 8 chunks) and
-//      arithmetic, all rows' ancestor indices, then all rows' K slices requested up front; a row's V slices are requested into the
-//      registers its K slices leave.  k / v of the position are appended to the cache.  -> tile A
-//   2. fc_o: acc[4 column tiles] over 16 k-steps, weight fragments streamed from L2 through a 16-fragment register ring, B fragments from
-//      tile A; epilogue = linear_wreg's residual form on a [16 x 512] staging tile (residual rows with their pending LayerNorm, rounding,
-//      the (row, 64-column tile) statistics with the same 8 x 8 summation tree).  Rounded rows -> tile B, statistics -> an LDS table.
-//   3. fc_q of head w from tile B with the LayerNorm fold on the accumulators (attn_cross_qproj_kernel's arithmetic, q straight into the
-//      K q^T operand), cross_core over the image's packed K / V^T of head w -> tile A
-//   4. enc fc_o from tile A, residual = LayerNorm(tile B rows), statistics -> the layer's output rows (pre-LayerNorm) + statistics.
-// Every value is produced by the same arithmetic, in the same order, as by dh_attn_self_decode + dh_linear_ln(_wreg) +
-// dh_attn_cross_qproj_decode + dh_linear_ln(_wreg): outputs, statistics and the cache are bit-identical (tests/test_bf16_gpu.py).
-struct AttnBlockParams {
-    const uint16_t* qkv; int ldqkv;                       // [rows, 3 D]: q | k | v of this position
-    uint16_t* kc; uint16_t* vc; const int32_t* src; int src_ld; const int32_t* tokens; int tok_ld;
-    int rows_per_img, row_mult, rows_total, t, pad_index; float sa_scale;
-    const uint4* wo_pk; const float* bo;
-    const uint16_t* x; int ldx; const float2* x_stats; float x_eps; const float* x_gamma; const float* x_beta;
-    uint16_t* y1; int ldy1; float2* st1;                  // fc_o output rows + statistics (written when !cross)
-    int cross, S; float ea_scale, ln1_eps;
-    const uint4* wq_pk; const float* bq; const float* cs_q;
-    const uint16_t* kp; const uint16_t* vt; const uint8_t* keymask;
-    const uint4* weo_pk; const float* beo; const float* ln1_gamma; const float* ln1_beta;
-    uint16_t* y2; int ldy2; float2* st2;
-    unsigned long long* stamps;                           // optional (DH_ATTN_BLOCK_STAMPS): s_memtime at the phase boundaries of workgroup 0
-};
-
-namespace {
-constexpr int AB_TILE = 16 * 1024;                        // [8 slabs][16 rows][128 B]
-__device__ __forceinline__ unsigned ab_tile_off(int row, int col8) {      // byte offset of the 16-byte chunk holding columns 8 col8 .. + 7
-    return (unsigned)((col8 >> 3) * 2048 + row * 128 + (((col8 & 7) ^ (row & 7)) << 4));
-}
-
-// one 512 x 512 projection of the workgroup's 16 rows: acc[c][r] = C[row l15][64 wave + 16 c + 4 lq + r]
-constexpr int AB_AHEAD = 4;                               // k-steps of weight fragments in flight per wave (4 fragments each)
-struct AbRing { uint4 f[4 * AB_AHEAD]; };
-__device__ __forceinline__ void ab_gemm_prologue(AbRing& ring, const uint4* wp, int wave, int lane) {
-#pragma unroll
-    for (int i = 0; i < 4 * AB_AHEAD; ++i) ring.f[i] = wp[((size_t)((i >> 2) * 32 + wave * 4 + (i & 3))) * 64 + lane];
-}
-template <typename T>
-__device__ __forceinline__ void ab_gemm_main(AbRing& ring, const uint4* wp, const unsigned char* tile, int wave, int lane, dh_f32x4 (&acc)[4]) {
-    const int l15 = lane & 15, lq = lane >> 4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int f = 0; f < 16; ++f) {
-        const uint4 bf = *reinterpret_cast<const uint4*>(tile + (f >> 1) * 2048 + l15 * 128 + ((((f & 1) * 4 + lq) ^ (l15 & 7)) << 4));
-        uint4 a[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a[c] = ring.f[(f % AB_AHEAD) * 4 + c];
-        if (f + AB_AHEAD < 16) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ring.f[(f % AB_AHEAD) * 4 + c] = wp[((size_t)((f + AB_AHEAD) * 32 + wave * 4 + c)) * 64 + lane];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = Op16<T>::mfma(a[c], bf, acc[c]);
-    }
-}
-
-// linear_wreg's residual-form epilogue on the workgroup's [16 x 512] tile: v = acc + bias (staged fp32), + residual rows (optionally
-// LayerNorm-ed: (mean, rstd) per row from `mstab`), rounding, statistics of the rounded values per (row, 64-column tile).  Its global
-// operands are requested by ab_res_issue / ab_row_stats BEFORE the projection's main loop, so their (cold) latency hides behind it.
-struct AbRes { uint4 rq[2]; float4 g[2], b[2]; };
-
-// residual chunks of this thread's two (row, 8-column chunk) slots + the LayerNorm gamma / beta of its 8 columns (the same for both slots)
-template <bool RES_LDS>
-__device__ __forceinline__ void ab_res_issue(AbRes& rs, const int tid, const int R, const size_t row0, const uint16_t* res, const int ldres,
-                                             const unsigned char* res_tile, const bool r_ln, const float* gamma, const float* beta) {
-    const int ch = tid & 63;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int row = (tid >> 6) + 8 * it;
-        if (RES_LDS) rs.rq[it] = *reinterpret_cast<const uint4*>(res_tile + ab_tile_off(row, ch));
-        else rs.rq[it] = *reinterpret_cast<const uint4*>(res + (row0 + min(row, R - 1)) * ldres + ch * 8);
-    }
-    if (r_ln) {
-        rs.g[0] = *reinterpret_cast<const float4*>(gamma + ch * 8); rs.g[1] = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
-        rs.b[0] = *reinterpret_cast<const float4*>(beta + ch * 8); rs.b[1] = *reinterpret_cast<const float4*>(beta + ch * 8 + 4);
-    }
-}
-// (mean, rstd) of the 16 tile rows from their partial statistics (global rows or the block's own LDS table): thread r < 16 -> mstab[r]
-__device__ __forceinline__ void ab_row_stats_load(float4 (&raw)[4], const int tid, const float2* stats_row) {
-    if (tid < 16) ln_load(stats_row, 8, raw);
-}
-__device__ __forceinline__ void ab_row_stats_store(const float4 (&raw)[4], const int tid, const float eps, float2* mstab) {
-    if (tid < 16) {
-        float mu, rsd;
-        ln_math(raw, 8, eps, mu, rsd);
-        mstab[tid] = make_float2(mu, rsd);
-    }
-}
-
-template <typename T>
-__device__ __forceinline__ void ab_epilogue(const dh_f32x4 (&acc)[4], const float* bias, float* ep, const int tid, const int wave, const int lane,
-                                            const int R, const size_t row0, const AbRes& rs, const bool r_ln, const float2* mstab,
-                                            uint16_t* out, const int ldo, float2* out_stats, unsigned char* out_tile, float2* out_table) {
-    const int l15 = lane & 15, lq = lane >> 4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float4 bb = *reinterpret_cast<const float4*>(bias + 64 * wave + 16 * c + 4 * lq);
-        const int slot = 16 * wave + 4 * c + lq;
-        float4 v;
-        v.x = acc[c][0] + bb.x; v.y = acc[c][1] + bb.y; v.z = acc[c][2] + bb.z; v.w = acc[c][3] + bb.w;
-        *reinterpret_cast<float4*>(ep + l15 * 512 + ((slot ^ l15) << 2)) = v;      // SLOTS = 128: slot ^ (row & 127) = slot ^ row
-    }
-    __syncthreads();                                       // the staging tile (and mstab, written before the main loop's barrier) complete
-    const int ch = tid & 63;
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int row = (tid >> 6) + 8 * it;
-        const float4 lo = *reinterpret_cast<const float4*>(ep + row * 512 + (((2 * ch) ^ row) << 2));
-        const float4 hi = *reinterpret_cast<const float4*>(ep + row * 512 + (((2 * ch + 1) ^ row) << 2));
-        float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-        const uint32_t w4[4] = {rs.rq[it].x, rs.rq[it].y, rs.rq[it].z, rs.rq[it].w};
-        float rr[8];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) Op16<T>::unpack2(w4[u], rr[2 * u], rr[2 * u + 1]);
-        if (r_ln) {
-            const float2 ms = mstab[row];
-            const float g8[8] = {rs.g[0].x, rs.g[0].y, rs.g[0].z, rs.g[0].w, rs.g[1].x, rs.g[1].y, rs.g[1].z, rs.g[1].w};
-            const float b8[8] = {rs.b[0].x, rs.b[0].y, rs.b[0].z, rs.b[0].w, rs.b[1].x, rs.b[1].y, rs.b[1].z, rs.b[1].w};
-#pragma unroll
-            for (int u = 0; u < 8; ++u) rr[u] = fmaf((rr[u] - ms.x) * ms.y, g8[u], b8[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] += rr[u];
-        float s1 = 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { v[u] = Op16<T>::to_f32(Op16<T>::from_f32(v[u])); s1 += v[u]; }
-        const float mean = sum8(s1) * (1.0f / 64.0f);
-        float s2 = 0.f;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { const float d = v[u] - mean; s2 = fmaf(d, d, s2); }
-        s2 = sum8(s2);
-        uint4 pk;
-        pk.x = (uint32_t)Op16<T>::from_f32(v[0]) | ((uint32_t)Op16<T>::from_f32(v[1]) << 16);
-        pk.y = (uint32_t)Op16<T>::from_f32(v[2]) | ((uint32_t)Op16<T>::from_f32(v[3]) << 16);
-        pk.z = (uint32_t)Op16<T>::from_f32(v[4]) | ((uint32_t)Op16<T>::from_f32(v[5]) << 16);
-        pk.w = (uint32_t)Op16<T>::from_f32(v[6]) | ((uint32_t)Op16<T>::from_f32(v[7]) << 16);
-        if (out_tile) {
-            *reinterpret_cast<uint4*>(out_tile + ab_tile_off(row, ch)) = pk;
-            if ((ch & 7) == 0) out_table[row * 8 + (ch >> 3)] = make_float2(mean, s2);
-        }
-        if (row < R) {
-            if (out) *reinterpret_cast<uint4*>(out + (row0 + row) * ldo + ch * 8) = pk;
-            if (out_stats && (ch & 7) == 0) out_stats[(row0 + row) * 8 + (ch >> 3)] = make_float2(mean, s2);
-        }
-    }
-}
-}  // namespace
-
-template <typename T, int NIT, int RMAX>
-__global__ __launch_bounds__(512, 1) void attn_block_kernel(AttnBlockParams p) {
-    constexpr int D = 512, H = 8, KPI = 8;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * AB_TILE + 16 * 512 * 4 + 16 * 8 * 8 + 16 * 8];
-    unsigned char* const tileA = lds;
-    unsigned char* const tileB = lds + AB_TILE;
-    float* const ep = reinterpret_cast<float*>(lds + 2 * AB_TILE);
-    float2* const table = reinterpret_cast<float2*>(lds + 2 * AB_TILE + 16 * 512 * 4);
-    float2* const mstab = table + 16 * 8;                  // (mean, rstd) of the residual rows of the projection in progress
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int img = blockIdx.x, R = p.rows_per_img, t = p.t, L = t + 1;
-    const size_t row0 = (size_t)img * R;
-    const int l15 = lane & 15, lq = lane >> 4, kg = lane >> 3, dc = lane & 7, h = wave;
-    const T* qkv = reinterpret_cast<const T*>(p.qkv);
-    T* kc = reinterpret_cast<T*>(p.kc);
-    T* vc = reinterpret_cast<T*>(p.vc);
-
-    int stamp_i = 0;
-    auto stamp = [&]() {
-        if (p.stamps && blockIdx.x == 0 && tid == 0) p.stamps[stamp_i] = __builtin_amdgcn_s_memtime();
-        ++stamp_i;
-    };
-    stamp();
-    // zero tile A (rows >= R are never written: keep them finite) while the first loads fly
-    for (int i = tid; i < AB_TILE / 16; i += 512) *reinterpret_cast<uint4*>(tileA + i * 16) = make_uint4(0u, 0u, 0u, 0u);
-    __syncthreads();
-
-    // ---- 1. self-attention of head h for the image's rows ------------------------------------------------------------------------
-    {
-        int phys[RMAX][NIT], aux[RMAX][NIT];
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const int rl = (int)(row0 + min(r, R - 1)) * p.row_mult;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                phys[r][it] = 0; aux[r][it] = 0;
-                if (t > 0) {
-                    phys[r][it] = p.src[(size_t)rl * p.src_ld + min(it * KPI + kg, t - 1)];
-                    if (p.tokens) aux[r][it] = p.tokens[(size_t)rl * p.tok_ld + min(max(it * KPI + kg - 1, 0), t - 1)];
-                }
-            }
-        }
-        Raw8<T> kv[RMAX][NIT], qr[RMAX];
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const size_t rc = row0 + min(r, R - 1);
-            raw_load(qkv + rc * p.ldqkv + h * 64 + dc * 8, qr[r]);
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int j = it * KPI + kg;
-                const T* kp_ = j < t ? kc + ((size_t)min(j, t) * p.rows_total + phys[r][it]) * D + h * 64 + dc * 8
-                                     : qkv + rc * p.ldqkv + D + h * 64 + dc * 8;
-                if (j < L) raw_load(kp_, kv[r][it]);
-            }
-        }
-        float e[RMAX][NIT], sum[RMAX];
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const size_t rc = row0 + min(r, R - 1);
-            float qv[8];
-            raw_unpack(qr[r], qv);
-            float mx = -INFINITY;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int j = it * KPI + kg;
-                e[r][it] = -INFINITY;
-                if (j < L) {
-                    float kk[8];
-                    raw_unpack(kv[r][it], kk);
-                    float a = 0.f;
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) a = fmaf(kk[u], qv[u], a);
-                    a = sum8(a);
-                    const bool masked = (j >= 1) && p.tokens && (aux[r][it] == p.pad_index);
-                    e[r][it] = masked ? -1e8f : SmMath<T>::div(a, p.sa_scale);
-                    // this key's V slice into the registers its K slice leaves
-                    const T* vp_ = j < t ? vc + ((size_t)j * p.rows_total + phys[r][it]) * D + h * 64 + dc * 8
-                                         : qkv + rc * p.ldqkv + 2 * D + h * 64 + dc * 8;
-                    raw_load(vp_, kv[r][it]);
-                }
-                mx = fmaxf(mx, e[r][it]);
-            }
-            mx = wave_max(mx);
-            float sm = 0.f;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                e[r][it] = (it * KPI + kg < L) ? SmMath<T>::exp(e[r][it] - mx) : 0.f;
-                sm += e[r][it];
-            }
-            sum[r] = wave_sum(sm) / 8.0f;
-        }
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-            const size_t rc = row0 + min(r, R - 1);
-            float o8[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o8[u] = 0.f;
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                if (it * KPI + kg < L) {
-                    float vv[8];
-                    raw_unpack(kv[r][it], vv);
-                    const float pj = SmMath<T>::div(e[r][it], sum[r]);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) o8[u] = fmaf(pj, vv[u], o8[u]);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) o8[u] = key_slots_sum8(o8[u]);
-            if (kg == 0 && r < R) {
-                T tmp[8];
-                store8(tmp, o8);
-                *reinterpret_cast<uint4*>(tileA + ab_tile_off(r, 8 * h + dc)) = *reinterpret_cast<const uint4*>(tmp);
-                const size_t rl = rc * p.row_mult;
-                copy8(kc + ((size_t)t * p.rows_total + rl) * D + h * 64 + dc * 8, qkv + rc * p.ldqkv + D + h * 64 + dc * 8);
-                copy8(vc + ((size_t)t * p.rows_total + rl) * D + h * 64 + dc * 8, qkv + rc * p.ldqkv + 2 * D + h * 64 + dc * 8);
-            }
-        }
-    }
-    stamp();                                               // 1: self-attention done (this wave)
-    // fc_o's residual operands (the layer input rows, their statistics, the pending LayerNorm's gamma / beta) and its first weight fragments
-    AbRes rs;
-    const bool x_ln = p.x_stats != nullptr;
-    float4 raw0[4];
-    ab_res_issue<false>(rs, tid, R, row0, p.x, p.ldx, nullptr, x_ln, p.x_gamma, p.x_beta);
-    if (x_ln) ab_row_stats_load(raw0, tid, p.x_stats + (row0 + min(tid & 15, R - 1)) * 8);
-    AbRing ring;
-    ab_gemm_prologue(ring, p.wo_pk, wave, lane);
-    if (x_ln) ab_row_stats_store(raw0, tid, p.x_eps, mstab);
-    __syncthreads();                                       // tile A (and mstab) complete
-    stamp();                                               // 2: barrier
-
-    // ---- 2. fc_o + residual + statistics -> tile B (+ global when this is the block's output) ------------------------------------------
-    dh_f32x4 acc[4];
-    ab_gemm_main<T>(ring, p.wo_pk, tileA, wave, lane, acc);
-    stamp();                                               // 3: fc_o main loop
-    if (p.cross) ab_gemm_prologue(ring, p.wq_pk, wave, lane);
-    ab_epilogue<T>(acc, p.bo, ep, tid, wave, lane, R, row0, rs, x_ln, mstab, p.cross ? nullptr : p.y1, p.ldy1, p.cross ? nullptr : p.st1,
-                   tileB, table);
-    if (!p.cross) return;
-    __syncthreads();                                       // tile B + the statistics table complete; tile A free
-    stamp();                                               // 4: fc_o epilogue + barrier
-
-    // ---- 3. fc_q of head h (LayerNorm fold on the accumulators) + cross-attention -> tile A ----------------------------------------------
-    {
-        const uint16_t* kb = p.kp + ((size_t)img * H + h) * 4096;
-        const uint16_t* vb = p.vt + ((size_t)img * H + h) * 4096;
-        uint4 kf[4][2], vf[4][2];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                kf[j][kk] = *reinterpret_cast<const uint4*>(kb + min(16 * j + l15, p.S - 1) * 64 + 32 * kk + 8 * lq);
-                vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
-            }
-        const uint8_t mbyte = p.keymask[img * p.S + min(lane, p.S - 1)];
-        // enc fc_o's residual = LayerNorm(fc_o rows): chunks from tile B, (mean, rstd) from the statistics table, gamma / beta of LN1
-        ab_res_issue<true>(rs, tid, R, row0, nullptr, 0, tileB, true, p.ln1_gamma, p.ln1_beta);
-        {
-            float4 raw1[4];
-            ab_row_stats_load(raw1, tid, table + (tid & 15) * 8);
-            ab_row_stats_store(raw1, tid, p.ln1_eps, mstab);   // (mstab's previous content was last read before the barrier above)
-        }
-        float4 cs4[4], b4[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cs4[j] = *reinterpret_cast<const float4*>(p.cs_q + 64 * h + 16 * j + 4 * lq);
-            b4[j] = *reinterpret_cast<const float4*>(p.bq + 64 * h + 16 * j + 4 * lq);
-        }
-        dh_f32x4 qacc[4];
-        ab_gemm_main<T>(ring, p.wq_pk, tileB, wave, lane, qacc);
-        stamp();                                           // 5: fc_q main loop
-        ab_gemm_prologue(ring, p.weo_pk, wave, lane);
-        float4 raw[4];
-        ln_load(table + l15 * 8, 8, raw);
-        float mu, rstd;
-        ln_math(raw, 8, p.ln1_eps, mu, rstd);
-        const bool live = l15 < R;
-        uint4 qf[2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            uint32_t w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float qv[2];
-#pragma unroll
-                for (int z = 0; z < 2; ++z) {
-                    const int ee = 2 * u + z, j = 2 * kk + (ee >> 2), r = ee & 3;
-                    const float c = r == 0 ? cs4[j].x : r == 1 ? cs4[j].y : r == 2 ? cs4[j].z : cs4[j].w;
-                    const float b = r == 0 ? b4[j].x : r == 1 ? b4[j].y : r == 2 ? b4[j].z : b4[j].w;
-                    qv[z] = fmaf(rstd, fmaf(-mu, c, qacc[j][r]), b);
-                }
-                w[u] = (uint32_t)Op16<T>::from_f32(qv[0]) | ((uint32_t)Op16<T>::from_f32(qv[1]) << 16);
-            }
-            qf[kk] = live ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
-        }
-        cross_core_f<T>(kf, vf, qf, __ballot(mbyte != 0), p.S, p.ea_scale, lq, [&](int jd, uint2 pk) {
-            // head dims 16 jd + 4 lq .. + 3 of row l15 = half (lq & 1) of the 16-byte chunk 8 h + 2 jd + (lq >> 1)
-            if (live) *reinterpret_cast<uint2*>(tileA + ab_tile_off(l15, 8 * h + 2 * jd + (lq >> 1)) + (lq & 1) * 8) = pk;
-        });
-    }
-    stamp();                                               // 6: cross-attention
-    __syncthreads();                                       // tile A = the cross-attention output rows
-    stamp();                                               // 7: barrier
-
-    // ---- 4. enc fc_o + LayerNorm(tile B) residual + statistics -> the block's output --------------------------------------------------------
-    ab_gemm_main<T>(ring, p.weo_pk, tileA, wave, lane, acc);
-    stamp();                                               // 8: enc fc_o main loop
-    ab_epilogue<T>(acc, p.beo, ep, tid, wave, lane, R, row0, rs, true, mstab, p.y2, p.ldy2, p.st2, nullptr, nullptr);
-    stamp();                                               // 9: end
-}
-
-static unsigned long long* g_ab_stamps = nullptr;
-// developer probe: the last launch's phase stamps (s_memtime of workgroup 0, thread 0) -> out[10]; DH_ERR_UNSUPPORTED when stamping is off
-extern "C" int dh_attn_block_stamps(unsigned long long* out) {
-    if (!g_ab_stamps || !out) return DH_ERR_UNSUPPORTED;
-    return hipMemcpy(out, g_ab_stamps, 10 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
-}
-
-extern "C" int dh_attn_block_supported(int D, int n_heads, int rows_per_img, int t, int cross, int S) {
-    return D == 512 && n_heads == 8 && rows_per_img >= 1 && rows_per_img <= 8 && t >= 0 && t <= 39 && (!cross || (S >= 1 && S <= 64)) &&
-           (rows_per_img <= 5 || t <= 15);
-}
-
-extern "C" int dh_attn_block_decode(const dh_attn_block_t* a, int n_img, int dtype, void* stream) {
-    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
-    DH_REQUIRE(a && n_img > 0 && dh_attn_block_supported(512, 8, a->rows_per_img, a->t, a->cross, a->S));
-    DH_REQUIRE(a->qkv && a->kcache && a->vcache && a->wo_packed && a->bo && a->x && (a->t == 0 || a->src) && a->ldqkv >= 1536 && (a->ldqkv % 8) == 0 &&
-               a->ldx >= 512 && (a->ldx % 8) == 0);
-    DH_REQUIRE(!a->x_stats || (a->x_gamma && a->x_beta));
-    DH_REQUIRE(a->cross ? (a->wq_packed && a->bq && a->cs_q && a->kp_dperm && a->vt && a->keymask && a->weo_packed && a->beo && a->ln1_gamma &&
-                           a->ln1_beta && a->y2 && a->st2 && a->ldy2 >= 512 && (a->ldy2 % 8) == 0)
-                        : (a->y1 && a->st1 && a->ldy1 >= 512 && (a->ldy1 % 8) == 0));
-    AttnBlockParams p{};
-    p.qkv = (const uint16_t*)a->qkv; p.ldqkv = a->ldqkv; p.kc = (uint16_t*)a->kcache; p.vc = (uint16_t*)a->vcache;
-    p.src = a->src; p.src_ld = a->src_ld; p.tokens = a->tokens; p.tok_ld = a->tok_ld;
-    p.rows_per_img = a->rows_per_img; p.row_mult = a->row_mult; p.rows_total = a->rows_total; p.t = a->t; p.pad_index = a->pad_index;
-    p.sa_scale = a->sa_scale;
-    p.wo_pk = (const uint4*)a->wo_packed; p.bo = a->bo; p.x = (const uint16_t*)a->x; p.ldx = a->ldx; p.x_stats = (const float2*)a->x_stats;
-    p.x_eps = a->x_eps; p.x_gamma = a->x_gamma; p.x_beta = a->x_beta; p.y1 = (uint16_t*)a->y1; p.ldy1 = a->ldy1; p.st1 = (float2*)a->st1;
-    p.cross = a->cross; p.S = a->S; p.ea_scale = a->ea_scale; p.ln1_eps = a->ln1_eps;
-    p.wq_pk = (const uint4*)a->wq_packed; p.bq = a->bq; p.cs_q = a->cs_q; p.kp = (const uint16_t*)a->kp_dperm; p.vt = (const uint16_t*)a->vt;
-    p.keymask = a->keymask; p.weo_pk = (const uint4*)a->weo_packed; p.beo = a->beo; p.ln1_gamma = a->ln1_gamma; p.ln1_beta = a->ln1_beta;
-    p.y2 = (uint16_t*)a->y2; p.ldy2 = a->ldy2; p.st2 = (float2*)a->st2;
-    static unsigned long long* stamps_dev = nullptr;
-    if (getenv("DH_ATTN_BLOCK_STAMPS")) {              // developer switch: phase stamps of workgroup 0 (read back with dh_attn_block_stamps)
-        if (!stamps_dev) { if (hipMalloc(&stamps_dev, 16 * sizeof(unsigned long long)) != hipSuccess) stamps_dev = nullptr; }
-        p.stamps = stamps_dev;
-    }
-    g_ab_stamps = stamps_dev;
-    const int rows = n_img * a->rows_per_img;
-    DhProfScope prof("dh_attn_block", 4.0 * rows * (a->t + 1) * 512 + (a->cross ? 3 : 1) * 2.0 * rows * 512 * 512 + (a->cross ? 4.0 * rows * a->S * 512 : 0.0),
-                     2.0 * (rows * ((a->t + 1) * 1024.0 + 1536 + 1024) + (a->cross ? n_img * a->S * 1024.0 + 3 * 512 * 512.0 : 512 * 512.0)), stream);
-    const dim3 grid(n_img), block(512);
-    hipStream_t s = (hipStream_t)stream;
-    const bool small = a->t <= 15;
-    DH_DISPATCH_16(dtype, {
-        if (small && a->rows_per_img > 5) hipLaunchKernelGGL((attn_block_kernel<T, 2, 8>), grid, block, 0, s, p);
-        else if (small) hipLaunchKernelGGL((attn_block_kernel<T, 2, 5>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((attn_block_kernel<T, 5, 5>), grid, block, 0, s, p);
-    });
     DH_LAUNCH_CHECK();
 }

@@ -50,13 +50,7 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         // 1. qkv = LN3_prev(X) Wqkv^T + b  (layer 0: X is the embedding, no LayerNorm in front) and the self-attention over the
         //    row's history: ONE launch where the fused kernel applies (head dim 64, <= 6 rows per image, <= 40 positions)
         static const int qkv_fusion_rows = getenv("DH_QKV_FUSION_MAX_ROWS") ? atoi(getenv("DH_QKV_FUSION_MAX_ROWS")) : DH_QKV_FUSION_DEFAULT_MAX_ROWS;
-        // steps 1b-4 (self-attention, fc_o, [fc_q + cross-attention, enc fc_o]) in ONE launch where the row-owning attention block takes
-        // the shape (csrc/attention.hip: attn_block_kernel; bit-identical to the separate launches).  DH_ATTN_BLOCK=0 switches it off.
-        const int attn_block = getenv("DH_ATTN_BLOCK") ? atoi(getenv("DH_ATTN_BLOCK")) : 1;      // (read per call: in-process A/B tests)
-        const bool qkv_fused = rows <= qkv_fusion_rows && D == 64 * m->n_heads && rows_per_img <= 6 && t <= 39;
-        const bool block_ok = attn_block && !qkv_fused && L.wo_pk && dh_attn_block_supported(D, m->n_heads, rows_per_img, t, m->cross, m->S) &&
-                              (!m->cross || (L.wq_pk && L.weo_pk && L.kp && L.vt && L.kp_dperm));
-        if (qkv_fused) {
+        if (rows <= qkv_fusion_rows && D == 64 * m->n_heads && rows_per_img <= 6 && t <= 39) {
             DH_TRY(dh_attn_self_qkv_decode(sc->x, D, P ? sc->st0 : nullptr, nt, P ? P->ln3_eps : 0.f, P ? L.cs_qkv : nullptr,
                                            P ? L.wqkv_f : L.wqkv, P ? L.bqkv_f : L.bqkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld,
                                            sc->att, n_img, rows_per_img, row_mult, rows_total, t, D, m->n_heads, L.sa_scale,
@@ -65,53 +59,37 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
             if (P) { f.a_stats = sc->st0; f.a_tiles = nt; f.a_eps = P->ln3_eps; f.a_colsum = L.cs_qkv; }
             dh_prof_set_tag("qkv");
             DH_TRY(chain_linear(sc->x, D, P ? L.wqkv_f : L.wqkv, L.wqkv_pk, P ? L.bqkv_f : L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
-            if (!block_ok)
-                DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
-                                           row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
+            DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
+                                       row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
         }
+        // 2. Y1 = LN3_prev(X) + att Wo^T + bo, statistics of Y1 -> st1
+        f = dh_ln_fold_t{};
+        if (P) { f.r_stats = sc->st0; f.r_tiles = nt; f.r_eps = P->ln3_eps; f.r_gamma = P->ln3_g; f.r_beta = P->ln3_b; }
+        f.o_stats = sc->st1;
+        dh_prof_set_tag("proj");
+        DH_TRY(chain_linear(sc->att, D, L.wo, L.wo_pk, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
         const void* yin = sc->o; const float* st_in = sc->st1;               // rows entering the FFN block, LayerNorm pending
         const float *g_in = L.ln1_g, *b_in = L.ln1_b; float eps_in = L.ln1_eps;
-        if (block_ok) {
-            dh_attn_block_t a{};
-            a.qkv = sc->qkv; a.ldqkv = 3 * D; a.kcache = L.kcache; a.vcache = L.vcache; a.src = src; a.src_ld = src_ld;
-            a.tokens = tokens; a.tok_ld = tok_ld; a.rows_per_img = rows_per_img; a.row_mult = row_mult; a.rows_total = rows_total; a.t = t;
-            a.pad_index = m->pad_index; a.sa_scale = L.sa_scale;
-            a.wo_packed = L.wo_pk; a.bo = L.bo; a.x = sc->x; a.ldx = D;
-            if (P) { a.x_stats = sc->st0; a.x_eps = P->ln3_eps; a.x_gamma = P->ln3_g; a.x_beta = P->ln3_b; }
-            a.y1 = sc->o; a.ldy1 = D; a.st1 = sc->st1;
-            a.cross = m->cross; a.S = m->S; a.ea_scale = L.ea_scale; a.ln1_eps = L.ln1_eps;
-            a.wq_packed = L.wq_pk; a.bq = L.bq_f; a.cs_q = L.cs_q; a.kp_dperm = L.kp; a.vt = L.vt; a.keymask = m->keymask;
-            a.weo_packed = L.weo_pk; a.beo = L.beo; a.ln1_gamma = L.ln1_g; a.ln1_beta = L.ln1_b; a.y2 = sc->y2; a.ldy2 = D; a.st2 = sc->st2;
-            DH_TRY(dh_attn_block_decode(&a, n_img, dt, stream));
-            if (m->cross) { yin = sc->y2; st_in = sc->st2; g_in = L.ln2_g; b_in = L.ln2_b; eps_in = L.ln2_eps; }
-        } else {
-            // 2. Y1 = LN3_prev(X) + att Wo^T + bo, statistics of Y1 -> st1
-            f = dh_ln_fold_t{};
-            if (P) { f.r_stats = sc->st0; f.r_tiles = nt; f.r_eps = P->ln3_eps; f.r_gamma = P->ln3_g; f.r_beta = P->ln3_b; }
-            f.o_stats = sc->st1;
-            dh_prof_set_tag("proj");
-            DH_TRY(chain_linear(sc->att, D, L.wo, L.wo_pk, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
-            if (m->cross) {
-                // 3. q = LN1(Y1) Wq^T + bq and the attention over the image's patches: ONE launch when K was packed for it
-                // DH_CROSS_QPROJ=0: fc_q as its own (register-stationary) GEMM, then the packed attention -- A/B of the fused launch
-                static const int fused_qproj = getenv("DH_CROSS_QPROJ") ? atoi(getenv("DH_CROSS_QPROJ")) : 1;
-                if (fused_qproj && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
-                    DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
-                                                      n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
-                } else {
-                    f = dh_ln_fold_t{};
-                    f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
-                    dh_prof_set_tag("proj");
-                    DH_TRY(chain_linear(sc->o, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
-                    DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
-                }
-                // 4. Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2
+        if (m->cross) {
+            // 3. q = LN1(Y1) Wq^T + bq and the attention over the image's patches: ONE launch when K was packed for it
+            // DH_CROSS_QPROJ=0: fc_q as its own (register-stationary) GEMM, then the packed attention -- A/B of the fused launch
+            static const int fused_qproj = getenv("DH_CROSS_QPROJ") ? atoi(getenv("DH_CROSS_QPROJ")) : 1;
+            if (fused_qproj && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
+                DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
+                                                  n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
+            } else {
                 f = dh_ln_fold_t{};
-                f.r_stats = sc->st1; f.r_tiles = nt; f.r_eps = L.ln1_eps; f.r_gamma = L.ln1_g; f.r_beta = L.ln1_b; f.o_stats = sc->st2;
+                f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
                 dh_prof_set_tag("proj");
-                DH_TRY(chain_linear(sc->att, D, L.weo, L.weo_pk, L.beo, sc->o, D, sc->y2, D, rows, D, D, 0, &f, dt, stream));
-                yin = sc->y2; st_in = sc->st2; g_in = L.ln2_g; b_in = L.ln2_b; eps_in = L.ln2_eps;
+                DH_TRY(chain_linear(sc->o, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
+                DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
             }
+            // 4. Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2
+            f = dh_ln_fold_t{};
+            f.r_stats = sc->st1; f.r_tiles = nt; f.r_eps = L.ln1_eps; f.r_gamma = L.ln1_g; f.r_beta = L.ln1_b; f.o_stats = sc->st2;
+            dh_prof_set_tag("proj");
+            DH_TRY(chain_linear(sc->att, D, L.weo, L.weo_pk, L.beo, sc->o, D, sc->y2, D, rows, D, D, 0, &f, dt, stream));
+            yin = sc->y2; st_in = sc->st2; g_in = L.ln2_g; b_in = L.ln2_b; eps_in = L.ln2_eps;
         }
         // 5. ff = relu(LN(Yin) W1^T + b1)
         f = dh_ln_fold_t{};

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 17
+ABI_VERSION = 16
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -38,16 +38,6 @@ class TrModel(_c.Structure):
 
 class TrScratch(_c.Structure):
     _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2")]
-
-
-class AttnBlock(_c.Structure):
-    """``dh_attn_block_t``: arguments of ``dh_attn_block_decode`` (the attention half of a decoder layer in one launch)."""
-    _fields_ = [("qkv", _P), ("ldqkv", _I), ("kcache", _P), ("vcache", _P), ("src", _P), ("src_ld", _I), ("tokens", _P), ("tok_ld", _I),
-                ("rows_per_img", _I), ("row_mult", _I), ("rows_total", _I), ("t", _I), ("pad_index", _I), ("sa_scale", _F),
-                ("wo_packed", _P), ("bo", _P), ("x", _P), ("ldx", _I), ("x_stats", _P), ("x_eps", _F), ("x_gamma", _P), ("x_beta", _P),
-                ("y1", _P), ("ldy1", _I), ("st1", _P), ("cross", _I), ("S", _I), ("ea_scale", _F), ("ln1_eps", _F),
-                ("wq_packed", _P), ("bq", _P), ("cs_q", _P), ("kp_dperm", _P), ("vt", _P), ("keymask", _P),
-                ("weo_packed", _P), ("beo", _P), ("ln1_gamma", _P), ("ln1_beta", _P), ("y2", _P), ("ldy2", _I), ("st2", _P)]
 
 
 class LnFold(_c.Structure):
@@ -95,8 +85,6 @@ SIGNATURES = {
     "dh_label_mean": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
     "dh_linear_ln": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
-    "dh_attn_block_supported": [_I, _I, _I, _I, _I, _I],
-    "dh_attn_block_decode": [_c.POINTER(AttnBlock), _I, _I, _P],
     "dh_linear_ln_wreg_supported": [_I, _I, _I],
     "dh_linear_ln_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
     "dh_attn_cross_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
@@ -468,39 +456,6 @@ def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_
             residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
             _dt(a), _stream(), tag=tag)
     return (out, stats) if residual is not None else out
-
-
-def attn_block_supported(d, n_heads, rows_per_img, t, cross, s):
-    return bool(load().dh_attn_block_supported(int(d), int(n_heads), int(rows_per_img), int(t), int(bool(cross)), int(s)))
-
-
-def attn_block_decode(qkv, kcache, vcache, src, tokens, n_img, rows_per_img, row_mult, rows_total, t, pad_index, sa_scale, wo_packed, bo, x,
-                      x_ln=None, cross=None):
-    """``dh_attn_block_decode``: self-attention + fc_o (+ fc_q + cross-attention + enc fc_o) of one decode position in one launch.
-    ``x_ln = (stats, eps, gamma, beta)`` of the residual rows; ``cross = dict(s, ea_scale, ln1_eps, wq_packed, bq, cs_q, kp, vt, keymask,
-    weo_packed, beo, ln1_gamma, ln1_beta)``.  Returns ``(y, stats)``: the block's output rows (pre-LayerNorm) and their statistics."""
-    _dev(qkv, kcache, vcache, src, tokens, wo_packed, bo, x)
-    rows, d = n_img * rows_per_img, x.shape[1]
-    y = torch.empty((rows, d), dtype=x.dtype, device=x.device)
-    st = torch.empty((rows, d // 64, 2), dtype=torch.float32, device=x.device)
-    a = AttnBlock()
-    a.qkv, a.ldqkv, a.kcache, a.vcache = _ptr(qkv), qkv.stride(0), _ptr(kcache), _ptr(vcache)
-    a.src, a.src_ld = _ptr(src), (src.stride(0) if src is not None else 0)
-    a.tokens, a.tok_ld = _ptr(tokens), (tokens.stride(0) if tokens is not None else 0)
-    a.rows_per_img, a.row_mult, a.rows_total, a.t, a.pad_index, a.sa_scale = rows_per_img, row_mult, rows_total, t, pad_index, float(sa_scale)
-    a.wo_packed, a.bo, a.x, a.ldx = _ptr(wo_packed), _ptr(bo), _ptr(x), x.stride(0)
-    if x_ln is not None:
-        a.x_stats, a.x_eps, a.x_gamma, a.x_beta = _ptr(x_ln[0]), float(x_ln[1]), _ptr(x_ln[2]), _ptr(x_ln[3])
-    if cross is None:
-        a.y1, a.ldy1, a.st1 = _ptr(y), y.stride(0), _ptr(st)
-    else:
-        a.cross, a.S, a.ea_scale, a.ln1_eps = 1, int(cross["s"]), float(cross["ea_scale"]), float(cross["ln1_eps"])
-        a.wq_packed, a.bq, a.cs_q = _ptr(cross["wq_packed"]), _ptr(cross["bq"]), _ptr(cross["cs_q"])
-        a.kp_dperm, a.vt, a.keymask = _ptr(cross["kp"]), _ptr(cross["vt"]), _ptr(cross["keymask"])
-        a.weo_packed, a.beo, a.ln1_gamma, a.ln1_beta = _ptr(cross["weo_packed"]), _ptr(cross["beo"]), _ptr(cross["ln1_gamma"]), _ptr(cross["ln1_beta"])
-        a.y2, a.ldy2, a.st2 = _ptr(y), y.stride(0), _ptr(st)
-    _launch("dh_attn_block_decode", _c.byref(a), n_img, _dt(x), _stream())
-    return y, st
 
 
 def attn_cross_pack(kv, n_img, s, d, n_heads, dperm=False):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 17
+#define DH_ABI_VERSION 16
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -325,28 +325,6 @@ int dh_attn_cross_decode_packed(const void* q, int ldq, const void* kp, const vo
                                 int n_img, int rows_per_img, int S, int D, int n_heads, float scale, int dperm, int dtype, void* stream);
 int dh_attn_cross_prefill_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
                                  int n_img, int n_pos, int S, int D, int n_heads, float scale, int dperm, int dtype, void* stream);
-
-/* The attention half of a decoder layer for one decode position in ONE launch (16-bit dtypes, D = 512, 8 heads; transformers.py:356-368 /
- * :625-629): dh_attn_self_decode -> dh_linear_ln(fc_o, residual x with its pending LayerNorm, output statistics) [-> with `cross`:
- * dh_attn_cross_qproj_decode -> dh_linear_ln(enc fc_o, residual = LayerNorm(fc_o rows), output statistics)], one workgroup per image
- * streaming the fragment-packed weights (dh_pack_mfma_fragments) itself; bit-identical to that sequence (csrc/attention.hip).
- * rows_per_img <= 8 (<= 5 beyond 16 keys), t <= 39, S <= 64 (_supported).  Outputs: y1 / st1 when !cross, y2 / st2 when cross. */
-typedef struct dh_attn_block {
-    const void* qkv; int ldqkv;                     /* [rows, 3 D]: q | k | v of this position (dh_linear_ln of the layer input) */
-    void *kcache, *vcache; const int32_t* src; int src_ld; const int32_t* tokens; int tok_ld;
-    int rows_per_img, row_mult, rows_total, t, pad_index; float sa_scale;
-    const void* wo_packed; const float* bo;
-    const void* x; int ldx; const float* x_stats; float x_eps; const float *x_gamma, *x_beta;   /* residual rows of fc_o; x_stats != NULL: pre-LayerNorm */
-    void* y1; int ldy1; float* st1;
-    int cross, S; float ea_scale, ln1_eps;
-    const void* wq_packed; const float *bq, *cs_q;  /* fc_q with the LayerNorm of the fc_o rows folded in (dh_ln_fold_t semantics) */
-    const void *kp_dperm, *vt; const uint8_t* keymask;
-    const void* weo_packed; const float *beo, *ln1_gamma, *ln1_beta;
-    void* y2; int ldy2; float* st2;
-} dh_attn_block_t;
-int dh_attn_block_supported(int D, int n_heads, int rows_per_img, int t, int cross, int S);
-int dh_attn_block_decode(const dh_attn_block_t* a, int n_img, int dtype, void* stream);
-int dh_attn_block_stamps(unsigned long long* out10);   /* developer probe (DH_ATTN_BLOCK_STAMPS=1): phase stamps of the last launch */
 
 /* keymask[r] = any(enc_out[r, :] == 0)  (transformers.py:480-481).  enc_out [rows, D]. */
 int dh_enc_key_mask(const void* enc_out, uint8_t* keymask, int rows, int D, int dtype, void* stream);

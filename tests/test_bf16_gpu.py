@@ -768,73 +768,3 @@ def test_decode_chain_wreg_equals_tile_chain(kind, monkeypatch):
         monkeypatch.delenv("DH_NO_DECODE_WREG")
         model.decoder._drop_plan()
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
-
-
-@pytest.mark.parametrize("n_img,beam,t,cross", [(256, 5, 17, True), (3, 5, 31, True), (7, 1, 0, True), (64, 5, 6, False), (5, 8, 12, True),
-                                                 (2, 3, 39, False)])
-def test_attention_block_equals_separate_launches(hip, n_img, beam, t, cross):
-    """dh_attn_block_decode (self-attention + fc_o [+ fc_q + cross-attention + enc fc_o] of one position, one workgroup per image)
-    against dh_attn_self_decode -> dh_linear_ln_wreg -> dh_attn_cross_qproj_decode -> dh_linear_ln_wreg on the same operands: output
-    rows, their statistics AND the appended KV-cache rows bit for bit -- shared ancestors, pad-masked keys, masked encoder keys."""
-    d, h, s = 512, 8, 49
-    rows = n_img * beam
-    g = torch.Generator().manual_seed(n_img * 1000 + t)
-    r = lambda *shape, sc=1.0: bf(torch.randn(*shape, generator=g) * sc).cuda()
-    qkv = r(rows, 3 * d)
-    kc0, vc0 = r(t + 1, rows, d), r(t + 1, rows, d)
-    base = (torch.arange(rows) // beam) * beam
-    src = (base[:, None] + torch.randint(0, beam, (rows, t + 1), generator=g)).to(torch.int32).cuda()
-    tokens = torch.randint(0, 9, (rows, t + 1), generator=g).to(torch.int32).cuda()          # some zeros: pad-masked keys (pad_index 0)
-    x = r(rows, d, sc=1.7)
-    xst = _tile_stats(x.float().cpu()).cuda()
-    gam = lambda: (torch.rand(d, generator=g) + 0.5).cuda()
-    bet = lambda: (torch.randn(d, generator=g) * 0.2).cuda()
-    g3, b3, g1, b1 = gam(), bet(), gam(), bet()
-    wo, weo, wq = r(d, d, sc=d ** -0.5), r(d, d, sc=d ** -0.5), r(d, d, sc=d ** -0.5)
-    bo, beo, bq, csq = bet(), bet(), bet(), (torch.randn(d, generator=g)).cuda()
-    wop, weop, wqp = hip.pack_mfma_fragments(wo), hip.pack_mfma_fragments(weo), hip.pack_mfma_fragments(wq)
-    kv = r(n_img * s, 2 * d)
-    mask = (torch.rand(n_img * s, generator=g) < 0.1).to(torch.uint8).cuda()
-    kp, vt = hip.attn_cross_pack(kv, n_img, s, d, h, dperm=True)
-    assert hip.attn_block_supported(d, h, beam, t, cross, s)
-    for x_ln in (None, (xst, 1e-5, g3, b3)):
-        # the separate launches
-        kc1, vc1 = kc0.clone(), vc0.clone()
-        att = torch.empty(rows, d, dtype=HALF, device="cuda")
-        hip.attn_self_decode(qkv, kc1, vc1, src, tokens, att, n_img, beam, 1, rows, t, d, h, 8.0, 0)
-        y1, st1 = hip.linear_ln_wreg(att, wop, d, bo, residual=x, r_ln=x_ln)
-        if cross:
-            att2 = torch.empty(rows, d, dtype=HALF, device="cuda")
-            hip.attn_cross_qproj_decode(y1, st1, 1e-5, wq, bq, csq, kp, vt, mask, att2, n_img, beam, s, d, h, 8.0)
-            want, wst = hip.linear_ln_wreg(att2, weop, d, beo, residual=y1, r_ln=(st1, 1e-5, g1, b1))
-        else:
-            want, wst = y1, st1
-        # one launch
-        kc2, vc2 = kc0.clone(), vc0.clone()
-        cr = dict(s=s, ea_scale=8.0, ln1_eps=1e-5, wq_packed=wqp, bq=bq, cs_q=csq, kp=kp, vt=vt, keymask=mask, weo_packed=weop, beo=beo,
-                  ln1_gamma=g1, ln1_beta=b1) if cross else None
-        got, gst = hip.attn_block_decode(qkv, kc2, vc2, src, tokens, n_img, beam, 1, rows, t, 0, 8.0, wop, bo, x, x_ln=x_ln, cross=cr)
-        assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
-        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
-        assert torch.equal(gst, wst)
-
-
-@pytest.mark.parametrize("kind", ["CaptioningTransformer", "CaptioningTransformerBase"])
-def test_decode_chain_attention_block_equals_separate_launches(kind, monkeypatch):
-    """The decode chain with the row-owning attention block against the same chain with its five launches (DH_ATTN_BLOCK=0): same
-    tokens and lengths, greedy and sampled, 64 images x beam 5 and the one-row-per-image first positions."""
-    import deephumor_amd.models as M
-    from deephumor_amd.synth import synth_state_dict
-    model = getattr(M, kind)(1000, hid_dim=512, n_layers=2).eval()
-    model.load_state_dict(synth_state_dict(model.state_dict(), seed=4321))
-    model = model.to(HALF).cuda()
-    imgs = synth_images(64, seed=11).cuda()
-    out = {}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("DH_ATTN_BLOCK", flag)
-        with torch.no_grad():
-            out[flag] = (model.generate_batch(imgs, max_len=12, beam_size=5, top_k=20, seed=5),
-                         model.generate_batch(imgs[:3], max_len=30, beam_size=1, top_k=1),
-                         model.generate_batch(imgs[:9], max_len=8, beam_size=8, top_k=20, seed=6))
-    for a, b in zip(out["1"], out["0"]):
-        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
