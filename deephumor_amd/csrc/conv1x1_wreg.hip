@@ -1,0 +1,186 @@
+// 1x1 convolution + BatchNorm + ReLU of the ResNet-50 bottlenecks' `conv1` (torchvision Bottleneck.conv1 / bn1 / relu; reference
+// encoders.py:37-38, :56) for the K >= 512 layers, with the WEIGHTS STATIONARY IN REGISTERS and the pixels streamed:
+//   y[M, N] = relu((x[M, K] W[N, K]^T) * scale[n] + shift[n]),   M = images x pixels (12,544 ... 200,704), N = 128 ... 512, K = 512 / 1,024.
+//
+// The implicit-GEMM tile kernel (gemm_bf16.hip, 128 x 128 tiles, both operands through a two-slab LDS ring) runs these layers at
+// 0.26-0.50 of their roofline ({50176 x 256 x 1024}: 48.5 us against 16 us of HBM time): one barrier + one wait per 64-k slab with
+// 8-16 MFMAs per wave in between, and the weight panel staged again for every 128-pixel tile.  Here (the partition of
+// linear_wreg.hip / lstm_wreg.hip, made persistent over the pixels):
+//   * a workgroup (8 waves, one per CU) owns ONE 128-column block of the output channels for its whole life: a wave keeps its 16 weight
+//     rows x all K as MFMA fragments in registers (64 or 128 VGPRs), loaded once from the fragment-packed weights;
+//   * the pixels stream through TWO LDS buffers of RB rows x all K (64 KB each) by LDS-DMA: the transfer of block i + 1 is issued
+//     behind block i's barrier (every wave has then left block i - 1, whose buffer it takes) and is in flight during block i's MFMAs;
+//   * per block: ONE barrier, TM x K / 32 MFMAs per wave fed by ds_read_b128 only, then BatchNorm + ReLU on the accumulators and
+//     8-byte stores straight from them;
+//   * vmcnt bookkeeping with immediates: vector-memory operations retire in order, so when block i is waited for exactly the TM
+//     stores of block i - 1 may still be outstanding;
+//   * the N / 128 workgroups that stream the same pixels sit on ONE XCD (blockIdx % 8) and walk them in the same order: a pixel block
+//     is fetched into that L2 once.
+// Same MFMA operand contents and k order per output as the tile kernel, same epilogue arithmetic: BIT-IDENTICAL (tests/test_bf16_gpu.py).
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "prof.h"
+
+namespace {
+struct C1Params {
+    const uint16_t* x; const uint4* wp; const float* scale; const float* shift; uint16_t* y;
+    int M, N, relu, nb_n, wg_per_n, nblk;
+};
+
+__device__ __forceinline__ void c1_dma16(const void* base, unsigned off, void* lds_dst) {
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dh_lptr_t)lds_dst);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m), "v"(off), "s"(base) : "memory");
+}
+
+// KF = K / 32 fragments per column tile, RB rows per block (RB x K x 2 B = 64 KB), TN column tiles per wave (NW = 8 / TN waves).
+// TN = 2: every pixel fragment read from LDS feeds two MFMAs -- with one column tile per wave all eight waves read the WHOLE pixel block
+// (8 x 64 KB per block at 128 B/clk = twice the block's MFMA time).  MEASURED: no gain -- TN = 2 with 4 waves 42 / 56 / 91 / 75 us, with 8
+// waves and 256 channels per workgroup 79.5 us for {200704 x 256 x 512}, against 36 / 53 / 76 / 59 us for TN = 1 with 8 waves: these layers
+// run at 3.6-4.9 TB/s of HBM traffic, not at the LDS read rate.  The dispatch uses TN = 1.
+template <typename OT, int KF, int RB, int TN, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
+    constexpr int K = 32 * KF, NSLAB = K / 64, SLABB = RB * 128, BUF = NSLAB * SLABB, TM = RB / 16, RG = RB / 8;
+    constexpr int NT = 64 * NW, BN = 16 * NW * TN;         // output channels per workgroup
+    constexpr int PPW = NSLAB * RG / NW;                  // LDS-DMA pieces per wave per block
+    constexpr int PF = 3;
+    static_assert(BUF == 65536 && (NSLAB * RG) % NW == 0, "block = 64 KB");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, lq = lane >> 4, lr = lane >> 3, lpos = lane & 7;
+    // workgroup -> (column block, member j of that block's pixel walkers); the nb_n column blocks of member j share blockIdx % 8
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int nb = idx % p.nb_n, j = (idx / p.nb_n) * 8 + xcd;
+    const int n0 = nb * BN;
+
+    // ---- this wave's 16 weight rows x all K + its columns' BatchNorm scale / shift ------------------------------------------------------
+    uint4 wf[TN][KF];
+    float4 sc4[TN], sh4[TN];
+#pragma unroll
+    for (int c = 0; c < TN; ++c) {
+        const uint4* wsrc = p.wp + ((size_t)(n0 / 16 + wave * TN + c)) * 64 + lane;
+        const size_t fstep = (size_t)(p.N / 16) * 64;
+#pragma unroll
+        for (int f = 0; f < KF; ++f) wf[c][f] = wsrc[(size_t)f * fstep];
+        sc4[c] = *reinterpret_cast<const float4*>(p.scale + n0 + 16 * (wave * TN + c) + 4 * lq);
+        sh4[c] = *reinterpret_cast<const float4*>(p.shift + n0 + 16 * (wave * TN + c) + 4 * lq);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only the counted operations below are in flight
+
+    // ---- pixel-block loader: block b = rows b RB .. + RB - 1 (rows past M re-read row M - 1) -----
+    const unsigned swz = (unsigned)((lpos ^ lr) << 4);
+    auto stage = [&](int b, int buf) {
+        unsigned char* dst0 = lds + buf * BUF;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {                   // piece = (8-row group g, 64-column slab s), dealt round-robin to the waves
+            const int pc = wave + NW * i, s = pc % NSLAB, g = pc / NSLAB;
+            const unsigned ro = (unsigned)min(b * RB + g * 8 + lr, p.M - 1) * (unsigned)(K * 2) + swz;
+            c1_dma16(p.x, ro + 128u * s, dst0 + s * SLABB + g * 1024);
+        }
+    };
+    // LDS read bases per (k half, buffer): row 16 i + l15 has (row & 7) == (l15 & 7); a buffer is one 64 KB ds_read window
+    unsigned rd_base[2][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int bf = 0; bf < 2; ++bf) {
+            rd_base[kk][bf] = (unsigned)(l15 * 128 + (((kk * 4 + lq) ^ (l15 & 7)) << 4) + bf * BUF);
+            asm volatile("" : "+v"(rd_base[kk][bf]));
+        }
+
+    const int first = j, step = p.wg_per_n;
+    int nmine = first < p.nblk ? (p.nblk - first + step - 1) / step : 0;
+    if (nmine == 0) return;
+    stage(first, 0);
+    if (nmine > 1) stage(first + step, 1);
+    uint16_t* const ybase = p.y + n0 + 16 * wave * TN + 4 * lq;
+    auto block = [&](auto BUFC, const int i) {
+        constexpr int buf = decltype(BUFC)::value;
+        const int b = first + i * step;
+        // block i has landed: the only younger operations are the transfer of block i + 1 when it was issued in the prologue (i = 0),
+        // else the TN TM stores of block i - 1 (the transfer of block i was issued before them)
+        if (i == 0) {
+            if (nmine > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TN * TM) : "memory");
+        }
+        __builtin_amdgcn_s_barrier();                     // every wave's pieces of block i landed AND every wave has left block i - 1
+        if (i >= 1 && i + 1 < nmine) stage(b + step, buf ^ 1);   // block i + 1 into block i - 1's buffer: in flight during this block
+        dh_f32x4 acc[TN][TM];
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+#pragma unroll
+            for (int t = 0; t < TM; ++t) acc[c][t] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
+        uint4 fa[PF + 1];
+        auto rd = [&](int q) {                            // q = TM f + t: fragment step f = 2 s + kk, row tile t
+            const int f = q / TM, t = q - f * TM, s = f >> 1, kk = f & 1;
+            fa[q % (PF + 1)] = *reinterpret_cast<const uint4*>(lds + rd_base[kk][buf] + (s * SLABB + t * 2048));
+        };
+#pragma unroll
+        for (int q = 0; q < PF; ++q) rd(q);
+#pragma unroll
+        for (int q = 0; q < KF * TM; ++q) {
+            const int f = q / TM, t = q - f * TM;
+            if (q + PF < KF * TM) rd(q + PF);
+#pragma unroll
+            for (int c = 0; c < TN; ++c) acc[c][t] = Op16<OT>::mfma(wf[c][f], fa[q % (PF + 1)], acc[c][t]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // BatchNorm + ReLU on the accumulators, stored straight from them: acc[c][t][r] = pixel b RB + 16 t + l15, channel
+        // n0 + 16 (wave TN + c) + 4 lq + r -- 8 bytes per lane (the staged 16-byte form cost a second barrier per block).  The store is
+        // unconditional (the waits above count it): lanes past M re-store pixel M - 1's own values (rows past M were loaded as copies of it)
+#pragma unroll
+        for (int c = 0; c < TN; ++c)
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                float v0 = fmaf(acc[c][t][0], sc4[c].x, sh4[c].x), v1 = fmaf(acc[c][t][1], sc4[c].y, sh4[c].y);
+                float v2 = fmaf(acc[c][t][2], sc4[c].z, sh4[c].z), v3 = fmaf(acc[c][t][3], sc4[c].w, sh4[c].w);
+                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                uint2 pk;
+                pk.x = (uint32_t)Op16<OT>::from_f32(v0) | ((uint32_t)Op16<OT>::from_f32(v1) << 16);
+                pk.y = (uint32_t)Op16<OT>::from_f32(v2) | ((uint32_t)Op16<OT>::from_f32(v3) << 16);
+                const int m = min(b * RB + 16 * t + l15, p.M - 1);
+                *reinterpret_cast<uint2*>(ybase + (size_t)m * p.N + 16 * c) = pk;
+            }
+    };
+    for (int i = 0; i < nmine; i += 2) {
+        block(std::integral_constant<int, 0>{}, i);
+        if (i + 1 < nmine) block(std::integral_constant<int, 1>{}, i + 1);
+    }
+}
+}  // namespace
+
+// 1 when dh_conv1x1_wreg_nhwc takes the layer: Cin 256, 512 or 1,024, Cout a multiple of 128 with Cout / 128 in {1, 2, 4, 8, 16}, enough pixels
+// to give every CU several 64 KB blocks
+extern "C" int dh_conv1x1_wreg_supported(long long M, int Cin, int Cout) {
+    const int nb = Cout / 128;
+    return (Cin == 256 || Cin == 512 || Cin == 1024) && (Cout % 128) == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8 || nb == 16) &&
+           M >= 8192 && M * Cin * 2 < (1ll << 32);
+}
+
+// y [M, Cout] = relu?((x [M, Cin] w^T) * scale + shift), channels-last rows (a 1x1 stride-1 convolution + BatchNorm [+ ReLU] without
+// residual); w_packed = dh_pack_mfma_fragments(w [Cout, Cin]).  Bit-identical to dh_conv2d_nhwc_bn_act(KS = 1).
+extern "C" int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale, const float* shift, void* y, long long M,
+                                    int Cin, int Cout, int relu, int dtype, void* stream) {
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(x && w_packed && scale && shift && y && dh_conv1x1_wreg_supported(M, Cin, Cout));
+    DH_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)scale % 16) == 0 &&
+               ((uintptr_t)shift % 16) == 0);
+    C1Params p{};
+    p.x = (const uint16_t*)x; p.wp = (const uint4*)w_packed; p.scale = scale; p.shift = shift; p.y = (uint16_t*)y;
+    p.M = (int)M; p.N = Cout; p.relu = relu; p.nb_n = Cout / 128; p.wg_per_n = 256 / p.nb_n;
+    const int rb = 65536 / (2 * Cin);                    // rows per 64 KB block: 128 / 64 / 32
+    p.nblk = dh_cdiv(M, rb);
+    dh_prof_set_tag("1x1");
+    dh_prof_set_dims((int)M, Cout, Cin);
+    DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * M * Cout * Cin, 2.0 * ((double)M * Cin + (double)Cout * Cin + (double)M * Cout), stream);
+    hipStream_t s = (hipStream_t)stream;
+    DH_DISPATCH_16(dtype, {
+        if (Cin == 256) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 8, 128, 1, 8>), dim3(256), dim3(512), 0, s, p);
+        else if (Cin == 512) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 16, 64, 1, 8>), dim3(256), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 32, 32, 1, 8>), dim3(256), dim3(512), 0, s, p);
+    });
+    DH_LAUNCH_CHECK();
+}

@@ -156,6 +156,10 @@ class ImageEncoder(_Planned, nn.Module):
                     down=conv(blk.downsample[0], blk.downsample[1], False) if blk.downsample is not None else None,
                     c1=conv(blk.conv1, blk.bn1, True), c2=conv(blk.conv2, blk.bn2, True),
                     c3=conv(blk.conv3, blk.bn3, True, residual=True), dual=None)
+                c1w = ent["c1"]["w"]
+                if (bf16 and c1w.is_cuda and tuple(c1w.shape[1:3]) == (1, 1) and ent["c1"]["stride"] == 1 and c1w.shape[3] in (256, 512, 1024)
+                        and c1w.shape[0] % 128 == 0):
+                    ent["c1"]["wpk1"] = hip.pack_mfma_fragments(c1w.reshape(c1w.shape[0], c1w.shape[3]).contiguous())
                 if bf16 and ent["down"] is not None:
                     # first block of a stage on the bf16 path: relu(bn3(conv3(y)) + bn_d(downsample(x))) as ONE GEMM over
                     # [y | x at the strided pixels] with the BatchNorm scales folded into the weights -- the identity
@@ -180,6 +184,10 @@ class ImageEncoder(_Planned, nn.Module):
 
     @staticmethod
     def _conv(x, c, residual=None, nhwc=False):
+        if (nhwc and residual is None and "wpk1" in c and hip.conv1x1_wreg_supported(x.shape[0] * x.shape[1] * x.shape[2], x.shape[3], c["w"].shape[0])
+                and not os.environ.get("DH_NO_CONV1X1_WREG")):
+            # conv1 of the K >= 512 bottlenecks: weights stationary in registers, pixels streamed (csrc/conv1x1_wreg.hip; bit-identical)
+            return hip.conv1x1_wreg_nhwc(x, c["wpk1"], c["w"].shape[0], c["scale"], c["shift"], relu=c["relu"])
         if (nhwc and residual is None and c["relu"] and c["stride"] == 1 and c["pad"] == 1 and c["w"].shape[1] == 3
                 and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], x.shape[3], c["w"].shape[0])
                 and not os.environ.get("DH_NO_DIRECT_3X3")):

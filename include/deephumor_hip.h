@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 16
+#define DH_ABI_VERSION 17
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -117,6 +117,14 @@ int dh_bottleneck_tail_s3_nhwc(const void* y1, const void* w2_packed, const floa
 /* 16-bit weight matrix w [R][K] row-major -> MFMA operand fragments: out[((k / 32) * (R / 16) + r / 16) * 64 + lane] (16 bytes) = the 8
  * values k = 32 s + 8 (lane >> 4) .. + 7 of row 16 rt + (lane & 15); R % 16 == 0, K % 32 == 0; out has R * K elements. */
 int dh_pack_mfma_fragments(const void* w, void* out, int R, int K, void* stream);
+
+/* 1x1 stride-1 convolution + BatchNorm (+ ReLU), no residual, channels-last rows, with the weights stationary in registers and the
+ * pixels streamed through two LDS buffers (csrc/conv1x1_wreg.hip; torchvision Bottleneck.conv1 / bn1 / relu of the K >= 512 stages,
+ * encoders.py:37-38): y [M, Cout] = relu?((x [M, Cin] w^T) * scale + shift), w_packed = dh_pack_mfma_fragments(w [Cout, Cin]).
+ * Cin 256, 512 or 1,024, Cout / 128 in {1, 2, 4, 8, 16}, M >= 8,192 (_supported).  Bit-identical to dh_conv2d_nhwc_bn_act(KS = 1). */
+int dh_conv1x1_wreg_supported(long long M, int Cin, int Cout);
+int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale, const float* shift, void* y, long long M, int Cin,
+                         int Cout, int relu, int dtype, void* stream);
 
 /* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */

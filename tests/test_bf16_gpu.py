@@ -768,3 +768,20 @@ def test_decode_chain_wreg_equals_tile_chain(kind, monkeypatch):
         monkeypatch.delenv("DH_NO_DECODE_WREG")
         model.decoder._drop_plan()
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,relu", [(16, 28, 512, 128, True), (64, 14, 1024, 256, True), (11, 28, 512, 256, False), (43, 14, 1024, 512, True),
+                                                (256, 7, 512, 2048, True), (3, 56, 1024, 128, True), (5, 56, 256, 128, True), (9, 31, 256, 256, False)])
+def test_conv1x1_wreg_equals_tile_gemm(hip, n, hw, cin, cout, relu):
+    """dh_conv1x1_wreg_nhwc (weights stationary in registers, pixels streamed through two 64 KB LDS buffers, persistent workgroups)
+    against the implicit-GEMM tile kernel on the same operands, bit for bit -- pixel counts that are not a multiple of the block (a
+    partial last block), 1 to 16 column blocks, with and without ReLU."""
+    g = torch.Generator().manual_seed(n * 7 + cout)
+    x = bf(torch.randn(n, hw, hw, cin, generator=g)).cuda()
+    w = bf(torch.randn(cout, 1, 1, cin, generator=g) / cin ** 0.5).cuda()
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.3).cuda()
+    assert hip.conv1x1_wreg_supported(n * hw * hw, cin, cout)
+    want = hip.conv2d_nhwc_bn_act(x, w, scale, shift, relu=relu)
+    got = hip.conv1x1_wreg_nhwc(x, hip.pack_mfma_fragments(w.view(cout, cin)), cout, scale, shift, relu=relu)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    assert not hip.conv1x1_wreg_supported(4096, cin, cout) and not hip.conv1x1_wreg_supported(n * hw * hw, 128, cout)
