@@ -26,6 +26,10 @@ namespace {
 struct C1Params {
     const uint16_t* x; const uint4* wp; const float* scale; const float* shift; uint16_t* y;
     int M, N, relu, nb_n, wg_per_n, nblk;
+    // second source of the virtual operand [x | x2 at the strided pixels] (dual form; x2 == nullptr otherwise): k slabs ns1 .. come from
+    // x2 [Nimg, H2, W2, C2]; row r = (n, oy, ox) of the Ho x Wo output grid reads pixel (n, oy * stride, ox * stride)
+    const uint16_t* x2; int ns1, howo, wo, h2w2, w2, stride2, c2;
+    unsigned magic_howo, magic_wo;                        // floor(2^32 / d) + 1: r / d == umulhi(r, magic) while r * d < 2^32
 };
 
 __device__ __forceinline__ void c1_dma16(const void* base, unsigned off, void* lds_dst) {
@@ -44,7 +48,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
     constexpr int NT = 64 * NW, BN = 16 * NW * TN;         // output channels per workgroup
     constexpr int PPW = NSLAB * RG / NW;                  // LDS-DMA pieces per wave per block
     constexpr int PF = 3;
-    static_assert(BUF == 65536 && (NSLAB * RG) % NW == 0, "block = 64 KB");
+    static_assert(BUF <= 65536 && (NSLAB * RG) % NW == 0, "two buffers of <= 64 KB (one ds_read offset window each)");
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,7 +67,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
         const size_t fstep = (size_t)(p.N / 16) * 64;
 #pragma unroll
         for (int f = 0; f < KF; ++f) wf[c][f] = wsrc[(size_t)f * fstep];
-        sc4[c] = *reinterpret_cast<const float4*>(p.scale + n0 + 16 * (wave * TN + c) + 4 * lq);
+        sc4[c] = p.scale ? *reinterpret_cast<const float4*>(p.scale + n0 + 16 * (wave * TN + c) + 4 * lq) : make_float4(1.f, 1.f, 1.f, 1.f);
         sh4[c] = *reinterpret_cast<const float4*>(p.shift + n0 + 16 * (wave * TN + c) + 4 * lq);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only the counted operations below are in flight
@@ -75,8 +79,15 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {                   // piece = (8-row group g, 64-column slab s), dealt round-robin to the waves
             const int pc = wave + NW * i, s = pc % NSLAB, g = pc / NSLAB;
-            const unsigned ro = (unsigned)min(b * RB + g * 8 + lr, p.M - 1) * (unsigned)(K * 2) + swz;
-            c1_dma16(p.x, ro + 128u * s, dst0 + s * SLABB + g * 1024);
+            const unsigned r = (unsigned)min(b * RB + g * 8 + lr, p.M - 1);
+            if (s < p.ns1) {
+                c1_dma16(p.x, r * (unsigned)(p.ns1 * 128) + swz + 128u * s, dst0 + s * SLABB + g * 1024);
+            } else {                                      // (wave-uniform branch: s depends on the wave and the unrolled i only)
+                const unsigned n = __umulhi(r, p.magic_howo), rem = r - n * (unsigned)p.howo;
+                const unsigned oy = __umulhi(rem, p.magic_wo), ox = rem - oy * (unsigned)p.wo;
+                const unsigned r2 = n * (unsigned)p.h2w2 + (oy * (unsigned)p.w2 + ox) * (unsigned)p.stride2;
+                c1_dma16(p.x2, r2 * (unsigned)(p.c2 * 2) + swz + 128u * (s - p.ns1), dst0 + s * SLABB + g * 1024);
+            }
         }
     };
     // LDS read bases per (k half, buffer): row 16 i + l15 has (row & 7) == (l15 & 7); a buffer is one 64 KB ds_read window
@@ -170,7 +181,7 @@ extern "C" int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const f
                ((uintptr_t)shift % 16) == 0);
     C1Params p{};
     p.x = (const uint16_t*)x; p.wp = (const uint4*)w_packed; p.scale = scale; p.shift = shift; p.y = (uint16_t*)y;
-    p.M = (int)M; p.N = Cout; p.relu = relu; p.nb_n = Cout / 128; p.wg_per_n = 256 / p.nb_n;
+    p.M = (int)M; p.N = Cout; p.relu = relu; p.nb_n = Cout / 128; p.wg_per_n = 256 / p.nb_n; p.ns1 = Cin / 64;
     const int rb = 65536 / (2 * Cin);                    // rows per 64 KB block: 128 / 64 / 32
     p.nblk = dh_cdiv(M, rb);
     dh_prof_set_tag("1x1");
@@ -181,6 +192,46 @@ extern "C" int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const f
         if (Cin == 256) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 8, 128, 1, 8>), dim3(256), dim3(512), 0, s, p);
         else if (Cin == 512) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 16, 64, 1, 8>), dim3(256), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 32, 32, 1, 8>), dim3(256), dim3(512), 0, s, p);
+    });
+    DH_LAUNCH_CHECK();
+}
+
+// The end of a stage's FIRST bottleneck, relu(bn3(conv3(y)) + bn_d(downsample(x))), in the same streaming form: one GEMM over the virtual
+// operand [y | x at the strided pixels] with the BatchNorm scales folded into the weights (dh_conv1x1_dual_nhwc, gemm_bf16.hip), for the
+// two HBM-bound instances: stage 1 (C1 = C2 = 64, Cout = 256: 616 MB per 256 images) and stage 2 (C1 = 128, C2 = 256, Cout = 512).
+// A workgroup owns 256 output channels (two column tiles per wave).
+extern "C" int dh_conv1x1_dual_wreg_supported(long long M, int C1, int C2, int Cout) {
+    const int K = C1 + C2, nb = Cout / 256;
+    return (K == 128 || K == 384) && (C1 % 64) == 0 && (C2 % 64) == 0 && (Cout % 256) == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8) &&
+           M >= 8192 && M * 4096 < (1ll << 32);
+}
+
+// out [N, Ho, Wo, Cout] = relu?([y | x at (oy * stride, ox * stride)] w^T + shift); w_packed = dh_pack_mfma_fragments(w [Cout, C1 + C2]).
+// Bit-identical to dh_conv1x1_dual_nhwc.
+extern "C" int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const void* w_packed, const float* shift, void* out, int N, int Ho,
+                                         int Wo, int C1, int H, int W, int C2, int stride, int Cout, int relu, int dtype, void* stream) {
+    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    const long long M = (long long)N * Ho * Wo;
+    DH_REQUIRE(y && x && w_packed && shift && out && N > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0 && stride >= 1 &&
+               dh_conv1x1_dual_wreg_supported(M, C1, C2, Cout));
+    DH_REQUIRE((Ho - 1) * stride < H && (Wo - 1) * stride < W && (long long)Ho * Wo <= 4096 && (long long)N * H * W * C2 * 2 < (1ll << 32));
+    DH_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
+               ((uintptr_t)shift % 16) == 0);
+    C1Params p{};
+    p.x = (const uint16_t*)y; p.wp = (const uint4*)w_packed; p.scale = nullptr; p.shift = shift; p.y = (uint16_t*)out;
+    p.M = (int)M; p.N = Cout; p.relu = relu; p.nb_n = Cout / 256; p.wg_per_n = 256 / p.nb_n; p.ns1 = C1 / 64;
+    p.x2 = (const uint16_t*)x; p.howo = Ho * Wo; p.wo = Wo; p.h2w2 = H * W; p.w2 = W; p.stride2 = stride; p.c2 = C2;
+    p.magic_howo = (unsigned)((1ull << 32) / (unsigned)p.howo + 1); p.magic_wo = (unsigned)((1ull << 32) / (unsigned)Wo + 1);
+    const int K = C1 + C2;
+    p.nblk = dh_cdiv(M, K == 128 ? 128 : 64);
+    dh_prof_set_tag("1x1");
+    dh_prof_set_dims((int)M, Cout, K);
+    DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * M * Cout * K,
+                     2.0 * ((double)M * C1 + (double)M * C2 + (double)Cout * K + (double)M * Cout), stream);
+    hipStream_t s = (hipStream_t)stream;
+    DH_DISPATCH_16(dtype, {
+        if (K == 128) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 4, 128, 2, 8>), dim3(256), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 12, 64, 2, 8>), dim3(256), dim3(512), 0, s, p);
     });
     DH_LAUNCH_CHECK();
 }

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 17
+ABI_VERSION = 18
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -76,6 +76,8 @@ SIGNATURES = {
     "dh_conv1x1_wreg_nhwc": [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P],
     "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
+    "dh_conv1x1_dual_wreg_supported": [_c.c_longlong, _I, _I, _I],
+    "dh_conv1x1_dual_wreg_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_resize_u8_hwc": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_normalize_pack_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -908,6 +910,22 @@ def conv1x1_dual_nhwc(y, x, w_cat, shift, stride, relu=True):
     cout = w_cat.shape[0]
     out = torch.empty((n, ho, wo, cout), dtype=y.dtype, device=y.device)
     _launch("dh_conv1x1_dual_nhwc", _ptr(y), _ptr(x), _ptr(w_cat), _ptr(shift), _ptr(out), n, ho, wo, c1, h, w_, c2, stride,
+            cout, int(relu), _dt(y), _stream())
+    return out
+
+
+def conv1x1_dual_wreg_supported(m, c1, c2, cout):
+    return bool(load().dh_conv1x1_dual_wreg_supported(int(m), int(c1), int(c2), int(cout)))
+
+
+def conv1x1_dual_wreg_nhwc(y, x, w_packed, cout, shift, stride, relu=True):
+    """``conv1x1_dual_nhwc`` with the weights stationary in registers and the pixels of both sources streamed
+    (``w_packed = pack_mfma_fragments(w_cat)``; csrc/conv1x1_wreg.hip).  Bit-identical to ``conv1x1_dual_nhwc``."""
+    _dev(y, x, w_packed, shift)
+    n, ho, wo, c1 = y.shape
+    _, h, w_, c2 = x.shape
+    out = torch.empty((n, ho, wo, cout), dtype=y.dtype, device=y.device)
+    _launch("dh_conv1x1_dual_wreg_nhwc", _ptr(y), _ptr(x), _ptr(w_packed), _ptr(shift), _ptr(out), n, ho, wo, c1, h, w_, c2, stride,
             cout, int(relu), _dt(y), _stream())
     return out
 

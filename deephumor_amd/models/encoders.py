@@ -171,6 +171,8 @@ class ImageEncoder(_Planned, nn.Module):
                     if c3["w"].shape[-1] % 64 == 0 and dn["w"].shape[-1] % 64 == 0:
                         ent["dual"] = dict(w=w_cat.to(wdt).contiguous(), shift=(c3["shift"] + dn["shift"]).contiguous(),
                                            stride=dn["stride"])
+                        if w_cat.is_cuda and w_cat.shape[1] in (128, 384) and cout % 256 == 0:
+                            ent["dual"]["wpk"] = hip.pack_mfma_fragments(ent["dual"]["w"])
                 if (bf16 and ent["down"] is None and ent["c2"]["stride"] == 1 and ent["c2"]["w"].shape[1] == 3
                         and ent["c3"]["w"].shape[0] == 4 * ent["c2"]["w"].shape[0] and ent["c2"]["w"].shape[0] == ent["c2"]["w"].shape[3]
                         and hip.bottleneck_tail_s3_supported(14, 14, ent["c2"]["w"].shape[0])):
@@ -250,6 +252,10 @@ class ImageEncoder(_Planned, nn.Module):
             y = self._conv(self._conv(x, blk["c1"], nhwc=nhwc), blk["c2"], nhwc=nhwc)
             if blk["dual"] is not None:
                 d = blk["dual"]
+                if ("wpk" in d and not os.environ.get("DH_NO_CONV1X1_WREG")
+                        and hip.conv1x1_dual_wreg_supported(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3], x.shape[3], d["w"].shape[0])):
+                    x = hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], d["w"].shape[0], d["shift"], d["stride"], relu=True)
+                    continue
                 x = hip.conv1x1_dual_nhwc(y, x, d["w"], d["shift"], d["stride"], relu=True)
                 continue
             idt = x if blk["down"] is None else self._conv(x, blk["down"], nhwc=nhwc)

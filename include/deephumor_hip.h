@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 17
+#define DH_ABI_VERSION 18
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -125,6 +125,13 @@ int dh_pack_mfma_fragments(const void* w, void* out, int R, int K, void* stream)
 int dh_conv1x1_wreg_supported(long long M, int Cin, int Cout);
 int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale, const float* shift, void* y, long long M, int Cin,
                          int Cout, int relu, int dtype, void* stream);
+
+/* The dual form (dh_conv1x1_dual_nhwc: relu(bn3(conv3(y)) + bn_d(downsample(x))) of a stage's first bottleneck, encoders.py:37-38 /
+ * torchvision Bottleneck.forward with `downsample`) in the same streaming structure, for the HBM-bound instances C1 + C2 = 128 or 384,
+ * Cout a multiple of 256 (_supported).  w_packed = dh_pack_mfma_fragments(w [Cout, C1 + C2]).  Bit-identical to dh_conv1x1_dual_nhwc. */
+int dh_conv1x1_dual_wreg_supported(long long M, int C1, int C2, int Cout);
+int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const void* w_packed, const float* shift, void* out, int N, int Ho, int Wo,
+                              int C1, int H, int W, int C2, int stride, int Cout, int relu, int dtype, void* stream);
 
 /* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */

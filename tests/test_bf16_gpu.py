@@ -785,3 +785,22 @@ def test_conv1x1_wreg_equals_tile_gemm(hip, n, hw, cin, cout, relu):
     got = hip.conv1x1_wreg_nhwc(x, hip.pack_mfma_fragments(w.view(cout, cin)), cout, scale, shift, relu=relu)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
     assert not hip.conv1x1_wreg_supported(4096, cin, cout) and not hip.conv1x1_wreg_supported(n * hw * hw, 128, cout)
+
+
+@pytest.mark.parametrize("n,ho,c1,c2,cout,stride", [(3, 56, 64, 64, 256, 1), (13, 28, 128, 256, 512, 2), (5, 57, 64, 64, 512, 1),
+                                                    (21, 27, 128, 256, 256, 2), (12, 28, 64, 320, 1024, 2)])
+def test_conv1x1_dual_wreg_equals_tile_gemm(hip, n, ho, c1, c2, cout, stride):
+    """dh_conv1x1_dual_wreg_nhwc (conv3 + strided downsample of a stage's first bottleneck as one streamed GEMM over [y | x at the strided
+    pixels], weights stationary in registers) against dh_conv1x1_dual_nhwc on the same operands, bit for bit: both strides, odd input
+    sizes (the strided pixel map), partial last blocks, 1 to 4 column blocks."""
+    g = torch.Generator().manual_seed(n * 11 + cout)
+    h = (ho - 1) * stride + 1 + (n % 2)                  # an input grid the strided walk does not end on, every other case
+    y = bf(torch.randn(n, ho, ho, c1, generator=g)).cuda()
+    x = bf(torch.randn(n, h, h, c2, generator=g)).cuda()
+    w = bf(torch.randn(cout, c1 + c2, generator=g) / (c1 + c2) ** 0.5).cuda()
+    shift = (torch.randn(cout, generator=g) * 0.3).cuda()
+    assert hip.conv1x1_dual_wreg_supported(n * ho * ho, c1, c2, cout)
+    want = hip.conv1x1_dual_nhwc(y, x, w, shift, stride, relu=True)
+    got = hip.conv1x1_dual_wreg_nhwc(y, x, hip.pack_mfma_fragments(w), cout, shift, stride, relu=True)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    assert not hip.conv1x1_dual_wreg_supported(n * ho * ho, 256, 512, cout) and not hip.conv1x1_dual_wreg_supported(4096, c1, c2, cout)
