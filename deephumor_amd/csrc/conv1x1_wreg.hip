@@ -34,7 +34,10 @@ struct C1Params {
 
 __device__ __forceinline__ void c1_dma16(const void* base, unsigned off, void* lds_dst) {
     const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(dh_lptr_t)lds_dst);
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m), "v"(off), "s"(base) : "memory");
+    // (the base is wave-uniform by construction; said explicitly because an if-converted source select otherwise lands in VGPRs)
+    const uint64_t b = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32)) << 32) |
+                       (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m), "v"(off), "s"(b) : "memory");
 }
 
 // KF = K / 32 fragments per column tile, RB rows per block (RB x K x 2 B = 64 KB), TN column tiles per wave (NW = 8 / TN waves).
@@ -42,14 +45,14 @@ __device__ __forceinline__ void c1_dma16(const void* base, unsigned off, void* l
 // (8 x 64 KB per block at 128 B/clk = twice the block's MFMA time).  MEASURED: no gain -- TN = 2 with 4 waves 42 / 56 / 91 / 75 us, with 8
 // waves and 256 channels per workgroup 79.5 us for {200704 x 256 x 512}, against 36 / 53 / 76 / 59 us for TN = 1 with 8 waves: these layers
 // run at 3.6-4.9 TB/s of HBM traffic, not at the LDS read rate.  The dispatch uses TN = 1.
-template <typename OT, int KF, int RB, int TN, int NW>
+template <typename OT, int KF, int RB, int TN, int NW>      // TN = 1 or 2
 __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
     constexpr int K = 32 * KF, NSLAB = K / 64, SLABB = RB * 128, BUF = NSLAB * SLABB, TM = RB / 16, RG = RB / 8;
     constexpr int NT = 64 * NW, BN = 16 * NW * TN;         // output channels per workgroup
     constexpr int PPW = NSLAB * RG / NW;                  // LDS-DMA pieces per wave per block
     constexpr int PF = 3;
     static_assert(BUF <= 65536 && (NSLAB * RG) % NW == 0, "two buffers of <= 64 KB (one ds_read offset window each)");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + (TN > 1 ? BN * 8 : 0)];   // + this workgroup's scale | shift (TN > 1)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4, lr = lane >> 3, lpos = lane & 7;
@@ -69,6 +72,12 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
         for (int f = 0; f < KF; ++f) wf[c][f] = wsrc[(size_t)f * fstep];
         sc4[c] = p.scale ? *reinterpret_cast<const float4*>(p.scale + n0 + 16 * (wave * TN + c) + 4 * lq) : make_float4(1.f, 1.f, 1.f, 1.f);
         sh4[c] = *reinterpret_cast<const float4*>(p.shift + n0 + 16 * (wave * TN + c) + 4 * lq);
+    }
+    // two column tiles per wave: the 16 epilogue constants live in LDS (read back per block) -- the K = 768 instance has no registers for them
+    float4* const bn_lds = reinterpret_cast<float4*>(lds + 2 * BUF) + (wave * TN) * 8 + lq;      // [tile][scale | shift][quad]
+    if constexpr (TN > 1) {
+        if (l15 == 0) { bn_lds[0] = sc4[0]; bn_lds[4] = sh4[0]; bn_lds[8] = sc4[TN - 1]; bn_lds[12] = sh4[TN - 1]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only the counted operations below are in flight
 
@@ -146,8 +155,10 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
         for (int c = 0; c < TN; ++c)
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
-                float v0 = fmaf(acc[c][t][0], sc4[c].x, sh4[c].x), v1 = fmaf(acc[c][t][1], sc4[c].y, sh4[c].y);
-                float v2 = fmaf(acc[c][t][2], sc4[c].z, sh4[c].z), v3 = fmaf(acc[c][t][3], sc4[c].w, sh4[c].w);
+                float4 sc = sc4[c], sh = sh4[c];
+                if constexpr (TN > 1) { sc = bn_lds[c * 8]; sh = bn_lds[c * 8 + 4]; }
+                float v0 = fmaf(acc[c][t][0], sc.x, sh.x), v1 = fmaf(acc[c][t][1], sc.y, sh.y);
+                float v2 = fmaf(acc[c][t][2], sc.z, sh.z), v3 = fmaf(acc[c][t][3], sc.w, sh.w);
                 if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                 uint2 pk;
                 pk.x = (uint32_t)Op16<OT>::from_f32(v0) | ((uint32_t)Op16<OT>::from_f32(v1) << 16);
@@ -202,7 +213,7 @@ extern "C" int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const f
 // A workgroup owns 256 output channels (two column tiles per wave).
 extern "C" int dh_conv1x1_dual_wreg_supported(long long M, int C1, int C2, int Cout) {
     const int K = C1 + C2, nb = Cout / 256;
-    return (K == 128 || K == 384) && (C1 % 64) == 0 && (C2 % 64) == 0 && (Cout % 256) == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8) &&
+    return (K == 128 || K == 384 || K == 768) && (C1 % 64) == 0 && (C2 % 64) == 0 && (Cout % 256) == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8) &&
            M >= 8192 && M * 4096 < (1ll << 32);
 }
 
@@ -223,7 +234,7 @@ extern "C" int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const voi
     p.x2 = (const uint16_t*)x; p.howo = Ho * Wo; p.wo = Wo; p.h2w2 = H * W; p.w2 = W; p.stride2 = stride; p.c2 = C2;
     p.magic_howo = (unsigned)((1ull << 32) / (unsigned)p.howo + 1); p.magic_wo = (unsigned)((1ull << 32) / (unsigned)Wo + 1);
     const int K = C1 + C2;
-    p.nblk = dh_cdiv(M, K == 128 ? 128 : 64);
+    p.nblk = dh_cdiv(M, K == 128 ? 128 : K == 384 ? 64 : 32);
     dh_prof_set_tag("1x1");
     dh_prof_set_dims((int)M, Cout, K);
     DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * M * Cout * K,
@@ -231,6 +242,7 @@ extern "C" int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const voi
     hipStream_t s = (hipStream_t)stream;
     DH_DISPATCH_16(dtype, {
         if (K == 128) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 4, 128, 2, 8>), dim3(256), dim3(512), 0, s, p);
+        else if (K == 768) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 24, 32, 2, 8>), dim3(256), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 12, 64, 2, 8>), dim3(256), dim3(512), 0, s, p);
     });
     DH_LAUNCH_CHECK();

@@ -171,7 +171,7 @@ class ImageEncoder(_Planned, nn.Module):
                     if c3["w"].shape[-1] % 64 == 0 and dn["w"].shape[-1] % 64 == 0:
                         ent["dual"] = dict(w=w_cat.to(wdt).contiguous(), shift=(c3["shift"] + dn["shift"]).contiguous(),
                                            stride=dn["stride"])
-                        if w_cat.is_cuda and w_cat.shape[1] in (128, 384) and cout % 256 == 0:
+                        if w_cat.is_cuda and w_cat.shape[1] in (128, 384, 768) and cout % 256 == 0:
                             ent["dual"]["wpk"] = hip.pack_mfma_fragments(ent["dual"]["w"])
                 if (bf16 and ent["down"] is None and ent["c2"]["stride"] == 1 and ent["c2"]["w"].shape[1] == 3
                         and ent["c3"]["w"].shape[0] == 4 * ent["c2"]["w"].shape[0] and ent["c2"]["w"].shape[0] == ent["c2"]["w"].shape[3]

@@ -127,7 +127,7 @@ int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale
                          int Cout, int relu, int dtype, void* stream);
 
 /* The dual form (dh_conv1x1_dual_nhwc: relu(bn3(conv3(y)) + bn_d(downsample(x))) of a stage's first bottleneck, encoders.py:37-38 /
- * torchvision Bottleneck.forward with `downsample`) in the same streaming structure, for the HBM-bound instances C1 + C2 = 128 or 384,
+ * torchvision Bottleneck.forward with `downsample`) in the same streaming structure, for the instances C1 + C2 = 128, 384 or 768,
  * Cout a multiple of 256 (_supported).  w_packed = dh_pack_mfma_fragments(w [Cout, C1 + C2]).  Bit-identical to dh_conv1x1_dual_nhwc. */
 int dh_conv1x1_dual_wreg_supported(long long M, int C1, int C2, int Cout);
 int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const void* w_packed, const float* shift, void* out, int N, int Ho, int Wo,
