@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 18
+ABI_VERSION = 19
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -70,6 +70,8 @@ SIGNATURES = {
     "dh_conv3x3_direct_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_s3_supported": [_I, _I, _I],
+    "dh_conv3x3_s4_supported": [_I, _I, _I],
+    "dh_conv3x3_s4_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_s3_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_pack_mfma_fragments": [_P, _P, _I, _I, _P],
     "dh_conv1x1_wreg_supported": [_c.c_longlong, _I, _I],
@@ -568,6 +570,20 @@ def pack_mfma_fragments(w):
     out = torch.empty((r * k,), dtype=w.dtype, device=w.device)
     _launch("dh_pack_mfma_fragments", _ptr(w), _ptr(out), r, k, _stream())
     return out
+
+
+def conv3x3_s4_supported(h, w, c):
+    return bool(load().dh_conv3x3_s4_supported(int(h), int(w), int(c)))
+
+
+def conv3x3_s4_nhwc(x, w_packed, scale, shift):
+    """``dh_conv3x3_s4_nhwc``: 3x3 stride-1 convolution + BatchNorm + ReLU of ``x [N, 7, 7, 512]`` on fragment-packed weights
+    (``pack_mfma_fragments(w [512, 3, 3, 512])``); bit-identical to ``conv2d_nhwc_bn_act``."""
+    _dev(x, w_packed, scale, shift)
+    n, h, w, c = x.shape
+    y = torch.empty_like(x)
+    _launch("dh_conv3x3_s4_nhwc", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(y), n, h, w, c, _dt(x), _stream())
+    return y
 
 
 def conv1x1_wreg_supported(m, cin, cout):

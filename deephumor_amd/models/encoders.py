@@ -179,6 +179,11 @@ class ImageEncoder(_Planned, nn.Module):
                     # stage-3 blocks: the fused tail streams the weights from L2 into registers in MFMA fragment order
                     ent["w2p"] = hip.pack_mfma_fragments(ent["c2"]["w"])
                     ent["w3p"] = hip.pack_mfma_fragments(ent["c3"]["w"].reshape(ent["c3"]["w"].shape[0], -1).contiguous())
+                c2w = ent["c2"]["w"]
+                if (bf16 and c2w.is_cuda and ent["c2"]["stride"] == 1 and ent["c2"]["pad"] == 1 and tuple(c2w.shape[1:3]) == (3, 3)
+                        and hip.conv3x3_s4_supported(7, 7, c2w.shape[0]) and c2w.shape[3] == c2w.shape[0]):
+                    # stage-4 conv2 (stride 1): two images x half of the channels per workgroup, weights register-streamed (conv_s4.hip)
+                    ent["c2"]["wpk4"] = hip.pack_mfma_fragments(c2w)
                 blocks.append(ent)
         s, b = _bn_affine(self.bn)
         return dict(stem=stem, blocks=blocks, bn_scale=s, bn_shift=b, bf16=bf16, dtype=wdt,
@@ -190,6 +195,9 @@ class ImageEncoder(_Planned, nn.Module):
                 and not os.environ.get("DH_NO_CONV1X1_WREG")):
             # conv1 of the K >= 512 bottlenecks: weights stationary in registers, pixels streamed (csrc/conv1x1_wreg.hip; bit-identical)
             return hip.conv1x1_wreg_nhwc(x, c["wpk1"], c["w"].shape[0], c["scale"], c["shift"], relu=c["relu"])
+        if (nhwc and residual is None and "wpk4" in c and c["relu"] and hip.conv3x3_s4_supported(x.shape[1], x.shape[2], x.shape[3])
+                and not os.environ.get("DH_NO_CONV_S4")):
+            return hip.conv3x3_s4_nhwc(x, c["wpk4"], c["scale"], c["shift"])
         if (nhwc and residual is None and c["relu"] and c["stride"] == 1 and c["pad"] == 1 and c["w"].shape[1] == 3
                 and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], x.shape[3], c["w"].shape[0])
                 and not os.environ.get("DH_NO_DIRECT_3X3")):

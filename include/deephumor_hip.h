@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 18
+#define DH_ABI_VERSION 19
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -113,6 +113,14 @@ int dh_bottleneck_tail_s3_supported(int H, int W, int C);
 int dh_bottleneck_tail_s3_nhwc(const void* y1, const void* w2_packed, const float* scale2, const float* shift2,
                                const void* w3_packed, const float* scale3, const float* shift3, const void* residual,
                                void* out, int N, int H, int W, int C, int dtype, void* stream);
+
+/* conv2 (3x3, stride 1) + bn2 + relu of the STAGE-4 bottlenecks without downsample (7 x 7 x 512; torchvision Bottleneck.conv2 / bn2 /
+ * relu of layer4.1-2, encoders.py:37-38): a workgroup = (two images, half of the output channels), pixels resident in LDS without a
+ * halo, weights from L2 into registers in fragment order (csrc/conv_s4.hip).  w_packed = dh_pack_mfma_fragments(w [512][3*3*512]).
+ * Bit-identical to dh_conv2d_nhwc_bn_act (KS 3, stride 1, pad 1, relu). */
+int dh_conv3x3_s4_supported(int H, int W, int C);
+int dh_conv3x3_s4_nhwc(const void* x, const void* w_packed, const float* scale, const float* shift, void* y, int N, int H, int W, int C,
+                       int dtype, void* stream);
 
 /* 16-bit weight matrix w [R][K] row-major -> MFMA operand fragments: out[((k / 32) * (R / 16) + r / 16) * 64 + lane] (16 bytes) = the 8
  * values k = 32 s + 8 (lane >> 4) .. + 7 of row 16 rt + (lane & 15); R % 16 == 0, K % 32 == 0; out has R * K elements. */

@@ -804,3 +804,18 @@ def test_conv1x1_dual_wreg_equals_tile_gemm(hip, n, ho, c1, c2, cout, stride):
     got = hip.conv1x1_dual_wreg_nhwc(y, x, hip.pack_mfma_fragments(w), cout, shift, stride, relu=True)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
     assert not hip.conv1x1_dual_wreg_supported(n * ho * ho, 512, 512, cout) and not hip.conv1x1_dual_wreg_supported(4096, c1, c2, cout)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 64])
+def test_conv3x3_s4_equals_tile_gemm(hip, n):
+    """dh_conv3x3_s4_nhwc (stage-4 conv2: two images x half of the channels per workgroup, halo-free patch in LDS, weights from L2 into
+    registers) against the implicit-GEMM tile kernel on the same operands, bit for bit -- odd image counts (a one-image last pair),
+    image counts that leave XCD slots without a pair."""
+    g = torch.Generator().manual_seed(40 + n)
+    x = bf(torch.randn(n, 7, 7, 512, generator=g)).cuda()
+    w = bf(torch.randn(512, 3, 3, 512, generator=g) / 4608 ** 0.5).cuda()
+    scale, shift = (torch.rand(512, generator=g) + 0.5).cuda(), (torch.randn(512, generator=g) * 0.3).cuda()
+    assert hip.conv3x3_s4_supported(7, 7, 512) and not hip.conv3x3_s4_supported(14, 14, 512) and not hip.conv3x3_s4_supported(7, 7, 256)
+    want = hip.conv2d_nhwc_bn_act(x, w, scale, shift, relu=True, stride=1, pad=1)
+    got = hip.conv3x3_s4_nhwc(x, hip.pack_mfma_fragments(w), scale, shift)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
