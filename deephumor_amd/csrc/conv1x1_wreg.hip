@@ -211,10 +211,13 @@ extern "C" int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const f
 // operand [y | x at the strided pixels] with the BatchNorm scales folded into the weights (dh_conv1x1_dual_nhwc, gemm_bf16.hip), for the
 // two HBM-bound instances: stage 1 (C1 = C2 = 64, Cout = 256: 616 MB per 256 images) and stage 2 (C1 = 128, C2 = 256, Cout = 512).
 // A workgroup owns 256 output channels (two column tiles per wave).
-extern "C" int dh_conv1x1_dual_wreg_supported(long long M, int C1, int C2, int Cout) {
+extern "C" int dh_conv1x1_dual_wreg_supported(int N, int Ho, int Wo, int H, int W, int C1, int C2, int Cout) {
     const int K = C1 + C2, nb = Cout / 256;
-    return (K == 128 || K == 384 || K == 768) && (C1 % 64) == 0 && (C2 % 64) == 0 && (Cout % 256) == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8) &&
-           M >= 8192 && M * 4096 < (1ll << 32);
+    const long long M = (long long)N * Ho * Wo;
+    // the pixel map divides by Ho Wo and Wo with 32-bit magic numbers (exact while M Ho Wo < 2^32); byte offsets are 32-bit
+    return N > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0 && (K == 128 || K == 384 || K == 768) && (C1 % 64) == 0 && (C2 % 64) == 0 &&
+           (Cout % 256) == 0 && (nb == 1 || nb == 2 || nb == 4 || nb == 8) && M >= 8192 && M * Ho * Wo < (1ll << 32) &&
+           M * C1 * 2 < (1ll << 32) && (long long)N * H * W * C2 * 2 < (1ll << 32);
 }
 
 // out [N, Ho, Wo, Cout] = relu?([y | x at (oy * stride, ox * stride)] w^T + shift); w_packed = dh_pack_mfma_fragments(w [Cout, C1 + C2]).
@@ -224,8 +227,8 @@ extern "C" int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const voi
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     const long long M = (long long)N * Ho * Wo;
     DH_REQUIRE(y && x && w_packed && shift && out && N > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0 && stride >= 1 &&
-               dh_conv1x1_dual_wreg_supported(M, C1, C2, Cout));
-    DH_REQUIRE((Ho - 1) * stride < H && (Wo - 1) * stride < W && (long long)Ho * Wo <= 4096 && (long long)N * H * W * C2 * 2 < (1ll << 32));
+               dh_conv1x1_dual_wreg_supported(N, Ho, Wo, H, W, C1, C2, Cout));
+    DH_REQUIRE((Ho - 1) * stride < H && (Wo - 1) * stride < W);
     DH_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                ((uintptr_t)shift % 16) == 0);
     C1Params p{};

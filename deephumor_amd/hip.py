@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 19
+ABI_VERSION = 20
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -78,7 +78,7 @@ SIGNATURES = {
     "dh_conv1x1_wreg_nhwc": [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P],
     "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
-    "dh_conv1x1_dual_wreg_supported": [_c.c_longlong, _I, _I, _I],
+    "dh_conv1x1_dual_wreg_supported": [_I] * 8,
     "dh_conv1x1_dual_wreg_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_resize_u8_hwc": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
@@ -930,8 +930,11 @@ def conv1x1_dual_nhwc(y, x, w_cat, shift, stride, relu=True):
     return out
 
 
-def conv1x1_dual_wreg_supported(m, c1, c2, cout):
-    return bool(load().dh_conv1x1_dual_wreg_supported(int(m), int(c1), int(c2), int(cout)))
+def conv1x1_dual_wreg_supported(y_shape, x_shape, cout):
+    """Whether ``conv1x1_dual_wreg_nhwc`` takes ``y [N, Ho, Wo, C1]`` + ``x [N, H, W, C2]`` -> ``Cout`` channels."""
+    n, ho, wo, c1 = y_shape
+    _, h, w, c2 = x_shape
+    return bool(load().dh_conv1x1_dual_wreg_supported(int(n), int(ho), int(wo), int(h), int(w), int(c1), int(c2), int(cout)))
 
 
 def conv1x1_dual_wreg_nhwc(y, x, w_packed, cout, shift, stride, relu=True):

@@ -261,7 +261,7 @@ class ImageEncoder(_Planned, nn.Module):
             if blk["dual"] is not None:
                 d = blk["dual"]
                 if ("wpk" in d and not os.environ.get("DH_NO_CONV1X1_WREG")
-                        and hip.conv1x1_dual_wreg_supported(y.shape[0] * y.shape[1] * y.shape[2], y.shape[3], x.shape[3], d["w"].shape[0])):
+                        and hip.conv1x1_dual_wreg_supported(y.shape, x.shape, d["w"].shape[0])):
                     x = hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], d["w"].shape[0], d["shift"], d["stride"], relu=True)
                     continue
                 x = hip.conv1x1_dual_nhwc(y, x, d["w"], d["shift"], d["stride"], relu=True)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 19
+#define DH_ABI_VERSION 20
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -137,7 +137,7 @@ int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale
 /* The dual form (dh_conv1x1_dual_nhwc: relu(bn3(conv3(y)) + bn_d(downsample(x))) of a stage's first bottleneck, encoders.py:37-38 /
  * torchvision Bottleneck.forward with `downsample`) in the same streaming structure, for the instances C1 + C2 = 128, 384 or 768,
  * Cout a multiple of 256 (_supported).  w_packed = dh_pack_mfma_fragments(w [Cout, C1 + C2]).  Bit-identical to dh_conv1x1_dual_nhwc. */
-int dh_conv1x1_dual_wreg_supported(long long M, int C1, int C2, int Cout);
+int dh_conv1x1_dual_wreg_supported(int N, int Ho, int Wo, int H, int W, int C1, int C2, int Cout);
 int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const void* w_packed, const float* shift, void* out, int N, int Ho, int Wo,
                               int C1, int H, int W, int C2, int stride, int Cout, int relu, int dtype, void* stream);
 

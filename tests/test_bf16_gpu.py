@@ -788,7 +788,7 @@ def test_conv1x1_wreg_equals_tile_gemm(hip, n, hw, cin, cout, relu):
 
 
 @pytest.mark.parametrize("n,ho,c1,c2,cout,stride", [(3, 56, 64, 64, 256, 1), (13, 28, 128, 256, 512, 2), (5, 57, 64, 64, 512, 1),
-                                                    (21, 27, 128, 256, 256, 2), (12, 28, 64, 320, 1024, 2), (47, 14, 256, 512, 1024, 2), (50, 13, 256, 512, 256, 2)])
+                                                    (21, 27, 128, 256, 256, 2), (12, 28, 64, 320, 1024, 2), (47, 14, 256, 512, 1024, 2), (50, 13, 256, 512, 256, 2), (2, 83, 64, 64, 256, 1)])
 def test_conv1x1_dual_wreg_equals_tile_gemm(hip, n, ho, c1, c2, cout, stride):
     """dh_conv1x1_dual_wreg_nhwc (conv3 + strided downsample of a stage's first bottleneck as one streamed GEMM over [y | x at the strided
     pixels], weights stationary in registers) against dh_conv1x1_dual_nhwc on the same operands, bit for bit: both strides, odd input
@@ -799,11 +799,11 @@ def test_conv1x1_dual_wreg_equals_tile_gemm(hip, n, ho, c1, c2, cout, stride):
     x = bf(torch.randn(n, h, h, c2, generator=g)).cuda()
     w = bf(torch.randn(cout, c1 + c2, generator=g) / (c1 + c2) ** 0.5).cuda()
     shift = (torch.randn(cout, generator=g) * 0.3).cuda()
-    assert hip.conv1x1_dual_wreg_supported(n * ho * ho, c1, c2, cout)
+    assert hip.conv1x1_dual_wreg_supported(y.shape, x.shape, cout)
     want = hip.conv1x1_dual_nhwc(y, x, w, shift, stride, relu=True)
     got = hip.conv1x1_dual_wreg_nhwc(y, x, hip.pack_mfma_fragments(w), cout, shift, stride, relu=True)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
-    assert not hip.conv1x1_dual_wreg_supported(n * ho * ho, 512, 512, cout) and not hip.conv1x1_dual_wreg_supported(4096, c1, c2, cout)
+    assert not hip.conv1x1_dual_wreg_supported((n, ho, ho, 512), (n, h, h, 512), cout) and not hip.conv1x1_dual_wreg_supported((1, 64, 64, c1), (1, 64, 64, c2), cout)
 
 
 @pytest.mark.parametrize("n", [1, 2, 7, 64])
