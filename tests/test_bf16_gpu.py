@@ -457,7 +457,7 @@ def test_stem_conv_with_fused_maxpool(hip, n, h, w):
     np.testing.assert_allclose(fused.float().cpu().permute(0, 3, 1, 2).numpy(), want.numpy(), atol=4e-2, rtol=2e-2)
 
 
-@pytest.mark.parametrize("n,h,w,c", [(2, 56, 56, 64), (3, 8, 56, 64), (2, 28, 28, 128), (5, 4, 28, 128)])
+@pytest.mark.parametrize("n,h,w,c", [(2, 56, 56, 64), (3, 8, 56, 64), (2, 28, 28, 128), (5, 4, 28, 128), (1, 4, 28, 128), (3, 28, 28, 128)])
 def test_direct_conv3x3(hip, n, h, w, c):
     """dh_conv3x3_direct_nhwc (patch-resident direct convolution, stages 1-2 of the ResNet) against the implicit-GEMM
     dh_conv2d_nhwc_bn_act and against fp32 F.conv2d on the same 16-bit operands."""
@@ -505,7 +505,7 @@ def test_fused_beam_step_equals_two_launches(hip, n_img, beam, top_k, v, src_len
     assert int(a.err.item()) == 0 and bool(a.has_ended.any())
 
 
-@pytest.mark.parametrize("n,h,w,c", [(2, 56, 56, 64), (3, 8, 56, 64), (2, 28, 28, 128), (5, 4, 28, 128)])
+@pytest.mark.parametrize("n,h,w,c", [(2, 56, 56, 64), (3, 8, 56, 64), (2, 28, 28, 128), (5, 4, 28, 128), (1, 4, 28, 128), (3, 28, 28, 128)])
 def test_fused_bottleneck_tail(hip, n, h, w, c):
     """dh_bottleneck_tail_nhwc (3x3 conv2 + 1x1 conv3 + residual in one launch, the conv2 tile resident in LDS) against the
     two-launch route, bit for bit, and against fp32 math."""
