@@ -106,6 +106,64 @@ def direct_trial(rng, idx):
     return rec
 
 
+def wreg_trial(rng, idx):
+    """The round-4 streaming / patch-resident kernels against the tile GEMM on random shapes, bit for bit, with canaries around the
+    outputs: dh_conv1x1_wreg_nhwc, dh_conv1x1_dual_wreg_nhwc (both strides, odd input grids), dh_conv3x3_s4_nhwc (odd image counts)."""
+    g = torch.Generator().manual_seed(70000 + idx)
+    dt = rng.choice([torch.bfloat16, torch.float16])
+    which = rng.choice(["c1", "c1", "dual", "dual", "s4"])
+    rec = dict(kind="wreg", which=which, dt=str(dt)[6:])
+    if which == "c1":
+        cin, cout = rng.choice([256, 512, 1024]), 128 * rng.choice([1, 2, 4, 8, 16])
+        n, hw = rng.randint(1, 24), rng.choice([7, 14, 28, 31, 56])
+        while n * hw * hw < 8192:
+            n += 1
+        relu = rng.random() < 0.7
+        x = torch.randn(n, hw, hw, cin, generator=g).to(dt).cuda()
+        w = (torch.randn(cout, 1, 1, cin, generator=g) / cin ** 0.5).to(dt).cuda()
+        scale, shift = (torch.rand(cout, generator=g) + 0.5).cuda(), torch.randn(cout, generator=g).cuda()
+        rec.update(N=n, HW=hw, Cin=cin, Cout=cout, relu=relu)
+        if not hip.conv1x1_wreg_supported(n * hw * hw, cin, cout):
+            return dict(rec, ok=True, skipped=True)
+        ref = hip.conv2d_nhwc_bn_act(x, w, scale, shift, relu=relu)
+        out, check = guarded((n, hw, hw, cout), dt)
+        hip._launch("dh_conv1x1_wreg_nhwc", hip._ptr(x), hip._ptr(hip.pack_mfma_fragments(w.view(cout, cin))), hip._ptr(scale), hip._ptr(shift),
+                    hip._ptr(out), n * hw * hw, cin, cout, int(relu), hip._dt(x), hip._stream())
+    elif which == "dual":
+        c1, c2 = rng.choice([(64, 64), (128, 256), (256, 512), (64, 320), (192, 192)])
+        cout, stride = 256 * rng.choice([1, 2, 4]), rng.choice([1, 2])
+        ho = rng.choice([14, 27, 28, 56, 61])
+        n = rng.randint(1, 12)
+        while n * ho * ho < 8192:
+            n += 1
+        h = (ho - 1) * stride + 1 + rng.randint(0, 1)
+        y = torch.randn(n, ho, ho, c1, generator=g).to(dt).cuda()
+        x = torch.randn(n, h, h, c2, generator=g).to(dt).cuda()
+        w = (torch.randn(cout, c1 + c2, generator=g) / (c1 + c2) ** 0.5).to(dt).cuda()
+        shift = torch.randn(cout, generator=g).cuda()
+        rec.update(N=n, Ho=ho, H=h, C1=c1, C2=c2, Cout=cout, stride=stride)
+        if not hip.conv1x1_dual_wreg_supported(y.shape, x.shape, cout):
+            return dict(rec, ok=True, skipped=True)
+        ref = hip.conv1x1_dual_nhwc(y, x, w, shift, stride, relu=True)
+        out, check = guarded((n, ho, ho, cout), dt)
+        hip._launch("dh_conv1x1_dual_wreg_nhwc", hip._ptr(y), hip._ptr(x), hip._ptr(hip.pack_mfma_fragments(w)), hip._ptr(shift), hip._ptr(out),
+                    n, ho, ho, c1, h, h, c2, stride, cout, 1, hip._dt(y), hip._stream())
+    else:
+        n = rng.choice([1, 2, 3, rng.randint(4, 70)])
+        x = torch.randn(n, 7, 7, 512, generator=g).to(dt).cuda()
+        w = (torch.randn(512, 3, 3, 512, generator=g) / 4608 ** 0.5).to(dt).cuda()
+        scale, shift = (torch.rand(512, generator=g) + 0.5).cuda(), torch.randn(512, generator=g).cuda()
+        rec.update(N=n)
+        ref = hip.conv2d_nhwc_bn_act(x, w, scale, shift, relu=True, stride=1, pad=1)
+        out, check = guarded((n, 7, 7, 512), dt)
+        hip._launch("dh_conv3x3_s4_nhwc", hip._ptr(x), hip._ptr(hip.pack_mfma_fragments(w)), hip._ptr(scale), hip._ptr(shift), hip._ptr(out),
+                    n, 7, 7, 512, hip._dt(x), hip._stream())
+    torch.cuda.synchronize()
+    eq = bool(torch.equal(out, ref))
+    rec.update(bit_equal=eq, canary_ok=check(), ok=bool(eq and check()))
+    return rec
+
+
 def stem_trial(rng, idx):
     g = torch.Generator().manual_seed(60000 + idx)
     dt = rng.choice([torch.bfloat16, torch.float16])
@@ -167,10 +225,10 @@ def main(argv=None):
     torch.backends.cudnn.allow_tf32 = False
     bad = 0
     for i in range(args.trials):
-        for fn in (nhwc_trial, direct_trial, stem_trial, fp32_trial):
+        for fn in (nhwc_trial, direct_trial, wreg_trial, stem_trial, fp32_trial):
             if args.only and args.only not in fn.__name__:
                 continue
-            if fn in (direct_trial, stem_trial) and i % 3:
+            if (fn in (direct_trial, stem_trial) and i % 3) or (fn is wreg_trial and i % 2):
                 continue
             rng = random.Random(args.seed * 100003 + i)
             try:
