@@ -62,6 +62,45 @@ def replay(fn, seed):
         beam_mod.BeamSearchHelper.__init__ = orig
 
 
+class _NearTies:
+    """While the CPU oracle runs: the smallest RELATIVE gap between neighbours of every ordering decision it takes -- the top-(k + 1)
+    logits of ``torch.topk`` and the top-(k + 1) ratios prob / Exp(1) of ``torch.multinomial`` without replacement (how torch's CPU
+    kernel draws; replayed from a saved generator state, which is then restored, and checked against the real result).  fp32 sums in
+    another order move such values by ~1e-6 relative: a caption that differs where the reference itself decided by less than that is
+    not comparable (both orders are results of the same algorithm)."""
+    def __init__(self):
+        self.min_gap, self.replica_ok = float("inf"), True
+
+    def __enter__(self):
+        self.mn, self.tk = torch.multinomial, torch.topk
+
+        def mn(probs, k, replacement=False, **kw):
+            st = torch.get_rng_state()
+            out = self.mn(probs, k, replacement, **kw)
+            if not probs.is_cuda and not replacement and probs.shape[-1] > k:
+                after = torch.get_rng_state()
+                torch.set_rng_state(st)
+                ratio = probs / torch.empty_like(probs).exponential_(1)
+                srt, idx = ratio.sort(dim=-1, descending=True)
+                self.replica_ok = self.replica_ok and bool(torch.equal(idx[..., :k], out))
+                top = srt[..., :k + 1].double()
+                self.min_gap = min(self.min_gap, float(((top[..., :-1] - top[..., 1:]) / top[..., :-1].clamp_min(1e-300)).min()))
+                torch.set_rng_state(after)
+            return out
+
+        def tk(x, k, *a, **kw):
+            out = self.tk(x, k, *a, **kw)
+            if not x.is_cuda and x.shape[-1] > k and x.is_floating_point():
+                srt = x.sort(dim=-1, descending=True)[0][..., :k + 1].double()
+                self.min_gap = min(self.min_gap, float(((srt[..., :-1] - srt[..., 1:]).abs() / srt[..., :-1].abs().clamp_min(1e-30)).min()))
+            return out
+        torch.multinomial, torch.topk = mn, tk
+        return self
+
+    def __exit__(self, *exc):
+        torch.multinomial, torch.topk = self.mn, self.tk
+
+
 def one_trial(rng, idx):
     kind = rng.choice(["lstm", "tfm", "tfm_self"])
     v = rng.choice([rng.randint(5, 70), rng.randint(71, 700), rng.randint(701, 4000)])
@@ -118,7 +157,7 @@ def one_trial(rng, idx):
     if kind == "lstm":
         emb = torch.randn(1, 1, cfg["emb"], generator=g)
         torch.manual_seed(seed)
-        with torch.no_grad():
+        with torch.no_grad(), _NearTies() as ties:
             want = R.lstm_decoder_generate(osd, "decoder", emb, **kw).reshape(-1).tolist()
         capd = cap.cuda() if cap is not None else None
         got = replay(lambda ns: dec.generate(emb.cuda(), **dict(kw, caption=capd), **({'rng': 'torch'} if ns is None else {'noise_source': ns})), seed)
@@ -128,7 +167,7 @@ def one_trial(rng, idx):
         enc = torch.randn(1, s_len, cfg["hid"], generator=g) if kind == "tfm" else None
         cfg["enc_len"] = s_len if enc is not None else 0
         torch.manual_seed(seed)
-        with torch.no_grad():
+        with torch.no_grad(), _NearTies() as ties:
             want = R.transformer_generate(osd, "decoder", start, enc, pad_index, cfg["heads"], **kw).reshape(-1).tolist()
         capd = cap.cuda() if cap is not None else None
         if kind == "tfm":
@@ -136,6 +175,7 @@ def one_trial(rng, idx):
         else:
             got = replay(lambda ns: dec.generate(start.cuda(), **dict(kw, caption=capd), **({'rng': 'torch'} if ns is None else {'noise_source': ns})), seed)
     cfg["undefined_candidate_draws"] = UNDEFINED_DRAWS[0]
+    cfg["oracle_min_rel_gap"] = ties.min_gap if ties.replica_ok else None
     if HALF:
         # the 16-bit paths on the same configuration: they must run, repeat exactly under the same Philox seed, and emit valid ids
         # (in range, never <unk>, nothing but <pad> after the reported length)
@@ -155,6 +195,7 @@ def one_trial(rng, idx):
     return cfg, want, got
 
 
+NEAR_TIE = 1e-6           # relative; fp32 softmax / cumulative-probability sums in a different order differ by up to about 1e-6
 HALF = False
 LONG = False
 R4 = False
@@ -171,7 +212,7 @@ def main(argv=None):
     args = ap.parse_args(argv)
     global HALF, LONG, R4
     HALF, LONG, R4 = args.half, args.long, args.r4
-    bad = 0
+    bad = near = 0
     for i in range(args.first, args.first + args.trials):
         rng = random.Random(args.seed * 100003 + i)
         try:
@@ -195,13 +236,17 @@ def main(argv=None):
             e = want.index(3)
             if want[:e + 1] == got[:e + 1] and not any(want[e + 1:]) and not any(got[e + 1:]):
                 ok, cfg["known"] = True, "trailing <pad> count differs (underflowed candidate probabilities)"
+        if not ok and cfg.get("oracle_min_rel_gap") is not None and cfg["oracle_min_rel_gap"] < NEAR_TIE:
+            ok, cfg["known"] = True, (f"fp32 near-tie: the reference itself ordered two candidates by a relative gap of "
+                                      f"{cfg['oracle_min_rel_gap']:.1e} (< {NEAR_TIE:.0e}); fp32 sums in another order decide it the other way")
+        near += str(cfg.get("known", "")).startswith("fp32 near-tie")
         ok = ok and all(v for k, v in cfg.items() if k.startswith("ok_"))
         bad += (not ok)
         rec = {"i": i, "ok": ok, **cfg}
         if not ok:
             rec.update(want=want, got=got)
         print(json.dumps(rec), flush=True)
-    print(json.dumps({"trials": args.trials, "mismatches_or_errors": bad}), flush=True)
+    print(json.dumps({"trials": args.trials, "mismatches_or_errors": bad, "fp32_near_ties_not_comparable": near}), flush=True)
     return 0
 
 
