@@ -22,6 +22,16 @@ static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const
     return dh_attn_cross_decode(q, m->D, L.kv, m->keymask, att, n_img, rows_per_img, m->S, m->D, m->n_heads, L.ea_scale, dt, stream);
 }
 
+// The classifier of a beam-search step with group maxima: the register-streamed kernel (csrc/vocab_wreg.hip; bit-identical) when the model
+// carries its operands and it takes the shape, else dh_vocab_logits.  DH_VOCAB_WREG=0 switches it off (A/B runs).
+static int classifier_groups(const void* A, int lda, const void* W, const float* bias, const void* W_pk, const float* bias_pad, float* logits,
+                             int ldl, float* group_max, int gm_ld, int rows, int V, int K, int dt, void* stream) {
+    static const int use_wreg = getenv("DH_VOCAB_WREG") ? atoi(getenv("DH_VOCAB_WREG")) : 1;
+    if (use_wreg && W_pk && bias_pad && logits && dh_vocab_logits_wreg_supported(rows, V, K, ldl, gm_ld))
+        return dh_vocab_logits_wreg(A, lda, W_pk, bias_pad, logits, ldl, group_max, gm_ld, rows, V, K, dt, stream);
+    return dh_vocab_logits(A, lda, W, K, bias, logits, ldl, group_max, gm_ld, rows, V, K, dt, stream);
+}
+
 // One GEMM of the deferred-LayerNorm chain: the register-stationary kernel (csrc/linear_wreg.hip; bit-identical results) when the
 // layer carries fragment-packed weights, the position has enough rows to fill the chip and the shape is one it takes; else the
 // tile kernels.  DH_DECODE_WREG=0 switches it off (A/B runs), DH_DECODE_WREG_MIN_ROWS moves the threshold.
@@ -126,7 +136,7 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
         void* xf = x_out ? x_out : sc->att;          // the final LayerNorm's output feeds the classifier (att is free by then)
         DH_TRY(decode_position_deferred(m, sc, tokens, tok_ld, src, src_ld, n_img, rows_per_img, row_mult, rows_total, t, xf, stream));
         if (logits && group_max) {
-            DH_TRY(dh_vocab_logits(xf, D, m->cls_w, D, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, D, dt, stream));
+            DH_TRY(classifier_groups(xf, D, m->cls_w, m->cls_b, m->cls_w_pk, m->cls_b_pad, logits, ldl, group_max, gm_ld, rows, m->V, D, dt, stream));
         } else if (logits) {
             dh_prof_set_tag("vocab");
             DH_TRY(dh_linear(xf, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, D, 0,
@@ -160,8 +170,8 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
     }
     (void)esz;
     if (logits && group_max && DH_IS_16BIT(dt)) {
-        DH_TRY(dh_vocab_logits(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, D,
-                               dt, stream));
+        DH_TRY(classifier_groups(x_out ? x_out : sc->x, D, m->cls_w, m->cls_b, m->cls_w_pk, m->cls_b_pad, logits, ldl, group_max, gm_ld, rows,
+                                 m->V, D, dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
         DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows,
@@ -209,7 +219,7 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
                                        l == 0 ? E : Hh, Hh, dt, stream));
         }
         if (logits && group_max) {
-            DH_TRY(dh_vocab_logits(top, top_ld, m->cls_w, Hh, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
+            DH_TRY(classifier_groups(top, top_ld, m->cls_w, m->cls_b, m->cls_w_pk, m->cls_b_pad, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
         } else if (logits) {
             dh_prof_set_tag("vocab");
             DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,
@@ -235,7 +245,7 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
                             m->c + (size_t)l * rows_total * Hh, dst, ld, rows, row_mult, Hh, dt, stream));
     }
     if (logits && group_max && DH_IS_16BIT(dt)) {
-        DH_TRY(dh_vocab_logits(top, top_ld, m->cls_w, Hh, m->cls_b, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
+        DH_TRY(classifier_groups(top, top_ld, m->cls_w, m->cls_b, m->cls_w_pk, m->cls_b_pad, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
         DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,

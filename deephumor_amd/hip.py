@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 20
+ABI_VERSION = 21
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -33,7 +33,7 @@ class TrLayer(_c.Structure):
 class TrModel(_c.Structure):
     _fields_ = ([(n, _I) for n in ("n_layers", "D", "n_heads", "pf_dim", "V", "pad_index", "cross", "S", "dtype")]
                 + [("emb_scale", _F), ("layers", _c.POINTER(TrLayer))]
-                + [(n, _P) for n in ("tok_emb", "pos_emb", "cls_w", "cls_b", "keymask")])
+                + [(n, _P) for n in ("tok_emb", "pos_emb", "cls_w", "cls_b", "keymask", "cls_w_pk", "cls_b_pad")])
 
 
 class TrScratch(_c.Structure):
@@ -52,7 +52,7 @@ class LstmLayer(_c.Structure):
 
 class LstmModel(_c.Structure):
     _fields_ = ([(n, _I) for n in ("n_layers", "E", "Hh", "V", "dtype", "_pad")] + [("layers", _c.POINTER(LstmLayer))]
-                + [(n, _P) for n in ("emb", "cls_w", "cls_b", "h", "c", "h_alt", "c_alt")])
+                + [(n, _P) for n in ("emb", "cls_w", "cls_b", "h", "c", "h_alt", "c_alt", "cls_w_pk", "cls_b_pad")])
 
 
 class LstmScratch(_c.Structure):
@@ -128,6 +128,8 @@ SIGNATURES = {
                             _I, _P, _I, _P, _I, _P],
     "dh_vocab_logprob": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "dh_vocab_logits_wreg_supported": [_I] * 5,
+    "dh_vocab_logits_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_beam_step_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P,
                             _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
@@ -812,6 +814,28 @@ def vocab_logits(a, w, bias, logits, group_max):
     _launch("dh_vocab_logits", _ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(logits),
             logits.stride(0) if logits is not None else 0,
             _ptr(group_max), group_max.stride(0), m, v, k, _dt(a), _stream())
+
+
+def pack_vocab_weights(w, bias):
+    """Classifier weights ``[V, 512]`` (16-bit) and bias -> (fragment-packed weights padded to whole 256-column chunks with copies of
+    row V - 1, fp32 bias padded likewise): the operands of ``vocab_logits_wreg``; made once per weight version."""
+    _dev(w, bias)
+    v = w.shape[0]
+    vpad = (v + 255) // 256 * 256
+    idx = torch.clamp(torch.arange(vpad, device=w.device), max=v - 1)
+    return pack_mfma_fragments(w.index_select(0, idx).contiguous()), (bias.float().index_select(0, idx).contiguous() if bias is not None else None)
+
+
+def vocab_logits_wreg_supported(m, v, k, ldl, gm_ld):
+    return bool(load().dh_vocab_logits_wreg_supported(int(m), int(v), int(k), int(ldl), int(gm_ld)))
+
+
+def vocab_logits_wreg(a, w_packed, bias_padded, v, logits, group_max):
+    """``vocab_logits`` on the operands of ``pack_vocab_weights`` (csrc/vocab_wreg.hip): same logits and group maxima, bit for bit."""
+    _dev(a, w_packed, bias_padded, logits, group_max)
+    m, k = a.shape
+    _launch("dh_vocab_logits_wreg", _ptr(a), a.stride(0), _ptr(w_packed), _ptr(bias_padded), _ptr(logits),
+            logits.stride(0) if logits is not None else 0, _ptr(group_max), group_max.stride(0), m, v, k, _dt(a), _stream())
 
 
 def vocab_logprob(a, w, bias, targets):

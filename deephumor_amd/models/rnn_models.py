@@ -8,6 +8,8 @@ SURVEY.md section 2b).  One time step of one layer is ONE launch on the bf16 pat
 state ping-pong); on the fp32 parity path ``dh_lstm_prepare`` (state/embedding gather incl. beam reorder) + per layer
 ``dh_linear`` ([x|h] gate GEMM) + ``dh_lstm_cell``.  Both are sequenced by the native ``dh_lstm_decode_step``.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -46,9 +48,13 @@ class LSTMDecoder(_Planned, nn.Module):
             else:
                 w_il = b_il = w_pk = None
             layers.append((w, b, w_il, b_il, w_pk))
-        return dict(layers=layers, emb=self.embedding.weight.detach(),
+        plan = dict(layers=layers, emb=self.embedding.weight.detach(),
                     cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach().float().contiguous(),
                     dtype=self.classifier.weight.dtype)
+        if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and plan["cls_w"].shape[1] == 512 and not os.environ.get("DH_NO_VOCAB_WREG"):
+            # the beam-search classifier with the weights streamed from L2 into registers (csrc/vocab_wreg.hip): padded, fragment-packed copy
+            plan["cls_w_pk"], plan["cls_b_pad"] = hip.pack_vocab_weights(plan["cls_w"], plan["cls_b"])
+        return plan
 
     def _check_mode(self):
         if self.training and self.lstm.dropout > 0:
@@ -79,6 +85,8 @@ class LSTMDecoder(_Planned, nn.Module):
             m.dtype = {torch.float32: hip.F32, torch.bfloat16: hip.BF16, torch.float16: hip.F16}[self.dtype]
             m.layers = self.c_layers
             m.emb, m.cls_w, m.cls_b = plan["emb"].data_ptr(), plan["cls_w"].data_ptr(), plan["cls_b"].data_ptr()
+            if "cls_w_pk" in plan:
+                m.cls_w_pk, m.cls_b_pad = plan["cls_w_pk"].data_ptr(), plan["cls_b_pad"].data_ptr()
             m.h, m.c = self.h.data_ptr(), self.c.data_ptr()
             if self.dtype in hip.HALF_DTYPES:     # fused step kernel: other workgroups still gather the old state rows
                 self.h_alt, self.c_alt = torch.empty_like(self.h), torch.empty_like(self.c)
@@ -175,8 +183,8 @@ class LSTMDecoder(_Planned, nn.Module):
                 helper.set_prefix(caption[lo:hi])
             st = self._State(self, plan, n, b, dev)
             # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
-            logits = torch.empty((r, (self.num_tokens + 127) // 128 * 128), device=dev)[:, :self.num_tokens]   # whole 128-column panels
-            gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
+            logits = torch.empty((r, (self.num_tokens + 255) // 256 * 256), device=dev)[:, :self.num_tokens]   # whole 256-column chunks (vocab_wreg)
+            gmax = (torch.empty((r, 4 * ((self.num_tokens + 255) // 256)), device=dev)[:, :hip.n_groups(self.num_tokens)]
                     if plan["dtype"] in hip.HALF_DTYPES else None)                   # column-group maxima (16-bit paths)
             gm = None if gmax is None else gmax[:n]
             # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam

@@ -215,9 +215,16 @@ class _IncrementalDecoder(_Planned, nn.Module):
                                                  ("wq_pk", "wq_f", hd, hd, False)):
                         if src in ent and hip.linear_ln_wreg_supported(n, k, lnx):
                             ent[name] = hip.pack_mfma_fragments(ent[src].contiguous())
-        return dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
+        plan = dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
                     scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=f(self.classifier.bias),
                     dtype=self.classifier.weight.dtype)
+        if (plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and os.environ.get("DH_VOCAB_WREG_TRANSFORMER")
+                and not os.environ.get("DH_NO_VOCAB_WREG")):
+            # opt-in here (the LSTM decoder uses it by default): csrc/vocab_wreg.hip wins where the 37 MB of weights are still in the
+            # Infinity Cache when the next position's classifier starts; a Transformer position moves ~1 GB of KV cache in between and
+            # the step takes the same time with either kernel (20.4-20.7 ms, three alternating runs)
+            plan["cls_w_pk"], plan["cls_b_pad"] = hip.pack_vocab_weights(plan["cls_w"], plan["cls_b"])
+        return plan
 
     def _check_mode(self):
         if self.training and self.dropout.p > 0:
@@ -293,6 +300,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
             m.layers = self.c_layers
             m.tok_emb, m.pos_emb, m.cls_w, m.cls_b = P(plan["tok"]), P(plan["pos"]), P(plan["cls_w"]), P(plan["cls_b"])
             m.keymask = P(self.keymask)
+            if "cls_w_pk" in plan:
+                m.cls_w_pk, m.cls_b_pad = P(plan["cls_w_pk"]), P(plan["cls_b_pad"])
 
         def scratch(self, rows):
             if rows not in self._scratch:
@@ -537,8 +546,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
             run = self._Run(self, plan, n, b, max_len + 1, None if enc_out is None else enc_out[lo:hi], dev)
             semb = start_emb[lo:hi]
             # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
-            logits = torch.empty((r, (self.num_tokens + 127) // 128 * 128), device=dev)[:, :self.num_tokens]   # whole 128-column panels
-            gmax = (torch.empty((r, hip.n_groups(self.num_tokens)), device=dev)
+            logits = torch.empty((r, (self.num_tokens + 255) // 256 * 256), device=dev)[:, :self.num_tokens]   # whole 256-column chunks (vocab_wreg)
+            gmax = (torch.empty((r, 4 * ((self.num_tokens + 255) // 256)), device=dev)[:, :hip.n_groups(self.num_tokens)]
                     if plan["dtype"] in hip.HALF_DTYPES else None)                   # column-group maxima (16-bit paths)
             gm = None if gmax is None else gmax[:n]
             # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`

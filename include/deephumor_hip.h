@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 20
+#define DH_ABI_VERSION 21
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -271,6 +271,15 @@ int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, const float*
  * it writes columns V .. 128 * ceil(V / 128) - 1 of every row too (finite values, never read); nothing outside [M, ldl] is touched. */
 int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float* bias, float* logits, int ldl,
                     float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream);
+
+/* dh_vocab_logits with the weights streamed from L2 into registers in MFMA fragment order and the activation rows resident in LDS
+ * (csrc/vocab_wreg.hip; the classifier of a beam-search step, rnn_models.py:45 / transformers.py:489 inside generate()).
+ * w_packed = dh_pack_mfma_fragments(W padded to Vpad = ceil(V / 256) * 256 rows with copies of row V - 1), bias_padded [Vpad] padded
+ * likewise (NULL: no bias).  _supported: K = 512, M = 80 x {1, 2, 4, 8, 16, 32}, ldl and gm_ld cover Vpad (ldl = 0: no logits).
+ * Bit-identical to dh_vocab_logits on the columns [0, Vpad) and on the group maxima. */
+int dh_vocab_logits_wreg_supported(int M, int V, int K, int ldl, int gm_ld);
+int dh_vocab_logits_wreg(const void* A, int lda, const void* w_packed, const float* bias_padded, float* logits, int ldl,
+                         float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row addressing shared by the decoder kernels.  A decode step works on `rows` compact rows
@@ -556,6 +565,7 @@ typedef struct dh_tr_model {
     const void *tok_emb, *pos_emb, *cls_w;
     const float* cls_b;
     const uint8_t* keymask;                                 /* [n_img*S] or NULL */
+    const void* cls_w_pk; const float* cls_b_pad;           /* optional: the operands of dh_vocab_logits_wreg (padded, fragment-packed classifier) */
 } dh_tr_model_t;
 
 typedef struct dh_tr_scratch {
@@ -587,6 +597,7 @@ typedef struct dh_lstm_model {
     void* h;                                                /* recurrent state [n_layers, rows_total, Hh], storage dtype */
     float* c;                                               /* cell state, fp32 */
     void* h_alt; float* c_alt;                              /* optional second state buffers (fused bf16 step: ping-pong) */
+    const void* cls_w_pk; const float* cls_b_pad;           /* optional: the operands of dh_vocab_logits_wreg */
 } dh_lstm_model_t;
 
 typedef struct dh_lstm_scratch { void *xcat0, *xcatl; float *c_cur, *gates; void* hout; } dh_lstm_scratch_t;

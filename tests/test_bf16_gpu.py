@@ -247,6 +247,40 @@ def test_vocab_logits_256_row_tiles(hip, rows, v):
     assert bool(torch.isnan(buf[rows]).all()) and bool(torch.isnan(gbuf[rows]).all()) and bool(torch.isnan(gbuf[:rows, ng:]).all())
 
 
+@pytest.mark.parametrize("rows,v,with_bias,with_logits", [(1280, 36541, True, True), (80, 300, True, True), (640, 8192, False, True),
+                                                           (320, 4100, True, False), (2560, 1000, True, True), (160, 36541, True, True)])
+def test_vocab_logits_wreg_equals_vocab_logits(hip, rows, v, with_bias, with_logits):
+    """dh_vocab_logits_wreg (weights from L2 into registers in fragment order, 80-row activation blocks resident in LDS, no barrier)
+    against dh_vocab_logits on the same operands, bit for bit: logits on every column of the padded row stride the old kernel
+    defines (copies of logit[V - 1] past V where both write), group maxima incl. the boundary group and the -inf groups past V;
+    vocabularies that end inside a chunk / a group / on a chunk boundary, with and without bias, group maxima only; nothing
+    written outside the buffers; bf16 and fp16."""
+    k = 512
+    a, w = bf(rnd(rows, k, seed=41)).cuda(), bf(rnd(v, k, seed=42) * 0.1).cuda()
+    b = rnd(v, seed=43).cuda() if with_bias else None
+    vpad = (v + 255) // 256 * 256
+    ng = vpad // 64
+    assert hip.vocab_logits_wreg_supported(rows, v, k, vpad if with_logits else 0, ng)
+    assert not hip.vocab_logits_wreg_supported(rows + 16, v, k, vpad, ng) and not hip.vocab_logits_wreg_supported(rows, v, 256, vpad, ng)
+    assert not hip.vocab_logits_wreg_supported(rows, v, k, vpad - 4, ng) and not hip.vocab_logits_wreg_supported(rows, v, k, vpad, ng - 1)
+    wp, bp = hip.pack_vocab_weights(w, b)
+    ref_l = torch.full((rows + 1, vpad), float("nan"), device="cuda")
+    ref_g = torch.full((rows + 1, ng), float("nan"), device="cuda")
+    hip.vocab_logits(a, w, b, ref_l[:rows, :v] if with_logits else None, ref_g[:rows])
+    got_l = torch.full((rows + 1, vpad), float("nan"), device="cuda")
+    got_g = torch.full((rows + 1, ng + 2), float("nan"), device="cuda")
+    hip.vocab_logits_wreg(a, wp, bp, v, got_l[:rows] if with_logits else None, got_g[:rows, :ng])
+    old_groups = hip.n_groups(v)                        # the old kernel defines whole 128-column panels of groups
+    assert torch.equal(got_g[:rows, :old_groups], ref_g[:rows, :old_groups])
+    assert bool((got_g[:rows, old_groups:ng] == float("-inf")).all()) and bool(torch.isnan(got_g[rows]).all()) and bool(torch.isnan(got_g[:rows, ng:]).all())
+    if with_logits:
+        assert torch.equal(got_l[:rows, :v], ref_l[:rows, :v])
+        assert bool((got_l[:rows, v:] == got_l[:rows, v - 1:v]).all())      # padding columns: copies of logit[V - 1]
+        assert bool(torch.isnan(got_l[rows]).all())
+    else:
+        assert bool(torch.isnan(got_l).all())
+
+
 @pytest.mark.parametrize("rows,row_mult,e,hh,use_tokens,with_state", [
     (37, 1, 64, 128, True, True), (8, 5, 256, 512, False, False), (130, 1, 512, 512, False, True),
     (64, 1, 256, 512, True, True)])
@@ -768,6 +802,33 @@ def test_decode_chain_wreg_equals_tile_chain(kind, monkeypatch):
         monkeypatch.delenv("DH_NO_DECODE_WREG")
         model.decoder._drop_plan()
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
+
+
+@pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
+def test_decode_with_vocab_wreg_equals_vocab_areg(kind, monkeypatch):
+    """Beam search with the register-streamed classifier (dh_vocab_logits_wreg: 64 images x beam 5 = 320 rows = 4 row blocks) against
+    the same decode on dh_vocab_logits (plan built with DH_NO_VOCAB_WREG): a vocabulary that ends inside a chunk -- same tokens, same
+    lengths, bit for bit; a batch whose row count the kernel does not take (3 images) falls back and is split-invariant."""
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import synth_state_dict
+    kw = dict(hid_dim=512, n_layers=1) if "Transformer" in kind else dict(hidden_size=512)
+    monkeypatch.setenv("DH_VOCAB_WREG_TRANSFORMER", "1")   # (opt-in for the Transformer decoder, default for the LSTM decoder)
+    model = getattr(M, kind)(3001, **kw).eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=987))
+    model = model.to(HALF).cuda()
+    imgs = synth_images(64, seed=12).cuda()
+    with torch.no_grad():
+        t1, l1 = model.generate_batch(imgs, max_len=9, beam_size=5, top_k=20, seed=6)
+        s1 = model.generate_batch(imgs[:3], max_len=9, beam_size=5, top_k=20, seed=6)
+        assert "cls_w_pk" in model.decoder._get_plan()
+        monkeypatch.setenv("DH_NO_VOCAB_WREG", "1")
+        model.decoder._drop_plan()
+        assert "cls_w_pk" not in model.decoder._get_plan()
+        t2, l2 = model.generate_batch(imgs, max_len=9, beam_size=5, top_k=20, seed=6)
+        monkeypatch.delenv("DH_NO_VOCAB_WREG")
+        model.decoder._drop_plan()
+    assert torch.equal(t1, t2) and torch.equal(l1, l2)
+    assert torch.equal(s1[0], t1[:3]) and torch.equal(s1[1], l1[:3])
 
 
 @pytest.mark.parametrize("n,hw,cin,cout,relu", [(16, 28, 512, 128, True), (64, 14, 1024, 256, True), (11, 28, 512, 256, False), (43, 14, 1024, 512, True),

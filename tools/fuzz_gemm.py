@@ -118,16 +118,52 @@ def vocab_trial(rng, idx):
     return rec
 
 
+def vocab_wreg_trial(rng, idx):
+    """dh_vocab_logits_wreg (round 4: weights streamed from L2 into registers) against dh_linear on the same operands: logits bit-equal,
+    group maxima exact, padding columns = copies of logit[V - 1], nothing outside the buffers -- every row count it takes, random
+    vocabularies, strides wider than the chunk padding."""
+    g = torch.Generator().manual_seed(35000 + idx)
+    dt = rng.choice([torch.bfloat16, torch.float16])
+    m = 80 * rng.choice([1, 2, 4, 8, 16, 32])
+    v = rng.choice([rng.randint(2, 300), rng.randint(301, 3000), rng.randint(3001, 12000), rng.randint(12001, 40000), 36541])
+    while m * v > (1 << 26):
+        m //= 2
+    k = 512
+    a = torch.randn(m, k, generator=g).to(dt).cuda()
+    w = (torch.randn(v, k, generator=g) * (2.5 / k ** 0.5)).to(dt).cuda()
+    bias = torch.randn(v, generator=g).cuda() if rng.random() < 0.8 else None
+    vpad = (v + 255) // 256 * 256
+    ldl, ng = vpad + rng.choice([0, 0, 4, 256]), vpad // 64
+    logits, check_l = guarded(m, vpad, ldl, torch.float32)
+    ldg = ng + rng.choice([0, 0, 3])
+    gmax, check_g = guarded(m, ng, ldg, torch.float32)
+    rec = dict(kind="vocab_wreg", M=m, V=v, dt=str(dt)[6:], bias=bias is not None, ldl=ldl, ldg=ldg)
+    if not hip.vocab_logits_wreg_supported(m, v, k, ldl, ldg):
+        return dict(rec, ok=False, error="supported() refused a shape of its contract")
+    wp, bp = hip.pack_vocab_weights(w, bias)
+    hip.vocab_logits_wreg(a, wp, bp, v, logits, gmax)
+    torch.cuda.synchronize()
+    ref = hip.linear(a, w, bias, out_dtype=torch.float32)
+    bit = bool(torch.equal(logits[:, :v], ref)) and bool((logits[:, v:] == ref[:, v - 1:v]).all())
+    pad = torch.full((m, ng * 64), float("-inf"), device="cuda")
+    pad[:, :v] = ref
+    gm_ok = bool(torch.equal(gmax, pad.view(m, ng, 64).max(-1).values))
+    rec.update(bit_equal=bit, gmax_ok=gm_ok, canary_ok=check_l() and check_g(), ok=bool(bit and gm_ok and check_l() and check_g()))
+    return rec
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--trials", type=int, default=150)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--only", choices=["linear", "vocab"], default=None)
+    ap.add_argument("--only", choices=["linear", "vocab", "wreg"], default=None)
     args = ap.parse_args(argv)
     bad = 0
     for i in range(args.trials):
-        for fn in (linear_trial, vocab_trial):
+        for fn in (linear_trial, vocab_trial, vocab_wreg_trial):
             if args.only and args.only not in fn.__name__:
+                continue
+            if fn is vocab_wreg_trial and i % 3:
                 continue
             rng = random.Random(args.seed * 100003 + i)
             try:

@@ -16,9 +16,9 @@ from pathlib import Path
 
 # bench.py roofline key -> (workload, kernel-name fragment, workgroups or None, note)
 KEYS = [
-    ("c2", "dh_linear[vocab]{1280x36541x512}", "vocab_areg256_kernel", 256,
-     "A-stationary persistent vocabulary GEMM + bias, 256-row tiles (activation fragments in registers, W-only LDS ring), fp32 logits "
-     "out into a row stride of whole 128-column panels; fetch above W + A = weight panels fetched by more than one XCD"),
+    ("c2", "dh_linear[vocab]{1280x36541x512}", "vocab_wreg_kernel", 256,
+     "classifier + bias with the weights streamed from L2 into registers (fragment-packed, 16 row-block workgroups per weight chunk on "
+     "one XCD) and 80-row activation blocks in LDS, fp32 logits out (non-temporal) into a row stride of whole 256-column chunks"),
     ("c3", "dh_linear[vocab]{1280x36541x512}", "vocab_areg256_kernel", 256, "same kernel, same shape (256 images x 5 beams)"),
     ("c3", "dh_attn_self_decode", "attn_decode_reg_kernel", 2048,
      "launch-weighted mean over the history depths of one sweep (2..22 keys per row)"),
