@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 21
+ABI_VERSION = 22
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -70,6 +70,8 @@ SIGNATURES = {
     "dh_conv3x3_direct_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_s3_supported": [_I, _I, _I],
+    "dh_bottleneck_tail_s2_supported": [_I, _I, _I],
+    "dh_bottleneck_tail_s2_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv3x3_s4_supported": [_I, _I, _I],
     "dh_conv3x3_s4_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_s3_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -571,6 +573,20 @@ def pack_mfma_fragments(w):
     r, k = w.shape[0], w.numel() // w.shape[0]
     out = torch.empty((r * k,), dtype=w.dtype, device=w.device)
     _launch("dh_pack_mfma_fragments", _ptr(w), _ptr(out), r, k, _stream())
+    return out
+
+
+def bottleneck_tail_s2_supported(h, w, c):
+    return bool(load().dh_bottleneck_tail_s2_supported(int(h), int(w), int(c)))
+
+
+def bottleneck_tail_s2_nhwc(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual):
+    """``dh_bottleneck_tail_s2_nhwc``: the stage-2 bottleneck tail on fragment-packed weights; bit-identical to ``bottleneck_tail_nhwc``."""
+    _dev(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual)
+    n, h, w, c = y1.shape
+    out = torch.empty((n, h, w, 4 * c), dtype=y1.dtype, device=y1.device)
+    _launch("dh_bottleneck_tail_s2_nhwc", _ptr(y1), _ptr(w2p), _ptr(scale2), _ptr(shift2), _ptr(w3p), _ptr(scale3), _ptr(shift3),
+            _ptr(residual), _ptr(out), n, h, w, c, _dt(y1), _stream())
     return out
 
 

@@ -179,6 +179,12 @@ class ImageEncoder(_Planned, nn.Module):
                     # stage-3 blocks: the fused tail streams the weights from L2 into registers in MFMA fragment order
                     ent["w2p"] = hip.pack_mfma_fragments(ent["c2"]["w"])
                     ent["w3p"] = hip.pack_mfma_fragments(ent["c3"]["w"].reshape(ent["c3"]["w"].shape[0], -1).contiguous())
+                elif (bf16 and ent["c2"]["w"].is_cuda and ent["down"] is None and ent["c2"]["stride"] == 1 and ent["c2"]["w"].shape[1] == 3
+                        and ent["c3"]["w"].shape[0] == 4 * ent["c2"]["w"].shape[0] and ent["c2"]["w"].shape[0] == ent["c2"]["w"].shape[3]
+                        and hip.bottleneck_tail_s2_supported(28, 28, ent["c2"]["w"].shape[0])):
+                    # stage-2 blocks: the same structure on 4-row strips, three workgroups per CU (conv_s2.hip)
+                    ent["w2p2"] = hip.pack_mfma_fragments(ent["c2"]["w"])
+                    ent["w3p2"] = hip.pack_mfma_fragments(ent["c3"]["w"].reshape(ent["c3"]["w"].shape[0], -1).contiguous())
                 c2w = ent["c2"]["w"]
                 if (bf16 and c2w.is_cuda and ent["c2"]["stride"] == 1 and ent["c2"]["pad"] == 1 and tuple(c2w.shape[1:3]) == (3, 3)
                         and hip.conv3x3_s4_supported(7, 7, c2w.shape[0]) and c2w.shape[3] == c2w.shape[0]):
@@ -248,6 +254,11 @@ class ImageEncoder(_Planned, nn.Module):
                 # stage 3 (14 x 14 x 256): one image per workgroup, patch-resident 3x3 + 1x1 expansion, weights register-streamed
                 y1 = self._conv(x, blk["c1"], nhwc=True)
                 x = hip.bottleneck_tail_s3_nhwc(y1, blk["w2p"], c2["scale"], c2["shift"], blk["w3p"], c3["scale"], c3["shift"], x)
+                continue
+            if (nhwc and "w2p2" in blk and hip.bottleneck_tail_s2_supported(x.shape[1], x.shape[2], c2["w"].shape[0])
+                    and not os.environ.get("DH_NO_FUSED_TAIL") and not os.environ.get("DH_NO_S2_TAIL")):
+                y1 = self._conv(x, blk["c1"], nhwc=True)
+                x = hip.bottleneck_tail_s2_nhwc(y1, blk["w2p2"], c2["scale"], c2["shift"], blk["w3p2"], c3["scale"], c3["shift"], x)
                 continue
             if (nhwc and blk["dual"] is None and blk["down"] is None and c2["stride"] == 1 and c2["w"].shape[1] == 3
                     and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], c2["w"].shape[3], c2["w"].shape[0])

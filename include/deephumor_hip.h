@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 21
+#define DH_ABI_VERSION 22
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -111,6 +111,15 @@ int dh_bottleneck_tail_nhwc(const void* y1, const void* w2, const float* scale2,
  * dh_conv2d_nhwc_bn_act launches. */
 int dh_bottleneck_tail_s3_supported(int H, int W, int C);
 int dh_bottleneck_tail_s3_nhwc(const void* y1, const void* w2_packed, const float* scale2, const float* shift2,
+                               const void* w3_packed, const float* scale3, const float* shift3, const void* residual,
+                               void* out, int N, int H, int W, int C, int dtype, void* stream);
+
+/* The stage-2 form of dh_bottleneck_tail_s3_nhwc (28 x 28 x 128 -> 512; layer2.1-layer2.3): four output rows of one image per
+ * workgroup, three workgroups per CU, weights from L2 into registers, no barrier in the loops (csrc/conv_s2.hip).
+ * w2_packed = dh_pack_mfma_fragments(w2 [128][3*3*128]), w3_packed = dh_pack_mfma_fragments(w3 [512][128]).
+ * Bit-identical to dh_bottleneck_tail_nhwc. */
+int dh_bottleneck_tail_s2_supported(int H, int W, int C);
+int dh_bottleneck_tail_s2_nhwc(const void* y1, const void* w2_packed, const float* scale2, const float* shift2,
                                const void* w3_packed, const float* scale3, const float* shift3, const void* residual,
                                void* out, int N, int H, int W, int C, int dtype, void* stream);
 

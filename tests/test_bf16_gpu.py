@@ -880,3 +880,24 @@ def test_conv3x3_s4_equals_tile_gemm(hip, n):
     want = hip.conv2d_nhwc_bn_act(x, w, scale, shift, relu=True, stride=1, pad=1)
     got = hip.conv3x3_s4_nhwc(x, hip.pack_mfma_fragments(w), scale, shift)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+
+@pytest.mark.parametrize("n", [1, 3, 32])
+def test_bottleneck_tail_s2_equals_fused_tail(hip, n):
+    """dh_bottleneck_tail_s2_nhwc (stage-2 tail: 4-row strips, three workgroups per CU, weights from L2 into registers, no barrier)
+    against dh_bottleneck_tail_nhwc and against the two implicit GEMMs, bit for bit."""
+    c, hw = 128, 28
+    g = torch.Generator().manual_seed(70 + n)
+    y1 = bf(torch.randn(n, hw, hw, c, generator=g)).cuda()
+    w2 = bf(torch.randn(c, 3, 3, c, generator=g) / (9 * c) ** 0.5).cuda()
+    s2, h2 = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    w3 = bf(torch.randn(4 * c, 1, 1, c, generator=g) / c ** 0.5).cuda()
+    s3, h3 = (torch.rand(4 * c, generator=g) + 0.5).cuda(), (torch.randn(4 * c, generator=g) * 0.3).cuda()
+    res = bf(torch.randn(n, hw, hw, 4 * c, generator=g)).cuda()
+    assert hip.bottleneck_tail_s2_supported(hw, hw, c) and not hip.bottleneck_tail_s2_supported(56, 56, 64)
+    want = hip.bottleneck_tail_nhwc(y1, w2, s2, h2, w3, s3, h3, res)
+    y2 = hip.conv2d_nhwc_bn_act(y1, w2, s2, h2, None, relu=True, stride=1, pad=1)
+    want2 = hip.conv2d_nhwc_bn_act(y2, w3, s3, h3, res, relu=True, stride=1, pad=0)
+    got = hip.bottleneck_tail_s2_nhwc(y1, hip.pack_mfma_fragments(w2), s2, h2, hip.pack_mfma_fragments(w3.view(4 * c, c)), s3, h3, res)
+    assert torch.equal(want, want2)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
