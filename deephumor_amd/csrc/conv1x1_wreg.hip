@@ -25,6 +25,7 @@
 namespace {
 struct C1Params {
     const uint16_t* x; const uint4* wp; const float* scale; const float* shift; uint16_t* y;
+    const uint16_t* res;                                  // RES instances: residual rows [M, N]
     int M, N, relu, nb_n, wg_per_n, nblk;
     // second source of the virtual operand [x | x2 at the strided pixels] (dual form; x2 == nullptr otherwise): k slabs ns1 .. come from
     // x2 [Nimg, H2, W2, C2]; row r = (n, oy, ox) of the Ho x Wo output grid reads pixel (n, oy * stride, ox * stride)
@@ -45,7 +46,7 @@ __device__ __forceinline__ void c1_dma16(const void* base, unsigned off, void* l
 // (8 x 64 KB per block at 128 B/clk = twice the block's MFMA time).  MEASURED: no gain -- TN = 2 with 4 waves 42 / 56 / 91 / 75 us, with 8
 // waves and 256 channels per workgroup 79.5 us for {200704 x 256 x 512}, against 36 / 53 / 76 / 59 us for TN = 1 with 8 waves: these layers
 // run at 3.6-4.9 TB/s of HBM traffic, not at the LDS read rate.  The dispatch uses TN = 1.
-template <typename OT, int KF, int RB, int TN, int NW>      // TN = 1 or 2
+template <typename OT, int KF, int RB, int TN, int NW, bool RES = false>      // TN = 1 or 2; RES: + residual [M, N] before the ReLU
 __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
     constexpr int K = 32 * KF, NSLAB = K / 64, SLABB = RB * 128, BUF = NSLAB * SLABB, TM = RB / 16, RG = RB / 8;
     constexpr int NT = 64 * NW, BN = 16 * NW * TN;         // output channels per workgroup
@@ -124,10 +125,21 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
             if (nmine > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(TN * TM) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RES ? 2 : 1) * TN * TM) : "memory");      // (RES: + block i - 1's residual loads)
         }
         __builtin_amdgcn_s_barrier();                     // every wave's pieces of block i landed AND every wave has left block i - 1
         if (i >= 1 && i + 1 < nmine) stage(b + step, buf ^ 1);   // block i + 1 into block i - 1's buffer: in flight during this block
+        // the block's residual quads in accumulator layout, requested in front of the MFMAs (plain loads behind the transfer just issued:
+        // the compiler's own counts for them can only be stricter than needed, the immediate above counts them)
+        uint2 rq[TN][TM];
+        if constexpr (RES) {
+#pragma unroll
+            for (int c = 0; c < TN; ++c)
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    rq[c][t] = *reinterpret_cast<const uint2*>(p.res + (n0 + 16 * wave * TN + 4 * lq) + (size_t)min(b * RB + 16 * t + l15, p.M - 1) * p.N + 16 * c);
+            asm volatile("" ::: "memory");
+        }
         dh_f32x4 acc[TN][TM];
 #pragma unroll
         for (int c = 0; c < TN; ++c)
@@ -159,6 +171,11 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
                 if constexpr (TN > 1) { sc = bn_lds[c * 8]; sh = bn_lds[c * 8 + 4]; }
                 float v0 = fmaf(acc[c][t][0], sc.x, sh.x), v1 = fmaf(acc[c][t][1], sc.y, sh.y);
                 float v2 = fmaf(acc[c][t][2], sc.z, sh.z), v3 = fmaf(acc[c][t][3], sc.w, sh.w);
+                if constexpr (RES) {
+                    float r0, r1, r2, r3;
+                    Op16<OT>::unpack2(rq[c][t].x, r0, r1); Op16<OT>::unpack2(rq[c][t].y, r2, r3);
+                    v0 += r0; v1 += r1; v2 += r2; v3 += r3;
+                }
                 if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
                 uint2 pk;
                 pk.x = (uint32_t)Op16<OT>::from_f32(v0) | ((uint32_t)Op16<OT>::from_f32(v1) << 16);
@@ -183,24 +200,27 @@ extern "C" int dh_conv1x1_wreg_supported(long long M, int Cin, int Cout) {
 }
 
 // y [M, Cout] = relu?((x [M, Cin] w^T) * scale + shift), channels-last rows (a 1x1 stride-1 convolution + BatchNorm [+ ReLU] without
-// residual); w_packed = dh_pack_mfma_fragments(w [Cout, Cin]).  Bit-identical to dh_conv2d_nhwc_bn_act(KS = 1).
-extern "C" int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale, const float* shift, void* y, long long M,
-                                    int Cin, int Cout, int relu, int dtype, void* stream) {
+// residual, or for Cin = 512 + residual [M, Cout] before the ReLU: conv3 of the stage-4 bottlenecks); w_packed =
+// dh_pack_mfma_fragments(w [Cout, Cin]).  Bit-identical to dh_conv2d_nhwc_bn_act(KS = 1).
+extern "C" int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual, void* y,
+                                    long long M, int Cin, int Cout, int relu, int dtype, void* stream) {
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
-    DH_REQUIRE(x && w_packed && scale && shift && y && dh_conv1x1_wreg_supported(M, Cin, Cout));
+    DH_REQUIRE(x && w_packed && scale && shift && y && dh_conv1x1_wreg_supported(M, Cin, Cout) && (!residual || Cin == 512));
+    DH_REQUIRE(((uintptr_t)residual % 16) == 0);
     DH_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)scale % 16) == 0 &&
                ((uintptr_t)shift % 16) == 0);
     C1Params p{};
-    p.x = (const uint16_t*)x; p.wp = (const uint4*)w_packed; p.scale = scale; p.shift = shift; p.y = (uint16_t*)y;
+    p.x = (const uint16_t*)x; p.wp = (const uint4*)w_packed; p.scale = scale; p.shift = shift; p.y = (uint16_t*)y; p.res = (const uint16_t*)residual;
     p.M = (int)M; p.N = Cout; p.relu = relu; p.nb_n = Cout / 128; p.wg_per_n = 256 / p.nb_n; p.ns1 = Cin / 64;
     const int rb = 65536 / (2 * Cin);                    // rows per 64 KB block: 128 / 64 / 32
     p.nblk = dh_cdiv(M, rb);
     dh_prof_set_tag("1x1");
     dh_prof_set_dims((int)M, Cout, Cin);
-    DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * M * Cout * Cin, 2.0 * ((double)M * Cin + (double)Cout * Cin + (double)M * Cout), stream);
+    DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * M * Cout * Cin, 2.0 * ((double)M * Cin + (double)Cout * Cin + (double)M * Cout * (residual ? 2 : 1)), stream);
     hipStream_t s = (hipStream_t)stream;
     DH_DISPATCH_16(dtype, {
         if (Cin == 256) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 8, 128, 1, 8>), dim3(256), dim3(512), 0, s, p);
+        else if (Cin == 512 && residual) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 16, 64, 1, 8, true>), dim3(256), dim3(512), 0, s, p);
         else if (Cin == 512) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 16, 64, 1, 8>), dim3(256), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 32, 32, 1, 8>), dim3(256), dim3(512), 0, s, p);
     });

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 22
+ABI_VERSION = 23
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -77,7 +77,7 @@ SIGNATURES = {
     "dh_bottleneck_tail_s3_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_pack_mfma_fragments": [_P, _P, _I, _I, _P],
     "dh_conv1x1_wreg_supported": [_c.c_longlong, _I, _I],
-    "dh_conv1x1_wreg_nhwc": [_P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P],
+    "dh_conv1x1_wreg_nhwc": [_P, _P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P],
     "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_conv1x1_dual_wreg_supported": [_I] * 8,
@@ -608,15 +608,15 @@ def conv1x1_wreg_supported(m, cin, cout):
     return bool(load().dh_conv1x1_wreg_supported(int(m), int(cin), int(cout)))
 
 
-def conv1x1_wreg_nhwc(x, w_packed, cout, scale, shift, relu=True):
-    """``dh_conv1x1_wreg_nhwc``: 1x1 convolution + BatchNorm (+ ReLU) of channels-last ``x [N, H, W, Cin]`` on fragment-packed
-    weights (``pack_mfma_fragments(w.view(Cout, Cin))``), weights stationary in registers, pixels streamed."""
-    _dev(x, w_packed, scale, shift)
-    assert x.is_contiguous() and x.dtype in HALF_DTYPES
+def conv1x1_wreg_nhwc(x, w_packed, cout, scale, shift, relu=True, residual=None):
+    """``dh_conv1x1_wreg_nhwc``: 1x1 convolution + BatchNorm (+ residual, Cin = 512 only) (+ ReLU) of channels-last ``x [N, H, W, Cin]`` on
+    fragment-packed weights (``pack_mfma_fragments(w [Cout, Cin])``): weights stationary in registers, pixels streamed
+    (csrc/conv1x1_wreg.hip).  Bit-identical to ``conv2d_nhwc_bn_act``."""
+    _dev(x, w_packed, scale, shift, residual)
     n, h, w, cin = x.shape
     out = torch.empty((n, h, w, cout), dtype=x.dtype, device=x.device)
-    _launch("dh_conv1x1_wreg_nhwc", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(out), n * h * w, cin, cout, int(relu),
-            _dt(x), _stream())
+    _launch("dh_conv1x1_wreg_nhwc", _ptr(x), _ptr(w_packed), _ptr(scale), _ptr(shift), _ptr(residual), _ptr(out), n * h * w, cin, cout,
+            int(relu), _dt(x), _stream())
     return out
 
 

@@ -185,6 +185,10 @@ class ImageEncoder(_Planned, nn.Module):
                     # stage-2 blocks: the same structure on 4-row strips, three workgroups per CU (conv_s2.hip)
                     ent["w2p2"] = hip.pack_mfma_fragments(ent["c2"]["w"])
                     ent["w3p2"] = hip.pack_mfma_fragments(ent["c3"]["w"].reshape(ent["c3"]["w"].shape[0], -1).contiguous())
+                c3w = ent["c3"]["w"]
+                if (bf16 and c3w.is_cuda and ent["down"] is None and tuple(c3w.shape[1:]) == (1, 1, 512) and c3w.shape[0] % 128 == 0
+                        and c3w.shape[0] // 128 in (1, 2, 4, 8, 16)):
+                    ent["c3"]["wpk1"] = hip.pack_mfma_fragments(c3w.reshape(c3w.shape[0], 512).contiguous())      # stage-4 conv3 + residual
                 c2w = ent["c2"]["w"]
                 if (bf16 and c2w.is_cuda and ent["c2"]["stride"] == 1 and ent["c2"]["pad"] == 1 and tuple(c2w.shape[1:3]) == (3, 3)
                         and hip.conv3x3_s4_supported(7, 7, c2w.shape[0]) and c2w.shape[3] == c2w.shape[0]):
@@ -197,10 +201,12 @@ class ImageEncoder(_Planned, nn.Module):
 
     @staticmethod
     def _conv(x, c, residual=None, nhwc=False):
-        if (nhwc and residual is None and "wpk1" in c and hip.conv1x1_wreg_supported(x.shape[0] * x.shape[1] * x.shape[2], x.shape[3], c["w"].shape[0])
+        if (nhwc and "wpk1" in c and (residual is None or x.shape[3] == 512)
+                and hip.conv1x1_wreg_supported(x.shape[0] * x.shape[1] * x.shape[2], x.shape[3], c["w"].shape[0])
                 and not os.environ.get("DH_NO_CONV1X1_WREG")):
-            # conv1 of the K >= 512 bottlenecks: weights stationary in registers, pixels streamed (csrc/conv1x1_wreg.hip; bit-identical)
-            return hip.conv1x1_wreg_nhwc(x, c["wpk1"], c["w"].shape[0], c["scale"], c["shift"], relu=c["relu"])
+            # conv1 of the K >= 256 bottlenecks, conv3 + residual of stage 4: weights stationary in registers, pixels streamed
+            # (csrc/conv1x1_wreg.hip; bit-identical)
+            return hip.conv1x1_wreg_nhwc(x, c["wpk1"], c["w"].shape[0], c["scale"], c["shift"], relu=c["relu"], residual=residual)
         if (nhwc and residual is None and "wpk4" in c and c["relu"] and hip.conv3x3_s4_supported(x.shape[1], x.shape[2], x.shape[3])
                 and not os.environ.get("DH_NO_CONV_S4")):
             return hip.conv3x3_s4_nhwc(x, c["wpk4"], c["scale"], c["shift"])

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 22
+#define DH_ABI_VERSION 23
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -140,8 +140,8 @@ int dh_pack_mfma_fragments(const void* w, void* out, int R, int K, void* stream)
  * encoders.py:37-38): y [M, Cout] = relu?((x [M, Cin] w^T) * scale + shift), w_packed = dh_pack_mfma_fragments(w [Cout, Cin]).
  * Cin 256, 512 or 1,024, Cout / 128 in {1, 2, 4, 8, 16}, M >= 8,192 (_supported).  Bit-identical to dh_conv2d_nhwc_bn_act(KS = 1). */
 int dh_conv1x1_wreg_supported(long long M, int Cin, int Cout);
-int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale, const float* shift, void* y, long long M, int Cin,
-                         int Cout, int relu, int dtype, void* stream);
+int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale, const float* shift, const void* residual /* or NULL; Cin = 512 */,
+                         void* y, long long M, int Cin, int Cout, int relu, int dtype, void* stream);
 
 /* The dual form (dh_conv1x1_dual_nhwc: relu(bn3(conv3(y)) + bn_d(downsample(x))) of a stage's first bottleneck, encoders.py:37-38 /
  * torchvision Bottleneck.forward with `downsample`) in the same streaming structure, for the instances C1 + C2 = 128, 384 or 768,

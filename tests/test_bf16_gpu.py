@@ -846,6 +846,11 @@ def test_conv1x1_wreg_equals_tile_gemm(hip, n, hw, cin, cout, relu):
     got = hip.conv1x1_wreg_nhwc(x, hip.pack_mfma_fragments(w.view(cout, cin)), cout, scale, shift, relu=relu)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
     assert not hip.conv1x1_wreg_supported(4096, cin, cout) and not hip.conv1x1_wreg_supported(n * hw * hw, 128, cout)
+    if cin == 512:                                       # + residual before the ReLU (conv3 of the stage-4 bottlenecks)
+        res = bf(torch.randn(n, hw, hw, cout, generator=g)).cuda()
+        want = hip.conv2d_nhwc_bn_act(x, w, scale, shift, residual=res, relu=relu)
+        got = hip.conv1x1_wreg_nhwc(x, hip.pack_mfma_fragments(w.view(cout, cin)), cout, scale, shift, relu=relu, residual=res)
+        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
 
 
 @pytest.mark.parametrize("n,ho,c1,c2,cout,stride", [(3, 56, 64, 64, 256, 1), (13, 28, 128, 256, 512, 2), (5, 57, 64, 64, 512, 1),

@@ -127,10 +127,12 @@ def wreg_trial(rng, idx):
         rec.update(N=n, HW=hw, Cin=cin, Cout=cout, relu=relu)
         if not hip.conv1x1_wreg_supported(n * hw * hw, cin, cout):
             return dict(rec, ok=True, skipped=True)
-        ref = hip.conv2d_nhwc_bn_act(x, w, scale, shift, relu=relu)
+        res = torch.randn(n, hw, hw, cout, generator=g).to(dt).cuda() if (cin == 512 and rng.random() < 0.5) else None
+        rec["res"] = res is not None
+        ref = hip.conv2d_nhwc_bn_act(x, w, scale, shift, residual=res, relu=relu)
         out, check = guarded((n, hw, hw, cout), dt)
         hip._launch("dh_conv1x1_wreg_nhwc", hip._ptr(x), hip._ptr(hip.pack_mfma_fragments(w.view(cout, cin))), hip._ptr(scale), hip._ptr(shift),
-                    hip._ptr(out), n * hw * hw, cin, cout, int(relu), hip._dt(x), hip._stream())
+                    hip._ptr(res), hip._ptr(out), n * hw * hw, cin, cout, int(relu), hip._dt(x), hip._stream())
     elif which == "dual":
         c1, c2 = rng.choice([(64, 64), (128, 256), (256, 512), (64, 320), (192, 192)])
         cout, stride = 256 * rng.choice([1, 2, 4]), rng.choice([1, 2])
