@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 23
+ABI_VERSION = 24
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -70,6 +70,8 @@ SIGNATURES = {
     "dh_conv3x3_direct_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_s3_supported": [_I, _I, _I],
+    "dh_bottleneck_tail_s1_supported": [_I, _I, _I, _I],
+    "dh_bottleneck_tail_s1_nhwc": [_P] * 13 + [_I] * 6 + [_P],
     "dh_bottleneck_tail_s2_supported": [_I, _I, _I],
     "dh_bottleneck_tail_s2_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv3x3_s4_supported": [_I, _I, _I],
@@ -574,6 +576,22 @@ def pack_mfma_fragments(w):
     out = torch.empty((r * k,), dtype=w.dtype, device=w.device)
     _launch("dh_pack_mfma_fragments", _ptr(w), _ptr(out), r, k, _stream())
     return out
+
+
+def bottleneck_tail_s1_supported(h, w, c, n1=0):
+    return bool(load().dh_bottleneck_tail_s1_supported(int(h), int(w), int(c), int(n1)))
+
+
+def bottleneck_tail_s1_nhwc(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual, w1p=None, scale1=None, shift1=None, n1=0):
+    """``dh_bottleneck_tail_s1_nhwc``: the stage-1 bottleneck tail on fragment-packed weights; with ``w1p`` also the NEXT bottleneck's
+    conv1 + bn1 + relu on the output tile while it is in LDS.  Returns ``out`` or ``(out, y1_next)``."""
+    _dev(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual, w1p, scale1, shift1)
+    n, h, w, c = y1.shape
+    out = torch.empty((n, h, w, 4 * c), dtype=y1.dtype, device=y1.device)
+    y1n = torch.empty((n, h, w, n1), dtype=y1.dtype, device=y1.device) if w1p is not None else None
+    _launch("dh_bottleneck_tail_s1_nhwc", _ptr(y1), _ptr(w2p), _ptr(scale2), _ptr(shift2), _ptr(w3p), _ptr(scale3), _ptr(shift3),
+            _ptr(residual), _ptr(out), _ptr(w1p), _ptr(scale1), _ptr(shift1), _ptr(y1n), n1, n, h, w, c, _dt(y1), _stream())
+    return out if w1p is None else (out, y1n)
 
 
 def bottleneck_tail_s2_supported(h, w, c):

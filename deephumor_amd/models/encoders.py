@@ -181,6 +181,15 @@ class ImageEncoder(_Planned, nn.Module):
                     ent["w3p"] = hip.pack_mfma_fragments(ent["c3"]["w"].reshape(ent["c3"]["w"].shape[0], -1).contiguous())
                 elif (bf16 and ent["c2"]["w"].is_cuda and ent["down"] is None and ent["c2"]["stride"] == 1 and ent["c2"]["w"].shape[1] == 3
                         and ent["c3"]["w"].shape[0] == 4 * ent["c2"]["w"].shape[0] and ent["c2"]["w"].shape[0] == ent["c2"]["w"].shape[3]
+                        and hip.bottleneck_tail_s1_supported(56, 56, ent["c2"]["w"].shape[0])):
+                    # stage-1 blocks: 4-row strips (conv_s1.hip); this block's conv1 in fragment order too, for the previous tail to run it
+                    ent["w2p1"] = hip.pack_mfma_fragments(ent["c2"]["w"])
+                    ent["w3p1"] = hip.pack_mfma_fragments(ent["c3"]["w"].reshape(ent["c3"]["w"].shape[0], -1).contiguous())
+                    if (tuple(c1w.shape[1:3]) == (1, 1) and ent["c1"]["stride"] == 1 and ent["c1"]["relu"]
+                            and hip.bottleneck_tail_s1_supported(56, 56, ent["c2"]["w"].shape[0], c1w.shape[0]) and c1w.shape[3] == 4 * ent["c2"]["w"].shape[0]):
+                        ent["c1"]["wpkf"] = hip.pack_mfma_fragments(c1w.reshape(c1w.shape[0], c1w.shape[3]).contiguous())
+                elif (bf16 and ent["c2"]["w"].is_cuda and ent["down"] is None and ent["c2"]["stride"] == 1 and ent["c2"]["w"].shape[1] == 3
+                        and ent["c3"]["w"].shape[0] == 4 * ent["c2"]["w"].shape[0] and ent["c2"]["w"].shape[0] == ent["c2"]["w"].shape[3]
                         and hip.bottleneck_tail_s2_supported(28, 28, ent["c2"]["w"].shape[0])):
                     # stage-2 blocks: the same structure on 4-row strips, three workgroups per CU (conv_s2.hip)
                     ent["w2p2"] = hip.pack_mfma_fragments(ent["c2"]["w"])
@@ -253,8 +262,23 @@ class ImageEncoder(_Planned, nn.Module):
     def _trunk(self, x, plan):
         """layer1..layer4 on the pooled stem output."""
         nhwc = plan["bf16"]
-        for blk in plan["blocks"]:
+        blocks = plan["blocks"]
+        ready = {}                                        # block index -> its conv1 output, already computed by the previous block's tail launch
+        for bi, blk in enumerate(blocks):
             c2, c3 = blk["c2"], blk["c3"]
+            nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
+            if (nhwc and "w2p1" in blk and nxt is not None and "wpkf" in nxt["c1"] and "w2p1" in nxt
+                    and hip.bottleneck_tail_s1_supported(x.shape[1], x.shape[2], c2["w"].shape[0], nxt["c1"]["w"].shape[0])
+                    and not os.environ.get("DH_NO_FUSED_TAIL") and not os.environ.get("DH_NO_S1_CONV1_FUSION")):
+                # stage 1 (56 x 56 x 64), next block's conv1 256 -> 64: 4-row strips, weights register-streamed, and that conv1 in the
+                # same launch on the output tile while it is in LDS -- the 411 MB tensor is not read back for it (conv_s1.hip).
+                # (Without the fusion the ring kernel below is the faster tail in the encoder: 195 against 214 us.)
+                y1 = ready.pop(bi, None)
+                if y1 is None:
+                    y1 = self._conv(x, blk["c1"], nhwc=True)
+                x, ready[bi + 1] = hip.bottleneck_tail_s1_nhwc(y1, blk["w2p1"], c2["scale"], c2["shift"], blk["w3p1"], c3["scale"], c3["shift"], x,
+                                                               nxt["c1"]["wpkf"], nxt["c1"]["scale"], nxt["c1"]["shift"], nxt["c1"]["w"].shape[0])
+                continue
             if (nhwc and "w2p" in blk and hip.bottleneck_tail_s3_supported(x.shape[1], x.shape[2], c2["w"].shape[0])
                     and not os.environ.get("DH_NO_FUSED_TAIL") and not os.environ.get("DH_NO_S3_TAIL")):
                 # stage 3 (14 x 14 x 256): one image per workgroup, patch-resident 3x3 + 1x1 expansion, weights register-streamed
@@ -271,7 +295,9 @@ class ImageEncoder(_Planned, nn.Module):
                     and c3["w"].shape[0] == 4 * c2["w"].shape[0] and not os.environ.get("DH_NO_FUSED_TAIL")
                     and not os.environ.get("DH_NO_DIRECT_3X3")):
                 # conv2 + bn2 + relu + conv3 + bn3 + residual + relu in one launch: the conv2 output tile stays in LDS
-                y1 = self._conv(x, blk["c1"], nhwc=True)
+                y1 = ready.pop(bi, None)
+                if y1 is None:
+                    y1 = self._conv(x, blk["c1"], nhwc=True)
                 x = hip.bottleneck_tail_nhwc(y1, c2["w"], c2["scale"], c2["shift"], c3["w"], c3["scale"], c3["shift"], x)
                 continue
             y = self._conv(self._conv(x, blk["c1"], nhwc=nhwc), blk["c2"], nhwc=nhwc)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 23
+#define DH_ABI_VERSION 24
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -113,6 +113,16 @@ int dh_bottleneck_tail_s3_supported(int H, int W, int C);
 int dh_bottleneck_tail_s3_nhwc(const void* y1, const void* w2_packed, const float* scale2, const float* shift2,
                                const void* w3_packed, const float* scale3, const float* shift3, const void* residual,
                                void* out, int N, int H, int W, int C, int dtype, void* stream);
+
+/* The stage-1 form (56 x 56 x 64 -> 256; layer1.1-layer1.2), optionally with the NEXT bottleneck's conv1 + bn1 + relu (256 -> N1 = 64)
+ * behind it in the same launch: the output tile is the operand of that conv1 straight from LDS, the 411 MB tensor is not read back
+ * (csrc/conv_s1.hip).  w1_packed = dh_pack_mfma_fragments(w1' [N1][256]) or NULL.  Bit-identical to dh_bottleneck_tail_nhwc followed by
+ * dh_conv2d_nhwc_bn_act (1x1). */
+int dh_bottleneck_tail_s1_supported(int H, int W, int C, int N1);
+int dh_bottleneck_tail_s1_nhwc(const void* y1, const void* w2_packed, const float* scale2, const float* shift2,
+                               const void* w3_packed, const float* scale3, const float* shift3, const void* residual, void* out,
+                               const void* w1_packed, const float* scale1, const float* shift1, void* y1_next, int N1, int N,
+                               int H, int W, int C, int dtype, void* stream);
 
 /* The stage-2 form of dh_bottleneck_tail_s3_nhwc (28 x 28 x 128 -> 512; layer2.1-layer2.3): four output rows of one image per
  * workgroup, three workgroups per CU, weights from L2 into registers, no barrier in the loops (csrc/conv_s2.hip).

@@ -906,3 +906,31 @@ def test_bottleneck_tail_s2_equals_fused_tail(hip, n):
     got = hip.bottleneck_tail_s2_nhwc(y1, hip.pack_mfma_fragments(w2), s2, h2, hip.pack_mfma_fragments(w3.view(4 * c, c)), s3, h3, res)
     assert torch.equal(want, want2)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+
+
+@pytest.mark.parametrize("n,fuse", [(1, False), (2, True), (5, True), (16, False)])
+def test_bottleneck_tail_s1_equals_fused_tail_and_next_conv1(hip, n, fuse):
+    """dh_bottleneck_tail_s1_nhwc (stage-1 tail on 4-row strips, weights from L2 into registers) against dh_bottleneck_tail_nhwc, and
+    its fused form -- the NEXT bottleneck's conv1 + bn1 + relu on the output tile while it is in LDS -- against the stand-alone 1x1
+    launch on the stored output: bit for bit."""
+    c, hw, n1 = 64, 56, 64
+    g = torch.Generator().manual_seed(90 + n)
+    y1 = bf(torch.randn(n, hw, hw, c, generator=g)).cuda()
+    w2 = bf(torch.randn(c, 3, 3, c, generator=g) / (9 * c) ** 0.5).cuda()
+    s2, h2 = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) * 0.3).cuda()
+    w3 = bf(torch.randn(4 * c, 1, 1, c, generator=g) / c ** 0.5).cuda()
+    s3, h3 = (torch.rand(4 * c, generator=g) + 0.5).cuda(), (torch.randn(4 * c, generator=g) * 0.3).cuda()
+    res = bf(torch.randn(n, hw, hw, 4 * c, generator=g)).cuda()
+    w1 = bf(torch.randn(n1, 1, 1, 4 * c, generator=g) / (4 * c) ** 0.5).cuda()
+    s1, h1 = (torch.rand(n1, generator=g) + 0.5).cuda(), (torch.randn(n1, generator=g) * 0.3).cuda()
+    assert hip.bottleneck_tail_s1_supported(hw, hw, c, n1) and not hip.bottleneck_tail_s1_supported(28, 28, 128) and not hip.bottleneck_tail_s1_supported(hw, hw, c, 128)
+    want = hip.bottleneck_tail_nhwc(y1, w2, s2, h2, w3, s3, h3, res)
+    w2p, w3p = hip.pack_mfma_fragments(w2), hip.pack_mfma_fragments(w3.view(4 * c, c))
+    if not fuse:
+        got = hip.bottleneck_tail_s1_nhwc(y1, w2p, s2, h2, w3p, s3, h3, res)
+        assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+        return
+    want1 = hip.conv2d_nhwc_bn_act(want, w1, s1, h1, relu=True)
+    got, got1 = hip.bottleneck_tail_s1_nhwc(y1, w2p, s2, h2, w3p, s3, h3, res, hip.pack_mfma_fragments(w1.view(n1, 4 * c)), s1, h1, n1)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    assert torch.equal(got1, want1), float((got1.float() - want1.float()).abs().max())
