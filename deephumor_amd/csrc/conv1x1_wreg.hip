@@ -26,6 +26,7 @@ namespace {
 struct C1Params {
     const uint16_t* x; const uint4* wp; const float* scale; const float* shift; uint16_t* y;
     const uint16_t* res;                                  // RES instances: residual rows [M, N]
+    const uint4* w1p; const float* scale1; const float* shift1; uint16_t* y1n;     // F1 instances: next conv1 (fragments [8][4][64]), [M, 64]
     int M, N, relu, nb_n, wg_per_n, nblk;
     // second source of the virtual operand [x | x2 at the strided pixels] (dual form; x2 == nullptr otherwise): k slabs ns1 .. come from
     // x2 [Nimg, H2, W2, C2]; row r = (n, oy, ox) of the Ho x Wo output grid reads pixel (n, oy * stride, ox * stride)
@@ -46,14 +47,19 @@ __device__ __forceinline__ void c1_dma16(const void* base, unsigned off, void* l
 // (8 x 64 KB per block at 128 B/clk = twice the block's MFMA time).  MEASURED: no gain -- TN = 2 with 4 waves 42 / 56 / 91 / 75 us, with 8
 // waves and 256 channels per workgroup 79.5 us for {200704 x 256 x 512}, against 36 / 53 / 76 / 59 us for TN = 1 with 8 waves: these layers
 // run at 3.6-4.9 TB/s of HBM traffic, not at the LDS read rate.  The dispatch uses TN = 1.
-template <typename OT, int KF, int RB, int TN, int NW, bool RES = false>      // TN = 1 or 2; RES: + residual [M, N] before the ReLU
+// F1 = 64 (the K = 128 dual instance, all 256 output channels in the workgroup): the NEXT bottleneck's conv1 + bn1 + relu (256 -> 64) on
+// the block's rounded outputs, which also go into an LDS operand tile [4 k blocks][RB rows][128 B] (conv_s1.hip does the same behind
+// the stage-1 tail): wave w = column tile w % 4 of the 64 channels x row tiles 4 (w / 4) .. + 3, its 8 weight fragments stationary
+template <typename OT, int KF, int RB, int TN, int NW, bool RES = false, int F1 = 0>      // TN = 1 or 2; RES: + residual [M, N] before the ReLU
 __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
     constexpr int K = 32 * KF, NSLAB = K / 64, SLABB = RB * 128, BUF = NSLAB * SLABB, TM = RB / 16, RG = RB / 8;
     constexpr int NT = 64 * NW, BN = 16 * NW * TN;         // output channels per workgroup
     constexpr int PPW = NSLAB * RG / NW;                  // LDS-DMA pieces per wave per block
     constexpr int PF = 3;
     static_assert(BUF <= 65536 && (NSLAB * RG) % NW == 0, "two buffers of <= 64 KB (one ds_read offset window each)");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + (TN > 1 ? BN * 8 : 0)];   // + this workgroup's scale | shift (TN > 1)
+    static_assert(F1 == 0 || (F1 == 64 && TN == 2 && NW == 8 && RB == 128), "the fused next conv1: the K = 128 dual instance only");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF + (TN > 1 ? BN * 8 : 0) + (F1 ? RB * 512 : 0)];   // + scale | shift (TN > 1) + out tile (F1)
+    unsigned char* const otile = lds + 2 * BUF + (TN > 1 ? BN * 8 : 0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, lq = lane >> 4, lr = lane >> 3, lpos = lane & 7;
@@ -79,6 +85,14 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
     if constexpr (TN > 1) {
         if (l15 == 0) { bn_lds[0] = sc4[0]; bn_lds[4] = sh4[0]; bn_lds[8] = sc4[TN - 1]; bn_lds[12] = sh4[TN - 1]; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    uint4 w1f[F1 ? 8 : 1];
+    float4 sc1 = make_float4(0.f, 0.f, 0.f, 0.f), sh1 = sc1;
+    if constexpr (F1 > 0) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) w1f[g] = p.w1p[(size_t)(g * (F1 / 16) + (wave & 3)) * 64 + lane];
+        sc1 = *reinterpret_cast<const float4*>(p.scale1 + 16 * (wave & 3) + 4 * lq);
+        sh1 = *reinterpret_cast<const float4*>(p.shift1 + 16 * (wave & 3) + 4 * lq);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // from here on only the counted operations below are in flight
 
@@ -125,7 +139,7 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
             if (nmine > 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RES ? 2 : 1) * TN * TM) : "memory");      // (RES: + block i - 1's residual loads)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((RES ? 2 : 1) * TN * TM + (F1 ? 4 : 0)) : "memory");   // (RES: + block i - 1's residual loads; F1: + its 4 y1_next stores)
         }
         __builtin_amdgcn_s_barrier();                     // every wave's pieces of block i landed AND every wave has left block i - 1
         if (i >= 1 && i + 1 < nmine) stage(b + step, buf ^ 1);   // block i + 1 into block i - 1's buffer: in flight during this block
@@ -182,7 +196,37 @@ __global__ __launch_bounds__(64 * NW, 1) void conv1x1_wreg_kernel(C1Params p) {
                 pk.y = (uint32_t)Op16<OT>::from_f32(v2) | ((uint32_t)Op16<OT>::from_f32(v3) << 16);
                 const int m = min(b * RB + 16 * t + l15, p.M - 1);
                 *reinterpret_cast<uint2*>(ybase + (size_t)m * p.N + 16 * c) = pk;
+                if constexpr (F1 > 0) {                  // the same 4 channels into the operand tile: k block, 16-byte chunk, half
+                    const int ch0 = 16 * (wave * TN + c) + 4 * lq, r = 16 * t + l15;
+                    *reinterpret_cast<uint2*>(otile + (ch0 >> 6) * (RB * 128) + r * 128 + ((((ch0 & 63) >> 3) ^ (r & 7)) << 4) + (lq & 1) * 8) = pk;
+                }
             }
+        if constexpr (F1 > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                 // the block's 256 channels of every row are in the tile
+            const int ct = wave & 3, rg = wave >> 2;
+            dh_f32x4 acc1[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) acc1[tt] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int g = 0; g < 8; ++g)                   // k = 32 g ..: k block g / 2, half g % 2
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                    const uint4 fb = *reinterpret_cast<const uint4*>(otile + (g >> 1) * (RB * 128) + (16 * (4 * rg + tt) + l15) * 128 +
+                                                                    ((((g & 1) * 4 + lq) ^ (l15 & 7)) << 4));
+                    acc1[tt] = Op16<OT>::mfma(w1f[g], fb, acc1[tt]);
+                }
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const float v0 = fmaxf(fmaf(acc1[tt][0], sc1.x, sh1.x), 0.f), v1 = fmaxf(fmaf(acc1[tt][1], sc1.y, sh1.y), 0.f);
+                const float v2 = fmaxf(fmaf(acc1[tt][2], sc1.z, sh1.z), 0.f), v3 = fmaxf(fmaf(acc1[tt][3], sc1.w, sh1.w), 0.f);
+                uint2 pk;
+                pk.x = (uint32_t)Op16<OT>::from_f32(v0) | ((uint32_t)Op16<OT>::from_f32(v1) << 16);
+                pk.y = (uint32_t)Op16<OT>::from_f32(v2) | ((uint32_t)Op16<OT>::from_f32(v3) << 16);
+                const int m = min(b * RB + 16 * (4 * rg + tt) + l15, p.M - 1);
+                *reinterpret_cast<uint2*>(p.y1n + (size_t)m * F1 + 16 * ct + 4 * lq) = pk;
+            }
+        }
     };
     for (int i = 0; i < nmine; i += 2) {
         block(std::integral_constant<int, 0>{}, i);
@@ -243,17 +287,22 @@ extern "C" int dh_conv1x1_dual_wreg_supported(int N, int Ho, int Wo, int H, int 
 // out [N, Ho, Wo, Cout] = relu?([y | x at (oy * stride, ox * stride)] w^T + shift); w_packed = dh_pack_mfma_fragments(w [Cout, C1 + C2]).
 // Bit-identical to dh_conv1x1_dual_nhwc.
 extern "C" int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const void* w_packed, const float* shift, void* out, int N, int Ho,
-                                         int Wo, int C1, int H, int W, int C2, int stride, int Cout, int relu, int dtype, void* stream) {
+                                         int Wo, int C1, int H, int W, int C2, int stride, int Cout, int relu, const void* w1_packed,
+                                         const float* scale1, const float* shift1, void* y1_next, int N1, int dtype, void* stream) {
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     const long long M = (long long)N * Ho * Wo;
     DH_REQUIRE(y && x && w_packed && shift && out && N > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0 && stride >= 1 &&
                dh_conv1x1_dual_wreg_supported(N, Ho, Wo, H, W, C1, C2, Cout));
     DH_REQUIRE((Ho - 1) * stride < H && (Wo - 1) * stride < W);
+    // the NEXT bottleneck's conv1 + bn1 + relu (Cout -> N1) in the same launch: the K = 128, Cout = 256, N1 = 64 instance (stage 1)
+    DH_REQUIRE(!w1_packed || (scale1 && shift1 && y1_next && N1 == 64 && C1 + C2 == 128 && Cout == 256 && relu == 1 && ((uintptr_t)w1_packed % 16) == 0 &&
+                              ((uintptr_t)scale1 % 16) == 0 && ((uintptr_t)shift1 % 16) == 0 && ((uintptr_t)y1_next % 16) == 0));
     DH_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)out % 16) == 0 &&
                ((uintptr_t)shift % 16) == 0);
     C1Params p{};
     p.x = (const uint16_t*)y; p.wp = (const uint4*)w_packed; p.scale = nullptr; p.shift = shift; p.y = (uint16_t*)out;
     p.M = (int)M; p.N = Cout; p.relu = relu; p.nb_n = Cout / 256; p.wg_per_n = 256 / p.nb_n; p.ns1 = C1 / 64;
+    p.w1p = (const uint4*)w1_packed; p.scale1 = scale1; p.shift1 = shift1; p.y1n = (uint16_t*)y1_next;
     p.x2 = (const uint16_t*)x; p.howo = Ho * Wo; p.wo = Wo; p.h2w2 = H * W; p.w2 = W; p.stride2 = stride; p.c2 = C2;
     p.magic_howo = (unsigned)((1ull << 32) / (unsigned)p.howo + 1); p.magic_wo = (unsigned)((1ull << 32) / (unsigned)Wo + 1);
     const int K = C1 + C2;
@@ -264,7 +313,8 @@ extern "C" int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const voi
                      2.0 * ((double)M * C1 + (double)M * C2 + (double)Cout * K + (double)M * Cout), stream);
     hipStream_t s = (hipStream_t)stream;
     DH_DISPATCH_16(dtype, {
-        if (K == 128) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 4, 128, 2, 8>), dim3(256), dim3(512), 0, s, p);
+        if (K == 128 && w1_packed) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 4, 128, 2, 8, false, 64>), dim3(256), dim3(512), 0, s, p);
+        else if (K == 128) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 4, 128, 2, 8>), dim3(256), dim3(512), 0, s, p);
         else if (K == 768) hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 24, 32, 2, 8>), dim3(256), dim3(512), 0, s, p);
         else hipLaunchKernelGGL((conv1x1_wreg_kernel<T, 12, 64, 2, 8>), dim3(256), dim3(512), 0, s, p);
     });

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 24
+ABI_VERSION = 25
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -83,7 +83,7 @@ SIGNATURES = {
     "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
     "dh_conv1x1_dual_wreg_supported": [_I] * 8,
-    "dh_conv1x1_dual_wreg_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
+    "dh_conv1x1_dual_wreg_nhwc": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P, _P, _P, _P, _I, _I, _P],
     "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_resize_u8_hwc": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_normalize_pack_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -995,16 +995,19 @@ def conv1x1_dual_wreg_supported(y_shape, x_shape, cout):
     return bool(load().dh_conv1x1_dual_wreg_supported(int(n), int(ho), int(wo), int(h), int(w), int(c1), int(c2), int(cout)))
 
 
-def conv1x1_dual_wreg_nhwc(y, x, w_packed, cout, shift, stride, relu=True):
+def conv1x1_dual_wreg_nhwc(y, x, w_packed, cout, shift, stride, relu=True, w1p=None, scale1=None, shift1=None, n1=0):
     """``conv1x1_dual_nhwc`` with the weights stationary in registers and the pixels of both sources streamed
-    (``w_packed = pack_mfma_fragments(w_cat)``; csrc/conv1x1_wreg.hip).  Bit-identical to ``conv1x1_dual_nhwc``."""
-    _dev(y, x, w_packed, shift)
+    (``w_packed = pack_mfma_fragments(w_cat)``; csrc/conv1x1_wreg.hip).  Bit-identical to ``conv1x1_dual_nhwc``.  With ``w1p``
+    (stage 1: K = 128, ``cout`` = 256, ``n1`` = 64) also the NEXT bottleneck's conv1 + bn1 + relu on the outputs while they are in
+    LDS: returns ``(out, y1_next)``."""
+    _dev(y, x, w_packed, shift, w1p, scale1, shift1)
     n, ho, wo, c1 = y.shape
     _, h, w_, c2 = x.shape
     out = torch.empty((n, ho, wo, cout), dtype=y.dtype, device=y.device)
+    y1n = torch.empty((n, ho, wo, n1), dtype=y.dtype, device=y.device) if w1p is not None else None
     _launch("dh_conv1x1_dual_wreg_nhwc", _ptr(y), _ptr(x), _ptr(w_packed), _ptr(shift), _ptr(out), n, ho, wo, c1, h, w_, c2, stride,
-            cout, int(relu), _dt(y), _stream())
-    return out
+            cout, int(relu), _ptr(w1p), _ptr(scale1), _ptr(shift1), _ptr(y1n), n1, _dt(y), _stream())
+    return out if w1p is None else (out, y1n)
 
 
 def normalize_u8_hwc(x, mean, std):

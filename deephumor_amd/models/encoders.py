@@ -305,6 +305,12 @@ class ImageEncoder(_Planned, nn.Module):
                 d = blk["dual"]
                 if ("wpk" in d and not os.environ.get("DH_NO_CONV1X1_WREG")
                         and hip.conv1x1_dual_wreg_supported(y.shape, x.shape, d["w"].shape[0])):
+                    if (nxt is not None and "wpkf" in nxt["c1"] and d["w"].shape == (256, 128) and nxt["c1"]["w"].shape[0] == 64
+                            and not os.environ.get("DH_NO_S1_CONV1_FUSION")):
+                        # layer1.0's ending + layer1.1's conv1 in one launch (the block's 256 output channels are in the workgroup)
+                        x, ready[bi + 1] = hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], 256, d["shift"], d["stride"], relu=True, w1p=nxt["c1"]["wpkf"],
+                                                                      scale1=nxt["c1"]["scale"], shift1=nxt["c1"]["shift"], n1=64)
+                        continue
                     x = hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], d["w"].shape[0], d["shift"], d["stride"], relu=True)
                     continue
                 x = hip.conv1x1_dual_nhwc(y, x, d["w"], d["shift"], d["stride"], relu=True)

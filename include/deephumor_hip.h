@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 24
+#define DH_ABI_VERSION 25
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -158,7 +158,10 @@ int dh_conv1x1_wreg_nhwc(const void* x, const void* w_packed, const float* scale
  * Cout a multiple of 256 (_supported).  w_packed = dh_pack_mfma_fragments(w [Cout, C1 + C2]).  Bit-identical to dh_conv1x1_dual_nhwc. */
 int dh_conv1x1_dual_wreg_supported(int N, int Ho, int Wo, int H, int W, int C1, int C2, int Cout);
 int dh_conv1x1_dual_wreg_nhwc(const void* y, const void* x, const void* w_packed, const float* shift, void* out, int N, int Ho, int Wo,
-                              int C1, int H, int W, int C2, int stride, int Cout, int relu, int dtype, void* stream);
+                              int C1, int H, int W, int C2, int stride, int Cout, int relu,
+                              const void* w1_packed /* or NULL: + the NEXT bottleneck's conv1 + bn1 + relu (Cout = 256 -> N1 = 64, C1 + C2 = 128) on the
+                              block's outputs while they are in LDS; dh_pack_mfma_fragments(w1' [64][256]) */,
+                              const float* scale1, const float* shift1, void* y1_next /* [N,Ho,Wo,N1] */, int N1, int dtype, void* stream);
 
 /* Stem of the bf16 path: conv 7x7/2 (or 3x3) + BN + ReLU reading the caller's NCHW fp32 image (fp32
  * weights [Cout,Cin,KS,KS]) on the vector ALUs and writing channels-last bf16 y [N,Ho,Wo,Cout]. */

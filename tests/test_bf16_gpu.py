@@ -934,3 +934,23 @@ def test_bottleneck_tail_s1_equals_fused_tail_and_next_conv1(hip, n, fuse):
     got, got1 = hip.bottleneck_tail_s1_nhwc(y1, w2p, s2, h2, w3p, s3, h3, res, hip.pack_mfma_fragments(w1.view(n1, 4 * c)), s1, h1, n1)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
     assert torch.equal(got1, want1), float((got1.float() - want1.float()).abs().max())
+
+
+@pytest.mark.parametrize("n", [3, 16])
+def test_conv1x1_dual_wreg_with_next_conv1(hip, n):
+    """The stage-1 dual launch (conv3 + downsample of layer1.0) with layer1.1's conv1 + bn1 + relu behind it on the outputs while they
+    are in LDS: both outputs against the two separate launches, bit for bit (a partial last block included)."""
+    g = torch.Generator().manual_seed(300 + n)
+    ho = 56
+    y = bf(torch.randn(n, ho, ho, 64, generator=g)).cuda()
+    x = bf(torch.randn(n, ho, ho, 64, generator=g)).cuda()
+    w = bf(torch.randn(256, 128, generator=g) / 128 ** 0.5).cuda()
+    shift = (torch.randn(256, generator=g) * 0.3).cuda()
+    w1 = bf(torch.randn(64, 1, 1, 256, generator=g) / 16).cuda()
+    s1, h1 = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.3).cuda()
+    want = hip.conv1x1_dual_nhwc(y, x, w, shift, 1, relu=True)
+    want1 = hip.conv2d_nhwc_bn_act(want, w1, s1, h1, relu=True)
+    got, got1 = hip.conv1x1_dual_wreg_nhwc(y, x, hip.pack_mfma_fragments(w), 256, shift, 1, relu=True, w1p=hip.pack_mfma_fragments(w1.view(64, 256)),
+                                           scale1=s1, shift1=h1, n1=64)
+    assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    assert torch.equal(got1, want1), float((got1.float() - want1.float()).abs().max())

@@ -160,7 +160,7 @@ def wreg_trial(rng, idx):
         ref = hip.conv1x1_dual_nhwc(y, x, w, shift, stride, relu=True)
         out, check = guarded((n, ho, ho, cout), dt)
         hip._launch("dh_conv1x1_dual_wreg_nhwc", hip._ptr(y), hip._ptr(x), hip._ptr(hip.pack_mfma_fragments(w)), hip._ptr(shift), hip._ptr(out),
-                    n, ho, ho, c1, h, h, c2, stride, cout, 1, hip._dt(y), hip._stream())
+                    n, ho, ho, c1, h, h, c2, stride, cout, 1, None, None, None, None, 0, hip._dt(y), hip._stream())
     else:
         n = rng.choice([1, 2, 3, rng.randint(4, 70)])
         x = torch.randn(n, 7, 7, 512, generator=g).to(dt).cuda()
