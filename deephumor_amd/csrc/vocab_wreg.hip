@@ -17,10 +17,11 @@
 //   * the 16 row-block workgroups that walk the same chunks sit on ONE XCD (blockIdx % 8): a chunk's 256 KB of weights is fetched into
 //     that L2 once.
 // MEASURED (1,280 x 36,541 x 512, per launch): back-to-back 58-61 us against 64-67 us for vocab_areg256_kernel (group maxima only: 46 / 50);
-// with the caches flushed between launches (320 MB read-modify-write) 92-99 against 73-78 us: the weight loads run RING - 1 = 15
-// k-steps (60 KB per wave) ahead, enough for L2 / Infinity Cache latency, not for HBM misses shared by 16 lock-stepped workgroups.
-// In the LSTM decode chain (C2) the weights survive in the Infinity Cache from one position to the next: step 7.37-7.40 against
-// 7.59-7.62 ms (three alternating runs) -- the default there; in the Transformer chain (~1 GB of KV cache per position in between) the
+// with the caches flushed between launches (320 MB read-modify-write) 88-91 against 72-75 us (92-99 before the chunk-major weight layout
+// and the next-chunk touch below; plain instead of non-temporal stores: 97): what the cold launch pays is not found yet -- not the
+// TLB reach of the weights, not the logits stores, not L2 misses of the ring loads.
+// In the LSTM decode chain (C2) the weights survive in the Infinity Cache from one position to the next: classifier 1.92-1.96 against
+// 2.11-2.16 ms per step, step 7.16-7.25 against 7.23-7.39 ms (three alternating runs) -- the default there; in the Transformer chain (~1 GB of KV cache per position in between) the
 // step takes the same time with either kernel: opt-in (DH_VOCAB_WREG_TRANSFORMER=1).  A ring of 8 lost in the chain (2.39 vs 2.11 ms of
 // classifier time per C2 step); plain instead of non-temporal logits stores lost there too (the 187 MB evict the weights).
 // Same MFMA chain per output as vocab_areg256_kernel / vocab_logits_kernel (weights = A operand, k ascending, one accumulator per
@@ -33,10 +34,10 @@
 namespace {
 struct VwParams {
     const uint16_t* A; int lda;
-    const uint4* wp;                                      // fragments of the padded weights [Vpad][512]: [(s * NT + tile) * 64 + lane]
+    const uint4* wp;                                      // fragments of the padded weights [Vpad][512], chunk-major: [((chunk * 16 + s) * 16 + tile) * 64 + lane]
     const float* bias;                                    // padded [Vpad]
     float* C; int ldc; float* gmax; int gmax_ld;
-    int M, V, NT, nrb, nchunk;
+    int M, V, NT, nrb, nchunk, nt;
 };
 
 __device__ __forceinline__ float4 vw_swap1(float4 v) {    // lane ^ 1
@@ -46,19 +47,24 @@ __device__ __forceinline__ float4 vw_swap1(float4 v) {    // lane ^ 1
 }
 // one 32-column half of a 16-row accumulator block as FULL 128-byte lines (gemm_bf16.hip, store_half_full_lines: same instruction
 // stream): lane pairs (l15, l15 ^ 1) swap one quad, an instruction then covers 8 rows x 128 bytes
-__device__ __forceinline__ void vw_store_half(float* r_even, size_t ldc, float4 va, float4 vb, bool odd) {
+__device__ __forceinline__ void vw_store_half(float* r_even, size_t ldc, float4 va, float4 vb, bool odd, bool nt) {
 #define VW_SEL4(c, a, b) make_float4((c) ? (a).x : (b).x, (c) ? (a).y : (b).y, (c) ? (a).z : (b).z, (c) ? (a).w : (b).w)
     const float4 own = VW_SEL4(odd, vb, va);
     const float4 rcv = vw_swap1(VW_SEL4(odd, va, vb));
     // non-temporal: 187 MB of logits per step stream THROUGH the L2 that holds the weight chunks the other row blocks are about to read
     typedef float vw_f4 __attribute__((ext_vector_type(4)));
     const float4 lo = VW_SEL4(odd, rcv, own), hi = VW_SEL4(odd, own, rcv);
-    __builtin_nontemporal_store(vw_f4{lo.x, lo.y, lo.z, lo.w}, reinterpret_cast<vw_f4*>(r_even));
-    __builtin_nontemporal_store(vw_f4{hi.x, hi.y, hi.z, hi.w}, reinterpret_cast<vw_f4*>(r_even + ldc));
+    if (nt) {
+        __builtin_nontemporal_store(vw_f4{lo.x, lo.y, lo.z, lo.w}, reinterpret_cast<vw_f4*>(r_even));
+        __builtin_nontemporal_store(vw_f4{hi.x, hi.y, hi.z, hi.w}, reinterpret_cast<vw_f4*>(r_even + ldc));
+    } else {
+        *reinterpret_cast<float4*>(r_even) = lo;
+        *reinterpret_cast<float4*>(r_even + ldc) = hi;
+    }
 #undef VW_SEL4
 }
 
-template <typename OT>
+template <typename OT, bool PREFETCH>
 __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
     constexpr int RB = 80, TM = 5, TN = 4, KS = 16, CB = 8, RING = 16, PF = 3;
     constexpr int PLANE = RB * 128;                       // 10 KB per 64-k plane
@@ -75,11 +81,13 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
     const int m0 = rb * RB;
 
     // ---- weight fragments of the first RING - 1 k-steps of the first chunk (plain loads: the compiler counts them) -----------------------
-    const size_t sstep = (size_t)p.NT * 64;               // uint4 elements between k-steps
-    const uint4* wbase = p.wp + (size_t)(wave * TN) * 64 + lane;                  // chunk c, step s, tile j: wbase[(s * NT + 16 c + j) * 64]
+    // chunk-major fragments: a chunk's 16 k-steps x 16 tiles are 256 KB contiguous (k-step-major over the whole vocabulary, every k-step
+    // of a chunk sat 2.3 MB from the next: 16 translations per chunk, and +25 us per launch with a cold TLB)
+    constexpr size_t sstep = 16 * 64;                     // uint4 elements between k-steps
+    const uint4* wbase = p.wp + (size_t)(wave * TN) * 64 + lane;                  // chunk c, step s, tile j: wbase[((c * 16 + s) * 16 + j) * 64]
     uint4 wq[RING][TN];
     {
-        const uint4* w0 = wbase + (size_t)(16 * cg) * 64;
+        const uint4* w0 = wbase + (size_t)cg * 16 * sstep;
 #pragma unroll
         for (int s = 0; s < RING - 1; ++s)
 #pragma unroll
@@ -104,12 +112,24 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
             asm volatile("" : "+v"(rd_base[kk][hf]));
         }
 
-    const uint4* wnext = wbase + (size_t)(16 * cg) * 64 + (size_t)(RING - 1) * sstep;      // fragments of step s + RING - 1
+    const uint4* wnext = wbase + (size_t)cg * 16 * sstep + (size_t)(RING - 1) * sstep;      // fragments of step s + RING - 1
 
 #pragma unroll 1
     for (int c = cg; c < p.nchunk; c += ncg) {
         const bool more = c + ncg < p.nchunk;
         const int n0 = c * 256 + wave * 64;               // this wave's 64 columns
+        // ONE of the walker's row-block workgroups (a different one per chunk) touches the NEXT chunk's weight lines now, a whole chunk
+        // time ahead: when the 37 MB of weights are not in the Infinity Cache (another 200+ MB moved since the last position) the 16
+        // lock-stepped workgroups otherwise all miss on the same lines with only 60 KB per wave in flight.  64 lanes x 8 loads of 4 bytes
+        // = the wave's 512 lines (16 k-steps x 4 KB); the values are not used.
+        uint32_t pfv[8];
+        const bool pf = PREFETCH && more && rb == (((c - cg) / ncg) & (p.nrb - 1));
+        if (pf) {
+            const unsigned char* nb = reinterpret_cast<const unsigned char*>(wbase - lane + (size_t)(c + ncg) * 16 * sstep);
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                pfv[e] = *reinterpret_cast<const uint32_t*>(nb + (size_t)(2 * e + (lane >> 5)) * sstep * 16 + (lane & 31) * 128);
+        }
         float4 b4[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) b4[j] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + 16 * j + 4 * lq) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
         for (int t = 0; t < KS * TM; ++t) {
             const int s = t / TM, i = t - s * TM;
             if (i == 0) {                                 // the weight fragments RING - 1 k-steps ahead: this chunk's, or the next chunk's first
-                if (s + RING - 1 == KS) wnext = wbase + (size_t)(16 * (c + ncg)) * 64;
+                if (s + RING - 1 == KS) wnext = wbase + (size_t)(c + ncg) * 16 * sstep;
                 if (s + RING - 1 < KS || more) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j) wq[(s + RING - 1) % RING][j] = wnext[j * 64];
@@ -157,11 +177,15 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
                 vb.x = acc[i][2 * h + 1][0] + b4[2 * h + 1].x; vb.y = acc[i][2 * h + 1][1] + b4[2 * h + 1].y;
                 vb.z = acc[i][2 * h + 1][2] + b4[2 * h + 1].z; vb.w = acc[i][2 * h + 1][3] + b4[2 * h + 1].w;
                 mxv = fmaxf(fmaxf(mxv, fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w))), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
-                if (p.C) vw_store_half(r_even + 32 * h, p.ldc, va, vb, l15 & 1);
+                if (p.C) vw_store_half(r_even + 32 * h, p.ldc, va, vb, l15 & 1, p.nt != 0);
             }
             mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
             mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
             if (p.gmax && lq == 0) p.gmax[(size_t)m * p.gmax_ld + n0 / 64] = n0 < p.V ? mxv : -INFINITY;      // -inf for a group that starts past V
+        }
+        if (pf) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" :: "v"(pfv[e]));
         }
     }
 }
@@ -177,7 +201,8 @@ extern "C" int dh_vocab_logits_wreg_supported(int M, int V, int K, int ldl, int 
 }
 
 // logits [M, ldl] fp32 (may be NULL: group maxima only) and group_max [M, gm_ld] as dh_vocab_logits writes them, from
-// w_packed = dh_pack_mfma_fragments(W padded to Vpad = ceil(V / 256) * 256 rows with copies of row V - 1) and bias_padded [Vpad]
+// w_packed = dh_pack_mfma_fragments(W padded to Vpad = ceil(V / 256) * 256 rows with copies of row V - 1), re-ordered chunk-major
+// ([k-step][Vpad / 16 tiles] -> [Vpad / 256 chunks][k-step][16 tiles]; deephumor_amd.hip.pack_vocab_weights), and bias_padded [Vpad]
 // (padded likewise; NULL = no bias).  Bit-identical to dh_vocab_logits on the columns [0, Vpad).
 extern "C" int dh_vocab_logits_wreg(const void* A, int lda, const void* w_packed, const float* bias_padded, float* logits, int ldl,
                                     float* group_max, int gm_ld, int M, int V, int K, int dtype, void* stream) {
@@ -192,6 +217,12 @@ extern "C" int dh_vocab_logits_wreg(const void* A, int lda, const void* w_packed
     dh_prof_set_dims(M, V, K);
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);
     hipStream_t s = (hipStream_t)stream;
-    DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_wreg_kernel<T>), dim3(256), dim3(256), 0, s, p));
+    static const int nt_stores = getenv("DH_VOCAB_WREG_NT") ? atoi(getenv("DH_VOCAB_WREG_NT")) : 1;
+    p.nt = nt_stores;
+    static const bool prefetch = !(getenv("DH_VOCAB_WREG_PREFETCH") && atoi(getenv("DH_VOCAB_WREG_PREFETCH")) == 0);
+    DH_DISPATCH_16(dtype, {
+        if (prefetch) hipLaunchKernelGGL((vocab_wreg_kernel<T, true>), dim3(256), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((vocab_wreg_kernel<T, false>), dim3(256), dim3(256), 0, s, p);
+    });
     DH_LAUNCH_CHECK();
 }

@@ -857,7 +857,10 @@ def pack_vocab_weights(w, bias):
     v = w.shape[0]
     vpad = (v + 255) // 256 * 256
     idx = torch.clamp(torch.arange(vpad, device=w.device), max=v - 1)
-    return pack_mfma_fragments(w.index_select(0, idx).contiguous()), (bias.float().index_select(0, idx).contiguous() if bias is not None else None)
+    frag = pack_mfma_fragments(w.index_select(0, idx).contiguous())           # [k-step][vpad / 16 tiles][64 lanes x 8 elements]
+    k32 = w.shape[1] // 32
+    frag = frag.view(k32, vpad // 256, 16, 512).permute(1, 0, 2, 3).contiguous().view(-1)      # chunk-major: 256 KB contiguous per 256 columns
+    return frag, (bias.float().index_select(0, idx).contiguous() if bias is not None else None)
 
 
 def vocab_logits_wreg_supported(m, v, k, ldl, gm_ld):
