@@ -954,3 +954,26 @@ def test_conv1x1_dual_wreg_with_next_conv1(hip, n):
                                            scale1=s1, shift1=h1, n1=64)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
     assert torch.equal(got1, want1), float((got1.float() - want1.float()).abs().max())
+
+
+@pytest.mark.parametrize("n", [4, 48])
+def test_encoder_round4_kernels_equal_the_kernels_they_replace(n, monkeypatch):
+    """The whole 16-bit encoder with the round-4 kernels (streaming 1x1 / dual layers, the register-streamed stage-1 / 2 / 4 kernels, the
+    next bottleneck's conv1 fused behind the stage-1 dual launch and the stage-1 tail) against the same encoder with every one of them
+    switched off: embeddings and spatial features bit for bit, at a batch where only some of them engage (4 images) and at one where
+    all do (48)."""
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import synth_state_dict
+    enc = M.ImageEncoder(256, spatial_features=True).eval()
+    enc.load_state_dict(synth_state_dict(enc.state_dict(), seed=4242))
+    enc = enc.cuda().to(HALF)
+    x = synth_images(n, seed=77).cuda()
+    with torch.no_grad():
+        emb, sp = enc(x)
+        for k in ("DH_NO_CONV1X1_WREG", "DH_NO_CONV_S4", "DH_NO_S2_TAIL", "DH_NO_S1_CONV1_FUSION"):
+            monkeypatch.setenv(k, "1")
+        emb0, sp0 = enc(x)
+        monkeypatch.delenv("DH_NO_S1_CONV1_FUSION")                 # the fusions alone on top of the tile / ring kernels
+        emb1, sp1 = enc(x)
+    assert torch.equal(emb, emb0) and torch.equal(sp, sp0)
+    assert torch.equal(emb, emb1) and torch.equal(sp, sp1)
