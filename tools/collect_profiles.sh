@@ -17,8 +17,9 @@ for wl in c2 c3; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d /tmp/pmc_${wl}_mfma -o p -- python3 $R/bench.py --workload $wl --steps 1 --warmup 1 --quick > /dev/null 2>&1
   python3 $R/tools/rocpd_stats.py /tmp/pmc_${wl}_mfma/p_results.db --pmc --top 0 --csv $OUT/pmc_${wl}_mfma.csv
 done
-# SQ-level PMC (wait / issue / LDS / MFMA counters) of the stand-alone probes: classifier, stage-3 bottleneck tail, LSTM step, decode GEMMs
-for pr in vocab_probe s3_probe lstm_probe kbench; do
+# SQ-level PMC (wait / issue / LDS / MFMA counters) of the stand-alone probes: classifier (both kernels), stage-3 bottleneck tail, the round-4
+# encoder kernels, LSTM step, decode GEMMs
+for pr in vocab_probe s3_probe enc_probe lstm_probe kbench; do
   bash $R/tools/pmc_sq.sh $pr $R/tools/$pr.py > /dev/null 2>&1
 done
 cp $R/gpurun_out/pmc_sq/*.csv $OUT/ 2>/dev/null

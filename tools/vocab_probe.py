@@ -24,3 +24,9 @@ def timeit(fn, iters=40, warm=5):
 print("logits ", os.environ.get("DH_VOCAB_TILE", "128"), timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, logits, gm)))
 print("gmax   ", os.environ.get("DH_VOCAB_GMAX_TILE", "256"), timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, None, gm)))
 print("logprob", os.environ.get("DH_LOGPROB_TILE", "auto"), timeit(lambda i: hip.vocab_logprob(a[i % 4], w, b, tg)))
+vpad = (V + 255) // 256 * 256
+if K == 512 and hip.vocab_logits_wreg_supported(M, V, K, vpad, vpad // 64):      # round 4: weights streamed from L2 into registers
+    wp, bp = hip.pack_vocab_weights(w, b)
+    lg2, gm2 = torch.empty(M, vpad, device=dev), torch.empty(M, vpad // 64, device=dev)
+    print("wreg logits ", timeit(lambda i: hip.vocab_logits_wreg(a[i % 4], wp, bp, V, lg2, gm2)))
+    print("wreg gmax   ", timeit(lambda i: hip.vocab_logits_wreg(a[i % 4], wp, bp, V, None, gm2)))
