@@ -29,10 +29,13 @@ struct S2Params {
     const uint4* w2p; const uint4* w3p;                  // fragment-packed [36][8][64] and [4][32][64] uint4
     const float* scale2; const float* shift2; const float* scale3; const float* shift3;
     const uint16_t* res; uint16_t* out;                  // [N,28,28,512]
+    const uint4* w1p; const float* scale1; const float* shift1; uint16_t* y1n;      // next conv1 (FUSE1): fragments [16][8][64], [N,28,28,128]
 };
 
-template <typename OT>
-__global__ __launch_bounds__(256, 3) void conv_s2_kernel(S2Params p) {
+// FUSE1: + the NEXT bottleneck's conv1 + bn1 + relu (512 -> 128) on the rounded output chunks, through a second LDS operand tile (as
+// conv_s1.hip): two workgroups per CU instead of three, two barriers per chunk
+template <typename OT, bool FUSE1>
+__global__ __launch_bounds__(256, FUSE1 ? 2 : 3) void conv_s2_kernel(S2Params p) {
     constexpr int C = 128, CB = 2, HW = 28, TR = 4, PITCH = HW + 2, NPX = TR * HW, TM = 7, TN = 2, NW = 4;
     constexpr int NPP = (TR + 2) * PITCH, PP_ROWS = (NPP + 7) / 8 * 8, NPIECE = CB * PP_ROWS / 8;      // 180 patch pixels in 184 slots
     constexpr int PLANE = PP_ROWS * 128, PATCH = CB * PLANE;                 // 23 KB per 64-channel plane
@@ -40,7 +43,9 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(S2Params p) {
     constexpr int NSTEP2 = 9 * CB * 2, SPT = CB * 2;                         // k32 steps of the 3x3; steps per tap
     constexpr int NT2 = C / 16, NT3 = 4 * C / 16, KS3 = C / 32;              // row tiles of the packed weights; k-steps of the 1x1
     constexpr int PF = 3;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[PATCH];
+    constexpr int N1 = 128, TN1 = 2, NT1 = N1 / 16;      // next conv1: this wave's 32 of its 128 output channels
+    __shared__ __attribute__((aligned(16))) unsigned char lds[PATCH + (FUSE1 ? CB * YPLANE : 0)];
+    unsigned char* const otile = lds + PATCH;            // FUSE1: the rounded output chunk [k block][112 pixels][128 B]
     static_assert(NPX == TM * 16 && CB * YPLANE + NW * 2048 <= PATCH, "y2 tile + the per-wave fp32 strips live in the dead patch");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -157,6 +162,14 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(S2Params p) {
     const int epx = lane >> 2, ec4 = lane & 3;            // epilogue lane role: pixel of the tile, 8-channel group
     const size_t pix0 = ((size_t)n * HW + y0) * HW;
     const unsigned a3 = (unsigned)(l15 * 128 + ((lq ^ (l15 & 7)) << 4));      // (16 i + l15) & 7 == l15 & 7
+    dh_f32x4 acc1[TM][FUSE1 ? TN1 : 1];
+    const uint4* w1 = p.w1p + (size_t)(TN1 * wave) * 64 + lane;              // step g (0 .. 15), tile j: w1[(g * NT1 + j) * 64]
+    if constexpr (FUSE1) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN1; ++j) acc1[i][j] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
         // this lane's residual chunks: the first RQ tiles requested before the MFMAs, tile i + RQ from tile i's epilogue
@@ -166,6 +179,13 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(S2Params p) {
         const uint16_t* resp = p.res + pix0 * (4 * C) + cbase;
 #pragma unroll
         for (int i = 0; i < RQ; ++i) rq[i] = *reinterpret_cast<const uint4*>(resp + (size_t)(16 * i + epx) * (4 * C));
+        uint4 w1q[KS3][FUSE1 ? TN1 : 1];                 // the chunk's four k-steps of the next conv1's weights, requested before the MFMAs
+        if constexpr (FUSE1) {
+#pragma unroll
+            for (int g = 0; g < KS3; ++g)
+#pragma unroll
+                for (int j = 0; j < TN1; ++j) w1q[g][j] = w1[(size_t)((KS3 * c + g) * NT1 + j) * 64];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -197,6 +217,7 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(S2Params p) {
         asm volatile("" ::: "memory");
         const float4 s3a = *reinterpret_cast<const float4*>(p.scale3 + cbase), s3b = *reinterpret_cast<const float4*>(p.scale3 + cbase + 4);
         const float4 h3a = *reinterpret_cast<const float4*>(p.shift3 + cbase), h3b = *reinterpret_cast<const float4*>(p.shift3 + cbase + 4);
+        if constexpr (FUSE1) { if (c > 0) __syncthreads(); }      // every wave has finished the previous chunk's conv1' reads of the out tile
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             // accumulator layout -> strip: lane (pixel l15, quarter lq) holds channels 16 j + 4 lq .. + 3 = 16-byte chunk 4 j + lq
@@ -218,7 +239,54 @@ __global__ __launch_bounds__(256, 3) void conv_s2_kernel(S2Params p) {
                 Op16<OT>::unpack2(w4[u], lo16, hi16);
                 v[2 * u] = fmaxf(v[2 * u] + lo16, 0.f); v[2 * u + 1] = fmaxf(v[2 * u + 1] + hi16, 0.f);
             }
-            store16(reinterpret_cast<OT*>(p.out) + (pix0 + 16 * i + epx) * (4 * C) + cbase, v);
+            uint4 o16;
+            o16.x = (uint32_t)Op16<OT>::from_f32(v[0]) | ((uint32_t)Op16<OT>::from_f32(v[1]) << 16);
+            o16.y = (uint32_t)Op16<OT>::from_f32(v[2]) | ((uint32_t)Op16<OT>::from_f32(v[3]) << 16);
+            o16.z = (uint32_t)Op16<OT>::from_f32(v[4]) | ((uint32_t)Op16<OT>::from_f32(v[5]) << 16);
+            o16.w = (uint32_t)Op16<OT>::from_f32(v[6]) | ((uint32_t)Op16<OT>::from_f32(v[7]) << 16);
+            *reinterpret_cast<uint4*>(p.out + (pix0 + 16 * i + epx) * (4 * C) + cbase) = o16;
+            if constexpr (FUSE1) {
+                // the same 8 channels (chunk-local 32 wave + 8 ec4 ..) of pixel q into the operand tile: k block wave / 2, chunk 4 (wave % 2) + ec4
+                const int q = 16 * i + epx;
+                *reinterpret_cast<uint4*>(otile + (wave >> 1) * YPLANE + q * 128 + (((4 * (wave & 1) + ec4) ^ (q & 7)) << 4)) = o16;
+            }
+        }
+        if constexpr (FUSE1) {
+            __syncthreads();                              // the chunk's 128 channels of every pixel are in the tile
+            // ---- next conv1: k = 128 c .. 128 c + 127 (four k-steps), this wave's 32 channels x 7 row tiles -----------------------------------
+            uint4 fb[PF + 1];
+            auto rd1 = [&](int t) {
+                const int u = t / TM, i = t - u * TM;
+                fb[t % (PF + 1)] = *reinterpret_cast<const uint4*>(otile + (u >> 1) * YPLANE + ((a3 ^ ((u & 1) << 6)) + i * 2048));
+            };
+#pragma unroll
+            for (int t = 0; t < PF; ++t) rd1(t);
+#pragma unroll
+            for (int t = 0; t < KS3 * TM; ++t) {
+                const int u = t / TM, i = t - u * TM;
+                if (t + PF < KS3 * TM) rd1(t + PF);
+#pragma unroll
+                for (int j = 0; j < TN1; ++j) acc1[i][j] = Op16<OT>::mfma(w1q[u][j], fb[t % (PF + 1)], acc1[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    if constexpr (FUSE1) {
+        // ---- y1_next = relu(bn1'(conv1')): acc1[i][j][r] = pixel 16 i + l15, channel 32 wave + 16 j + 4 lq + r ---------------------------------
+        const int c1 = 32 * wave + 4 * lq;
+        uint16_t* const o1 = p.y1n + (pix0 + l15) * N1 + c1;
+#pragma unroll
+        for (int j = 0; j < TN1; ++j) {
+            const float4 sc1 = *reinterpret_cast<const float4*>(p.scale1 + c1 + 16 * j), sh1 = *reinterpret_cast<const float4*>(p.shift1 + c1 + 16 * j);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float v0 = fmaxf(fmaf(acc1[i][j][0], sc1.x, sh1.x), 0.f), v1 = fmaxf(fmaf(acc1[i][j][1], sc1.y, sh1.y), 0.f);
+                const float v2 = fmaxf(fmaf(acc1[i][j][2], sc1.z, sh1.z), 0.f), v3 = fmaxf(fmaf(acc1[i][j][3], sc1.w, sh1.w), 0.f);
+                uint2 o;
+                o.x = (uint32_t)Op16<OT>::from_f32(v0) | ((uint32_t)Op16<OT>::from_f32(v1) << 16);
+                o.y = (uint32_t)Op16<OT>::from_f32(v2) | ((uint32_t)Op16<OT>::from_f32(v3) << 16);
+                *reinterpret_cast<uint2*>(o1 + (size_t)(16 * i) * N1 + 16 * j) = o;
+            }
         }
     }
 }
@@ -230,10 +298,14 @@ extern "C" int dh_bottleneck_tail_s2_supported(int H, int W, int C) { return H =
 // w3_packed = dh_pack_mfma_fragments(w3 [512][128]).  Bit-identical to dh_bottleneck_tail_nhwc.
 extern "C" int dh_bottleneck_tail_s2_nhwc(const void* y1, const void* w2_packed, const float* scale2, const float* shift2,
                                           const void* w3_packed, const float* scale3, const float* shift3, const void* residual,
-                                          void* out, int N, int H, int W, int C, int dtype, void* stream) {
+                                          void* out, const void* w1_packed, const float* scale1, const float* shift1, void* y1_next, int N1,
+                                          int N, int H, int W, int C, int dtype, void* stream) {
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
     DH_REQUIRE(y1 && w2_packed && scale2 && shift2 && w3_packed && scale3 && shift3 && residual && out && N > 0 &&
                dh_bottleneck_tail_s2_supported(H, W, C) && (long long)N * (H / 4) < (1ll << 31));
+    // the NEXT bottleneck's conv1 + bn1 + relu (512 -> 128) in the same launch
+    DH_REQUIRE(!w1_packed || (scale1 && shift1 && y1_next && N1 == 128 && ((uintptr_t)w1_packed % 16) == 0 && ((uintptr_t)scale1 % 16) == 0 &&
+                              ((uintptr_t)shift1 % 16) == 0 && ((uintptr_t)y1_next % 16) == 0));
     DH_REQUIRE(((uintptr_t)y1 % 16) == 0 && ((uintptr_t)w2_packed % 16) == 0 && ((uintptr_t)w3_packed % 16) == 0 &&
                ((uintptr_t)residual % 16) == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)scale2 % 16) == 0 &&
                ((uintptr_t)shift2 % 16) == 0 && ((uintptr_t)scale3 % 16) == 0 && ((uintptr_t)shift3 % 16) == 0);
@@ -241,12 +313,17 @@ extern "C" int dh_bottleneck_tail_s2_nhwc(const void* y1, const void* w2_packed,
     p.x = (const uint16_t*)y1; p.w2p = (const uint4*)w2_packed; p.w3p = (const uint4*)w3_packed;
     p.scale2 = scale2; p.shift2 = shift2; p.scale3 = scale3; p.shift3 = shift3;
     p.res = (const uint16_t*)residual; p.out = (uint16_t*)out;
+    p.w1p = (const uint4*)w1_packed; p.scale1 = scale1; p.shift1 = shift1; p.y1n = (uint16_t*)y1_next;
     const double px = (double)N * H * W;
-    dh_prof_set_tag("3x3+1x1");
-    dh_prof_set_dims(N * H * W, 4 * C, 9 * C + C / 4);
-    DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * px * C * 9.0 * C + 2.0 * px * 4.0 * C * C,
-                     2.0 * (px * C + 9.0 * C * C + 4.0 * C * C + 2.0 * px * 4 * C), stream);
+    const int n1 = w1_packed ? N1 : 0;
+    dh_prof_set_tag(n1 ? "3x3+1x1+1x1" : "3x3+1x1");
+    dh_prof_set_dims(N * H * W, 4 * C, 9 * C + C / 4 + n1);
+    DhProfScope prof("dh_conv2d_nhwc_bn_act", 2.0 * px * C * 9.0 * C + 2.0 * px * 4.0 * C * C + 2.0 * px * 4.0 * C * n1,
+                     2.0 * (px * C + 9.0 * C * C + 4.0 * C * C + 2.0 * px * 4 * C + px * n1 + 4.0 * C * n1), stream);
     hipStream_t s = (hipStream_t)stream;
-    DH_DISPATCH_16(dtype, hipLaunchKernelGGL((conv_s2_kernel<T>), dim3(N * (H / 4)), dim3(256), 0, s, p));
+    DH_DISPATCH_16(dtype, {
+        if (n1) hipLaunchKernelGGL((conv_s2_kernel<T, true>), dim3(N * (H / 4)), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((conv_s2_kernel<T, false>), dim3(N * (H / 4)), dim3(256), 0, s, p);
+    });
     DH_LAUNCH_CHECK();
 }

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 25
+ABI_VERSION = 26
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -73,7 +73,7 @@ SIGNATURES = {
     "dh_bottleneck_tail_s1_supported": [_I, _I, _I, _I],
     "dh_bottleneck_tail_s1_nhwc": [_P] * 13 + [_I] * 6 + [_P],
     "dh_bottleneck_tail_s2_supported": [_I, _I, _I],
-    "dh_bottleneck_tail_s2_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_bottleneck_tail_s2_nhwc": [_P] * 13 + [_I] * 6 + [_P],
     "dh_conv3x3_s4_supported": [_I, _I, _I],
     "dh_conv3x3_s4_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dh_bottleneck_tail_s3_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -598,14 +598,17 @@ def bottleneck_tail_s2_supported(h, w, c):
     return bool(load().dh_bottleneck_tail_s2_supported(int(h), int(w), int(c)))
 
 
-def bottleneck_tail_s2_nhwc(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual):
-    """``dh_bottleneck_tail_s2_nhwc``: the stage-2 bottleneck tail on fragment-packed weights; bit-identical to ``bottleneck_tail_nhwc``."""
-    _dev(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual)
+def bottleneck_tail_s2_nhwc(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual, w1p=None, scale1=None, shift1=None, n1=0):
+    """``dh_bottleneck_tail_s2_nhwc``: the stage-2 bottleneck tail on fragment-packed weights; bit-identical to ``bottleneck_tail_nhwc``.
+    With ``w1p`` also the NEXT bottleneck's conv1 + bn1 + relu (512 -> 128) on the output chunks while they are in LDS: returns
+    ``(out, y1_next)``."""
+    _dev(y1, w2p, scale2, shift2, w3p, scale3, shift3, residual, w1p, scale1, shift1)
     n, h, w, c = y1.shape
     out = torch.empty((n, h, w, 4 * c), dtype=y1.dtype, device=y1.device)
+    y1n = torch.empty((n, h, w, n1), dtype=y1.dtype, device=y1.device) if w1p is not None else None
     _launch("dh_bottleneck_tail_s2_nhwc", _ptr(y1), _ptr(w2p), _ptr(scale2), _ptr(shift2), _ptr(w3p), _ptr(scale3), _ptr(shift3),
-            _ptr(residual), _ptr(out), n, h, w, c, _dt(y1), _stream())
-    return out
+            _ptr(residual), _ptr(out), _ptr(w1p), _ptr(scale1), _ptr(shift1), _ptr(y1n), n1, n, h, w, c, _dt(y1), _stream())
+    return out if w1p is None else (out, y1n)
 
 
 def conv3x3_s4_supported(h, w, c):

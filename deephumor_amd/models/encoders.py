@@ -194,6 +194,8 @@ class ImageEncoder(_Planned, nn.Module):
                     # stage-2 blocks: the same structure on 4-row strips, three workgroups per CU (conv_s2.hip)
                     ent["w2p2"] = hip.pack_mfma_fragments(ent["c2"]["w"])
                     ent["w3p2"] = hip.pack_mfma_fragments(ent["c3"]["w"].reshape(ent["c3"]["w"].shape[0], -1).contiguous())
+                    if (tuple(c1w.shape[1:3]) == (1, 1) and ent["c1"]["stride"] == 1 and ent["c1"]["relu"] and tuple(c1w.shape[::3]) == (128, 512)):
+                        ent["c1"]["wpkf"] = hip.pack_mfma_fragments(c1w.reshape(128, 512).contiguous())     # for the previous tail to run it
                 c3w = ent["c3"]["w"]
                 if (bf16 and c3w.is_cuda and ent["down"] is None and tuple(c3w.shape[1:]) == (1, 1, 512) and c3w.shape[0] % 128 == 0
                         and c3w.shape[0] // 128 in (1, 2, 4, 8, 16)):
@@ -287,7 +289,14 @@ class ImageEncoder(_Planned, nn.Module):
                 continue
             if (nhwc and "w2p2" in blk and hip.bottleneck_tail_s2_supported(x.shape[1], x.shape[2], c2["w"].shape[0])
                     and not os.environ.get("DH_NO_FUSED_TAIL") and not os.environ.get("DH_NO_S2_TAIL")):
-                y1 = self._conv(x, blk["c1"], nhwc=True)
+                y1 = ready.pop(bi, None)
+                if y1 is None:
+                    y1 = self._conv(x, blk["c1"], nhwc=True)
+                if (nxt is not None and "wpkf" in nxt["c1"] and "w2p2" in nxt and not os.environ.get("DH_NO_S2_CONV1_FUSION")):
+                    # + the next block's conv1 (512 -> 128) on the output chunks in LDS: 170 us against 135 + 55 us
+                    x, ready[bi + 1] = hip.bottleneck_tail_s2_nhwc(y1, blk["w2p2"], c2["scale"], c2["shift"], blk["w3p2"], c3["scale"], c3["shift"], x,
+                                                                   nxt["c1"]["wpkf"], nxt["c1"]["scale"], nxt["c1"]["shift"], 128)
+                    continue
                 x = hip.bottleneck_tail_s2_nhwc(y1, blk["w2p2"], c2["scale"], c2["shift"], blk["w3p2"], c3["scale"], c3["shift"], x)
                 continue
             if (nhwc and blk["dual"] is None and blk["down"] is None and c2["stride"] == 1 and c2["w"].shape[1] == 3

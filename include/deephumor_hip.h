@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 25
+#define DH_ABI_VERSION 26
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -130,8 +130,11 @@ int dh_bottleneck_tail_s1_nhwc(const void* y1, const void* w2_packed, const floa
  * Bit-identical to dh_bottleneck_tail_nhwc. */
 int dh_bottleneck_tail_s2_supported(int H, int W, int C);
 int dh_bottleneck_tail_s2_nhwc(const void* y1, const void* w2_packed, const float* scale2, const float* shift2,
-                               const void* w3_packed, const float* scale3, const float* shift3, const void* residual,
-                               void* out, int N, int H, int W, int C, int dtype, void* stream);
+                               const void* w3_packed, const float* scale3, const float* shift3, const void* residual, void* out,
+                               const void* w1_packed /* or NULL: + the NEXT bottleneck's conv1 + bn1 + relu (512 -> N1 = 128) on the output
+                               chunks while they are in LDS; dh_pack_mfma_fragments(w1' [128][512]) */,
+                               const float* scale1, const float* shift1, void* y1_next /* [N,28,28,N1] */, int N1,
+                               int N, int H, int W, int C, int dtype, void* stream);
 
 /* conv2 (3x3, stride 1) + bn2 + relu of the STAGE-4 bottlenecks without downsample (7 x 7 x 512; torchvision Bottleneck.conv2 / bn2 /
  * relu of layer4.1-2, encoders.py:37-38): a workgroup = (two images, half of the output channels), pixels resident in LDS without a

@@ -906,6 +906,13 @@ def test_bottleneck_tail_s2_equals_fused_tail(hip, n):
     got = hip.bottleneck_tail_s2_nhwc(y1, hip.pack_mfma_fragments(w2), s2, h2, hip.pack_mfma_fragments(w3.view(4 * c, c)), s3, h3, res)
     assert torch.equal(want, want2)
     assert torch.equal(got, want), float((got.float() - want.float()).abs().max())
+    # + the NEXT bottleneck's conv1 (512 -> 128) on the output chunks while they are in LDS: both outputs against the two launches
+    w1 = bf(torch.randn(128, 1, 1, 4 * c, generator=g) / (4 * c) ** 0.5).cuda()
+    s1, h1 = (torch.rand(128, generator=g) + 0.5).cuda(), (torch.randn(128, generator=g) * 0.3).cuda()
+    want1 = hip.conv2d_nhwc_bn_act(want, w1, s1, h1, relu=True)
+    gotf, got1 = hip.bottleneck_tail_s2_nhwc(y1, hip.pack_mfma_fragments(w2), s2, h2, hip.pack_mfma_fragments(w3.view(4 * c, c)), s3, h3, res,
+                                             hip.pack_mfma_fragments(w1.view(128, 4 * c)), s1, h1, 128)
+    assert torch.equal(gotf, want) and torch.equal(got1, want1), float((got1.float() - want1.float()).abs().max())
 
 
 @pytest.mark.parametrize("n,fuse", [(1, False), (2, True), (5, True), (16, False)])
@@ -970,10 +977,11 @@ def test_encoder_round4_kernels_equal_the_kernels_they_replace(n, monkeypatch):
     x = synth_images(n, seed=77).cuda()
     with torch.no_grad():
         emb, sp = enc(x)
-        for k in ("DH_NO_CONV1X1_WREG", "DH_NO_CONV_S4", "DH_NO_S2_TAIL", "DH_NO_S1_CONV1_FUSION"):
+        for k in ("DH_NO_CONV1X1_WREG", "DH_NO_CONV_S4", "DH_NO_S2_TAIL", "DH_NO_S1_CONV1_FUSION", "DH_NO_S2_CONV1_FUSION"):
             monkeypatch.setenv(k, "1")
         emb0, sp0 = enc(x)
-        monkeypatch.delenv("DH_NO_S1_CONV1_FUSION")                 # the fusions alone on top of the tile / ring kernels
+        monkeypatch.delenv("DH_NO_S1_CONV1_FUSION")                 # the stage-1 fusions alone on top of the tile / ring kernels
+        monkeypatch.delenv("DH_NO_S2_TAIL")                         # ... and the stage-2 strip tail without its fusion
         emb1, sp1 = enc(x)
     assert torch.equal(emb, emb0) and torch.equal(sp, sp0)
     assert torch.equal(emb, emb1) and torch.equal(sp, sp1)
