@@ -78,10 +78,10 @@ def nhwc_trial(rng, idx):
 def direct_trial(rng, idx):
     g = torch.Generator().manual_seed(50000 + idx)
     dt = rng.choice([torch.bfloat16, torch.float16])
-    which = rng.choice(["c3_56", "c3_28", "tail_56", "tail_56_s1", "tail_56_s1f", "tail_28", "tail_28_s2", "s3", "s3_conv2"])
+    which = rng.choice(["c3_56", "c3_28", "tail_56", "tail_56_s1", "tail_56_s1f", "tail_28", "tail_28_s2", "tail_28_s2f", "s3", "s3_conv2"])
     n = rng.choice([1, 2, 3, rng.randint(4, 40)])
     rec = dict(kind="direct", which=which, dt=str(dt)[6:], N=n)
-    hw, c = {"c3_56": (56, 64), "tail_56": (56, 64), "tail_56_s1": (56, 64), "tail_56_s1f": (56, 64), "c3_28": (28, 128), "tail_28": (28, 128), "tail_28_s2": (28, 128), "s3": (14, 256), "s3_conv2": (14, 256)}[which]
+    hw, c = {"c3_56": (56, 64), "tail_56": (56, 64), "tail_56_s1": (56, 64), "tail_56_s1f": (56, 64), "c3_28": (28, 128), "tail_28": (28, 128), "tail_28_s2": (28, 128), "tail_28_s2f": (28, 128), "s3": (14, 256), "s3_conv2": (14, 256)}[which]
     y1 = torch.randn(n, hw, hw, c, generator=g).to(dt).cuda()
     w2 = (torch.randn(c, 3, 3, c, generator=g) / (9 * c) ** 0.5).to(dt).cuda()
     s2, h2 = (torch.rand(c, generator=g) + 0.5).cuda(), torch.randn(c, generator=g).cuda()
@@ -106,6 +106,13 @@ def direct_trial(rng, idx):
             s1, h1 = (torch.rand(64, generator=g) + 0.5).cuda(), torch.randn(64, generator=g).cuda()
             got, got1 = hip.bottleneck_tail_s1_nhwc(y1, hip.pack_mfma_fragments(w2), s2, h2, hip.pack_mfma_fragments(w3.view(4 * c, c)), s3, h3, res,
                                                     hip.pack_mfma_fragments(w1.view(64, 4 * c)), s1, h1, 64)
+            ref1 = hip.conv2d_nhwc_bn_act(ref, w1, s1, h1, relu=True)
+            got, ref = torch.cat([got.reshape(-1), got1.reshape(-1)]), torch.cat([ref.reshape(-1), ref1.reshape(-1)])
+        elif which == "tail_28_s2f":                  # + the next bottleneck's conv1 (512 -> 128) on the output chunks (both outputs compared)
+            w1 = (torch.randn(128, 1, 1, 4 * c, generator=g) / (4 * c) ** 0.5).to(dt).cuda()
+            s1, h1 = (torch.rand(128, generator=g) + 0.5).cuda(), torch.randn(128, generator=g).cuda()
+            got, got1 = hip.bottleneck_tail_s2_nhwc(y1, hip.pack_mfma_fragments(w2), s2, h2, hip.pack_mfma_fragments(w3.view(4 * c, c)), s3, h3, res,
+                                                    hip.pack_mfma_fragments(w1.view(128, 4 * c)), s1, h1, 128)
             ref1 = hip.conv2d_nhwc_bn_act(ref, w1, s1, h1, relu=True)
             got, ref = torch.cat([got.reshape(-1), got1.reshape(-1)]), torch.cat([ref.reshape(-1), ref1.reshape(-1)])
         elif which == "tail_28_s2":
