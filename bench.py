@@ -46,7 +46,7 @@ V_WORD = 36541          # deephumor_demo.ipynb:524
 MAX_LEN = 32            # deephumor_demo.ipynb:1127
 BEAM, TOP_K, TEMP = 5, 50, 1.0
 N_CHECK = 4             # images of the greedy parity check against the CPU oracle
-STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))
+STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))      # (option "decode_streams"; read before the library is loaded)
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
 PEAK_16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
@@ -247,6 +247,15 @@ def compare_greedy(ref, got):
             "step0_ref_margin_median": float((top2[:, 0] - top2[:, 1]).median())}
 
 
+def dist_always():
+    """Option "dist_always" (environment default DH_DIST_ALWAYS): a one-rank process group still runs its collectives."""
+    try:
+        from deephumor_amd import hip
+        return bool(hip.option("dist_always"))
+    except Exception:                                     # (--stub on a box without the library)
+        return os.environ.get("DH_DIST_ALWAYS", "0") not in ("", "0")
+
+
 # ---- the timed region ----------------------------------------------------------------------------------------------
 def timed_region(step_fn, steps, world, device):
     """Contract of the brief: barrier + device synchronize, EXACTLY ``steps`` calls of ``step_fn(s)``, device synchronize +
@@ -255,7 +264,7 @@ def timed_region(step_fn, steps, world, device):
     import torch.distributed as dist
     # (a one-rank process group counts when DH_DIST_ALWAYS is set: --rccl-single runs the barriers / the max-reduction / the
     #  all_gather on RCCL with one rank, the only RCCL run a one-GPU box allows)
-    multi = (world > 1 or os.environ.get("DH_DIST_ALWAYS", "0") not in ("", "0")) and dist.is_available() and dist.is_initialized()
+    multi = (world > 1 or dist_always()) and dist.is_available() and dist.is_initialized()
     cuda = torch.device(device).type == "cuda"
 
     def fence():
@@ -640,7 +649,7 @@ def main(argv=None):
     n_ranks_seen = 1
     single_pg = args.rccl_single and world == 1 and not args.stub
     if single_pg:
-        os.environ["DH_DIST_ALWAYS"] = "1"
+        os.environ["DH_DIST_ALWAYS"] = "1"             # default source of option "dist_always" (the library is loaded later)
         os.environ.setdefault("MASTER_PORT", str(free_port()))
     if world > 1 or single_pg:
         import datetime

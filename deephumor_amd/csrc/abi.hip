@@ -1,3 +1,4 @@
+#include <stdlib.h>
 #include <string.h>
 #include <mutex>
 #include <string>
@@ -5,6 +6,7 @@
 #include <map>
 #include "common.h"
 #include "prof.h"
+#include "options.h"
 
 extern "C" int dh_abi_version(void) { return DH_ABI_VERSION; }
 
@@ -124,5 +126,89 @@ extern "C" int dh_prof_get(int i, char* name, int cap, int* calls, double* ms, d
     if (ms) *ms = a.ms;
     if (flops) *flops = a.flops;
     if (bytes) *bytes = a.bytes;
+    return DH_OK;
+}
+
+// ---- run-time options (options.h) --------------------------------------------------------------------
+namespace {
+struct OptDef { const char* key; const char* env; int def; bool inverted; };   // inverted: a set, non-"0" environment variable means 0
+// order == enum DhOption
+const OptDef g_opt_defs[DH_OPT_COUNT] = {
+    {"vocab_wreg", "DH_VOCAB_WREG", 1, false},
+    {"decode_wreg", "DH_DECODE_WREG", 1, false},
+    {"decode_wreg_min_rows", "DH_DECODE_WREG_MIN_ROWS", 320, false},
+    {"qkv_fusion_max_rows", "DH_QKV_FUSION_MAX_ROWS", 0, false},
+    {"cross_qproj", "DH_CROSS_QPROJ", 1, false},
+    {"lstm_wreg", "DH_LSTM_WREG", 1, false},
+    {"lstm_wreg_min_rows", "DH_LSTM_WREG_MIN_ROWS", 256, false},
+    {"gemm64_ns", "DH_GEMM64_NS", 0, false},
+    {"vocab_tile", "DH_VOCAB_TILE", 128, false},
+    {"vocab_gmax_tile", "DH_VOCAB_GMAX_TILE", 256, false},
+    {"vocab_areg", "DH_VOCAB_AREG", 1, false},
+    {"logprob_tile", "DH_LOGPROB_TILE", 0, false},
+    {"lstm_bm", "DH_LSTM_BM", 0, false},
+    {"lstm_ns", "DH_LSTM_NS", 0, false},
+    {"vocab_wreg_nt", "DH_VOCAB_WREG_NT", 1, false},
+    {"vocab_wreg_prefetch", "DH_VOCAB_WREG_PREFETCH", 1, false},
+    {"f32_split", "DH_F32_SPLIT", 0, false},
+    {"conv1x1_wreg", "DH_NO_CONV1X1_WREG", 1, true},
+    {"conv_s4", "DH_NO_CONV_S4", 1, true},
+    {"direct_3x3", "DH_NO_DIRECT_3X3", 1, true},
+    {"direct_stem", "DH_NO_DIRECT_STEM", 1, true},
+    {"stem_pool", "DH_NO_STEM_POOL", 1, true},
+    {"fused_tail", "DH_NO_FUSED_TAIL", 1, true},
+    {"s1_conv1_fusion", "DH_NO_S1_CONV1_FUSION", 1, true},
+    {"s2_conv1_fusion", "DH_NO_S2_CONV1_FUSION", 1, true},
+    {"s3_tail", "DH_NO_S3_TAIL", 1, true},
+    {"s2_tail", "DH_NO_S2_TAIL", 1, true},
+    {"vocab_wreg_plan", "DH_NO_VOCAB_WREG", 1, true},
+    {"vocab_wreg_transformer", "DH_VOCAB_WREG_TRANSFORMER", 0, false},
+    {"deferred_ln", "DH_NO_DEFERRED_LN", 1, true},
+    {"decode_wreg_plan", "DH_NO_DECODE_WREG", 1, true},
+    {"packed_cross", "DH_NO_PACKED_CROSS", 1, true},
+    {"qproj_fusion", "DH_NO_QPROJ_FUSION", 1, true},
+    {"fused_beam_step", "DH_FUSED_BEAM_STEP", 0, false},
+    {"fused_beam_step_max_rows", "DH_FUSED_BEAM_STEP_MAX_ROWS", 0, false},
+    {"pipe_prio", "DH_PIPE_PRIO", 0, false},
+    {"dist_always", "DH_DIST_ALWAYS", 0, false},
+    {"decode_streams", "DH_DECODE_STREAMS", 1, false},
+};
+int g_opt_val[DH_OPT_COUNT];
+bool g_opt_init[DH_OPT_COUNT];
+
+int opt_default(const OptDef& d) {
+    const char* e = getenv(d.env);
+    if (!e || !e[0]) return d.def;
+    if (d.inverted) return strcmp(e, "0") == 0 ? d.def : 0;
+    return atoi(e);
+}
+int opt_find(const char* key) {
+    if (!key) return -1;
+    for (int i = 0; i < DH_OPT_COUNT; ++i)
+        if (strcmp(g_opt_defs[i].key, key) == 0) return i;
+    return -1;
+}
+}  // namespace
+
+int dh_opt(int which) {
+    if (which < 0 || which >= DH_OPT_COUNT) return 0;
+    if (!g_opt_init[which]) { g_opt_val[which] = opt_default(g_opt_defs[which]); g_opt_init[which] = true; }
+    return g_opt_val[which];
+}
+
+extern "C" int dh_option_count(void) { return DH_OPT_COUNT; }
+extern "C" const char* dh_option_name(int i) { return i >= 0 && i < DH_OPT_COUNT ? g_opt_defs[i].key : nullptr; }
+extern "C" const char* dh_option_env(int i) { return i >= 0 && i < DH_OPT_COUNT ? g_opt_defs[i].env : nullptr; }
+extern "C" int dh_get_option(const char* key, int* value) {
+    const int i = opt_find(key);
+    if (i < 0 || !value) return DH_ERR_BAD_ARG;
+    *value = dh_opt(i);
+    return DH_OK;
+}
+extern "C" int dh_set_option(const char* key, int value) {
+    const int i = opt_find(key);
+    if (i < 0) return DH_ERR_BAD_ARG;
+    g_opt_val[i] = value;
+    g_opt_init[i] = true;
     return DH_OK;
 }

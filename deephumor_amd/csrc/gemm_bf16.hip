@@ -24,6 +24,7 @@
 #include <type_traits>
 #include "common.h"
 #include "prof.h"
+#include "options.h"
 
 typedef dh_f32x4 f32x4;
 
@@ -652,7 +653,7 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     // ring depth (16 KB per slab) by workgroup count, so that all tiles are co-resident in ONE round where possible:
     // <= 320: one per CU with a deep ring (7 slabs in flight); <= 512: two per CU; <= 768: three; <= 1280: five
     // (the fused LSTM step, 640 workgroups: 20.7 us with 4 slabs / 1.25 rounds, 16.6 us with 3 slabs / one round)
-    static const int force_ns = getenv("DH_GEMM64_NS") ? atoi(getenv("DH_GEMM64_NS")) : 0;
+    const int force_ns = dh_opt(DH_OPT_GEMM64_NS);
     // (32 x 64 tiles for the 160-workgroup decoder projections: slower -- proj 5.5 -> 6.1 ms, ffn 6.0 -> 7.6 ms per C3 step)
     if (force_ns == 4 || blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)
         hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
@@ -1374,12 +1375,11 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         // DH_VOCAB_TILE=256: the 256 x 256 kernel (vocab256_kernel).  With the 187 MB of fp32 logits to store both kernels take the
         // same 86-89 us per launch (store-bound: the stores of a tile cannot overlap the next tile's MFMAs, vmcnt is in-order); where
         // nothing is stored (dh_vocab_logprob) the bigger tile is the default.
-        static const int vns = getenv("DH_VOCAB_TILE") ? atoi(getenv("DH_VOCAB_TILE")) : 128;
-        static const int gns = getenv("DH_VOCAB_GMAX_TILE") ? atoi(getenv("DH_VOCAB_GMAX_TILE")) : 256;
+        const int vns = dh_opt(DH_OPT_VOCAB_TILE), gns = dh_opt(DH_OPT_VOCAB_GMAX_TILE);
         {   // A-stationary kernel: K = 512, row tiles of 128, groups of tiles_m workgroups per XCD (32 CUs each)
             // default since round 2: in the C2 / C3 steps 3-5 % faster than the 128 x 128 kernel below (2.43 vs 2.49 ms and 2.81 vs 2.99 ms
             // of classifier time per step, three alternating runs in one call); DH_VOCAB_AREG=0 restores the tile kernel
-            static const int areg = getenv("DH_VOCAB_AREG") ? atoi(getenv("DH_VOCAB_AREG")) : 1;
+            const int areg = dh_opt(DH_OPT_VOCAB_AREG);
             const int tm128 = dh_cdiv(M, 128), tn128 = dh_cdiv(V, 128);
             // round 3: 256-row tiles (32 MFMAs per wave per slab instead of 16) when the rows fill them (DH_VOCAB_AREG=128: never)
             const int tm256 = dh_cdiv(M, 256);
@@ -1479,7 +1479,7 @@ extern "C" int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, 
     hipStream_t s = (hipStream_t)stream;
     // 256 x 256 tiles (vocab256_kernel) once there are enough rows to fill them: without the logits stores the classifier is
     // MFMA-bound and the bigger tile pays (teacher-forced scoring of 9,000 captions: 36.5 -> 29.1 ms per pass)
-    static const int lns = getenv("DH_LOGPROB_TILE") ? atoi(getenv("DH_LOGPROB_TILE")) : 0;
+    const int lns = dh_opt(DH_OPT_LOGPROB_TILE);
     if (lns == 256 || (lns == 0 && M >= 512)) {
         v.tiles_m = dh_cdiv(M, 256); v.tiles_n = dh_cdiv(V, 256);
         const int nt = v.tiles_m * v.tiles_n;

@@ -14,6 +14,7 @@
 // Same ring / swizzle / wave layout as gemm_bf16_kernel<64, 64, 2, false, 4, 4>.
 #include "common.h"
 #include "prof.h"
+#include "options.h"
 
 typedef dh_f32x4 f32x4;
 typedef const void __attribute__((address_space(1)))* gptr_t;
@@ -243,7 +244,7 @@ extern "C" int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const
     // 160-row tiles (DH_LSTM_BM=160; one full round of 256 workgroups at 1280 rows, 42 % less L2 -> LDS traffic on the busiest
     // CU) are correct but measured SLOWER in the C2 step (1.33 vs 1.24 ms per step at any ring depth): one wave per SIMD hides
     // less latency than the 2-3 co-resident 64 x 64 workgroups, so the small tile stays the default
-    static const int force_bm = getenv("DH_LSTM_BM") ? atoi(getenv("DH_LSTM_BM")) : 0;
+    const int force_bm = dh_opt(DH_OPT_LSTM_BM);
     const int blocks160 = dh_cdiv(rows, 160) * p.tiles_n;
     const bool big = force_bm == 160;
     DhProfScope prof("dh_lstm_layer_fused", 2.0 * rows * 4 * Hh * K, 2.0 * (rows * K + 4.0 * Hh * K) + 12.0 * rows * Hh, stream);
@@ -251,7 +252,7 @@ extern "C" int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const
     // measured at 1280 rows x 2048 gate columns (640 workgroups): 4 slabs (2 per CU, 1.25 rounds) 20.7 / 24.3 us,
     // 3 slabs (3 per CU) 16.6 / 19.0 us, 2 slabs (5 per CU) 16.4 / 18.6 us  (E = 256 / 512)
     const int blocks = p.tiles_m * p.tiles_n;
-    static const int force_ns = getenv("DH_LSTM_NS") ? atoi(getenv("DH_LSTM_NS")) : 0;
+    const int force_ns = dh_opt(DH_OPT_LSTM_NS);
     if (big) {
         p.tiles_m = dh_cdiv(rows, 160);
         DH_DISPATCH_16(dtype, {

@@ -6,13 +6,12 @@
 #include <stdlib.h>
 #include "common.h"
 #include "prof.h"
+#include "options.h"
 
-// dh_attn_self_qkv_decode replaces the QKV GEMM + self-attention pair of a decode position only below this many rows: at
-// 1280 rows (256 images x beam 5) it takes 30.5 us against 12.1 + 13.5 us for the pair (its attention part runs 8 waves per CU
-// instead of 40 and is latency-bound), measured per C3 step: 29.4 vs 28.1 ms.  DH_QKV_FUSION_MAX_ROWS overrides.
-#ifndef DH_QKV_FUSION_DEFAULT_MAX_ROWS
-#define DH_QKV_FUSION_DEFAULT_MAX_ROWS 0
-#endif
+// Kernel selection here goes through the option table (options.h; dh_set_option): every use reads the current value.
+// "qkv_fusion_max_rows": dh_attn_self_qkv_decode replaces the QKV GEMM + self-attention pair of a decode position only up to
+// this many rows: at 1280 rows (256 images x beam 5) it takes 30.5 us against 12.1 + 13.5 us for the pair (its attention part
+// runs 8 waves per CU instead of 40 and is latency-bound), measured per C3 step: 29.4 vs 28.1 ms.
 
 static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* q, void* att, int n_img, int rows_per_img,
                            int dt, void* stream) {
@@ -23,23 +22,20 @@ static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const
 }
 
 // The classifier of a beam-search step with group maxima: the register-streamed kernel (csrc/vocab_wreg.hip; bit-identical) when the model
-// carries its operands and it takes the shape, else dh_vocab_logits.  DH_VOCAB_WREG=0 switches it off (A/B runs).
+// carries its operands and it takes the shape, else dh_vocab_logits.  Option "vocab_wreg" = 0 switches it off (A/B runs).
 static int classifier_groups(const void* A, int lda, const void* W, const float* bias, const void* W_pk, const float* bias_pad, float* logits,
                              int ldl, float* group_max, int gm_ld, int rows, int V, int K, int dt, void* stream) {
-    static const int use_wreg = getenv("DH_VOCAB_WREG") ? atoi(getenv("DH_VOCAB_WREG")) : 1;
-    if (use_wreg && W_pk && bias_pad && logits && dh_vocab_logits_wreg_supported(rows, V, K, ldl, gm_ld))
+    if (dh_opt(DH_OPT_VOCAB_WREG) && W_pk && bias_pad && logits && dh_vocab_logits_wreg_supported(rows, V, K, ldl, gm_ld))
         return dh_vocab_logits_wreg(A, lda, W_pk, bias_pad, logits, ldl, group_max, gm_ld, rows, V, K, dt, stream);
     return dh_vocab_logits(A, lda, W, K, bias, logits, ldl, group_max, gm_ld, rows, V, K, dt, stream);
 }
 
 // One GEMM of the deferred-LayerNorm chain: the register-stationary kernel (csrc/linear_wreg.hip; bit-identical results) when the
 // layer carries fragment-packed weights, the position has enough rows to fill the chip and the shape is one it takes; else the
-// tile kernels.  DH_DECODE_WREG=0 switches it off (A/B runs), DH_DECODE_WREG_MIN_ROWS moves the threshold.
+// tile kernels.  Option "decode_wreg" = 0 switches it off (A/B runs), "decode_wreg_min_rows" moves the threshold.
 static int chain_linear(const void* A, int lda, const void* W, const void* W_pk, const float* bias, const void* res, int ldres, void* C,
                         int ldc, int rows, int N, int K, int relu, const dh_ln_fold_t* f, int dt, void* stream) {
-    static const int use_wreg = getenv("DH_DECODE_WREG") ? atoi(getenv("DH_DECODE_WREG")) : 1;
-    static const int min_rows = getenv("DH_DECODE_WREG_MIN_ROWS") ? atoi(getenv("DH_DECODE_WREG_MIN_ROWS")) : 320;
-    if (use_wreg && W_pk && rows >= min_rows && (res == nullptr) == (f->o_stats == nullptr) &&
+    if (dh_opt(DH_OPT_DECODE_WREG) && W_pk && rows >= dh_opt(DH_OPT_DECODE_WREG_MIN_ROWS) && (res == nullptr) == (f->o_stats == nullptr) &&
         dh_linear_ln_wreg_occupancy(rows, N, K, res != nullptr) >= 0.85)
         return dh_linear_ln_wreg(A, lda, W_pk, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
     return dh_linear_ln(A, lda, W, K, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
@@ -59,8 +55,7 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         dh_ln_fold_t f{};
         // 1. qkv = LN3_prev(X) Wqkv^T + b  (layer 0: X is the embedding, no LayerNorm in front) and the self-attention over the
         //    row's history: ONE launch where the fused kernel applies (head dim 64, <= 6 rows per image, <= 40 positions)
-        static const int qkv_fusion_rows = getenv("DH_QKV_FUSION_MAX_ROWS") ? atoi(getenv("DH_QKV_FUSION_MAX_ROWS")) : DH_QKV_FUSION_DEFAULT_MAX_ROWS;
-        if (rows <= qkv_fusion_rows && D == 64 * m->n_heads && rows_per_img <= 6 && t <= 39) {
+        if (rows <= dh_opt(DH_OPT_QKV_FUSION_MAX_ROWS) && D == 64 * m->n_heads && rows_per_img <= 6 && t <= 39) {
             DH_TRY(dh_attn_self_qkv_decode(sc->x, D, P ? sc->st0 : nullptr, nt, P ? P->ln3_eps : 0.f, P ? L.cs_qkv : nullptr,
                                            P ? L.wqkv_f : L.wqkv, P ? L.bqkv_f : L.bqkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld,
                                            sc->att, n_img, rows_per_img, row_mult, rows_total, t, D, m->n_heads, L.sa_scale,
@@ -82,9 +77,8 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         const float *g_in = L.ln1_g, *b_in = L.ln1_b; float eps_in = L.ln1_eps;
         if (m->cross) {
             // 3. q = LN1(Y1) Wq^T + bq and the attention over the image's patches: ONE launch when K was packed for it
-            // DH_CROSS_QPROJ=0: fc_q as its own (register-stationary) GEMM, then the packed attention -- A/B of the fused launch
-            static const int fused_qproj = getenv("DH_CROSS_QPROJ") ? atoi(getenv("DH_CROSS_QPROJ")) : 1;
-            if (fused_qproj && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
+            // option "cross_qproj" = 0: fc_q as its own (register-stationary) GEMM, then the packed attention -- A/B of the fused launch
+            if (dh_opt(DH_OPT_CROSS_QPROJ) && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
                 DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
                                                   n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
             } else {
@@ -202,9 +196,8 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
             const void* x = l == 0 ? img_emb : (const char*)sc->xcatl + (size_t)(l - 1) * rows * 2 * Hh * esz;
             void* dst = l + 1 < nl ? (void*)((char*)sc->xcatl + (size_t)l * rows * 2 * Hh * esz) : top;
             const int El = l == 0 ? E : Hh;
-            // decode shapes: the step with the gate weights stationary in registers (DH_LSTM_WREG=0: the tile kernel)
-            static const int use_wreg = getenv("DH_LSTM_WREG") ? atoi(getenv("DH_LSTM_WREG")) : 1;
-            if (use_wreg && m->layers[l].w_pk && dh_lstm_layer_wreg_supported(El, Hh) && rows >= 256) {
+            // decode shapes: the step with the gate weights stationary in registers (option "lstm_wreg" = 0: the tile kernel)
+            if (dh_opt(DH_OPT_LSTM_WREG) && m->layers[l].w_pk && dh_lstm_layer_wreg_supported(El, Hh) && rows >= dh_opt(DH_OPT_LSTM_WREG_MIN_ROWS)) {
                 DH_TRY(dh_lstm_layer_wreg(x, l == 0 ? E : 2 * Hh, l == 0 ? rows_per_img : 1, l == 0 ? m->emb : nullptr,
                                           l == 0 ? tokens : nullptr, tok_ld, tok_pos, hr ? hr + so * esz : nullptr,
                                           cr ? cr + so : nullptr, hparent, hw + so * esz, cw + so, dst,

@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "prof.h"
+#include "options.h"
 
 namespace {
 struct VwParams {
@@ -217,9 +218,8 @@ extern "C" int dh_vocab_logits_wreg(const void* A, int lda, const void* w_packed
     dh_prof_set_dims(M, V, K);
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);
     hipStream_t s = (hipStream_t)stream;
-    static const int nt_stores = getenv("DH_VOCAB_WREG_NT") ? atoi(getenv("DH_VOCAB_WREG_NT")) : 1;
-    p.nt = nt_stores;
-    static const bool prefetch = !(getenv("DH_VOCAB_WREG_PREFETCH") && atoi(getenv("DH_VOCAB_WREG_PREFETCH")) == 0);
+    p.nt = dh_opt(DH_OPT_VOCAB_WREG_NT);
+    const bool prefetch = dh_opt(DH_OPT_VOCAB_WREG_PREFETCH) != 0;
     DH_DISPATCH_16(dtype, {
         if (prefetch) hipLaunchKernelGGL((vocab_wreg_kernel<T, true>), dim3(256), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((vocab_wreg_kernel<T, false>), dim3(256), dim3(256), 0, s, p);

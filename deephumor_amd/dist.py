@@ -30,7 +30,8 @@ def _skip_collective(group, always):
     if not (dist.is_available() and dist.is_initialized()):
         return True
     if always is None:
-        always = os.environ.get("DH_DIST_ALWAYS", "0") not in ("", "0")
+        from . import hip
+        always = bool(hip.option("dist_always"))
     return dist.get_world_size(group) == 1 and not always
 
 

@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 26
+ABI_VERSION = 27
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -150,6 +150,9 @@ SIGNATURES = {
     "dh_beam_sample_k": [_P, _I, _I, _I, _I, _F, _P, _I, _U64, _P, _I, _I, _P, _P, _P],
     "dh_beam_gather": [_P, _I, _I, _P, _I, _P, _I, _P, _P],
     "dh_beam_expand": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "dh_option_count": [],
+    "dh_get_option": [_c.c_char_p, _c.POINTER(_I)],
+    "dh_set_option": [_c.c_char_p, _I],
 }
 
 
@@ -193,11 +196,68 @@ def load():
     lib.dh_error_string.restype = _c.c_char_p
     lib.dh_prof_tag.argtypes = [_c.c_char_p]
     lib.dh_prof_tag.restype = None
+    for name in ("dh_option_name", "dh_option_env"):
+        getattr(lib, name).argtypes = [_I]
+        getattr(lib, name).restype = _c.c_char_p
     if lib.dh_abi_version() != ABI_VERSION:
         raise RuntimeError(f"deephumor_amd: {path} has ABI v{lib.dh_abi_version()}, this binding expects v{ABI_VERSION}; "
                            "rebuild with `python __graft_entry__.py build`")
     _lib = lib
     return lib
+
+
+def option(key):
+    """Current value of a run-time option (``dh_get_option``): the library's ONE table of kernel-selection switches -- default
+    from the option's environment variable, else built in; see ``options()`` and INTEGRATION.md."""
+    got = _opt_cache.get(key)
+    if got is None:          # (cached on the Python side: the models ask per layer; every change goes through set_option below)
+        v = _I()
+        _check(load().dh_get_option(key.encode(), _c.byref(v)), f"dh_get_option({key!r})")
+        got = _opt_cache[key] = v.value
+    return got
+
+
+def set_option(key, value):
+    """``dh_set_option``: overrides an option from now on.  Dispatch options of the native step drivers (``decode_wreg``,
+    ``decode_wreg_min_rows``, ``qkv_fusion_max_rows``, ``cross_qproj``, ``lstm_wreg``, ``vocab_wreg``, tile choices) take effect at
+    the next launch; the options the Python layer reads while it builds a model's weight plan (``conv1x1_wreg`` ... ``qproj_fusion``,
+    ``f32_split``) are part of every plan's cache key (``options_epoch``): models rebuild their plans -- and re-capture their
+    hipGraphs -- at the next call.  Returns the previous value."""
+    global options_epoch
+    old = option(key)
+    _check(load().dh_set_option(key.encode(), int(value)), f"dh_set_option({key!r})")
+    _opt_cache.pop(key, None)
+    if int(value) != old:
+        options_epoch += 1
+    return old
+
+
+_opt_cache = {}
+options_epoch = 0       # bumped by every set_option that changes a value; part of the models' plan keys
+
+
+class option_scope:
+    """``with hip.option_scope(decode_wreg=0, s3_tail=0): ...`` -- options set for the block, previous values restored after it
+    (A/B tests of results-identical kernels)."""
+
+    def __init__(self, **kv):
+        self.kv, self.old = kv, {}
+
+    def __enter__(self):
+        for k, v in self.kv.items():
+            self.old[k] = set_option(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self.old.items():
+            set_option(k, v)
+
+
+def options():
+    """{key: (value, environment variable)} of every option."""
+    lib = load()
+    return {lib.dh_option_name(i).decode(): (option(lib.dh_option_name(i).decode()), lib.dh_option_env(i).decode())
+            for i in range(lib.dh_option_count())}
 
 
 def _check(code, name):

@@ -88,12 +88,15 @@ class TorchRngNoise:
     A parity feature, not a throughput path: the noise is generated on the host (rows x V floats per step) and the ended flags are
     read back once per step."""
 
-    def __init__(self, seed, n_img, img0=0):
+    def __init__(self, seed, n_img, img0=0, state0=None):
+        """``state0``: for ``seed=None``, the default generator's state at the start of the ``generate`` call (``torch.get_rng_state()``
+        taken ONCE by the caller): a repeated session (``BeamOverflow`` retry builds a new noise source) then replays the same
+        draws instead of continuing from wherever the first attempt left the generator."""
         if seed is None and n_img != 1:
             raise ValueError('rng="torch" with seed=None draws from torch\'s default generator, which only one image at a time can '
                              'consume in the reference\'s order: pass seed=<int> (image i then draws from manual_seed(seed + i))')
         self.seed, self.n_img, self.img0 = seed, int(n_img), int(img0)
-        self.gens, self.h, self._state0 = None, None, None
+        self.gens, self.h, self._state0 = None, None, state0
 
     def attach(self, helper):
         """Called by the helper that will consume the noise; (re-)positions the generators at the start of their streams, so a
@@ -196,8 +199,9 @@ class BeamSearchHelper:
         self.arrive = piece(8)            # per-image arrival counters of the fused beam step (the kernel leaves them zero)
         # one launch per step (dh_beam_step_groups; needs an image's token + ancestor rows to fit the row kernel's LDS).  Same
         # results, measured gain within run-to-run noise (C2 9.03 / 8.72 vs 9.01 ms, C3 25.2 / 24.9 vs 25.4 ms per step), so the two
-        # launches stay the default and DH_FUSED_BEAM_STEP=1 opts in
-        self.fused_step = (beam_size * (max_len + src_len) <= hip.SEL_STAGE_MAX) and beam_size <= 16 and bool(os.environ.get("DH_FUSED_BEAM_STEP"))
+        # launches stay the default; option "fused_beam_step" = 1 opts in, "fused_beam_step_max_rows" selects it by row count
+        self.fused_step = ((beam_size * (max_len + src_len) <= hip.SEL_STAGE_MAX) and beam_size <= 16
+                           and bool(hip.option("fused_beam_step") or r <= hip.option("fused_beam_step_max_rows")))
         self.pick_idx = torch.empty((r, beam_size), dtype=torch.int32, device=dev)
         self.pick_val = torch.empty((r, beam_size), dtype=torch.float32, device=dev)
         # KV-cache ancestor table (Transformer only): src[r, j] = row holding position j of r's history
@@ -372,7 +376,7 @@ class BeamSearchHelper:
         return (prev_seqs, prev_vals), (out_ind, out_val)
 
 
-def make_noise_source(rng, seed, noise_source, lo, hi, img0):
+def make_noise_source(rng, seed, noise_source, lo, hi, img0, state0=None):
     """The noise source of one decode session (images ``[lo, hi)`` of the batch): the caller's hook, or the torch-generator replay
     of ``rng="torch"`` (``TorchRngNoise``); ``rng`` None / "philox" = the kernels' own counter-based generator."""
     if rng in (None, "philox"):
@@ -381,7 +385,7 @@ def make_noise_source(rng, seed, noise_source, lo, hi, img0):
         raise ValueError(f'rng must be None, "philox" or "torch", not {rng!r}')
     if noise_source is not None:
         raise ValueError('rng="torch" and noise_source are mutually exclusive')
-    return TorchRngNoise(seed, hi - lo, img0 + lo)
+    return TorchRngNoise(seed, hi - lo, img0 + lo, state0=state0)
 
 
 _overflow_warned = False
@@ -453,7 +457,13 @@ def run_interleaved(make_session, n_img, n_streams):
                     alive.discard(i)
     for st in pool[:n_streams]:
         main.wait_stream(st)
-    for toks, lens in results:
-        toks.record_stream(main)
-        lens.record_stream(main)
-    return torch.cat([r[0] for r in results], 0), torch.cat([r[1] for r in results], 0)
+    for r in results:
+        for t in r:
+            t.record_stream(main)
+    out = (torch.cat([r[0] for r in results], 0), torch.cat([r[1] for r in results], 0))
+    if len(results[0]) > 2:               # defer_check sessions also return their device error word: OR of the sub-batches' words
+        err = results[0][2].clone()
+        for r in results[1:]:
+            err |= r[2]
+        out += (err,)
+    return out

@@ -49,7 +49,8 @@ class _CaptioningBase(nn.Module):
         """Identity of everything a captured graph holds raw pointers to or derives constants from: storage pointer and
         in-place version counter of every parameter and buffer of the model."""
         ts = list(self.parameters()) + list(self.buffers())
-        return tuple(t.data_ptr() for t in ts), tuple(t._version for t in ts)
+        from .. import hip
+        return tuple(t.data_ptr() for t in ts), tuple(t._version for t in ts), hip.options_epoch
 
     MAX_GRAPHS = 4      # captured graphs kept per model (one per (input shapes, decode settings))
 
@@ -75,11 +76,13 @@ class _CaptioningBase(nn.Module):
         key = (tuple((tuple(t.shape), t.dtype) for t in inputs), None if caption is None else tuple(caption.shape),
                tuple(sorted(kw.items())), next(self.parameters()).dtype)
         cache = self.__dict__.setdefault("_graphs", {})
-        eager_keys = self.__dict__.setdefault("_graph_overflowed", set())
+        eager_keys = self.__dict__.setdefault("_graph_overflowed", {})       # key -> plan signature it overflowed with
+        sig = self._plan_signature()
+        if key in eager_keys and eager_keys[key] != sig:
+            del eager_keys[key]           # other weights since: the graphed path gets another chance
         if key in eager_keys:             # this configuration overflowed the pre-filtered samplers before (flat logits): straight to
             return self.generate_batch(*inputs, caption=caption, seed=seed, exact=True, **kw)     # the general sampler, eagerly
         state = cache.get(key)
-        sig = self._plan_signature()
         if state is not None and state[5] != sig:
             cache.clear()                                 # weights changed: every captured graph points at dead tensors
             state = None
@@ -118,7 +121,7 @@ class _CaptioningBase(nn.Module):
             BeamSearchHelper.raise_for(int(err.item()))
         except BeamOverflow:              # flat logits: the captured chain cannot switch samplers -- this batch (and, from now on, this
             warn_overflow_retry()         # configuration) eagerly through the general sampler
-            eager_keys.add(key)
+            eager_keys[key] = self._plan_signature()
             return self.generate_batch(*inputs, caption=caption, seed=seed, exact=True, **kw)
         return toks.clone(), lens.clone()
 

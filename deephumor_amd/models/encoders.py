@@ -78,7 +78,7 @@ class _Planned:
 
     def _plan_key(self, refresh=False):
         ts = self._plan_tensors_list(refresh)
-        return tuple(t.data_ptr() for t in ts), tuple(t._version for t in ts)
+        return tuple(t.data_ptr() for t in ts), tuple(t._version for t in ts), hip.options_epoch
 
     def _drop_plan(self):
         for m in self.modules():
@@ -214,19 +214,21 @@ class ImageEncoder(_Planned, nn.Module):
     def _conv(x, c, residual=None, nhwc=False):
         if (nhwc and "wpk1" in c and (residual is None or x.shape[3] == 512)
                 and hip.conv1x1_wreg_supported(x.shape[0] * x.shape[1] * x.shape[2], x.shape[3], c["w"].shape[0])
-                and not os.environ.get("DH_NO_CONV1X1_WREG")):
+                and hip.option("conv1x1_wreg")):
             # conv1 of the K >= 256 bottlenecks, conv3 + residual of stage 4: weights stationary in registers, pixels streamed
             # (csrc/conv1x1_wreg.hip; bit-identical)
             return hip.conv1x1_wreg_nhwc(x, c["wpk1"], c["w"].shape[0], c["scale"], c["shift"], relu=c["relu"], residual=residual)
         if (nhwc and residual is None and "wpk4" in c and c["relu"] and hip.conv3x3_s4_supported(x.shape[1], x.shape[2], x.shape[3])
-                and not os.environ.get("DH_NO_CONV_S4")):
+                and hip.option("conv_s4")):
             return hip.conv3x3_s4_nhwc(x, c["wpk4"], c["scale"], c["shift"])
         if (nhwc and residual is None and c["relu"] and c["stride"] == 1 and c["pad"] == 1 and c["w"].shape[1] == 3
                 and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], x.shape[3], c["w"].shape[0])
-                and not os.environ.get("DH_NO_DIRECT_3X3")):
+                and hip.option("direct_3x3")):
             return hip.conv3x3_direct_nhwc(x, c["w"], c["scale"], c["shift"])      # patch-resident direct convolution (stages 1-2)
         fn = hip.conv2d_nhwc_bn_act if nhwc else hip.conv2d_bn_act
         return fn(x, c["w"], c["scale"], c["shift"], residual=residual, relu=c["relu"], stride=c["stride"], pad=c["pad"])
+
+    TRUNK_MAX_IMAGES = 384
 
     def features(self, images):
         """Trunk output (encoders.py:56): ``[N, 2048, H/32, W/32]`` fp32 on the parity path,
@@ -234,11 +236,16 @@ class ImageEncoder(_Planned, nn.Module):
         plan = self._get_plan()
         nhwc = plan["bf16"]
         st = plan["stem"]
+        if nhwc and images.shape[0] > self.TRUNK_MAX_IMAGES:
+            #  the streaming / register-streamed 16-bit kernels index pixels with 32-bit magic divisions and are tuned for
+            # <= 256 images per launch (the stage-1 dual kernel stops applying near 436 images): larger batches go through the trunk
+            # in chunks of 256 -- every image's arithmetic is independent of its batch, so the features are the same bit for bit
+            return torch.cat([self.features(images[i:i + 256]) for i in range(0, images.shape[0], 256)], 0)
         if nhwc:
             prepacked = images.dim() == 4 and images.shape[-1] == 8 and images.dtype == plan["dtype"]
             h_in, w_in = (images.shape[1], images.shape[2]) if prepacked else (images.shape[2], images.shape[3])
             direct = ("wpk" in st and h_in >= 2 and w_in >= 2 and ((h_in - 1) // 2 + 1) % 2 == 0 and ((w_in - 1) // 2 + 1) % 2 == 0
-                      and (prepacked or images.shape[1] == 3) and not os.environ.get("DH_NO_DIRECT_STEM"))
+                      and (prepacked or images.shape[1] == 3) and hip.option("direct_stem"))
             if direct:
                 # conv1 + bn1 + relu + maxpool as ONE direct-convolution launch that reads the caller's tensor as it is (fp32 NCHW
                 # or the preprocessing kernels' packed 16-bit layout): no packing launch, no im2col traffic, no un-pooled activation
@@ -252,7 +259,7 @@ class ImageEncoder(_Planned, nn.Module):
             ks, cout = st["w"].shape[1], st["w"].shape[0]
             ho = (packed.shape[1] + 2 * st["pad"] - ks) // st["stride"] + 1
             wo = (packed.shape[2] + 2 * st["pad"] - ks) // st["stride"] + 1
-            if ho % 2 == 0 and wo % 2 == 0 and cout <= 64 and not os.environ.get("DH_NO_STEM_POOL"):
+            if ho % 2 == 0 and wo % 2 == 0 and cout <= 64 and hip.option("stem_pool"):
                 # conv1 + bn1 + relu + maxpool in one launch: the un-pooled 112 x 112 x 64 activation never exists
                 x = hip.conv2d_nhwc_bn_relu_maxpool(packed, st["w"], st["scale"], st["shift"], st["stride"], st["pad"])
             else:
@@ -271,7 +278,7 @@ class ImageEncoder(_Planned, nn.Module):
             nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
             if (nhwc and "w2p1" in blk and nxt is not None and "wpkf" in nxt["c1"] and "w2p1" in nxt
                     and hip.bottleneck_tail_s1_supported(x.shape[1], x.shape[2], c2["w"].shape[0], nxt["c1"]["w"].shape[0])
-                    and not os.environ.get("DH_NO_FUSED_TAIL") and not os.environ.get("DH_NO_S1_CONV1_FUSION")):
+                    and hip.option("fused_tail") and hip.option("s1_conv1_fusion")):
                 # stage 1 (56 x 56 x 64), next block's conv1 256 -> 64: 4-row strips, weights register-streamed, and that conv1 in the
                 # same launch on the output tile while it is in LDS -- the 411 MB tensor is not read back for it (conv_s1.hip).
                 # (Without the fusion the ring kernel below is the faster tail in the encoder: 195 against 214 us.)
@@ -282,17 +289,17 @@ class ImageEncoder(_Planned, nn.Module):
                                                                nxt["c1"]["wpkf"], nxt["c1"]["scale"], nxt["c1"]["shift"], nxt["c1"]["w"].shape[0])
                 continue
             if (nhwc and "w2p" in blk and hip.bottleneck_tail_s3_supported(x.shape[1], x.shape[2], c2["w"].shape[0])
-                    and not os.environ.get("DH_NO_FUSED_TAIL") and not os.environ.get("DH_NO_S3_TAIL")):
+                    and hip.option("fused_tail") and hip.option("s3_tail")):
                 # stage 3 (14 x 14 x 256): one image per workgroup, patch-resident 3x3 + 1x1 expansion, weights register-streamed
                 y1 = self._conv(x, blk["c1"], nhwc=True)
                 x = hip.bottleneck_tail_s3_nhwc(y1, blk["w2p"], c2["scale"], c2["shift"], blk["w3p"], c3["scale"], c3["shift"], x)
                 continue
             if (nhwc and "w2p2" in blk and hip.bottleneck_tail_s2_supported(x.shape[1], x.shape[2], c2["w"].shape[0])
-                    and not os.environ.get("DH_NO_FUSED_TAIL") and not os.environ.get("DH_NO_S2_TAIL")):
+                    and hip.option("fused_tail") and hip.option("s2_tail")):
                 y1 = ready.pop(bi, None)
                 if y1 is None:
                     y1 = self._conv(x, blk["c1"], nhwc=True)
-                if (nxt is not None and "wpkf" in nxt["c1"] and "w2p2" in nxt and not os.environ.get("DH_NO_S2_CONV1_FUSION")):
+                if (nxt is not None and "wpkf" in nxt["c1"] and "w2p2" in nxt and hip.option("s2_conv1_fusion")):
                     # + the next block's conv1 (512 -> 128) on the output chunks in LDS: 170 us against 135 + 55 us
                     x, ready[bi + 1] = hip.bottleneck_tail_s2_nhwc(y1, blk["w2p2"], c2["scale"], c2["shift"], blk["w3p2"], c3["scale"], c3["shift"], x,
                                                                    nxt["c1"]["wpkf"], nxt["c1"]["scale"], nxt["c1"]["shift"], 128)
@@ -301,8 +308,8 @@ class ImageEncoder(_Planned, nn.Module):
                 continue
             if (nhwc and blk["dual"] is None and blk["down"] is None and c2["stride"] == 1 and c2["w"].shape[1] == 3
                     and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], c2["w"].shape[3], c2["w"].shape[0])
-                    and c3["w"].shape[0] == 4 * c2["w"].shape[0] and not os.environ.get("DH_NO_FUSED_TAIL")
-                    and not os.environ.get("DH_NO_DIRECT_3X3")):
+                    and c3["w"].shape[0] == 4 * c2["w"].shape[0] and hip.option("fused_tail")
+                    and hip.option("direct_3x3")):
                 # conv2 + bn2 + relu + conv3 + bn3 + residual + relu in one launch: the conv2 output tile stays in LDS
                 y1 = ready.pop(bi, None)
                 if y1 is None:
@@ -312,10 +319,10 @@ class ImageEncoder(_Planned, nn.Module):
             y = self._conv(self._conv(x, blk["c1"], nhwc=nhwc), blk["c2"], nhwc=nhwc)
             if blk["dual"] is not None:
                 d = blk["dual"]
-                if ("wpk" in d and not os.environ.get("DH_NO_CONV1X1_WREG")
+                if ("wpk" in d and hip.option("conv1x1_wreg")
                         and hip.conv1x1_dual_wreg_supported(y.shape, x.shape, d["w"].shape[0])):
                     if (nxt is not None and "wpkf" in nxt["c1"] and d["w"].shape == (256, 128) and nxt["c1"]["w"].shape[0] == 64
-                            and not os.environ.get("DH_NO_S1_CONV1_FUSION")):
+                            and hip.option("s1_conv1_fusion")):
                         # layer1.0's ending + layer1.1's conv1 in one launch (the block's 256 output channels are in the workgroup)
                         x, ready[bi + 1] = hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], 256, d["shift"], d["stride"], relu=True, w1p=nxt["c1"]["wpkf"],
                                                                       scale1=nxt["c1"]["scale"], shift1=nxt["c1"]["shift"], n1=64)

@@ -51,7 +51,7 @@ class LSTMDecoder(_Planned, nn.Module):
         plan = dict(layers=layers, emb=self.embedding.weight.detach(),
                     cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach().float().contiguous(),
                     dtype=self.classifier.weight.dtype)
-        if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and plan["cls_w"].shape[1] == 512 and not os.environ.get("DH_NO_VOCAB_WREG"):
+        if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and plan["cls_w"].shape[1] == 512 and hip.option("vocab_wreg_plan"):
             # the beam-search classifier with the weights streamed from L2 into registers (csrc/vocab_wreg.hip): padded, fragment-packed copy
             plan["cls_w_pk"], plan["cls_b_pad"] = hip.pack_vocab_weights(plan["cls_w"], plan["cls_b"])
         return plan
@@ -167,6 +167,9 @@ class LSTMDecoder(_Planned, nn.Module):
         plan = self._get_plan()
         rng_seed = seed
         seed = 0 if rng == "torch" else resolve_seed(seed, noise_source)
+        # rng="torch" with seed=None draws from torch's DEFAULT generator: its state is snapshotted once per call so that a repeated
+        # session (BeamOverflow retry) replays the same draws (beam.TorchRngNoise)
+        rng_state0 = torch.get_rng_state() if (rng == "torch" and rng_seed is None) else None
         image_emb = image_emb.reshape(image_emb.shape[0], -1).to(plan["dtype"]).contiguous()
 
         def session(lo, hi):
@@ -175,7 +178,7 @@ class LSTMDecoder(_Planned, nn.Module):
             dev = image_emb.device
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
                                       max_len=max_len, seed=seed, img0=img0 + lo,
-                                      noise_source=make_noise_source(rng, rng_seed, noise_source, lo, hi, img0), seed_tensor=seed_tensor,
+                                      noise_source=make_noise_source(rng, rng_seed, noise_source, lo, hi, img0, rng_state0), seed_tensor=seed_tensor,
                                       exact=exact[0])
             pos = 0
             if caption is not None:

@@ -193,7 +193,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     ln2=(f(lyr.enc_attn_ln.weight), f(lyr.enc_attn_ln.bias), lyr.enc_attn_ln.eps))
             layers.append(ent)
         dt = self.classifier.weight.dtype
-        if dt in hip.HALF_DTYPES and self.hid_dim % 128 == 0 and self.hid_dim <= 512 and not os.environ.get("DH_NO_DEFERRED_LN"):
+        if dt in hip.HALF_DTYPES and self.hid_dim % 128 == 0 and self.hid_dim <= 512 and hip.option("deferred_ln"):
             # deferred-LayerNorm chain (dh_linear_ln): the gamma of the LayerNorm in front of a projection folded into its
             # weight, beta into its bias, plus the row sums of the folded (rounded) weight
             def fold(w, b, ln):
@@ -206,7 +206,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 if self._cross:
                     ent["wq_f"], ent["bq_f"], ent["cs_q"] = fold(ent["wq"], ent["bq"], ent["ln1"])
                 ent["w1_f"], ent["b1_f"], ent["cs_1"] = fold(ent["w1"], ent["b1"], ent["ln2"] if self._cross else ent["ln1"])
-            if torch.cuda.is_available() and self.classifier.weight.is_cuda and not os.environ.get("DH_NO_DECODE_WREG"):
+            if torch.cuda.is_available() and self.classifier.weight.is_cuda and hip.option("decode_wreg_plan"):
                 # register-stationary decode GEMMs (dh_linear_ln_wreg): fragment-packed copies of the chain's weights, once per plan
                 hd, pf = self.hid_dim, self.layers[0].pf.fc_1.out_features
                 for i, ent in enumerate(layers):
@@ -218,8 +218,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
         plan = dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
                     scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=f(self.classifier.bias),
                     dtype=self.classifier.weight.dtype)
-        if (plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and os.environ.get("DH_VOCAB_WREG_TRANSFORMER")
-                and not os.environ.get("DH_NO_VOCAB_WREG")):
+        if (plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and hip.option("vocab_wreg_transformer")
+                and hip.option("vocab_wreg_plan")):
             # opt-in here (the LSTM decoder uses it by default): csrc/vocab_wreg.hip wins where the 37 MB of weights are still in the
             # Infinity Cache when the next position's classifier starts; a Transformer position moves ~1 GB of KV cache in between and
             # the step takes the same time with either kernel (20.4-20.7 ms, three alternating runs)
@@ -264,10 +264,10 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 self.s = s
                 self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv") for L in plan["layers"]]   # once per image
                 if (self.dtype in hip.HALF_DTYPES and s <= 64 and d == 64 * dec.n_heads and beam <= 16
-                        and not os.environ.get("DH_NO_PACKED_CROSS")):
+                        and hip.option("packed_cross")):
                     # matrix-core cross-attention: K | V re-laid out per (image, head) in MFMA operand order, once per batch; on the
                     # deferred-LayerNorm chain additionally with K's head-dim slots permuted, so that fc_q runs inside the attention launch
-                    self.dperm = "wq_f" in plan["layers"][0] and d <= 512 and not os.environ.get("DH_NO_QPROJ_FUSION")
+                    self.dperm = "wq_f" in plan["layers"][0] and d <= 512 and hip.option("qproj_fusion")
                     self.packed = [hip.attn_cross_pack(kv, n, s, d, dec.n_heads, dperm=self.dperm) for kv in self.kv]
             self._scratch = {}
             self.pf = dec.layers[0].pf.fc_1.out_features
@@ -454,7 +454,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             if packed_ok:                                  # matrix-core cross-attention, 16 positions per launch
                 # (dperm: the head-dim slot order of the decode chain's fused fc_q + attention launch, so that teacher-forced
                 # logits and incremental decoding sum in the same order)
-                dperm = "wq_f" in L and not os.environ.get("DH_NO_QPROJ_FUSION")
+                dperm = "wq_f" in L and hip.option("qproj_fusion")
                 kp, vt = hip.attn_cross_pack(kv, bs, s_enc, d, nh, dperm=dperm)
                 return hip.attn_cross_prefill_packed(q, kp, vt, keymask, bs, seq, s_enc, d, nh, L["ea_scale"], dperm=dperm)
             return hip.attn_cross_prefill(q, kv, keymask, bs, seq, s_enc, d, nh, L["ea_scale"])
@@ -512,6 +512,9 @@ class _IncrementalDecoder(_Planned, nn.Module):
         plan = self._get_plan()
         rng_seed = seed                   # rng="torch": the draws replay torch CPU generators (beam.TorchRngNoise)
         seed = 0 if rng == "torch" else resolve_seed(seed, noise_source)
+        # rng="torch" with seed=None draws from torch's DEFAULT generator: its state is snapshotted once per call so that a repeated
+        # session (BeamOverflow retry) replays the same draws (beam.TorchRngNoise)
+        rng_state0 = torch.get_rng_state() if (rng == "torch" and rng_seed is None) else None
         if max_len + 1 > self.pos_embedding.num_embeddings:
             raise IndexError("index out of range in self")    # reference: pos_embedding lookup, SURVEY.md section 5
         start_emb = start_emb.to(plan["dtype"]).contiguous()
@@ -525,6 +528,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 if exact:
                     raise
                 warn_overflow_retry()
+                if rng_state0 is not None:
+                    torch.set_rng_state(rng_state0)
                 return self._generate_reforward(start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index, seed,
                                                 img0, noise_source, logits_hook, rng, rng_seed, True)
 
@@ -535,7 +540,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             dev = start_emb.device
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
                                       max_len=max_len, src_len=max_len + 1, seed=seed, img0=img0 + lo,
-                                      noise_source=make_noise_source(rng, rng_seed, noise_source, lo, hi, img0),
+                                      noise_source=make_noise_source(rng, rng_seed, noise_source, lo, hi, img0, rng_state0),
                                       seed_tensor=seed_tensor, exact=exact[0])
             if self.pad_index != 0:
                 helper.tokens.fill_(self.pad_index)

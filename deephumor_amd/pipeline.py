@@ -13,9 +13,9 @@ so that the copy and the encoder of the next batch fill the CUs / the PCIe link 
 Captions are the ones ``generate_batch`` gives for the same ``seed`` / ``img0`` (the streams only reorder independent
 work).  Nothing here computes: every operation is a kernel of libdeephumor_hip.so or a copy.
 """
-import os
-
 import torch
+
+from . import hip
 
 __all__ = ["CaptionPipeline", "u8_preprocess"]
 
@@ -45,7 +45,7 @@ class CaptionPipeline:
             # (a high-priority decode stream -- DH_PIPE_PRIO=1 -- was measured: no gain, the encoder's workgroups hold the CUs
             #  until they retire whatever the queue priority)
             self.copy_s, self.enc_s = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
-            self.dec_s = torch.cuda.Stream(device=self.dev, priority=-1 if os.environ.get("DH_PIPE_PRIO") else 0)
+            self.dec_s = torch.cuda.Stream(device=self.dev, priority=-1 if hip.option("pipe_prio") else 0)
         else:
             self.copy_s = self.enc_s = self.dec_s = torch.cuda.current_stream(self.dev)
         # staging buffers, ONE per (slot, input) / output slot: a batch of another shape replaces the slot's buffer (a service fed
@@ -121,15 +121,16 @@ class CaptionPipeline:
             if len(res) > 2:
                 err_host = torch.empty((1,), dtype=torch.int32).pin_memory()
                 err_host.copy_(res[2].view(-1)[:1], non_blocking=True)
+            slot = None
             if to_host:
-                toks, lens = self._to_host(toks, lens)
+                slot = self._out_slot
+                self._out_slot = (self._out_slot + 1) % 3
+                toks, lens = self._to_host(toks, lens, slot)
             done = torch.cuda.Event()
             done.record(self.dec_s)
-        return dict(toks=toks, lens=lens, done=done, err=err_host, redo=(enc, seed, img0, to_host))
+        return dict(toks=toks, lens=lens, done=done, err=err_host, redo=(enc, seed, img0, to_host, slot))
 
-    def _to_host(self, toks, lens):
-        key = self._out_slot
-        self._out_slot = (self._out_slot + 1) % 3
+    def _to_host(self, toks, lens, key):
         bufs = self._host_out.get(key)
         if bufs is None or bufs[0].shape != toks.shape:    # (a replaced pinned pair stays alive while a consumer holds it)
             bufs = self._host_out[key] = (torch.empty(toks.shape, dtype=toks.dtype).pin_memory(),
@@ -149,11 +150,11 @@ class CaptionPipeline:
                 BeamSearchHelper.raise_for(int(q["err"][0]))
             except BeamOverflow:
                 warn_overflow_retry()
-                enc, seed, img0, to_host = q["redo"]
+                enc, seed, img0, to_host, slot = q["redo"]
                 with torch.cuda.stream(self.dec_s), torch.no_grad():
                     toks, lens = self.model.decode(enc, seed=seed, img0=img0, exact=True, **self.gen_kw)
-                    if to_host:
-                        toks, lens = self._to_host(toks, lens)
+                    if to_host:           # into the pinned pair THIS batch already owns (the other two may still be held by the consumer)
+                        toks, lens = self._to_host(toks, lens, slot)
                 self.dec_s.synchronize()
                 return toks, lens
         return q["toks"], q["lens"]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 26
+#define DH_ABI_VERSION 27
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -675,6 +675,24 @@ int dh_prof_end(void);
 int dh_prof_num(void);
 int dh_prof_get(int i, char* name, int cap, int* calls, double* ms, double* flops, double* bytes);
 void dh_prof_tag(const char* tag);
+
+/* ---------------------------------------------------------------------------------------------
+ * Run-time options: every switch that selects between (results-identical) kernels or tile shapes, and the one that
+ * selects the arithmetic of fp32 models ("f32_split"), lives in ONE table.  An option's default comes from its
+ * environment variable (read once, at the option's first use) or, when that is unset, from the built-in default;
+ * dh_set_option overrides it from then on and takes effect at the next call of any entry point (nothing is latched).
+ * Weight plans the Python layer has already built keep the kernels they were built for (deephumor_amd.hip.set_option
+ * documents which options are plan-time).  Process-global, not thread-safe against concurrent launches.
+ *   dh_option_count()              number of options
+ *   dh_option_name(i)              "key" of option i (NULL when out of range); dh_option_env(i) its environment variable
+ *   dh_get_option(key, &value)     DH_ERR_BAD_ARG for an unknown key
+ *   dh_set_option(key, value)
+ * ------------------------------------------------------------------------------------------- */
+int dh_option_count(void);
+const char* dh_option_name(int i);
+const char* dh_option_env(int i);
+int dh_get_option(const char* key, int* value);
+int dh_set_option(const char* key, int value);
 
 #ifdef __cplusplus
 }

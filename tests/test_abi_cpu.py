@@ -61,16 +61,37 @@ def test_every_entry_point_rejects_all_zero_arguments():
     lib = hip.load()
     called = 0
     for name, sig in hip.SIGNATURES.items():
-        if name == "dh_abi_version" or name.endswith("_supported") or name.startswith("dh_prof") or name == "dh_strerror":
+        if name in ("dh_abi_version", "dh_option_count") or name.endswith("_supported") or name.startswith("dh_prof") or name == "dh_strerror":
             continue
         args = []
         for t in sig:
             if t in (ctypes.c_float, ctypes.c_double):
                 args.append(0.0)
-            elif isinstance(getattr(t, "_type_", None), type):            # POINTER(struct)
+            elif isinstance(getattr(t, "_type_", None), type) or t is ctypes.c_char_p:            # POINTER(struct), const char*
                 args.append(None)
             else:
                 args.append(0)
         assert getattr(lib, name)(*args) != 0, name
         called += 1
     assert called >= 55
+
+
+def test_option_table():
+    """dh_set_option / dh_get_option: one table for every kernel-selection switch; defaults from the environment at first use, a set
+    value is read back, an unknown key is an argument error, and changing an option re-keys the models' weight plans."""
+    from deephumor_amd import hip
+    opts = hip.options()
+    assert len(opts) >= 30 and all(env.startswith("DH_") for _, env in opts.values())
+    for key in ("decode_wreg", "decode_wreg_min_rows", "qkv_fusion_max_rows", "cross_qproj", "lstm_wreg", "vocab_wreg", "f32_split",
+                "conv1x1_wreg", "deferred_ln", "fused_beam_step_max_rows", "dist_always"):
+        assert key in opts, key
+    lib = hip.load()
+    assert lib.dh_set_option(b"no_such_option", 1) == 1 and lib.dh_get_option(b"no_such_option", None) == 1
+    epoch = hip.options_epoch
+    old = hip.set_option("decode_wreg_min_rows", 123)
+    assert hip.option("decode_wreg_min_rows") == 123 and hip.options_epoch == epoch + 1
+    with hip.option_scope(decode_wreg_min_rows=7, cross_qproj=0):
+        assert hip.option("decode_wreg_min_rows") == 7 and hip.option("cross_qproj") == 0
+    assert hip.option("decode_wreg_min_rows") == 123 and hip.option("cross_qproj") == opts["cross_qproj"][0]
+    hip.set_option("decode_wreg_min_rows", old)
+    assert hip.option("decode_wreg_min_rows") == opts["decode_wreg_min_rows"][0]

@@ -518,7 +518,7 @@ def test_fused_beam_step_equals_two_launches(hip, n_img, beam, top_k, v, src_len
     max_len = 9
     mk = lambda: BeamSearchHelper(1.1, beam, top_k, 1, 3, "cuda", n_img=n_img, max_len=max_len, src_len=src_len, seed=77, img0=5)
     a, b = mk(), mk()
-    a.fused_step, b.fused_step = True, False              # (the model path opts in with DH_FUSED_BEAM_STEP=1)
+    a.fused_step, b.fused_step = True, False              # (the model path opts in with option fused_beam_step = 1)
     ng = hip.n_groups(v)
     for step in range(5):
         rows = n_img if step == 0 else n_img * beam
@@ -580,13 +580,9 @@ def test_encoder_16bit_other_image_sizes(h, w):
         tol = 0.12 if HALF == torch.bfloat16 else 0.02
         assert float((emb16.float() - emb32).abs().max()) < tol * max(1.0, float(emb32.abs().max()))
         if (h, w) == (224, 224):
-            saved = {k: os.environ.get(k) for k in ("DH_NO_S3_TAIL", "DH_NO_FUSED_TAIL", "DH_NO_DIRECT_3X3")}
-            try:
-                os.environ.update(DH_NO_S3_TAIL="1", DH_NO_FUSED_TAIL="1", DH_NO_DIRECT_3X3="1")
+            from deephumor_amd import hip as H
+            with H.option_scope(s3_tail=0, fused_tail=0, direct_3x3=0):
                 emb_g, sp_g = e16(x)
-            finally:
-                for k, v in saved.items():
-                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             assert torch.equal(emb_g, emb16) and torch.equal(sp_g, sp16)
 
 
@@ -783,9 +779,9 @@ def test_linear_ln_wreg_equals_tile_kernels(hip, m):
 
 
 @pytest.mark.parametrize("kind", ["CaptioningTransformer", "CaptioningTransformerBase"])
-def test_decode_chain_wreg_equals_tile_chain(kind, monkeypatch):
-    """The decode chain on the register-stationary GEMMs against the same chain on the tile kernels (plan built with
-    DH_NO_DECODE_WREG): 64 images x beam 5 (320 rows: the wreg threshold) -- same tokens, same lengths, bit for bit."""
+def test_decode_chain_wreg_equals_tile_chain(kind):
+    """The decode chain on the register-stationary GEMMs against the same chain on the tile kernels (plan built with option
+    decode_wreg_plan = 0): 64 images x beam 5 (320 rows: the wreg threshold) -- same tokens, same lengths, bit for bit."""
     import deephumor_amd.models as M
     from deephumor_amd.synth import synth_state_dict
     model = getattr(M, kind)(1000, hid_dim=512, n_layers=2).eval()
@@ -795,38 +791,34 @@ def test_decode_chain_wreg_equals_tile_chain(kind, monkeypatch):
     with torch.no_grad():
         t1, l1 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
         assert "wo_pk" in model.decoder._get_plan()["layers"][0]
-        monkeypatch.setenv("DH_NO_DECODE_WREG", "1")
-        model.decoder._drop_plan()
-        assert "wo_pk" not in model.decoder._get_plan()["layers"][0]
-        t2, l2 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
-        monkeypatch.delenv("DH_NO_DECODE_WREG")
-        model.decoder._drop_plan()
+        from deephumor_amd import hip as H
+        with H.option_scope(decode_wreg_plan=0):          # (a changed option re-keys the plan: it is rebuilt at the next call)
+            assert "wo_pk" not in model.decoder._get_plan()["layers"][0]
+            t2, l2 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
+        assert "wo_pk" in model.decoder._get_plan()["layers"][0]
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
 
 
 @pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
-def test_decode_with_vocab_wreg_equals_vocab_areg(kind, monkeypatch):
+def test_decode_with_vocab_wreg_equals_vocab_areg(kind):
     """Beam search with the register-streamed classifier (dh_vocab_logits_wreg: 64 images x beam 5 = 320 rows = 4 row blocks) against
-    the same decode on dh_vocab_logits (plan built with DH_NO_VOCAB_WREG): a vocabulary that ends inside a chunk -- same tokens, same
+    the same decode on dh_vocab_logits (plan built with option vocab_wreg_plan = 0): a vocabulary that ends inside a chunk -- same tokens, same
     lengths, bit for bit; a batch whose row count the kernel does not take (3 images) falls back and is split-invariant."""
     import deephumor_amd.models as M
     from deephumor_amd.synth import synth_state_dict
     kw = dict(hid_dim=512, n_layers=1) if "Transformer" in kind else dict(hidden_size=512)
-    monkeypatch.setenv("DH_VOCAB_WREG_TRANSFORMER", "1")   # (opt-in for the Transformer decoder, default for the LSTM decoder)
+    from deephumor_amd import hip as H
     model = getattr(M, kind)(3001, **kw).eval()
     model.load_state_dict(synth_state_dict(model.state_dict(), seed=987))
     model = model.to(HALF).cuda()
     imgs = synth_images(64, seed=12).cuda()
-    with torch.no_grad():
+    with torch.no_grad(), H.option_scope(vocab_wreg_transformer=1):   # (opt-in for the Transformer decoder, default for the LSTM decoder)
         t1, l1 = model.generate_batch(imgs, max_len=9, beam_size=5, top_k=20, seed=6)
         s1 = model.generate_batch(imgs[:3], max_len=9, beam_size=5, top_k=20, seed=6)
         assert "cls_w_pk" in model.decoder._get_plan()
-        monkeypatch.setenv("DH_NO_VOCAB_WREG", "1")
-        model.decoder._drop_plan()
-        assert "cls_w_pk" not in model.decoder._get_plan()
-        t2, l2 = model.generate_batch(imgs, max_len=9, beam_size=5, top_k=20, seed=6)
-        monkeypatch.delenv("DH_NO_VOCAB_WREG")
-        model.decoder._drop_plan()
+        with H.option_scope(vocab_wreg_plan=0):
+            assert "cls_w_pk" not in model.decoder._get_plan()
+            t2, l2 = model.generate_batch(imgs, max_len=9, beam_size=5, top_k=20, seed=6)
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
     assert torch.equal(s1[0], t1[:3]) and torch.equal(s1[1], l1[:3])
 
@@ -964,7 +956,7 @@ def test_conv1x1_dual_wreg_with_next_conv1(hip, n):
 
 
 @pytest.mark.parametrize("n", [4, 48])
-def test_encoder_round4_kernels_equal_the_kernels_they_replace(n, monkeypatch):
+def test_encoder_round4_kernels_equal_the_kernels_they_replace(n):
     """The whole 16-bit encoder with the round-4 kernels (streaming 1x1 / dual layers, the register-streamed stage-1 / 2 / 4 kernels, the
     next bottleneck's conv1 fused behind the stage-1 dual launch and the stage-1 tail) against the same encoder with every one of them
     switched off: embeddings and spatial features bit for bit, at a batch where only some of them engage (4 images) and at one where
@@ -977,11 +969,11 @@ def test_encoder_round4_kernels_equal_the_kernels_they_replace(n, monkeypatch):
     x = synth_images(n, seed=77).cuda()
     with torch.no_grad():
         emb, sp = enc(x)
-        for k in ("DH_NO_CONV1X1_WREG", "DH_NO_CONV_S4", "DH_NO_S2_TAIL", "DH_NO_S1_CONV1_FUSION", "DH_NO_S2_CONV1_FUSION"):
-            monkeypatch.setenv(k, "1")
-        emb0, sp0 = enc(x)
-        monkeypatch.delenv("DH_NO_S1_CONV1_FUSION")                 # the stage-1 fusions alone on top of the tile / ring kernels
-        monkeypatch.delenv("DH_NO_S2_TAIL")                         # ... and the stage-2 strip tail without its fusion
-        emb1, sp1 = enc(x)
+        from deephumor_amd import hip as H
+        with H.option_scope(conv1x1_wreg=0, conv_s4=0, s2_tail=0, s1_conv1_fusion=0, s2_conv1_fusion=0):
+            emb0, sp0 = enc(x)
+        # the stage-1 fusions alone on top of the tile / ring kernels, and the stage-2 strip tail without its fusion
+        with H.option_scope(conv1x1_wreg=0, conv_s4=0, s2_conv1_fusion=0):
+            emb1, sp1 = enc(x)
     assert torch.equal(emb, emb0) and torch.equal(sp, sp0)
     assert torch.equal(emb, emb1) and torch.equal(sp, sp1)

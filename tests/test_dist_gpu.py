@@ -35,7 +35,8 @@ with torch.no_grad():
     rows = torch.randn(6, 5, device=dev)
     back = score_sharded(lambda lo, hi: rows[lo:hi], 6, always=True)
 import bench
-os.environ["DH_DIST_ALWAYS"] = "1"
+from deephumor_amd import hip
+hip.set_option("dist_always", 1)
 dt, out = bench.timed_region(lambda s: s + 1, 3, 1, dev)
 print("RESULT " + json.dumps({"backend": dist.get_backend(), "ids": bool(torch.equal(want[0], got[0]) and torch.equal(want[1], got[1])),
                               "rows": bool(torch.equal(rows, back)), "timed_out": out, "dt_ok": dt > 0,

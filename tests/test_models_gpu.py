@@ -465,6 +465,38 @@ def test_pipeline_schedules_and_deferred_error_word(kind):
         flat = model.generate_batch(batches[0][0].cuda(), seed=5, max_len=6, beam_size=3, top_k=20)
         pipe = CaptionPipeline(model, max_len=6, beam_size=3, top_k=20)
         got = [(t.clone(), l.clone()) for t, l in pipe.run(batches[:2], seeds=[5, 6])]
+        flat1 = model.generate_batch(batches[1][0].cuda(), seed=6, max_len=6, beam_size=3, top_k=20)
+        #  the repeated batch lands in the pinned pair it already owns: the PREVIOUS result, which the consumer may hold
+        # across one further iteration, is not overwritten by it
+        pipe = CaptionPipeline(model, max_len=6, beam_size=3, top_k=20)
+        held = None
+        for i, (t, l) in enumerate(pipe.run(batches[:3], seeds=[5, 6, 5])):
+            if held is not None:
+                assert torch.equal(held[0], held[2]) and held[0].data_ptr() != t.data_ptr(), i
+            held = (t, l, t.clone())
+    assert torch.equal(flat[0].cpu(), got[0][0]) and torch.equal(flat[1].cpu(), got[0][1])
+    assert torch.equal(flat1[0].cpu(), got[1][0]) and torch.equal(flat1[1].cpu(), got[1][1])
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_pipeline_with_decode_streams(kind):
+    """ ``CaptionPipeline(model, streams=2)``: the decode sessions run as two interleaved sub-batches AND defer their error
+    words -- same captions as ``generate_batch``; flat logits are still caught (the sub-batches' error words are OR-ed)."""
+    from deephumor_amd.pipeline import CaptionPipeline
+    model, _, _ = build(kind)
+    model = model.bfloat16()
+    imgs = synth_images(9, seed=4)
+    batches = [(imgs[3 * i:3 * i + 3].pin_memory(),) for i in range(3)]
+    kw = dict(max_len=8, beam_size=3, top_k=20, temperature=1.0)
+    with torch.no_grad():
+        want = [model.generate_batch(b[0].cuda(), seed=30 + i, **kw) for i, b in enumerate(batches)]
+        pipe = CaptionPipeline(model, streams=2, **kw)
+        for i, (gt, gl) in enumerate(pipe.run(batches, seeds=[30, 31, 32])):
+            assert torch.equal(want[i][0].cpu(), gt) and torch.equal(want[i][1].cpu(), gl), i
+        model.decoder.classifier.weight.zero_()
+        model.decoder.classifier.bias.zero_()
+        flat = model.generate_batch(batches[0][0].cuda(), seed=5, **kw)
+        got = [(t.clone(), l.clone()) for t, l in CaptionPipeline(model, streams=2, **kw).run(batches[:1], seeds=[5])]
     assert torch.equal(flat[0].cpu(), got[0][0]) and torch.equal(flat[1].cpu(), got[0][1])
 
 
