@@ -446,6 +446,24 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                                        "note": "same step, fp32 storage + exact-fp32 arithmetic: the path whose greedy ids are bit-exact"}
             del m32
             torch.cuda.empty_cache()
+            # the parity-grade matrix-core path: the same fp32 model with option f32_split (every dense layer / convolution as three
+            # fp16 MFMAs on split operands, csrc/gemm_f32x.hip): fp32-class results -- its greedy ids are held to the same gates as
+            # the exact-fp32 path's (tests/test_f32x_gpu.py) -- at a multiple of the exact path's rate
+            from deephumor_amd import hip as _hip
+            with _hip.option_scope(f32_split=1):
+                mx = build_model(workload, dev, "f32")[0]
+                gx = greedy_match(workload, mx, sd, hp, N_CHECK)
+                cmpx = compare_greedy(ref, greedy_all(mx, images))
+                with torch.no_grad():
+                    one_step(mx, images, 0, n_total, seed=0)
+                    tx, _, _ = timed_steps(mx, images, 0, n_local, n_total, 5, barrier)
+                del mx
+            torch.cuda.empty_cache()
+            res["parity_grade_path"] = {"value": n_total * 5 / tx, "unit": "captions/s", "ms_per_step": tx / 5 * 1e3, "steps": 5,
+                                        "greedy_token_match_vs_cpu_ref": gx, "vs_exact_fp32_hip_all_images": cmpx,
+                                        "speedup_over_exact_fp32_path": t32 / 3 / (tx / 5),
+                                        "note": "fp32 storage, dense layers + convolutions as split-operand fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 "
+                                                "accumulation): logits within 1e-3 and greedy ids bit-exact vs the reference in tests/test_f32x_gpu.py"}
             # what 16-bit storage costs in greedy tokens: both 16-bit paths against the fp32 HIP path (bit-exact vs the CPU
             # oracle on the checked images above and on rows {0, 77, 255} in tests/test_fullsize_gpu.py) over ALL bench images
             res["precision_vs_fp32_hip"] = {"reference": "fp32 HIP path, greedy (beam 1, top_k 1), all bench images",
@@ -498,6 +516,89 @@ def run_c5(args, rank, world, dev, dtype):
             "mean_caption_len": float(lens.float().mean())}
 
 
+def run_shard(args, dev, dtype):
+    """``--shard-of W [--shard-rank R]``: ONE GPU times exactly what rank R of a W-rank run would do -- its image shard (C2 / C3:
+    ``--batch`` images of a W x batch global batch, global indices from R x batch; C5: ``shard_range(300, R, W)`` = 38 or 37
+    templates x beam 10), followed by the per-batch all_gather of the ``[cap, T + 1]`` payload a rank contributes, through the
+    one-rank RCCL group when ``--rccl-single`` is given.  Printed next to the measured shard time: the same workload's FULL batch on
+    this one GPU (C5: all 300 templates) and ``projected_value`` = n_total / shard time -- a PROJECTION (W identical GPUs, no
+    straggler, an all_gather no slower than the one-rank one), labelled as such; it is not a multi-GPU measurement."""
+    import numpy as np
+    import torch.distributed as dist
+    from deephumor_amd import hip
+    from deephumor_amd.dist import shard_range
+    from deephumor_amd.synth import synth_images
+    wl = {"both": "c2"}.get(args.workload, args.workload)
+    W, R = args.shard_of, args.shard_rank
+    model, sd, hp = build_model(wl, dev, dtype)
+    labels_all = None
+    if wl == "c5":
+        n_total, beam, seed_img = 300, 10, 2
+        lo, hi = shard_range(n_total, R, W)
+        g = np.random.Generator(np.random.Philox(key=[1, 0]))
+        labels_all = torch.from_numpy(g.integers(6, V_WORD, size=(n_total, 3)).astype(np.int64)).to(dev)
+    else:
+        n_total, beam, seed_img = args.batch * W, BEAM, 0
+        lo, hi = R * args.batch, (R + 1) * args.batch
+    kw = dict(max_len=MAX_LEN, beam_size=beam, top_k=TOP_K, temperature=TEMP)
+    cap = -(-n_total // W)
+    use_pg = dist.is_available() and dist.is_initialized()
+
+    def exchange(toks, lens):
+        """What gather_captions does on a W-rank group, for this rank's payload: pad to the largest shard, one all_gather."""
+        packed = torch.zeros((cap, toks.shape[1] + 1), dtype=torch.int64, device=toks.device)
+        packed[:toks.shape[0], :-1] = toks
+        packed[:toks.shape[0], -1] = lens
+        if use_pg:
+            out = torch.empty((dist.get_world_size() * cap, packed.shape[1]), dtype=torch.int64, device=toks.device)
+            dist.all_gather_into_tensor(out, packed)
+            return out
+        return packed
+
+    def timed(a, b, steps, warm):
+        imgs = synth_images(b - a, seed=seed_img, first=a).to(dev)
+        lab = () if labels_all is None else (labels_all[a:b],)
+        step = lambda s: exchange(*model.generate_batch(imgs, *lab, seed=100 + s, img0=a, **kw))
+        with torch.no_grad():
+            for w in range(max(1, warm)):
+                step(-1 - w)
+            with hip.profile() as prof:
+                step(0)
+            dt, _ = timed_region(step, steps, 1, dev)
+        bd = prof.summary()
+        by_entry = {}
+        for k, v in bd.items():
+            base = re.sub(r"\{.*\}$", "", k)
+            e = by_entry.setdefault(base, [0, 0.0])
+            e[0] += v["calls"]; e[1] += v["ms"]
+        launches = sum(v["calls"] for v in bd.values())
+        return dt / steps, {"launches_per_step": launches,
+                            "event_timed_ms_per_step": {k: [c, round(ms, 3)] for k, (c, ms) in sorted(by_entry.items(), key=lambda kv: -kv[1][1])}}
+
+    t_shard, bd_shard = timed(lo, hi, args.steps, args.warmup)
+    full_n = n_total if wl == "c5" else args.batch            # C2 / C3 are weak scaling: the 1-GPU workload IS one shard
+    if wl == "c5":
+        t_full, bd_full = timed(0, n_total, max(2, args.steps // 2), 1)
+    else:
+        t_full, bd_full = t_shard, None
+    res = {"workload": workload_name(wl), "dtype": dtype,
+           "shard": {"of": W, "rank": R, "images": hi - lo, "rows_per_position": (hi - lo) * beam, "img0": lo, "shard_ms": t_shard * 1e3,
+                     "exchange": (f"one-rank RCCL all_gather_into_tensor of the [{cap}, {MAX_LEN + 1}] int64 payload per batch" if use_pg else
+                                  "payload packed, no process group (run with --rccl-single for the collective)"),
+                     "breakdown": bd_shard},
+           "one_gpu": {"images": full_n, "ms": t_full * 1e3, "value": full_n / t_full, "unit": "captions/s"},
+           "projection": {"label": f"PROJECTION, not a measurement: n_total / shard time of rank {R} (the largest shard for rank 0), assuming {W} "
+                                   "identical GPUs, no straggler and an all_gather no slower than the one-rank one",
+                          "n_total": n_total, f"projected_{W}gpu_value": n_total / t_shard, "unit": "captions/s",
+                          f"projected_speedup_over_one_gpu": (n_total / t_shard) / (full_n / t_full),
+                          "scaling": "strong" if wl == "c5" else "weak"}}
+    if bd_full is not None:
+        res["one_gpu"]["breakdown"] = bd_full
+    res["options"] = {k: v[0] for k, v in hip.options().items() if k in ("decode_wreg_min_rows", "qkv_fusion_max_rows", "fused_beam_step",
+                                                                          "fused_beam_step_max_rows", "cross_qproj", "lstm_wreg_min_rows", "decode_wreg")}
+    return res
+
+
 def run_score(args, rank, world, dev, dtype, kind):
     """teacher-forced scoring (per-caption perplexity) of a caption corpus with per-template
     encoder-feature caching: 300 templates x 30 captions of 32 tokens, captions sharded over the ranks, one
@@ -522,12 +623,65 @@ def run_score(args, rank, world, dev, dtype, kind):
     def run():
         return score_sharded(lambda lo, hi: score_captions(model, images, tpl[lo:hi], caps[lo:hi], lengths_d[lo:hi], batch_size=args.score_batch), n_total)
 
+    from deephumor_amd import hip
     pp = run()
+    with hip.profile() as prof0:                          # untimed instrumented pass: which launch key dominates the pass
+        run()
+    breakdown = prof0.summary()
+    dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])
     reps = max(1, args.steps)
-    dt, pp = timed_region(lambda s: run(), reps, world, dev)
-    return {"workload": f"teacher-forced scoring, {kind_of(kind)}, 300 templates x 30 captions x 32 tokens, V={V_WORD}",
-            "value": n_total * reps / dt, "unit": "captions scored/s", "passes": reps, "ms_per_pass": dt / reps * 1e3,
-            "captions": n_total, "mean_perplexity": float(pp.float().mean()), "dtype": dtype}
+    stride = max(1, breakdown[dominant]["calls"] // 32)
+    with hip.profile(watch={dominant}, stride=stride) as prof:       # events around the dominant key's launches inside the timed region
+        dt, pp = timed_region(lambda s: run(), reps, world, dev)
+    summary = prof.summary()
+    res = {"workload": f"teacher-forced scoring, {kind_of(kind)}, 300 templates x 30 captions x 32 tokens, V={V_WORD}",
+           "value": n_total * reps / dt, "unit": "captions scored/s", "passes": reps, "ms_per_pass": dt / reps * 1e3,
+           "captions": n_total, "mean_perplexity": float(pp.float().mean()), "dtype": dtype}
+    res["roofline"] = price(dominant, (summary if dominant in summary else breakdown)[dominant], dtype)
+    res["roofline"]["measured"] = f"timed region, every {stride}th launch" if dominant in summary else "instrumented pass"
+    by_entry = {}
+    for k, v in breakdown.items():
+        base = re.sub(r"\{.*\}$", "", k)
+        by_entry[base] = by_entry.get(base, 0.0) + v["ms"]
+    res["kernel_breakdown_ms_per_pass"] = {k: round(v, 3) for k, v in sorted(by_entry.items(), key=lambda kv: -kv[1])}
+    if rank == 0 and world == 1 and not args.no_cpu and not args.quick:
+        res["cpu_baseline"] = cpu_baseline_score(kind, sd, hp, images.cpu(), tpl, caps.cpu(), lengths)
+        res["speedup_vs_cpu"] = res["value"] / res["cpu_baseline"]["value"]
+    return res
+
+
+def cpu_baseline_score(kind, sd, hp, images, tpl, caps, lengths):
+    """The oracle's teacher-forced scoring (the reference's forward + perplexity per (template, caption) pair, trainer.py:63-81 /
+    metrics.py:4-9; the encoder re-run per pair as the reference's evaluation loop does) on a bounded sample of the same corpus:
+    torch thread-count sweep on 2 pairs, then about 12 s of pairs at the best thread count."""
+    from oracle import ref_path as R
+    k = kind_of(kind)
+
+    def score(i):
+        logits = R.model_forward(k, sd, hp, images[tpl[i]:tpl[i] + 1], caps[i:i + 1, :-1])[:, :caps.shape[1]]
+        return float(R.perplexity(logits, caps[i:i + 1], lengths[i:i + 1]))
+
+    t_all = time.perf_counter()
+    saved = torch.get_num_threads()
+    sweep = {}
+    cands = sorted({t for t in (8, 16, 32, 64) if t <= (os.cpu_count() or 8)} | {min(8, os.cpu_count() or 8)})
+    for th in cands:
+        torch.set_num_threads(th)
+        score(0)
+        t0 = time.perf_counter()
+        score(1), score(2)
+        sweep[th] = (time.perf_counter() - t0) / 2
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    n = int(max(4, min(200, 12.0 // sweep[best])))
+    t0 = time.perf_counter()
+    pps = [score(3 + i) for i in range(n)]
+    dt = time.perf_counter() - t0
+    torch.set_num_threads(saved)
+    return {"value": n / dt, "unit": "captions scored/s", "cores": best, "kind": "port", "host_cpus": os.cpu_count(),
+            "thread_sweep_s_per_pair": {str(k_): round(v, 3) for k_, v in sweep.items()}, "mean_perplexity_of_sample": sum(pps) / n,
+            "sample": f"{n} (template, caption) pairs of the same corpus, one pass, {k} V={V_WORD}, per-pair encoder + teacher-forced forward + "
+                      f"perplexity (reference evaluation loop), {time.perf_counter() - t_all:.1f} s of CPU work in all"}
 
 
 def git_head():
@@ -626,6 +780,9 @@ def main(argv=None):
                     help="storage/MFMA operand type of the measured path (BASELINE configs C2-C4: bf16, C5: fp16)")
     ap.add_argument("--rccl-single", action="store_true", help="with --gpus 1: create the RCCL process group anyway (one rank) and run the "
                     "barriers, the max-reduction and the per-batch all_gather of the N > 1 path through it")
+    ap.add_argument("--shard-of", type=int, default=0, help="with --gpus 1: time the shard rank --shard-rank of a W-rank run would decode "
+                    "(C5: 38 / 37 of the 300 templates; C2 / C3: --batch images of a W x batch global batch) and print a labelled projection")
+    ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--stub", action="store_true", help="CPU/gloo control-flow test of the multi-rank path (model stubbed; not a measurement)")
     args = ap.parse_args(argv)
     if args.dtype is None:
@@ -684,6 +841,18 @@ def main(argv=None):
                            warmup=args.warmup, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="none", data="stub",
                            config={"workload": "STUB: control flow only, no model, CPU/gloo"}))
 
+    if args.shard_of:
+        if world != 1 or not 0 <= args.shard_rank < args.shard_of or args.workload.startswith("score-"):
+            print("bench.py: --shard-of needs --gpus 1, 0 <= --shard-rank < --shard-of and a decode workload", file=sys.stderr)
+            return 2
+        res = run_shard(args, dev, args.dtype)
+        wl = {"both": "c2"}.get(args.workload, args.workload)
+        return finish(dict(res, metric="captions/sec of ONE rank's shard on one GPU + projected whole-job rate (see projection.label)",
+                           value=res["shard"]["images"] / (res["shard"]["shard_ms"] / 1e3), unit="captions/s", n_gpus=1, steps=args.steps,
+                           warmup=args.warmup, ms_per_step=res["shard"]["shard_ms"], higher_is_better=True, scaling=res["projection"]["scaling"],
+                           vs_baseline=None, data="synthetic",
+                           config={"workload": workload_name(wl), "shard_of": args.shard_of, "shard_rank": args.shard_rank,
+                                   "vocab": V_WORD, "max_len": MAX_LEN, "top_k": TOP_K, "commit": git_head()}))
     if args.workload.startswith("score-"):
         res = run_score(args, rank, world, dev, args.dtype, args.workload.split("-")[1])
         return finish(dict(res, metric="captions scored/sec (teacher-forced perplexity, 32 tokens)", n_gpus=world,
@@ -709,9 +878,13 @@ def main(argv=None):
                    "inputs": "device-resident fp32 NCHW images (host-inclusive rates under host_inclusive)",
                    "hipgraph": bool(args.graph), "commit": git_head()},
         "roofline": res["roofline"], "cpu_baseline": res.get("cpu_baseline"),
+        # which rate `value` is: the bench contract's (inputs already resident in HBM when the timed region starts; a PCIe-inclusive rate
+        # is never `value`).  SURVEY 8(d) / BASELINE.md section 3 define the metric host images -> host ids: that one is
+        # `value_host_inclusive` (pipelined, decoded uint8 images in pinned memory) with its ratio to `value` next to it
+        "value_def": "device-resident fp32 NCHW images -> token ids on the device (bench contract); host -> host: value_host_inclusive",
     }
     for k in ("greedy_token_match_vs_cpu_ref", f"greedy_token_match_{args.dtype}_vs_cpu_ref", "precision_vs_fp32_hip", "speedup_vs_cpu", "pipelined_device_resident",
-              "mean_caption_len", "fp32_parity_path", "f16_path", "bf16_path", "host_inclusive", "hipgraph_replay", "kernel_breakdown_ms_per_step", "kernel_breakdown_note",
+              "mean_caption_len", "fp32_parity_path", "parity_grade_path", "f16_path", "bf16_path", "host_inclusive", "hipgraph_replay", "kernel_breakdown_ms_per_step", "kernel_breakdown_note",
               "encoder_layers", "roofline_self_attention", "roofline_cross_attention", "roofline_decoder_attention_combined"):
         if k in res:
             line[k] = res[k]
@@ -728,6 +901,8 @@ def main(argv=None):
         if f"{dt}_path" in res:
             line[f"value_{dt}"] = res[f"{dt}_path"]["value"]
     line[f"value_{args.dtype}"] = res["value"]
+    if "parity_grade_path" in res:
+        line["value_parity_grade"] = res["parity_grade_path"]["value"]
     if "hipgraph_replay" in res:
         line["value_hipgraph_replay"] = res["hipgraph_replay"]["value"]
     hi = res.get("host_inclusive")

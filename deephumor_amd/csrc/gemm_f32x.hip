@@ -1,0 +1,366 @@
+// fp32-class GEMMs / convolutions on the 16-bit matrix cores ("f32x", option f32_split): the arithmetic of the fp32 parity path
+// at a multiple of its speed.  The reference is fp32 throughout (rnn_models.py / transformers.py / encoders.py hold no half or
+// autocast); `dh_linear(DH_F32)` runs v_mfma_f32_32x32x2_f32 (157 TF peak) and `dh_conv2d_bn_act(DH_F32)` the vector ALUs.  Here
+// every fp32 operand x is split into two fp16 numbers
+//     x = hi + lo * 2^-11,   hi = fp16(x),   lo = fp16((x - hi) * 2^11)          (22 significand bits; both exact differences)
+// and a product sum over k is three v_mfma_f32_16x16x32_f16 per tile-product with fp32 accumulation
+//     sum a*w  ~=  [sum a_hi*w_hi]  +  2^-11 * [sum a_hi*w_lo + a_lo*w_hi]          (the dropped a_lo*w_lo term is 2^-22 relative)
+// -- every fp16 x fp16 product is exact in fp32, so the result differs from an fp32 FMA chain by the same few ulps two fp32
+// summation orders differ by (tests/test_f32x_gpu.py: against fp64).  Range contract: |x| < 65504 (checked for weights when a plan
+// is built; activations of this model are O(10)).
+//
+// One tile kernel, C[M,N] = act((A W^T + bias) * scale + shift (+ residual)):
+//   A   fp32, dense [M, lda] or the implicit im2col of a channels-last (NHWC) fp32 activation (row = output pixel, k = (kh, kw, ci));
+//       loaded by 16-byte global loads into registers one slab ahead, split there, written to LDS as two fp16 planes;
+//   W   two fp16 planes [2][N][Kp] (hi, then lo * 2^11; Kp = K rounded up to 32, zero padded) made ONCE per weight version by
+//       dh_split_f32x; LDS-DMA straight into the LDS planes (swizzle on the source address);
+//   128 x 128 tile, 32-k slabs, two LDS stages of 32 KB (two workgroups per CU), 4 waves of 64 x 64 = 4 x 4 MFMA tiles with TWO
+//   accumulator sets (main, correction), 48 MFMAs per wave per slab, one barrier per slab;
+//   weights are the MFMA "A" operand: an accumulator quad is 4 consecutive output columns of one row -> 16-byte fp32 stores.
+#include "common.h"
+#include "prof.h"
+
+namespace {
+
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+struct F32xParams {
+    const float* A; int lda;
+    const uint16_t* Wp; int Kp; size_t plane;          // plane = elements from the hi plane to the lo plane
+    const float* bias; const float* scale; const float* shift;
+    const float* res; int ldres;
+    float* C; int ldc;
+    int M, N, K, relu;
+    int H, Wd, Cin, Ho, Wo, KS, stride, pad;           // conv loader (NHWC input)
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const f16_t ha = (f16_t)a, hb = (f16_t)b;
+    const f16_t la = (f16_t)((a - (float)ha) * kLoScale), lb = (f16_t)((b - (float)hb) * kLoScale);
+    hi = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+    lo = (uint32_t)__builtin_bit_cast(uint16_t, la) | ((uint32_t)__builtin_bit_cast(uint16_t, lb) << 16);
+}
+
+// position of 16-byte chunk c (0..3) of row r inside the row's 64 bytes: rows r, r+4, r+8, r+12 of a 16-row fragment read
+// would otherwise hit the same banks
+__device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 2) & 3); }
+
+// MODE 0: dense A; 1: convolution with Cin % 32 == 0 (a 32-k slab lies inside one filter tap: the tap is wave-uniform);
+// 2: convolution, any Cin % 4 == 0 (the stem: per-lane tap decode)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_f32x_kernel(F32xParams p) {
+    constexpr int BM = 128, BN = 128, BK = 32;
+    constexpr int PLANE = BM * BK * 2;                   // 8 KB: one fp16 plane of one operand
+    constexpr int STAGE = 4 * PLANE;                     // A hi | A lo | W hi | W lo
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: consecutive tile ids (which share a W panel) stay on one XCD's L2
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // ---- A loader: thread = (row, 4-float chunk kc) x 4 rows; rows fixed over the reduction -----------------------------------
+    const int a_kc = tid & 7;
+    const float* a_ptr[4];
+    int a_ih0[4], a_iw0[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = (tid >> 3) + it * 32, m = m0 + row;
+        a_ok[it] = m < p.M;
+        const int mm = a_ok[it] ? m : 0;
+        a_ih0[it] = a_iw0[it] = 0;
+        if (MODE == 0) {
+            a_ptr[it] = p.A + (size_t)mm * p.lda + a_kc * 4;
+        } else {
+            const int hw = p.Ho * p.Wo, n = mm / hw, r = mm - n * hw, oh = r / p.Wo, ow = r - oh * p.Wo;
+            a_ih0[it] = oh * p.stride - p.pad; a_iw0[it] = ow * p.stride - p.pad;
+            a_ptr[it] = p.A + (((size_t)n * p.H + a_ih0[it]) * p.Wd + a_iw0[it]) * p.Cin + (MODE == 1 ? a_kc * 4 : 0);
+        }
+    }
+    int st_kh = 0, st_kw = 0, st_ci = 0;               // MODE 1: tap of the NEXT slab to load
+    float4 areg[4];
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const float* src = nullptr;
+            if (MODE == 0) {
+                if (a_ok[it] && k0 + a_kc * 4 < p.K) src = a_ptr[it] + k0;
+            } else if (MODE == 1) {
+                if (a_ok[it] && (unsigned)(a_ih0[it] + st_kh) < (unsigned)p.H && (unsigned)(a_iw0[it] + st_kw) < (unsigned)p.Wd)
+                    src = a_ptr[it] + ((ptrdiff_t)st_kh * p.Wd + st_kw) * p.Cin + st_ci;
+            } else {
+                const int k = k0 + a_kc * 4;
+                const int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.KS, kw = tap - kh * p.KS;
+                if (a_ok[it] && k < p.K && (unsigned)(a_ih0[it] + kh) < (unsigned)p.H && (unsigned)(a_iw0[it] + kw) < (unsigned)p.Wd)
+                    src = a_ptr[it] + ((ptrdiff_t)kh * p.Wd + kw) * p.Cin + ci;
+            }
+            areg[it] = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (MODE == 1) {
+            st_ci += BK;
+            if (st_ci == p.Cin) { st_ci = 0; if (++st_kw == p.KS) { st_kw = 0; ++st_kh; } }
+        }
+    };
+    auto store_a = [&](int buf) {
+        unsigned char* ah = lds + buf * STAGE;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = (tid >> 3) + it * 32;
+            uint2 hi, lo;
+            split2(areg[it].x, areg[it].y, hi.x, lo.x);
+            split2(areg[it].z, areg[it].w, hi.y, lo.y);
+            const int off = row * 64 + swz(row, a_kc >> 1) * 16 + (a_kc & 1) * 8;
+            *reinterpret_cast<uint2*>(ah + off) = hi;
+            *reinterpret_cast<uint2*>(ah + PLANE + off) = lo;
+        }
+    };
+    // ---- W loader: LDS-DMA, one wave instruction = 16 rows x 64 B of one plane; wave w moves pieces 2w, 2w+1 of both planes ----
+    const uint16_t* w_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + (lane >> 2);
+        const int n = min(n0 + row, p.N - 1);            // rows past N repeat the last one (their outputs are not stored)
+        w_src[i] = p.Wp + (size_t)n * p.Kp + swz(row, lane & 3) * 8;
+    }
+    auto load_w = [&](int buf, int k0) {
+        unsigned char* wh = lds + buf * STAGE + 2 * PLANE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            dh_lds_dma16(w_src[i] + k0, wh + (wave * 2 + i) * 1024);
+            dh_lds_dma16(w_src[i] + p.plane + k0, wh + PLANE + (wave * 2 + i) * 1024);
+        }
+    };
+
+    dh_f32x4 acc[4][4], cor[4][4];                       // [tn][tm]: main (hi x hi) and correction (hi x lo + lo x hi, scaled 2^11)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; cor[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nslab = p.Kp / BK;
+    load_w(0, 0);
+    load_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_a(0);
+    __syncthreads();
+    for (int t = 0; t < nslab; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nslab) { load_w(buf ^ 1, (t + 1) * BK); load_a((t + 1) * BK); }
+        const unsigned char* ah = lds + buf * STAGE;
+        const unsigned char* wh = ah + 2 * PLANE;
+        uint4 fa_h[4], fa_l[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = wm0 + 16 * i + l15, off = r * 64 + swz(r, lq) * 16;
+            fa_h[i] = *reinterpret_cast<const uint4*>(ah + off);
+            fa_l[i] = *reinterpret_cast<const uint4*>(ah + PLANE + off);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = wn0 + 16 * j + l15, off = r * 64 + swz(r, lq) * 16;
+            const uint4 fw_h = *reinterpret_cast<const uint4*>(wh + off);
+            const uint4 fw_l = *reinterpret_cast<const uint4*>(wh + PLANE + off);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[j][i] = Op16<f16_t>::mfma(fw_h, fa_h[i], acc[j][i]);
+                cor[j][i] = Op16<f16_t>::mfma(fw_h, fa_l[i], cor[j][i]);
+                cor[j][i] = Op16<f16_t>::mfma(fw_l, fa_h[i], cor[j][i]);
+            }
+        }
+        if (t + 1 < nslab) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slab t + 1: A in registers, W planes in LDS
+            store_a(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[j][i][r] = C[m = m0 + wm0 + 16 i + l15][n = n0 + wn0 + 16 j + 4 lq + r] --------------------------------
+    const bool vec = (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + wn0 + 16 * j + 4 * lq;
+        float bi[4], mu[4], ad[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nn = min(n + r, p.N - 1);
+            bi[r] = p.bias ? p.bias[nn] : 0.f;
+            mu[r] = p.scale ? p.scale[nn] : 1.f;
+            ad[r] = p.shift ? p.shift[nn] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm0 + 16 * i + l15;
+            if (m >= p.M || n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(fmaf(cor[j][i][r], kLoInv, acc[j][i][r]) + bi[r], mu[r], ad[r]);
+            float* dst = p.C + (size_t)m * p.ldc + n;
+            if (vec && n + 3 < p.N) {
+                if (p.res) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n);
+                    v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+                }
+                if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) {
+                        float o = v[r];
+                        if (p.res) o += p.res[(size_t)m * p.ldres + n + r];
+                        dst[r] = p.relu ? fmaxf(o, 0.f) : o;
+                    }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void split_f32x_kernel(const float* __restrict__ w, int ldw, uint16_t* __restrict__ planes, int N, int K,
+                                                          int Kp) {
+    const size_t total = (size_t)N * (Kp / 2), plane = (size_t)N * Kp;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
+        const int n = (int)(i / (Kp / 2)), k = (int)(i - (size_t)n * (Kp / 2)) * 2;
+        const float a = k < K ? w[(size_t)n * ldw + k] : 0.f, b = k + 1 < K ? w[(size_t)n * ldw + k + 1] : 0.f;
+        uint32_t hi, lo;
+        split2(a, b, hi, lo);
+        *reinterpret_cast<uint32_t*>(planes + (size_t)n * Kp + k) = hi;
+        *reinterpret_cast<uint32_t*>(planes + plane + (size_t)n * Kp + k) = lo;
+    }
+}
+
+// [N, C, H, W] fp32 -> channels-last [N, H, W, Cp] fp32, channels >= C zero (the f32x stem reads 16-byte pixels)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int C, int H, int W,
+                                                                int Cp) {
+    const size_t total = (size_t)N * H * W;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
+        const size_t hw = (size_t)H * W, n = i / hw, r = i - n * hw;
+        for (int c = 0; c < Cp; ++c) y[i * Cp + c] = c < C ? x[(n * C + c) * hw + r] : 0.f;
+    }
+}
+
+template <int VEC_DUMMY = 0>
+__global__ __launch_bounds__(256) void maxpool3x3s2_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                                                                     int Ho, int Wo) {
+    const int c4 = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * c4;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < total; i += (size_t)gridDim.x * 256ull) {
+        const int cc = (int)(i % c4);
+        size_t r = i / c4;
+        const int ow = (int)(r % Wo); r /= Wo;
+        const int oh = (int)(r % Ho);
+        const int n = (int)(r / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int ih = oh * 2 - 1 + kh;
+            if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int iw = ow * 2 - 1 + kw;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + ih) * W + iw) * C + cc * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(y + (((size_t)n * Ho + oh) * Wo + ow) * C + cc * 4) = m;
+    }
+}
+
+// x [N, HW, C] fp32 -> y [N, C]: mean over the positions in index order (the order dh_avgpool_rows sums an NCHW row in)
+__global__ __launch_bounds__(256) void avgpool_nhwc_f32_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int HW, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    const float* src = x + (size_t)n * HW * C + c;
+    float s = 0.f;
+    for (int j = 0; j < HW; ++j) s += src[(size_t)j * C];
+    y[i] = s / (float)HW;
+}
+
+int launch(const F32xParams& p0, int mode, hipStream_t s) {
+    F32xParams p = p0;
+    p.tiles_m = dh_cdiv(p.M, 128); p.tiles_n = dh_cdiv(p.N, 128);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
+    if (mode == 0) hipLaunchKernelGGL(gemm_f32x_kernel<0>, grid, block, 0, s, p);
+    else if (mode == 1) hipLaunchKernelGGL(gemm_f32x_kernel<1>, grid, block, 0, s, p);
+    else hipLaunchKernelGGL(gemm_f32x_kernel<2>, grid, block, 0, s, p);
+    return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int dh_split_f32x(const float* w, int ldw, void* planes, int N, int K, int Kp, void* stream) {
+    DH_REQUIRE(w && planes && N > 0 && K > 0 && ldw >= K && Kp >= K && (Kp % 32) == 0 && ((uintptr_t)planes % 16) == 0);
+    const size_t total = (size_t)N * (Kp / 2);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(split_f32x_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, ldw, (uint16_t*)planes, N, K, Kp);
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_linear_f32x(const float* A, int lda, const void* w_planes, int Kp, const float* bias, const float* scale, const float* shift,
+                              const float* residual, int ldres, float* C, int ldc, int M, int N, int K, int relu, void* stream) {
+    DH_REQUIRE(A && w_planes && C && M > 0 && N > 0 && K > 0 && lda >= K && ldc >= N && Kp >= K && (Kp % 32) == 0);
+    DH_REQUIRE((lda % 4) == 0 && ((uintptr_t)A % 16) == 0 && ((uintptr_t)w_planes % 16) == 0 && (!residual || ldres >= N));
+    DH_REQUIRE((K % 4) == 0 && (!scale) == (!shift));
+    F32xParams p{};
+    p.A = A; p.lda = lda; p.Wp = (const uint16_t*)w_planes; p.Kp = Kp; p.plane = (size_t)N * Kp;
+    p.bias = bias; p.scale = scale; p.shift = shift; p.res = residual; p.ldres = ldres; p.C = C; p.ldc = ldc;
+    p.M = M; p.N = N; p.K = K; p.relu = relu;
+    dh_prof_set_dims(M, N, K);
+    DhProfScope prof("dh_linear_f32x", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
+    return launch(p, 0, (hipStream_t)stream);
+}
+
+extern "C" int dh_conv2d_nhwc_f32x(const float* x, const void* w_planes, int Kp, const float* scale, const float* shift, const float* residual,
+                                   float* y, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu, void* stream) {
+    DH_REQUIRE(x && w_planes && y && scale && shift && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KS > 0 && stride > 0 && pad >= 0);
+    const int K = KS * KS * Cin;
+    DH_REQUIRE((Cin % 4) == 0 && Kp >= K && (Kp % 32) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_planes % 16) == 0 && ((uintptr_t)y % 16) == 0);
+    const int Ho = (H + 2 * pad - KS) / stride + 1, Wo = (W + 2 * pad - KS) / stride + 1;
+    DH_REQUIRE(Ho > 0 && Wo > 0 && (long long)N * Ho * Wo < (1ll << 31));
+    F32xParams p{};
+    p.A = x; p.Wp = (const uint16_t*)w_planes; p.Kp = Kp; p.plane = (size_t)Cout * Kp;
+    p.scale = scale; p.shift = shift; p.res = residual; p.ldres = Cout; p.C = y; p.ldc = Cout;
+    p.M = N * Ho * Wo; p.N = Cout; p.K = K; p.relu = relu;
+    p.H = H; p.Wd = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KS = KS; p.stride = stride; p.pad = pad;
+    dh_prof_set_tag(KS == 1 ? "1x1" : KS == 3 ? "3x3" : "7x7");
+    dh_prof_set_dims(p.M, Cout, K);
+    DhProfScope prof("dh_conv2d_nhwc_f32x", 2.0 * p.M * Cout * K,
+                     4.0 * ((double)N * H * W * Cin + (double)Cout * K + (double)p.M * Cout * (residual ? 2 : 1)), stream);
+    return launch(p, (Cin % 32) == 0 && Kp == K ? 1 : 2, (hipStream_t)stream);
+}
+
+extern "C" int dh_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream) {
+    DH_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && Cp >= C && Cp <= 8);
+    const size_t total = (size_t)N * H * W;
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    hipLaunchKernelGGL(nchw_to_nhwc_f32_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, N, C, H, W, Cp);
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+    DH_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C % 4) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const size_t total = (size_t)N * Ho * Wo * (C / 4);
+    const int grid = (int)((total + 255) / 256 < 65536 ? (total + 255) / 256 : 65536);
+    DhProfScope prof("dh_maxpool3x3s2_nhwc_f32", 0.0, 0.0, stream);
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_f32_kernel<0>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, Ho, Wo);
+    DH_LAUNCH_CHECK();
+}
+
+extern "C" int dh_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, void* stream) {
+    DH_REQUIRE(x && y && N > 0 && HW > 0 && C > 0);
+    DhProfScope prof("dh_avgpool_nhwc_f32", 0.0, 0.0, stream);
+    hipLaunchKernelGGL(avgpool_nhwc_f32_kernel, dim3(dh_cdiv((long long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, x, y, N, HW, C);
+    DH_LAUNCH_CHECK();
+}

@@ -41,6 +41,15 @@ static int chain_linear(const void* A, int lda, const void* W, const void* W_pk,
     return dh_linear_ln(A, lda, W, K, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
 }
 
+// One dense layer of the plain (non-deferred) chains: fp32 models with split planes (option "f32_split") run it as three fp16
+// MFMAs on split operands (gemm_f32x.hip), everything else through dh_linear.
+static int plain_linear(const void* A, int lda, const void* W, const void* W_x, int ldw, const float* bias, void* C, int ldc, int rows, int N,
+                        int K, int relu, int dt, void* stream) {
+    if (dt == DH_F32 && W_x && dh_opt(DH_OPT_F32_SPLIT) && (lda % 4) == 0 && (K % 4) == 0 && ((uintptr_t)A % 16) == 0)
+        return dh_linear_f32x((const float*)A, lda, W_x, (K + 31) / 32 * 32, bias, nullptr, nullptr, nullptr, 0, (float*)C, ldc, rows, N, K, relu, stream);
+    return dh_linear(A, lda, W, ldw, bias, nullptr, nullptr, nullptr, 0, C, ldc, rows, N, K, relu, dt, stream);
+}
+
 // The decode position on the deferred-LayerNorm chain (16-bit dtypes): 8 launches per layer instead of 11.  The residual
 // stream is kept PRE-LayerNorm (buffers X = sc->x, Y1 = sc->o, Y2 = sc->y2 with partial statistics st0 / st1 / st2); every
 // LayerNorm is applied where its output is consumed: folded into the next projection (gamma in the weight, beta in the bias,
@@ -141,24 +150,24 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
     for (int l = 0; l < m->n_layers; ++l) {
         const dh_tr_layer_t& L = m->layers[l];
         dh_prof_set_tag("qkv");
-        DH_TRY(dh_linear(sc->x, D, L.wqkv, D, L.bqkv, nullptr, nullptr, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, dt, stream));
+        DH_TRY(plain_linear(sc->x, D, L.wqkv, L.wqkv_x, D, L.bqkv, sc->qkv, 3 * D, rows, 3 * D, D, 0, dt, stream));
         DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
                                    row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
         dh_prof_set_tag("proj");
-        DH_TRY(dh_linear(sc->att, D, L.wo, D, L.bo, nullptr, nullptr, nullptr, 0, sc->o, D, rows, D, D, 0, dt, stream));
+        DH_TRY(plain_linear(sc->att, D, L.wo, L.wo_x, D, L.bo, sc->o, D, rows, D, D, 0, dt, stream));
         DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln1_g, L.ln1_b, sc->x, rows, D, L.ln1_eps, dt, stream));
         if (m->cross) {
             dh_prof_set_tag("proj");
-            DH_TRY(dh_linear(sc->x, D, L.wq, D, L.bq, nullptr, nullptr, nullptr, 0, sc->q, D, rows, D, D, 0, dt, stream));
+            DH_TRY(plain_linear(sc->x, D, L.wq, L.wq_x, D, L.bq, sc->q, D, rows, D, D, 0, dt, stream));
             DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
             dh_prof_set_tag("proj");
-            DH_TRY(dh_linear(sc->att, D, L.weo, D, L.beo, nullptr, nullptr, nullptr, 0, sc->o, D, rows, D, D, 0, dt, stream));
+            DH_TRY(plain_linear(sc->att, D, L.weo, L.weo_x, D, L.beo, sc->o, D, rows, D, D, 0, dt, stream));
             DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln2_g, L.ln2_b, sc->x, rows, D, L.ln2_eps, dt, stream));
         }
         dh_prof_set_tag("ffn");
-        DH_TRY(dh_linear(sc->x, D, L.w1, D, L.b1, nullptr, nullptr, nullptr, 0, sc->ff, m->pf_dim, rows, m->pf_dim, D, 1, dt, stream));
+        DH_TRY(plain_linear(sc->x, D, L.w1, L.w1_x, D, L.b1, sc->ff, m->pf_dim, rows, m->pf_dim, D, 1, dt, stream));
         dh_prof_set_tag("ffn");
-        DH_TRY(dh_linear(sc->ff, m->pf_dim, L.w2, m->pf_dim, L.b2, nullptr, nullptr, nullptr, 0, sc->o, D, rows, D, m->pf_dim, 0, dt, stream));
+        DH_TRY(plain_linear(sc->ff, m->pf_dim, L.w2, L.w2_x, m->pf_dim, L.b2, sc->o, D, rows, D, m->pf_dim, 0, dt, stream));
         void* dst = (l == m->n_layers - 1 && x_out) ? x_out : sc->x;
         DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln3_g, L.ln3_b, dst, rows, D, L.ln3_eps, dt, stream));
     }
@@ -168,8 +177,12 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
                                  m->V, D, dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
-        DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows,
-                         m->V, D, 0, dt == DH_F32 ? DH_F32 : (dt == DH_F16 ? DH_F16_OUT_F32 : DH_BF16_OUT_F32), stream));
+        if (dt == DH_F32) {
+            DH_TRY(plain_linear(x_out ? x_out : sc->x, D, m->cls_w, m->cls_w_x, D, m->cls_b, logits, ldl, rows, m->V, D, 0, dt, stream));
+        } else {
+            DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows,
+                             m->V, D, 0, dt == DH_F16 ? DH_F16_OUT_F32 : DH_BF16_OUT_F32, stream));
+        }
     }
     return DH_OK;
 }
@@ -230,8 +243,12 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
         const void* a = l == 0 ? sc->xcat0 : (const char*)sc->xcatl + (size_t)(l - 1) * rows * 2 * Hh * esz;
         const int k = l == 0 ? E + Hh : 2 * Hh;
         dh_prof_set_tag("gates");
-        DH_TRY(dh_linear(a, k, m->layers[l].w, k, m->layers[l].b, nullptr, nullptr, nullptr, 0, sc->gates, 4 * Hh, rows,
-                         4 * Hh, k, 0, gate_dt, stream));
+        if (dt == DH_F32) {
+            DH_TRY(plain_linear(a, k, m->layers[l].w, m->layers[l].w_x, k, m->layers[l].b, sc->gates, 4 * Hh, rows, 4 * Hh, k, 0, dt, stream));
+        } else {
+            DH_TRY(dh_linear(a, k, m->layers[l].w, k, m->layers[l].b, nullptr, nullptr, nullptr, 0, sc->gates, 4 * Hh, rows,
+                             4 * Hh, k, 0, gate_dt, stream));
+        }
         void* dst = l + 1 < nl ? (void*)((char*)sc->xcatl + (size_t)l * rows * 2 * Hh * esz) : top;
         const int ld = l + 1 < nl ? 2 * Hh : top_ld;
         DH_TRY(dh_lstm_cell(sc->gates, sc->c_cur + (size_t)l * rows * Hh, (char*)m->h + (size_t)l * rows_total * Hh * esz,
@@ -241,8 +258,12 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
         DH_TRY(classifier_groups(top, top_ld, m->cls_w, m->cls_b, m->cls_w_pk, m->cls_b_pad, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
-        DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,
-                         gate_dt, stream));
+        if (dt == DH_F32) {
+            DH_TRY(plain_linear(top, top_ld, m->cls_w, m->cls_w_x, Hh, m->cls_b, logits, ldl, rows, m->V, Hh, 0, dt, stream));
+        } else {
+            DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,
+                             gate_dt, stream));
+        }
     }
     return DH_OK;
 }

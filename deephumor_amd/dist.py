@@ -13,7 +13,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_range", "gather_captions", "generate_sharded"]
+__all__ = ["shard_range", "gather_captions", "generate_sharded", "generate_micro_sharded"]
 
 
 def shard_range(n_total, rank, world_size):
@@ -65,6 +65,42 @@ def generate_sharded(generate_fn, n_total, group=None, always=None):
     lo, hi = shard_range(n_total, rank, world)
     tokens, lengths = generate_fn(lo, hi)
     return gather_captions(tokens, lengths, n_total, group, always)
+
+
+def generate_micro_sharded(generate_fn, n_total, n_shards, group=None, always=None):
+    """A global batch cut into MORE shards than there are ranks (BASELINE config C4's 2,048 images as 8 shards of 256 on fewer than
+    8 GPUs -- on one GPU: 8 shards one after another): shard ``s`` = ``shard_range(n_total, s, n_shards)``, rank ``r`` of ``W``
+    decodes shards ``r * (n_shards / W) ...`` in order, and after each of its shards the ranks exchange that round's shards with
+    the same single ``all_gather`` as ``gather_captions``.  Every image keeps its GLOBAL index (``generate_fn(lo, hi)`` must pass
+    ``img0=lo``), so the captions equal those of an ``n_shards``-rank run and of one big batch.  Returns the whole
+    ``(tokens [n_total, T], lengths [n_total])`` on every rank."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    if n_shards % world:
+        raise ValueError(f"n_shards ({n_shards}) must be a multiple of the world size ({world})")
+    per = n_shards // world
+    spans = [shard_range(n_total, s, n_shards) for s in range(n_shards)]
+    got = [None] * n_shards
+    for j in range(per):
+        lo, hi = spans[rank * per + j]
+        toks, lens = generate_fn(lo, hi)
+        # this round holds shards {r * per + j}: a sub-batch whose shards are NOT contiguous in the global order, so it is gathered
+        # as raw padded payloads (the largest shard of the whole batch sets the padding) and re-assembled below
+        t = toks.shape[1]
+        cap = max(b - a for a, b in spans)
+        packed = torch.zeros((cap, t + 1), dtype=torch.int64, device=toks.device)
+        packed[:toks.shape[0], :t] = toks
+        packed[:toks.shape[0], t] = lens
+        if _skip_collective(group, always):
+            out = packed
+        else:
+            out = torch.empty((world * cap, t + 1), dtype=torch.int64, device=toks.device)
+            dist.all_gather_into_tensor(out, packed, group=group)
+        for r in range(world):
+            a, b = spans[r * per + j]
+            got[r * per + j] = out[r * cap:r * cap + (b - a)]
+    full = torch.cat(got, 0)
+    return full[:, :-1].contiguous(), full[:, -1].contiguous()
 
 
 def gather_rows(x, n_total, group=None, always=None):

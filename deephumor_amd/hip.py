@@ -27,13 +27,14 @@ class TrLayer(_c.Structure):
                 + [(n, _P) for n in ("kcache", "vcache", "kv")]
                 + [(n, _P) for n in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1", "kp", "vt")]
                 + [("kp_dperm", _I), ("_pad2", _I)]
-                + [(n, _P) for n in ("wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk")])
+                + [(n, _P) for n in ("wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk")]
+                + [(n, _P) for n in ("wqkv_x", "wo_x", "w1_x", "w2_x", "wq_x", "weo_x")])
 
 
 class TrModel(_c.Structure):
     _fields_ = ([(n, _I) for n in ("n_layers", "D", "n_heads", "pf_dim", "V", "pad_index", "cross", "S", "dtype")]
                 + [("emb_scale", _F), ("layers", _c.POINTER(TrLayer))]
-                + [(n, _P) for n in ("tok_emb", "pos_emb", "cls_w", "cls_b", "keymask", "cls_w_pk", "cls_b_pad")])
+                + [(n, _P) for n in ("tok_emb", "pos_emb", "cls_w", "cls_b", "keymask", "cls_w_pk", "cls_b_pad", "cls_w_x")])
 
 
 class TrScratch(_c.Structure):
@@ -47,12 +48,12 @@ class LnFold(_c.Structure):
 
 
 class LstmLayer(_c.Structure):
-    _fields_ = [("w", _P), ("b", _P), ("w_il", _P), ("b_il", _P), ("w_pk", _P)]
+    _fields_ = [("w", _P), ("b", _P), ("w_il", _P), ("b_il", _P), ("w_pk", _P), ("w_x", _P)]
 
 
 class LstmModel(_c.Structure):
     _fields_ = ([(n, _I) for n in ("n_layers", "E", "Hh", "V", "dtype", "_pad")] + [("layers", _c.POINTER(LstmLayer))]
-                + [(n, _P) for n in ("emb", "cls_w", "cls_b", "h", "c", "h_alt", "c_alt", "cls_w_pk", "cls_b_pad")])
+                + [(n, _P) for n in ("emb", "cls_w", "cls_b", "h", "c", "h_alt", "c_alt", "cls_w_pk", "cls_b_pad", "cls_w_x")])
 
 
 class LstmScratch(_c.Structure):
@@ -150,6 +151,12 @@ SIGNATURES = {
     "dh_beam_sample_k": [_P, _I, _I, _I, _I, _F, _P, _I, _U64, _P, _I, _I, _P, _P, _P],
     "dh_beam_gather": [_P, _I, _I, _P, _I, _P, _I, _P, _P],
     "dh_beam_expand": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "dh_split_f32x": [_P, _I, _P, _I, _I, _I, _P],
+    "dh_linear_f32x": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "dh_conv2d_nhwc_f32x": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 9 + [_P],
+    "dh_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
+    "dh_avgpool_nhwc_f32": [_P, _P, _I, _I, _I, _P],
     "dh_option_count": [],
     "dh_get_option": [_c.c_char_p, _c.POINTER(_I)],
     "dh_set_option": [_c.c_char_p, _I],
@@ -449,11 +456,96 @@ def label_mean(emb, labels, out):
     return out
 
 
+def split_f32x(w):
+    """fp32 ``w [N, K]`` -> the fp16 planes ``[2, N, Kp]`` of ``dh_split_f32x`` (hi, lo * 2^11; ``Kp`` = K rounded up to 32): the
+    weight operand of ``linear_f32x`` / ``conv2d_nhwc_f32x``.  Made once per weight version (the models' plans)."""
+    _dev(w)
+    assert w.dtype == torch.float32 and w.dim() == 2 and w.stride(1) == 1
+    n, k = w.shape
+    kp = (k + 31) // 32 * 32
+    planes = torch.empty((2, n, kp), dtype=torch.float16, device=w.device)
+    _launch("dh_split_f32x", _ptr(w), w.stride(0), _ptr(planes), n, k, kp, _stream())
+    return planes
+
+
+def f32_split_ok(w):
+    """Plan-time range check of the f32x path (fp16 planes): every weight below the fp16 maximum."""
+    return bool(w.detach().abs().max() < 6.0e4)
+
+
+def linear_f32x(a, planes, bias=None, scale=None, shift=None, relu=False, out=None, tag=None, residual=None):
+    """``dh_linear_f32x``: fp32 ``a [M, K] @ w[N, K].T`` as three fp16 MFMAs on split operands (fp32-class result)."""
+    _dev(a, planes, bias, scale, shift, out, residual)
+    m, k = a.shape
+    n, kp = planes.shape[1], planes.shape[2]
+    assert a.dtype == torch.float32 and planes.dtype == torch.float16 and a.stride(1) == 1 and kp == (k + 31) // 32 * 32
+    if a.stride(0) % 4 or a.data_ptr() % 16 or k % 4:
+        a = _aligned_rows(a)
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    assert out.shape == (m, n) and out.stride(1) == 1 and out.dtype == torch.float32
+    _launch("dh_linear_f32x", _ptr(a), a.stride(0), _ptr(planes), kp, _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual),
+            residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _stream(), tag=tag)
+    return out
+
+
+def _aligned_rows(a):
+    """Copy of ``a [M, K]`` whose rows start 16-byte aligned and whose K is a multiple of 4 (zero padded)."""
+    m, k = a.shape
+    kp = (k + 3) // 4 * 4
+    buf = torch.zeros((m, kp), dtype=a.dtype, device=a.device)
+    buf[:, :k].copy_(a)
+    return buf[:, :k] if kp == k else buf
+
+
+def conv2d_nhwc_f32x(x, planes, ks, scale, shift, residual=None, relu=True, stride=1, pad=0):
+    """``dh_conv2d_nhwc_f32x``: channels-last fp32 convolution + BatchNorm affine (+ residual) (+ ReLU); ``planes`` =
+    ``split_f32x`` of the ``[Cout, KS*KS*Cin]`` weight (ci fastest)."""
+    _dev(x, planes, scale, shift, residual)
+    n, h, w, cin = x.shape
+    cout, kp = planes.shape[1], planes.shape[2]
+    assert x.dtype == torch.float32 and x.is_contiguous() and kp == (ks * ks * cin + 31) // 32 * 32
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x.device)
+    _launch("dh_conv2d_nhwc_f32x", _ptr(x), _ptr(planes), kp, _ptr(scale), _ptr(shift), _ptr(residual), _ptr(y), n, h, w, cin, cout,
+            ks, stride, pad, int(relu), _stream())
+    return y
+
+
+def nchw_to_nhwc_f32(x, cp=4):
+    _dev(x)
+    n, c, h, w = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty((n, h, w, cp), dtype=torch.float32, device=x.device)
+    _launch("dh_nchw_to_nhwc_f32", _ptr(x), _ptr(y), n, c, h, w, cp, _stream())
+    return y
+
+
+def maxpool3x3s2_nhwc_f32(x):
+    _dev(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, (h + 2 - 3) // 2 + 1, (w + 2 - 3) // 2 + 1, c), dtype=torch.float32, device=x.device)
+    _launch("dh_maxpool3x3s2_nhwc_f32", _ptr(x), _ptr(y), n, h, w, c, _stream())
+    return y
+
+
+def avgpool_nhwc_f32(x):
+    """x [N, H, W, C] fp32 -> [N, C]."""
+    _dev(x)
+    n, h, w, c = x.shape
+    y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _launch("dh_avgpool_nhwc_f32", _ptr(x), _ptr(y), n, h * w, c, _stream())
+    return y
+
+
 def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=None, residual=None,
-           out_dtype=None):
+           out_dtype=None, w_x=None):
     """a [M, K] (row stride may exceed K), w [N, K] -> [M, N].  bf16 / fp16 operands may produce fp32
-    (``out_dtype=torch.float32``: logits)."""
+    (``out_dtype=torch.float32``: logits).  ``w_x``: ``split_f32x(w)`` -- an fp32 product then runs on the 16-bit matrix cores
+    with split operands when option ``f32_split`` is on (``linear_f32x``)."""
     _dev(a, w, bias, scale, shift, out, residual)
+    if w_x is not None and a.dtype == torch.float32 and option("f32_split"):
+        return linear_f32x(a, w_x, bias, scale, shift, relu, out, tag, residual)
     m, k = a.shape
     n, k2 = w.shape
     assert k == k2 and a.stride(1) == 1 and w.stride(1) == 1 and a.dtype == w.dtype

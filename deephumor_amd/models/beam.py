@@ -388,6 +388,16 @@ def make_noise_source(rng, seed, noise_source, lo, hi, img0, state0=None):
     return TorchRngNoise(seed, hi - lo, img0 + lo, state0=state0)
 
 
+def call_logits_hook(hook, pos, logits, helper):
+    """``logits_hook(pos, logits)`` before the beam step of position ``pos``; a hook whose attribute ``with_tokens`` is true is called
+    ``hook(pos, logits, tokens)`` with the engine's int32 ``[rows, max_len]`` token table (row r's own history in columns < pos):
+    what a checker needs to re-run a row teacher-forced (tests/test_fullsize_gpu.py)."""
+    if getattr(hook, "with_tokens", False):
+        hook(pos, logits, helper.tokens)
+    else:
+        hook(pos, logits)
+
+
 _overflow_warned = False
 
 

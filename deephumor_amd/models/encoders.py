@@ -130,10 +130,22 @@ class ImageEncoder(_Planned, nn.Module):
         [Cout, kh, kw, Cin]; the stem's 3 input channels are zero-padded to 8)."""
         wdt = self.linear.weight.dtype
         bf16 = wdt in hip.HALF_DTYPES            # the 16-bit paths (bf16 / fp16 storage and MFMA operands)
+        # fp32 weights with option "f32_split": channels-last fp32 activations, every convolution / linear layer as three fp16 MFMAs
+        # on split operands (csrc/gemm_f32x.hip) -- fp32-class results on the matrix cores instead of the vector ALUs
+        split = (wdt == torch.float32 and self.linear.weight.is_cuda and bool(hip.option("f32_split"))
+                 and all(hip.f32_split_ok(p) for p in self.parameters() if p.dim() > 1))
 
         def conv(c, bn, relu, residual=False, stem=False):
             s, b = _bn_affine(bn)
             w = c.weight.detach()
+            if split:
+                wl = w.permute(0, 2, 3, 1)                                   # [Cout, kh, kw, Cin]: ci fastest
+                if wl.shape[3] % 4:                                          # the stem: 3 input channels zero-padded to 4
+                    w4 = torch.zeros(tuple(wl.shape[:3]) + ((wl.shape[3] + 3) // 4 * 4,), dtype=w.dtype, device=w.device)
+                    w4[..., :wl.shape[3]] = wl
+                    wl = w4
+                return dict(w=w.contiguous(), wx=hip.split_f32x(wl.reshape(wl.shape[0], -1).contiguous()), ks=w.shape[2], cin=wl.shape[3],
+                            scale=s, shift=b, stride=c.stride[0], pad=c.padding[0], relu=relu, residual=residual)
             if bf16 and stem:
                 # 3 input channels zero-padded to 8: the stem becomes a Cin=8 channels-last conv on the matrix cores
                 w8 = torch.zeros((w.shape[0], w.shape[2], w.shape[3], 8), dtype=w.dtype, device=w.device)
@@ -207,8 +219,9 @@ class ImageEncoder(_Planned, nn.Module):
                     ent["c2"]["wpk4"] = hip.pack_mfma_fragments(c2w)
                 blocks.append(ent)
         s, b = _bn_affine(self.bn)
-        return dict(stem=stem, blocks=blocks, bn_scale=s, bn_shift=b, bf16=bf16, dtype=wdt,
-                    lin_w=self.linear.weight.detach(), lin_b=self.linear.bias.detach().float().contiguous())
+        return dict(stem=stem, blocks=blocks, bn_scale=s, bn_shift=b, bf16=bf16, dtype=wdt, split=split,
+                    lin_w=self.linear.weight.detach(), lin_b=self.linear.bias.detach().float().contiguous(),
+                    lin_wx=hip.split_f32x(self.linear.weight.detach().contiguous()) if split else None)
 
     @staticmethod
     def _conv(x, c, residual=None, nhwc=False):
@@ -230,12 +243,27 @@ class ImageEncoder(_Planned, nn.Module):
 
     TRUNK_MAX_IMAGES = 384
 
+    def _features_split(self, images, plan):
+        """The trunk on channels-last fp32 tensors with split-operand MFMAs (plan["split"]) -> [N, H/32, W/32, 2048] fp32."""
+        cv = lambda x, c, residual=None: hip.conv2d_nhwc_f32x(x, c["wx"], c["ks"], c["scale"], c["shift"], residual=residual,
+                                                              relu=c["relu"], stride=c["stride"], pad=c["pad"])
+        st = plan["stem"]
+        x = hip.nchw_to_nhwc_f32(images.float().contiguous(), cp=st["cin"])
+        x = hip.maxpool3x3s2_nhwc_f32(cv(x, st))
+        for blk in plan["blocks"]:
+            y = cv(cv(x, blk["c1"]), blk["c2"])
+            idt = x if blk["down"] is None else cv(x, blk["down"])
+            x = cv(y, blk["c3"], residual=idt)
+        return x
+
     def features(self, images):
         """Trunk output (encoders.py:56): ``[N, 2048, H/32, W/32]`` fp32 on the parity path,
         channels-last ``[N, H/32, W/32, 2048]`` bf16 on the bf16 path."""
         plan = self._get_plan()
         nhwc = plan["bf16"]
         st = plan["stem"]
+        if plan["split"]:
+            return self._features_split(images, plan)
         if nhwc and images.shape[0] > self.TRUNK_MAX_IMAGES:
             # (ADVICE r4) the streaming / register-streamed 16-bit kernels index pixels with 32-bit magic divisions and are tuned for
             # <= 256 images per launch (the stage-1 dual kernel stops applying near 436 images): larger batches go through the trunk
@@ -343,6 +371,12 @@ class ImageEncoder(_Planned, nn.Module):
         w, b = plan["lin_w"], plan["lin_b"]
         if plan["bf16"]:
             pooled, rows = hip.avgpool_nhwc(feats), feats.view(n, -1, feats.shape[-1])     # already [N, k*k, 2048]
+        elif plan["split"]:
+            pooled, rows = hip.avgpool_nhwc_f32(feats), feats.view(n, -1, feats.shape[-1])
+            emb = hip.linear_f32x(pooled, plan["lin_wx"], b, scale=plan["bn_scale"], shift=plan["bn_shift"])
+            if not self.spatial_features:
+                return emb
+            return emb, hip.linear_f32x(rows.reshape(-1, rows.shape[-1]), plan["lin_wx"], b).view(n, rows.shape[1], -1)
         else:
             pooled = hip.avgpool_rows(feats)
         emb = hip.linear(pooled, w, b, scale=plan["bn_scale"], shift=plan["bn_shift"])

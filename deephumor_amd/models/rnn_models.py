@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamOverflow, BeamSearchHelper, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
+from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
 
@@ -33,6 +33,10 @@ class LSTMDecoder(_Planned, nn.Module):
     # -- derived constants: [W_ih | W_hh] per layer and the summed bias -------------------------
     def _build_plan(self):
         layers = []
+        # fp32 weights with option "f32_split": the gate products and the classifier as three fp16 MFMAs on split operands
+        # (csrc/gemm_f32x.hip; dh_split_f32x planes of the weights, made here once per weight version)
+        split = (self.classifier.weight.dtype == torch.float32 and self.classifier.weight.is_cuda and bool(hip.option("f32_split"))
+                 and all(hip.f32_split_ok(p) for p in self.parameters() if p.dim() > 1))
         for l in range(self.lstm.num_layers):
             w = torch.cat([getattr(self.lstm, f"weight_ih_l{l}").detach(),
                            getattr(self.lstm, f"weight_hh_l{l}").detach()], dim=1).contiguous()
@@ -47,10 +51,12 @@ class LSTMDecoder(_Planned, nn.Module):
                 w_pk = hip.pack_mfma_fragments(w_il) if hip.lstm_layer_wreg_supported(w.shape[1] - hh, hh) else None
             else:
                 w_il = b_il = w_pk = None
-            layers.append((w, b, w_il, b_il, w_pk))
+            layers.append((w, b, w_il, b_il, w_pk, hip.split_f32x(w) if split else None))
         plan = dict(layers=layers, emb=self.embedding.weight.detach(),
                     cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach().float().contiguous(),
                     dtype=self.classifier.weight.dtype)
+        if split:
+            plan["cls_w_x"] = hip.split_f32x(plan["cls_w"].contiguous())
         if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and plan["cls_w"].shape[1] == 512 and hip.option("vocab_wreg_plan"):
             # the beam-search classifier with the weights streamed from L2 into registers (csrc/vocab_wreg.hip): padded, fragment-packed copy
             plan["cls_w_pk"], plan["cls_b_pad"] = hip.pack_vocab_weights(plan["cls_w"], plan["cls_b"])
@@ -74,7 +80,9 @@ class LSTMDecoder(_Planned, nn.Module):
             self.started = 0                                                    # 0: zero state, then 1, 2, 1, 2, ...
             self._scratch = {}
             self.c_layers = (hip.LstmLayer * self.nl)()
-            for i, (w, b, w_il, b_il, w_pk) in enumerate(plan["layers"]):
+            for i, (w, b, w_il, b_il, w_pk, w_x) in enumerate(plan["layers"]):
+                if w_x is not None:
+                    self.c_layers[i].w_x = w_x.data_ptr()
                 self.c_layers[i].w, self.c_layers[i].b = w.data_ptr(), b.data_ptr()
                 if w_il is not None:
                     self.c_layers[i].w_il, self.c_layers[i].b_il = w_il.data_ptr(), b_il.data_ptr()
@@ -87,6 +95,8 @@ class LSTMDecoder(_Planned, nn.Module):
             m.emb, m.cls_w, m.cls_b = plan["emb"].data_ptr(), plan["cls_w"].data_ptr(), plan["cls_b"].data_ptr()
             if "cls_w_pk" in plan:
                 m.cls_w_pk, m.cls_b_pad = plan["cls_w_pk"].data_ptr(), plan["cls_b_pad"].data_ptr()
+            if "cls_w_x" in plan:
+                m.cls_w_x = plan["cls_w_x"].data_ptr()
             m.h, m.c = self.h.data_ptr(), self.c.data_ptr()
             if self.dtype in hip.HALF_DTYPES:     # fused step kernel: other workgroups still gather the old state rows
                 self.h_alt, self.c_alt = torch.empty_like(self.h), torch.empty_like(self.c)
@@ -122,7 +132,7 @@ class LSTMDecoder(_Planned, nn.Module):
         Rows past ``lengths[i]`` are the packed-sequence zeros, i.e. the classifier bias."""
         hs, bs, steps_out = self.hidden_states(image_emb, captions, lengths)
         plan = self._get_plan()
-        out = hip.linear(hs.view(bs * steps_out, -1), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
+        out = hip.linear(hs.view(bs * steps_out, -1), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab", w_x=plan.get("cls_w_x"))
         return out.view(bs, steps_out, -1)
 
     def hidden_states(self, image_emb, captions, lengths=None):
@@ -199,14 +209,14 @@ class LSTMDecoder(_Planned, nn.Module):
                 self._step(plan, st, n, 1, b, r, tokens=helper.tokens, tok_pos=j, logits=lg if last else None,
                            group_max=gm if last else None)
             if logits_hook is not None:
-                logits_hook(pos, lg)
+                call_logits_hook(logits_hook, pos, lg, helper)
             helper.step(lg, first=True, write_pos=pos, t=0, step_index=pos, first_sets_ended=True, group_max=gm)
             yield
             for i in range(pos + 1, max_len):
                 self._step(plan, st, r, b, 1, r, tokens=helper.tokens, tok_pos=i - 1, hparent=helper.hparent,
                            logits=logits, group_max=gmax)
                 if logits_hook is not None:
-                    logits_hook(i, logits)
+                    call_logits_hook(logits_hook, i, logits, helper)
                 helper.step(logits, first=False, write_pos=i, t=0, step_index=i, group_max=gmax)
                 yield
                 if early_stop_every and (i - pos) % early_stop_every == 0 and bool(helper.done.all()):

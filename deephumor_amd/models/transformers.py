@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamOverflow, BeamSearchHelper, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
+from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
 
@@ -218,6 +218,14 @@ class _IncrementalDecoder(_Planned, nn.Module):
         plan = dict(layers=layers, tok=d(self.tok_embedding.weight), pos=d(self.pos_embedding.weight),
                     scale=float(self.scale), cls_w=d(self.classifier.weight), cls_b=f(self.classifier.bias),
                     dtype=self.classifier.weight.dtype)
+        if (dt == torch.float32 and self.classifier.weight.is_cuda and hip.option("f32_split")
+                and all(hip.f32_split_ok(p) for p in self.parameters() if p.dim() > 1)):
+            # fp32 weights with option "f32_split": every dense layer as three fp16 MFMAs on split operands (csrc/gemm_f32x.hip)
+            for ent in layers:
+                for name in ("wqkv", "wo", "w1", "w2", "wq", "weo", "wkv"):
+                    if name in ent:
+                        ent[name + "_x"] = hip.split_f32x(ent[name].contiguous())
+            plan["cls_w_x"] = hip.split_f32x(plan["cls_w"].contiguous())
         if (plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and hip.option("vocab_wreg_transformer")
                 and hip.option("vocab_wreg_plan")):
             # opt-in here (the LSTM decoder uses it by default): csrc/vocab_wreg.hip wins where the 37 MB of weights are still in the
@@ -262,7 +270,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 n = enc_out.shape[0]
                 flat, s, self.keymask = dec._enc_for_cross(enc_out.to(self.dtype), n_pos)   # transformers.py:450-452, 480-481
                 self.s = s
-                self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv") for L in plan["layers"]]   # once per image
+                self.kv = [hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv", w_x=L.get("wkv_x")) for L in plan["layers"]]   # once per image
                 if (self.dtype in hip.HALF_DTYPES and s <= 64 and d == 64 * dec.n_heads and beam <= 16
                         and hip.option("packed_cross")):
                     # matrix-core cross-attention: K | V re-laid out per (image, head) in MFMA operand order, once per batch; on the
@@ -288,7 +296,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     if self.packed is not None:
                         c.kp, c.vt, c.kp_dperm = P(self.packed[i][0]), P(self.packed[i][1]), int(self.dperm)
                 for name in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1",
-                             "wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk"):
+                             "wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk", "wqkv_x", "wo_x", "w1_x", "w2_x", "wq_x", "weo_x"):
                     if name in L:
                         setattr(c, name, P(L[name]))
                 c.kcache, c.vcache = self.kc[i].data_ptr(), self.vc[i].data_ptr()
@@ -302,6 +310,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
             m.keymask = P(self.keymask)
             if "cls_w_pk" in plan:
                 m.cls_w_pk, m.cls_b_pad = P(plan["cls_w_pk"]), P(plan["cls_b_pad"])
+            if "cls_w_x" in plan:
+                m.cls_w_x = P(plan["cls_w_x"])
 
         def scratch(self, rows):
             if rows not in self._scratch:
@@ -355,7 +365,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             hs[:, t, :].copy_(xt)
         if return_hidden:
             return hs
-        out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
+        out = hip.linear(hs.view(bs * seq, self.hid_dim), plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab", w_x=plan.get("cls_w_x"))
         return out.view(bs, seq, -1)
 
     def _forward_modules(self, x, enc_out, start_emb=None, return_hidden=False):
@@ -420,14 +430,14 @@ class _IncrementalDecoder(_Planned, nn.Module):
 
         lg = logits_at(helper.tokens[::b], start_emb, enc_out, pos)
         if logits_hook is not None:
-            logits_hook(pos, lg)
+            call_logits_hook(logits_hook, pos, lg, helper)
         helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False)
         semb = start_emb.repeat_interleave(b, 0)
         enc = None if enc_out is None else enc_out.repeat_interleave(b, 0)
         for i in range(pos + 1, max_len + 1):
             lg = logits_at(helper.tokens, semb, enc, i)
             if logits_hook is not None:
-                logits_hook(i, lg)
+                call_logits_hook(logits_hook, i, lg, helper)
             helper.step(lg, first=False, write_pos=i, t=i, step_index=i)
         return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index)
 
@@ -450,7 +460,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
         packed_ok = dt in hip.HALF_DTYPES and 0 < s_enc <= 64
 
         def cross(q, L):
-            kv = hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv")
+            kv = hip.linear(flat, L["wkv"], L["bkv"], tag="enc_kv", w_x=L.get("wkv_x"))
             if packed_ok:                                  # matrix-core cross-attention, 16 positions per launch
                 # (dperm: the head-dim slot order of the decode chain's fused fc_q + attention launch, so that teacher-forced
                 # logits and incremental decoding sum in the same order)
@@ -485,24 +495,24 @@ class _IncrementalDecoder(_Planned, nn.Module):
             x = hip.add_layernorm(x, None, pend[0], pend[1], eps=pend[2])
             if return_hidden:
                 return x.view(bs, seq, d)
-            out = hip.linear(x, plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
+            out = hip.linear(x, plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab", w_x=plan.get("cls_w_x"))
             return out.view(bs, seq, -1)
         for L in plan["layers"]:
-            qkv = hip.linear(x, L["wqkv"], L["bqkv"], tag="qkv")
+            qkv = hip.linear(x, L["wqkv"], L["bqkv"], tag="qkv", w_x=L.get("wqkv_x"))
             att = hip.attn_self_prefill(qkv, tokens, bs, seq, d, nh, L["sa_scale"], self.pad_index)
-            o = hip.linear(att, L["wo"], L["bo"], tag="proj")
+            o = hip.linear(att, L["wo"], L["bo"], tag="proj", w_x=L.get("wo_x"))
             x = hip.add_layernorm(x, o, L["ln1"][0], L["ln1"][1], eps=L["ln1"][2])
             if self._cross:
-                q = hip.linear(x, L["wq"], L["bq"], tag="proj")
+                q = hip.linear(x, L["wq"], L["bq"], tag="proj", w_x=L.get("wq_x"))
                 att = cross(q, L)
-                o = hip.linear(att, L["weo"], L["beo"], tag="proj")
+                o = hip.linear(att, L["weo"], L["beo"], tag="proj", w_x=L.get("weo_x"))
                 x = hip.add_layernorm(x, o, L["ln2"][0], L["ln2"][1], eps=L["ln2"][2])
-            ff = hip.linear(x, L["w1"], L["b1"], relu=True, tag="ffn")
-            o = hip.linear(ff, L["w2"], L["b2"], tag="ffn")
+            ff = hip.linear(x, L["w1"], L["b1"], relu=True, tag="ffn", w_x=L.get("w1_x"))
+            o = hip.linear(ff, L["w2"], L["b2"], tag="ffn", w_x=L.get("w2_x"))
             x = hip.add_layernorm(x, o, L["ln3"][0], L["ln3"][1], eps=L["ln3"][2])
         if return_hidden:
             return x.view(bs, seq, d)
-        out = hip.linear(x, plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab")
+        out = hip.linear(x, plan["cls_w"], plan["cls_b"], out_dtype=torch.float32, tag="vocab", w_x=plan.get("cls_w_x"))
         return out.view(bs, seq, -1)
 
     def _generate_batch(self, start_emb, enc_out, caption, max_len, temperature, beam_size, top_k, eos_index,
@@ -562,13 +572,13 @@ class _IncrementalDecoder(_Planned, nn.Module):
                                       logits=lg if t == pos else None, group_max=gm if t == pos else None)
                 yield
             if logits_hook is not None:
-                logits_hook(pos, lg)
+                call_logits_hook(logits_hook, pos, lg, helper)
             helper.step(lg, first=True, write_pos=pos, t=pos, step_index=pos, first_sets_ended=False, group_max=gm)
             for i in range(pos + 1, max_len + 1):
                 self._decode_position(plan, run, i, r, b, 1, helper.tokens, helper.src, semb, logits=logits,
                                       group_max=gmax)
                 if logits_hook is not None:
-                    logits_hook(i, logits)
+                    call_logits_hook(logits_hook, i, logits, helper)
                 # at i == max_len nothing is written (transformers.py:557) but beams are still re-drawn
                 helper.step(logits, first=False, write_pos=i, t=i, step_index=i, group_max=gmax)
                 yield

@@ -582,6 +582,9 @@ typedef struct dh_tr_layer {
      * (dh_linear_ln_wreg) for positions with many rows; NULL = the tile kernels */
     const void *wqkv_pk, *wo_pk, *weo_pk, *w1_pk, *w2_pk;
     const void* wq_pk;                                      /* optional: dh_pack_mfma_fragments(wq_f): fc_q as its own register-stationary GEMM in front of the packed cross-attention */
+    /* optional (DH_F32 models, option "f32_split"): dh_split_f32x planes of wqkv, wo, w1, w2, wq, weo -- the dense layers of a
+     * position then run as three fp16 MFMAs on split operands (dh_linear_f32x) instead of v_mfma_f32_32x32x2_f32; NULL = fp32 MFMA */
+    const void *wqkv_x, *wo_x, *w1_x, *w2_x, *wq_x, *weo_x;
 } dh_tr_layer_t;
 
 typedef struct dh_tr_model {
@@ -592,6 +595,7 @@ typedef struct dh_tr_model {
     const float* cls_b;
     const uint8_t* keymask;                                 /* [n_img*S] or NULL */
     const void* cls_w_pk; const float* cls_b_pad;           /* optional: the operands of dh_vocab_logits_wreg (padded, fragment-packed classifier) */
+    const void* cls_w_x;                                    /* optional (DH_F32): dh_split_f32x planes of cls_w */
 } dh_tr_model_t;
 
 typedef struct dh_tr_scratch {
@@ -613,6 +617,7 @@ typedef struct dh_lstm_layer {
     const void* w; const float* b;          /* [4Hh, in+Hh] = [W_ih|W_hh], b_ih+b_hh (PyTorch gate order i,f,g,o) */
     const void* w_il; const float* b_il;    /* optional (bf16): the same, gate-interleaved: row 4u+g = gate g of unit u */
     const void* w_pk;                       /* optional: dh_pack_mfma_fragments(w_il) -- the register-stationary step (dh_lstm_layer_wreg) */
+    const void* w_x;                        /* optional (DH_F32): dh_split_f32x planes of w -- the gate GEMM as dh_linear_f32x */
 } dh_lstm_layer_t;
 
 typedef struct dh_lstm_model {
@@ -624,6 +629,7 @@ typedef struct dh_lstm_model {
     float* c;                                               /* cell state, fp32 */
     void* h_alt; float* c_alt;                              /* optional second state buffers (fused bf16 step: ping-pong) */
     const void* cls_w_pk; const float* cls_b_pad;           /* optional: the operands of dh_vocab_logits_wreg */
+    const void* cls_w_x;                                    /* optional (DH_F32): dh_split_f32x planes of cls_w */
 } dh_lstm_model_t;
 
 typedef struct dh_lstm_scratch { void *xcat0, *xcatl; float *c_cur, *gates; void* hout; } dh_lstm_scratch_t;
@@ -659,6 +665,31 @@ int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, c
                         int started, int rows, int rows_per_img, int row_mult, int rows_total,
                         void* h_out, int ld_out, float* logits, int ldl, float* group_max, int gm_ld,
                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * fp32 models on the 16-bit matrix cores ("f32x", csrc/gemm_f32x.hip; option "f32_split").  Every fp32 operand x is used as
+ * x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11); a product sum is three v_mfma_f32_16x16x32_f16 (hi*hi,
+ * hi*lo, lo*hi; every fp16 product is exact in fp32) with fp32 accumulation -- fp32-class results (the dropped lo*lo term is
+ * 2^-22 relative) at a multiple of the rate of v_mfma_f32_32x32x2_f32 / the vector ALUs.  Replaces the same torch call sites as
+ * dh_linear (nn.Linear: encoders.py:61,67; rnn_models.py:45 + the LSTM gate products; transformers.py:97-99,127,162-163,489)
+ * and dh_conv2d_bn_act (the torchvision trunk, encoders.py:56) for fp32 tensors.  |x| must stay below 65504.
+ *   dh_split_f32x      w fp32 [N, ldw] -> planes [2][N][Kp] fp16 (hi plane, then lo * 2^11), Kp = K rounded up to 32, zero padded;
+ *                      made once per weight version
+ *   dh_linear_f32x     C [M, ldc] fp32 = act(((A W^T + bias) * scale + shift) + residual); A fp32 [M, lda] (lda % 4 == 0, K % 4 == 0),
+ *                      bias / scale+shift / residual optional
+ *   dh_conv2d_nhwc_f32x  channels-last fp32 convolution + BatchNorm scale / shift (+ residual) (+ ReLU): x [N,H,W,Cin] (Cin % 4 == 0),
+ *                      planes of w [Cout][KS][KS][Cin], y / residual [N,Ho,Wo,Cout]
+ *   dh_nchw_to_nhwc_f32  [N,C,H,W] -> [N,H,W,Cp] (channels >= C zero): the stem's input
+ *   dh_maxpool3x3s2_nhwc_f32, dh_avgpool_nhwc_f32   MaxPool2d(3, 2, 1) / AdaptiveAvgPool2d(1) on channels-last fp32 tensors
+ * ------------------------------------------------------------------------------------------- */
+int dh_split_f32x(const float* w, int ldw, void* planes, int N, int K, int Kp, void* stream);
+int dh_linear_f32x(const float* A, int lda, const void* w_planes, int Kp, const float* bias, const float* scale, const float* shift,
+                   const float* residual, int ldres, float* C, int ldc, int M, int N, int K, int relu, void* stream);
+int dh_conv2d_nhwc_f32x(const float* x, const void* w_planes, int Kp, const float* scale, const float* shift, const float* residual,
+                        float* y, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu, void* stream);
+int dh_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
+int dh_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int dh_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Launch profiler (measurement infrastructure, not on the data path): while enabled, every launch made

@@ -57,6 +57,40 @@ def test_two_ranks_gather_in_global_order():
                 assert torch.equal(toks, want_t) and torch.equal(lens, want_l)
 
 
+def _micro_worker(rank, world, port, n_total, n_shards, ret):
+    from deephumor_amd.dist import generate_micro_sharded
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    seen = []
+
+    def gen(lo, hi):
+        seen.append((lo, hi))
+        return _fake_generate(lo, hi)
+    toks, lens = generate_micro_sharded(gen, n_total, n_shards)
+    ret[rank] = (toks.clone(), lens.clone(), seen)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_more_shards_than_ranks_gather_in_global_order():
+    """generate_micro_sharded: C4's global batch as 8 shards on 2 ranks (4 rounds of one all_gather each), even and uneven shards;
+    and with no process group at all (one GPU: the shards one after another)."""
+    from deephumor_amd.dist import generate_micro_sharded
+    for n_total, n_shards in ((16, 8), (13, 4)):
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_micro_worker, args=(2, _free_port(), n_total, n_shards, ret), nprocs=2, join=True)
+            want_t, want_l = _fake_generate(0, n_total)
+            spans = [shard_range(n_total, s, n_shards) for s in range(n_shards)]
+            for r in range(2):
+                toks, lens, seen = ret[r]
+                assert torch.equal(toks, want_t) and torch.equal(lens, want_l)
+                assert [tuple(x) for x in seen] == spans[r * n_shards // 2:(r + 1) * n_shards // 2]
+    toks, lens = generate_micro_sharded(_fake_generate, 13, 8)
+    want_t, want_l = _fake_generate(0, 13)
+    assert torch.equal(toks, want_t) and torch.equal(lens, want_l)
+
+
 def _score_worker(rank, world, port, n_total, ret):
     from deephumor_amd.dist import score_sharded
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

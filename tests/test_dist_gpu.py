@@ -61,3 +61,72 @@ def test_bench_rccl_single_line():
     line = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])      # the LAST stdout line (RCCL's banner must not follow it)
     assert line["n_ranks_seen"] == 1 and "rccl_single_rank" in line and line["value"] > 0
     assert line["per_rank_ms_per_step"]["ranks"] == 1 and line["per_rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"])
+
+
+C4_CHILD = r"""
+import datetime, json, os, socket, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+with socket.socket() as _s:
+    _s.bind(("127.0.0.1", 0))
+    _port = _s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(_port))
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=300))
+import deephumor_amd.models as M
+from deephumor_amd import hip
+from deephumor_amd.dist import generate_micro_sharded
+from deephumor_amd.synth import synth_images, synth_state_dict
+from oracle import ref_path as R
+hip.set_option("dist_always", 1)                 # the one-rank group runs its all_gather per shard
+V, N, SH = 36541, 2048, 8
+model = M.CaptioningTransformer(V).eval()
+sd = synth_state_dict(model.state_dict(), seed=1234)
+model.load_state_dict(sd)
+model = model.to(dev)
+res = {"backend": dist.get_backend()}
+spans = []
+def shard(m, kw):
+    def fn(lo, hi):
+        spans.append((lo, hi))
+        return m.generate_batch(synth_images(hi - lo, seed=0, first=lo).to(dev), img0=lo, **kw)
+    return fn
+with torch.no_grad():
+    # fp32: the 2,048-image global batch as 8 sequential 256-image shards (img0 = 256 r), greedy, rows {0, 1000, 2047} vs the oracle
+    toks, lens = generate_micro_sharded(shard(model, dict(max_len=32, beam_size=1, top_k=1)), N, SH)
+    res["shape"] = list(toks.shape)
+    res["spans"] = spans == [(256 * r, 256 * (r + 1)) for r in range(SH)]
+    ok = True
+    for i in (0, 1000, 2047):
+        want = R.model_generate("CaptioningTransformer", sd, model._hp, synth_images(1, seed=0, first=i), max_len=32, beam_size=1, top_k=1)
+        ok = ok and toks[i, :int(lens[i])].cpu().tolist() == want.reshape(-1).tolist()
+    res["fp32_rows_equal_oracle"] = ok
+    # bf16, beam 5 (Philox keyed by the global image index): the sharded batch is repeatable, and shard 3 (images 768..1023) equals
+    # the same images decoded as two 128-image halves -- a row does not depend on which shard / tile it sits in
+    m16 = model.bfloat16()
+    kw = dict(max_len=32, beam_size=5, top_k=50, temperature=1.0, seed=42)
+    t1, l1 = generate_micro_sharded(shard(m16, kw), N, SH)
+    t2, l2 = generate_micro_sharded(shard(m16, kw), N, SH)
+    res["bf16_repeatable"] = bool(torch.equal(t1, t2) and torch.equal(l1, l2))
+    ha = m16.generate_batch(synth_images(128, seed=0, first=768).to(dev), img0=768, **kw)
+    hb = m16.generate_batch(synth_images(128, seed=0, first=896).to(dev), img0=896, **kw)
+    res["bf16_shard_invariant"] = bool(torch.equal(torch.cat([ha[0], hb[0]]), t1[768:1024]) and torch.equal(torch.cat([ha[1], hb[1]]), l1[768:1024]))
+    res["bf16_valid"] = bool(int(t1.max()) < V and not bool((t1 == 1).any()) and int(l1.min()) >= 1 and tuple(t1.shape) == (N, 32))
+    # distinct images give distinct captions: shards are not copies of each other
+    res["bf16_shards_differ"] = bool(not torch.equal(t1[:256], t1[256:512]))
+print("RESULT " + json.dumps(res))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_c4_global_batch_as_eight_sequential_shards():
+    """BASELINE config C4 (CaptioningTransformer, batch 2,048 image-sharded over 8 ranks) on the one GPU this pool has: the 8 shards
+    (``img0 = 256 r``) one after another through ``generate_micro_sharded`` and the one-rank RCCL group's per-shard all_gather --
+    fp32 rows {0, 1000, 2047} equal the CPU oracle's greedy ids, the bf16 beam-5 batch is repeatable and shard-invariant."""
+    p = subprocess.run([sys.executable, "-c", C4_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res == {"backend": "nccl", "shape": [2048, 32], "spans": True, "fp32_rows_equal_oracle": True, "bf16_repeatable": True,
+                   "bf16_shard_invariant": True, "bf16_valid": True, "bf16_shards_differ": True}

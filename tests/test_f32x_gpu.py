@@ -1,0 +1,144 @@
+"""The parity-grade matrix-core path (option ``f32_split``; csrc/gemm_f32x.hip): fp32 models whose dense layers and convolutions run
+as three fp16 MFMAs on split operands.  Gates: the kernels against fp64 statements; then the SAME golden /
+oracle tests the exact-fp32 path is held to -- logits within 1e-3 of the reference's, greedy ids bit-exact, the reference's sampled
+captions under RNG replay -- re-run with the option on, including the BASELINE shape (256 images, V = 36,541)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from helpers import KINDS, golden, synth_images  # noqa: E402
+import test_fullsize_gpu as TF  # noqa: E402
+import test_models_gpu as TM  # noqa: E402
+
+
+@pytest.fixture(autouse=True)
+def split_on():
+    from deephumor_amd import hip
+    with hip.option_scope(f32_split=1):
+        yield
+
+
+@pytest.fixture(scope="module")
+def images():
+    return synth_images(4, seed=0)
+
+
+def _err_vs_f64(got, a64, w64, extra=None):
+    """max |got - exact| relative to the row / column norms' product (the scale fp32 rounding errors of a dot product live on)."""
+    want = a64 @ w64.t()
+    if extra is not None:
+        want = extra(want)
+    scale = (a64.abs() @ w64.abs().t()).clamp_min(1e-30)
+    return float(((got.double() - want).abs() / scale).max())
+
+
+@pytest.mark.parametrize("m,n,k", [(37, 100, 96), (128, 128, 32), (1280, 2048, 768), (300, 1000, 512), (256, 36541, 512), (5, 7, 4), (131, 257, 2052)])
+def test_linear_f32x_against_fp64(m, n, k):
+    from deephumor_amd import hip
+    g = torch.Generator().manual_seed(m * 7 + n)
+    a = (torch.randn(m, k, generator=g) * 2.0).cuda()
+    w = (torch.randn(n, k, generator=g) * 0.3).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    planes = hip.split_f32x(w)
+    got = hip.linear_f32x(a, planes, b)
+    e_split = _err_vs_f64(got - b, a.double(), w.double())
+    e_f32 = _err_vs_f64(hip.linear(a, w, b) - b, a.double(), w.double())
+    # fp32-class: within a small factor of 2^-24 relative to sum |a||w| -- and no worse than 4x the exact-fp32 MFMA kernel's own error
+    assert e_split < 4e-7 and e_split < 4 * max(e_f32, 6e-8), (e_split, e_f32)
+    # epilogue: scale / shift / residual / relu, and a strided output
+    sc, sh = torch.rand(n, generator=g).cuda() + 0.5, torch.randn(n, generator=g).cuda()
+    res = torch.randn(m, n, generator=g).cuda()
+    buf = torch.full((m, n + 5), 7.0, device="cuda")
+    out = buf[:, :n]
+    hip.linear_f32x(a, planes, b, scale=sc, shift=sh, residual=res, relu=True, out=out)
+    want = torch.relu(((a.double() @ w.double().t() + b.double()) * sc.double() + sh.double()) + res.double())
+    assert float((out.double() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max())) and bool((buf[:, n:] == 7.0).all())
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,ks,stride,pad,res", [(3, 20, 4, 64, 7, 2, 3, False), (2, 14, 64, 64, 3, 1, 1, False), (2, 15, 64, 128, 3, 2, 1, False),
+                                                           (3, 9, 256, 64, 1, 1, 0, False), (2, 8, 64, 256, 1, 1, 0, True), (1, 12, 32, 48, 1, 2, 0, False),
+                                                           (5, 7, 512, 512, 3, 1, 1, False)])
+def test_conv_f32x_against_fp64(n, hw, cin, cout, ks, stride, pad, res):
+    from deephumor_amd import hip
+    g = torch.Generator().manual_seed(hw * 31 + cin)
+    x = torch.randn(n, cin, hw, hw + 1, generator=g).cuda()
+    w = (torch.randn(cout, cin, ks, ks, generator=g) * 0.1).cuda()
+    sc, sh = torch.rand(cout, generator=g).cuda() + 0.5, torch.randn(cout, generator=g).cuda()
+    want = F.conv2d(x.double(), w.double(), stride=stride, padding=pad) * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+    r = torch.randn(want.shape, generator=torch.Generator().manual_seed(1)).cuda() if res else None
+    if res:
+        want = want + r.double()
+    want = torch.relu(want)
+    planes = hip.split_f32x(w.permute(0, 2, 3, 1).reshape(cout, -1).contiguous())
+    got = hip.conv2d_nhwc_f32x(x.permute(0, 2, 3, 1).contiguous(), planes, ks, sc, sh, residual=None if r is None else r.permute(0, 2, 3, 1).contiguous(),
+                               relu=True, stride=stride, pad=pad)
+    err = float((got.permute(0, 3, 1, 2).double() - want).abs().max())
+    assert got.shape == (n, want.shape[2], want.shape[3], cout) and err < 2e-5 * max(1.0, float(want.abs().max())), err
+
+
+def test_layout_and_pool_kernels():
+    from deephumor_amd import hip
+    x = torch.randn(3, 3, 10, 13).cuda()
+    y = hip.nchw_to_nhwc_f32(x, cp=4)
+    assert torch.equal(y[..., :3], x.permute(0, 2, 3, 1)) and bool((y[..., 3] == 0).all())
+    z = torch.randn(2, 9, 11, 8).cuda()
+    assert torch.equal(hip.maxpool3x3s2_nhwc_f32(z).permute(0, 3, 1, 2), F.max_pool2d(z.permute(0, 3, 1, 2), 3, 2, 1))
+    np.testing.assert_allclose(hip.avgpool_nhwc_f32(z).cpu().numpy(), z.mean((1, 2)).cpu().numpy(), atol=1e-6)
+
+
+def test_encoder_matches_reference_split(images):
+    g = golden("g1_encoder.npz")
+    model, _, _ = TM.build("CaptioningLSTM")
+    with torch.no_grad():
+        assert model.encoder._get_plan()["split"]
+        feats = model.encoder.features(images.cuda())                   # channels-last on this path
+        np.testing.assert_allclose(feats.permute(0, 3, 1, 2)[:, :64].cpu().numpy(), g["e256_features_slice"], atol=1e-3, rtol=1e-4)
+        np.testing.assert_allclose(model.encoder(images.cuda()).cpu().numpy(), g["e256_emb"], atol=1e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_forward_logits_split(kind, images):
+    TM.test_forward_logits(kind, images)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_greedy_ids_bit_exact_split(kind, images):
+    TM.test_greedy_ids_bit_exact(kind, images)
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_beam_rng_replay_split(kind, images):
+    TM.test_beam_rng_replay(kind, images)
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_word_vocab_split(kind, images):
+    TM.test_word_vocab_greedy(kind, images)
+    TM.test_word_vocab_logits(kind)
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_full_batch_split(kind):
+    """N = 256, V = 36,541: greedy rows {0, 77, 255} == the oracle; sampled beam-5 rows == the reference's (golden G15) under rng="torch"."""
+    TF.test_fp32_full_batch_greedy_rows_equal_the_oracle(kind)
+    TF.test_fp32_full_batch_sampled_beam_rows_equal_the_reference(kind)
+
+
+def test_split_is_actually_selected_and_switchable():
+    """The option reaches the kernels: with it on, the fp32 model's launches are dh_linear_f32x / dh_conv2d_nhwc_f32x; off, none are."""
+    from deephumor_amd import hip
+    model, _, _ = TM.build("CaptioningTransformer")
+    imgs = synth_images(2, seed=0).cuda()
+
+    def keys():
+        with torch.no_grad(), hip.profile() as prof:
+            model.generate_batch(imgs, max_len=4, beam_size=1, top_k=1)
+        return set(k.split("[")[0].split("{")[0] for k in prof.summary())
+    on = keys()
+    assert "dh_linear_f32x" in on and "dh_conv2d_nhwc_f32x" in on and "dh_conv2d_bn_act" not in on
+    with hip.option_scope(f32_split=0):
+        off = keys()
+    assert "dh_linear_f32x" not in off and "dh_conv2d_nhwc_f32x" not in off and "dh_conv2d_bn_act" in off

@@ -33,8 +33,81 @@ def test_fp32_full_batch_greedy_rows_equal_the_oracle(kind):
     with torch.no_grad():
         toks, lens = model.generate_batch(imgs.cuda(), max_len=32, beam_size=1, top_k=1)
     for i in (0, 77, 255):
-        want = R.model_generate(kind, sd, model._hp, imgs[i:i + 1], max_len=32, beam_size=1, top_k=1).reshape(-1).tolist()
+        want = _oracle_greedy(kind, sd, model._hp, imgs, i)
         assert toks[i, :int(lens[i])].cpu().tolist() == want, (kind, i)
+
+
+_ORACLE_GREEDY = {}
+
+
+def _oracle_greedy(kind, sd, hp, imgs, i):
+    from oracle import ref_path as R
+    if (kind, i) not in _ORACLE_GREEDY:
+        _ORACLE_GREEDY[(kind, i)] = R.model_generate(kind, sd, hp, imgs[i:i + 1], max_len=32, beam_size=1, top_k=1).reshape(-1).tolist()
+    return _ORACLE_GREEDY[(kind, i)]
+
+
+# what the 16-bit paths must stay within of the fp32 CPU oracle at the BASELINE shape (observed by bench.py's precision_vs_fp32_hip,
+# round 4: bf16 0.21 max / 0.020 mean, fp16 0.022 / 0.0024 at step 0) -- gates with ~1.7x margin, fp16 about 8x tighter than bf16
+LOGIT_TOL = {torch.bfloat16: (0.36, 0.045), torch.float16: (0.045, 0.006)}
+# greedy token agreement of rows {0, 77, 255} with the oracle's captions (chaotic on synthetic weights: DESIGN section 10): floors set
+# below the values the committed kernels give (printed by the test), so a kernel that degrades precision turns the run red
+GREEDY_FLOOR = {("CaptioningLSTM", torch.bfloat16): 0.25, ("CaptioningLSTM", torch.float16): 0.60,
+                ("CaptioningTransformer", torch.bfloat16): 0.40, ("CaptioningTransformer", torch.float16): 0.60}
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
+def test_16bit_big_batch_kernels_against_the_oracle(kind, dtype):
+    """The kernels only a BASELINE-size batch selects (256 images x beam 5 = 1,280 rows, V = 36,541: ``vocab_wreg`` / ``vocab_areg256``,
+    ``linear_wreg``, ``lstm_wreg``, the 256-workgroup encoder kernels) tied to the CPU ORACLE directly, not through bit-equality with
+    older kernels: (a) the logits the beam-5 decode itself computes at step 0 (256 rows) and step 1 (1,280 rows, each
+    row teacher-forced by the token the engine drew for it) for rows of images {0, 77, 255} against ``oracle.ref_path.model_forward``
+    within the type's tolerance, arg-max inside the oracle's near-top set; (b) greedy ids of those images at N = 256 against the
+    oracle's captions at or above the recorded floor."""
+    import json
+    import os
+    from oracle import ref_path as R
+    from deephumor_amd.synth import synth_images
+    model, sd = _model(kind, dtype)
+    imgs = synth_images(256, seed=0)
+    picks = {0: [0, 77, 255], 1: [0 * 5 + 0, 77 * 5 + 2, 255 * 5 + 4]}
+    cap = {}
+
+    def hook(i, lg, tokens):
+        if i in picks:
+            rows = torch.tensor(picks[i], device=lg.device)
+            cap[i] = (lg[rows].float().cpu(), tokens[rows].cpu())
+    hook.with_tokens = True
+    with torch.no_grad():
+        model.generate_batch(imgs.cuda(), max_len=32, beam_size=5, top_k=50, temperature=1.0, seed=42, logits_hook=hook)
+    tol_max, tol_mean = LOGIT_TOL[dtype]
+    seen = {}
+    for step, rows in picks.items():
+        got, toks = cap[step]
+        for j, r in enumerate(rows):
+            img = r if step == 0 else r // 5
+            prefix = toks[j, :step].long()[None]                      # the row's own history: teacher forcing
+            want = R.model_forward(kind, sd, model._hp, imgs[img:img + 1], prefix)[0, step]
+            d = (got[j] - want).abs()
+            seen[f"step{step}_row{r}"] = [round(float(d.max()), 4), round(float(d.mean()), 5)]
+            assert float(d.max()) < tol_max and float(d.mean()) < tol_mean, (kind, dtype, step, r, float(d.max()), float(d.mean()))
+            assert float(want[int(got[j].argmax())]) >= float(want.max()) - 2 * tol_max, (kind, dtype, step, r)
+    with torch.no_grad():
+        toks, lens = model.generate_batch(imgs.cuda(), max_len=32, beam_size=1, top_k=1)
+    same = total = 0
+    for i in (0, 77, 255):
+        want = _oracle_greedy(kind, sd, model._hp, imgs, i)
+        g = toks[i, :int(lens[i])].cpu().tolist()
+        total += max(len(want), len(g))
+        same += sum(int(a == b) for a, b in zip(want, g))
+    seen["greedy_token_match_rows_0_77_255"] = round(same / total, 4)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out):                                            # (kept next to the run's other records; not asserted on)
+        with open(os.path.join(out, f"oracle_gate_{kind}_{str(dtype).split('.')[-1]}.json"), "w") as f:
+            json.dump(seen, f)
+    print(kind, dtype, seen)
+    assert same / total >= GREEDY_FLOOR[(kind, dtype)], (kind, dtype, seen)
 
 
 @pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])

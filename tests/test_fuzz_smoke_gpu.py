@@ -31,3 +31,7 @@ def test_one_seed_of_the_sweep(tool, trials, extra, capsys):
     failed = [l for l in lines[:-1] if '"ok": true' not in l and "fewer positive" not in l]
     assert rc == 0 and summary["trials"] == trials, summary
     assert summary.get("failures", 0) + summary.get("mismatches_or_errors", 0) == 0, (summary, failed[:3])
+    # fuzz_generate reclassifies a caption mismatch as "not comparable" when the ORACLE's own decision gap at the first differing draw
+    # is below 1e-6 relative (two ulps of fp32): a judgment call, so it is bounded here, not just printed (<= 1 per seed;
+    # the full sweeps saw 3 in ~4,900 trials)
+    assert summary.get("fp32_near_ties_not_comparable", 0) <= 1, summary
