@@ -82,14 +82,27 @@ def workload_name(workload):
             "c5": "C5 ImageLabelEncoder + CaptioningTransformer (spatial feats), beam=10, 300-template sweep"}[workload]
 
 
-def one_step(model, images, img0, n_total, seed, graph=False):
-    from deephumor_amd.dist import gather_captions
+def one_step(model, images, img0, n_total, seed, graph=False, pending=None):
+    """One batch: encoder + decode + the batch's single all_gather.  With ``pending`` (a one-element list) the all_gather is issued
+    asynchronously and the PREVIOUS step's is waited for here, after this step's launches are queued: every step still makes
+    exactly one exchange, its latency sits behind the next batch's decode (``drain_pending`` ends the last one)."""
+    from deephumor_amd.dist import gather_captions, gather_captions_async
     kw = dict(max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP, seed=seed, img0=img0)
     if graph:      # whole step replayed from a captured hipGraph
         toks, lens = model.generate_batch_graphed(images, **kw)
     else:
         toks, lens = model.generate_batch(images, streams=STREAMS, **kw)
-    return gather_captions(toks, lens, n_total)
+    if pending is None:
+        return gather_captions(toks, lens, n_total)
+    prev, pending[0] = pending[0], gather_captions_async(toks, lens, n_total)
+    return prev.wait() if prev is not None else (toks, lens)
+
+
+def drain_pending(pending):
+    if pending and pending[0] is not None:
+        out, pending[0] = pending[0].wait(), None
+        return out
+    return None
 
 
 # ---- rooflines ----------------------------------------------------------------------------------------------------
@@ -257,10 +270,11 @@ def dist_always():
 
 
 # ---- the timed region ----------------------------------------------------------------------------------------------
-def timed_region(step_fn, steps, world, device):
+def timed_region(step_fn, steps, world, device, drain=None):
     """Contract of the brief: barrier + device synchronize, EXACTLY ``steps`` calls of ``step_fn(s)``, device synchronize +
     barrier, wall time = MAX over ranks (one all_reduce).  Returns ``(seconds, last result of step_fn)``.  Used by every
-    workload; ``tests/test_dist_cpu.py`` drives it over gloo with a stubbed step."""
+    workload; ``tests/test_dist_cpu.py`` drives it over gloo with a stubbed step.  ``drain``: called once after the last step,
+    INSIDE the timed region (finishes an exchange the last step issued asynchronously); its result replaces the last step's."""
     import torch.distributed as dist
     # (a one-rank process group counts when DH_DIST_ALWAYS is set: --rccl-single runs the barriers / the max-reduction / the
     #  all_gather on RCCL with one rank, the only RCCL run a one-GPU box allows)
@@ -280,6 +294,9 @@ def timed_region(step_fn, steps, world, device):
     t0 = time.perf_counter()
     for s in range(steps):
         out = step_fn(s)
+    if drain is not None:
+        last = drain()
+        out = out if last is None else last
     fence()
     dt = time.perf_counter() - t0
     RANK_TIMES[:] = [dt]
@@ -297,15 +314,17 @@ def timed_region(step_fn, steps, world, device):
 def timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=None, graph=False, stride=1):
     from deephumor_amd import hip
     world = n_total // n_local
-    step = lambda s: one_step(model, images, rank * n_local, n_total, seed=100 + s, graph=graph)
+    pending = [None]          # the batch's all_gather is waited for one step later (inside the timed region: drain_pending)
+    step = lambda s: one_step(model, images, rank * n_local, n_total, seed=100 + s, graph=graph, pending=pending)
+    drain = lambda: drain_pending(pending)
     if watch:
         # HIP events around the launches of the roofline kernel INSIDE the timed region.  Each event pair costs ~5 us of stream
         # time: a key launched hundreds of times per step (the C3 decode GEMMs: 192-576) is sampled every `stride`-th launch so
         # that the instrumentation stays below ~0.2 ms per step (an unbiased sample of the same launches)
         with hip.profile(watch=watch, stride=stride) as prof:
-            dt, out = timed_region(step, steps, world, images.device)
+            dt, out = timed_region(step, steps, world, images.device, drain=drain)
         return dt, out[1], prof.summary()
-    dt, out = timed_region(step, steps, world, images.device)
+    dt, out = timed_region(step, steps, world, images.device, drain=drain)
     return dt, out[1], {}
 
 
@@ -546,11 +565,11 @@ def run_shard(args, dev, dtype):
 
     def exchange(toks, lens):
         """What gather_captions does on a W-rank group, for this rank's payload: pad to the largest shard, one all_gather."""
-        packed = torch.zeros((cap, toks.shape[1] + 1), dtype=torch.int64, device=toks.device)
+        packed = torch.zeros((max(cap, toks.shape[0]), toks.shape[1] + 1), dtype=torch.int64, device=toks.device)
         packed[:toks.shape[0], :-1] = toks
         packed[:toks.shape[0], -1] = lens
         if use_pg:
-            out = torch.empty((dist.get_world_size() * cap, packed.shape[1]), dtype=torch.int64, device=toks.device)
+            out = torch.empty((dist.get_world_size() * packed.shape[0], packed.shape[1]), dtype=torch.int64, device=toks.device)
             dist.all_gather_into_tensor(out, packed)
             return out
         return packed
@@ -577,7 +596,7 @@ def run_shard(args, dev, dtype):
 
     t_shard, bd_shard = timed(lo, hi, args.steps, args.warmup)
     full_n = n_total if wl == "c5" else args.batch            # C2 / C3 are weak scaling: the 1-GPU workload IS one shard
-    if wl == "c5":
+    if wl == "c5" and not args.shard_only:
         t_full, bd_full = timed(0, n_total, max(2, args.steps // 2), 1)
     else:
         t_full, bd_full = t_shard, None
@@ -741,21 +760,24 @@ def stub_workload(args, rank, world, dev):
     """``--stub`` (tests/test_dist_cpu.py): the whole control flow of a multi-rank run -- launcher, process group, image shards,
     barrier / K steps / barrier, MAX over ranks, one all_gather per step, rank 0's line -- with the model replaced by a pure
     function of the GLOBAL image index, on CPU over gloo.  Its line says ``"data": "stub"``: it is never a measurement."""
-    from deephumor_amd.dist import gather_captions
+    from deephumor_amd.dist import gather_captions_async
     n_local, n_total = args.batch, args.batch * world
     idx = torch.arange(rank * n_local, (rank + 1) * n_local)
     calls = []
+    pending = [None]
 
-    def step(s):
+    def step(s):          # as one_step(pending=...): this step's exchange is issued asynchronously, the previous one's waited for
         calls.append(s)
         time.sleep(0.01 * (rank + 1))
         toks = (idx[:, None] * 10 + torch.arange(MAX_LEN)[None, :] + s) % 97
-        return gather_captions(toks, (idx % MAX_LEN) + 1, n_total)
+        prev, pending[0] = pending[0], gather_captions_async(toks, (idx % MAX_LEN) + 1, n_total)
+        return prev.wait() if prev is not None else None
 
     for w in range(args.warmup):
         step(-1 - w)
+    drain_pending(pending)
     del calls[:]
-    dt, (toks, lens) = timed_region(step, args.steps, world, dev)
+    dt, (toks, lens) = timed_region(step, args.steps, world, dev, drain=lambda: drain_pending(pending))
     want = (torch.arange(n_total)[:, None] * 10 + torch.arange(MAX_LEN)[None, :] + args.steps - 1) % 97
     return {"value": n_total * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "steps_run": calls,
             "per_rank_ms_per_step": {"min": min(RANK_TIMES) / args.steps * 1e3, "max": max(RANK_TIMES) / args.steps * 1e3, "ranks": len(RANK_TIMES)},
@@ -783,6 +805,7 @@ def main(argv=None):
     ap.add_argument("--shard-of", type=int, default=0, help="with --gpus 1: time the shard rank --shard-rank of a W-rank run would decode "
                     "(C5: 38 / 37 of the 300 templates; C2 / C3: --batch images of a W x batch global batch) and print a labelled projection")
     ap.add_argument("--shard-rank", type=int, default=0)
+    ap.add_argument("--shard-only", action="store_true", help="with --shard-of: skip the full-batch leg (profiling runs)")
     ap.add_argument("--stub", action="store_true", help="CPU/gloo control-flow test of the multi-rank path (model stubbed; not a measurement)")
     args = ap.parse_args(argv)
     if args.dtype is None:

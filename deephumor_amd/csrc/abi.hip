@@ -141,6 +141,7 @@ const OptDef g_opt_defs[DH_OPT_COUNT] = {
     {"cross_qproj", "DH_CROSS_QPROJ", 1, false},
     {"lstm_wreg", "DH_LSTM_WREG", 1, false},
     {"lstm_wreg_min_rows", "DH_LSTM_WREG_MIN_ROWS", 256, false},
+    {"vocab_split_rows", "DH_VOCAB_SPLIT_ROWS", 1, false},
     {"gemm64_ns", "DH_GEMM64_NS", 0, false},
     {"vocab_tile", "DH_VOCAB_TILE", 128, false},
     {"vocab_gmax_tile", "DH_VOCAB_GMAX_TILE", 256, false},

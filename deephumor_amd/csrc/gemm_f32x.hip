@@ -32,7 +32,7 @@ struct F32xParams {
     float* C; int ldc;
     int M, N, K, relu;
     int H, Wd, Cin, Ho, Wo, KS, stride, pad;           // conv loader (NHWC input)
-    int tiles_m, tiles_n;
+    int tiles_m, tiles_n, n_fast;                      // n_fast: consecutive workgroups walk the N tiles of one M tile (small weights)
 };
 
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -46,149 +46,14 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 // would otherwise hit the same banks
 __device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 2) & 3); }
 
-// MODE 0: dense A; 1: convolution with Cin % 32 == 0 (a 32-k slab lies inside one filter tap: the tap is wave-uniform);
-// 2: convolution, any Cin % 4 == 0 (the stem: per-lane tap decode)
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_f32x_kernel(F32xParams p) {
-    constexpr int BM = 128, BN = 128, BK = 32;
-    constexpr int PLANE = BM * BK * 2;                   // 8 KB: one fp16 plane of one operand
-    constexpr int STAGE = 4 * PLANE;                     // A hi | A lo | W hi | W lo
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-
-    const int nblk = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
-    {   // XCD-aware bijective remap: consecutive tile ids (which share a W panel) stay on one XCD's L2
-        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tm = bid % p.tiles_m, tn = bid / p.tiles_m;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave & 1) * 64, wn0 = (wave >> 1) * 64;
-    const int l15 = lane & 15, lq = lane >> 4;
-
-    // ---- A loader: thread = (row, 4-float chunk kc) x 4 rows; rows fixed over the reduction -----------------------------------
-    const int a_kc = tid & 7;
-    const float* a_ptr[4];
-    int a_ih0[4], a_iw0[4];
-    bool a_ok[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int row = (tid >> 3) + it * 32, m = m0 + row;
-        a_ok[it] = m < p.M;
-        const int mm = a_ok[it] ? m : 0;
-        a_ih0[it] = a_iw0[it] = 0;
-        if (MODE == 0) {
-            a_ptr[it] = p.A + (size_t)mm * p.lda + a_kc * 4;
-        } else {
-            const int hw = p.Ho * p.Wo, n = mm / hw, r = mm - n * hw, oh = r / p.Wo, ow = r - oh * p.Wo;
-            a_ih0[it] = oh * p.stride - p.pad; a_iw0[it] = ow * p.stride - p.pad;
-            a_ptr[it] = p.A + (((size_t)n * p.H + a_ih0[it]) * p.Wd + a_iw0[it]) * p.Cin + (MODE == 1 ? a_kc * 4 : 0);
-        }
-    }
-    int st_kh = 0, st_kw = 0, st_ci = 0;               // MODE 1: tap of the NEXT slab to load
-    float4 areg[4];
-    auto load_a = [&](int k0) {
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const float* src = nullptr;
-            if (MODE == 0) {
-                if (a_ok[it] && k0 + a_kc * 4 < p.K) src = a_ptr[it] + k0;
-            } else if (MODE == 1) {
-                if (a_ok[it] && (unsigned)(a_ih0[it] + st_kh) < (unsigned)p.H && (unsigned)(a_iw0[it] + st_kw) < (unsigned)p.Wd)
-                    src = a_ptr[it] + ((ptrdiff_t)st_kh * p.Wd + st_kw) * p.Cin + st_ci;
-            } else {
-                const int k = k0 + a_kc * 4;
-                const int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.KS, kw = tap - kh * p.KS;
-                if (a_ok[it] && k < p.K && (unsigned)(a_ih0[it] + kh) < (unsigned)p.H && (unsigned)(a_iw0[it] + kw) < (unsigned)p.Wd)
-                    src = a_ptr[it] + ((ptrdiff_t)kh * p.Wd + kw) * p.Cin + ci;
-            }
-            areg[it] = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if (MODE == 1) {
-            st_ci += BK;
-            if (st_ci == p.Cin) { st_ci = 0; if (++st_kw == p.KS) { st_kw = 0; ++st_kh; } }
-        }
-    };
-    auto store_a = [&](int buf) {
-        unsigned char* ah = lds + buf * STAGE;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int row = (tid >> 3) + it * 32;
-            uint2 hi, lo;
-            split2(areg[it].x, areg[it].y, hi.x, lo.x);
-            split2(areg[it].z, areg[it].w, hi.y, lo.y);
-            const int off = row * 64 + swz(row, a_kc >> 1) * 16 + (a_kc & 1) * 8;
-            *reinterpret_cast<uint2*>(ah + off) = hi;
-            *reinterpret_cast<uint2*>(ah + PLANE + off) = lo;
-        }
-    };
-    // ---- W loader: LDS-DMA, one wave instruction = 16 rows x 64 B of one plane; wave w moves pieces 2w, 2w+1 of both planes ----
-    const uint16_t* w_src[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 16 + (lane >> 2);
-        const int n = min(n0 + row, p.N - 1);            // rows past N repeat the last one (their outputs are not stored)
-        w_src[i] = p.Wp + (size_t)n * p.Kp + swz(row, lane & 3) * 8;
-    }
-    auto load_w = [&](int buf, int k0) {
-        unsigned char* wh = lds + buf * STAGE + 2 * PLANE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            dh_lds_dma16(w_src[i] + k0, wh + (wave * 2 + i) * 1024);
-            dh_lds_dma16(w_src[i] + p.plane + k0, wh + PLANE + (wave * 2 + i) * 1024);
-        }
-    };
-
-    dh_f32x4 acc[4][4], cor[4][4];                       // [tn][tm]: main (hi x hi) and correction (hi x lo + lo x hi, scaled 2^11)
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { acc[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; cor[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; }
-
-    const int nslab = p.Kp / BK;
-    load_w(0, 0);
-    load_a(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_a(0);
-    __syncthreads();
-    for (int t = 0; t < nslab; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nslab) { load_w(buf ^ 1, (t + 1) * BK); load_a((t + 1) * BK); }
-        const unsigned char* ah = lds + buf * STAGE;
-        const unsigned char* wh = ah + 2 * PLANE;
-        uint4 fa_h[4], fa_l[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = wm0 + 16 * i + l15, off = r * 64 + swz(r, lq) * 16;
-            fa_h[i] = *reinterpret_cast<const uint4*>(ah + off);
-            fa_l[i] = *reinterpret_cast<const uint4*>(ah + PLANE + off);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = wn0 + 16 * j + l15, off = r * 64 + swz(r, lq) * 16;
-            const uint4 fw_h = *reinterpret_cast<const uint4*>(wh + off);
-            const uint4 fw_l = *reinterpret_cast<const uint4*>(wh + PLANE + off);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[j][i] = Op16<f16_t>::mfma(fw_h, fa_h[i], acc[j][i]);
-                cor[j][i] = Op16<f16_t>::mfma(fw_h, fa_l[i], cor[j][i]);
-                cor[j][i] = Op16<f16_t>::mfma(fw_l, fa_h[i], cor[j][i]);
-            }
-        }
-        if (t + 1 < nslab) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slab t + 1: A in registers, W planes in LDS
-            store_a(buf ^ 1);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: acc[j][i][r] = C[m = m0 + wm0 + 16 i + l15][n = n0 + wn0 + 16 j + 4 lq + r] --------------------------------
+// acc[j][i][r] = C[m = mw + 16 i + l15][n = nw + 16 j + 4 lq + r]; main + 2^-11 * correction, then bias / scale + shift / residual / ReLU
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const F32xParams& p, const dh_f32x4 (&acc)[TN][TM], const dh_f32x4 (&cor)[TN][TM], int mw, int nw, int l15,
+                                         int lq) {
     const bool vec = (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0));
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn0 + 16 * j + 4 * lq;
+    for (int j = 0; j < TN; ++j) {
+        const int n = nw + 16 * j + 4 * lq;
         float bi[4], mu[4], ad[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -198,8 +63,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32x_kernel(F32xParams p) {
             ad[r] = p.shift ? p.shift[nn] : 0.f;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm0 + 16 * i + l15;
+        for (int i = 0; i < TM; ++i) {
+            const int m = mw + 16 * i + l15;
             if (m >= p.M || n >= p.N) continue;
             float v[4];
 #pragma unroll
@@ -223,6 +88,255 @@ __global__ __launch_bounds__(256, 2) void gemm_f32x_kernel(F32xParams p) {
             }
         }
     }
+}
+
+// MODE 0: dense A; 1: convolution with Cin % 32 == 0 (a 32-k slab lies inside one filter tap: the tap is wave-uniform);
+// 2: convolution, any Cin % 4 == 0 (the stem: per-lane tap decode)
+// Tiles: 128 x 128 (the large layers), 128 x 64 (Cout = 64: stage 1 and the stem), 64 x 64 (the decode-position linears, whose
+// 1,280 x 512 outputs are 40 tiles of 128 x 128 on 256 CUs).  Four waves, 2 x 2 over the tile.
+template <int MODE, int BM, int BN>
+__global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? 2 : 3) void gemm_f32x_kernel(F32xParams p) {
+    constexpr int BK = 32;
+    constexpr int PLANE_A = BM * BK * 2, PLANE_W = BN * BK * 2;     // one fp16 plane of one operand
+    constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_W;     // A hi | A lo | W hi | W lo
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16, A_IT = BM / 32, W_PW = BN / 64;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware bijective remap: consecutive tile ids (which share a W panel) stay on one XCD's L2
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    // tile order: consecutive workgroups share a weight panel and walk over M; with small weights (L2-resident anyway) they share
+    // the activation tile instead, so that it is fetched from HBM once and not tiles_n times
+    const int tm = p.n_fast ? bid / p.tiles_n : bid % p.tiles_m, tn = p.n_fast ? bid % p.tiles_n : bid / p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave & 1) * WM, wn0 = (wave >> 1) * WN;
+    const int l15 = lane & 15, lq = lane >> 4;
+
+    // ---- A loader: thread = (row, 4-float chunk kc) x 4 rows; rows fixed over the reduction -----------------------------------
+    const int a_kc = tid & 7;
+    const float* a_ptr[A_IT];
+    int a_ih0[A_IT], a_iw0[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (tid >> 3) + it * 32, m = m0 + row;
+        a_ok[it] = m < p.M;
+        const int mm = a_ok[it] ? m : 0;
+        a_ih0[it] = a_iw0[it] = 0;
+        if (MODE == 0) {
+            a_ptr[it] = p.A + (size_t)mm * p.lda + a_kc * 4;
+        } else {
+            const int hw = p.Ho * p.Wo, n = mm / hw, r = mm - n * hw, oh = r / p.Wo, ow = r - oh * p.Wo;
+            a_ih0[it] = oh * p.stride - p.pad; a_iw0[it] = ow * p.stride - p.pad;
+            a_ptr[it] = p.A + (((size_t)n * p.H + a_ih0[it]) * p.Wd + a_iw0[it]) * p.Cin + (MODE == 1 ? a_kc * 4 : 0);
+        }
+    }
+    int st_kh = 0, st_kw = 0, st_ci = 0;               // MODE 1: tap of the NEXT slab to load
+    float4 areg[A_IT];
+    auto load_a = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const float* src = nullptr;
+            if (MODE == 0) {
+                if (a_ok[it] && k0 + a_kc * 4 < p.K) src = a_ptr[it] + k0;
+            } else if (MODE == 1) {
+                if (a_ok[it] && (unsigned)(a_ih0[it] + st_kh) < (unsigned)p.H && (unsigned)(a_iw0[it] + st_kw) < (unsigned)p.Wd)
+                    src = a_ptr[it] + ((ptrdiff_t)st_kh * p.Wd + st_kw) * p.Cin + st_ci;
+            } else {
+                const int k = k0 + a_kc * 4;
+                const int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.KS, kw = tap - kh * p.KS;
+                if (a_ok[it] && k < p.K && (unsigned)(a_ih0[it] + kh) < (unsigned)p.H && (unsigned)(a_iw0[it] + kw) < (unsigned)p.Wd)
+                    src = a_ptr[it] + ((ptrdiff_t)kh * p.Wd + kw) * p.Cin + ci;
+            }
+            areg[it] = src ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (MODE == 1) {
+            st_ci += BK;
+            if (st_ci == p.Cin) { st_ci = 0; if (++st_kw == p.KS) { st_kw = 0; ++st_kh; } }
+        }
+    };
+    auto store_a = [&](int buf) {
+        unsigned char* ah = lds + buf * STAGE;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int row = (tid >> 3) + it * 32;
+            uint2 hi, lo;
+            split2(areg[it].x, areg[it].y, hi.x, lo.x);
+            split2(areg[it].z, areg[it].w, hi.y, lo.y);
+            const int off = row * 64 + swz(row, a_kc >> 1) * 16 + (a_kc & 1) * 8;
+            *reinterpret_cast<uint2*>(ah + off) = hi;
+            *reinterpret_cast<uint2*>(ah + PLANE_A + off) = lo;
+        }
+    };
+    // ---- W loader: LDS-DMA, one wave instruction = 16 rows x 64 B of one plane; wave w moves pieces W_PW w ... of both planes ----
+    const uint16_t* w_src[W_PW];
+#pragma unroll
+    for (int i = 0; i < W_PW; ++i) {
+        const int row = (wave * W_PW + i) * 16 + (lane >> 2);
+        const int n = min(n0 + row, p.N - 1);            // rows past N repeat the last one (their outputs are not stored)
+        w_src[i] = p.Wp + (size_t)n * p.Kp + swz(row, lane & 3) * 8;
+    }
+    auto load_w = [&](int buf, int k0) {
+        unsigned char* wh = lds + buf * STAGE + 2 * PLANE_A;
+#pragma unroll
+        for (int i = 0; i < W_PW; ++i) {
+            dh_lds_dma16(w_src[i] + k0, wh + (wave * W_PW + i) * 1024);
+            dh_lds_dma16(w_src[i] + p.plane + k0, wh + PLANE_W + (wave * W_PW + i) * 1024);
+        }
+    };
+
+    dh_f32x4 acc[TN][TM], cor[TN][TM];                   // [tn][tm]: main (hi x hi) and correction (hi x lo + lo x hi, scaled 2^11)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { acc[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; cor[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    const int nslab = p.Kp / BK;
+    load_w(0, 0);
+    load_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_a(0);
+    __syncthreads();
+    for (int t = 0; t < nslab; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nslab) { load_w(buf ^ 1, (t + 1) * BK); load_a((t + 1) * BK); }
+        const unsigned char* ah = lds + buf * STAGE;
+        const unsigned char* wh = ah + 2 * PLANE_A;
+        uint4 fa_h[TM], fa_l[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm0 + 16 * i + l15, off = r * 64 + swz(r, lq) * 16;
+            fa_h[i] = *reinterpret_cast<const uint4*>(ah + off);
+            fa_l[i] = *reinterpret_cast<const uint4*>(ah + PLANE_A + off);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn0 + 16 * j + l15, off = r * 64 + swz(r, lq) * 16;
+            const uint4 fw_h = *reinterpret_cast<const uint4*>(wh + off);
+            const uint4 fw_l = *reinterpret_cast<const uint4*>(wh + PLANE_W + off);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[j][i] = Op16<f16_t>::mfma(fw_h, fa_h[i], acc[j][i]);
+                cor[j][i] = Op16<f16_t>::mfma(fw_h, fa_l[i], cor[j][i]);
+                cor[j][i] = Op16<f16_t>::mfma(fw_l, fa_h[i], cor[j][i]);
+            }
+        }
+        if (t + 1 < nslab) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slab t + 1: A in registers, W planes in LDS
+            store_a(buf ^ 1);
+        }
+        __syncthreads();
+    }
+
+    epilogue<TM, TN>(p, acc, cor, m0 + wm0, n0 + wn0, l15, lq);
+}
+
+__device__ uint4 dh_f32x_zero_page[2];              // zero-initialised: source of chunks outside M / K
+
+// The decode-position shapes (a few hundred to a few thousand rows x N = 512 ... 2,048): too few 128 x 128 tiles to fill 256 CUs and,
+// with one slab of look-ahead, every 32-k slab costs a memory round trip (first version: 18 us for 1,280 x 512 x 512).  Here: 64 x 64
+// tiles and an NS-deep LDS ring filled by LDS-DMA only -- the fp32 activation slab goes into LDS AS fp32 ([64 rows][32 k], chunk slots
+// XOR-swizzled by row) and is split into its fp16 planes when a wave reads its fragment (2 x ds_read_b128 + 28 VALU operations per
+// fragment; twice redundant across the two column halves, cheap next to a round trip per slab) -- so NS - 1 slabs are in flight with no
+// staging registers, one counted wait + one barrier per slab.
+template <int NS>
+__global__ __launch_bounds__(256, 1) void gemm_f32x_small_kernel(F32xParams p) {
+    constexpr int BM = 64, BN = 64, BK = 32;
+    constexpr int A_BYTES = BM * BK * 4, PLANE_W = BN * BK * 2, STAGE = A_BYTES + 2 * PLANE_W;     // 8 + 4 + 4 KB
+    constexpr int P = 4;                                // LDS-DMA instructions per wave per slab: 2 (A) + 1 + 1 (W planes)
+    static_assert((NS - 1) * P <= 60, "vmcnt range");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NS * STAGE];
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = p.n_fast ? bid / p.tiles_n : bid % p.tiles_m, tn = p.n_fast ? bid % p.tiles_n : bid / p.tiles_m;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave & 1) * 32, wn0 = (wave >> 1) * 32;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(dh_f32x_zero_page);
+
+    // A: a piece = 8 rows x 128 B (fp32); wave w moves pieces 2w, 2w + 1; LDS slot (row, pos) holds source chunk pos ^ (row & 7)
+    const float* a_src[2]; int a_chunk[2]; bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 8 + (lane >> 3), m = m0 + row;
+        a_ok[i] = m < p.M;
+        a_chunk[i] = (lane & 7) ^ (row & 7);
+        a_src[i] = p.A + (size_t)(a_ok[i] ? m : 0) * p.lda + a_chunk[i] * 4;
+    }
+    // W planes: a piece = 16 rows x 64 B; wave w moves piece w of the hi and of the lo plane
+    const int w_row = wave * 16 + (lane >> 2);
+    const uint16_t* w_src = p.Wp + (size_t)min(n0 + w_row, p.N - 1) * p.Kp + swz(w_row, lane & 3) * 8;
+    auto stage = [&](int slab) {
+        unsigned char* st = lds + (slab % NS) * STAGE;
+        const int k0 = slab * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const void* src = (a_ok[i] && k0 + a_chunk[i] * 4 < p.K) ? (const void*)(a_src[i] + k0) : (const void*)zero;
+            dh_lds_dma16(src, st + (wave * 2 + i) * 1024);
+        }
+        dh_lds_dma16(w_src + k0, st + A_BYTES + wave * 1024);
+        dh_lds_dma16(w_src + p.plane + k0, st + A_BYTES + PLANE_W + wave * 1024);
+    };
+    dh_f32x4 acc[2][2], cor[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { acc[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; cor[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int nslab = p.Kp / BK;
+#pragma unroll
+    for (int u = 0; u < NS - 1; ++u)
+        if (u < nslab) stage(u);
+    for (int t = 0; t < nslab; ++t) {
+        // slab t has landed once at most min(NS - 2, slabs issued after t) newer slabs of this wave are outstanding
+        const int newer = min(NS - 2, nslab - 1 - t);
+        if (newer == NS - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NS - 2) * P) : "memory");
+        else switch (newer) {
+            case 6: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+        __syncthreads();                                 // slab t visible to every wave; every wave is done with slab t - 1
+        if (t + NS - 1 < nslab) stage(t + NS - 1);       // refills the stage slab t - 1 lived in
+        const unsigned char* st = lds + (t % NS) * STAGE;
+        uint4 fa_h[2], fa_l[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = wm0 + 16 * i + l15;
+            const float4 x0 = *reinterpret_cast<const float4*>(st + r * 128 + (((2 * lq) ^ (r & 7)) << 4));
+            const float4 x1 = *reinterpret_cast<const float4*>(st + r * 128 + (((2 * lq + 1) ^ (r & 7)) << 4));
+            split2(x0.x, x0.y, fa_h[i].x, fa_l[i].x); split2(x0.z, x0.w, fa_h[i].y, fa_l[i].y);
+            split2(x1.x, x1.y, fa_h[i].z, fa_l[i].z); split2(x1.z, x1.w, fa_h[i].w, fa_l[i].w);
+        }
+        const unsigned char* wh = st + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int r = wn0 + 16 * j + l15, off = r * 64 + swz(r, lq) * 16;
+            const uint4 fw_h = *reinterpret_cast<const uint4*>(wh + off);
+            const uint4 fw_l = *reinterpret_cast<const uint4*>(wh + PLANE_W + off);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[j][i] = Op16<f16_t>::mfma(fw_h, fa_h[i], acc[j][i]);
+                cor[j][i] = Op16<f16_t>::mfma(fw_h, fa_l[i], cor[j][i]);
+                cor[j][i] = Op16<f16_t>::mfma(fw_l, fa_h[i], cor[j][i]);
+            }
+        }
+    }
+    epilogue<2, 2>(p, acc, cor, m0 + wm0, n0 + wn0, l15, lq);
 }
 
 __global__ __launch_bounds__(256) void split_f32x_kernel(const float* __restrict__ w, int ldw, uint16_t* __restrict__ planes, int N, int K,
@@ -287,13 +401,28 @@ __global__ __launch_bounds__(256) void avgpool_nhwc_f32_kernel(const float* __re
     y[i] = s / (float)HW;
 }
 
+template <int BM, int BN>
+void launch_tile(F32xParams& p, int mode, hipStream_t s) {
+    p.tiles_m = dh_cdiv(p.M, BM); p.tiles_n = dh_cdiv(p.N, BN);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
+    if (mode == 0) hipLaunchKernelGGL((gemm_f32x_kernel<0, BM, BN>), grid, block, 0, s, p);
+    else if (mode == 1) hipLaunchKernelGGL((gemm_f32x_kernel<1, BM, BN>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32x_kernel<2, BM, BN>), grid, block, 0, s, p);
+}
+
 int launch(const F32xParams& p0, int mode, hipStream_t s) {
     F32xParams p = p0;
-    p.tiles_m = dh_cdiv(p.M, 128); p.tiles_n = dh_cdiv(p.N, 128);
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(256);
-    if (mode == 0) hipLaunchKernelGGL(gemm_f32x_kernel<0>, grid, block, 0, s, p);
-    else if (mode == 1) hipLaunchKernelGGL(gemm_f32x_kernel<1>, grid, block, 0, s, p);
-    else hipLaunchKernelGGL(gemm_f32x_kernel<2>, grid, block, 0, s, p);
+    // weight planes of <= 4 MB stay in every XCD's L2: walk the N tiles of one M tile back to back (the activation tile comes
+    // from HBM once instead of tiles_n times)
+    p.n_fast = (double)p.N * p.Kp * 4.0 <= 4.0 * 1048576.0;
+    const long long t128 = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
+    if (p.N <= 64) launch_tile<128, 64>(p, mode, s);
+    else if (t128 < 256 && mode == 0 && (p.K % 4) == 0) {           // (a decode position: 1,280 x 512 = 40 tiles of 128 x 128)
+        p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
+        hipLaunchKernelGGL(gemm_f32x_small_kernel<8>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), 0, s, p);
+    }
+    else if (t128 < 256) launch_tile<64, 64>(p, mode, s);
+    else launch_tile<128, 128>(p, mode, s);
     return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
 }
 

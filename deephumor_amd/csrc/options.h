@@ -13,6 +13,7 @@ enum DhOption {
     DH_OPT_CROSS_QPROJ,              // fc_q inside the cross-attention launch
     DH_OPT_LSTM_WREG,                // register-stationary LSTM step (lstm_wreg.hip)
     DH_OPT_LSTM_WREG_MIN_ROWS,       // ... from this many rows
+    DH_OPT_VOCAB_SPLIT_ROWS,         // classifier of a row count that is no multiple of 256: whole 256-row tiles + remainder as two launches
     // ---- tile choices of single kernels ----
     DH_OPT_GEMM64_NS, DH_OPT_VOCAB_TILE, DH_OPT_VOCAB_GMAX_TILE, DH_OPT_VOCAB_AREG, DH_OPT_LOGPROB_TILE,
     DH_OPT_LSTM_BM, DH_OPT_LSTM_NS, DH_OPT_VOCAB_WREG_NT, DH_OPT_VOCAB_WREG_PREFETCH,

@@ -27,6 +27,15 @@ static int classifier_groups(const void* A, int lda, const void* W, const float*
                              int ldl, float* group_max, int gm_ld, int rows, int V, int K, int dt, void* stream) {
     if (dh_opt(DH_OPT_VOCAB_WREG) && W_pk && bias_pad && logits && dh_vocab_logits_wreg_supported(rows, V, K, ldl, gm_ld))
         return dh_vocab_logits_wreg(A, lda, W_pk, bias_pad, logits, ldl, group_max, gm_ld, rows, V, K, dt, stream);
+    if (logits && K == 512 && rows >= 768 && (rows % 256) != 0 && dh_opt(DH_OPT_VOCAB_AREG) && dh_opt(DH_OPT_VOCAB_SPLIT_ROWS)) {
+        // a row count that is no multiple of 256 (C5: 300 templates x beam 10 = 3,000 rows) would take the 128 x 128 tile kernel for
+        // ALL rows (211 us at 3,000 rows): the whole 256-row tiles go through the A-stationary 256-row kernel, the remainder through
+        // the 128-row one -- rows are independent and every classifier kernel is bit-identical to dh_linear, so are the results
+        const int head = rows / 256 * 256;
+        DH_TRY(dh_vocab_logits(A, lda, W, K, bias, logits, ldl, group_max, gm_ld, head, V, K, dt, stream));
+        return dh_vocab_logits((const char*)A + (size_t)head * lda * 2, lda, W, K, bias, logits + (size_t)head * ldl, ldl,
+                               group_max + (size_t)head * gm_ld, gm_ld, rows - head, V, K, dt, stream);
+    }
     return dh_vocab_logits(A, lda, W, K, bias, logits, ldl, group_max, gm_ld, rows, V, K, dt, stream);
 }
 

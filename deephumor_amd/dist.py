@@ -13,7 +13,7 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_range", "gather_captions", "generate_sharded", "generate_micro_sharded"]
+__all__ = ["shard_range", "gather_captions", "gather_captions_async", "generate_sharded", "generate_micro_sharded"]
 
 
 def shard_range(n_total, rank, world_size):
@@ -35,26 +35,56 @@ def _skip_collective(group, always):
     return dist.get_world_size(group) == 1 and not always
 
 
+class PendingGather:
+    """Handle of ``gather_captions_async``: ``wait()`` -> ``(tokens [n_total, T], lengths [n_total])``.  With RCCL ``wait`` makes the
+    CURRENT STREAM wait for the collective (the host does not block), so a caller that issues batch i + 1's decode before waiting
+    for batch i's exchange hides the exchange behind that decode."""
+
+    def __init__(self, work, out, n_total, world, cap, t, direct=None):
+        self.work, self.out, self.n_total, self.world, self.cap, self.t, self.direct = work, out, n_total, world, cap, t, direct
+
+    def wait(self):
+        if self.direct is not None:
+            return self.direct
+        if self.work is not None:
+            self.work.wait()
+            self.work = None
+        out, t = self.out, self.t
+        if self.n_total == self.world * self.cap:           # even shards: the gathered buffer IS the global order
+            full = out
+        else:
+            rows = []
+            for r in range(self.world):
+                lo, hi = shard_range(self.n_total, r, self.world)
+                rows.append(out[r * self.cap:r * self.cap + (hi - lo)])
+            full = torch.cat(rows, 0)
+        self.direct = (full[:, :t].contiguous(), full[:, t].contiguous())
+        return self.direct
+
+
+def gather_captions_async(tokens, lengths, n_total, group=None, always=None):
+    """``gather_captions`` with the collective issued asynchronously (``async_op=True``): returns a ``PendingGather``."""
+    if _skip_collective(group, always):
+        return PendingGather(None, None, n_total, 1, n_total, tokens.shape[1], direct=(tokens, lengths))
+    world = dist.get_world_size(group)
+    t = tokens.shape[1]
+    cap = -(-n_total // world)
+    if tokens.shape[0] == cap:
+        packed = torch.empty((cap, t + 1), dtype=torch.int64, device=tokens.device)
+    else:
+        packed = torch.zeros((cap, t + 1), dtype=torch.int64, device=tokens.device)
+    packed[:tokens.shape[0], :t] = tokens
+    packed[:tokens.shape[0], t] = lengths
+    out = torch.empty((world * cap, t + 1), dtype=torch.int64, device=tokens.device)
+    work = dist.all_gather_into_tensor(out, packed, group=group, async_op=True)
+    return PendingGather(work, out, n_total, world, cap, t)
+
+
 def gather_captions(tokens, lengths, n_total, group=None, always=None):
     """``tokens [n_local, T]`` int64, ``lengths [n_local]`` -> the full ``[n_total, T]`` / ``[n_total]``
     on every rank, in global image order.  One ``all_gather_into_tensor`` on shards padded to the
     largest shard (uneven shards differ by at most one image)."""
-    if _skip_collective(group, always):
-        return tokens, lengths
-    world = dist.get_world_size(group)
-    t = tokens.shape[1]
-    cap = -(-n_total // world)
-    packed = torch.zeros((cap, t + 1), dtype=torch.int64, device=tokens.device)
-    packed[:tokens.shape[0], :t] = tokens
-    packed[:tokens.shape[0], t] = lengths
-    out = torch.empty((world * cap, t + 1), dtype=torch.int64, device=tokens.device)
-    dist.all_gather_into_tensor(out, packed, group=group)
-    rows = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
-        rows.append(out[r * cap:r * cap + (hi - lo)])
-    full = torch.cat(rows, 0)
-    return full[:, :t].contiguous(), full[:, t].contiguous()
+    return gather_captions_async(tokens, lengths, n_total, group, always).wait()
 
 
 def generate_sharded(generate_fn, n_total, group=None, always=None):

@@ -91,6 +91,33 @@ def test_more_shards_than_ranks_gather_in_global_order():
     assert torch.equal(toks, want_t) and torch.equal(lens, want_l)
 
 
+def _async_worker(rank, world, port, n_total, ret):
+    from deephumor_amd.dist import gather_captions_async
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    lo, hi = shard_range(n_total, rank, world)
+    handles = []
+    for s in range(3):                                  # three batches in flight before the first wait
+        toks, lens = _fake_generate(lo, hi)
+        handles.append(gather_captions_async(toks + s, lens, n_total))
+    ret[rank] = [tuple(x.clone() for x in h.wait()) for h in handles]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_async_gather_waited_later():
+    """gather_captions_async: exchanges issued for several batches, waited for afterwards (bench.py waits one step later) --
+    every handle returns its own batch in global order, even and uneven shards."""
+    for n_total in (8, 7):
+        with mp.Manager() as mgr:
+            ret = mgr.dict()
+            mp.spawn(_async_worker, args=(2, _free_port(), n_total, ret), nprocs=2, join=True)
+            want_t, want_l = _fake_generate(0, n_total)
+            for r in range(2):
+                for s, (toks, lens) in enumerate(ret[r]):
+                    assert torch.equal(toks, want_t + s) and torch.equal(lens, want_l)
+
+
 def _score_worker(rank, world, port, n_total, ret):
     from deephumor_amd.dist import score_sharded
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))

@@ -52,8 +52,9 @@ def _oracle_greedy(kind, sd, hp, imgs, i):
 LOGIT_TOL = {torch.bfloat16: (0.36, 0.045), torch.float16: (0.045, 0.006)}
 # greedy token agreement of rows {0, 77, 255} with the oracle's captions (chaotic on synthetic weights: DESIGN section 10): floors set
 # below the values the committed kernels give (printed by the test), so a kernel that degrades precision turns the run red
-GREEDY_FLOOR = {("CaptioningLSTM", torch.bfloat16): 0.25, ("CaptioningLSTM", torch.float16): 0.60,
-                ("CaptioningTransformer", torch.bfloat16): 0.40, ("CaptioningTransformer", torch.float16): 0.60}
+# (values of the round-5 tree on these three images: LSTM bf16 0.5625, fp16 1.0; Transformer bf16 0.9167, fp16 1.0)
+GREEDY_FLOOR = {("CaptioningLSTM", torch.bfloat16): 0.40, ("CaptioningLSTM", torch.float16): 0.80,
+                ("CaptioningTransformer", torch.bfloat16): 0.70, ("CaptioningTransformer", torch.float16): 0.80}
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
