@@ -50,7 +50,8 @@ STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))      # (option "decode_s
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
 PEAK_16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
-PMC_FILE = os.path.join(ROOT, "profiles", "r4", "pmc_hbm_traffic.json")
+PMC_ROUND = "r5"
+PMC_FILE = os.path.join(ROOT, "profiles", PMC_ROUND, "pmc_hbm_traffic.json")
 TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
 _SD_CACHE = {}
@@ -144,7 +145,7 @@ def attach_traffic(rl, workload, dtype):
         if ent:
             rl["traffic"] = ent["traffic_bytes_per_launch"]
             rl["traffic_over_algorithmic"] = ent["traffic_bytes_per_launch"] / rl["algorithmic_bytes_per_launch"]
-            rl["traffic_source"] = f"profiles/r4/pmc_hbm_traffic.json @ {pmc.get('commit', '?')} ({ent.get('note', '')})"
+            rl["traffic_source"] = f"profiles/{PMC_ROUND}/pmc_hbm_traffic.json @ {pmc.get('commit', '?')} ({ent.get('note', '')})"
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return rl
@@ -406,7 +407,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
         by_entry[base] = by_entry.get(base, 0.0) + v["ms"]
     res["kernel_breakdown_ms_per_step"] = {k: round(v, 3) for k, v in sorted(by_entry.items(), key=lambda kv: -kv[1])}
     res["kernel_breakdown_note"] = ("untimed pass with HIP events around every launch: the events add ~15 % to a chain of "
-                                    "small launches; per-kernel shares of the clean run: profiles/r4/*_kernel_stats.csv (rocprofv3)")
+                                    "small launches; per-kernel shares of the clean run: profiles/r5/*_kernel_stats.csv (rocprofv3)")
     src = summary if dominant in summary else breakdown
     res["roofline"] = attach_traffic(price(dominant, src[dominant], dtype), workload, dtype)
     res["roofline"]["measured"] = ((f"timed region, every {stride}th launch" if main_line and not graph and stride > 1 else "timed region, every launch")

@@ -136,7 +136,7 @@ struct OptDef { const char* key; const char* env; int def; bool inverted; };   /
 const OptDef g_opt_defs[DH_OPT_COUNT] = {
     {"vocab_wreg", "DH_VOCAB_WREG", 1, false},
     {"decode_wreg", "DH_DECODE_WREG", 1, false},
-    {"decode_wreg_min_rows", "DH_DECODE_WREG_MIN_ROWS", 320, false},
+    {"decode_wreg_min_rows", "DH_DECODE_WREG_MIN_ROWS", 1, false},
     {"qkv_fusion_max_rows", "DH_QKV_FUSION_MAX_ROWS", 0, false},
     {"cross_qproj", "DH_CROSS_QPROJ", 1, false},
     {"lstm_wreg", "DH_LSTM_WREG", 1, false},
@@ -164,6 +164,7 @@ const OptDef g_opt_defs[DH_OPT_COUNT] = {
     {"s2_tail", "DH_NO_S2_TAIL", 1, true},
     {"vocab_wreg_plan", "DH_NO_VOCAB_WREG", 1, true},
     {"vocab_wreg_transformer", "DH_VOCAB_WREG_TRANSFORMER", 0, false},
+    {"vocab_wreg_transformer_max_rows", "DH_VOCAB_WREG_TRANSFORMER_MAX_ROWS", 640, false},
     {"deferred_ln", "DH_NO_DEFERRED_LN", 1, true},
     {"decode_wreg_plan", "DH_NO_DECODE_WREG", 1, true},
     {"packed_cross", "DH_NO_PACKED_CROSS", 1, true},

@@ -417,11 +417,14 @@ int launch(const F32xParams& p0, int mode, hipStream_t s) {
     p.n_fast = (double)p.N * p.Kp * 4.0 <= 4.0 * 1048576.0;
     const long long t128 = (long long)dh_cdiv(p.M, 128) * dh_cdiv(p.N, 128);
     if (p.N <= 64) launch_tile<128, 64>(p, mode, s);
-    else if (t128 < 256 && mode == 0 && (p.K % 4) == 0) {           // (a decode position: 1,280 x 512 = 40 tiles of 128 x 128)
+    else if (t128 < 256 && mode == 0 && (p.K % 4) == 0 && (long long)dh_cdiv(p.M, 64) * dh_cdiv(p.N, 64) <= 256) {
+        // fewer 64 x 64 tiles than CUs (a decode position's N = 512 layers: 160 tiles): one workgroup per CU at best, so the deep ring
+        // (measured: proj 16.4 against 18.2 us per launch); with several workgroups per CU the 2-stage kernel is the faster one
+        // (qkv 480 tiles: 21 against 28 us, the LSTM gate product 640 tiles: 34 against 59 us)
         p.tiles_m = dh_cdiv(p.M, 64); p.tiles_n = dh_cdiv(p.N, 64);
         hipLaunchKernelGGL(gemm_f32x_small_kernel<8>, dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(256), 0, s, p);
     }
-    else if (t128 < 256) launch_tile<64, 64>(p, mode, s);
+    else if (t128 < 256) launch_tile<64, 64>(p, mode, s);          // (a decode position: 1,280 x 512 = 40 tiles of 128 x 128)
     else launch_tile<128, 128>(p, mode, s);
     return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
 }

@@ -22,7 +22,7 @@ enum DhOption {
     // ---- switches read by the Python layer (kernel selection in the plans) ----
     DH_OPT_CONV1X1_WREG, DH_OPT_CONV_S4, DH_OPT_DIRECT_3X3, DH_OPT_DIRECT_STEM, DH_OPT_STEM_POOL, DH_OPT_FUSED_TAIL,
     DH_OPT_S1_CONV1_FUSION, DH_OPT_S2_CONV1_FUSION, DH_OPT_S3_TAIL, DH_OPT_S2_TAIL, DH_OPT_VOCAB_WREG_PLAN,
-    DH_OPT_VOCAB_WREG_TRANSFORMER, DH_OPT_DEFERRED_LN, DH_OPT_DECODE_WREG_PLAN, DH_OPT_PACKED_CROSS, DH_OPT_QPROJ_FUSION,
+    DH_OPT_VOCAB_WREG_TRANSFORMER, DH_OPT_VOCAB_WREG_TRANSFORMER_MAX_ROWS, DH_OPT_DEFERRED_LN, DH_OPT_DECODE_WREG_PLAN, DH_OPT_PACKED_CROSS, DH_OPT_QPROJ_FUSION,
     DH_OPT_FUSED_BEAM_STEP, DH_OPT_FUSED_BEAM_STEP_MAX_ROWS, DH_OPT_PIPE_PRIO, DH_OPT_DIST_ALWAYS, DH_OPT_DECODE_STREAMS,
     DH_OPT_COUNT
 };

@@ -39,6 +39,7 @@ struct VwParams {
     const float* bias;                                    // padded [Vpad]
     float* C; int ldc; float* gmax; int gmax_ld;
     int M, V, NT, nrb, nchunk, nt;
+    int nrb_real;                                         // row blocks that exist (ceil(M / 80)); nrb = that rounded up to a power of two
 };
 
 __device__ __forceinline__ float4 vw_swap1(float4 v) {    // lane ^ 1
@@ -48,7 +49,7 @@ __device__ __forceinline__ float4 vw_swap1(float4 v) {    // lane ^ 1
 }
 // one 32-column half of a 16-row accumulator block as FULL 128-byte lines (gemm_bf16.hip, store_half_full_lines: same instruction
 // stream): lane pairs (l15, l15 ^ 1) swap one quad, an instruction then covers 8 rows x 128 bytes
-__device__ __forceinline__ void vw_store_half(float* r_even, size_t ldc, float4 va, float4 vb, bool odd, bool nt) {
+__device__ __forceinline__ void vw_store_half(float* r_even, size_t ldc, float4 va, float4 vb, bool odd, bool nt, bool ok0, bool ok1) {
 #define VW_SEL4(c, a, b) make_float4((c) ? (a).x : (b).x, (c) ? (a).y : (b).y, (c) ? (a).z : (b).z, (c) ? (a).w : (b).w)
     const float4 own = VW_SEL4(odd, vb, va);
     const float4 rcv = vw_swap1(VW_SEL4(odd, va, vb));
@@ -56,11 +57,11 @@ __device__ __forceinline__ void vw_store_half(float* r_even, size_t ldc, float4 
     typedef float vw_f4 __attribute__((ext_vector_type(4)));
     const float4 lo = VW_SEL4(odd, rcv, own), hi = VW_SEL4(odd, own, rcv);
     if (nt) {
-        __builtin_nontemporal_store(vw_f4{lo.x, lo.y, lo.z, lo.w}, reinterpret_cast<vw_f4*>(r_even));
-        __builtin_nontemporal_store(vw_f4{hi.x, hi.y, hi.z, hi.w}, reinterpret_cast<vw_f4*>(r_even + ldc));
+        if (ok0) __builtin_nontemporal_store(vw_f4{lo.x, lo.y, lo.z, lo.w}, reinterpret_cast<vw_f4*>(r_even));
+        if (ok1) __builtin_nontemporal_store(vw_f4{hi.x, hi.y, hi.z, hi.w}, reinterpret_cast<vw_f4*>(r_even + ldc));
     } else {
-        *reinterpret_cast<float4*>(r_even) = lo;
-        *reinterpret_cast<float4*>(r_even + ldc) = hi;
+        if (ok0) *reinterpret_cast<float4*>(r_even) = lo;
+        if (ok1) *reinterpret_cast<float4*>(r_even + ldc) = hi;
     }
 #undef VW_SEL4
 }
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, gpx = 32 / p.nrb;
     if (local >= gpx * p.nrb) return;
     const int rb = local % p.nrb, cg = xcd * gpx + local / p.nrb, ncg = 8 * gpx;
-    if (cg >= p.nchunk) return;
+    if (cg >= p.nchunk || rb >= p.nrb_real) return;       // (row counts that are no power-of-two number of blocks: the padding blocks idle)
     const int m0 = rb * RB;
 
     // ---- weight fragments of the first RING - 1 k-steps of the first chunk (plain loads: the compiler counts them) -----------------------
@@ -94,11 +95,12 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) wq[s][j] = w0[(size_t)s * sstep + j * 64];
     }
-    // ---- the row block: 8 planes x 10 groups of 8 rows, 20 pieces per wave (host: M % 80 == 0) -------------------------------------------
+    // ---- the row block: 8 planes x 10 groups of 8 rows, 20 pieces per wave; rows past M (last block of a row count that is no multiple
+    //      of 80) re-read row M - 1, their outputs are not stored ----------------------------------------------------------------------------
 #pragma unroll
     for (int u = 0; u < CB * (RB / 8) / 4; ++u) {
         const int pc = wave * (CB * (RB / 8) / 4) + u, cb = pc / (RB / 8), g = pc - cb * (RB / 8);
-        dh_lds_dma16(p.A + (size_t)(m0 + g * 8 + lr) * p.lda + cb * 64 + ((lpos ^ lr) << 3), lds + cb * PLANE + g * 1024);
+        dh_lds_dma16(p.A + (size_t)min(m0 + g * 8 + lr, p.M - 1) * p.lda + cb * 64 + ((lpos ^ lr) << 3), lds + cb * PLANE + g * 1024);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces (and its first fragments) have landed
     __syncthreads();
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
         //      accumulator set costs AGPR <-> VGPR moves in the loop that the spread-out stores do not buy back.) ------------------------------
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int m = m0 + 16 * i + l15;
-            float* r_even = p.C + (size_t)(m0 + 16 * i + (l15 & ~1)) * p.ldc + n0 + ((l15 & 1) ? 16 : 0) + 4 * lq;
+            const int m = m0 + 16 * i + l15, m_even = m0 + 16 * i + (l15 & ~1);
+            float* r_even = p.C + (size_t)m_even * p.ldc + n0 + ((l15 & 1) ? 16 : 0) + 4 * lq;
             float mxv = -INFINITY;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -178,11 +180,11 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
                 vb.x = acc[i][2 * h + 1][0] + b4[2 * h + 1].x; vb.y = acc[i][2 * h + 1][1] + b4[2 * h + 1].y;
                 vb.z = acc[i][2 * h + 1][2] + b4[2 * h + 1].z; vb.w = acc[i][2 * h + 1][3] + b4[2 * h + 1].w;
                 mxv = fmaxf(fmaxf(mxv, fmaxf(fmaxf(va.x, va.y), fmaxf(va.z, va.w))), fmaxf(fmaxf(vb.x, vb.y), fmaxf(vb.z, vb.w)));
-                if (p.C) vw_store_half(r_even + 32 * h, p.ldc, va, vb, l15 & 1, p.nt != 0);
+                if (p.C) vw_store_half(r_even + 32 * h, p.ldc, va, vb, l15 & 1, p.nt != 0, m_even < p.M, m_even + 1 < p.M);
             }
             mxv = fmaxf(mxv, __shfl_xor(mxv, 16, 64));
             mxv = fmaxf(mxv, __shfl_xor(mxv, 32, 64));
-            if (p.gmax && lq == 0) p.gmax[(size_t)m * p.gmax_ld + n0 / 64] = n0 < p.V ? mxv : -INFINITY;      // -inf for a group that starts past V
+            if (p.gmax && lq == 0 && m < p.M) p.gmax[(size_t)m * p.gmax_ld + n0 / 64] = n0 < p.V ? mxv : -INFINITY;      // -inf for a group that starts past V
         }
         if (pf) {
 #pragma unroll
@@ -192,13 +194,14 @@ __global__ __launch_bounds__(256, 1) void vocab_wreg_kernel(VwParams p) {
 }
 }  // namespace
 
-// 1 when dh_vocab_logits_wreg takes the shape: K = 512, M = 80 x {1, 2, 4, 8, 16, 32} rows, a logits row stride and a group-maxima
-// stride that cover the vocabulary padded to whole 256-column chunks
+// 1 when dh_vocab_logits_wreg takes the shape: K = 512; M = 80 x {1, 2, 4, 8, 16, 32} rows, or (round 5: the small-shard regime) ANY
+// M <= 640 -- the row blocks are then padded to a power of two with idle workgroups and the last block's missing rows are masked; a
+// logits row stride and a group-maxima stride that cover the vocabulary padded to whole 256-column chunks
 extern "C" int dh_vocab_logits_wreg_supported(int M, int V, int K, int ldl, int gm_ld) {
-    if (K != 512 || M <= 0 || (M % 80) != 0 || V <= 0) return 0;
-    const int nrb = M / 80, vpad = dh_cdiv(V, 256) * 256;
-    return (nrb == 1 || nrb == 2 || nrb == 4 || nrb == 8 || nrb == 16 || nrb == 32) && (ldl == 0 || (ldl >= vpad && (ldl % 4) == 0)) &&
-           gm_ld >= vpad / 64;
+    if (K != 512 || M <= 0 || V <= 0) return 0;
+    const int nrb = dh_cdiv(M, 80), vpad = dh_cdiv(V, 256) * 256;
+    const bool pow2_blocks = (M % 80) == 0 && (nrb == 1 || nrb == 2 || nrb == 4 || nrb == 8 || nrb == 16 || nrb == 32);
+    return (pow2_blocks || M <= 640) && (ldl == 0 || (ldl >= vpad && (ldl % 4) == 0)) && gm_ld >= vpad / 64;
 }
 
 // logits [M, ldl] fp32 (may be NULL: group maxima only) and group_max [M, gm_ld] as dh_vocab_logits writes them, from
@@ -213,7 +216,10 @@ extern "C" int dh_vocab_logits_wreg(const void* A, int lda, const void* w_packed
                ((uintptr_t)logits % 16) == 0);
     VwParams p{};
     p.A = (const uint16_t*)A; p.lda = lda; p.wp = (const uint4*)w_packed; p.bias = bias_padded; p.C = logits; p.ldc = ldl;
-    p.gmax = group_max; p.gmax_ld = gm_ld; p.M = M; p.V = V; p.nrb = M / 80; p.nchunk = dh_cdiv(V, 256); p.NT = p.nchunk * 16;
+    p.gmax = group_max; p.gmax_ld = gm_ld; p.M = M; p.V = V; p.nchunk = dh_cdiv(V, 256); p.NT = p.nchunk * 16;
+    p.nrb_real = dh_cdiv(M, 80);
+    p.nrb = 1;
+    while (p.nrb < p.nrb_real) p.nrb *= 2;
     dh_prof_set_tag("vocab");
     dh_prof_set_dims(M, V, K);
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);

@@ -479,23 +479,15 @@ def linear_f32x(a, planes, bias=None, scale=None, shift=None, relu=False, out=No
     m, k = a.shape
     n, kp = planes.shape[1], planes.shape[2]
     assert a.dtype == torch.float32 and planes.dtype == torch.float16 and a.stride(1) == 1 and kp == (k + 31) // 32 * 32
-    if a.stride(0) % 4 or a.data_ptr() % 16 or k % 4:
-        a = _aligned_rows(a)
+    assert k % 4 == 0, "dh_linear_f32x takes K % 4 == 0 (16-byte fp32 chunks); hip.linear() keeps the exact-fp32 kernel otherwise"
+    if a.stride(0) % 4 or a.data_ptr() % 16:
+        a = a.contiguous()
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=a.device)
     assert out.shape == (m, n) and out.stride(1) == 1 and out.dtype == torch.float32
     _launch("dh_linear_f32x", _ptr(a), a.stride(0), _ptr(planes), kp, _ptr(bias), _ptr(scale), _ptr(shift), _ptr(residual),
             residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _stream(), tag=tag)
     return out
-
-
-def _aligned_rows(a):
-    """Copy of ``a [M, K]`` whose rows start 16-byte aligned and whose K is a multiple of 4 (zero padded)."""
-    m, k = a.shape
-    kp = (k + 3) // 4 * 4
-    buf = torch.zeros((m, kp), dtype=a.dtype, device=a.device)
-    buf[:, :k].copy_(a)
-    return buf[:, :k] if kp == k else buf
 
 
 def conv2d_nhwc_f32x(x, planes, ks, scale, shift, residual=None, relu=True, stride=1, pad=0):
@@ -544,7 +536,7 @@ def linear(a, w, bias=None, scale=None, shift=None, relu=False, out=None, tag=No
     (``out_dtype=torch.float32``: logits).  ``w_x``: ``split_f32x(w)`` -- an fp32 product then runs on the 16-bit matrix cores
     with split operands when option ``f32_split`` is on (``linear_f32x``)."""
     _dev(a, w, bias, scale, shift, out, residual)
-    if w_x is not None and a.dtype == torch.float32 and option("f32_split"):
+    if w_x is not None and a.dtype == torch.float32 and a.shape[1] % 4 == 0 and option("f32_split"):
         return linear_f32x(a, w_x, bias, scale, shift, relu, out, tag, residual)
     m, k = a.shape
     n, k2 = w.shape

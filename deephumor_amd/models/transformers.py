@@ -226,11 +226,12 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     if name in ent:
                         ent[name + "_x"] = hip.split_f32x(ent[name].contiguous())
             plan["cls_w_x"] = hip.split_f32x(plan["cls_w"].contiguous())
-        if (plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and hip.option("vocab_wreg_transformer")
-                and hip.option("vocab_wreg_plan")):
-            # opt-in here (the LSTM decoder uses it by default): csrc/vocab_wreg.hip wins where the 37 MB of weights are still in the
-            # Infinity Cache when the next position's classifier starts; a Transformer position moves ~1 GB of KV cache in between and
-            # the step takes the same time with either kernel (20.4-20.7 ms, three alternating runs)
+        if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and hip.option("vocab_wreg_plan"):
+            # the register-streamed classifier (csrc/vocab_wreg.hip; bit-identical).  The LSTM decoder uses it at every size; here it is
+            # selected per batch by row count (_Run): at <= "vocab_wreg_transformer_max_rows" rows per position (small shards, single
+            # images: the 128-row A-stationary kernel takes 54 us at 380 rows) or always with option "vocab_wreg_transformer" -- at 1,280
+            # rows a Transformer position moves ~1 GB of KV cache between two classifier launches, the 37 MB of weights do not survive in
+            # the Infinity Cache and the step takes the same time with either kernel (20.4-20.7 ms, three alternating runs)
             plan["cls_w_pk"], plan["cls_b_pad"] = hip.pack_vocab_weights(plan["cls_w"], plan["cls_b"])
         return plan
 
@@ -308,7 +309,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             m.layers = self.c_layers
             m.tok_emb, m.pos_emb, m.cls_w, m.cls_b = P(plan["tok"]), P(plan["pos"]), P(plan["cls_w"]), P(plan["cls_b"])
             m.keymask = P(self.keymask)
-            if "cls_w_pk" in plan:
+            if "cls_w_pk" in plan and (hip.option("vocab_wreg_transformer") or self.rows_total <= hip.option("vocab_wreg_transformer_max_rows")):
                 m.cls_w_pk, m.cls_b_pad = P(plan["cls_w_pk"]), P(plan["cls_b_pad"])
             if "cls_w_x" in plan:
                 m.cls_w_x = P(plan["cls_w_x"])

@@ -301,7 +301,8 @@ int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, const float*
  * (csrc/vocab_wreg.hip; the classifier of a beam-search step, rnn_models.py:45 / transformers.py:489 inside generate()).
  * w_packed = dh_pack_mfma_fragments(W padded to Vpad = ceil(V / 256) * 256 rows with copies of row V - 1) re-ordered chunk-major
  * ([16 k-steps][Vpad / 16 tiles][1 KB] -> [Vpad / 256 chunks][16 k-steps][16 tiles][1 KB]), bias_padded [Vpad] padded
- * likewise (NULL: no bias).  _supported: K = 512, M = 80 x {1, 2, 4, 8, 16, 32}, ldl and gm_ld cover Vpad (ldl = 0: no logits).
+ * likewise (NULL: no bias).  _supported: K = 512, M = 80 x {1, 2, 4, 8, 16, 32} or any M <= 640 (row blocks padded to a power of two
+ * with idle workgroups, the last block's missing rows masked), ldl and gm_ld cover Vpad (ldl = 0: no logits).
  * Bit-identical to dh_vocab_logits on the columns [0, Vpad) and on the group maxima. */
 int dh_vocab_logits_wreg_supported(int M, int V, int K, int ldl, int gm_ld);
 int dh_vocab_logits_wreg(const void* A, int lda, const void* w_packed, const float* bias_padded, float* logits, int ldl,

@@ -248,7 +248,9 @@ def test_vocab_logits_256_row_tiles(hip, rows, v):
 
 
 @pytest.mark.parametrize("rows,v,with_bias,with_logits", [(1280, 36541, True, True), (80, 300, True, True), (640, 8192, False, True),
-                                                           (320, 4100, True, False), (2560, 1000, True, True), (160, 36541, True, True)])
+                                                           (320, 4100, True, False), (2560, 1000, True, True), (160, 36541, True, True),
+                                                           (380, 36541, True, True), (37, 3001, True, True), (5, 1000, False, True), (600, 5000, True, False),
+                                                           (81, 2000, True, True), (370, 36541, True, True)])
 def test_vocab_logits_wreg_equals_vocab_logits(hip, rows, v, with_bias, with_logits):
     """dh_vocab_logits_wreg (weights from L2 into registers in fragment order, 80-row activation blocks resident in LDS, no barrier)
     against dh_vocab_logits on the same operands, bit for bit: logits on every column of the padded row stride the old kernel
@@ -261,7 +263,9 @@ def test_vocab_logits_wreg_equals_vocab_logits(hip, rows, v, with_bias, with_log
     vpad = (v + 255) // 256 * 256
     ng = vpad // 64
     assert hip.vocab_logits_wreg_supported(rows, v, k, vpad if with_logits else 0, ng)
-    assert not hip.vocab_logits_wreg_supported(rows + 16, v, k, vpad, ng) and not hip.vocab_logits_wreg_supported(rows, v, 256, vpad, ng)
+    # (round 5: ANY row count up to 640 -- the small-shard regime: 380 = C5's 38-template shard x beam 10 -- with idle padding row blocks
+    #  and a masked last block; above 640 rows only 80 x a power of two)
+    assert hip.vocab_logits_wreg_supported(rows + 16, v, k, vpad, ng) == (rows + 16 <= 640) and not hip.vocab_logits_wreg_supported(rows, v, 256, vpad, ng)
     assert not hip.vocab_logits_wreg_supported(rows, v, k, vpad - 4, ng) and not hip.vocab_logits_wreg_supported(rows, v, k, vpad, ng - 1)
     wp, bp = hip.pack_vocab_weights(w, b)
     ref_l = torch.full((rows + 1, vpad), float("nan"), device="cuda")
@@ -797,6 +801,25 @@ def test_decode_chain_wreg_equals_tile_chain(kind):
             t2, l2 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
         assert "wo_pk" in model.decoder._get_plan()["layers"][0]
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
+
+
+def test_decode_chain_unfused_qproj_equals_fused():
+    """Option cross_qproj = 0 (fc_q as its own register-stationary GEMM in front of the packed cross-attention, K still packed in the
+    fused launch's head-dim slot order) against the fused launch: same tokens, same lengths, bit for bit -- so the two can be selected by
+    row count without touching shard invariance."""
+    import deephumor_amd.models as M
+    from deephumor_amd import hip as H
+    from deephumor_amd.synth import synth_state_dict
+    model = M.CaptioningTransformer(1000, hid_dim=512, n_layers=2).eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=99))
+    model = model.to(HALF).cuda()
+    for n in (7, 64):
+        imgs = synth_images(n, seed=13).cuda()
+        with torch.no_grad():
+            t1, l1 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
+            with H.option_scope(cross_qproj=0):
+                t2, l2 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
+        assert torch.equal(t1, t2) and torch.equal(l1, l2), n
 
 
 @pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])

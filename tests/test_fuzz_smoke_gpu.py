@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEED = 11
 
-SWEEPS = [("fuzz_generate", 12, ["--half"]), ("fuzz_generate", 2, ["--long"]), ("fuzz_generate", 8, ["--r4", "--half"]), ("fuzz_forward", 12, []), ("fuzz_forward", 2, ["--big"]),
+SWEEPS = [("fuzz_generate", 12, ["--half"]), ("fuzz_generate", 2, ["--long"]), ("fuzz_generate", 8, ["--r4", "--half"]), ("fuzz_generate", 10, ["--split"]), ("fuzz_forward", 12, []), ("fuzz_forward", 2, ["--big"]),
           ("fuzz_encoder", 4, []), ("fuzz_beam_methods", 15, []), ("fuzz_sampler", 25, []), ("fuzz_scoring", 15, []),
-          ("fuzz_gemm", 15, []), ("fuzz_conv", 8, []), ("fuzz_pipeline", 6, []), ("fuzz_variants", 6, [])]
+          ("fuzz_gemm", 15, []), ("fuzz_f32x", 24, []), ("fuzz_conv", 8, []), ("fuzz_pipeline", 6, []), ("fuzz_variants", 6, [])]
 
 
 @pytest.mark.parametrize("tool,trials,extra", SWEEPS, ids=[t + "".join(e) for t, _, e in SWEEPS])

@@ -1,10 +1,10 @@
 #!/usr/bin/env bash
 # Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel traces and PMC passes of the bench workloads of THIS tree, reduced to
-# CSV summaries under gpurun_out/profiles_${ROUND:-r4}/ (copied to profiles/<round>/ afterwards).  Counters in their own passes
+# CSV summaries under gpurun_out/profiles_${ROUND:-r5}/ (copied to profiles/<round>/ afterwards).  Counters in their own passes
 # (--pmc with --kernel-trace only; FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950).
 set -uo pipefail
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/profiles_${ROUND:-r4}
+OUT=$R/gpurun_out/profiles_${ROUND:-r5}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for wl in c2 c3; do
@@ -24,10 +24,28 @@ for pr in vocab_probe s3_probe enc_probe lstm_probe kbench; do
 done
 cp $R/gpurun_out/pmc_sq/*.csv $OUT/ 2>/dev/null
 python3 $R/tools/make_pmc_json.py $OUT "$(cat $R/deephumor_amd/lib/BUILD_COMMIT 2>/dev/null || echo unknown)" > /dev/null 2>&1
-mkdir -p $R/profiles/${ROUND:-r4} && cp $OUT/pmc_hbm_traffic.json $R/profiles/${ROUND:-r4}/pmc_hbm_traffic.json   # bench.py reads it for roofline.traffic
+mkdir -p $R/profiles/${ROUND:-r5} && cp $OUT/pmc_hbm_traffic.json $R/profiles/${ROUND:-r5}/pmc_hbm_traffic.json   # bench.py reads it for roofline.traffic
 python3 $R/bench.py > $OUT/bench_default_bf16.json 2> /dev/null
 python3 $R/bench.py --workload c5 --steps 5 > $OUT/bench_c5_f16.json 2> /dev/null
 python3 $R/bench.py --workload c2 --steps 20 --warmup 5 --quick --rccl-single 2> /dev/null | tail -1 > $OUT/bench_c2_rccl_single_rank.json
 python3 $R/bench.py --workload score-c2 --steps 3 > $OUT/bench_score_c2.json 2> /dev/null
 python3 $R/bench.py --workload score-c3 --steps 3 > $OUT/bench_score_c3.json 2> /dev/null
+# round 5: the fp32 paths under rocprofv3 (exact fp32, and option f32_split = the split-operand matrix-core path), their timing,
+# the shard regime as one rank of 8 would see it, the launch-floor probe, the exchange's cost
+for mode in 0 1; do
+  DH_F32_SPLIT=$mode rocprofv3 --kernel-trace --stats -d /tmp/prof_f32_$mode -o t -- python3 $R/bench.py --workload c2 --dtype f32 --steps 2 --warmup 1 --quick > $OUT/bench_c2_f32_split${mode}_under_rocprof.json 2>/dev/null
+  python3 $R/tools/rocpd_stats.py /tmp/prof_f32_$mode/t_results.db --by-grid --top 0 --csv $OUT/c2_f32_split${mode}_kernel_stats.csv 2> $OUT/c2_f32_split${mode}_kernel_stats.txt
+  DH_F32_SPLIT=$mode rocprofv3 --kernel-trace --stats -d /tmp/prof_f32c3_$mode -o t -- python3 $R/bench.py --workload c3 --dtype f32 --steps 2 --warmup 1 --quick > $OUT/bench_c3_f32_split${mode}_under_rocprof.json 2>/dev/null
+  python3 $R/tools/rocpd_stats.py /tmp/prof_f32c3_$mode/t_results.db --by-grid --top 0 --csv $OUT/c3_f32_split${mode}_kernel_stats.csv 2> $OUT/c3_f32_split${mode}_kernel_stats.txt
+done
+cd $R
+python3 $R/tools/f32x_bench.py c2 c3 > $OUT/f32x_bench.json 2>/dev/null
+python3 $R/bench.py --workload c5 --shard-of 8 --rccl-single --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_c5_shard_of_8_rank0.json
+python3 $R/bench.py --workload c5 --shard-of 8 --shard-rank 7 --shard-only --rccl-single --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_c5_shard_of_8_rank7.json
+python3 $R/bench.py --workload c3 --shard-of 8 --rccl-single --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_c3_shard_of_8.json
+python3 $R/bench.py --workload c3 --batch 32 --shard-of 8 --steps 5 --warmup 2 2>/dev/null | tail -1 > $OUT/bench_c3_batch32_strong_shard.json
+( cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_c5s -o t -- python3 $R/bench.py --workload c5 --shard-of 8 --shard-only --steps 2 --warmup 1 > /dev/null 2>&1
+  python3 $R/tools/rocpd_stats.py /tmp/prof_c5s/t_results.db --by-grid --top 0 --sequence 60 --csv $OUT/c5_shard_kernel_stats.csv > $OUT/c5_shard_kernel_stats.txt 2>&1 )
+$R/tools/probe/launch_floor_probe > $OUT/launch_floor_probe.jsonl 2>&1
+python3 $R/tools/gather_cost.py > $OUT/gather_cost.json 2>/dev/null
 ls -la $OUT

@@ -18,6 +18,7 @@ run() {   # name, trials, extra args...
 run fuzz_generate 250 --half
 run fuzz_generate 25 --long
 run fuzz_generate 120 --r4 --half
+run fuzz_generate 150 --split
 run fuzz_forward 250
 run fuzz_forward 40 --big
 run fuzz_encoder 80
@@ -26,5 +27,6 @@ run fuzz_sampler 500
 run fuzz_scoring 300
 run fuzz_gemm 300
 run fuzz_conv 150
+run fuzz_f32x 300
 run fuzz_pipeline 120
 run fuzz_variants 120

@@ -209,7 +209,11 @@ def main(argv=None):
     ap.add_argument("--long", action="store_true", help="captions of 100-380 positions on small decoders")
     ap.add_argument("--half", action="store_true", help="also run the bf16 / fp16 paths on every configuration (validity + repeatability)")
     ap.add_argument("--r4", action="store_true", help="beam_size 17-64, pad_index in {0, 1, 7}, draws through the product's rng=\"torch\"")
+    ap.add_argument("--split", action="store_true", help="the fp32 model with option f32_split: dense layers as split-operand fp16 MFMAs (round 5)")
     args = ap.parse_args(argv)
+    if args.split:
+        from deephumor_amd import hip
+        hip.set_option("f32_split", 1)
     global HALF, LONG, R4
     HALF, LONG, R4 = args.half, args.long, args.r4
     bad = near = 0
@@ -247,6 +251,9 @@ def main(argv=None):
             rec.update(want=want, got=got)
         print(json.dumps(rec), flush=True)
     print(json.dumps({"trials": args.trials, "mismatches_or_errors": bad, "fp32_near_ties_not_comparable": near}), flush=True)
+    if args.split:
+        from deephumor_amd import hip
+        hip.set_option("f32_split", 0)
     return 0
 
 

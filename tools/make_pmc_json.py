@@ -45,7 +45,7 @@ def mean_kb(rs, frag, wgs):
 
 
 def main():
-    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r4")
+    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r5")
     commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(
         ["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     out = {"commit": commit,
