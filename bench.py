@@ -9,7 +9,10 @@
 A "step" is one pass of the hot path over one batch of synthetic images that are already resident in HBM:
 ResNet-50 encoder -> decoder -> beam-search generate (beam=5, top_k=50, 32 tokens) for ``--batch`` images per rank,
 followed -- when N > 1 -- by the single all_gather of token ids.  ``value`` = captions finished by all ranks / wall time
-(max over ranks), weak scaling (256 images per GPU).  Workloads (BASELINE.json configs): ``c2`` = CaptioningLSTM
+(max over ranks), weak scaling (256 images per GPU).  Schedule (``--schedule``, round 5): the K steps of the timed region run as ONE
+stream of batches (``CaptionPipeline``: batch i + 1's encoder on its own HIP stream under batch i's decode, the batch's all_gather
+waited for one step later) -- every step still encodes, decodes and exchanges exactly one batch and all K are complete when the
+region closes; the one-batch-at-a-time rate of rounds 1-4 is measured in the same run and reported as ``value_sequential``.  Workloads (BASELINE.json configs): ``c2`` = CaptioningLSTM
 (default, configs[1]); ``c3`` = CaptioningTransformer 6-layer/8-head; ``c5`` = the 300-template fp16 beam-10 sweep.
 The default run reports c2 as the contract line and attaches a c3 measurement under ``"c3"``.
 
@@ -112,7 +115,11 @@ def price(key, d, dtype):
     sec = d["ms"] / 1e3 / max(d["calls"], 1)
     fl, by = d["flops"] / max(d["calls"], 1), d["bytes"] / max(d["calls"], 1)
     peak = PEAK_F32_TFLOPS if dtype == "f32" else PEAK_16_TFLOPS
+    if "_f32x" in key:          # split-operand fp32 kernels: three fp16 MFMAs per algorithmic product
+        peak = PEAK_16_TFLOPS / 3.0
     out = {"kernel": key, "launches": d["calls"], "avg_launch_us": sec * 1e6, "traffic": None}
+    if "_f32x" in key:
+        out["peak_note"] = "dense fp16 MFMA peak / 3 (hi*hi + hi*lo + lo*hi per product)"
     if by:
         out["algorithmic_bytes_per_launch"] = by
     if fl:
@@ -312,11 +319,44 @@ def timed_region(step_fn, steps, world, device, drain=None):
 
 
 # ---- legs on the GPU ----------------------------------------------------------------------------------------------
-def timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=None, graph=False, stride=1):
+def pipelined_stepper(model, images, img0, n_total, steps, pending, first_seed=100):
+    """``step(s)`` for ``timed_region`` on the production schedule (``deephumor_amd.pipeline.CaptionPipeline``): the K batches of the
+    timed region as ONE stream of batches -- the encoder of batch i + 1 runs on its own HIP stream while batch i decodes (the decode
+    chains of both workloads leave most CUs idle; the encoder is throughput-bound) -- every step still encodes, decodes and exchanges
+    exactly one batch, and all K are complete when the region closes (the pipeline is fed exactly K batches; call s returns batch
+    s's captions)."""
+    from deephumor_amd.dist import gather_captions_async
+    from deephumor_amd.pipeline import CaptionPipeline
+    kw = dict(max_len=MAX_LEN, beam_size=BEAM, top_k=TOP_K, temperature=TEMP)
+    if STREAMS > 1:
+        kw["streams"] = STREAMS
+    pipe = CaptionPipeline(model, overlap=True, **kw)
+    gen = []
+
+    def step(s):
+        if not gen:
+            gen.append(pipe.run([(images,)] * steps, seeds=range(first_seed, first_seed + steps), img0=img0, to_host=False))
+        toks, lens = next(gen[0])
+        if toks.is_cuda:                                   # produced on the pipeline's decode stream, consumed on this one
+            toks.record_stream(torch.cuda.current_stream())
+            lens.record_stream(torch.cuda.current_stream())
+        prev, pending[0] = pending[0], gather_captions_async(toks, lens, n_total)
+        return prev.wait() if prev is not None else (toks, lens)
+    return step
+
+
+def timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=None, graph=False, stride=1, pipelined=False):
     from deephumor_amd import hip
     world = n_total // n_local
     pending = [None]          # the batch's all_gather is waited for one step later (inside the timed region: drain_pending)
-    step = lambda s: one_step(model, images, rank * n_local, n_total, seed=100 + s, graph=graph, pending=pending)
+    if pipelined:
+        with torch.no_grad():                             # untimed: the pipeline's streams and buffers exist before the region opens
+            warm = pipelined_stepper(model, images, rank * n_local, n_total, 2, pending, first_seed=1)
+            warm(0), warm(1)
+            drain_pending(pending)
+        step = pipelined_stepper(model, images, rank * n_local, n_total, steps, pending)
+    else:
+        step = lambda s: one_step(model, images, rank * n_local, n_total, seed=100 + s, graph=graph, pending=pending)
     drain = lambda: drain_pending(pending)
     if watch:
         # HIP events around the launches of the roofline kernel INSIDE the timed region.  Each event pair costs ~5 us of stream
@@ -393,14 +433,29 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
         dominant = max(breakdown, key=lambda k: breakdown[k]["ms"])          # ONE kernel template at ONE shape
         for w in range(1, warmup):
             one_step(model, images, rank * n_local, n_total, seed=w, graph=graph)
-        if main_line and not graph:
-            # timed region: events only around the launches of the dominant key (a few dozen pairs per step)
-            stride = max(1, breakdown[dominant]["calls"] // 32)
-            dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch={dominant}, stride=stride)
+        pipelined = args.schedule == "pipelined" and not graph
+        seq = None
+        # events only around the launches of the dominant key (a few dozen pairs per step)
+        stride = max(1, breakdown[dominant]["calls"] // 32)
+        watch = {dominant} if main_line and not graph else None
+        if pipelined:
+            # the same K steps one batch at a time first (rounds 1-4's headline; kept as value_sequential) -- the roofline kernel's
+            # launches are event-timed in THIS region, where the kernel has the chip to itself (in the pipelined region it shares the
+            # CUs with the next batch's encoder: its elapsed time there says nothing about the kernel) -- then the production schedule
+            ts, _, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=watch, stride=stride)
+            seq = {"value": n_total * steps / ts, "unit": "captions/s", "ms_per_step": ts / steps * 1e3}
+            dt, lens, _ = timed_steps(model, images, rank, n_local, n_total, steps, barrier, pipelined=True)
+        elif watch:
+            dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=watch, stride=stride)
         else:
             dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, graph=graph)
     res = {"value": n_total * steps / dt, "ms_per_step": dt / steps * 1e3,
            "mean_caption_len": float(lens.float().mean()) if lens is not None else None}
+    res["schedule"] = ("pipelined: the K batches of the timed region as one stream of batches (CaptionPipeline), encoder of batch i + 1 on its own "
+                       "HIP stream under the decode of batch i; every step = one batch encoded + decoded + exchanged, all K complete inside "
+                       "the region" if pipelined else "sequential: one batch at a time")
+    if seq is not None:
+        res["sequential"] = seq
     by_entry = {}
     for k, v in breakdown.items():
         base = re.sub(r"\{.*\}$", "", k)
@@ -412,6 +467,9 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
     res["roofline"] = attach_traffic(price(dominant, src[dominant], dtype), workload, dtype)
     res["roofline"]["measured"] = ((f"timed region, every {stride}th launch" if main_line and not graph and stride > 1 else "timed region, every launch")
                                    if dominant in summary else "instrumented pass")
+    if seq is not None and dominant in summary:
+        res["roofline"]["measured"] += (" of the SEQUENTIAL timed pass of this run (value_sequential): the kernel alone on the chip; the pipelined "
+                                        "region overlaps it with the next batch's encoder")
     res["per_rank_ms_per_step"] = {"min": min(RANK_TIMES) / steps * 1e3, "max": max(RANK_TIMES) / steps * 1e3, "ranks": len(RANK_TIMES)}
     res["encoder_layers"] = encoder_table(breakdown, dtype)
     if workload in ("c3", "c5"):
@@ -434,6 +492,8 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
     if world == 1 and not args.quick:
         with torch.no_grad():
             res["host_inclusive"] = host_inclusive(model, n_local, max(10, steps))    # enough batches for the pipeline's steady state
+    if world == 1 and not args.quick and args.schedule != "pipelined":
+        with torch.no_grad():
             # the same device-resident batches as `value`, but as a STREAM of batches through CaptionPipeline: the encoder of batch
             # i+1 runs on its own HIP stream while batch i decodes (reported next to `value`, which times one batch at a time)
             from deephumor_amd.pipeline import CaptionPipeline
@@ -463,7 +523,8 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                 one_step(m32, images, 0, n_total, seed=0)
                 t32, _, _ = timed_steps(m32, images, 0, n_local, n_total, 3, barrier)
             res["fp32_parity_path"] = {"value": n_total * 3 / t32, "unit": "captions/s", "ms_per_step": t32 / 3 * 1e3, "steps": 3,
-                                       "note": "same step, fp32 storage + exact-fp32 arithmetic: the path whose greedy ids are bit-exact"}
+                                       "note": "same step, fp32 storage + exact-fp32 arithmetic: the path whose greedy ids are bit-exact (sequential schedule, as "
+                                               "parity_grade_path: compare these two with each other and with value_sequential)"}
             del m32
             torch.cuda.empty_cache()
             # the parity-grade matrix-core path: the same fp32 model with option f32_split (every dense layer / convolution as three
@@ -496,8 +557,9 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                 else:
                     with torch.no_grad():
                         one_step(model, images, 0, n_total, seed=0)
-                        t16, _, _ = timed_steps(model, images, 0, n_local, n_total, 3, barrier)
-                    res[f"{dt}_path"] = {"value": n_total * 3 / t16, "unit": "captions/s", "ms_per_step": t16 / 3 * 1e3, "steps": 3}
+                        t16, _, _ = timed_steps(model, images, 0, n_local, n_total, 5, barrier, pipelined=args.schedule == "pipelined")
+                    res[f"{dt}_path"] = {"value": n_total * 5 / t16, "unit": "captions/s", "ms_per_step": t16 / 5 * 1e3, "steps": 5,
+                                         "schedule": args.schedule}
                 del model
                 torch.cuda.empty_cache()
             del ref
@@ -807,6 +869,9 @@ def main(argv=None):
                     "(C5: 38 / 37 of the 300 templates; C2 / C3: --batch images of a W x batch global batch) and print a labelled projection")
     ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--shard-only", action="store_true", help="with --shard-of: skip the full-batch leg (profiling runs)")
+    ap.add_argument("--schedule", choices=["pipelined", "sequential"], default="pipelined",
+                    help="pipelined (default): the timed region's K batches as one stream of batches, the next batch's encoder overlapping the "
+                         "current batch's decode (deephumor_amd.pipeline.CaptionPipeline); sequential: one batch at a time (the rounds 1-4 headline)")
     ap.add_argument("--stub", action="store_true", help="CPU/gloo control-flow test of the multi-rank path (model stubbed; not a measurement)")
     args = ap.parse_args(argv)
     if args.dtype is None:
@@ -905,8 +970,12 @@ def main(argv=None):
         # which rate `value` is: the bench contract's (inputs already resident in HBM when the timed region starts; a PCIe-inclusive rate
         # is never `value`).  SURVEY 8(d) / BASELINE.md section 3 define the metric host images -> host ids: that one is
         # `value_host_inclusive` (pipelined, decoded uint8 images in pinned memory) with its ratio to `value` next to it
-        "value_def": "device-resident fp32 NCHW images -> token ids on the device (bench contract); host -> host: value_host_inclusive",
+        "value_def": "device-resident fp32 NCHW images -> token ids on the device (bench contract), K batches as one pipelined stream "
+                     "(config.schedule; one batch at a time: value_sequential); host -> host: value_host_inclusive",
     }
+    line["config"]["schedule"] = res.get("schedule")
+    if "sequential" in res:
+        line["value_sequential"] = res["sequential"]["value"]
     for k in ("greedy_token_match_vs_cpu_ref", f"greedy_token_match_{args.dtype}_vs_cpu_ref", "precision_vs_fp32_hip", "speedup_vs_cpu", "pipelined_device_resident",
               "mean_caption_len", "fp32_parity_path", "parity_grade_path", "f16_path", "bf16_path", "host_inclusive", "hipgraph_replay", "kernel_breakdown_ms_per_step", "kernel_breakdown_note",
               "encoder_layers", "roofline_self_attention", "roofline_cross_attention", "roofline_decoder_attention_combined"):

@@ -8,13 +8,13 @@ OUT=$R/gpurun_out/profiles_${ROUND:-r5}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for wl in c2 c3; do
-  rocprofv3 --kernel-trace --stats -d /tmp/prof_$wl -o t -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --quick > $OUT/bench_${wl}_bf16_under_rocprof.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats -d /tmp/prof_$wl -o t -- python3 $R/bench.py --workload $wl --steps 3 --warmup 1 --quick --schedule sequential > $OUT/bench_${wl}_bf16_under_rocprof.json 2>/dev/null
   python3 $R/tools/rocpd_stats.py /tmp/prof_$wl/t_results.db --by-grid --top 0 --csv $OUT/${wl}_bf16_kernel_stats.csv 2> $OUT/${wl}_bf16_kernel_stats.txt
   for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_${wl}_$ctr -o p -- python3 $R/bench.py --workload $wl --steps 1 --warmup 1 --quick > /dev/null 2>&1
+    rocprofv3 --pmc $ctr --kernel-trace -d /tmp/pmc_${wl}_$ctr -o p -- python3 $R/bench.py --workload $wl --steps 1 --warmup 1 --quick --schedule sequential > /dev/null 2>&1
     python3 $R/tools/rocpd_stats.py /tmp/pmc_${wl}_$ctr/p_results.db --pmc --top 0 --csv $OUT/pmc_${wl}_$ctr.csv
   done
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d /tmp/pmc_${wl}_mfma -o p -- python3 $R/bench.py --workload $wl --steps 1 --warmup 1 --quick > /dev/null 2>&1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace -d /tmp/pmc_${wl}_mfma -o p -- python3 $R/bench.py --workload $wl --steps 1 --warmup 1 --quick --schedule sequential > /dev/null 2>&1
   python3 $R/tools/rocpd_stats.py /tmp/pmc_${wl}_mfma/p_results.db --pmc --top 0 --csv $OUT/pmc_${wl}_mfma.csv
 done
 # SQ-level PMC (wait / issue / LDS / MFMA counters) of the stand-alone probes: classifier (both kernels), stage-3 bottleneck tail, the round-4
@@ -33,9 +33,9 @@ python3 $R/bench.py --workload score-c3 --steps 3 > $OUT/bench_score_c3.json 2> 
 # round 5: the fp32 paths under rocprofv3 (exact fp32, and option f32_split = the split-operand matrix-core path), their timing,
 # the shard regime as one rank of 8 would see it, the launch-floor probe, the exchange's cost
 for mode in 0 1; do
-  DH_F32_SPLIT=$mode rocprofv3 --kernel-trace --stats -d /tmp/prof_f32_$mode -o t -- python3 $R/bench.py --workload c2 --dtype f32 --steps 2 --warmup 1 --quick > $OUT/bench_c2_f32_split${mode}_under_rocprof.json 2>/dev/null
+  DH_F32_SPLIT=$mode rocprofv3 --kernel-trace --stats -d /tmp/prof_f32_$mode -o t -- python3 $R/bench.py --workload c2 --dtype f32 --steps 2 --warmup 1 --quick --schedule sequential > $OUT/bench_c2_f32_split${mode}_under_rocprof.json 2>/dev/null
   python3 $R/tools/rocpd_stats.py /tmp/prof_f32_$mode/t_results.db --by-grid --top 0 --csv $OUT/c2_f32_split${mode}_kernel_stats.csv 2> $OUT/c2_f32_split${mode}_kernel_stats.txt
-  DH_F32_SPLIT=$mode rocprofv3 --kernel-trace --stats -d /tmp/prof_f32c3_$mode -o t -- python3 $R/bench.py --workload c3 --dtype f32 --steps 2 --warmup 1 --quick > $OUT/bench_c3_f32_split${mode}_under_rocprof.json 2>/dev/null
+  DH_F32_SPLIT=$mode rocprofv3 --kernel-trace --stats -d /tmp/prof_f32c3_$mode -o t -- python3 $R/bench.py --workload c3 --dtype f32 --steps 2 --warmup 1 --quick --schedule sequential > $OUT/bench_c3_f32_split${mode}_under_rocprof.json 2>/dev/null
   python3 $R/tools/rocpd_stats.py /tmp/prof_f32c3_$mode/t_results.db --by-grid --top 0 --csv $OUT/c3_f32_split${mode}_kernel_stats.csv 2> $OUT/c3_f32_split${mode}_kernel_stats.txt
 done
 cd $R
