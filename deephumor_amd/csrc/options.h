@@ -11,6 +11,7 @@ enum DhOption {
     DH_OPT_DECODE_WREG_MIN_ROWS,     // ... from this many rows per position
     DH_OPT_QKV_FUSION_MAX_ROWS,      // dh_attn_self_qkv_decode instead of GEMM + attention up to this many rows per position
     DH_OPT_CROSS_QPROJ,              // fc_q inside the cross-attention launch
+    DH_OPT_DECODE_CHAIN_FUSION,      // (enc_)fc_o -> fc_1 -> fc_2 -> next fc_qkv of a decode position as ONE launch (dh_decode_gemm_chain)
     DH_OPT_LSTM_WREG,                // register-stationary LSTM step (lstm_wreg.hip)
     DH_OPT_LSTM_WREG_MIN_ROWS,       // ... from this many rows
     DH_OPT_VOCAB_SPLIT_ROWS,         // classifier of a row count that is no multiple of 256: whole 256-row tiles + remainder as two launches

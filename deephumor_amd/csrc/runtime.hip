@@ -67,10 +67,79 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
                                     const int32_t* src, int src_ld, int n_img, int rows_per_img, int row_mult, int rows_total,
                                     int t, void* x_final, void* stream) {
     const int rows = n_img * rows_per_img, D = m->D, PF = m->pf_dim, dt = m->dtype, nt = D / 64;
+    // Option "decode_chain_fusion": the GEMMs that follow each other without an attention launch in between -- (enc_)fc_o -> fc_1 ->
+    // fc_2 -> the NEXT layer's fc_q|k|v -- as ONE persistent launch with XCD-local hand-overs (csrc/linear_wreg.hip,
+    // decode_gemm_chain_kernel; bit-identical): 4 launches per layer instead of 7 (3 instead of 6 without encoder attention)
+    bool chain = dh_opt(DH_OPT_DECODE_CHAIN_FUSION) && sc->chain_sync && dh_opt(DH_OPT_DECODE_WREG) && rows > dh_opt(DH_OPT_QKV_FUSION_MAX_ROWS) &&
+                 dh_decode_gemm_chain_supported(D, D, 1) && dh_decode_gemm_chain_supported(PF, D, 0) && dh_decode_gemm_chain_supported(D, PF, 1) &&
+                 dh_decode_gemm_chain_supported(3 * D, D, 0) && nt == 8;
+    for (int l = 0; l < m->n_layers && chain; ++l) {
+        const dh_tr_layer_t& L = m->layers[l];
+        chain = L.w1_pk && L.w2_pk && L.wqkv_pk && (m->cross ? (L.weo_pk != nullptr) : (L.wo_pk != nullptr));
+    }
     for (int l = 0; l < m->n_layers; ++l) {
         const dh_tr_layer_t& L = m->layers[l];
         const dh_tr_layer_t* P = l > 0 ? &m->layers[l - 1] : nullptr;       // its LN3 is pending on X
         dh_ln_fold_t f{};
+        if (chain) {
+            // qkv of layer l > 0 came out of layer l - 1's chain launch
+            if (!P) {
+                dh_prof_set_tag("qkv");
+                DH_TRY(chain_linear(sc->x, D, L.wqkv, L.wqkv_pk, L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
+            }
+            DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
+                                       row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
+            dh_chain_step_t st[4] = {};
+            int ns = 0;
+            const void* yin; const float* st_in; const float *g_in, *b_in; float eps_in;
+            // fc_o: Y1 = LN3_prev(X) + att Wo^T + bo, statistics -> st1
+            dh_chain_step_t fo{};
+            fo.A = sc->att; fo.lda = D; fo.w_packed = L.wo_pk; fo.bias = L.bo; fo.residual = sc->x; fo.ldres = D; fo.C = sc->o; fo.ldc = D;
+            fo.N = D; fo.K = D;
+            if (P) { fo.ln.r_stats = sc->st0; fo.ln.r_tiles = nt; fo.ln.r_eps = P->ln3_eps; fo.ln.r_gamma = P->ln3_g; fo.ln.r_beta = P->ln3_b; }
+            fo.ln.o_stats = sc->st1;
+            if (m->cross) {
+                dh_prof_set_tag("proj");
+                f = fo.ln;
+                DH_TRY(chain_linear(sc->att, D, L.wo, L.wo_pk, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
+                if (dh_opt(DH_OPT_CROSS_QPROJ) && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
+                    DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
+                                                      n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
+                } else {
+                    f = dh_ln_fold_t{};
+                    f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
+                    dh_prof_set_tag("proj");
+                    DH_TRY(chain_linear(sc->o, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
+                    DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
+                }
+                // enc fc_o: Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2
+                dh_chain_step_t& e = st[ns++];
+                e.A = sc->att; e.lda = D; e.w_packed = L.weo_pk; e.bias = L.beo; e.residual = sc->o; e.ldres = D; e.C = sc->y2; e.ldc = D; e.N = D; e.K = D;
+                e.ln.r_stats = sc->st1; e.ln.r_tiles = nt; e.ln.r_eps = L.ln1_eps; e.ln.r_gamma = L.ln1_g; e.ln.r_beta = L.ln1_b; e.ln.o_stats = sc->st2;
+                yin = sc->y2; st_in = sc->st2; g_in = L.ln2_g; b_in = L.ln2_b; eps_in = L.ln2_eps;
+            } else {
+                st[ns++] = fo;
+                yin = sc->o; st_in = sc->st1; g_in = L.ln1_g; b_in = L.ln1_b; eps_in = L.ln1_eps;
+            }
+            {   // fc_1: ff = relu(LN(Yin) W1^T + b1)
+                dh_chain_step_t& e = st[ns++];
+                e.A = yin; e.lda = D; e.w_packed = L.w1_pk; e.bias = L.b1_f; e.C = sc->ff; e.ldc = PF; e.N = PF; e.K = D; e.relu = 1;
+                e.ln.a_stats = st_in; e.ln.a_tiles = nt; e.ln.a_eps = eps_in; e.ln.a_colsum = L.cs_1;
+            }
+            {   // fc_2: X = LN(Yin) + ff W2^T + b2, statistics -> st0
+                dh_chain_step_t& e = st[ns++];
+                e.A = sc->ff; e.lda = PF; e.w_packed = L.w2_pk; e.bias = L.b2; e.residual = yin; e.ldres = D; e.C = sc->x; e.ldc = D; e.N = D; e.K = PF;
+                e.ln.r_stats = st_in; e.ln.r_tiles = nt; e.ln.r_eps = eps_in; e.ln.r_gamma = g_in; e.ln.r_beta = b_in; e.ln.o_stats = sc->st0;
+            }
+            if (l + 1 < m->n_layers) {   // the next layer's qkv = LN3(X) Wqkv^T + b
+                const dh_tr_layer_t& Nx = m->layers[l + 1];
+                dh_chain_step_t& e = st[ns++];
+                e.A = sc->x; e.lda = D; e.w_packed = Nx.wqkv_pk; e.bias = Nx.bqkv_f; e.C = sc->qkv; e.ldc = 3 * D; e.N = 3 * D; e.K = D;
+                e.ln.a_stats = sc->st0; e.ln.a_tiles = nt; e.ln.a_eps = L.ln3_eps; e.ln.a_colsum = Nx.cs_qkv;
+            }
+            DH_TRY(dh_decode_gemm_chain(st, ns, rows, sc->chain_sync, dt, stream));
+            continue;
+        }
         // 1. qkv = LN3_prev(X) Wqkv^T + b  (layer 0: X is the embedding, no LayerNorm in front) and the self-attention over the
         //    row's history: ONE launch where the fused kernel applies (head dim 64, <= 6 rows per image, <= 40 positions)
         if (rows <= dh_opt(DH_OPT_QKV_FUSION_MAX_ROWS) && D == 64 * m->n_heads && rows_per_img <= 6 && t <= 39) {

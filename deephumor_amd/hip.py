@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 27
+ABI_VERSION = 28
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -38,13 +38,19 @@ class TrModel(_c.Structure):
 
 
 class TrScratch(_c.Structure):
-    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2")]
+    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2", "chain_sync")]
 
 
 class LnFold(_c.Structure):
     """``dh_ln_fold_t``: deferred-LayerNorm options of ``dh_linear_ln``."""
     _fields_ = [("a_stats", _P), ("a_tiles", _I), ("a_eps", _F), ("a_colsum", _P),
                 ("r_stats", _P), ("r_tiles", _I), ("r_eps", _F), ("r_gamma", _P), ("r_beta", _P), ("o_stats", _P)]
+
+
+class ChainStep(_c.Structure):
+    """``dh_chain_step_t``: one GEMM of ``dh_decode_gemm_chain``."""
+    _fields_ = [("A", _P), ("lda", _I), ("w_packed", _P), ("bias", _P), ("residual", _P), ("ldres", _I), ("C", _P), ("ldc", _I),
+                ("N", _I), ("K", _I), ("relu", _I), ("_pad", _I), ("ln", LnFold)]
 
 
 class LstmLayer(_c.Structure):
@@ -151,6 +157,8 @@ SIGNATURES = {
     "dh_beam_sample_k": [_P, _I, _I, _I, _I, _F, _P, _I, _U64, _P, _I, _I, _P, _P, _P],
     "dh_beam_gather": [_P, _I, _I, _P, _I, _P, _I, _P, _P],
     "dh_beam_expand": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "dh_decode_gemm_chain_supported": [_I, _I, _I],
+    "dh_decode_gemm_chain": [_c.POINTER(ChainStep), _I, _I, _P, _I, _P],
     "dh_split_f32x": [_P, _I, _P, _I, _I, _I, _P],
     "dh_linear_f32x": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv2d_nhwc_f32x": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 9 + [_P],
@@ -612,6 +620,29 @@ def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_
             residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
             _dt(a), _stream(), tag=tag)
     return (out, stats) if residual is not None else out
+
+
+def decode_gemm_chain(steps, m, sync):
+    """``dh_decode_gemm_chain``: up to four dependent ``linear_ln_wreg`` GEMMs as ONE launch.  ``steps``: dicts with ``a``, ``w_packed``,
+    ``n``, ``bias``, ``out`` and optionally ``residual``, ``relu``, ``a_ln`` (stats, eps, colsum), ``r_ln`` (stats, eps, gamma, beta),
+    ``o_stats`` (required with ``residual``); ``sync``: int32 tensor of >= 74 zeros, private to the stream."""
+    arr = (ChainStep * len(steps))()
+    for c, st in zip(arr, steps):
+        a, out = st["a"], st["out"]
+        _dev(a, st["w_packed"], st["bias"], out, st.get("residual"))
+        c.A, c.lda, c.w_packed, c.bias, c.C, c.ldc = _ptr(a), a.stride(0), _ptr(st["w_packed"]), _ptr(st["bias"]), _ptr(out), out.stride(0)
+        c.N, c.K, c.relu = int(st["n"]), a.shape[1], int(bool(st.get("relu")))
+        res = st.get("residual")
+        if res is not None:
+            c.residual, c.ldres = _ptr(res), res.stride(0)
+            c.ln.o_stats = _ptr(st["o_stats"])
+        if st.get("a_ln") is not None:
+            stats, eps, colsum = st["a_ln"]
+            c.ln.a_stats, c.ln.a_tiles, c.ln.a_eps, c.ln.a_colsum = _ptr(stats), a.shape[1] // 64, float(eps), _ptr(colsum)
+        if st.get("r_ln") is not None:
+            stats, eps, gamma, beta = st["r_ln"]
+            c.ln.r_stats, c.ln.r_tiles, c.ln.r_eps, c.ln.r_gamma, c.ln.r_beta = _ptr(stats), int(st["n"]) // 64, float(eps), _ptr(gamma), _ptr(beta)
+    _launch("dh_decode_gemm_chain", arr, len(steps), int(m), _ptr(sync), _dt(steps[0]["a"]), _stream())
 
 
 def attn_cross_pack(kv, n_img, s, d, n_heads, dperm=False):

@@ -323,6 +323,9 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     bufs["y2"] = e(rows, self.d)
                     for k in ("st0", "st1", "st2"):
                         bufs[k] = torch.empty((rows, self.d // 64, 2), device=self.dev, dtype=torch.float32)
+                    # counters of the one-launch GEMM chain (dh_decode_gemm_chain): zero once, the kernel leaves them zero; private to
+                    # this run (= this stream)
+                    bufs["chain_sync"] = torch.zeros((80,), device=self.dev, dtype=torch.int32)
                 c = hip.TrScratch()
                 for k, v in bufs.items():
                     setattr(c, k, v.data_ptr())

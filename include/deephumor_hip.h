@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 27
+#define DH_ABI_VERSION 28
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -287,6 +287,22 @@ int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats);
 double dh_linear_ln_wreg_occupancy(int M, int N, int K, int with_residual_stats);
 int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
                       void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream);
+
+/* Up to four DEPENDENT GEMMs of one decode position in ONE launch (round 5; csrc/linear_wreg.hip, decode_gemm_chain_kernel): the
+ * deferred-LayerNorm chain of a DecoderLayer ends in (enc_)fc_o -> fc_1 -> fc_2 -> the next layer's fc_q|k|v (transformers.py:127 /
+ * :364-375 / :162-163 / :97), each reading whole rows of its predecessor.  Step i = dh_linear_ln_wreg's arguments (either form); a
+ * later step may read the C / o_stats an earlier one wrote.  The rows are cut into 8 groups, each worked on by the workgroups of ONE
+ * XCD (hardware id) so that a step's outputs are read back through the L2 they were written to: no agent-scope fence between the
+ * steps.  Bit-identical to the same steps as separate dh_linear_ln_wreg launches.  sync: 74 uint32 of device memory private to the
+ * stream, zero before the first launch that uses them (the kernel leaves words 0..72 zero); sync[73] != 0 = a bounded wait timed out.
+ * _supported: 1 when a step (N, K, residual form) is one the chain takes (K = 512; K = 2,048 with residual; N % 64 == 0). */
+typedef struct dh_chain_step {
+    const void* A; int lda; const void* w_packed; const float* bias; const void* residual; int ldres; void* C; int ldc;
+    int N, K, relu, _pad;
+    dh_ln_fold_t ln;
+} dh_chain_step_t;
+int dh_decode_gemm_chain_supported(int N, int K, int with_residual_stats);
+int dh_decode_gemm_chain(const dh_chain_step_t* steps, int n_steps, int M, uint32_t* sync, int dtype, void* stream);
 
 /* Vocabulary projection feeding beam search (bf16 operands): logits [M,V] fp32 = A*W^T + bias, and
  * group_max[m, g] = max(logits[m, 64g .. 64g+63]) for g < 2*ceil(V/128) (row stride gm_ld) -- the pre-filter
@@ -603,6 +619,8 @@ typedef struct dh_tr_scratch {
     void *x, *qkv, *att, *o, *q, *ff;       /* [rows, D|3D|D|D|D|PF] */
     void* y2;                               /* [rows, D]      second pre-LayerNorm row buffer of the deferred chain (or NULL) */
     float *st0, *st1, *st2;                 /* [rows, D/64, 2] partial LayerNorm statistics of x / o / y2 (or NULL) */
+    uint32_t* chain_sync;                   /* optional: 74 zeroed uint32 private to the stream -- the layer's trailing GEMMs then run as ONE
+                                               launch (dh_decode_gemm_chain; option "decode_chain_fusion") */
 } dh_tr_scratch_t;
 
 /* Hidden state of position t for n_img*rows_per_img compact rows; x_out (optional, [rows,D]) receives the

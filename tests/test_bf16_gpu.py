@@ -803,6 +803,83 @@ def test_decode_chain_wreg_equals_tile_chain(kind):
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
 
 
+@pytest.mark.parametrize("m,cross", [(37, True), (380, True), (1280, True), (81, False), (640, False), (3000, True)])
+def test_decode_gemm_chain_equals_separate_launches(hip, m, cross):
+    """dh_decode_gemm_chain ((enc_)fc_o -> fc_1 -> fc_2 -> next qkv as ONE persistent launch, rows owned by XCDs, XCD-local hand-overs)
+    against the same four GEMMs as separate dh_linear_ln_wreg launches: every output and every statistics array bit for bit, three
+    launches in a row on the same counters (they must come back to zero), the error word clear.  ``cross = False`` is the
+    SelfAttentionDecoderLayer chain, where fc_2 re-writes the rows fc_o read (the phase behind it takes the L1-invalidate path)."""
+    d, pf = 512, 2048
+    g = torch.Generator().manual_seed(m + int(cross))
+    r = lambda *shape, sc=1.0: bf(torch.randn(*shape, generator=g) * sc).cuda()
+    f32 = lambda *shape, sc=1.0: (torch.randn(*shape, generator=g) * sc).cuda()
+    att, x_in = r(m, d), r(m, d)
+    w_o, w_1, w_2, w_q = r(d, d, sc=d ** -0.5), r(pf, d, sc=d ** -0.5), r(d, pf, sc=pf ** -0.5), r(3 * d, d, sc=d ** -0.5)
+    b_o, b_1, b_2, b_q = f32(d, sc=0.1), f32(pf, sc=0.1), f32(d, sc=0.1), f32(3 * d, sc=0.1)
+    cs_1, cs_q = w_1.float().sum(1).contiguous(), w_q.float().sum(1).contiguous()
+    gam = [(torch.rand(d, generator=g) + 0.5).cuda() for _ in range(2)]
+    bet = [f32(d, sc=0.2) for _ in range(2)]
+    t = x_in.float().view(m, -1, 64)
+    mean = t.mean(-1)
+    st_in = torch.stack([mean, ((t - mean[..., None]) ** 2).sum(-1)], -1).contiguous()
+    pk = {k: hip.pack_mfma_fragments(v) for k, v in (("o", w_o), ("1", w_1), ("2", w_2), ("q", w_q))}
+
+    def run(fused, x):
+        """x: the residual stream (pre-LayerNorm rows + st_x); returns every tensor the chain writes"""
+        st_x = st_in.clone()
+        o, ff, xq = torch.empty_like(x), torch.empty((m, pf), dtype=HALF, device="cuda"), torch.empty((m, 3 * d), dtype=HALF, device="cuda")
+        st_o = torch.empty((m, 8, 2), device="cuda")
+        xout, st_out = (torch.empty_like(x), torch.empty((m, 8, 2), device="cuda")) if cross else (x, st_x)   # no encoder attention: fc_2 re-writes x / st_x
+        steps = [dict(a=att, w_packed=pk["o"], n=d, bias=b_o, out=o, residual=x, r_ln=(st_x, 1e-5, gam[0], bet[0]), o_stats=st_o),
+                 dict(a=o, w_packed=pk["1"], n=pf, bias=b_1, out=ff, relu=True, a_ln=(st_o, 1e-5, cs_1)),
+                 dict(a=ff, w_packed=pk["2"], n=d, bias=b_2, out=xout, residual=o, r_ln=(st_o, 1e-5, gam[1], bet[1]), o_stats=st_out),
+                 dict(a=xout, w_packed=pk["q"], n=3 * d, bias=b_q, out=xq, a_ln=(st_out, 1e-5, cs_q))]
+        if fused:
+            sync = torch.zeros(80, dtype=torch.int32, device="cuda")
+            outs = []
+            for rep in range(3):
+                if not cross:
+                    x.copy_(x_in); st_x.copy_(st_in)
+                hip.decode_gemm_chain(steps, m, sync)
+                outs.append([v.clone() for v in (o, st_o, ff, xout, st_out, xq)])
+                assert int(sync[:73].abs().sum()) == 0 and int(sync[73]) == 0
+            for other in outs[1:]:
+                assert all(torch.equal(a, b) for a, b in zip(outs[0], other))
+            return outs[0]
+        for s_ in steps:
+            if s_.get("residual") is not None:
+                _, stats = hip.linear_ln_wreg(s_["a"], s_["w_packed"], s_["n"], s_["bias"], out=s_["out"], residual=s_["residual"], r_ln=s_["r_ln"])
+                s_["o_stats"].copy_(stats)
+            else:
+                hip.linear_ln_wreg(s_["a"], s_["w_packed"], s_["n"], s_["bias"], out=s_["out"], relu=bool(s_.get("relu")), a_ln=s_["a_ln"])
+        return [v.clone() for v in (o, st_o, ff, xout, st_out, xq)]
+    want = run(False, x_in.clone())
+    got = run(True, x_in.clone())
+    for name, a, b in zip(("o", "st_o", "ff", "x", "st_x", "qkv"), want, got):
+        assert torch.equal(a, b), name
+
+
+@pytest.mark.parametrize("kind", ["CaptioningTransformer", "CaptioningTransformerBase"])
+def test_decode_chain_fusion_equals_separate_launches(kind):
+    """Option decode_chain_fusion: the layer's trailing GEMMs + the next layer's qkv as one launch per layer -- same tokens, same lengths
+    as the chain of separate launches, at 3, 38 (x beam 10: the C5 shard's 380 rows) and 130 images, twice."""
+    import deephumor_amd.models as M
+    from deephumor_amd import hip as H
+    from deephumor_amd.synth import synth_state_dict
+    model = getattr(M, kind)(1000, hid_dim=512, n_layers=3).eval()
+    model.load_state_dict(synth_state_dict(model.state_dict(), seed=77))
+    model = model.to(HALF).cuda()
+    for n, beam in ((3, 5), (38, 10), (130, 5)):
+        imgs = synth_images(n, seed=21).cuda()
+        kw = dict(max_len=9, beam_size=beam, top_k=20, seed=3)
+        with torch.no_grad():
+            t1, l1 = model.generate_batch(imgs, **kw)
+            with H.option_scope(decode_chain_fusion=1):
+                for _ in range(2):
+                    t2, l2 = model.generate_batch(imgs, **kw)
+                    assert torch.equal(t1, t2) and torch.equal(l1, l2), (kind, n)
+
+
 def test_decode_chain_unfused_qproj_equals_fused():
     """Option cross_qproj = 0 (fc_q as its own register-stationary GEMM in front of the packed cross-attention, K still packed in the
     fused launch's head-dim slot order) against the fused launch: same tokens, same lengths, bit for bit -- so the two can be selected by
