@@ -138,7 +138,8 @@ const OptDef g_opt_defs[DH_OPT_COUNT] = {
     {"decode_wreg", "DH_DECODE_WREG", 1, false},
     {"decode_wreg_min_rows", "DH_DECODE_WREG_MIN_ROWS", 1, false},
     {"qkv_fusion_max_rows", "DH_QKV_FUSION_MAX_ROWS", 0, false},
-    {"cross_qproj", "DH_CROSS_QPROJ", 1, false},
+    {"cross_qproj", "DH_CROSS_QPROJ", 0, false},
+    {"cross_kv_prefetch", "DH_CROSS_KV_PREFETCH", 0, false},
     {"decode_chain_fusion", "DH_DECODE_CHAIN_FUSION", 0, false},
     {"lstm_wreg", "DH_LSTM_WREG", 1, false},
     {"lstm_wreg_min_rows", "DH_LSTM_WREG_MIN_ROWS", 256, false},

@@ -31,6 +31,8 @@ struct LwParams {
     const float2* a_stats; int a_nt; float a_eps; const float* a_colsum;
     const float2* r_stats; int r_nt; float r_eps; const float* r_gamma; const float* r_beta;
     float2* o_stats;
+    // L2 prefetch for the NEXT launch of the stream (dh_linear_ln_wreg_prefetch): workgroups n_work .. gridDim.x - 1 only do this
+    const unsigned char* pf_base[2]; unsigned pf_stride, pf_bytes[2]; int pf_groups, pf_tpg, pf_tiles, pf_part, pf_parts, n_work;
 };
 
 // global -> LDS, 16 bytes per lane: wave-uniform base (SGPR pair) + per-lane byte offset
@@ -238,10 +240,38 @@ __device__ __forceinline__ void lw_item(const LwParams& p, const int cb, const i
     }
 }
 
+// Prefetch workgroups (blockIdx >= n_work; dh_linear_ln_wreg_prefetch): pull the operands the NEXT kernel of the stream will read
+// into the L2 of the XCD that kernel's workgroups will run on, while this (latency-bound, 5 us, a few MB of traffic) GEMM runs.  The
+// operands are two arrays of tiles (stride pf_stride, pf_bytes[a] used bytes per tile); the consumer's workgroup g reads tiles
+// g * pf_tpg .. + pf_tpg - 1 and runs on XCD g % 8 (workgroups go round-robin over the XCDs), as prefetch workgroup j does on XCD
+// (n_work + j) % 8 = j % 8.  Read-only lines survive a kernel boundary in L2 (tools/probe/launch_floor_probe.hip).  The loads are
+// LDS-DMA transfers into a scratch kilobyte per wave: no registers, nothing waits for them but the end of the wave.  A wrong placement
+// guess costs time only -- nothing reads what lands in LDS.
+template <int NT>
+__device__ __forceinline__ void lw_prefetch(const LwParams& p, unsigned char* lds) {
+    const int j = (int)blockIdx.x - p.n_work, n_pf = (int)gridDim.x - p.n_work;
+    const int xcd = j & 7, slot = j >> 3, per_xcd = max(1, n_pf >> 3);
+    const int tid = threadIdx.x;
+    unsigned char* dst = lds + (tid >> 6) * 1024;
+    // (part k of n: this launch takes every n-th of an XCD's groups -- the tiles can be spread over several launches in front of the consumer)
+    for (int g = xcd + 8 * (p.pf_part + p.pf_parts * slot); g < p.pf_groups; g += 8 * p.pf_parts * per_xcd) {
+        for (int t = g * p.pf_tpg; t < min((g + 1) * p.pf_tpg, p.pf_tiles); ++t) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const unsigned char* src = p.pf_base[a] + (size_t)t * p.pf_stride;
+                const unsigned bytes = p.pf_bytes[a];
+                for (unsigned off = 0; off < bytes; off += NT * 16u)         // (uniform bounds; lanes past the end repeat the last chunk)
+                    dh_lds_dma16(src + min(off + (unsigned)tid * 16u, bytes - 16u), dst);
+            }
+        }
+    }
+}
+
 template <typename OT, int NW, int RL, int KQ, int LNX>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void linear_wreg_kernel(LwParams p) {
     constexpr int NSLAB = 8 * KQ, SLABB = RL * 128;
     __shared__ __attribute__((aligned(16))) unsigned char lds[NSLAB * SLABB];
+    if (NW == 4 && KQ == 1 && p.pf_groups && (int)blockIdx.x >= p.n_work) { lw_prefetch<64 * NW>(p, lds); return; }
     int cb, rb;
     if (p.xn) {                                        // XCD x = blockIdx % 8 owns column group x % xn, row group x / xn
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -430,7 +460,21 @@ extern "C" double dh_linear_ln_wreg_occupancy(int M, int N, int K, int with_resi
 //   * residual (+ optional ln->r_stats) AND ln->o_stats.
 extern "C" int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
                                  void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream) {
+    return dh_linear_ln_wreg_prefetch(A, lda, w_packed, bias, residual, ldres, C, ldc, M, N, K, relu, ln, nullptr, 0, dtype, stream);
+}
+
+// dh_linear_ln_wreg + `n_pf` extra workgroups that pull `pf`'s tiles (the operands of the NEXT kernel on the stream) into L2 while the
+// GEMM runs -- only in the 4-wave K = 512 forms (64-column x 40-row blocks: the residual form, and without residual N % 128 != 0 or
+// <= 256 blocks -- fc_o and the cross-attention's fc_q); other forms ignore `pf`.  Same results as dh_linear_ln_wreg (the extra workgroups write nothing).
+extern "C" int dh_linear_ln_wreg_prefetch(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
+                                          void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln,
+                                          const dh_l2_prefetch_t* pf, int n_pf, int dtype, void* stream) {
     if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
+    DH_REQUIRE(!pf || n_pf <= 0 || (pf->base[0] && pf->base[1] && pf->n_tiles > 0 && pf->tiles_per_group > 0 && pf->tile_bytes[0] >= 16 &&
+                                    pf->tile_bytes[1] >= 16 && (pf->tile_bytes[0] % 16) == 0 && (pf->tile_bytes[1] % 16) == 0 &&
+                                    pf->tile_bytes[0] <= pf->tile_stride && pf->tile_bytes[1] <= pf->tile_stride && (pf->tile_stride % 16) == 0 &&
+                                    pf->parts >= 1 && pf->part >= 0 && pf->part < pf->parts &&
+                                    ((uintptr_t)pf->base[0] % 16) == 0 && ((uintptr_t)pf->base[1] % 16) == 0 && n_pf <= 4096));
     DH_REQUIRE(A && w_packed && bias && C && ln && M > 0 && N > 0 && (lda % 8) == 0 && lda >= K && ldc >= N && (ldc % 8) == 0);
     DH_REQUIRE(((uintptr_t)A % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)bias % 16) == 0);
     DH_REQUIRE((unsigned long long)M * (unsigned)lda * 2ull < (1ull << 32));
@@ -453,13 +497,21 @@ extern "C" int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, c
     dh_prof_set_dims(M, N, K);
     DhProfScope prof("dh_linear", 2.0 * M * N * K, 2.0 * ((double)M * K + (double)N * K + (double)M * N * (residual ? 2 : 1)), stream);
     hipStream_t s = (hipStream_t)stream;
+    auto with_prefetch = [&]() -> int {                  // extra workgroups of a 4-wave K = 512 launch
+        p.n_work = p.tiles_m * p.tiles_n;
+        if (!pf || n_pf <= 0 || (p.n_work % 8) != 0) return 0;       // (a grid that is no multiple of 8 would shift the prefetchers' XCDs)
+        p.pf_base[0] = (const unsigned char*)pf->base[0]; p.pf_base[1] = (const unsigned char*)pf->base[1];
+        p.pf_stride = pf->tile_stride; p.pf_bytes[0] = pf->tile_bytes[0]; p.pf_bytes[1] = pf->tile_bytes[1];
+        p.pf_tiles = pf->n_tiles; p.pf_tpg = pf->tiles_per_group; p.pf_groups = dh_cdiv(pf->n_tiles, pf->tiles_per_group);
+        p.pf_part = pf->part; p.pf_parts = pf->parts;
+        return (n_pf + 7) / 8 * 8;
+    };
     if (lnx) {
         p.tiles_n = N / 64; p.tiles_m = dh_cdiv(M, 40);
         p.xn = pick_xn(p.tiles_m, p.tiles_n, 64.0 * K * 2, 40.0 * K * 2);
-        const dim3 grid(p.tiles_m * p.tiles_n);
         DH_DISPATCH_16(dtype, {
-            if (K == 512) hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 1, 1>), grid, dim3(256), 0, s, p);
-            else hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 4, 1>), grid, dim3(256), 0, s, p);
+            if (K == 512) hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 1, 1>), dim3(p.tiles_m * p.tiles_n + with_prefetch()), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 4, 1>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p);
         });
         DH_LAUNCH_CHECK();
     }
@@ -467,7 +519,7 @@ extern "C" int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, c
         // narrow outputs (the cross-attention query projection, N = D = 512): 64-column x 40-row blocks, 4 waves, as the residual form
         p.tiles_n = N / 64; p.tiles_m = dh_cdiv(M, 40);
         p.xn = pick_xn(p.tiles_m, p.tiles_n, 64.0 * K * 2, 40.0 * K * 2);
-        DH_DISPATCH_16(dtype, hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 1, 0>), dim3(p.tiles_m * p.tiles_n), dim3(256), 0, s, p));
+        DH_DISPATCH_16(dtype, hipLaunchKernelGGL((linear_wreg_kernel<T, 4, 40, 1, 0>), dim3(p.tiles_m * p.tiles_n + with_prefetch()), dim3(256), 0, s, p));
         DH_LAUNCH_CHECK();
     }
     p.tiles_n = N / 128;

@@ -10,7 +10,8 @@ enum DhOption {
     DH_OPT_DECODE_WREG,              // register-stationary decode-chain GEMMs (linear_wreg.hip)
     DH_OPT_DECODE_WREG_MIN_ROWS,     // ... from this many rows per position
     DH_OPT_QKV_FUSION_MAX_ROWS,      // dh_attn_self_qkv_decode instead of GEMM + attention up to this many rows per position
-    DH_OPT_CROSS_QPROJ,              // fc_q inside the cross-attention launch
+    DH_OPT_CROSS_QPROJ,              // 1: fc_q inside the cross-attention launch (dh_attn_cross_qproj_decode); 0 (default): its own GEMM
+    DH_OPT_CROSS_KV_PREFETCH,        // fc_q as its own GEMM: this many extra workgroups of it pull the attention's K / V tiles into L2 (0 = none)
     DH_OPT_DECODE_CHAIN_FUSION,      // (enc_)fc_o -> fc_1 -> fc_2 -> next fc_qkv of a decode position as ONE launch (dh_decode_gemm_chain)
     DH_OPT_LSTM_WREG,                // register-stationary LSTM step (lstm_wreg.hip)
     DH_OPT_LSTM_WREG_MIN_ROWS,       // ... from this many rows

@@ -50,6 +50,41 @@ static int chain_linear(const void* A, int lda, const void* W, const void* W_pk,
     return dh_linear_ln(A, lda, W, K, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
 }
 
+// fc_q of the encoder attention as its own GEMM (option "cross_qproj" = 0).  With option "cross_kv_prefetch" = n > 0 and packed K / V,
+// the launches in front of the attention carry n extra workgroups each that pull the (image, head) tiles it will read into the L2 of the
+// XCD its workgroups run on (attn_cross_mfma_kernel: workgroup g = 4 consecutive (image, head) tiles; K rows >= S are never read):
+// fc_o of the self-attention takes part 0 of 2, fc_q part 1 of 2 -- 15 MB each at 256 images, under two latency-bound 5 us GEMMs.
+static bool cross_prefetch(const dh_tr_model_t* m, const dh_tr_layer_t& L, int rows, int n_img, int rows_per_img, int dt, int part,
+                           dh_l2_prefetch_t* pf) {
+    const int D = m->D;
+    if (dh_opt(DH_OPT_CROSS_KV_PREFETCH) <= 0 || dh_opt(DH_OPT_CROSS_QPROJ) || !m->cross) return false;
+    if (!(L.kp && L.vt && DH_IS_16BIT(dt) && m->S <= 64 && D == 64 * m->n_heads && D == 512 && rows_per_img <= 16)) return false;
+    if (!(dh_opt(DH_OPT_DECODE_WREG) && L.wq_pk && L.wo_pk && rows >= dh_opt(DH_OPT_DECODE_WREG_MIN_ROWS))) return false;
+    *pf = dh_l2_prefetch_t{};
+    pf->base[0] = L.kp; pf->base[1] = L.vt; pf->tile_stride = 8192; pf->tile_bytes[0] = (uint32_t)m->S * 128u; pf->tile_bytes[1] = 8192;
+    pf->n_tiles = n_img * m->n_heads; pf->tiles_per_group = 4; pf->part = part; pf->parts = 2;
+    return true;
+}
+
+static int cross_query(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* y, void* q, int rows, int n_img, int rows_per_img,
+                       const dh_ln_fold_t* f, int dt, void* stream) {
+    const int D = m->D;
+    dh_l2_prefetch_t pf;
+    if (cross_prefetch(m, L, rows, n_img, rows_per_img, dt, 1, &pf) && dh_linear_ln_wreg_occupancy(rows, D, D, 0) >= 0.85)
+        return dh_linear_ln_wreg_prefetch(y, D, L.wq_pk, L.bq_f, nullptr, 0, q, D, rows, D, D, 0, f, &pf, dh_opt(DH_OPT_CROSS_KV_PREFETCH), dt, stream);
+    return chain_linear(y, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, q, D, rows, D, D, 0, f, dt, stream);
+}
+
+// fc_o of the self-attention in front of it (residual form): carries the other half of the prefetch
+static int self_out(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* att, const void* x, void* o, int rows, int n_img,
+                    int rows_per_img, const dh_ln_fold_t* f, int dt, void* stream) {
+    const int D = m->D;
+    dh_l2_prefetch_t pf;
+    if (cross_prefetch(m, L, rows, n_img, rows_per_img, dt, 0, &pf) && f->o_stats && dh_linear_ln_wreg_occupancy(rows, D, D, 1) >= 0.85)
+        return dh_linear_ln_wreg_prefetch(att, D, L.wo_pk, L.bo, x, D, o, D, rows, D, D, 0, f, &pf, dh_opt(DH_OPT_CROSS_KV_PREFETCH), dt, stream);
+    return chain_linear(att, D, L.wo, L.wo_pk, L.bo, x, D, o, D, rows, D, D, 0, f, dt, stream);
+}
+
 // One dense layer of the plain (non-deferred) chains: fp32 models with split planes (option "f32_split") run it as three fp16
 // MFMAs on split operands (gemm_f32x.hip), everything else through dh_linear.
 static int plain_linear(const void* A, int lda, const void* W, const void* W_x, int ldw, const float* bias, void* C, int ldc, int rows, int N,
@@ -101,7 +136,7 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
             if (m->cross) {
                 dh_prof_set_tag("proj");
                 f = fo.ln;
-                DH_TRY(chain_linear(sc->att, D, L.wo, L.wo_pk, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
+                DH_TRY(self_out(m, L, sc->att, sc->x, sc->o, rows, n_img, rows_per_img, &f, dt, stream));
                 if (dh_opt(DH_OPT_CROSS_QPROJ) && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
                     DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
                                                       n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
@@ -109,7 +144,7 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
                     f = dh_ln_fold_t{};
                     f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
                     dh_prof_set_tag("proj");
-                    DH_TRY(chain_linear(sc->o, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
+                    DH_TRY(cross_query(m, L, sc->o, sc->q, rows, n_img, rows_per_img, &f, dt, stream));
                     DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
                 }
                 // enc fc_o: Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2
@@ -159,7 +194,7 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
         if (P) { f.r_stats = sc->st0; f.r_tiles = nt; f.r_eps = P->ln3_eps; f.r_gamma = P->ln3_g; f.r_beta = P->ln3_b; }
         f.o_stats = sc->st1;
         dh_prof_set_tag("proj");
-        DH_TRY(chain_linear(sc->att, D, L.wo, L.wo_pk, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
+        DH_TRY(self_out(m, L, sc->att, sc->x, sc->o, rows, n_img, rows_per_img, &f, dt, stream));
         const void* yin = sc->o; const float* st_in = sc->st1;               // rows entering the FFN block, LayerNorm pending
         const float *g_in = L.ln1_g, *b_in = L.ln1_b; float eps_in = L.ln1_eps;
         if (m->cross) {
@@ -172,7 +207,7 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
                 f = dh_ln_fold_t{};
                 f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
                 dh_prof_set_tag("proj");
-                DH_TRY(chain_linear(sc->o, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
+                DH_TRY(cross_query(m, L, sc->o, sc->q, rows, n_img, rows_per_img, &f, dt, stream));
                 DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
             }
             // 4. Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2

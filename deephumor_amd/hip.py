@@ -12,7 +12,7 @@ import torch
 from . import _build
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 28
+ABI_VERSION = 29
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
 MAX_BEAMS = 64
@@ -45,6 +45,12 @@ class LnFold(_c.Structure):
     """``dh_ln_fold_t``: deferred-LayerNorm options of ``dh_linear_ln``."""
     _fields_ = [("a_stats", _P), ("a_tiles", _I), ("a_eps", _F), ("a_colsum", _P),
                 ("r_stats", _P), ("r_tiles", _I), ("r_eps", _F), ("r_gamma", _P), ("r_beta", _P), ("o_stats", _P)]
+
+
+class L2Prefetch(_c.Structure):
+    """``dh_l2_prefetch_t``: the next kernel's operand tiles, for ``dh_linear_ln_wreg_prefetch``."""
+    _fields_ = [("base0", _P), ("base1", _P), ("tile_stride", _c.c_uint32), ("tile_bytes0", _c.c_uint32), ("tile_bytes1", _c.c_uint32),
+                ("n_tiles", _I), ("tiles_per_group", _I), ("part", _I), ("parts", _I)]
 
 
 class ChainStep(_c.Structure):
@@ -104,6 +110,7 @@ SIGNATURES = {
     "dh_linear_ln": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
     "dh_linear_ln_wreg_supported": [_I, _I, _I],
     "dh_linear_ln_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
+    "dh_linear_ln_wreg_prefetch": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _P, _I, _I, _P],
     "dh_attn_cross_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dh_attn_cross_qproj_decode": [_P, _I, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
     "dh_attn_cross_decode_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
@@ -598,10 +605,11 @@ def linear_ln_wreg_supported(n, k, with_residual_stats):
     return bool(load().dh_linear_ln_wreg_supported(int(n), int(k), int(bool(with_residual_stats))))
 
 
-def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_ln=None, r_ln=None, tag=None):
+def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_ln=None, r_ln=None, tag=None, prefetch=None):
     """``dh_linear_ln_wreg``: ``linear_ln`` on ``w_packed = pack_mfma_fragments(w [n, k])`` -- the register-stationary decode
     GEMM (bit-identical results).  With ``residual`` the partial statistics of the output rows are always produced and
-    returned: ``(out, stats)``."""
+    returned: ``(out, stats)``.  ``prefetch = (t0, t1, tile_stride, bytes0, bytes1, n_tiles, tiles_per_group, n_pf[, part, parts])``:
+    ``dh_linear_ln_wreg_prefetch`` -- ``n_pf`` extra workgroups pull those tiles (the next kernel's operands) into L2."""
     _dev(a, w_packed, bias, out, residual)
     m, k = a.shape
     assert a.dtype in HALF_DTYPES and a.dtype == w_packed.dtype and a.stride(1) == 1 and w_packed.numel() == n * k
@@ -616,6 +624,15 @@ def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_
         f.r_stats, f.r_tiles, f.r_eps, f.r_gamma, f.r_beta = _ptr(st), n // 64, float(eps), _ptr(gamma), _ptr(beta)
     stats = torch.empty((m, n // 64, 2), dtype=torch.float32, device=a.device) if residual is not None else None
     f.o_stats = _ptr(stats)
+    if prefetch is not None:
+        t0, t1, stride, b0, b1, n_tiles, tpg, n_pf = prefetch[:8]
+        part, parts = prefetch[8:] if len(prefetch) > 8 else (0, 1)
+        _dev(t0, t1)
+        pf = L2Prefetch(_ptr(t0), _ptr(t1), int(stride), int(b0), int(b1), int(n_tiles), int(tpg), int(part), int(parts))
+        _launch("dh_linear_ln_wreg_prefetch", _ptr(a), a.stride(0), _ptr(w_packed), _ptr(bias), _ptr(residual),
+                residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
+                _c.byref(pf), int(n_pf), _dt(a), _stream(), tag=tag)
+        return (out, stats) if residual is not None else out
     _launch("dh_linear_ln_wreg", _ptr(a), a.stride(0), _ptr(w_packed), _ptr(bias), _ptr(residual),
             residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
             _dt(a), _stream(), tag=tag)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 28
+#define DH_ABI_VERSION 29
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -287,6 +287,19 @@ int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats);
 double dh_linear_ln_wreg_occupancy(int M, int N, int K, int with_residual_stats);
 int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
                       void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream);
+/* dh_linear_ln_wreg whose launch carries n_pf (rounded up to 8) extra workgroups that pull the operands of the NEXT kernel on the stream
+ * into L2 while the (latency-bound) GEMM computes: two arrays of tiles (tile_stride bytes apart, tile_bytes[a] used bytes of each tile, all
+ * multiples of 16); the consumer's workgroup g reads tiles g * tiles_per_group .. and runs on XCD g % 8, which is where the prefetch
+ * workgroups for group g run.  Used for fc_q (transformers.py:97 inside :364) in front of dh_attn_cross_decode_packed: Kp / Vt of the
+ * (image, head) pairs.  Only the 4-wave K = 512 forms (64-column x 40-row blocks) carry them (others ignore pf); results as dh_linear_ln_wreg. */
+typedef struct dh_l2_prefetch {
+    const void* base[2]; uint32_t tile_stride; uint32_t tile_bytes[2]; int n_tiles; int tiles_per_group;
+    int part, parts;                 /* this launch takes part `part` of `parts` (every parts-th of an XCD's groups): several launches in
+                                      * front of the consumer can share the transfer */
+} dh_l2_prefetch_t;
+int dh_linear_ln_wreg_prefetch(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
+                               void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, const dh_l2_prefetch_t* pf, int n_pf,
+                               int dtype, void* stream);
 
 /* Up to four DEPENDENT GEMMs of one decode position in ONE launch (round 5; csrc/linear_wreg.hip, decode_gemm_chain_kernel): the
  * deferred-LayerNorm chain of a DecoderLayer ends in (enc_)fc_o -> fc_1 -> fc_2 -> the next layer's fc_q|k|v (transformers.py:127 /

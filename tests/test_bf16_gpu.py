@@ -881,9 +881,9 @@ def test_decode_chain_fusion_equals_separate_launches(kind):
 
 
 def test_decode_chain_unfused_qproj_equals_fused():
-    """Option cross_qproj = 0 (fc_q as its own register-stationary GEMM in front of the packed cross-attention, K still packed in the
-    fused launch's head-dim slot order) against the fused launch: same tokens, same lengths, bit for bit -- so the two can be selected by
-    row count without touching shard invariance."""
+    """Option cross_qproj: 0 (default since round 5: fc_q as its own register-stationary GEMM in front of the packed cross-attention, K
+    packed in the fused launch's head-dim slot order) against 1 (fc_q inside the attention launch, dh_attn_cross_qproj_decode): same
+    tokens, same lengths, bit for bit -- the choice does not touch shard invariance."""
     import deephumor_amd.models as M
     from deephumor_amd import hip as H
     from deephumor_amd.synth import synth_state_dict
@@ -893,10 +893,45 @@ def test_decode_chain_unfused_qproj_equals_fused():
     for n in (7, 64):
         imgs = synth_images(n, seed=13).cuda()
         with torch.no_grad():
-            t1, l1 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
+            with H.option_scope(cross_qproj=1):
+                t1, l1 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
             with H.option_scope(cross_qproj=0):
                 t2, l2 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
         assert torch.equal(t1, t2) and torch.equal(l1, l2), n
+        # ... and with the K / V prefetch workgroups riding on the fc_q launch (dh_linear_ln_wreg_prefetch): they write nothing
+        with torch.no_grad(), H.option_scope(cross_qproj=0, cross_kv_prefetch=256):
+            t3, l3 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
+        assert torch.equal(t1, t3) and torch.equal(l1, l3), n
+
+
+@pytest.mark.parametrize("m,n_pf", [(40, 8), (200, 100), (1280, 256), (1280, 1024)])
+def test_linear_wreg_prefetch_workgroups_change_nothing(m, n_pf):
+    """dh_linear_ln_wreg_prefetch: the GEMM's outputs with prefetch workgroups in the launch equal the plain launch bit for bit, the
+    prefetched arrays are untouched (tile sizes as the packed cross-attention operands: 49 x 128 used bytes of 8 KB K tiles)."""
+    from deephumor_amd import hip as H
+    g = torch.Generator().manual_seed(m)
+    a = (torch.randn(m, 512, generator=g)).to(HALF).cuda()
+    w = (torch.randn(512, 512, generator=g) / 22.6).to(HALF).cuda()
+    bias = torch.randn(512, generator=g).cuda()
+    st = torch.stack([torch.randn(m, 8, generator=g) * 0.1, torch.rand(m, 8, generator=g) * 50 + 10], -1).contiguous().cuda()
+    cs = torch.randn(512, generator=g).cuda()
+    wp = H.pack_mfma_fragments(w)
+    n_tiles = 37 * 8
+    kp = torch.randn(n_tiles, 4096, generator=g).to(HALF).cuda()
+    vt = torch.randn(n_tiles, 4096, generator=g).to(HALF).cuda()
+    kp0, vt0 = kp.clone(), vt.clone()
+    want = H.linear_ln_wreg(a, wp, 512, bias, a_ln=(st, 1e-5, cs))
+    got = H.linear_ln_wreg(a, wp, 512, bias, a_ln=(st, 1e-5, cs), prefetch=(kp, vt, 8192, 49 * 128, 8192, n_tiles, 4, n_pf))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(kp, kp0) and torch.equal(vt, vt0)
+    # the residual form (fc_o) carrying part 0 of 2
+    res = torch.randn(m, 512, generator=g).to(HALF).cuda()
+    gamma, beta = torch.randn(512, generator=g).cuda(), torch.randn(512, generator=g).cuda()
+    want, wst = H.linear_ln_wreg(a, wp, 512, bias, residual=res, r_ln=(st, 1e-5, gamma, beta))
+    got, gst = H.linear_ln_wreg(a, wp, 512, bias, residual=res, r_ln=(st, 1e-5, gamma, beta),
+                                prefetch=(kp, vt, 8192, 49 * 128, 8192, n_tiles, 4, n_pf, 0, 2))
+    torch.cuda.synchronize()
+    assert torch.equal(got, want) and torch.equal(gst, wst) and torch.equal(kp, kp0) and torch.equal(vt, vt0)
 
 
 @pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])

@@ -22,10 +22,10 @@ KEYS = [
     ("c3", "dh_linear[vocab]{1280x36541x512}", "vocab_areg256_kernel", 256, "same kernel, same shape (256 images x 5 beams)"),
     ("c3", "dh_attn_self_decode", "attn_decode_reg_kernel", 2048,
      "launch-weighted mean over the history depths of one sweep (2..22 keys per row)"),
-    ("c3", "dh_attn_cross_decode", "attn_cross_qproj_kernel", 256,
-     "fused fc_q + cross-attention launch: includes the 8 x 64 KB fc_q weight slices every workgroup stages"),
+    ("c3", "dh_attn_cross_decode", "attn_cross_mfma_kernel", 512,
+     "the packed cross-attention launch (option cross_qproj 0, the default since round 5: fc_q is its own GEMM in front of it)"),
     ("c3", "dh_attn_cross_decode[qproj+attn]", "attn_cross_qproj_kernel", 256,
-     "the same launch under its full profiler key (C3's dominant launch key since round 4)"),
+     "the fused fc_q + cross-attention launch (option cross_qproj 1): includes the 8 x 64 KB fc_q weight slices every workgroup stages"),
     ("c3", "dh_linear[ffn]{1280x512x2048}", "linear_wreg_kernelIDF16bLi4ELi1ELi40ELi4ELi1E", 256,
      "fc_2 of the feed-forward layer on the register-stationary kernel (64 columns x 40 rows per workgroup, K = 2,048)"),
     ("c3", "dh_linear[ffn]{1280x2048x512}", "linear_wreg_kernelIDF16bLi8ELi1ELi80ELi1ELi0E", 256,
