@@ -478,6 +478,10 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             if m:
                 res[name] = attach_traffic(price(entry, m, dtype), workload, dtype)
                 res[name]["measured"] = "instrumented pass (events around every launch; rocprofv3 kernel-only times are ~2 us lower)"
+                if name == "roofline_cross_attention":
+                    from deephumor_amd import hip as _hip
+                    res[name]["launch"] = ("fc_q + attention in one launch (option cross_qproj 1)" if _hip.option("cross_qproj") else
+                                           "the attention launch alone; fc_q is its own GEMM in front of it (option cross_qproj 0, default since round 5)")
         sa, ca = res.get("roofline_self_attention"), res.get("roofline_cross_attention")
         if sa and ca:
             tot_b = sa["algorithmic_bytes_per_launch"] * sa["launches"] + ca["algorithmic_bytes_per_launch"] * ca["launches"]
