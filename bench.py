@@ -470,6 +470,11 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
     if seq is not None and dominant in summary:
         res["roofline"]["measured"] += (" of the SEQUENTIAL timed pass of this run (value_sequential): the kernel alone on the chip; the pipelined "
                                         "region overlaps it with the next batch's encoder")
+    if workload in ("c3", "c5"):
+        res["roofline"]["note"] = ("the Transformer step is ~53 dependent launches per position; its largest launch KEY is a 5 - 6 us decode GEMM "
+                                   "at the dependent-launch floor (DESIGN section 12), so this fraction prices launch latency, not bandwidth -- the "
+                                   "kernels north_star names are priced in roofline_self_attention / roofline_cross_attention / "
+                                   "roofline_decoder_attention_combined")
     res["per_rank_ms_per_step"] = {"min": min(RANK_TIMES) / steps * 1e3, "max": max(RANK_TIMES) / steps * 1e3, "ranks": len(RANK_TIMES)}
     res["encoder_layers"] = encoder_table(breakdown, dtype)
     if workload in ("c3", "c5"):
