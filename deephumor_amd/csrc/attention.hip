@@ -1051,6 +1051,10 @@ __global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restri
                 const float c = r == 0 ? cs4[j].x : r == 1 ? cs4[j].y : r == 2 ? cs4[j].z : cs4[j].w;
                 const float b = r == 0 ? b4[j].x : r == 1 ? b4[j].y : r == 2 ? b4[j].z : b4[j].w;
                 qv[z] = fmaf(rstd, fmaf(-mu, c, qacc[j][r]), b);
+                // keep the fp32 rounding of q: with -ffp-contract the compiler may otherwise turn (f16)fma(...) into v_fma_mix*_f16, which
+                // rounds the exact product-sum ONCE to fp16 -- the GEMM route (dh_linear_ln: fp32 value through LDS, then converted)
+                // rounds twice, and the two differ at near-ties (1 q element in ~15,000, fp16 only)
+                asm volatile("" : "+v"(qv[z]));
             }
             w[u] = (uint32_t)Op16<T>::from_f32(qv[0]) | ((uint32_t)Op16<T>::from_f32(qv[1]) << 16);
         }

@@ -644,7 +644,7 @@ def test_direct_stem_convolution(hip, n, h, w):
     np.testing.assert_allclose(got.float().cpu().numpy(), old.float().cpu().numpy(), atol=4e-2 if HALF == torch.bfloat16 else 6e-3, rtol=2e-2)
 
 
-@pytest.mark.parametrize("n_img,beam", [(3, 5), (8, 16), (11, 1), (17, 10)])
+@pytest.mark.parametrize("n_img,beam", [(3, 5), (8, 16), (11, 1), (17, 10), (256, 5)])
 def test_cross_attention_with_fused_query_projection(hip, n_img, beam):
     """dh_attn_cross_qproj_decode (fc_q on the deferred-LayerNorm rows + attention, one launch, K head-dim slots permuted)
     against the two-launch route (dh_linear_ln A-fold -> dh_attn_cross_decode_packed) and against fp32 math."""
@@ -672,6 +672,13 @@ def test_cross_attention_with_fused_query_projection(hip, n_img, beam):
     two = torch.empty_like(out)
     hip.attn_cross_decode_packed(q2, kp0, vt0, mask.cuda(), two, n_img, beam, s, d, h, 8.0)
     np.testing.assert_allclose(out.float().cpu().numpy(), two.float().cpu().numpy(), atol=3e-2, rtol=2e-2)
+    # ... and BIT FOR BIT against the two-launch route on the same (head-dim permuted) K tiles, through either GEMM kernel: the fused
+    # launch keeps the fp32 rounding of q (round 5: the compiler had turned its (f16)fma(...) into v_fma_mixlo_f16, one rounding
+    # instead of two -- 1 q element in ~15,000 differed in fp16, found by tools/fuzz_variants.py's option sweep)
+    for q_route in (q2, hip.linear_ln_wreg(y.cuda(), hip.pack_mfma_fragments(wf.cuda()), d, bfold.cuda(), a_ln=(stats.cuda(), 1e-5, colsum.cuda()))):
+        same = torch.empty_like(out)
+        hip.attn_cross_decode_packed(q_route, kp1, vt, mask.cuda(), same, n_img, beam, s, d, h, 8.0, dperm=True)
+        assert torch.equal(out, same)
     q32 = F.linear(F.layer_norm(y.float(), (d,), gamma, beta, 1e-5), wq.float(), bq)
     for row in range(0, r, max(1, r // 7)):
         i = row // beam

@@ -1,7 +1,9 @@
 """Randomised equivalence sweep of the ways one batch can be decoded on the GPU box: ``generate_batch`` against the same call with
 ``streams`` = 2 / 3 (image sub-batches on concurrent HIP streams), ``early_stop_every`` (host-polled early exit), the captured-hipGraph
-replay (``generate_batch_graphed``, replayed with other images and seeds after capture), a 2-way split with ``img0``, and a
-``save`` / ``from_pretrained`` round trip of the model -- all five model classes, fp32 / bf16 / fp16, random batch sizes, decode
+replay (``generate_batch_graphed``, replayed with other images and seeds after capture), a 2-way split with ``img0``, a random
+combination of the run-time options that select between bit-identical kernels (``hip.option_scope``: fused / unfused cross-attention
+query projection, the K / V prefetch workgroups, the one-launch GEMM chain, tile instead of register-stationary GEMMs, the fused beam
+step, the fused QKV + self-attention launch, both classifiers), and a ``save`` / ``from_pretrained`` round trip of the model -- all five model classes, fp32 / bf16 / fp16, random batch sizes, decode
 settings, prefixes, EOS made likely so that images finish at different steps.  Everything must be bit-equal.  TEST INFRASTRUCTURE.
 
     python tools/fuzz_variants.py --trials 60 > gpurun_out/fuzz_var.jsonl
@@ -19,7 +21,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 import deephumor_amd.models as M                          # noqa: E402
+from deephumor_amd import hip                             # noqa: E402
 from deephumor_amd.synth import load_synthetic, synth_images           # noqa: E402
+
+# options whose every value must give the same tokens (each selects between kernels that are bit-identical by construction)
+OPTION_CHOICES = {"cross_qproj": (0, 1), "cross_kv_prefetch": (0, 64), "decode_chain_fusion": (0, 1), "decode_wreg_min_rows": (1, 100000),
+                  "vocab_wreg_transformer": (0, 1), "fused_beam_step": (0, 1), "qkv_fusion_max_rows": (0, 100000), "lstm_wreg_min_rows": (1, 256),
+                  "vocab_wreg": (0, 1)}
 
 KINDS = ("CaptioningLSTM", "CaptioningLSTMWithLabels", "CaptioningTransformerBase", "CaptioningTransformer", "CaptioningTransformerWithLabels")
 
@@ -68,6 +76,19 @@ def main(argv=None):
                     a = model.generate_batch(images[:h], *(e[:h] for e in extra), seed=seed, img0=0, **k1)
                     b = model.generate_batch(images[h:], *(e[h:] for e in extra), seed=seed, img0=h, **k2)
                     rec["split"] = same((torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])))
+                if dt != torch.float32:
+                    opts = {k: rng.choice(v) for k, v in OPTION_CHOICES.items() if rng.random() < 0.6}
+                    rec["options_set"] = opts
+                    with hip.option_scope(**opts):
+                        rec["options"] = same(model.generate_batch(images, *extra, seed=seed, **kw))
+                    if not rec["options"]:                   # which of them alone changes the tokens
+                        rec["options_culprits"] = {}
+                        for k, val in opts.items():
+                            with hip.option_scope(**{k: val}):
+                                rec["options_culprits"][k] = not same(model.generate_batch(images, *extra, seed=seed, **kw))
+                        with hip.option_scope(**{k: (1 - val if val in (0, 1) else val) for k, val in opts.items() if k in ("cross_qproj", "vocab_wreg")}):
+                            rec["options_flipped_same"] = same(model.generate_batch(images, *extra, seed=seed, **kw))
+                        rec["base_repeat_same"] = same(model.generate_batch(images, *extra, seed=seed, **kw))
                 if t % 3 == 0:
                     g0 = model.generate_batch_graphed(images, *extra, seed=seed, **kw)               # capture
                     other = synth_images(n, seed=t + 1000).cuda()
@@ -81,7 +102,7 @@ def main(argv=None):
                         model.save(path)
                         again = type(model).from_pretrained(path).cuda().to(dt).eval()
                     rec["reload"] = same(again.generate_batch(images, *extra, seed=seed, **kw))
-            ok = all(x for k, x in rec.items() if k in ("streams", "early_stop", "split", "graph", "reload"))
+            ok = all(x for k, x in rec.items() if k in ("streams", "early_stop", "split", "options", "graph", "reload"))
         except Exception as e:
             rec["error"], ok = f"{type(e).__name__}: {e}"[:300], False
         rec["ok"] = bool(ok)
