@@ -27,7 +27,13 @@ from deephumor_amd.synth import load_synthetic, synth_images           # noqa: E
 # options whose every value must give the same tokens (each selects between kernels that are bit-identical by construction)
 OPTION_CHOICES = {"cross_qproj": (0, 1), "cross_kv_prefetch": (0, 64), "decode_chain_fusion": (0, 1), "decode_wreg_min_rows": (1, 100000),
                   "vocab_wreg_transformer": (0, 1), "fused_beam_step": (0, 1), "qkv_fusion_max_rows": (0, 100000), "lstm_wreg_min_rows": (1, 256),
-                  "vocab_wreg": (0, 1)}
+                  "vocab_wreg": (0, 1),
+                  # kernel selection in the encoder / decoder plans (each replacement is bit-identical to the kernel it replaces; NOT in the list:
+                  # direct_stem -- the direct stem sums its 147 products in another order than the implicit GEMM, close but not bit-equal --
+                  # deferred_ln, packed_cross, qproj_fusion (other arithmetic by design) and f32_split)
+                  "conv1x1_wreg": (0, 1), "conv_s4": (0, 1), "direct_3x3": (0, 1), "stem_pool": (0, 1), "fused_tail": (0, 1),
+                  "s1_conv1_fusion": (0, 1), "s2_conv1_fusion": (0, 1), "s3_tail": (0, 1), "s2_tail": (0, 1), "vocab_wreg_plan": (0, 1),
+                  "decode_wreg_plan": (0, 1)}
 
 KINDS = ("CaptioningLSTM", "CaptioningLSTMWithLabels", "CaptioningTransformerBase", "CaptioningTransformer", "CaptioningTransformerWithLabels")
 
@@ -77,7 +83,7 @@ def main(argv=None):
                     b = model.generate_batch(images[h:], *(e[h:] for e in extra), seed=seed, img0=h, **k2)
                     rec["split"] = same((torch.cat([a[0], b[0]]), torch.cat([a[1], b[1]])))
                 if dt != torch.float32:
-                    opts = {k: rng.choice(v) for k, v in OPTION_CHOICES.items() if rng.random() < 0.6}
+                    opts = {k: rng.choice(v) for k, v in OPTION_CHOICES.items() if rng.random() < 0.5}
                     rec["options_set"] = opts
                     with hip.option_scope(**opts):
                         rec["options"] = same(model.generate_batch(images, *extra, seed=seed, **kw))
