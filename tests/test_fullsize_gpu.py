@@ -170,6 +170,19 @@ def test_c5_shape_fp16_beam10_300_templates():
         ta, la = model.generate_batch(imgs[:150], labels[:150], img0=0, **kw)
         tb, lb = model.generate_batch(imgs[150:], labels[150:], img0=150, **kw)
     assert tuple(t1.shape) == (300, 32) and int(t1.max()) < V and not bool((t1 == 1).any()) and int(l1.min()) >= 1
+    # the bit-identical kernel options at THIS shape (3,000 rows per position: the classifier's row split, three-round GEMMs) and at the
+    # 38-template shard of an 8-rank run (380 rows: the register-streamed classifier, one-round GEMMs)
+    from deephumor_amd import hip as H
+    short = dict(kw, max_len=10)
+    for n in (300, 38):
+        with torch.no_grad():
+            base = model.generate_batch(imgs[:n], labels[:n], **short)
+            for opts in (dict(cross_qproj=1), dict(cross_kv_prefetch=256), dict(decode_chain_fusion=1), dict(decode_wreg_min_rows=100000),
+                         dict(vocab_split_rows=0), dict(vocab_wreg_transformer_max_rows=0), dict(fused_beam_step=1),
+                         dict(cross_qproj=1, decode_chain_fusion=1, fused_beam_step=1, vocab_split_rows=0)):
+                with H.option_scope(**opts):
+                    got = model.generate_batch(imgs[:n], labels[:n], **short)
+                assert torch.equal(got[0], base[0]) and torch.equal(got[1], base[1]), (n, opts)
     assert torch.equal(torch.cat([ta, tb]), t1) and torch.equal(torch.cat([la, lb]), l1)
 
 
