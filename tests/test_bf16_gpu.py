@@ -1119,3 +1119,23 @@ def test_encoder_round4_kernels_equal_the_kernels_they_replace(n):
             emb1, sp1 = enc(x)
     assert torch.equal(emb, emb0) and torch.equal(sp, sp0)
     assert torch.equal(emb, emb1) and torch.equal(sp, sp1)
+
+
+@pytest.mark.parametrize("n", [385, 520])
+def test_encoder_batches_above_the_chunk_limit_equal_their_parts(n):
+    """ImageEncoder on more than TRUNK_MAX_IMAGES = 384 images runs the trunk in chunks of 256 (encoders.py: the 16-bit kernels are
+    tuned for <= 256 images per launch): embeddings and spatial features equal those of the same images encoded as two separate
+    batches cut at another place, bit for bit -- an image's arithmetic does not depend on its batch."""
+    import deephumor_amd.models as M
+    from deephumor_amd.synth import synth_state_dict
+    enc = M.ImageEncoder(256, spatial_features=True).eval()
+    enc.load_state_dict(synth_state_dict(enc.state_dict(), seed=4242))
+    enc = enc.cuda().to(HALF)
+    x = synth_images(n, seed=5).cuda()
+    cut = 200
+    with torch.no_grad():
+        emb, sp = enc(x)
+        ea, sa = enc(x[:cut])
+        eb, sb = enc(x[cut:])
+    assert tuple(emb.shape)[0] == n
+    assert torch.equal(emb, torch.cat([ea, eb])) and torch.equal(sp, torch.cat([sa, sb]))
