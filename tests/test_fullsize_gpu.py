@@ -214,3 +214,18 @@ def test_fp32_full_batch_sampled_beam_rows_equal_the_reference(kind):
     with torch.no_grad():
         one = model.generate(imgs[255:256].cuda(), rng="torch", **kw)
     assert one.reshape(-1).cpu().tolist() == g["beam_255"].tolist()
+
+
+@pytest.mark.parametrize("kind,dtype,beam,n", [("CaptioningTransformer", torch.bfloat16, 5, 1024), ("CaptioningLSTM", torch.float16, 5, 2048)])
+def test_one_batch_of_thousands_of_images_equals_its_256_image_shards(kind, dtype, beam, n):
+    """C4's global batch (and half of it) as ONE generate_batch call on one GPU -- 5,120 / 10,240 rows per position: the encoder in
+    chunks of 256, the classifier in several launches, multi-round decode GEMMs -- against the same images as 256-image shards with
+    ``img0``: same tokens, same lengths (what an 8-rank run produces)."""
+    from deephumor_amd.synth import synth_images
+    model, _ = _model(kind, dtype)
+    imgs = synth_images(n, seed=4).cuda()
+    kw = dict(max_len=8, beam_size=beam, top_k=50, temperature=1.0, seed=3)
+    with torch.no_grad():
+        big = model.generate_batch(imgs, **kw)
+        parts = [model.generate_batch(imgs[i:i + 256], img0=i, **kw) for i in range(0, n, 256)]
+    assert torch.equal(big[0], torch.cat([p[0] for p in parts])) and torch.equal(big[1], torch.cat([p[1] for p in parts]))
