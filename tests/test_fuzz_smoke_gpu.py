@@ -1,7 +1,8 @@
 """One fixed seed of every randomised sweep of tools/ (``tools/fuzz_all.sh`` runs them at ~20x these trial counts; the summary
 lines of a full run are committed under profiles/r4/fuzz_summary.txt) inside ``-m gpu``: a regression in any swept entry point --
 generate / forward against the CPU oracle on random model shapes, the samplers, the scorer, the GEMM / convolution / encoder
-kernels against fp32 references, the BeamSearchHelper method surface, the pipeline, the kernel variants -- turns the driver's
+kernels against fp32 references, the BeamSearchHelper method surface, the pipeline, the kernel variants and option combinations,
+the poisoned-allocator check (no kernel reads memory it did not write) -- turns the driver's
 run red.  Each tool prints one JSON record per trial and a last summary line; the bar is zero failing trials."""
 import importlib
 import json
@@ -17,7 +18,7 @@ SEED = 11
 
 SWEEPS = [("fuzz_generate", 12, ["--half"]), ("fuzz_generate", 2, ["--long"]), ("fuzz_generate", 8, ["--r4", "--half"]), ("fuzz_generate", 10, ["--split"]), ("fuzz_forward", 12, []), ("fuzz_forward", 2, ["--big"]),
           ("fuzz_encoder", 4, []), ("fuzz_beam_methods", 15, []), ("fuzz_sampler", 25, []), ("fuzz_scoring", 15, []),
-          ("fuzz_gemm", 15, []), ("fuzz_f32x", 24, []), ("fuzz_conv", 8, []), ("fuzz_pipeline", 6, []), ("fuzz_variants", 6, [])]
+          ("fuzz_gemm", 15, []), ("fuzz_f32x", 24, []), ("fuzz_conv", 8, []), ("fuzz_pipeline", 6, []), ("fuzz_variants", 6, []), ("poison_check", 4, [])]
 
 
 @pytest.mark.parametrize("tool,trials,extra", SWEEPS, ids=[t + "".join(e) for t, _, e in SWEEPS])

@@ -30,3 +30,4 @@ run fuzz_conv 150
 run fuzz_f32x 300
 run fuzz_pipeline 120
 run fuzz_variants 120
+run poison_check 40
