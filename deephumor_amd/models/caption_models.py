@@ -101,7 +101,10 @@ class _CaptioningBase(nn.Module):
                 run()                                     # builds the weight plans, grows the allocator
             cur.wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(graph):
+            # thread_local: HIP calls of OTHER threads must not invalidate the capture -- with a process group alive, c10d's watchdog thread
+            # polls hipEventQuery every few hundred ms, and in the default (global) mode one such call inside the capture window fails
+            # the capture ("operation not permitted when stream is capturing": 1 run in 25 of `bench.py --rccl-single`, round 5)
+            with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 out = run()
             sig = self._plan_signature()                  # (the warm-up built the plans)
             plans = [m._get_plan() for m in self.modules() if isinstance(m, _Planned)]     # outlive the graph

@@ -63,6 +63,55 @@ def test_bench_rccl_single_line():
     assert line["per_rank_ms_per_step"]["ranks"] == 1 and line["per_rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"])
 
 
+GRAPH_CHILD = r"""
+import datetime, json, os, socket, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+with socket.socket() as _s:
+    _s.bind(("127.0.0.1", 0))
+    _port = _s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(_port))
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=120))
+from deephumor_amd.dist import gather_captions_async
+from deephumor_amd.models import CaptioningTransformer
+from deephumor_amd.synth import load_synthetic, synth_images
+# (a 6-layer Transformer at 30 positions: ~1,600 launches per capture = a capture window of tens of ms; the watchdog polls every 100 ms)
+model = load_synthetic(CaptioningTransformer(300), seed=7).to(dev).eval()
+images = synth_images(3, seed=0).to(dev)
+kw = dict(max_len=30, beam_size=3, top_k=20)
+ok, captures = True, 0
+with torch.no_grad():
+    want = model.generate_batch(images, seed=11, **kw)
+    for it in range(40):
+        # works the watchdog thread keeps polling (hipEventQuery) while the next capture runs
+        pend = [gather_captions_async(want[0], want[1], 3, always=True) for _ in range(3)]
+        model.__dict__.pop("_graphs", None)                       # a fresh capture every iteration
+        got = model.generate_batch_graphed(images, seed=11, **kw)
+        captures += 1
+        ok = ok and bool(torch.equal(got[0], want[0]) and torch.equal(got[1], want[1]))
+        for h in pend:
+            t, l = h.wait()
+            ok = ok and bool(torch.equal(t, want[0]))
+print("RESULT " + json.dumps({"ok": ok, "captures": captures}))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_hipgraph_capture_next_to_the_rccl_watchdog():
+    """Capturing a decode graph while c10d's watchdog thread polls pending RCCL works: in HIP's default (global) capture mode one
+    ``hipEventQuery`` of that thread inside the capture window fails the capture and aborts the process ("operation not permitted when
+    stream is capturing"; ``bench.py --rccl-single`` died in 1 run of 25, a bare capture loop next to pending works within a few
+    iterations).  ``generate_batch_graphed`` captures in thread-local mode: 40 captures of ~1,600 launches each with works pending, all equal to eager
+    (with the default mode this test aborts)."""
+    p = subprocess.run([sys.executable, "-c", GRAPH_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res == {"ok": True, "captures": 40}
+
+
 C4_CHILD = r"""
 import datetime, json, os, socket, sys
 sys.path.insert(0, %(root)r)
