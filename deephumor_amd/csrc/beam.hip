@@ -81,8 +81,14 @@ template <int NT>
 __device__ __attribute__((noinline)) void row_overflow(const float* __restrict__ row, int V, uint32_t thr, int rc, int ldl, int rows_per_img, int beam,
                              float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
                              const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
-                             float* __restrict__ pick_val, float* sq, int* si, int* picks, bool shared_picks);
+                             float* __restrict__ pick_val, float* sq, int* si, int* picks, bool shared_picks, int32_t* __restrict__ err);
 __device__ __forceinline__ void pick_store(int32_t* pi, float* pv, size_t at, int32_t idx, float val, bool shared);
+
+// softmax over a row's survivors: max m, sum s of exp(x - m).  Finite logits give a finite m and s >= 1 (the maximum contributes exp(0));
+// a NaN among them makes s NaN, +inf makes m = +inf and s NaN, only-NaN survivors leave m = -inf: the reference's torch.multinomial raises
+// on such a row ("probability tensor contains either `inf`, `nan` or element < 0", beam.py:46) -- the samplers flag DH_BEAM_ERR_NONFINITE
+// and hand on a finite dummy pick, so that nothing downstream indexes with garbage
+__device__ __forceinline__ bool dh_softmax_nonfinite(float m, float s) { return !(s >= 1.0f) || !(fabsf(m) < INFINITY); }
 
 __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     const float* __restrict__ logits, int ldl, int V, int rows_per_img, int beam, int top_k,
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     int n = s_cnt;
     if (n > CAP) {                   // more ties at the threshold than the candidate buffers hold: the draw over the row itself
         row_overflow<256>(row, V, thr, rc, ldl, rows_per_img, beam, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val,
-                          qv, idx_b, picks, false);
+                          qv, idx_b, picks, false, err);
         return;
     }
     if (n == 0) {
@@ -153,6 +159,11 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     float s = 0.f;
     for (int i = tid; i < n; i += 256) { const float e = expf(val_b[i] / temperature - m); qv[i] = e; s += e; }
     s = block_reduce_256(s, red, false);
+    if (dh_softmax_nonfinite(m, s)) {                  // (block-uniform)
+        if (tid == 0) atomicOr(err, DH_BEAM_ERR_NONFINITE);
+        if (tid < beam) { pick_idx[(size_t)rc * beam + tid] = 0; pick_val[(size_t)rc * beam + tid] = 0.f; }
+        return;
+    }
     const int img = rc / rows_per_img, rin = rc % rows_per_img;
     for (int i = tid; i < n; i += 256) {
         const float nz = noise ? noise[(size_t)rc * ldl + idx_b[i]]
@@ -259,7 +270,7 @@ template <int NT>
 __device__ __attribute__((noinline)) void row_overflow(const float* __restrict__ row, int V, uint32_t thr, int rc, int ldl, int rows_per_img, int beam,
                              float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
                              const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
-                             float* __restrict__ pick_val, float* sq, int* si, int* picks, bool shared_picks) {
+                             float* __restrict__ pick_val, float* sq, int* si, int* picks, bool shared_picks, int32_t* __restrict__ err) {
     const int tid = threadIdx.x;
     // (every loop rolled: this path must not raise the register count of the kernels that call it -- at 116 VGPRs instead of 44 the
     //  group-guided sampler lost a wave of occupancy, its 1,280 workgroups no longer fitted the chip in one round: +9 us per launch)
@@ -281,6 +292,11 @@ __device__ __attribute__((noinline)) void row_overflow(const float* __restrict__
 #pragma unroll 1
     for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) sq[tid] += sq[tid + st]; __syncthreads(); }
     const float s = sq[0];
+    if (dh_softmax_nonfinite(m, s)) {                  // (block-uniform)
+        if (tid == 0) atomicOr(err, DH_BEAM_ERR_NONFINITE);
+        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f, shared_picks);
+        return;
+    }
     const int img = rc / rows_per_img, rin = rc % rows_per_img;
     const uint64_t sd = seed ^ (seed_ptr ? *seed_ptr : 0ull);
 #pragma unroll 1
@@ -396,6 +412,11 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
     s = red[0];
 #pragma unroll
     for (int w = 1; w < NWV; ++w) s += red[w];      // same order in every thread: one value for the whole block
+    if (dh_softmax_nonfinite(m, s)) {                  // (block-uniform)
+        if (tid == 0) atomicOr(err, DH_BEAM_ERR_NONFINITE);
+        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f, shared_picks);
+        return;
+    }
     const int img = rc / rows_per_img, rin = rc % rows_per_img;
     for (int i = tid; i < n; i += NT) {
         const float nz = noise ? noise[(size_t)rc * ldl + idx_a[i]]
@@ -591,6 +612,9 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
                                      : philox_exp1(p.seed ^ (p.seed_ptr ? *p.seed_ptr : 0ull), (uint32_t)(p.img0 + img), (uint32_t)p.step_index, 1u, 0u, (uint32_t)c);
             q[c] = (q[c] / s) / nz;
         }
+        // (every slot valid whatever the scores are: with a NaN among them no rank below comes out right, and the rewrite loop must
+        //  not index with what the LDS held before)
+        for (int j = lane; j < B; j += 64) keep[j] = min(j, n - 1);
         wave_lds_sync();
         for (int c = lane; c < n; c += 64) {
             const float me = q[c];
@@ -1030,7 +1054,7 @@ __global__ __launch_bounds__(64) void beam_finalize_kernel(
     }
     const float best = wave_max(qq);
     const unsigned long long bal = __ballot(qq == best && lane < beam);
-    const int ind = __ffsll((long long)bal) - 1;
+    const int ind = max(__ffsll((long long)bal) - 1, 0);          // (NaN scores: no lane equals the maximum -- never index row -1)
     int len = done[img] ? end_step[img] + len_bias_done : full_len;
     len = min(len, min(out_ld, tok_ld));
     for (int i = lane; i < out_ld; i += 64)

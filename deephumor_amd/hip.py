@@ -14,7 +14,7 @@ from . import _build
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
 ABI_VERSION = 29
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
-ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW = 1, 2, 4
+ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW, ERR_NONFINITE = 1, 2, 4, 8
 MAX_BEAMS = 64
 
 _c = ctypes

@@ -290,6 +290,9 @@ class BeamSearchHelper:
     def raise_for(code):
         if code == 0:
             return
+        if code & hip.ERR_NONFINITE:
+            # torch.multinomial's message for a probability row holding NaN (softmax over logits with a NaN or +inf among them)
+            raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0 (a row's logits hold NaN or +inf)")
         if code & hip.ERR_ALL_FILTERED:
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0 "
                                "(every logit of a row was filtered: <unk> was the only top-k token)")
@@ -386,6 +389,17 @@ def make_noise_source(rng, seed, noise_source, lo, hi, img0, state0=None):
     if noise_source is not None:
         raise ValueError('rng="torch" and noise_source are mutually exclusive')
     return TorchRngNoise(seed, hi - lo, img0 + lo, state0=state0)
+
+
+def classifier_must_be_finite(plan):
+    """A NaN or inf in the classifier's weight or bias is in every row's logits: the reference's ``torch.multinomial`` raises on the
+    first draw (beam.py:46).  The full-row samplers see such a logit (it sorts above everything) and flag ERR_NONFINITE; the
+    group-maximum pre-filter of the 16-bit paths would not (``max`` drops NaN), so generate checks the operands once per plan."""
+    ok = plan.get("_cls_finite")
+    if ok is None:
+        ok = plan["_cls_finite"] = bool(torch.isfinite(plan["cls_w"]).all()) and bool(torch.isfinite(plan["cls_b"]).all())
+    if not ok:
+        raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0 (the classifier's weight or bias holds NaN or inf)")
 
 
 def call_logits_hook(hook, pos, logits, helper):

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
+from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, classifier_must_be_finite, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
 
@@ -175,6 +175,7 @@ class LSTMDecoder(_Planned, nn.Module):
         replays ``torch.manual_seed(seed + img0 + i)``."""
         self._check_mode()
         plan = self._get_plan()
+        classifier_must_be_finite(plan)
         rng_seed = seed
         seed = 0 if rng == "torch" else resolve_seed(seed, noise_source)
         # rng="torch" with seed=None draws from torch's DEFAULT generator: its state is snapshotted once per call so that a repeated

@@ -37,8 +37,10 @@ enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weig
 enum { DH_BEAM_ERR_ALL_FILTERED = 1,   /* every logit filtered (-inf): reference raises RuntimeError, beam.py:46 */
        DH_BEAM_ERR_OVERFLOW = 2,       /* more than DH_BEAM_MAX_SURVIVORS logits at a row's top-k threshold in a pre-filtered kernel: repeat
                                           the step / batch with dh_beam_row_sample_exact (the models do) */
-       DH_BEAM_ERR_TOO_FEW = 4 };      /* informational: fewer positive-probability tokens than beams (dead beams, as torch's
+       DH_BEAM_ERR_TOO_FEW = 4,        /* informational: fewer positive-probability tokens than beams (dead beams, as torch's
                                           zero-probability picks) */
+       DH_BEAM_ERR_NONFINITE = 8 };    /* a row's top-k survivors hold NaN or +inf: softmax is NaN, the reference's torch.multinomial raises
+                                          RuntimeError (beam.py:46); the kernels hand on a finite dummy pick (token 0) */
 #define DH_BEAM_MAX_SURVIVORS 1024
 #define DH_BEAM_MAX_BEAMS 64
 

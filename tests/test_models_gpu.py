@@ -721,3 +721,53 @@ def test_constant_logits_decode_like_the_reference(dec_kind):
         a = half.generate_batch(first.cuda().to(torch.bfloat16).reshape(1, -1), seed=4, **kw)
         b = half.generate_batch(first.cuda().to(torch.bfloat16).reshape(1, -1), seed=4, **kw)
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and int(a[0].max()) < v and not bool((a[0] == 1).any())
+
+
+@pytest.mark.parametrize("what", ["nan_bias", "inf_bias", "nan_weight", "nan_hidden"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
+def test_nonfinite_logits_raise_like_the_reference(kind, dtype, what, images):
+    """A NaN or +inf among a row's logits makes the reference's ``torch.multinomial`` raise (beam.py:46: softmax of such a row is NaN).
+    Round 5 found the engine returning float bit patterns as token ids instead (NaN scores -> no lane equals the maximum -> row -1 of the
+    token buffer; uninitialised survivor slots in the candidate draw): the samplers flag the row (DH_BEAM_ERR_NONFINITE) and hand on a finite
+    dummy pick, the 16-bit paths check the classifier operands once per plan -- RuntimeError with torch's message, for greedy and beam
+    search, whether the NaN comes from the classifier, from +inf, or from the decoder's activations (every logit NaN)."""
+    model, sd, hp = build(kind)
+    with torch.no_grad():
+        if what == "nan_bias":
+            model.decoder.classifier.bias[17] = float("nan")
+        elif what == "inf_bias":
+            model.decoder.classifier.bias[17] = float("inf")
+        elif what == "nan_weight":
+            model.decoder.classifier.weight[23, 5] = float("nan")
+    if dtype != torch.float32:
+        model = model.to(dtype)
+    imgs = images.clone().cuda()
+    if what == "nan_hidden":                              # every logit of every row NaN (a NaN pixel would not do: INTEGRATION.md, the
+        with torch.no_grad():                            # encoder's ReLU is a hardware maximum, which drops NaN)
+            p0 = next(p for n, p in model.decoder.named_parameters() if n.endswith("weight_hh_l0") or n.endswith("fc_o.weight"))
+            p0.view(-1)[3] = float("nan")                 # (no ReLU between these and the classifier: the NaN reaches every logit)
+    for beam, top_k in ((1, 1), (3, 20)):
+        with torch.no_grad(), pytest.raises(RuntimeError, match="probability tensor contains"):
+            model.generate_batch(imgs, max_len=6, beam_size=beam, top_k=top_k, seed=1)
+    # ... and the engine is usable afterwards (the error word is per call; nothing indexed out of bounds)
+    clean, _, _ = build(kind)
+    if dtype != torch.float32:
+        clean = clean.to(dtype)
+    with torch.no_grad():
+        toks, lens = clean.generate_batch(images.cuda(), max_len=6, beam_size=3, top_k=20, seed=1)
+    assert int(toks.max()) < hp["num_tokens"] and int(toks.min()) >= 0
+
+
+def test_reference_raises_on_nonfinite_logits(images):
+    """The behaviour the test above mirrors, from the CPU oracle (the reference's own sequence of torch calls)."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_path as R
+    _, sd, hp = build("CaptioningLSTM")
+    sd = dict(sd)
+    sd["decoder.classifier.bias"] = sd["decoder.classifier.bias"].clone()
+    sd["decoder.classifier.bias"][17] = float("nan")
+    with pytest.raises(RuntimeError, match="probability tensor contains"):
+        R.model_generate("CaptioningLSTM", sd, hp, images[:1], max_len=4, beam_size=3, top_k=20)
