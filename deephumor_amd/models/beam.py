@@ -391,6 +391,28 @@ def make_noise_source(rng, seed, noise_source, lo, hi, img0, state0=None):
     return TorchRngNoise(seed, hi - lo, img0 + lo, state0=state0)
 
 
+def check_ids(ids, n, capturing_ok=True):
+    """``nn.Embedding``'s ``IndexError`` for ids outside ``[0, n)`` (reference: every token / label lookup).  The kernels gather rows by
+    these ids without a bounds test, so an id outside the table would read foreign memory (round 5: a GPU memory fault on a label of -3,
+    silent garbage on a token of V + 100): checked on the host, two scalars per call.  Inside a hipGraph capture nothing can be read
+    back: ``generate_batch_graphed`` checks its inputs before the replay instead."""
+    if ids is None or ids.numel() == 0:
+        return
+    if ids.is_cuda and capturing_ok and torch.cuda.is_current_stream_capturing():
+        return
+    lo, hi = torch.aminmax(ids)
+    if int(lo) < 0 or int(hi) >= n:
+        raise IndexError("index out of range in self")
+
+
+def check_lengths(lengths, steps):
+    """``pack_padded_sequence``'s errors for the teacher-forced LSTM forward (reference rnn_models.py:39)."""
+    if int(lengths.min()) <= 0:
+        raise RuntimeError("Length of all samples has to be greater than 0, but found an element in 'lengths' that is <= 0")
+    if int(lengths.max()) > steps:
+        raise RuntimeError(f"Expected sequence length to be larger than or equal to the maximum of lengths, but got sequence length {steps} and max length {int(lengths.max())}")
+
+
 def classifier_must_be_finite(plan):
     """A NaN or inf in the classifier's weight or bias is in every row's logits: the reference's ``torch.multinomial`` raises on the
     first draw (beam.py:46).  The full-row samplers see such a logit (it sorts above everything) and flag ERR_NONFINITE; the

@@ -73,6 +73,18 @@ class _CaptioningBase(nn.Module):
         if kw.get("rng") == "torch":      # host-generated noise (parity mode): nothing to replay
             return self.generate_batch(*inputs, caption=caption, seed=seed, **kw)
         seed = resolve_seed(seed)
+        # ids are looked up without bounds tests and nothing can be read back inside a capture: the caption prefix and integer inputs
+        # (labels) are range-checked here, in front of the capture / replay (beam.check_ids: nn.Embedding's IndexError)
+        from .beam import check_ids
+        dec = getattr(self, "decoder", None)
+        emb = getattr(dec, "embedding", None) or getattr(dec, "tok_embedding", None)
+        if emb is not None:
+            check_ids(caption, emb.num_embeddings, capturing_ok=False)
+        lab = getattr(getattr(self, "encoder", None), "label_encoder", None)
+        if lab is not None:
+            for t in inputs:
+                if not t.is_floating_point() and t.dtype != torch.uint8:
+                    check_ids(t, lab.embedding.num_embeddings, capturing_ok=False)
         key = (tuple((tuple(t.shape), t.dtype) for t in inputs), None if caption is None else tuple(caption.shape),
                tuple(sorted(kw.items())), next(self.parameters()).dtype)
         cache = self.__dict__.setdefault("_graphs", {})

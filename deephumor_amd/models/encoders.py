@@ -404,6 +404,8 @@ class LabelEncoder(nn.Module):
 
     def forward(self, labels, out=None):
         _require_eval(self, self.dropout.p)
+        from .beam import check_ids
+        check_ids(labels, self.embedding.num_embeddings)                               # (nn.Embedding's IndexError)
         w = self.embedding.weight.detach()
         if out is None:
             out = torch.empty((labels.shape[0], w.shape[1]), dtype=w.dtype, device=w.device)

@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, classifier_must_be_finite, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
+from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, check_ids, check_lengths, classifier_must_be_finite, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
 
@@ -145,6 +145,8 @@ class LSTMDecoder(_Planned, nn.Module):
         if lengths is None:
             lengths = torch.full((bs,), steps, dtype=torch.long)
         lengths = torch.as_tensor(lengths).cpu()
+        check_lengths(lengths, steps)                     # (pack_padded_sequence's errors)
+        check_ids(captions, self.embedding.num_embeddings)
         steps_out = int(lengths.max())
         hh = self.lstm.hidden_size
         tokens = captions.to(torch.int32).contiguous()
@@ -176,6 +178,7 @@ class LSTMDecoder(_Planned, nn.Module):
         self._check_mode()
         plan = self._get_plan()
         classifier_must_be_finite(plan)
+        check_ids(caption, self.embedding.num_embeddings)
         rng_seed = seed
         seed = 0 if rng == "torch" else resolve_seed(seed, noise_source)
         # rng="torch" with seed=None draws from torch's DEFAULT generator: its state is snapshotted once per call so that a repeated

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from .. import hip
-from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, classifier_must_be_finite, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
+from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, check_ids, classifier_must_be_finite, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
 
@@ -343,6 +343,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
         return x_out if x_out is not None else sc["x"]
 
     def _forward(self, x, enc_out, start_emb, num_positions=None, return_hidden=False):
+        check_ids(x, self.tok_embedding.num_embeddings)                               # (nn.Embedding's IndexError)
         if start_emb is None or self.pad_index == 1:
             return self._forward_modules(x, enc_out, start_emb, return_hidden=return_hidden)
         self._check_mode()
@@ -525,6 +526,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
         self._check_mode()
         plan = self._get_plan()
         classifier_must_be_finite(plan)
+        check_ids(caption, self.tok_embedding.num_embeddings)
         rng_seed = seed                   # rng="torch": the draws replay torch CPU generators (beam.TorchRngNoise)
         seed = 0 if rng == "torch" else resolve_seed(seed, noise_source)
         # rng="torch" with seed=None draws from torch's DEFAULT generator: its state is snapshotted once per call so that a repeated

@@ -771,3 +771,50 @@ def test_reference_raises_on_nonfinite_logits(images):
     sd["decoder.classifier.bias"][17] = float("nan")
     with pytest.raises(RuntimeError, match="probability tensor contains"):
         R.model_generate("CaptioningLSTM", sd, hp, images[:1], max_len=4, beam_size=3, top_k=20)
+
+
+@pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer", "CaptioningTransformerWithLabels", "CaptioningLSTMWithLabels"])
+def test_out_of_range_ids_raise_like_nn_embedding(kind, images):
+    """Token and label ids outside their table raise ``IndexError`` as the reference's ``nn.Embedding`` lookups do, a length outside the
+    padded sequence ``RuntimeError`` as ``pack_padded_sequence`` does -- BEFORE any kernel gathers with them (round 5: a label of -3 or a
+    token of 2^31 + 5 was a GPU memory fault, V + 100 silent garbage).  Good inputs still run afterwards."""
+    model, _, hp = build(kind)
+    v = hp["num_tokens"]
+    imgs = images[:3].cuda()
+    g = torch.Generator().manual_seed(3)
+    lab = (torch.randint(4, v, (3, 2), generator=g).cuda(),) if "WithLabels" in kind else ()
+    good = torch.randint(4, v, (3, 5), generator=g).cuda()
+    lengths = torch.tensor([5, 4, 2])
+    bad = []
+    for r, c, val in ((1, 2, v + 100), (0, 1, -1), (2, 0, 2 ** 31 + 5), (2, 4, v)):
+        t = good.clone()
+        t[r, c] = val
+        bad.append(t)
+    gen_kw = dict(max_len=6, beam_size=3, top_k=20, seed=1)
+    with torch.no_grad():
+        for t in bad:
+            with pytest.raises(IndexError, match="index out of range"):
+                model(imgs, t, lengths, *lab)
+            with pytest.raises(IndexError, match="index out of range"):
+                model.generate_batch(imgs, *lab, caption=t, **gen_kw)
+            with pytest.raises(IndexError, match="index out of range"):
+                model.generate_batch_graphed(imgs, *lab, caption=t, **gen_kw)
+        if lab:
+            for val in (v + 7, -3):
+                bl = lab[0].clone()
+                bl[1, 1] = val
+                with pytest.raises(IndexError, match="index out of range"):
+                    model.generate_batch(imgs, bl, **gen_kw)
+                with pytest.raises(IndexError, match="index out of range"):
+                    model.generate_batch_graphed(imgs, bl, **gen_kw)
+                with pytest.raises(IndexError, match="index out of range"):
+                    model(imgs, good, lengths, bl)
+        if "LSTM" in kind:
+            with pytest.raises(RuntimeError, match="sequence length"):
+                model(imgs, good, torch.tensor([9, 4, 2]), *lab)
+            with pytest.raises(RuntimeError, match="greater than 0"):
+                model(imgs, good, torch.tensor([5, 0, 2]), *lab)
+        out = model(imgs, good, lengths, *lab)
+        toks, _ = model.generate_batch(imgs, *lab, caption=good[:, :2], **gen_kw)
+        tg, _ = model.generate_batch_graphed(imgs, *lab, caption=good[:, :2], **gen_kw)
+    assert bool(torch.isfinite(out).all()) and int(toks.max()) < v and int(toks.min()) >= 0 and torch.equal(toks, tg)
