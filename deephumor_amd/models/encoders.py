@@ -262,6 +262,18 @@ class ImageEncoder(_Planned, nn.Module):
         plan = self._get_plan()
         nhwc = plan["bf16"]
         st = plan["stem"]
+        # what torch's conv2d would refuse (the kernels take the layout on trust: a 1- or 4-channel tensor read as 3 channels is foreign
+        # memory or garbage, not an error -- round 5 probe)
+        if images.dim() != 4:
+            raise RuntimeError(f"Expected 4D (batched) input to conv2d, but got input of size: {list(images.shape)}")
+        packed_in = nhwc and images.shape[-1] == 8 and images.dtype == plan["dtype"]      # experiments.inference.preprocess_images' layout
+        if not packed_in:
+            if images.shape[1] != 3:
+                raise RuntimeError(f"Given groups=1, weight of size [64, 3, 7, 7], expected input{list(images.shape)} to have 3 channels, "
+                                   f"but got {images.shape[1]} channels instead")
+            if images.dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                raise TypeError(f"unsupported image dtype {images.dtype}: float32 (or the model's 16-bit type) NCHW images, or the packed "
+                                "tensor of experiments.inference.preprocess_images")
         if plan["split"]:
             return self._features_split(images, plan)
         if nhwc and images.shape[0] > self.TRUNK_MAX_IMAGES:

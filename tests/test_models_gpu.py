@@ -818,3 +818,24 @@ def test_out_of_range_ids_raise_like_nn_embedding(kind, images):
         toks, _ = model.generate_batch(imgs, *lab, caption=good[:, :2], **gen_kw)
         tg, _ = model.generate_batch_graphed(imgs, *lab, caption=good[:, :2], **gen_kw)
     assert bool(torch.isfinite(out).all()) and int(toks.max()) < v and int(toks.min()) >= 0 and torch.equal(toks, tg)
+
+
+@pytest.mark.parametrize("half", [False, True], ids=["f32", "bf16"])
+def test_images_torch_conv2d_would_refuse_are_refused(half, images):
+    """A tensor that is not [N, 3, H, W] (or the packed layout of ``preprocess_images``) raises as ``conv2d`` does in the reference; round 5:
+    the 16-bit stem read a 1-channel batch as 3 channels (foreign memory) and captioned it."""
+    model, _, _ = build("CaptioningTransformer")
+    if half:
+        model = model.bfloat16()
+    x = images.cuda()
+    with torch.no_grad():
+        for bad in (x[:, :1], torch.cat([x, x[:, :1]], 1)):
+            with pytest.raises(RuntimeError, match="to have 3 channels"):
+                model.generate_batch(bad, max_len=3, beam_size=1, top_k=1)
+        with pytest.raises(RuntimeError, match="4D"):
+            model.generate_batch(x[0], max_len=3, beam_size=1, top_k=1)
+        for bad in (x.double(), (x * 40 + 128).clamp(0, 255).to(torch.uint8)):
+            with pytest.raises(TypeError, match="dtype"):
+                model.generate_batch(bad, max_len=3, beam_size=1, top_k=1)
+        toks, _ = model.generate_batch(x.permute(0, 1, 3, 2), max_len=3, beam_size=1, top_k=1)      # a non-contiguous view is fine
+    assert tuple(toks.shape) == (4, 3)
