@@ -190,8 +190,11 @@ class LSTMDecoder(_Planned, nn.Module):
             n, b = hi - lo, beam_size
             r = n * b
             dev = image_emb.device
+            # a prefix of max_len or more tokens: the reference still makes its first draw and returns prefix + 1 tokens -- it never
+            # truncates to max_len (rnn_models.py:97-101: the loop simply does not run); the token buffers are that wide then
+            eff_len = max(max_len, (0 if caption is None else caption.shape[1]) + 1)
             helper = BeamSearchHelper(temperature, beam_size, top_k, eos_index=eos_index, device=dev, n_img=n,
-                                      max_len=max_len, seed=seed, img0=img0 + lo,
+                                      max_len=eff_len, seed=seed, img0=img0 + lo,
                                       noise_source=make_noise_source(rng, rng_seed, noise_source, lo, hi, img0, rng_state0), seed_tensor=seed_tensor,
                                       exact=exact[0])
             pos = 0
@@ -226,7 +229,7 @@ class LSTMDecoder(_Planned, nn.Module):
                 if early_stop_every and (i - pos) % early_stop_every == 0 and bool(helper.done.all()):
                     break                                   # finished images are frozen by dh_beam_select: nothing left to do
             # (no decode step when the prefix fills max_len - 1: the reference then returns beam 0 -- see finalize)
-            return helper.finalize(len_bias_done=1, full_len=max_len, defer_check=defer_check, first_beam=pos + 1 >= max_len)
+            return helper.finalize(len_bias_done=1, full_len=eff_len, defer_check=defer_check, first_beam=pos + 1 >= max_len)
 
         exact = [bool(exact)]
         try:

@@ -839,3 +839,24 @@ def test_images_torch_conv2d_would_refuse_are_refused(half, images):
                 model.generate_batch(bad, max_len=3, beam_size=1, top_k=1)
         toks, _ = model.generate_batch(x.permute(0, 1, 3, 2), max_len=3, beam_size=1, top_k=1)      # a non-contiguous view is fine
     assert tuple(toks.shape) == (4, 3)
+
+
+def test_lstm_prefix_as_long_as_max_len_is_not_truncated(images):
+    """The reference's LSTM ``generate`` makes its first draw whatever the prefix length and never truncates to ``max_len``
+    (rnn_models.py:82-101): a prefix of L >= max_len tokens comes back as L + 1 tokens.  (Round 5 edge-shape sweep: the engine returned
+    max_len tokens for L == max_len and raised for L > max_len.)  Greedy ids against the CPU oracle."""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import ref_path as R
+    model, sd, hp = build("CaptioningLSTM")
+    g = torch.Generator().manual_seed(1)
+    cap = torch.randint(4, hp["num_tokens"], (1, 6), generator=g)
+    for L, max_len in ((4, 4), (5, 3), (3, 4), (6, 1)):
+        kw = dict(caption=cap[:, :L], max_len=max_len, beam_size=1, top_k=1)
+        want = R.model_generate("CaptioningLSTM", sd, hp, images[:1], **kw).reshape(-1).tolist()
+        with torch.no_grad():
+            toks, lens = model.generate_batch(images[:1].cuda(), caption=cap[:, :L].cuda(), max_len=max_len, beam_size=1, top_k=1)
+            one = model.generate(images[:1].cuda(), caption=cap[:, :L].cuda(), max_len=max_len, beam_size=1, top_k=1)
+        assert toks[0, :int(lens[0])].cpu().tolist() == want and len(want) == max(L + 1, min(max_len, L + 1)), (L, max_len, want)
+        assert one.reshape(-1).cpu().tolist() == want
