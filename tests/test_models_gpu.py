@@ -860,3 +860,36 @@ def test_lstm_prefix_as_long_as_max_len_is_not_truncated(images):
             one = model.generate(images[:1].cuda(), caption=cap[:, :L].cuda(), max_len=max_len, beam_size=1, top_k=1)
         assert toks[0, :int(lens[0])].cpu().tolist() == want and len(want) == max(L + 1, min(max_len, L + 1)), (L, max_len, want)
         assert one.reshape(-1).cpu().tolist() == want
+
+
+@pytest.mark.parametrize("kind,half", [("CaptioningLSTM", True), ("CaptioningTransformer", True), ("CaptioningTransformer", False)])
+def test_concurrent_generate_calls_from_threads(kind, half, images):
+    """One model, several host threads decoding different batches at once (each on its own HIP stream, or all on the default one):
+    every call returns what it returns alone -- plans are shared read-only, decode state, scratch and beam buffers are per call."""
+    import threading
+    from deephumor_amd.synth import synth_images as si
+    model, _, _ = build(kind)
+    if half:
+        model = model.bfloat16()
+    jobs = [(si(n, seed=j).cuda(), dict(max_len=10, beam_size=b, top_k=20, seed=100 + j)) for j, (n, b) in enumerate(((3, 3), (17, 5), (40, 1), (8, 10), (5, 3)))]
+    with torch.no_grad():
+        want = [model.generate_batch(i, **kw) for i, kw in jobs]
+    torch.cuda.synchronize()
+    for own_stream in (False, True):
+        got, errs = [None] * len(jobs), []
+
+        def work(k):
+            try:
+                s = torch.cuda.Stream() if own_stream else torch.cuda.current_stream()
+                with torch.no_grad(), torch.cuda.stream(s):
+                    got[k] = model.generate_batch(jobs[k][0], **jobs[k][1])
+                s.synchronize()
+            except Exception as e:                        # noqa: BLE001
+                errs.append(repr(e))
+        ths = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        torch.cuda.synchronize()
+        assert not errs, errs[:2]
+        for k in range(len(jobs)):
+            assert torch.equal(got[k][0], want[k][0]) and torch.equal(got[k][1], want[k][1]), (own_stream, k)
