@@ -121,3 +121,27 @@ def test_torch_cpu_stream_replica_is_bit_equal_to_torch():
     cand = src("cand", 0, (8, 9))
     for i, g in enumerate(gens):                  # 3 + 1 + 3 candidates (beam.py:72-101), the rest of the row untouched
         assert torch.equal(cand[i, :7], torch.empty(7).exponential_(1, generator=g)) and bool((cand[i, 7:] == 1).all())
+
+
+def test_id_and_length_checks_raise_like_torch():
+    """beam.check_ids / check_lengths (host logic in front of the kernels): nn.Embedding's IndexError for ids outside [0, n),
+    pack_padded_sequence's RuntimeErrors for lengths <= 0 or beyond the padded sequence; empty and None inputs pass."""
+    import pytest
+    import torch
+    from deephumor_amd.models.beam import check_ids, check_lengths
+    emb = torch.nn.Embedding(10, 4)
+    for bad in (torch.tensor([[1, 10]]), torch.tensor([[-1, 3]]), torch.tensor([[2 ** 31 + 5]])):
+        with pytest.raises(IndexError, match="index out of range"):
+            check_ids(bad, 10)
+        with pytest.raises(IndexError):                    # what the reference's lookup does with the same ids
+            emb(bad)
+    check_ids(torch.tensor([[0, 9]]), 10)
+    check_ids(torch.zeros((3, 0), dtype=torch.long), 10)
+    check_ids(None, 10)
+    x = torch.zeros(2, 5, 3)
+    for lens, pat in ((torch.tensor([5, 0]), "greater than 0"), (torch.tensor([6, 2]), "sequence length")):
+        with pytest.raises(RuntimeError, match=pat):
+            check_lengths(lens, 5)
+        with pytest.raises(RuntimeError):
+            torch.nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False)
+    check_lengths(torch.tensor([5, 1]), 5)
