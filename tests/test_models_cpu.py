@@ -142,6 +142,6 @@ def test_id_and_length_checks_raise_like_torch():
     for lens, pat in ((torch.tensor([5, 0]), "greater than 0"), (torch.tensor([6, 2]), "sequence length")):
         with pytest.raises(RuntimeError, match=pat):
             check_lengths(lens, 5)
-        with pytest.raises(RuntimeError):
-            torch.nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False)
+        with pytest.raises(RuntimeError):                  # the reference: at pack time (<= 0) or inside the LSTM call (too long)
+            torch.nn.LSTM(3, 4, batch_first=True)(torch.nn.utils.rnn.pack_padded_sequence(x, lens, batch_first=True, enforce_sorted=False))
     check_lengths(torch.tensor([5, 1]), 5)
