@@ -53,7 +53,7 @@ STREAMS = int(os.environ.get("DH_DECODE_STREAMS", "1"))      # (option "decode_s
 PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_F32_TFLOPS = 157.3  # fp32 vector == fp32 MFMA peak
 PEAK_16_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak
-PMC_ROUND = "r5"
+PMC_ROUND = next((r for r in ("r6", "r5") if os.path.exists(os.path.join(ROOT, "profiles", r, "pmc_hbm_traffic.json"))), "r6")
 PMC_FILE = os.path.join(ROOT, "profiles", PMC_ROUND, "pmc_hbm_traffic.json")
 TORCH_DTYPE = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}
 
@@ -153,6 +153,19 @@ def attach_traffic(rl, workload, dtype):
             rl["traffic"] = ent["traffic_bytes_per_launch"]
             rl["traffic_over_algorithmic"] = ent["traffic_bytes_per_launch"] / rl["algorithmic_bytes_per_launch"]
             rl["traffic_source"] = f"profiles/{PMC_ROUND}/pmc_hbm_traffic.json @ {pmc.get('commit', '?')} ({ent.get('note', '')})"
+            if ent.get("kernel_only_us"):
+                # the same kernel's average duration in the rocprofv3 kernel trace of that tree (no event pair around the launch): the
+                # event-timed `avg_launch_us` above carries ~2 us of instrumentation on a 10 us launch
+                us = ent["kernel_only_us"]
+                rl["kernel_only_us"] = us
+                rl["kernel_only_source"] = f"profiles/{PMC_ROUND}/{workload}_bf16_kernel_stats.csv (rocprofv3 --kernel-trace, {ent.get('kernel_only_launches', '?')} launches)"
+                if rl.get("bound") == "hbm":
+                    rl["frac_kernel_only"] = rl["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
+                    # HBM-side: what the chip really moved per launch (PMC) over the same time -- below the effective fraction when
+                    # sibling beams share ancestor rows in L2 (self-attention), above it when padding / re-reads are fetched
+                    rl["frac_hbm_side_kernel_only"] = ent["traffic_bytes_per_launch"] / (us * 1e-6) / 1e9 / PEAK_HBM_GBS
+                elif rl.get("bound") == "mfma":
+                    rl["frac_kernel_only"] = rl["algorithmic_flops_per_launch"] / (us * 1e-6) / 1e12 / rl["peak"]
     except (OSError, ValueError, KeyError, TypeError):
         pass
     return rl
@@ -449,13 +462,27 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=watch, stride=stride)
         else:
             dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, graph=graph)
-    res = {"value": n_total * steps / dt, "ms_per_step": dt / steps * 1e3,
+    # `value` is ONE BATCH AT A TIME (rounds 1-4's definition: a step = one pass of the hot path over one batch, nothing of the next
+    # batch under it) -- the region the roofline kernel is event-timed in; the production schedule's rate (the same K batches as one
+    # pipelined stream, round 5's `value`) is reported next to it as `pipelined` / value_pipelined
+    pipe = {"value": n_total * steps / dt, "unit": "captions/s", "ms_per_step": dt / steps * 1e3,
+            "schedule": "the K batches of the timed region as one stream of batches (CaptionPipeline): encoder of batch i + 1 on its own HIP "
+                        "stream under the decode of batch i; every step = one batch encoded + decoded + exchanged, all K complete inside the region"}
+    if seq is None:
+        seq, pipe = {"value": n_total * steps / dt, "unit": "captions/s", "ms_per_step": dt / steps * 1e3}, None
+    res = {"value": seq["value"], "ms_per_step": seq["ms_per_step"],
            "mean_caption_len": float(lens.float().mean()) if lens is not None else None}
-    res["schedule"] = ("pipelined: the K batches of the timed region as one stream of batches (CaptionPipeline), encoder of batch i + 1 on its own "
-                       "HIP stream under the decode of batch i; every step = one batch encoded + decoded + exchanged, all K complete inside "
-                       "the region" if pipelined else "sequential: one batch at a time")
-    if seq is not None:
-        res["sequential"] = seq
+    res["schedule"] = "sequential: one batch at a time" + (" (hipGraph replay)" if graph else "")
+    res["sequential"] = seq
+    if pipe is not None:
+        res["pipelined"] = pipe
+    # whole-step fraction of the dense 16-bit MFMA peak: the algorithmic flops of every launch of one step (the library attaches them to
+    # each launch; instrumented pass) over the sequential step time
+    step_flops = sum(v["flops"] for v in breakdown.values())
+    peak = PEAK_F32_TFLOPS if dtype == "f32" else PEAK_16_TFLOPS
+    res["whole_step"] = {"algorithmic_tflop": step_flops / 1e12, "launches": sum(v["calls"] for v in breakdown.values()),
+                         "achieved_tflops": step_flops / 1e12 / (seq["ms_per_step"] / 1e3), "peak_tflops": peak,
+                         "mfma_frac": step_flops / 1e12 / (seq["ms_per_step"] / 1e3) / peak}
     by_entry = {}
     for k, v in breakdown.items():
         base = re.sub(r"\{.*\}$", "", k)
@@ -467,9 +494,8 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
     res["roofline"] = attach_traffic(price(dominant, src[dominant], dtype), workload, dtype)
     res["roofline"]["measured"] = ((f"timed region, every {stride}th launch" if main_line and not graph and stride > 1 else "timed region, every launch")
                                    if dominant in summary else "instrumented pass")
-    if seq is not None and dominant in summary:
-        res["roofline"]["measured"] += (" of the SEQUENTIAL timed pass of this run (value_sequential): the kernel alone on the chip; the pipelined "
-                                        "region overlaps it with the next batch's encoder")
+    if pipe is not None and dominant in summary:
+        res["roofline"]["measured"] += " of the timed region `value` comes from (one batch at a time: the kernel alone on the chip)"
     if workload in ("c3", "c5"):
         res["roofline"]["note"] = ("the Transformer step is ~53 dependent launches per position; its largest launch KEY is a 5 - 6 us decode GEMM "
                                    "at the dependent-launch floor (DESIGN section 12), so this fraction prices launch latency, not bandwidth -- the "
@@ -484,9 +510,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                 res[name] = attach_traffic(price(entry, m, dtype), workload, dtype)
                 res[name]["measured"] = "instrumented pass (events around every launch; rocprofv3 kernel-only times are ~2 us lower)"
                 if name == "roofline_cross_attention":
-                    from deephumor_amd import hip as _hip
-                    res[name]["launch"] = ("fc_q + attention in one launch (option cross_qproj 1)" if _hip.option("cross_qproj") else
-                                           "the attention launch alone; fc_q is its own GEMM in front of it (option cross_qproj 0, default since round 5)")
+                    res[name]["launch"] = "the packed cross-attention launch alone; fc_q is its own register-stationary GEMM in front of it"
         sa, ca = res.get("roofline_self_attention"), res.get("roofline_cross_attention")
         if sa and ca:
             tot_b = sa["algorithmic_bytes_per_launch"] * sa["launches"] + ca["algorithmic_bytes_per_launch"] * ca["launches"]
@@ -566,9 +590,9 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                 else:
                     with torch.no_grad():
                         one_step(model, images, 0, n_total, seed=0)
-                        t16, _, _ = timed_steps(model, images, 0, n_local, n_total, 5, barrier, pipelined=args.schedule == "pipelined")
+                        t16, _, _ = timed_steps(model, images, 0, n_local, n_total, 5, barrier)
                     res[f"{dt}_path"] = {"value": n_total * 5 / t16, "unit": "captions/s", "ms_per_step": t16 / 5 * 1e3, "steps": 5,
-                                         "schedule": args.schedule}
+                                         "schedule": "sequential (as `value`)"}
                 del model
                 torch.cuda.empty_cache()
             del ref
@@ -685,8 +709,7 @@ def run_shard(args, dev, dtype):
                           "scaling": "strong" if wl == "c5" else "weak"}}
     if bd_full is not None:
         res["one_gpu"]["breakdown"] = bd_full
-    res["options"] = {k: v[0] for k, v in hip.options().items() if k in ("decode_wreg_min_rows", "qkv_fusion_max_rows", "fused_beam_step",
-                                                                          "fused_beam_step_max_rows", "cross_qproj", "lstm_wreg_min_rows", "decode_wreg")}
+    res["options"] = {k: v[0] for k, v in hip.options().items()}
     return res
 
 
@@ -979,12 +1002,21 @@ def main(argv=None):
         # which rate `value` is: the bench contract's (inputs already resident in HBM when the timed region starts; a PCIe-inclusive rate
         # is never `value`).  SURVEY 8(d) / BASELINE.md section 3 define the metric host images -> host ids: that one is
         # `value_host_inclusive` (pipelined, decoded uint8 images in pinned memory) with its ratio to `value` next to it
-        "value_def": "device-resident fp32 NCHW images -> token ids on the device (bench contract), K batches as one pipelined stream "
-                     "(config.schedule; one batch at a time: value_sequential); host -> host: value_host_inclusive",
+        "value_def": "device-resident fp32 NCHW images -> token ids on the device (bench contract), ONE BATCH AT A TIME (= value_sequential, the "
+                     "definition of rounds 1-4 and of the timed region the roofline kernel is measured in); the same K batches as one pipelined "
+                     "stream (round 5's `value`): value_pipelined; host -> host (SURVEY 8(d)): value_host_inclusive.  speedup_vs_cpu = value / "
+                     "cpu_baseline.value.  Top-level workload = BASELINE.json configs[1] (C2, the configuration the metric is quoted on that fits "
+                     "one GPU -- the bench contract's rule); C3, the Transformer configuration north_star's roofline target names, is the nested "
+                     "`c3` object with the same keys",
     }
     line["config"]["schedule"] = res.get("schedule")
-    if "sequential" in res:
-        line["value_sequential"] = res["sequential"]["value"]
+    line["value_sequential"] = res["sequential"]["value"]
+    if "pipelined" in res:
+        line["value_pipelined"] = res["pipelined"]["value"]
+        line["ms_per_step_pipelined"] = res["pipelined"]["ms_per_step"]
+        line["pipelined_schedule"] = res["pipelined"]["schedule"]
+    line["whole_step"] = res["whole_step"]
+    line["whole_step_mfma_frac"] = res["whole_step"]["mfma_frac"]
     for k in ("greedy_token_match_vs_cpu_ref", f"greedy_token_match_{args.dtype}_vs_cpu_ref", "precision_vs_fp32_hip", "speedup_vs_cpu", "pipelined_device_resident",
               "mean_caption_len", "fp32_parity_path", "parity_grade_path", "f16_path", "bf16_path", "host_inclusive", "hipgraph_replay", "kernel_breakdown_ms_per_step", "kernel_breakdown_note",
               "encoder_layers", "roofline_self_attention", "roofline_cross_attention", "roofline_decoder_attention_combined"):

@@ -131,51 +131,23 @@ extern "C" int dh_prof_get(int i, char* name, int cap, int* calls, double* ms, d
 
 // ---- run-time options (options.h) --------------------------------------------------------------------
 namespace {
-struct OptDef { const char* key; const char* env; int def; bool inverted; };   // inverted: a set, non-"0" environment variable means 0
-// order == enum DhOption
+struct OptDef { const char* key; const char* env; int def; };
+// order == enum DhOption; the environment variable (DH_ + the key in capitals) supplies the default
 const OptDef g_opt_defs[DH_OPT_COUNT] = {
-    {"vocab_wreg", "DH_VOCAB_WREG", 1, false},
-    {"decode_wreg", "DH_DECODE_WREG", 1, false},
-    {"decode_wreg_min_rows", "DH_DECODE_WREG_MIN_ROWS", 1, false},
-    {"qkv_fusion_max_rows", "DH_QKV_FUSION_MAX_ROWS", 0, false},
-    {"cross_qproj", "DH_CROSS_QPROJ", 0, false},
-    {"cross_kv_prefetch", "DH_CROSS_KV_PREFETCH", 0, false},
-    {"decode_chain_fusion", "DH_DECODE_CHAIN_FUSION", 0, false},
-    {"lstm_wreg", "DH_LSTM_WREG", 1, false},
-    {"lstm_wreg_min_rows", "DH_LSTM_WREG_MIN_ROWS", 256, false},
-    {"vocab_split_rows", "DH_VOCAB_SPLIT_ROWS", 1, false},
-    {"gemm64_ns", "DH_GEMM64_NS", 0, false},
-    {"vocab_tile", "DH_VOCAB_TILE", 128, false},
-    {"vocab_gmax_tile", "DH_VOCAB_GMAX_TILE", 256, false},
-    {"vocab_areg", "DH_VOCAB_AREG", 1, false},
-    {"logprob_tile", "DH_LOGPROB_TILE", 0, false},
-    {"lstm_bm", "DH_LSTM_BM", 0, false},
-    {"lstm_ns", "DH_LSTM_NS", 0, false},
-    {"vocab_wreg_nt", "DH_VOCAB_WREG_NT", 1, false},
-    {"vocab_wreg_prefetch", "DH_VOCAB_WREG_PREFETCH", 1, false},
-    {"f32_split", "DH_F32_SPLIT", 0, false},
-    {"conv1x1_wreg", "DH_NO_CONV1X1_WREG", 1, true},
-    {"conv_s4", "DH_NO_CONV_S4", 1, true},
-    {"direct_3x3", "DH_NO_DIRECT_3X3", 1, true},
-    {"direct_stem", "DH_NO_DIRECT_STEM", 1, true},
-    {"stem_pool", "DH_NO_STEM_POOL", 1, true},
-    {"fused_tail", "DH_NO_FUSED_TAIL", 1, true},
-    {"s1_conv1_fusion", "DH_NO_S1_CONV1_FUSION", 1, true},
-    {"s2_conv1_fusion", "DH_NO_S2_CONV1_FUSION", 1, true},
-    {"s3_tail", "DH_NO_S3_TAIL", 1, true},
-    {"s2_tail", "DH_NO_S2_TAIL", 1, true},
-    {"vocab_wreg_plan", "DH_NO_VOCAB_WREG", 1, true},
-    {"vocab_wreg_transformer", "DH_VOCAB_WREG_TRANSFORMER", 0, false},
-    {"vocab_wreg_transformer_max_rows", "DH_VOCAB_WREG_TRANSFORMER_MAX_ROWS", 640, false},
-    {"deferred_ln", "DH_NO_DEFERRED_LN", 1, true},
-    {"decode_wreg_plan", "DH_NO_DECODE_WREG", 1, true},
-    {"packed_cross", "DH_NO_PACKED_CROSS", 1, true},
-    {"qproj_fusion", "DH_NO_QPROJ_FUSION", 1, true},
-    {"fused_beam_step", "DH_FUSED_BEAM_STEP", 0, false},
-    {"fused_beam_step_max_rows", "DH_FUSED_BEAM_STEP_MAX_ROWS", 0, false},
-    {"pipe_prio", "DH_PIPE_PRIO", 0, false},
-    {"dist_always", "DH_DIST_ALWAYS", 0, false},
-    {"decode_streams", "DH_DECODE_STREAMS", 1, false},
+    {"vocab_wreg", "DH_VOCAB_WREG", 1},
+    {"vocab_areg", "DH_VOCAB_AREG", 1},
+    {"vocab_wreg_transformer", "DH_VOCAB_WREG_TRANSFORMER", 0},
+    {"vocab_wreg_transformer_max_rows", "DH_VOCAB_WREG_TRANSFORMER_MAX_ROWS", 640},
+    {"decode_wreg", "DH_DECODE_WREG", 1},
+    {"decode_wreg_min_rows", "DH_DECODE_WREG_MIN_ROWS", 1},
+    {"lstm_wreg", "DH_LSTM_WREG", 1},
+    {"lstm_wreg_min_rows", "DH_LSTM_WREG_MIN_ROWS", 256},
+    {"f32_split", "DH_F32_SPLIT", 0},
+    {"deferred_ln", "DH_DEFERRED_LN", 1},
+    {"packed_cross", "DH_PACKED_CROSS", 1},
+    {"encoder_generic", "DH_ENCODER_GENERIC", 0},
+    {"dist_always", "DH_DIST_ALWAYS", 0},
+    {"decode_streams", "DH_DECODE_STREAMS", 1},
 };
 int g_opt_val[DH_OPT_COUNT];
 bool g_opt_init[DH_OPT_COUNT];
@@ -183,7 +155,6 @@ bool g_opt_init[DH_OPT_COUNT];
 int opt_default(const OptDef& d) {
     const char* e = getenv(d.env);
     if (!e || !e[0]) return d.def;
-    if (d.inverted) return strcmp(e, "0") == 0 ? d.def : 0;
     return atoi(e);
 }
 int opt_find(const char* key) {

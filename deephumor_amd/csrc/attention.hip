@@ -803,7 +803,8 @@ __global__ __launch_bounds__(256) void attn_cross_pack_kernel(const T* __restric
             val = *reinterpret_cast<const uint4*>(row);
             vv = *reinterpret_cast<const uint4*>(row + D);
             if (dperm) {
-                // head-dim slots in the order a q row leaves the projection's MFMA accumulators (dh_attn_cross_qproj_decode):
+                // head-dim slots in the order a q row leaves a 16 x 16 MFMA accumulator tile (the layout of rounds 2-5's fused fc_q + attention
+                // launch, kept so that the summation order over the head dimension -- and every 16-bit token -- stays what it was):
                 // slot 32 kk + 8 lq + e holds dim 16 (2 kk + (e >> 2)) + 4 lq + (e & 3) -- two runs of 4 consecutive dims
                 const int kk = ch >> 2, lq4 = ch & 3;
                 const uint16_t* r0 = src + (size_t)(img * S + key) * (2 * D) + h * 64;
@@ -932,402 +933,6 @@ __global__ __launch_bounds__(256) void attn_cross_mfma_kernel(const T* __restric
     const uint64_t kbits = __ballot(keymask[img * S + min(lane, S - 1)] != 0);     // bit key = that key is masked (one byte per lane)
     uint16_t* orow = reinterpret_cast<uint16_t*>(out) + qrow * D + h * 64;
     cross_core<T>(kf, vf, qf, kbits, S, scale, live, orow, lq);
-}
-
-// ---- query projection + cross-attention in one launch (decode chain of the 16-bit Transformer decoder) -----------------------
-// enc_attn of a DecoderLayer (transformers.py:364 -> 97-127) for one position: q = fc_q(LN1(y)) and the attention over the
-// image's patches, without the [rows, D] q matrix ever going to memory and without a separate GEMM launch.
-// Workgroup = 8 waves = 8 images x ONE head.  The head's 64 rows of the (gamma-folded) fc_q weight -- 64 KB -- are staged once
-// per workgroup in LDS by LDS-DMA (XOR-swizzled 128-byte rows, 8 k-slabs); meanwhile every wave has already requested its own
-// image's K / V^T fragments (dh_attn_cross_pack, dperm = 1), its <= 16 pre-LayerNorm rows y as MFMA B fragments, their
-// LayerNorm statistics and the per-dim constants.  One wait + barrier, then per wave:
-//   qacc[m][d] = sum_k y[m][k] W'[d][k]            64 MFMAs (4 dim tiles x 16 k-steps), W' fragments from LDS
-//   q = rstd[m] * (qacc - mu[m] * colsum[d]) + bias'[d]      (deferred LayerNorm, dh_linear_ln's A-fold)
-//   the lane's 16 q values, rounded to the operand type, ARE its B operand for K q^T: K's head-dim slots were packed in
-//   exactly the order the accumulators hold them -- then scores / softmax / P V as in attn_cross_mfma_kernel.
-template <typename T>
-__global__ __launch_bounds__(512) void attn_cross_qproj_kernel(const T* __restrict__ y, int ldy, const float2* __restrict__ stats, int nt,
-                                                                float eps, const T* __restrict__ wq, const float* __restrict__ bq,
-                                                                const float* __restrict__ csum, const T* __restrict__ kp,
-                                                                const T* __restrict__ vt, const uint8_t* __restrict__ keymask,
-                                                                T* __restrict__ out, int n_img, int rows_per_img, int S, int D, int H,
-                                                                float scale) {
-    __shared__ __attribute__((aligned(16))) unsigned char wlds[8 * 8192 + 512];
-    float* cb = reinterpret_cast<float*>(wlds + 8 * 8192);          // colsum | bias of the head's 64 columns
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = blockIdx.y, img = blockIdx.x * 8 + wave;
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int K = D, nslab = K / 64;                                // host: D % 64 == 0, D <= 512
-    // this wave's share of the weight slice: k-slabs wave, wave + 8, ... (8 pieces of 8 rows each)
-    {
-        const int lr = lane >> 3, lpos = lane & 7;
-        for (int sl = wave; sl < nslab; sl += 8)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                dh_lds_dma16(reinterpret_cast<const uint16_t*>(wq) + (size_t)(h * 64 + 8 * i + lr) * K + sl * 64 + (lpos ^ lr) * 8,
-                             wlds + sl * 8192 + i * 1024);
-    }
-    const bool have = img < n_img;                                  // wave-uniform; idle waves still join the barrier
-    const int im = have ? img : 0;
-    const bool live = have && l15 < rows_per_img;
-    const size_t row = (size_t)im * rows_per_img + (live ? l15 : 0);
-    const uint16_t* kb = reinterpret_cast<const uint16_t*>(kp) + ((size_t)im * H + h) * 4096;
-    const uint16_t* vb = reinterpret_cast<const uint16_t*>(vt) + ((size_t)im * H + h) * 4096;
-    uint4 kf[4][2], vf[4][2], yf[8][2];
-    float cbv[2] = {0.f, 0.f};
-    if (threadIdx.x < 64) { cbv[0] = csum[h * 64 + threadIdx.x]; cbv[1] = bq[h * 64 + threadIdx.x]; }
-    const uint16_t* yrow = reinterpret_cast<const uint16_t*>(y) + row * ldy;
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            // lanes past the image's rows carry a copy of its row 0: every output row depends on its own input row only, and
-            // theirs are never stored (a select on the loaded value here would make the compiler drain the queue mid-issue)
-            yf[sl][kk] = *reinterpret_cast<const uint4*>(yrow + min(sl, nslab - 1) * 64 + 32 * kk + 8 * lq);
-        }
-    float4 raw[4];
-    ln_load(stats + row * nt, nt, raw);
-    const uint8_t mbyte = keymask[im * S + min(lane, S - 1)];       // one byte per lane; balloted into a 64-bit key mask below
-    // K and V last: vector-memory operations retire in order, so waiting until only these 16 loads are outstanding covers the
-    // weight pieces (issued first; LDS-DMA is invisible to the compiler's own waits) and leaves K / V in flight under the projection
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            // key rows >= S are padding whose scores are replaced by -inf: those lanes re-read row S - 1 (a line the wave fetches
-            // anyway) instead of pulling the 64 - S zero rows of every (image, head) from HBM (15 of 64 rows at S = 49)
-            kf[j][kk] = *reinterpret_cast<const uint4*>(kb + min(16 * j + l15, S - 1) * 64 + 32 * kk + 8 * lq);
-            vf[j][kk] = *reinterpret_cast<const uint4*>(vb + (16 * j + l15) * 64 + 32 * kk + 8 * lq);
-        }
-    __builtin_amdgcn_sched_barrier(0);
-    if (threadIdx.x < 64) { cb[threadIdx.x] = cbv[0]; cb[64 + threadIdx.x] = cbv[1]; }
-    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (!have) return;
-    dh_f32x4 qacc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) qacc[j] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
-    // weight fragments of half-slab t + 1 are read while the 4 MFMAs of half-slab t run (two register sets)
-    uint4 wf[2][4];
-    auto read_w = [&](int buf, int t) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int rr = 16 * j + l15;
-            wf[buf][j] = *reinterpret_cast<const uint4*>(wlds + (t >> 1) * 8192 + rr * 128 + ((((t & 1) * 4 + lq) ^ (rr & 7)) << 4));
-        }
-    };
-    read_w(0, 0);
-#pragma unroll
-    for (int t = 0; t < 16; ++t) {
-        if (t < 2 * nslab) {
-            if (t + 1 < 2 * nslab) read_w((t + 1) & 1, t + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                qacc[j] = Op16<T>::mfma(wf[t & 1][j], yf[t >> 1][t & 1], qacc[j]);   // qacc[j][r] = q[m = l15][d = 16j + 4lq + r]
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    float mu, rstd;
-    ln_math(raw, nt, eps, mu, rstd);
-    float4 cs4[4], b4[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        cs4[j] = *reinterpret_cast<const float4*>(cb + 16 * j + 4 * lq);
-        b4[j] = *reinterpret_cast<const float4*>(cb + 64 + 16 * j + 4 * lq);
-    }
-    uint4 qf[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        uint32_t w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            float qv[2];
-#pragma unroll
-            for (int z = 0; z < 2; ++z) {
-                const int e = 2 * u + z, j = 2 * kk + (e >> 2), r = e & 3;
-                const float c = r == 0 ? cs4[j].x : r == 1 ? cs4[j].y : r == 2 ? cs4[j].z : cs4[j].w;
-                const float b = r == 0 ? b4[j].x : r == 1 ? b4[j].y : r == 2 ? b4[j].z : b4[j].w;
-                qv[z] = fmaf(rstd, fmaf(-mu, c, qacc[j][r]), b);
-                // keep the fp32 rounding of q: with -ffp-contract the compiler may otherwise turn (f16)fma(...) into v_fma_mix*_f16, which
-                // rounds the exact product-sum ONCE to fp16 -- the GEMM route (dh_linear_ln: fp32 value through LDS, then converted)
-                // rounds twice, and the two differ at near-ties (1 q element in ~15,000, fp16 only)
-                asm volatile("" : "+v"(qv[z]));
-            }
-            w[u] = (uint32_t)Op16<T>::from_f32(qv[0]) | ((uint32_t)Op16<T>::from_f32(qv[1]) << 16);
-        }
-        qf[kk] = live ? make_uint4(w[0], w[1], w[2], w[3]) : make_uint4(0u, 0u, 0u, 0u);
-    }
-    uint16_t* orow = reinterpret_cast<uint16_t*>(out) + row * D + h * 64;
-    cross_core<T>(kf, vf, qf, __ballot(mbyte != 0), S, scale, live, orow, lq);
-}
-
-extern "C" int dh_attn_cross_qproj_decode(const void* y, int ldy, const float* stats, int n_tiles, float eps, const void* wq_folded,
-                                          const float* bq_folded, const float* colsum, const void* kp_dperm, const void* vt,
-                                          const uint8_t* keymask, void* out, int n_img, int rows_per_img, int S, int D, int n_heads,
-                                          float scale, int dtype, void* stream) {
-    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
-    DH_REQUIRE(y && stats && wq_folded && bq_folded && colsum && kp_dperm && vt && keymask && out && n_img > 0);
-    DH_REQUIRE(rows_per_img > 0 && rows_per_img <= 16 && S > 0 && S <= 64 && n_heads > 0 && D == 64 * n_heads && D <= 512);
-    DH_REQUIRE(n_tiles * 64 == D && n_tiles >= 2 && (n_tiles % 2) == 0 && ldy >= D && (ldy % 8) == 0);
-    DH_REQUIRE(((uintptr_t)y % 16) == 0 && ((uintptr_t)stats % 16) == 0 && ((uintptr_t)wq_folded % 16) == 0 && ((uintptr_t)bq_folded % 16) == 0 &&
-               ((uintptr_t)colsum % 16) == 0 && ((uintptr_t)kp_dperm % 16) == 0 && ((uintptr_t)vt % 16) == 0 && ((uintptr_t)out % 8) == 0);
-    const int rows = n_img * rows_per_img;
-    dh_prof_set_tag("qproj+attn");
-    DhProfScope prof("dh_attn_cross_decode", 2.0 * rows * D * D + 4.0 * rows * S * D,
-                     2.0 * (n_img * S * 2.0 * D + rows * 2.0 * D + (double)D * D), stream);
-    DH_DISPATCH_16(dtype, hipLaunchKernelGGL(attn_cross_qproj_kernel<T>, dim3(dh_cdiv(n_img, 8), n_heads), dim3(512), 0, (hipStream_t)stream,
-                                             (const T*)y, ldy, (const float2*)stats, n_tiles, eps, (const T*)wq_folded, bq_folded, colsum,
-                                             (const T*)kp_dperm, (const T*)vt, keymask, (T*)out, n_img, rows_per_img, S, D, n_heads, scale));
-    DH_LAUNCH_CHECK();
-}
-
-// ---- QKV projection + masked self-attention + KV-cache append in one launch (decode chain, 16-bit dtypes) -----------------------
-// self_attn of a DecoderLayer for one position (transformers.py:356 -> 97-127, KV-cached form): q|k|v = fc_{q,k,v}(LN(x)) for the
-// head, attention over the row's history, append of k / v to the cache -- without the [rows, 3D] qkv matrix going through memory
-// and without a separate GEMM launch.  Workgroup = 8 waves = 8 images x ONE head (as dh_attn_cross_qproj_decode):
-//   * the head's three 64-row weight slices (q, k, v: 64 KB each) stream through two LDS buffers by LDS-DMA while the previous
-//     slice feeds the MFMAs (12 accumulator quads per wave: <= 16 rows x 192 columns);
-//   * every wave loads its image's rows as MFMA B fragments and -- up front, in the same memory round trip -- the ancestor rows
-//     and pad-mask tokens of every key slot of every row;
-//   * q|k|v of the position (rounded to the storage type, exactly what dh_linear would have written) go to a wave-private LDS
-//     strip, from which the attention reads them in its (key slot, 8-dim chunk) lane layout; the history K / V come from the
-//     cache with the register-resident scheme of attn_decode_reg_kernel (three rows' loads in flight at a time).
-// Arithmetic and summation order equal dh_linear(_ln) + dh_attn_self_decode: the outputs and the cache are bit-identical.
-struct SelfQkvParams {
-    const uint16_t* x; int ldx;
-    const float2* a_stats; int a_nt; float a_eps; const float* colsum;    // deferred LayerNorm on x (NULL: plain rows)
-    const uint16_t* w; const float* bias;                                  // [3D, D] (gamma-folded when a_stats), [3D]
-    uint16_t* kc; uint16_t* vc; const int32_t* src; int src_ld; const int32_t* tokens; int tok_ld;
-    uint16_t* out;
-    int n_img, rpi, row_mult, rows_total, t, D, H, pad_index;
-    float scale;
-};
-
-template <typename T>
-__global__ __launch_bounds__(512) void attn_self_qkv_kernel(SelfQkvParams p) {
-    constexpr int NIT = 5, MAXR = 6, KPI = 8;                      // 40 key slots; rows per image handled here
-    extern __shared__ __attribute__((aligned(16))) unsigned char dyn[];
-    unsigned char* wbuf[2] = {dyn, dyn + 65536};
-    float* cb = reinterpret_cast<float*>(dyn + 131072);             // [2][192]: colsum | bias of the head's q, k, v columns
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    unsigned char* strip = dyn + 131072 + 1536 + wave * (p.rpi * 384);   // [row][q | k | v][64] storage type
-    const int h = blockIdx.y, img = blockIdx.x * 8 + wave;
-    const int l15 = lane & 15, lq = lane >> 4, kg = lane >> 3, dc = lane & 7;
-    const int D = p.D, K = D, nslab = K / 64, t = p.t, L = t + 1;
-    const bool have = img < p.n_img;
-    const int im = have ? img : 0;
-    // ---- ordinary loads first (they are older than every LDS-DMA piece below) -------------------------------------------
-    const bool live = have && l15 < p.rpi;
-    const size_t grow = (size_t)im * p.rpi + (live ? l15 : 0);      // compact row of the GEMM lane
-    uint4 yf[8][2];
-    const uint16_t* xrow = p.x + grow * p.ldx;
-#pragma unroll
-    for (int sl = 0; sl < 8; ++sl)
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const uint4 v4 = *reinterpret_cast<const uint4*>(xrow + min(sl, nslab - 1) * 64 + 32 * kk + 8 * lq);
-            yf[sl][kk] = live ? v4 : make_uint4(0u, 0u, 0u, 0u);
-        }
-    float4 raw[4];
-    if (p.a_stats) ln_load(p.a_stats + grow * p.a_nt, p.a_nt, raw);
-    if (threadIdx.x < 192) {
-        const int col = (threadIdx.x >> 6) * D + h * 64 + (threadIdx.x & 63);
-        cb[threadIdx.x] = p.colsum ? p.colsum[col] : 0.f;
-        cb[192 + threadIdx.x] = p.bias[col];
-    }
-    int phys[MAXR][NIT];                                            // ancestor row of every key slot of every row (one round trip, now)
-#pragma unroll
-    for (int m = 0; m < MAXR; ++m) {
-        const size_t rl = ((size_t)im * p.rpi + min(m, p.rpi - 1)) * p.row_mult;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) phys[m][it] = t > 0 ? p.src[rl * p.src_ld + min(it * KPI + kg, t - 1)] : 0;
-    }
-    // ---- weight slices: q -> buffer 0, k -> buffer 1 now; v -> buffer 0 once q is consumed -------------------------------
-    auto stage = [&](int part, unsigned char* buf) {
-        const int lr = lane >> 3, lpos = lane & 7;
-        for (int sl = wave; sl < nslab; sl += 8)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-                dh_lds_dma16(p.w + (size_t)(part * D + h * 64 + 8 * i + lr) * K + sl * 64 + (lpos ^ lr) * 8, buf + sl * 8192 + i * 1024);
-    };
-    const int per = ((nslab - 1 - wave) >> 3) + (wave < nslab ? 1 : 0);   // k-slabs this wave stages per slice (wave-uniform)
-    stage(0, wbuf[0]);
-    stage(1, wbuf[1]);
-    float mu = 0.f, rstd = 1.f;
-    auto project = [&](int part, const unsigned char* buf) {
-        dh_f32x4 acc[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = dh_f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int sl = 0; sl < 8; ++sl) {
-            if (sl < nslab) {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int rr = 16 * j + l15;
-                        const uint4 wf = *reinterpret_cast<const uint4*>(buf + sl * 8192 + rr * 128 + (((kk * 4 + lq) ^ (rr & 7)) << 4));
-                        acc[j] = Op16<T>::mfma(wf, yf[sl][kk], acc[j]);        // acc[j][r] = (q|k|v)[row l15][dim 16j + 4lq + r]
-                    }
-            }
-        }
-        if (live) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float4 c4 = *reinterpret_cast<const float4*>(cb + part * 64 + 16 * j + 4 * lq);
-                const float4 b4 = *reinterpret_cast<const float4*>(cb + 192 + part * 64 + 16 * j + 4 * lq);
-                float v[4];
-                if (p.a_stats) {
-                    v[0] = fmaf(rstd, fmaf(-mu, c4.x, acc[j][0]), b4.x); v[1] = fmaf(rstd, fmaf(-mu, c4.y, acc[j][1]), b4.y);
-                    v[2] = fmaf(rstd, fmaf(-mu, c4.z, acc[j][2]), b4.z); v[3] = fmaf(rstd, fmaf(-mu, c4.w, acc[j][3]), b4.w);
-                } else {
-                    v[0] = fmaf(acc[j][0], 1.f, b4.x); v[1] = fmaf(acc[j][1], 1.f, b4.y);
-                    v[2] = fmaf(acc[j][2], 1.f, b4.z); v[3] = fmaf(acc[j][3], 1.f, b4.w);
-                }
-                uint2 pk;
-                pk.x = (uint32_t)Op16<T>::from_f32(v[0]) | ((uint32_t)Op16<T>::from_f32(v[1]) << 16);
-                pk.y = (uint32_t)Op16<T>::from_f32(v[2]) | ((uint32_t)Op16<T>::from_f32(v[3]) << 16);
-                *reinterpret_cast<uint2*>(strip + l15 * 384 + part * 128 + (16 * j + 4 * lq) * 2) = pk;
-            }
-        }
-    };
-    // q: everything except this wave's share of the k slice has landed (and the colsum | bias strip is written)
-    if (per == 1) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (p.a_stats) ln_math(raw, p.a_nt, p.a_eps, mu, rstd);
-    project(0, wbuf[0]);
-    __builtin_amdgcn_s_barrier();                                   // every wave is done reading buffer 0
-    stage(2, wbuf[0]);
-    if (per == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                   // the k slice has landed for every wave
-    project(1, wbuf[1]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    project(2, wbuf[0]);
-    if (!have) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");          // the strip is wave-private: order its writes before the reads below
-    // ---- attention: rows in groups of three (their K / V loads share one memory round trip) -----------------------------
-    const T* sq = reinterpret_cast<const T*>(strip);
-#pragma unroll
-    for (int m0 = 0; m0 < MAXR; m0 += 3) {
-        if (m0 >= p.rpi) break;                                     // wave-uniform
-        Raw8<T> kr[3][NIT], vr[3][NIT];
-        int aux[3][NIT];
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int mm = m0 + b;
-            if (mm < p.rpi) {
-                const size_t rl = ((size_t)img * p.rpi + mm) * p.row_mult;
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int j = it * KPI + kg;
-                    aux[b][it] = (t > 0 && p.tokens) ? p.tokens[rl * p.tok_ld + min(max(j - 1, 0), t - 1)] : 0;
-                    if (j < t) {
-                        const size_t off = ((size_t)j * p.rows_total + phys[mm][it]) * D + h * 64 + dc * 8;
-                        raw_load(reinterpret_cast<const T*>(p.kc) + off, kr[b][it]);
-                        raw_load(reinterpret_cast<const T*>(p.vc) + off, vr[b][it]);
-                    } else if (j == t) {
-                        raw_load(sq + mm * 192 + 64 + dc * 8, kr[b][it]);
-                        raw_load(sq + mm * 192 + 128 + dc * 8, vr[b][it]);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            const int mm = m0 + b;
-            if (mm < p.rpi) {
-                const size_t rc = (size_t)img * p.rpi + mm, rl = rc * p.row_mult;
-                float qv[8];
-                load8(sq + mm * 192 + dc * 8, qv);
-                float e[NIT];
-                float mx = -INFINITY;
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int j = it * KPI + kg;
-                    e[it] = -INFINITY;
-                    if (j < L) {
-                        float kk8[8];
-                        raw_unpack(kr[b][it], kk8);
-                        float a = 0.f;
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) a = fmaf(kk8[u], qv[u], a);
-                        a = sum8(a);
-                        const bool masked = (j >= 1) && p.tokens && (aux[b][it] == p.pad_index);
-                        e[it] = masked ? -1e8f : SmMath<T>::div(a, p.scale);
-                    }
-                    mx = fmaxf(mx, e[it]);
-                }
-                mx = wave_max(mx);
-                float sum = 0.f;
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    e[it] = (it * KPI + kg < L) ? SmMath<T>::exp(e[it] - mx) : 0.f;
-                    sum += e[it];
-                }
-                sum = wave_sum(sum) / 8.0f;
-                float o8[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) o8[u] = 0.f;
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    if (it * KPI + kg < L) {
-                        float vv[8];
-                        raw_unpack(vr[b][it], vv);
-                        const float pj = SmMath<T>::div(e[it], sum);
-#pragma unroll
-                        for (int u = 0; u < 8; ++u) o8[u] = fmaf(pj, vv[u], o8[u]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u)
-                    o8[u] = key_slots_sum8(o8[u]);
-                if (kg == 0) {
-                    store8(reinterpret_cast<T*>(p.out) + rc * D + h * 64 + dc * 8, o8);
-                    copy8(reinterpret_cast<T*>(p.kc) + ((size_t)t * p.rows_total + rl) * D + h * 64 + dc * 8, sq + mm * 192 + 64 + dc * 8);
-                    copy8(reinterpret_cast<T*>(p.vc) + ((size_t)t * p.rows_total + rl) * D + h * 64 + dc * 8, sq + mm * 192 + 128 + dc * 8);
-                }
-            }
-        }
-    }
-}
-
-extern "C" int dh_attn_self_qkv_decode(const void* x, int ldx, const float* a_stats, int a_tiles, float a_eps, const float* colsum,
-                                       const void* wqkv, const float* bqkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
-                                       const int32_t* tokens, int tok_ld, void* out, int n_img, int rows_per_img, int row_mult,
-                                       int rows_total, int t, int D, int n_heads, float scale, int pad_index, int dtype, void* stream) {
-    if (!DH_IS_16BIT(dtype)) return DH_ERR_UNSUPPORTED;
-    DH_REQUIRE(x && wqkv && bqkv && kcache && vcache && out && n_img > 0 && rows_per_img > 0 && rows_per_img <= 6 && row_mult > 0);
-    DH_REQUIRE(t >= 0 && t <= 39 && n_heads > 0 && D == 64 * n_heads && D <= 512 && ldx >= D && (ldx % 8) == 0);
-    DH_REQUIRE((t == 0 || src) && (t == 0 || pad_index < 0 || tokens) && (!a_stats || (colsum && a_tiles * 64 == D && (a_tiles % 2) == 0)));
-    DH_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)wqkv % 16) == 0 && ((uintptr_t)kcache % 16) == 0 && ((uintptr_t)vcache % 16) == 0 &&
-               ((uintptr_t)out % 16) == 0 && ((uintptr_t)a_stats % 16) == 0);
-    SelfQkvParams p{};
-    p.x = (const uint16_t*)x; p.ldx = ldx; p.a_stats = (const float2*)a_stats; p.a_nt = a_tiles; p.a_eps = a_eps; p.colsum = colsum;
-    p.w = (const uint16_t*)wqkv; p.bias = bqkv; p.kc = (uint16_t*)kcache; p.vc = (uint16_t*)vcache; p.src = src; p.src_ld = src_ld;
-    p.tokens = pad_index < 0 ? nullptr : tokens; p.tok_ld = tok_ld; p.out = (uint16_t*)out;
-    p.n_img = n_img; p.rpi = rows_per_img; p.row_mult = row_mult; p.rows_total = rows_total; p.t = t; p.D = D; p.H = n_heads;
-    p.pad_index = pad_index; p.scale = scale;
-    const int rows = n_img * rows_per_img;
-    const size_t lds = 131072 + 1536 + (size_t)8 * rows_per_img * 384;
-    dh_prof_set_tag("qkv+attn");
-    DhProfScope prof("dh_attn_self_decode", 6.0 * rows * D * D + 4.0 * rows * (t + 1) * D,
-                     2.0 * (rows * ((t + 1) * 2.0 * D + 2.0 * D) + 3.0 * D * D), stream);
-    hipStream_t s = (hipStream_t)stream;
-    if (dtype == DH_BF16) {
-        static bool attr_bf = false;
-        if (!attr_bf) { hipFuncSetAttribute((const void*)attn_self_qkv_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_bf = true; }
-        hipLaunchKernelGGL(attn_self_qkv_kernel<bf16_t>, dim3(dh_cdiv(n_img, 8), n_heads), dim3(512), lds, s, p);
-    } else {
-        static bool attr_f = false;
-        if (!attr_f) { hipFuncSetAttribute((const void*)attn_self_qkv_kernel<f16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_f = true; }
-        hipLaunchKernelGGL(attn_self_qkv_kernel<f16_t>, dim3(dh_cdiv(n_img, 8), n_heads), dim3(512), lds, s, p);
-    }
-    DH_LAUNCH_CHECK();
 }
 
 // q [n_img * row_si rows, ldq] (image i's rows start at row i * row_si; rows_per_img <= 16 of them are used), out likewise

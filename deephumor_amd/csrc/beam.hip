@@ -81,8 +81,8 @@ template <int NT>
 __device__ __attribute__((noinline)) void row_overflow(const float* __restrict__ row, int V, uint32_t thr, int rc, int ldl, int rows_per_img, int beam,
                              float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
                              const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
-                             float* __restrict__ pick_val, float* sq, int* si, int* picks, bool shared_picks, int32_t* __restrict__ err);
-__device__ __forceinline__ void pick_store(int32_t* pi, float* pv, size_t at, int32_t idx, float val, bool shared);
+                             float* __restrict__ pick_val, float* sq, int* si, int* picks, int32_t* __restrict__ err);
+__device__ __forceinline__ void pick_store(int32_t* pi, float* pv, size_t at, int32_t idx, float val);
 
 // softmax over a row's survivors: max m, sum s of exp(x - m).  Finite logits give a finite m and s >= 1 (the maximum contributes exp(0));
 // a NaN among them makes s NaN, +inf makes m = +inf and s NaN, only-NaN survivors leave m = -inf: the reference's torch.multinomial raises
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void beam_row_sample_kernel(
     int n = s_cnt;
     if (n > CAP) {                   // more ties at the threshold than the candidate buffers hold: the draw over the row itself
         row_overflow<256>(row, V, thr, rc, ldl, rows_per_img, beam, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val,
-                          qv, idx_b, picks, false, err);
+                          qv, idx_b, picks, err);
         return;
     }
     if (n == 0) {
@@ -239,25 +239,7 @@ __device__ void radix_row_candidates(const float* __restrict__ row, int V, int t
 // (about top_k..2*top_k values on real logits) is compacted into LDS and the exact threshold,
 // the survivors and the draws are computed there.  If more than CAP values pass the bound (flat / tied
 // logits) the kernel re-derives the exact candidate set in place with radix_row_candidates.
-// Picks handed from one workgroup to another inside a launch (fused beam step): stored / loaded with the sc1 bit (agent-scope
-// relaxed atomics) so they bypass the non-coherent per-XCD L2s; the ordering is the storing waves' vmcnt(0) + workgroup barrier
-// before the arrival counter's add and the reader's barrier after it (MI355X_MICROARCH "Correctness boundaries").  A full
-// agent-scope release fence instead (L2 write-back) in each of the 1,280 workgroups cost 19 us per step.
-__device__ __forceinline__ void pick_store(int32_t* pi, float* pv, size_t at, int32_t idx, float val, bool shared) {
-    if (shared) {
-        __hip_atomic_store(pi + at, idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(reinterpret_cast<int32_t*>(pv) + at, __builtin_bit_cast(int32_t, val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        pi[at] = idx; pv[at] = val;
-    }
-}
-__device__ __forceinline__ int32_t pick_load_idx(const int32_t* pi, size_t at, bool shared) {
-    return shared ? __hip_atomic_load(pi + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pi[at];
-}
-__device__ __forceinline__ float pick_load_val(const float* pv, size_t at, bool shared) {
-    return shared ? __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const int32_t*>(pv) + at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                  : pv[at];
-}
+__device__ __forceinline__ void pick_store(int32_t* pi, float* pv, size_t at, int32_t idx, float val) { pi[at] = idx; pv[at] = val; }
 
 // More than CAP logits of a row tie at (or exceed) its top-k threshold -- flat or constant logits -- so the survivors do not fit the
 // LDS candidate buffers: the draw runs over the ROW in global memory instead (beam.py:32-48 unchanged: every logit >= the threshold
@@ -270,7 +252,7 @@ template <int NT>
 __device__ __attribute__((noinline)) void row_overflow(const float* __restrict__ row, int V, uint32_t thr, int rc, int ldl, int rows_per_img, int beam,
                              float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
                              const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
-                             float* __restrict__ pick_val, float* sq, int* si, int* picks, bool shared_picks, int32_t* __restrict__ err) {
+                             float* __restrict__ pick_val, float* sq, int* si, int* picks, int32_t* __restrict__ err) {
     const int tid = threadIdx.x;
     // (every loop rolled: this path must not raise the register count of the kernels that call it -- at 116 VGPRs instead of 44 the
     //  group-guided sampler lost a wave of occupancy, its 1,280 workgroups no longer fitted the chip in one round: +9 us per launch)
@@ -294,7 +276,7 @@ __device__ __attribute__((noinline)) void row_overflow(const float* __restrict__
     const float s = sq[0];
     if (dh_softmax_nonfinite(m, s)) {                  // (block-uniform)
         if (tid == 0) atomicOr(err, DH_BEAM_ERR_NONFINITE);
-        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f, shared_picks);
+        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f);
         return;
     }
     const int img = rc / rows_per_img, rin = rc % rows_per_img;
@@ -337,7 +319,7 @@ __device__ __attribute__((noinline)) void row_overflow(const float* __restrict__
         for (int b = 0; b < beam; ++b) se += expf(row[picks[b]] - mx);
         const float lse = logf(se);
 #pragma unroll 1
-        for (int b = 0; b < beam; ++b) pick_store(pick_idx, pick_val, (size_t)rc * beam + b, picks[b], (row[picks[b]] - mx) - lse, shared_picks);
+        for (int b = 0; b < beam; ++b) pick_store(pick_idx, pick_val, (size_t)rc * beam + b, picks[b], (row[picks[b]] - mx) - lse);
     }
 }
 
@@ -352,7 +334,7 @@ template <int NT>
 __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int rows_per_img, int beam, int top_k,
                                          float temperature, int unk, const float* __restrict__ noise, uint64_t seed,
                                          const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx,
-                                         float* __restrict__ pick_val, int32_t* __restrict__ err, bool shared_picks = false) {
+                                         float* __restrict__ pick_val, int32_t* __restrict__ err) {
     const int tid = threadIdx.x;
     int* idx_a = L.idx_a; int* idx_b = L.idx_b; float* val_a = L.val_a; float* val_b = L.val_b;
     float* qv = L.qv; float* red = L.red; int* picks = L.picks;
@@ -382,7 +364,7 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
     const int n = s_cnt;
     if (n == 0) {
         if (tid == 0) atomicOr(err, DH_BEAM_ERR_ALL_FILTERED);
-        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f, shared_picks);
+        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f);
         return;
     }
     // deterministic order: sort survivors by token index
@@ -414,7 +396,7 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
     for (int w = 1; w < NWV; ++w) s += red[w];      // same order in every thread: one value for the whole block
     if (dh_softmax_nonfinite(m, s)) {                  // (block-uniform)
         if (tid == 0) atomicOr(err, DH_BEAM_ERR_NONFINITE);
-        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f, shared_picks);
+        if (tid < beam) pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, 0, 0.f);
         return;
     }
     const int img = rc / rows_per_img, rin = rc % rows_per_img;
@@ -441,7 +423,7 @@ __device__ __forceinline__ void row_tail(const RowLds& L, int rc, int ldl, int r
         const float se = wave_sum(pi >= 0 ? expf(lv - mx) : 0.f);
         const float lse = logf(se);
         if (tid < beam) {
-            pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, pi >= 0 ? idx_a[pi] : 0, pi >= 0 ? (lv - mx) - lse : -INFINITY, shared_picks);
+            pick_store(pick_idx, pick_val, (size_t)rc * beam + tid, pi >= 0 ? idx_a[pi] : 0, pi >= 0 ? (lv - mx) - lse : -INFINITY);
         }
     }
 #undef s_cnt
@@ -508,7 +490,7 @@ __global__ __launch_bounds__(NT, WPE) void beam_row_sample_fast_kernel(
     row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err);
 }
 
-// ---- candidate draw of one image (used by beam_select_kernel and by the fused step below) ------------------------------------
+// ---- candidate draw of one image (beam_select_kernel) -----------------------------------------------------------------------
 struct SelectParams {
     const int32_t* pick_idx; const float* pick_val;
     int32_t* tokens; int tok_ld; float* vals; uint8_t* ended; int32_t* src; int src_ld;
@@ -517,21 +499,18 @@ struct SelectParams {
     float temperature; const float* noise; uint64_t seed; const uint64_t* seed_ptr;
 };
 
-// LDS scratch of one image's candidate draw: carved by the caller (its own arrays in beam_select_kernel, the dead candidate
-// buffers of the row kernel in the fused step)
+// LDS scratch of one image's candidate draw, carved by the caller (beam_select_kernel's own arrays)
 struct SelLds {
     int32_t* stage;                                     // [beam][tok_ld] tokens, then [beam][t] ancestors
     int* ctok; int* cpar; int* keep; float* cval; float* q; uint8_t* cend; int* s_n;
     int32_t* pki = nullptr; float* pkv = nullptr;       // optional [beam * beam]: the image's picks, brought in with the first round trip
 };
-#define DH_SEL_STAGE_MAX 3072                           // ints available for `stage` in the fused step
 
 // The candidate draw + in-place rewrite of one image's beam state, executed by ONE wave (lane = 0..63); LDS hand-overs are
-// wave-local (wave_lds_sync), so the same body serves the stand-alone kernel and the tail of the fused row kernel.  MB = the largest beam
+// wave-local (wave_lds_sync).  MB = the largest beam
 // count the instantiation takes (register arrays of the beams' flags / scores): 16 for the usual settings, 64 for beam_size > 16.
 template <int MB>
-__device__ __forceinline__ void beam_select_image(const SelectParams& p, const int img, const int lane, const SelLds& L,
-                                                  const bool shared_picks = false) {
+__device__ __forceinline__ void beam_select_image(const SelectParams& p, const int img, const int lane, const SelLds& L) {
     int32_t* stage = L.stage;
     int* ctok = L.ctok; int* cpar = L.cpar; int* keep = L.keep; float* cval = L.cval; float* q = L.q; uint8_t* cend = L.cend;
 #define s_n (*L.s_n)
@@ -539,7 +518,7 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
     // Stand-alone kernel (L.pki set): EVERYTHING the image needs -- its token rows, ancestor rows and all its picks -- is requested
     // up front by LDS-DMA, next to the loads of done / ended / vals: ONE memory round trip instead of four dependent ones (done ->
     // ended -> picks -> token rows), which were most of this 8 us kernel.
-    const bool pre = L.pki != nullptr && !shared_picks;
+    const bool pre = L.pki != nullptr;
     int32_t* const tokbuf0 = stage;
     int32_t* const srcbuf0 = stage + (size_t)B * p.tok_ld;
     if (pre) {
@@ -568,8 +547,8 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
     // Every lane derives the (short) offset table itself; candidates are then filled in parallel.
     if (p.first) {
         for (int j = lane; j < B; j += 64) {
-            const int tok = pre ? L.pki[j] : pick_load_idx(p.pick_idx, (size_t)img * B + j, shared_picks);
-            ctok[j] = tok; cval[j] = pre ? L.pkv[j] : pick_load_val(p.pick_val, (size_t)img * B + j, shared_picks); cpar[j] = 0;
+            const int tok = pre ? L.pki[j] : p.pick_idx[(size_t)img * B + j];
+            ctok[j] = tok; cval[j] = pre ? L.pkv[j] : p.pick_val[(size_t)img * B + j]; cpar[j] = 0;
             cend[j] = (uint8_t)(p.first_sets_ended && tok == p.eos);
             keep[j] = j;
         }
@@ -589,9 +568,9 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
             bool was = false; float vb = 0.f;             // (static register indexing: b is a run-time value)
 #pragma unroll
             for (int k = 0; k < MB; ++k) if (k == b) { was = was_ended[k] != 0; vb = val_b[k]; }
-            const int tok = was ? 0 : (pre ? L.pki[b * B + j] : pick_load_idx(p.pick_idx, (size_t)(base + b) * B + j, shared_picks));
+            const int tok = was ? 0 : (pre ? L.pki[b * B + j] : p.pick_idx[(size_t)(base + b) * B + j]);
             ctok[c] = tok;
-            cval[c] = vb + (was ? 0.f : (pre ? L.pkv[b * B + j] : pick_load_val(p.pick_val, (size_t)(base + b) * B + j, shared_picks)));
+            cval[c] = vb + (was ? 0.f : (pre ? L.pkv[b * B + j] : p.pick_val[(size_t)(base + b) * B + j]));
             cpar[c] = b;
             cend[c] = (uint8_t)(was || tok == p.eos);
         }
@@ -660,29 +639,23 @@ __device__ __forceinline__ void beam_select_image(const SelectParams& p, const i
 // consecutive columns of each row.  The k-th largest GROUP maximum is a lower bound of the row's k-th largest
 // value (k groups hold a value >= it), and only groups whose maximum reaches that bound can contain one of the
 // top-k values: about top_k of the ~570 groups.  So this kernel reads ~9 % of the row instead of all of it.
-// FUSED: the workgroup that finishes an image's LAST row also runs that image's candidate draw (beam_select_image) -- one launch
-// per beam step instead of two.  Hand-over between workgroups (possibly on different XCDs, whose L2s are not coherent): every
-// row's picks are stored with sc1 stores and drained (vmcnt(0)), the workgroup's barrier, then one lane adds 1 to the image's
-// arrival counter (agent-scope atomic); the workgroup whose add returns rows_per_img - 1 is the last one: barrier, sc1 loads of
-// all rows' picks.  It resets the counter for the next step.
-template <int NT, bool FUSED = false>
+template <int NT>
 __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     const float* __restrict__ logits, int ldl, int V, const float* __restrict__ gmax, int gm_ld, int n_groups,
     int gcols, int rows_per_img, int beam, int top_k, float temperature, int unk, const float* __restrict__ noise,
     uint64_t seed, const uint64_t* __restrict__ seed_ptr, int img0, int step, int32_t* __restrict__ pick_idx, float* __restrict__ pick_val,
-    int32_t* __restrict__ err, SelectParams sel = SelectParams{}, int32_t* __restrict__ arrive = nullptr) {
+    int32_t* __restrict__ err) {
     constexpr int MAXG = 1024, GPT = MAXG / NT;       // group keys per thread, kept in registers
     __shared__ int glist[MAXG];
     __shared__ int hist[4][256];
     __shared__ uint32_t s_prefix, s_thr;
     __shared__ int s_k, s_cnt, s_ng, wtot[4];
-    __shared__ __attribute__((aligned(16))) int32_t pool[5 * CAP];       // the five candidate buffers; dead after row_tail (FUSED reuses them)
+    __shared__ __attribute__((aligned(16))) int32_t pool[5 * CAP];       // the five candidate buffers
     int* const idx_a = pool; int* const idx_b = pool + CAP;
     float* const val_a = reinterpret_cast<float*>(pool + 2 * CAP); float* const val_b = reinterpret_cast<float*>(pool + 3 * CAP);
     float* const qv = reinterpret_cast<float*>(pool + 4 * CAP);
     __shared__ float red[NT];
     __shared__ int picks[DH_BEAM_MAX_BEAMS];
-    __shared__ int s_last;
     const int rc = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (size_t)rc * ldl;
     uint32_t gk[GPT];
@@ -735,24 +708,7 @@ __global__ __launch_bounds__(NT) void beam_row_sample_groups_kernel(
     __syncthreads();
     if (s_cnt > CAP) radix_row_candidates<NT>(row, V, top_k, &hist[0][0], &s_prefix, &s_k, &s_cnt, wtot, idx_a, val_a);
     const RowLds L{idx_a, idx_b, val_a, val_b, qv, red, picks, &s_cnt, &s_thr};
-    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err, FUSED);
-    if constexpr (FUSED) {
-        const int img = rc / rows_per_img;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's sc1 pick stores have been acknowledged
-        __syncthreads();
-        if (tid == 0) {
-            const int old = __hip_atomic_fetch_add(&arrive[img], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = old == rows_per_img - 1;
-            if (s_last) __hip_atomic_store(&arrive[img], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // reset for the next step
-        }
-        __syncthreads();
-        if (s_last && wave == 0) {
-            const SelLds SL{pool, pool + DH_SEL_STAGE_MAX, pool + DH_SEL_STAGE_MAX + 256, pool + DH_SEL_STAGE_MAX + 512,
-                            reinterpret_cast<float*>(pool + DH_SEL_STAGE_MAX + 528), reinterpret_cast<float*>(pool + DH_SEL_STAGE_MAX + 784),
-                            reinterpret_cast<uint8_t*>(pool + DH_SEL_STAGE_MAX + 1040), pool + DH_SEL_STAGE_MAX + 1104};
-            beam_select_image<16>(sel, img, lane, SL, true);
-        }
-    }
+    row_tail<NT>(L, rc, ldl, rows_per_img, beam, top_k, temperature, unk, noise, seed, seed_ptr, img0, step, pick_idx, pick_val, err);
 }
 
 extern "C" int dh_beam_row_sample_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld,
@@ -840,33 +796,6 @@ extern "C" int dh_beam_select(const int32_t* pick_idx, const float* pick_val, in
     DH_REQUIRE(lds <= 56 * 1024);                         // beam * (tok_ld + t) ints of staging next to the candidate arrays
     if (beam <= 16) hipLaunchKernelGGL(beam_select_kernel<16>, dim3(n_img), dim3(64), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(beam_select_kernel<DH_BEAM_MAX_BEAMS>, dim3(n_img), dim3(64), lds, (hipStream_t)stream, p);   // beam.py:7-9: any beam_size <= top_k
-    DH_LAUNCH_CHECK();
-}
-
-// One beam step in ONE launch (16-bit paths): dh_beam_row_sample_groups for every row, and -- by the workgroup that finishes an
-// image's last row -- dh_beam_select for that image.  Same arguments as the two entry points; `arrive` = int32 [n_img], zero
-// before the first call (the kernel leaves it zero).  Returns DH_ERR_UNSUPPORTED when the image's token / ancestor rows do not
-// fit the row kernel's LDS (beam * (tok_ld + t) > 3072 ints): use the two launches then.
-extern "C" int dh_beam_step_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld, int n_groups,
-                                   int group_cols, int rows, int rows_per_img, int beam, int top_k, float temperature,
-                                   int unk_index, const float* row_noise, uint64_t seed, const uint64_t* seed_ptr, int img0,
-                                   int step, int32_t* pick_idx, float* pick_val, int32_t* err, int32_t* tokens, int tok_ld,
-                                   float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent, int32_t* hparent,
-                                   uint8_t* done, int32_t* end_step, int first, int first_sets_ended, int write_pos, int t,
-                                   int eos_index, const float* cand_noise, int32_t* arrive, void* stream) {
-    DH_REQUIRE(logits && group_max && pick_idx && pick_val && err && rows > 0 && rows_per_img > 0 && V > 0 && ldl >= V);
-    DH_REQUIRE(beam >= 1 && beam <= DH_BEAM_MAX_BEAMS && beam <= top_k && top_k <= V && temperature > 0.f);
-    DH_REQUIRE(n_groups > 0 && n_groups <= 1024 && top_k <= n_groups && gm_ld >= n_groups && group_cols > 0 && group_cols <= 64 &&
-               (long long)n_groups * group_cols >= V);
-    DH_REQUIRE(tokens && vals && ended && parent && hparent && done && end_step && arrive && tok_ld > 0 && t >= 0 && (!src || src_ld > t));
-    DH_REQUIRE((rows % rows_per_img) == 0 && (first ? rows_per_img == 1 : rows_per_img == beam));
-    if ((long long)beam * (tok_ld + (src ? t : 0)) > DH_SEL_STAGE_MAX || beam > 16) return DH_ERR_UNSUPPORTED;
-    DhProfScope prof("dh_beam_step", 0.0, 0.0, stream);
-    SelectParams sp{pick_idx, pick_val, tokens, tok_ld, vals, ended, src, src_ld, parent, hparent, done, end_step,
-                    beam, first, first_sets_ended, write_pos, t, step, eos_index, img0, temperature, cand_noise, seed, seed_ptr};
-    hipLaunchKernelGGL((beam_row_sample_groups_kernel<256, true>), dim3(rows), dim3(256), 0, (hipStream_t)stream, logits, ldl, V,
-                       group_max, gm_ld, n_groups, group_cols, rows_per_img, beam, top_k, temperature, unk_index, row_noise,
-                       seed, seed_ptr, img0, step, pick_idx, pick_val, err, sp, arrive);
     DH_LAUNCH_CHECK();
 }
 

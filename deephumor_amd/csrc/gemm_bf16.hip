@@ -653,9 +653,8 @@ static void launch_gemm_bf16(GemmBf16Params& p, hipStream_t s) {
     // ring depth (16 KB per slab) by workgroup count, so that all tiles are co-resident in ONE round where possible:
     // <= 320: one per CU with a deep ring (7 slabs in flight); <= 512: two per CU; <= 768: three; <= 1280: five
     // (the fused LSTM step, 640 workgroups: 20.7 us with 4 slabs / 1.25 rounds, 16.6 us with 3 slabs / one round)
-    const int force_ns = dh_opt(DH_OPT_GEMM64_NS);
     // (32 x 64 tiles for the 160-workgroup decoder projections: slower -- proj 5.5 -> 6.1 ms, ffn 6.0 -> 7.6 ms per C3 step)
-    if (force_ns == 4 || blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)
+    if (blocks > 1280 || (blocks > 320 && blocks <= 512) || p.K <= 128)
         hipLaunchKernelGGL((gemm_bf16_kernel<OT, 64, 64, 2, CONV, 4>), dim3(blocks), dim3(256), 0, s, p);
     else if (blocks <= 320)
         // 8 waves on the 64 x 64 tile (32 x 16 per wave): twice the waves issuing LDS-DMA for the 7 slabs in flight --
@@ -1372,10 +1371,8 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
         //  4-slab ring, the two wave halves one barrier apart -- 85 us with LDS-DMA, 170 us register-staged; with 64-byte
         //  row segments every 128-byte line is fetched twice.  scratch/dma_probe shows the LDS-DMA path itself sustains
         //  110-125 GB/s per CU against the ~46 GB/s this kernel draws: DESIGN.md section 9.)
-        // DH_VOCAB_TILE=256: the 256 x 256 kernel (vocab256_kernel).  With the 187 MB of fp32 logits to store both kernels take the
-        // same 86-89 us per launch (store-bound: the stores of a tile cannot overlap the next tile's MFMAs, vmcnt is in-order); where
-        // nothing is stored (dh_vocab_logprob) the bigger tile is the default.
-        const int vns = dh_opt(DH_OPT_VOCAB_TILE), gns = dh_opt(DH_OPT_VOCAB_GMAX_TILE);
+        // The 256 x 256 kernel (vocab256_kernel): with the 187 MB of fp32 logits to store both tile kernels take the same 86-89 us per
+        // launch (store-bound), so logits go through the 128 x 128 one; where nothing is stored (group maxima only) the bigger tile is used.
         {   // A-stationary kernel: K = 512, row tiles of 128, groups of tiles_m workgroups per XCD (32 CUs each)
             // default since round 2: in the C2 / C3 steps 3-5 % faster than the 128 x 128 kernel below (2.43 vs 2.49 ms and 2.81 vs 2.99 ms
             // of classifier time per step, three alternating runs in one call); DH_VOCAB_AREG=0 restores the tile kernel
@@ -1413,13 +1410,10 @@ extern "C" int dh_vocab_logits(const void* A, int lda, const void* W, int ldw, c
                 DH_LAUNCH_CHECK();
             }
         }
-        if ((logits ? vns : gns) == 256 && (logits || M >= 512)) {
+        if (!logits && M >= 512) {
             v.tiles_m = dh_cdiv(M, 256); v.tiles_n = dh_cdiv(V, 256);
             const int nt = v.tiles_m * v.tiles_n;
             DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab256_kernel<T>), dim3(nt < 256 ? nt : 256), dim3(512), 0, (hipStream_t)stream, v));
-        } else if (vns == 1284) {       // 4 waves of 64 x 64 per 128 x 128 tile (less LDS read traffic per MFMA), 2 workgroups per CU
-            DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 2, 4>), dim3(ntiles < 512 ? ntiles : 512), dim3(256), 0,
-                                                     (hipStream_t)stream, v));
         } else {
             DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_logits_kernel<T, 2, 128, 128, 4, 8>), dim3(ntiles < 512 ? ntiles : 512), dim3(512), 0,
                                                      (hipStream_t)stream, v));
@@ -1479,8 +1473,7 @@ extern "C" int dh_vocab_logprob(const void* A, int lda, const void* W, int ldw, 
     hipStream_t s = (hipStream_t)stream;
     // 256 x 256 tiles (vocab256_kernel) once there are enough rows to fill them: without the logits stores the classifier is
     // MFMA-bound and the bigger tile pays (teacher-forced scoring of 9,000 captions: 36.5 -> 29.1 ms per pass)
-    const int lns = dh_opt(DH_OPT_LOGPROB_TILE);
-    if (lns == 256 || (lns == 0 && M >= 512)) {
+    if (M >= 512) {
         v.tiles_m = dh_cdiv(M, 256); v.tiles_n = dh_cdiv(V, 256);
         const int nt = v.tiles_m * v.tiles_n;
         DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab256_kernel<T, true>), dim3(nt < 256 ? nt : 256), dim3(512), 0, s, v));

@@ -241,31 +241,15 @@ extern "C" int dh_lstm_layer_fused(const void* x_rows, int ldx, int x_div, const
     p.W = (const uint16_t*)w_il; p.bias = b_il; p.rows = rows; p.row_mult = row_mult; p.E = E; p.Hh = Hh;
     p.tiles_m = dh_cdiv(rows, 64); p.tiles_n = dh_cdiv(4 * Hh, 64);
     const double K = E + Hh;
-    // 160-row tiles (DH_LSTM_BM=160; one full round of 256 workgroups at 1280 rows, 42 % less L2 -> LDS traffic on the busiest
-    // CU) are correct but measured SLOWER in the C2 step (1.33 vs 1.24 ms per step at any ring depth): one wave per SIMD hides
-    // less latency than the 2-3 co-resident 64 x 64 workgroups, so the small tile stays the default
-    const int force_bm = dh_opt(DH_OPT_LSTM_BM);
-    const int blocks160 = dh_cdiv(rows, 160) * p.tiles_n;
-    const bool big = force_bm == 160;
     DhProfScope prof("dh_lstm_layer_fused", 2.0 * rows * 4 * Hh * K, 2.0 * (rows * K + 4.0 * Hh * K) + 12.0 * rows * Hh, stream);
     // ring depth by workgroup count so that all tiles are co-resident in ONE round where possible (16 KB per slab):
     // measured at 1280 rows x 2048 gate columns (640 workgroups): 4 slabs (2 per CU, 1.25 rounds) 20.7 / 24.3 us,
     // 3 slabs (3 per CU) 16.6 / 19.0 us, 2 slabs (5 per CU) 16.4 / 18.6 us  (E = 256 / 512)
     const int blocks = p.tiles_m * p.tiles_n;
-    const int force_ns = dh_opt(DH_OPT_LSTM_NS);
-    if (big) {
-        p.tiles_m = dh_cdiv(rows, 160);
-        DH_DISPATCH_16(dtype, {
-            if (force_ns == 3) hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 3, 160>), dim3(blocks160), dim3(256), 0, (hipStream_t)stream, p);
-            else if (force_ns == 5) hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 5, 160>), dim3(blocks160), dim3(256), 0, (hipStream_t)stream, p);
-            else hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 4, 160>), dim3(blocks160), dim3(256), 0, (hipStream_t)stream, p);
-        });
-        DH_LAUNCH_CHECK();
-    }
     DH_DISPATCH_16(dtype, {
-        if (force_ns == 2 || (!force_ns && blocks > 768 && blocks <= 1280))
+        if (blocks > 768 && blocks <= 1280)
             hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-        else if (force_ns == 3 || (!force_ns && blocks > 512 && blocks <= 768))
+        else if (blocks > 512 && blocks <= 768)
             hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
         else
             hipLaunchKernelGGL((lstm_layer_fused_kernel<T, 4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);

@@ -9,9 +9,6 @@
 #include "options.h"
 
 // Kernel selection here goes through the option table (options.h; dh_set_option): every use reads the current value.
-// "qkv_fusion_max_rows": dh_attn_self_qkv_decode replaces the QKV GEMM + self-attention pair of a decode position only up to
-// this many rows: at 1280 rows (256 images x beam 5) it takes 30.5 us against 12.1 + 13.5 us for the pair (its attention part
-// runs 8 waves per CU instead of 40 and is latency-bound), measured per C3 step: 29.4 vs 28.1 ms.
 
 static int cross_attention(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* q, void* att, int n_img, int rows_per_img,
                            int dt, void* stream) {
@@ -27,7 +24,7 @@ static int classifier_groups(const void* A, int lda, const void* W, const float*
                              int ldl, float* group_max, int gm_ld, int rows, int V, int K, int dt, void* stream) {
     if (dh_opt(DH_OPT_VOCAB_WREG) && W_pk && bias_pad && logits && dh_vocab_logits_wreg_supported(rows, V, K, ldl, gm_ld))
         return dh_vocab_logits_wreg(A, lda, W_pk, bias_pad, logits, ldl, group_max, gm_ld, rows, V, K, dt, stream);
-    if (logits && K == 512 && rows >= 768 && (rows % 256) != 0 && dh_opt(DH_OPT_VOCAB_AREG) && dh_opt(DH_OPT_VOCAB_SPLIT_ROWS)) {
+    if (logits && K == 512 && rows >= 768 && (rows % 256) != 0 && dh_opt(DH_OPT_VOCAB_AREG)) {
         // a row count that is no multiple of 256 (C5: 300 templates x beam 10 = 3,000 rows) would take the 128 x 128 tile kernel for
         // ALL rows (211 us at 3,000 rows): the whole 256-row tiles go through the A-stationary 256-row kernel, the remainder through
         // the 128-row one -- rows are independent and every classifier kernel is bit-identical to dh_linear, so are the results
@@ -50,41 +47,6 @@ static int chain_linear(const void* A, int lda, const void* W, const void* W_pk,
     return dh_linear_ln(A, lda, W, K, bias, res, ldres, C, ldc, rows, N, K, relu, f, dt, stream);
 }
 
-// fc_q of the encoder attention as its own GEMM (option "cross_qproj" = 0).  With option "cross_kv_prefetch" = n > 0 and packed K / V,
-// the launches in front of the attention carry n extra workgroups each that pull the (image, head) tiles it will read into the L2 of the
-// XCD its workgroups run on (attn_cross_mfma_kernel: workgroup g = 4 consecutive (image, head) tiles; K rows >= S are never read):
-// fc_o of the self-attention takes part 0 of 2, fc_q part 1 of 2 -- 15 MB each at 256 images, under two latency-bound 5 us GEMMs.
-static bool cross_prefetch(const dh_tr_model_t* m, const dh_tr_layer_t& L, int rows, int n_img, int rows_per_img, int dt, int part,
-                           dh_l2_prefetch_t* pf) {
-    const int D = m->D;
-    if (dh_opt(DH_OPT_CROSS_KV_PREFETCH) <= 0 || dh_opt(DH_OPT_CROSS_QPROJ) || !m->cross) return false;
-    if (!(L.kp && L.vt && DH_IS_16BIT(dt) && m->S <= 64 && D == 64 * m->n_heads && D == 512 && rows_per_img <= 16)) return false;
-    if (!(dh_opt(DH_OPT_DECODE_WREG) && L.wq_pk && L.wo_pk && rows >= dh_opt(DH_OPT_DECODE_WREG_MIN_ROWS))) return false;
-    *pf = dh_l2_prefetch_t{};
-    pf->base[0] = L.kp; pf->base[1] = L.vt; pf->tile_stride = 8192; pf->tile_bytes[0] = (uint32_t)m->S * 128u; pf->tile_bytes[1] = 8192;
-    pf->n_tiles = n_img * m->n_heads; pf->tiles_per_group = 4; pf->part = part; pf->parts = 2;
-    return true;
-}
-
-static int cross_query(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* y, void* q, int rows, int n_img, int rows_per_img,
-                       const dh_ln_fold_t* f, int dt, void* stream) {
-    const int D = m->D;
-    dh_l2_prefetch_t pf;
-    if (cross_prefetch(m, L, rows, n_img, rows_per_img, dt, 1, &pf) && dh_linear_ln_wreg_occupancy(rows, D, D, 0) >= 0.85)
-        return dh_linear_ln_wreg_prefetch(y, D, L.wq_pk, L.bq_f, nullptr, 0, q, D, rows, D, D, 0, f, &pf, dh_opt(DH_OPT_CROSS_KV_PREFETCH), dt, stream);
-    return chain_linear(y, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, q, D, rows, D, D, 0, f, dt, stream);
-}
-
-// fc_o of the self-attention in front of it (residual form): carries the other half of the prefetch
-static int self_out(const dh_tr_model_t* m, const dh_tr_layer_t& L, const void* att, const void* x, void* o, int rows, int n_img,
-                    int rows_per_img, const dh_ln_fold_t* f, int dt, void* stream) {
-    const int D = m->D;
-    dh_l2_prefetch_t pf;
-    if (cross_prefetch(m, L, rows, n_img, rows_per_img, dt, 0, &pf) && f->o_stats && dh_linear_ln_wreg_occupancy(rows, D, D, 1) >= 0.85)
-        return dh_linear_ln_wreg_prefetch(att, D, L.wo_pk, L.bo, x, D, o, D, rows, D, D, 0, f, &pf, dh_opt(DH_OPT_CROSS_KV_PREFETCH), dt, stream);
-    return chain_linear(att, D, L.wo, L.wo_pk, L.bo, x, D, o, D, rows, D, D, 0, f, dt, stream);
-}
-
 // One dense layer of the plain (non-deferred) chains: fp32 models with split planes (option "f32_split") run it as three fp16
 // MFMAs on split operands (gemm_f32x.hip), everything else through dh_linear.
 static int plain_linear(const void* A, int lda, const void* W, const void* W_x, int ldw, const float* bias, void* C, int ldc, int rows, int N,
@@ -102,114 +64,33 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
                                     const int32_t* src, int src_ld, int n_img, int rows_per_img, int row_mult, int rows_total,
                                     int t, void* x_final, void* stream) {
     const int rows = n_img * rows_per_img, D = m->D, PF = m->pf_dim, dt = m->dtype, nt = D / 64;
-    // Option "decode_chain_fusion": the GEMMs that follow each other without an attention launch in between -- (enc_)fc_o -> fc_1 ->
-    // fc_2 -> the NEXT layer's fc_q|k|v -- as ONE persistent launch with XCD-local hand-overs (csrc/linear_wreg.hip,
-    // decode_gemm_chain_kernel; bit-identical): 4 launches per layer instead of 7 (3 instead of 6 without encoder attention)
-    bool chain = dh_opt(DH_OPT_DECODE_CHAIN_FUSION) && sc->chain_sync && dh_opt(DH_OPT_DECODE_WREG) && rows > dh_opt(DH_OPT_QKV_FUSION_MAX_ROWS) &&
-                 dh_decode_gemm_chain_supported(D, D, 1) && dh_decode_gemm_chain_supported(PF, D, 0) && dh_decode_gemm_chain_supported(D, PF, 1) &&
-                 dh_decode_gemm_chain_supported(3 * D, D, 0) && nt == 8;
-    for (int l = 0; l < m->n_layers && chain; ++l) {
-        const dh_tr_layer_t& L = m->layers[l];
-        chain = L.w1_pk && L.w2_pk && L.wqkv_pk && (m->cross ? (L.weo_pk != nullptr) : (L.wo_pk != nullptr));
-    }
     for (int l = 0; l < m->n_layers; ++l) {
         const dh_tr_layer_t& L = m->layers[l];
         const dh_tr_layer_t* P = l > 0 ? &m->layers[l - 1] : nullptr;       // its LN3 is pending on X
         dh_ln_fold_t f{};
-        if (chain) {
-            // qkv of layer l > 0 came out of layer l - 1's chain launch
-            if (!P) {
-                dh_prof_set_tag("qkv");
-                DH_TRY(chain_linear(sc->x, D, L.wqkv, L.wqkv_pk, L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
-            }
-            DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
-                                       row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
-            dh_chain_step_t st[4] = {};
-            int ns = 0;
-            const void* yin; const float* st_in; const float *g_in, *b_in; float eps_in;
-            // fc_o: Y1 = LN3_prev(X) + att Wo^T + bo, statistics -> st1
-            dh_chain_step_t fo{};
-            fo.A = sc->att; fo.lda = D; fo.w_packed = L.wo_pk; fo.bias = L.bo; fo.residual = sc->x; fo.ldres = D; fo.C = sc->o; fo.ldc = D;
-            fo.N = D; fo.K = D;
-            if (P) { fo.ln.r_stats = sc->st0; fo.ln.r_tiles = nt; fo.ln.r_eps = P->ln3_eps; fo.ln.r_gamma = P->ln3_g; fo.ln.r_beta = P->ln3_b; }
-            fo.ln.o_stats = sc->st1;
-            if (m->cross) {
-                dh_prof_set_tag("proj");
-                f = fo.ln;
-                DH_TRY(self_out(m, L, sc->att, sc->x, sc->o, rows, n_img, rows_per_img, &f, dt, stream));
-                if (dh_opt(DH_OPT_CROSS_QPROJ) && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
-                    DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
-                                                      n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
-                } else {
-                    f = dh_ln_fold_t{};
-                    f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
-                    dh_prof_set_tag("proj");
-                    DH_TRY(cross_query(m, L, sc->o, sc->q, rows, n_img, rows_per_img, &f, dt, stream));
-                    DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
-                }
-                // enc fc_o: Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2
-                dh_chain_step_t& e = st[ns++];
-                e.A = sc->att; e.lda = D; e.w_packed = L.weo_pk; e.bias = L.beo; e.residual = sc->o; e.ldres = D; e.C = sc->y2; e.ldc = D; e.N = D; e.K = D;
-                e.ln.r_stats = sc->st1; e.ln.r_tiles = nt; e.ln.r_eps = L.ln1_eps; e.ln.r_gamma = L.ln1_g; e.ln.r_beta = L.ln1_b; e.ln.o_stats = sc->st2;
-                yin = sc->y2; st_in = sc->st2; g_in = L.ln2_g; b_in = L.ln2_b; eps_in = L.ln2_eps;
-            } else {
-                st[ns++] = fo;
-                yin = sc->o; st_in = sc->st1; g_in = L.ln1_g; b_in = L.ln1_b; eps_in = L.ln1_eps;
-            }
-            {   // fc_1: ff = relu(LN(Yin) W1^T + b1)
-                dh_chain_step_t& e = st[ns++];
-                e.A = yin; e.lda = D; e.w_packed = L.w1_pk; e.bias = L.b1_f; e.C = sc->ff; e.ldc = PF; e.N = PF; e.K = D; e.relu = 1;
-                e.ln.a_stats = st_in; e.ln.a_tiles = nt; e.ln.a_eps = eps_in; e.ln.a_colsum = L.cs_1;
-            }
-            {   // fc_2: X = LN(Yin) + ff W2^T + b2, statistics -> st0
-                dh_chain_step_t& e = st[ns++];
-                e.A = sc->ff; e.lda = PF; e.w_packed = L.w2_pk; e.bias = L.b2; e.residual = yin; e.ldres = D; e.C = sc->x; e.ldc = D; e.N = D; e.K = PF;
-                e.ln.r_stats = st_in; e.ln.r_tiles = nt; e.ln.r_eps = eps_in; e.ln.r_gamma = g_in; e.ln.r_beta = b_in; e.ln.o_stats = sc->st0;
-            }
-            if (l + 1 < m->n_layers) {   // the next layer's qkv = LN3(X) Wqkv^T + b
-                const dh_tr_layer_t& Nx = m->layers[l + 1];
-                dh_chain_step_t& e = st[ns++];
-                e.A = sc->x; e.lda = D; e.w_packed = Nx.wqkv_pk; e.bias = Nx.bqkv_f; e.C = sc->qkv; e.ldc = 3 * D; e.N = 3 * D; e.K = D;
-                e.ln.a_stats = sc->st0; e.ln.a_tiles = nt; e.ln.a_eps = L.ln3_eps; e.ln.a_colsum = Nx.cs_qkv;
-            }
-            DH_TRY(dh_decode_gemm_chain(st, ns, rows, sc->chain_sync, dt, stream));
-            continue;
-        }
-        // 1. qkv = LN3_prev(X) Wqkv^T + b  (layer 0: X is the embedding, no LayerNorm in front) and the self-attention over the
-        //    row's history: ONE launch where the fused kernel applies (head dim 64, <= 6 rows per image, <= 40 positions)
-        if (rows <= dh_opt(DH_OPT_QKV_FUSION_MAX_ROWS) && D == 64 * m->n_heads && rows_per_img <= 6 && t <= 39) {
-            DH_TRY(dh_attn_self_qkv_decode(sc->x, D, P ? sc->st0 : nullptr, nt, P ? P->ln3_eps : 0.f, P ? L.cs_qkv : nullptr,
-                                           P ? L.wqkv_f : L.wqkv, P ? L.bqkv_f : L.bqkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld,
-                                           sc->att, n_img, rows_per_img, row_mult, rows_total, t, D, m->n_heads, L.sa_scale,
-                                           m->pad_index, dt, stream));
-        } else {
-            if (P) { f.a_stats = sc->st0; f.a_tiles = nt; f.a_eps = P->ln3_eps; f.a_colsum = L.cs_qkv; }
-            dh_prof_set_tag("qkv");
-            DH_TRY(chain_linear(sc->x, D, P ? L.wqkv_f : L.wqkv, L.wqkv_pk, P ? L.bqkv_f : L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
-            DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
-                                       row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
-        }
+        // 1. qkv = LN3_prev(X) Wqkv^T + b  (layer 0: X is the embedding, no LayerNorm in front), then the self-attention over the
+        //    row's history
+        if (P) { f.a_stats = sc->st0; f.a_tiles = nt; f.a_eps = P->ln3_eps; f.a_colsum = L.cs_qkv; }
+        dh_prof_set_tag("qkv");
+        DH_TRY(chain_linear(sc->x, D, P ? L.wqkv_f : L.wqkv, L.wqkv_pk, P ? L.bqkv_f : L.bqkv, nullptr, 0, sc->qkv, 3 * D, rows, 3 * D, D, 0, &f, dt, stream));
+        DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
+                                   row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
         // 2. Y1 = LN3_prev(X) + att Wo^T + bo, statistics of Y1 -> st1
         f = dh_ln_fold_t{};
         if (P) { f.r_stats = sc->st0; f.r_tiles = nt; f.r_eps = P->ln3_eps; f.r_gamma = P->ln3_g; f.r_beta = P->ln3_b; }
         f.o_stats = sc->st1;
         dh_prof_set_tag("proj");
-        DH_TRY(self_out(m, L, sc->att, sc->x, sc->o, rows, n_img, rows_per_img, &f, dt, stream));
+        DH_TRY(chain_linear(sc->att, D, L.wo, L.wo_pk, L.bo, sc->x, D, sc->o, D, rows, D, D, 0, &f, dt, stream));
         const void* yin = sc->o; const float* st_in = sc->st1;               // rows entering the FFN block, LayerNorm pending
         const float *g_in = L.ln1_g, *b_in = L.ln1_b; float eps_in = L.ln1_eps;
         if (m->cross) {
-            // 3. q = LN1(Y1) Wq^T + bq and the attention over the image's patches: ONE launch when K was packed for it
-            // option "cross_qproj" = 0: fc_q as its own (register-stationary) GEMM, then the packed attention -- A/B of the fused launch
-            if (dh_opt(DH_OPT_CROSS_QPROJ) && L.kp && L.vt && L.kp_dperm && m->S <= 64 && D == 64 * m->n_heads && rows_per_img <= 16) {
-                DH_TRY(dh_attn_cross_qproj_decode(sc->o, D, sc->st1, nt, L.ln1_eps, L.wq_f, L.bq_f, L.cs_q, L.kp, L.vt, m->keymask, sc->att,
-                                                  n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale, dt, stream));
-            } else {
-                f = dh_ln_fold_t{};
-                f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
-                dh_prof_set_tag("proj");
-                DH_TRY(cross_query(m, L, sc->o, sc->q, rows, n_img, rows_per_img, &f, dt, stream));
-                DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
-            }
+            // 3. q = LN1(Y1) Wq^T + bq (its own register-stationary GEMM), then the attention over the image's patches on the packed
+            //    K / V^T tiles (the fused fc_q + attention launch of rounds 2-5 took the same time per step and was removed in round 6)
+            f = dh_ln_fold_t{};
+            f.a_stats = sc->st1; f.a_tiles = nt; f.a_eps = L.ln1_eps; f.a_colsum = L.cs_q;
+            dh_prof_set_tag("proj");
+            DH_TRY(chain_linear(sc->o, D, L.wq_f, L.wq_pk, L.bq_f, nullptr, 0, sc->q, D, rows, D, D, 0, &f, dt, stream));
+            DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
             // 4. Y2 = LN1(Y1) + att Weo^T + beo, statistics -> st2
             f = dh_ln_fold_t{};
             f.r_stats = sc->st1; f.r_tiles = nt; f.r_eps = L.ln1_eps; f.r_gamma = L.ln1_g; f.r_beta = L.ln1_b; f.o_stats = sc->st2;

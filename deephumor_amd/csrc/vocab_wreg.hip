@@ -224,11 +224,7 @@ extern "C" int dh_vocab_logits_wreg(const void* A, int lda, const void* w_packed
     dh_prof_set_dims(M, V, K);
     DhProfScope prof("dh_linear", 2.0 * M * V * K, 2.0 * ((double)M * K + (double)V * K) + 4.0 * M * V, stream);
     hipStream_t s = (hipStream_t)stream;
-    p.nt = dh_opt(DH_OPT_VOCAB_WREG_NT);
-    const bool prefetch = dh_opt(DH_OPT_VOCAB_WREG_PREFETCH) != 0;
-    DH_DISPATCH_16(dtype, {
-        if (prefetch) hipLaunchKernelGGL((vocab_wreg_kernel<T, true>), dim3(256), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((vocab_wreg_kernel<T, false>), dim3(256), dim3(256), 0, s, p);
-    });
+    p.nt = 1;                                            // non-temporal logits stores (plain ones evict the weights: measured slower)
+    DH_DISPATCH_16(dtype, hipLaunchKernelGGL((vocab_wreg_kernel<T, true>), dim3(256), dim3(256), 0, s, p));
     DH_LAUNCH_CHECK();
 }

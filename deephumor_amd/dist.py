@@ -30,8 +30,11 @@ def _skip_collective(group, always):
     if not (dist.is_available() and dist.is_initialized()):
         return True
     if always is None:
-        from . import hip
-        always = bool(hip.option("dist_always"))
+        try:
+            from . import hip
+            always = bool(hip.option("dist_always"))
+        except (RuntimeError, OSError):    # gloo / CPU ranks on a box without the GPU library: the option's environment default
+            always = os.environ.get("DH_DIST_ALWAYS", "0") not in ("", "0")
     return dist.get_world_size(group) == 1 and not always
 
 

@@ -11,172 +11,11 @@ import torch
 
 from . import _build
 
-F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 29
-HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
-ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW, ERR_NONFINITE = 1, 2, 4, 8
-MAX_BEAMS = 64
+from ._abi import (ABI_VERSION, BF16, BF16_OUT_F32, ERR_ALL_FILTERED, ERR_NONFINITE, ERR_OVERFLOW, ERR_TOO_FEW, F16, F16_OUT_F32, F32,  # noqa: F401
+                   HALF_DTYPES, MAX_BEAMS, SIGNATURES, LnFold, LstmLayer, LstmModel, LstmScratch, TrLayer, TrModel, TrScratch)
 
 _c = ctypes
 _P, _I, _F, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64
-
-class TrLayer(_c.Structure):
-    _fields_ = ([(n, _P) for n in ("wqkv", "wo", "w1", "w2", "wq", "weo", "bqkv", "bo", "b1", "b2", "bq", "beo",
-                                   "ln1_g", "ln1_b", "ln2_g", "ln2_b", "ln3_g", "ln3_b")]
-                + [(n, _F) for n in ("ln1_eps", "ln2_eps", "ln3_eps", "sa_scale", "ea_scale")] + [("_pad", _I)]
-                + [(n, _P) for n in ("kcache", "vcache", "kv")]
-                + [(n, _P) for n in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1", "kp", "vt")]
-                + [("kp_dperm", _I), ("_pad2", _I)]
-                + [(n, _P) for n in ("wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk")]
-                + [(n, _P) for n in ("wqkv_x", "wo_x", "w1_x", "w2_x", "wq_x", "weo_x")])
-
-
-class TrModel(_c.Structure):
-    _fields_ = ([(n, _I) for n in ("n_layers", "D", "n_heads", "pf_dim", "V", "pad_index", "cross", "S", "dtype")]
-                + [("emb_scale", _F), ("layers", _c.POINTER(TrLayer))]
-                + [(n, _P) for n in ("tok_emb", "pos_emb", "cls_w", "cls_b", "keymask", "cls_w_pk", "cls_b_pad", "cls_w_x")])
-
-
-class TrScratch(_c.Structure):
-    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2", "chain_sync")]
-
-
-class LnFold(_c.Structure):
-    """``dh_ln_fold_t``: deferred-LayerNorm options of ``dh_linear_ln``."""
-    _fields_ = [("a_stats", _P), ("a_tiles", _I), ("a_eps", _F), ("a_colsum", _P),
-                ("r_stats", _P), ("r_tiles", _I), ("r_eps", _F), ("r_gamma", _P), ("r_beta", _P), ("o_stats", _P)]
-
-
-class L2Prefetch(_c.Structure):
-    """``dh_l2_prefetch_t``: the next kernel's operand tiles, for ``dh_linear_ln_wreg_prefetch``."""
-    _fields_ = [("base0", _P), ("base1", _P), ("tile_stride", _c.c_uint32), ("tile_bytes0", _c.c_uint32), ("tile_bytes1", _c.c_uint32),
-                ("n_tiles", _I), ("tiles_per_group", _I), ("part", _I), ("parts", _I)]
-
-
-class ChainStep(_c.Structure):
-    """``dh_chain_step_t``: one GEMM of ``dh_decode_gemm_chain``."""
-    _fields_ = [("A", _P), ("lda", _I), ("w_packed", _P), ("bias", _P), ("residual", _P), ("ldres", _I), ("C", _P), ("ldc", _I),
-                ("N", _I), ("K", _I), ("relu", _I), ("_pad", _I), ("ln", LnFold)]
-
-
-class LstmLayer(_c.Structure):
-    _fields_ = [("w", _P), ("b", _P), ("w_il", _P), ("b_il", _P), ("w_pk", _P), ("w_x", _P)]
-
-
-class LstmModel(_c.Structure):
-    _fields_ = ([(n, _I) for n in ("n_layers", "E", "Hh", "V", "dtype", "_pad")] + [("layers", _c.POINTER(LstmLayer))]
-                + [(n, _P) for n in ("emb", "cls_w", "cls_b", "h", "c", "h_alt", "c_alt", "cls_w_pk", "cls_b_pad", "cls_w_x")])
-
-
-class LstmScratch(_c.Structure):
-    _fields_ = [(n, _P) for n in ("xcat0", "xcatl", "c_cur", "gates", "hout")]
-
-
-# name -> argtypes, mirrors include/deephumor_hip.h line by line
-SIGNATURES = {
-    "dh_abi_version": [],
-    "dh_conv2d_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 11 + [_P],
-    "dh_stem_conv_nhwc": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P],
-    "dh_pack_nchw_to_nhwc8": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_round16_keep_nonzero": [_P, _P, _c.c_longlong, _I, _P],
-    "dh_conv3x3_direct_supported": [_I, _I, _I, _I],
-    "dh_conv3x3_direct_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dh_bottleneck_tail_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_bottleneck_tail_s3_supported": [_I, _I, _I],
-    "dh_bottleneck_tail_s1_supported": [_I, _I, _I, _I],
-    "dh_bottleneck_tail_s1_nhwc": [_P] * 13 + [_I] * 6 + [_P],
-    "dh_bottleneck_tail_s2_supported": [_I, _I, _I],
-    "dh_bottleneck_tail_s2_nhwc": [_P] * 13 + [_I] * 6 + [_P],
-    "dh_conv3x3_s4_supported": [_I, _I, _I],
-    "dh_conv3x3_s4_nhwc": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_bottleneck_tail_s3_nhwc": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_pack_mfma_fragments": [_P, _P, _I, _I, _P],
-    "dh_conv1x1_wreg_supported": [_c.c_longlong, _I, _I],
-    "dh_conv1x1_wreg_nhwc": [_P, _P, _P, _P, _P, _P, _c.c_longlong, _I, _I, _I, _I, _P],
-    "dh_stem_conv7_bn_relu_maxpool": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "dh_conv1x1_dual_nhwc": [_P, _P, _P, _P, _P] + [_I] * 11 + [_P],
-    "dh_conv1x1_dual_wreg_supported": [_I] * 8,
-    "dh_conv1x1_dual_wreg_nhwc": [_P, _P, _P, _P, _P] + [_I] * 10 + [_P, _P, _P, _P, _I, _I, _P],
-    "dh_normalize_u8_hwc": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "dh_resize_u8_hwc": [_P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dh_normalize_pack_u8": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_maxpool3x3s2_nhwc": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_avgpool_nhwc": [_P, _P, _I, _I, _I, _I, _P],
-    "dh_maxpool3x3s2": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_avgpool_rows": [_P, _P, _I, _I, _I, _P],
-    "dh_nchw_to_rows": [_P, _P, _I, _I, _I, _I, _P],
-    "dh_label_mean": [_P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_linear": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P],
-    "dh_linear_ln": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
-    "dh_linear_ln_wreg_supported": [_I, _I, _I],
-    "dh_linear_ln_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _I, _P],
-    "dh_linear_ln_wreg_prefetch": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _c.POINTER(LnFold), _P, _I, _I, _P],
-    "dh_attn_cross_pack": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
-    "dh_attn_cross_qproj_decode": [_P, _I, _P, _I, _F, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
-    "dh_attn_cross_decode_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
-    "dh_attn_cross_prefill_packed": [_P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
-    "dh_conv2d_nhwc_bn_act": [_P, _P, _P, _P, _P, _P] + [_I] * 10 + [_P],
-    "dh_conv2d_nhwc_bn_relu_maxpool": [_P, _P, _P, _P, _P] + [_I] * 9 + [_P],
-    "dh_embed_rows": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _I, _P],
-    "dh_add_layernorm": [_P, _P, _P, _P, _P, _I, _I, _F, _I, _P],
-    "dh_attn_self_decode": [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
-    "dh_attn_cross_decode": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
-    "dh_attn_self_qkv_decode": [_P, _I, _P, _I, _F, _P, _P, _P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
-    "dh_enc_key_mask": [_P, _P, _I, _I, _I, _P],
-    "dh_pad_mask": [_P, _P, _I, _I, _I, _c.c_longlong, _P],
-    "dh_autoregressive_mask": [_P, _I, _I, _P],
-    "dh_mask_or": [_P, _P, _c.c_longlong, _P],
-    "dh_enc_nonzero_rows": [_P, _P, _I, _I, _I, _P],
-    "dh_attn_masked": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P],
-    "dh_lstm_prepare": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dh_lstm_cell": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_embed_prefill": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _F, _I, _P],
-    "dh_attn_self_prefill": [_P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P],
-    "dh_attn_cross_prefill": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],
-    "dh_lstm_layer_fused": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_lstm_layer_wreg_supported": [_I, _I],
-    "dh_lstm_layer_wreg": [_P, _I, _I, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_beam_row_sample": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
-    "dh_beam_row_sample_exact": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
-    "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
-                       _U64, _P, _I, _P],
-    "dh_transformer_decode_position": [_c.POINTER(TrModel), _c.POINTER(TrScratch), _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
-                                       _P, _P, _I, _P, _I, _P],
-    "dh_lstm_decode_step": [_c.POINTER(LstmModel), _c.POINTER(LstmScratch), _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P,
-                            _I, _P, _I, _P, _I, _P],
-    "dh_vocab_logprob": [_P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_vocab_logits": [_P, _I, _P, _I, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "dh_vocab_logits_wreg_supported": [_I] * 5,
-    "dh_vocab_logits_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "dh_beam_step_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _P,
-                            _P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
-    "dh_beam_row_sample_groups": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
-    "dh_token_logprob": [_P, _I, _I, _P, _P, _I, _P],
-    "dh_seq_perplexity": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "dh_prof_begin": [_c.c_char_p],
-    "dh_prof_set_stride": [_I],
-    "dh_prof_end": [],
-    "dh_prof_num": [],
-    "dh_prof_get": [_I, _c.c_char_p, _I, _c.POINTER(_I), _c.POINTER(_c.c_double), _c.POINTER(_c.c_double),
-                    _c.POINTER(_c.c_double)],
-    "dh_beam_finalize": [_P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _U64, _P, _I, _P],
-    "dh_beam_filter_top_k": [_P, _I, _I, _I, _I, _I, _P],
-    "dh_beam_sample_k": [_P, _I, _I, _I, _I, _F, _P, _I, _U64, _P, _I, _I, _P, _P, _P],
-    "dh_beam_gather": [_P, _I, _I, _P, _I, _P, _I, _P, _P],
-    "dh_beam_expand": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "dh_decode_gemm_chain_supported": [_I, _I, _I],
-    "dh_decode_gemm_chain": [_c.POINTER(ChainStep), _I, _I, _P, _I, _P],
-    "dh_split_f32x": [_P, _I, _P, _I, _I, _I, _P],
-    "dh_linear_f32x": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
-    "dh_conv2d_nhwc_f32x": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 9 + [_P],
-    "dh_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
-    "dh_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
-    "dh_avgpool_nhwc_f32": [_P, _P, _I, _I, _I, _P],
-    "dh_option_count": [],
-    "dh_get_option": [_c.c_char_p, _c.POINTER(_I)],
-    "dh_set_option": [_c.c_char_p, _I],
-}
-
 
 
 _lib = None
@@ -605,11 +444,10 @@ def linear_ln_wreg_supported(n, k, with_residual_stats):
     return bool(load().dh_linear_ln_wreg_supported(int(n), int(k), int(bool(with_residual_stats))))
 
 
-def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_ln=None, r_ln=None, tag=None, prefetch=None):
+def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_ln=None, r_ln=None, tag=None):
     """``dh_linear_ln_wreg``: ``linear_ln`` on ``w_packed = pack_mfma_fragments(w [n, k])`` -- the register-stationary decode
     GEMM (bit-identical results).  With ``residual`` the partial statistics of the output rows are always produced and
-    returned: ``(out, stats)``.  ``prefetch = (t0, t1, tile_stride, bytes0, bytes1, n_tiles, tiles_per_group, n_pf[, part, parts])``:
-    ``dh_linear_ln_wreg_prefetch`` -- ``n_pf`` extra workgroups pull those tiles (the next kernel's operands) into L2."""
+    returned: ``(out, stats)``."""
     _dev(a, w_packed, bias, out, residual)
     m, k = a.shape
     assert a.dtype in HALF_DTYPES and a.dtype == w_packed.dtype and a.stride(1) == 1 and w_packed.numel() == n * k
@@ -624,42 +462,10 @@ def linear_ln_wreg(a, w_packed, n, bias, out=None, residual=None, relu=False, a_
         f.r_stats, f.r_tiles, f.r_eps, f.r_gamma, f.r_beta = _ptr(st), n // 64, float(eps), _ptr(gamma), _ptr(beta)
     stats = torch.empty((m, n // 64, 2), dtype=torch.float32, device=a.device) if residual is not None else None
     f.o_stats = _ptr(stats)
-    if prefetch is not None:
-        t0, t1, stride, b0, b1, n_tiles, tpg, n_pf = prefetch[:8]
-        part, parts = prefetch[8:] if len(prefetch) > 8 else (0, 1)
-        _dev(t0, t1)
-        pf = L2Prefetch(_ptr(t0), _ptr(t1), int(stride), int(b0), int(b1), int(n_tiles), int(tpg), int(part), int(parts))
-        _launch("dh_linear_ln_wreg_prefetch", _ptr(a), a.stride(0), _ptr(w_packed), _ptr(bias), _ptr(residual),
-                residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
-                _c.byref(pf), int(n_pf), _dt(a), _stream(), tag=tag)
-        return (out, stats) if residual is not None else out
     _launch("dh_linear_ln_wreg", _ptr(a), a.stride(0), _ptr(w_packed), _ptr(bias), _ptr(residual),
             residual.stride(0) if residual is not None else 0, _ptr(out), out.stride(0), m, n, k, int(relu), _c.byref(f),
             _dt(a), _stream(), tag=tag)
     return (out, stats) if residual is not None else out
-
-
-def decode_gemm_chain(steps, m, sync):
-    """``dh_decode_gemm_chain``: up to four dependent ``linear_ln_wreg`` GEMMs as ONE launch.  ``steps``: dicts with ``a``, ``w_packed``,
-    ``n``, ``bias``, ``out`` and optionally ``residual``, ``relu``, ``a_ln`` (stats, eps, colsum), ``r_ln`` (stats, eps, gamma, beta),
-    ``o_stats`` (required with ``residual``); ``sync``: int32 tensor of >= 74 zeros, private to the stream."""
-    arr = (ChainStep * len(steps))()
-    for c, st in zip(arr, steps):
-        a, out = st["a"], st["out"]
-        _dev(a, st["w_packed"], st["bias"], out, st.get("residual"))
-        c.A, c.lda, c.w_packed, c.bias, c.C, c.ldc = _ptr(a), a.stride(0), _ptr(st["w_packed"]), _ptr(st["bias"]), _ptr(out), out.stride(0)
-        c.N, c.K, c.relu = int(st["n"]), a.shape[1], int(bool(st.get("relu")))
-        res = st.get("residual")
-        if res is not None:
-            c.residual, c.ldres = _ptr(res), res.stride(0)
-            c.ln.o_stats = _ptr(st["o_stats"])
-        if st.get("a_ln") is not None:
-            stats, eps, colsum = st["a_ln"]
-            c.ln.a_stats, c.ln.a_tiles, c.ln.a_eps, c.ln.a_colsum = _ptr(stats), a.shape[1] // 64, float(eps), _ptr(colsum)
-        if st.get("r_ln") is not None:
-            stats, eps, gamma, beta = st["r_ln"]
-            c.ln.r_stats, c.ln.r_tiles, c.ln.r_eps, c.ln.r_gamma, c.ln.r_beta = _ptr(stats), int(st["n"]) // 64, float(eps), _ptr(gamma), _ptr(beta)
-    _launch("dh_decode_gemm_chain", arr, len(steps), int(m), _ptr(sync), _dt(steps[0]["a"]), _stream())
 
 
 def attn_cross_pack(kv, n_img, s, d, n_heads, dperm=False):
@@ -670,14 +476,6 @@ def attn_cross_pack(kv, n_img, s, d, n_heads, dperm=False):
     vt = torch.empty_like(kp)
     _launch("dh_attn_cross_pack", _ptr(kv), _ptr(kp), _ptr(vt), n_img, s, d, n_heads, int(dperm), _dt(kv), _stream())
     return kp, vt
-
-
-def attn_cross_qproj_decode(y, stats, eps, wq_f, bq_f, colsum, kp_dperm, vt, keymask, out, n_img, rows_per_img, s, d, n_heads, scale):
-    """fc_q(LayerNorm(y)) + cross-attention in one launch (deferred-LayerNorm chain): see include/deephumor_hip.h."""
-    _dev(y, stats, wq_f, bq_f, colsum, kp_dperm, vt, keymask, out)
-    _launch("dh_attn_cross_qproj_decode", _ptr(y), y.stride(0), _ptr(stats), d // 64, float(eps), _ptr(wq_f), _ptr(bq_f), _ptr(colsum),
-            _ptr(kp_dperm), _ptr(vt), _ptr(keymask), _ptr(out), n_img, rows_per_img, s, d, n_heads, float(scale), _dt(y), _stream())
-    return out
 
 
 def attn_cross_decode_packed(q, kp, vt, keymask, out, n_img, rows_per_img, s, d, n_heads, scale, dperm=False):
@@ -904,18 +702,6 @@ def attn_self_decode(qkv, kcache, vcache, src, tokens, out, n_img, rows_per_img,
     return out
 
 
-def attn_self_qkv_decode(x, wqkv, bqkv, kcache, vcache, src, tokens, out, n_img, rows_per_img, row_mult, rows_total, t, d,
-                         n_heads, scale, pad_index, a_ln=None):
-    """QKV projection + self-attention + cache append in one launch; ``a_ln = (stats, eps, colsum)`` when ``x`` is pre-LayerNorm."""
-    _dev(x, wqkv, bqkv, kcache, vcache, src, tokens, out)
-    st, eps, cs = a_ln if a_ln is not None else (None, 0.0, None)
-    _launch("dh_attn_self_qkv_decode", _ptr(x), x.stride(0), _ptr(st), d // 64, float(eps), _ptr(cs), _ptr(wqkv), _ptr(bqkv),
-            _ptr(kcache), _ptr(vcache), _ptr(src), src.stride(0) if src is not None else 0, _ptr(tokens),
-            tokens.stride(0) if tokens is not None else 0, _ptr(out), n_img, rows_per_img, row_mult, rows_total, t, d, n_heads,
-            float(scale), pad_index, _dt(x), _stream())
-    return out
-
-
 def attn_cross_decode(q, kv, keymask, out, n_img, rows_per_img, s, d, n_heads, scale):
     _dev(q, kv, keymask, out)
     _launch("dh_attn_cross_decode", _ptr(q), q.stride(0), _ptr(kv), _ptr(keymask), _ptr(out), n_img,
@@ -1093,19 +879,6 @@ def beam_row_sample_groups(logits, v, group_max, rows, rows_per_img, beam, top_k
             _ptr(seed_ptr), img0, step, _ptr(pick_idx), _ptr(pick_val), _ptr(err), _stream())
 
 
-SEL_STAGE_MAX = 3072      # ints of LDS the fused beam step has for an image's token + ancestor rows (DH_SEL_STAGE_MAX)
-
-
-def beam_step_groups(logits, v, group_max, rows, rows_per_img, beam, top_k, temperature, unk_index, row_noise, seed, img0, step,
-                     pick_idx, pick_val, err, tokens, vals, ended, src, parent, hparent, done, end_step, first, first_sets_ended,
-                     write_pos, t, eos_index, cand_noise, arrive, seed_ptr=None):
-    """``beam_row_sample_groups`` + ``beam_select`` as one launch (same results)."""
-    _dev(logits, group_max, row_noise, pick_idx, pick_val, err, tokens, vals, ended, src, parent, hparent, done, end_step, cand_noise, arrive)
-    _launch("dh_beam_step_groups", _ptr(logits), logits.stride(0), v, _ptr(group_max), group_max.stride(0), n_groups(v), GROUP_COLS,
-            rows, rows_per_img, beam, top_k, float(temperature), unk_index, _ptr(row_noise), seed, _ptr(seed_ptr), img0, step,
-            _ptr(pick_idx), _ptr(pick_val), _ptr(err), _ptr(tokens), tokens.stride(0), _ptr(vals), _ptr(ended), _ptr(src),
-            src.stride(0) if src is not None else 0, _ptr(parent), _ptr(hparent), _ptr(done), _ptr(end_step), int(first),
-            int(first_sets_ended), write_pos, t, eos_index, _ptr(cand_noise), _ptr(arrive), _stream())
 
 
 def beam_select(pick_idx, pick_val, tokens, vals, ended, src, parent, hparent, done, end_step, n_img, beam, first,

@@ -180,7 +180,7 @@ class BeamSearchHelper:
         r = n_img * beam_size
         dev = device
         # all zero-initialised state carved out of ONE zeroed arena (one fill launch instead of eight per generate call)
-        words = [r * max_len, r, (r + 3) // 4, r, r, (n_img + 3) // 4, n_img, 1, n_img]
+        words = [r * max_len, r, (r + 3) // 4, r, r, (n_img + 3) // 4, n_img, 1]
         offs = [0]
         for w in words:
             offs.append(offs[-1] + (w + 3) // 4 * 4)                                   # 16-byte aligned pieces
@@ -196,12 +196,6 @@ class BeamSearchHelper:
         self.parent, self.hparent = piece(3), piece(4)
         self.done = piece(5).view(torch.uint8)[:n_img]
         self.end_step, self.err = piece(6), piece(7)
-        self.arrive = piece(8)            # per-image arrival counters of the fused beam step (the kernel leaves them zero)
-        # one launch per step (dh_beam_step_groups; needs an image's token + ancestor rows to fit the row kernel's LDS).  Same
-        # results, measured gain within run-to-run noise (C2 9.03 / 8.72 vs 9.01 ms, C3 25.2 / 24.9 vs 25.4 ms per step), so the two
-        # launches stay the default; option "fused_beam_step" = 1 opts in, "fused_beam_step_max_rows" selects it by row count
-        self.fused_step = ((beam_size * (max_len + src_len) <= hip.SEL_STAGE_MAX) and beam_size <= 16
-                           and bool(hip.option("fused_beam_step") or r <= hip.option("fused_beam_step_max_rows")))
         self.pick_idx = torch.empty((r, beam_size), dtype=torch.int32, device=dev)
         self.pick_val = torch.empty((r, beam_size), dtype=torch.float32, device=dev)
         # KV-cache ancestor table (Transformer only): src[r, j] = row holding position j of r's history
@@ -237,15 +231,6 @@ class BeamSearchHelper:
         v = logits.shape[1]
         if self.exact:
             group_max = None              # the general sampler reads the whole row
-        if group_max is not None and self.top_k <= hip.n_groups(v) and self.fused_step:
-            # 16-bit paths: row draw + candidate draw of the step in one launch
-            hip.beam_step_groups(logits, v, group_max, rows, rpi, self.beam_size, self.top_k, self.temperature, self.unk_index,
-                                 self._noise("row", step_index, (rows, v), logits.stride(0)), self.seed, self.img0, step_index,
-                                 self.pick_idx, self.pick_val, self.err, self.tokens, self.vals, self._ended, self.src,
-                                 self.parent, self.hparent, self.done, self.end_step, first, first_sets_ended, write_pos, t,
-                                 self.eos_index, None if first else self._noise("cand", step_index, (self.n_img, self.beam_size ** 2)),
-                                 self.arrive, seed_ptr=self.seed_tensor)
-            return
         if group_max is not None and self.top_k <= hip.n_groups(v):   # k group maxima bound the k-th logit
             # bf16 path: the vocabulary GEMM left per-row maxima of every 64-column group (dh_vocab_logits)
             hip.beam_row_sample_groups(logits, v, group_max, rows, rpi, self.beam_size, self.top_k, self.temperature,

@@ -227,16 +227,16 @@ class ImageEncoder(_Planned, nn.Module):
     def _conv(x, c, residual=None, nhwc=False):
         if (nhwc and "wpk1" in c and (residual is None or x.shape[3] == 512)
                 and hip.conv1x1_wreg_supported(x.shape[0] * x.shape[1] * x.shape[2], x.shape[3], c["w"].shape[0])
-                and hip.option("conv1x1_wreg")):
+                and hip.option("encoder_generic") < 1):
             # conv1 of the K >= 256 bottlenecks, conv3 + residual of stage 4: weights stationary in registers, pixels streamed
             # (csrc/conv1x1_wreg.hip; bit-identical)
             return hip.conv1x1_wreg_nhwc(x, c["wpk1"], c["w"].shape[0], c["scale"], c["shift"], relu=c["relu"], residual=residual)
         if (nhwc and residual is None and "wpk4" in c and c["relu"] and hip.conv3x3_s4_supported(x.shape[1], x.shape[2], x.shape[3])
-                and hip.option("conv_s4")):
+                and hip.option("encoder_generic") < 1):
             return hip.conv3x3_s4_nhwc(x, c["wpk4"], c["scale"], c["shift"])
         if (nhwc and residual is None and c["relu"] and c["stride"] == 1 and c["pad"] == 1 and c["w"].shape[1] == 3
                 and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], x.shape[3], c["w"].shape[0])
-                and hip.option("direct_3x3")):
+                and hip.option("encoder_generic") < 2):
             return hip.conv3x3_direct_nhwc(x, c["w"], c["scale"], c["shift"])      # patch-resident direct convolution (stages 1-2)
         fn = hip.conv2d_nhwc_bn_act if nhwc else hip.conv2d_bn_act
         return fn(x, c["w"], c["scale"], c["shift"], residual=residual, relu=c["relu"], stride=c["stride"], pad=c["pad"])
@@ -285,7 +285,7 @@ class ImageEncoder(_Planned, nn.Module):
             prepacked = images.dim() == 4 and images.shape[-1] == 8 and images.dtype == plan["dtype"]
             h_in, w_in = (images.shape[1], images.shape[2]) if prepacked else (images.shape[2], images.shape[3])
             direct = ("wpk" in st and h_in >= 2 and w_in >= 2 and ((h_in - 1) // 2 + 1) % 2 == 0 and ((w_in - 1) // 2 + 1) % 2 == 0
-                      and (prepacked or images.shape[1] == 3) and hip.option("direct_stem"))
+                      and (prepacked or images.shape[1] == 3) and hip.option("encoder_generic") < 3)
             if direct:
                 # conv1 + bn1 + relu + maxpool as ONE direct-convolution launch that reads the caller's tensor as it is (fp32 NCHW
                 # or the preprocessing kernels' packed 16-bit layout): no packing launch, no im2col traffic, no un-pooled activation
@@ -299,7 +299,7 @@ class ImageEncoder(_Planned, nn.Module):
             ks, cout = st["w"].shape[1], st["w"].shape[0]
             ho = (packed.shape[1] + 2 * st["pad"] - ks) // st["stride"] + 1
             wo = (packed.shape[2] + 2 * st["pad"] - ks) // st["stride"] + 1
-            if ho % 2 == 0 and wo % 2 == 0 and cout <= 64 and hip.option("stem_pool"):
+            if ho % 2 == 0 and wo % 2 == 0 and cout <= 64 and hip.option("encoder_generic") < 3:
                 # conv1 + bn1 + relu + maxpool in one launch: the un-pooled 112 x 112 x 64 activation never exists
                 x = hip.conv2d_nhwc_bn_relu_maxpool(packed, st["w"], st["scale"], st["shift"], st["stride"], st["pad"])
             else:
@@ -309,71 +309,87 @@ class ImageEncoder(_Planned, nn.Module):
         return self._trunk(x, plan)
 
     def _trunk(self, x, plan):
-        """layer1..layer4 on the pooled stem output."""
-        nhwc = plan["bf16"]
-        blocks = plan["blocks"]
-        ready = {}                                        # block index -> its conv1 output, already computed by the previous block's tail launch
+        """layer1..layer4 on the pooled stem output: the kernel of every bottleneck is chosen ONCE per (plan, input shape) -- a table of
+        steps kept with the plan (``_trunk_table``) -- and a forward is a walk over that table."""
+        key = (tuple(x.shape), hip.options_epoch)
+        table = plan.setdefault("_trunk_tables", {}).get(key)
+        if table is None:
+            table = plan["_trunk_tables"][key] = self._trunk_table(plan, tuple(x.shape))
+        ready = None                                      # the NEXT block's conv1 output when the previous tail launch computed it
+        for step in table:
+            x, ready = step(x, ready)
+        return x
+
+    def _trunk_table(self, plan, shape):
+        """[step(x, y1_ready) -> (x, y1_for_next_block)] for an input of ``shape`` ([N, H, W, C] on the 16-bit paths, NCHW in fp32).
+        Option ``encoder_generic``: 0 = every specialised kernel; >= 1 without round 4's (streaming 1x1, stage-1 / 2 / 4 tails, conv1 fusions);
+        >= 2 also without the patch-resident 3x3 / fused tails of rounds 2-3: every convolution through the implicit-GEMM tile kernel (all
+        of them bit-identical to it: tests/test_bf16_gpu.py)."""
+        nhwc, blocks, lvl = plan["bf16"], plan["blocks"], hip.option("encoder_generic")
+        conv = self._conv
+        table = []
+        h, w = (shape[1], shape[2]) if nhwc else (shape[2], shape[3])
         for bi, blk in enumerate(blocks):
-            c2, c3 = blk["c2"], blk["c3"]
+            c1, c2, c3 = blk["c1"], blk["c2"], blk["c3"]
             nxt = blocks[bi + 1] if bi + 1 < len(blocks) else None
-            if (nhwc and "w2p1" in blk and nxt is not None and "wpkf" in nxt["c1"] and "w2p1" in nxt
-                    and hip.bottleneck_tail_s1_supported(x.shape[1], x.shape[2], c2["w"].shape[0], nxt["c1"]["w"].shape[0])
-                    and hip.option("fused_tail") and hip.option("s1_conv1_fusion")):
+            cmid = c2["w"].shape[0]
+            first = lambda x, ready, c1=c1: ready if ready is not None else conv(x, c1, nhwc=True)
+            if (nhwc and lvl < 1 and "w2p1" in blk and nxt is not None and "wpkf" in nxt["c1"] and "w2p1" in nxt
+                    and hip.bottleneck_tail_s1_supported(h, w, cmid, nxt["c1"]["w"].shape[0])):
                 # stage 1 (56 x 56 x 64), next block's conv1 256 -> 64: 4-row strips, weights register-streamed, and that conv1 in the
                 # same launch on the output tile while it is in LDS -- the 411 MB tensor is not read back for it (conv_s1.hip).
                 # (Without the fusion the ring kernel below is the faster tail in the encoder: 195 against 214 us.)
-                y1 = ready.pop(bi, None)
-                if y1 is None:
-                    y1 = self._conv(x, blk["c1"], nhwc=True)
-                x, ready[bi + 1] = hip.bottleneck_tail_s1_nhwc(y1, blk["w2p1"], c2["scale"], c2["shift"], blk["w3p1"], c3["scale"], c3["shift"], x,
-                                                               nxt["c1"]["wpkf"], nxt["c1"]["scale"], nxt["c1"]["shift"], nxt["c1"]["w"].shape[0])
-                continue
-            if (nhwc and "w2p" in blk and hip.bottleneck_tail_s3_supported(x.shape[1], x.shape[2], c2["w"].shape[0])
-                    and hip.option("fused_tail") and hip.option("s3_tail")):
+                n1 = nxt["c1"]
+                table.append(lambda x, ready, blk=blk, c2=c2, c3=c3, n1=n1, first=first: hip.bottleneck_tail_s1_nhwc(
+                    first(x, ready), blk["w2p1"], c2["scale"], c2["shift"], blk["w3p1"], c3["scale"], c3["shift"], x,
+                    n1["wpkf"], n1["scale"], n1["shift"], n1["w"].shape[0]))
+            elif nhwc and lvl < 2 and "w2p" in blk and hip.bottleneck_tail_s3_supported(h, w, cmid):
                 # stage 3 (14 x 14 x 256): one image per workgroup, patch-resident 3x3 + 1x1 expansion, weights register-streamed
-                y1 = self._conv(x, blk["c1"], nhwc=True)
-                x = hip.bottleneck_tail_s3_nhwc(y1, blk["w2p"], c2["scale"], c2["shift"], blk["w3p"], c3["scale"], c3["shift"], x)
-                continue
-            if (nhwc and "w2p2" in blk and hip.bottleneck_tail_s2_supported(x.shape[1], x.shape[2], c2["w"].shape[0])
-                    and hip.option("fused_tail") and hip.option("s2_tail")):
-                y1 = ready.pop(bi, None)
-                if y1 is None:
-                    y1 = self._conv(x, blk["c1"], nhwc=True)
-                if (nxt is not None and "wpkf" in nxt["c1"] and "w2p2" in nxt and hip.option("s2_conv1_fusion")):
+                table.append(lambda x, ready, blk=blk, c2=c2, c3=c3, first=first: (hip.bottleneck_tail_s3_nhwc(
+                    first(x, ready), blk["w2p"], c2["scale"], c2["shift"], blk["w3p"], c3["scale"], c3["shift"], x), None))
+            elif nhwc and lvl < 1 and "w2p2" in blk and hip.bottleneck_tail_s2_supported(h, w, cmid):
+                if nxt is not None and "wpkf" in nxt["c1"] and "w2p2" in nxt:
                     # + the next block's conv1 (512 -> 128) on the output chunks in LDS: 170 us against 135 + 55 us
-                    x, ready[bi + 1] = hip.bottleneck_tail_s2_nhwc(y1, blk["w2p2"], c2["scale"], c2["shift"], blk["w3p2"], c3["scale"], c3["shift"], x,
-                                                                   nxt["c1"]["wpkf"], nxt["c1"]["scale"], nxt["c1"]["shift"], 128)
-                    continue
-                x = hip.bottleneck_tail_s2_nhwc(y1, blk["w2p2"], c2["scale"], c2["shift"], blk["w3p2"], c3["scale"], c3["shift"], x)
-                continue
-            if (nhwc and blk["dual"] is None and blk["down"] is None and c2["stride"] == 1 and c2["w"].shape[1] == 3
-                    and hip.conv3x3_direct_supported(x.shape[1], x.shape[2], c2["w"].shape[3], c2["w"].shape[0])
-                    and c3["w"].shape[0] == 4 * c2["w"].shape[0] and hip.option("fused_tail")
-                    and hip.option("direct_3x3")):
+                    n1 = nxt["c1"]
+                    table.append(lambda x, ready, blk=blk, c2=c2, c3=c3, n1=n1, first=first: hip.bottleneck_tail_s2_nhwc(
+                        first(x, ready), blk["w2p2"], c2["scale"], c2["shift"], blk["w3p2"], c3["scale"], c3["shift"], x,
+                        n1["wpkf"], n1["scale"], n1["shift"], 128))
+                else:
+                    table.append(lambda x, ready, blk=blk, c2=c2, c3=c3, first=first: (hip.bottleneck_tail_s2_nhwc(
+                        first(x, ready), blk["w2p2"], c2["scale"], c2["shift"], blk["w3p2"], c3["scale"], c3["shift"], x), None))
+            elif (nhwc and lvl < 2 and blk["dual"] is None and blk["down"] is None and c2["stride"] == 1 and c2["w"].shape[1] == 3
+                    and hip.conv3x3_direct_supported(h, w, c2["w"].shape[3], cmid) and c3["w"].shape[0] == 4 * cmid):
                 # conv2 + bn2 + relu + conv3 + bn3 + residual + relu in one launch: the conv2 output tile stays in LDS
-                y1 = ready.pop(bi, None)
-                if y1 is None:
-                    y1 = self._conv(x, blk["c1"], nhwc=True)
-                x = hip.bottleneck_tail_nhwc(y1, c2["w"], c2["scale"], c2["shift"], c3["w"], c3["scale"], c3["shift"], x)
-                continue
-            y = self._conv(self._conv(x, blk["c1"], nhwc=nhwc), blk["c2"], nhwc=nhwc)
-            if blk["dual"] is not None:
-                d = blk["dual"]
-                if ("wpk" in d and hip.option("conv1x1_wreg")
-                        and hip.conv1x1_dual_wreg_supported(y.shape, x.shape, d["w"].shape[0])):
-                    if (nxt is not None and "wpkf" in nxt["c1"] and d["w"].shape == (256, 128) and nxt["c1"]["w"].shape[0] == 64
-                            and hip.option("s1_conv1_fusion")):
+                table.append(lambda x, ready, c2=c2, c3=c3, first=first: (hip.bottleneck_tail_nhwc(
+                    first(x, ready), c2["w"], c2["scale"], c2["shift"], c3["w"], c3["scale"], c3["shift"], x), None))
+            else:
+                table.append(self._generic_block(blk, nxt, nhwc, lvl))
+            if blk["down"] is not None:
+                st = blk["down"]["stride"]
+                h, w = (h - 1) // st + 1, (w - 1) // st + 1
+        return table
+
+    def _generic_block(self, blk, nxt, nhwc, lvl):
+        """conv1 -> conv2 -> (conv3 + downsample as ONE GEMM | downsample, conv3 + residual): the first block of every stage, and every
+        block when the specialised tails do not apply."""
+        conv = self._conv
+
+        def step(x, ready):
+            y1 = ready if ready is not None else conv(x, blk["c1"], nhwc=nhwc)
+            y = conv(y1, blk["c2"], nhwc=nhwc)
+            d = blk["dual"]
+            if d is not None:
+                if "wpk" in d and lvl < 1 and hip.conv1x1_dual_wreg_supported(y.shape, x.shape, d["w"].shape[0]):
+                    if nxt is not None and "wpkf" in nxt["c1"] and d["w"].shape == (256, 128) and nxt["c1"]["w"].shape[0] == 64:
                         # layer1.0's ending + layer1.1's conv1 in one launch (the block's 256 output channels are in the workgroup)
-                        x, ready[bi + 1] = hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], 256, d["shift"], d["stride"], relu=True, w1p=nxt["c1"]["wpkf"],
-                                                                      scale1=nxt["c1"]["scale"], shift1=nxt["c1"]["shift"], n1=64)
-                        continue
-                    x = hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], d["w"].shape[0], d["shift"], d["stride"], relu=True)
-                    continue
-                x = hip.conv1x1_dual_nhwc(y, x, d["w"], d["shift"], d["stride"], relu=True)
-                continue
-            idt = x if blk["down"] is None else self._conv(x, blk["down"], nhwc=nhwc)
-            x = self._conv(y, blk["c3"], residual=idt, nhwc=nhwc)
-        return x
+                        n1 = nxt["c1"]
+                        return hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], 256, d["shift"], d["stride"], relu=True, w1p=n1["wpkf"],
+                                                          scale1=n1["scale"], shift1=n1["shift"], n1=64)
+                    return hip.conv1x1_dual_wreg_nhwc(y, x, d["wpk"], d["w"].shape[0], d["shift"], d["stride"], relu=True), None
+                return hip.conv1x1_dual_nhwc(y, x, d["w"], d["shift"], d["stride"], relu=True), None
+            idt = x if blk["down"] is None else conv(x, blk["down"], nhwc=nhwc)
+            return conv(y, blk["c3"], residual=idt, nhwc=nhwc), None
+        return step
 
     def forward(self, images):
         _require_eval(self, self.dropout.p)
@@ -414,10 +430,16 @@ class LabelEncoder(nn.Module):
         self.embedding = nn.Embedding(num_tokens, emb_dim)
         self.dropout = nn.Dropout(dropout)
 
-    def forward(self, labels, out=None):
-        _require_eval(self, self.dropout.p)
+    def check(self, labels):
+        """``nn.Embedding``'s IndexError for a label outside the table: one ``aminmax`` + a host read -- a blocking sync on the current
+        stream, so the image + label encoders make it BEFORE the image trunk is queued (``ImageLabelEncoder.forward``), not behind it."""
         from .beam import check_ids
-        check_ids(labels, self.embedding.num_embeddings)                               # (nn.Embedding's IndexError)
+        check_ids(labels, self.embedding.num_embeddings)
+
+    def forward(self, labels, out=None, checked=False):
+        _require_eval(self, self.dropout.p)
+        if not checked:
+            self.check(labels)
         w = self.embedding.weight.detach()
         if out is None:
             out = torch.empty((labels.shape[0], w.shape[1]), dtype=w.dtype, device=w.device)
@@ -438,11 +460,12 @@ class ImageLabelEncoder(nn.Module):
         n, e = image_emb.shape
         both = torch.empty((n, 2 * e), dtype=image_emb.dtype, device=image_emb.device)
         both[:, :e].copy_(image_emb)
-        self.label_encoder(labels, out=both[:, e:])
+        self.label_encoder(labels, out=both[:, e:], checked=True)
         return hip.linear(both, self.linear.weight.detach(), self.linear.bias.detach().float())
 
     def forward(self, images, labels):
         _require_eval(self, self.dropout.p)
+        self.label_encoder.check(labels)                    # host sync in front of the trunk's launches, not behind them
         return self._combine(self.image_encoder(images), labels)
 
 
@@ -456,5 +479,6 @@ class SpatialImageLabelEncoder(ImageLabelEncoder):
 
     def forward(self, images, labels):
         _require_eval(self, self.dropout.p)
+        self.label_encoder.check(labels)
         emb, spatial = self.image_encoder(images)
         return self._combine(emb, labels), spatial

@@ -57,7 +57,7 @@ class LSTMDecoder(_Planned, nn.Module):
                     dtype=self.classifier.weight.dtype)
         if split:
             plan["cls_w_x"] = hip.split_f32x(plan["cls_w"].contiguous())
-        if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and plan["cls_w"].shape[1] == 512 and hip.option("vocab_wreg_plan"):
+        if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and plan["cls_w"].shape[1] == 512 and hip.option("vocab_wreg"):
             # the beam-search classifier with the weights streamed from L2 into registers (csrc/vocab_wreg.hip): padded, fragment-packed copy
             plan["cls_w_pk"], plan["cls_b_pad"] = hip.pack_vocab_weights(plan["cls_w"], plan["cls_b"])
         return plan

@@ -206,7 +206,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 if self._cross:
                     ent["wq_f"], ent["bq_f"], ent["cs_q"] = fold(ent["wq"], ent["bq"], ent["ln1"])
                 ent["w1_f"], ent["b1_f"], ent["cs_1"] = fold(ent["w1"], ent["b1"], ent["ln2"] if self._cross else ent["ln1"])
-            if torch.cuda.is_available() and self.classifier.weight.is_cuda and hip.option("decode_wreg_plan"):
+            if torch.cuda.is_available() and self.classifier.weight.is_cuda and hip.option("decode_wreg"):
                 # register-stationary decode GEMMs (dh_linear_ln_wreg): fragment-packed copies of the chain's weights, once per plan
                 hd, pf = self.hid_dim, self.layers[0].pf.fc_1.out_features
                 for i, ent in enumerate(layers):
@@ -226,7 +226,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     if name in ent:
                         ent[name + "_x"] = hip.split_f32x(ent[name].contiguous())
             plan["cls_w_x"] = hip.split_f32x(plan["cls_w"].contiguous())
-        if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and hip.option("vocab_wreg_plan"):
+        if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and hip.option("vocab_wreg"):
             # the register-streamed classifier (csrc/vocab_wreg.hip; bit-identical).  The LSTM decoder uses it at every size; here it is
             # selected per batch by row count (_Run): at <= "vocab_wreg_transformer_max_rows" rows per position (small shards, single
             # images: the 128-row A-stationary kernel takes 54 us at 380 rows) or always with option "vocab_wreg_transformer" -- at 1,280
@@ -275,8 +275,9 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 if (self.dtype in hip.HALF_DTYPES and s <= 64 and d == 64 * dec.n_heads and beam <= 16
                         and hip.option("packed_cross")):
                     # matrix-core cross-attention: K | V re-laid out per (image, head) in MFMA operand order, once per batch; on the
-                    # deferred-LayerNorm chain additionally with K's head-dim slots permuted, so that fc_q runs inside the attention launch
-                    self.dperm = "wq_f" in plan["layers"][0] and d <= 512 and hip.option("qproj_fusion")
+                    # deferred-LayerNorm chain with K's head-dim slots in accumulator-tile order (the layout of rounds 2-5's fused
+                    # fc_q + attention launch, kept: it fixes the summation order over the head dimension, i.e. every 16-bit token)
+                    self.dperm = "wq_f" in plan["layers"][0] and d <= 512
                     self.packed = [hip.attn_cross_pack(kv, n, s, d, dec.n_heads, dperm=self.dperm) for kv in self.kv]
             self._scratch = {}
             self.pf = dec.layers[0].pf.fc_1.out_features
@@ -323,9 +324,6 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     bufs["y2"] = e(rows, self.d)
                     for k in ("st0", "st1", "st2"):
                         bufs[k] = torch.empty((rows, self.d // 64, 2), device=self.dev, dtype=torch.float32)
-                    # counters of the one-launch GEMM chain (dh_decode_gemm_chain): zero once, the kernel leaves them zero; private to
-                    # this run (= this stream)
-                    bufs["chain_sync"] = torch.zeros((80,), device=self.dev, dtype=torch.int32)
                 c = hip.TrScratch()
                 for k, v in bufs.items():
                     setattr(c, k, v.data_ptr())
@@ -469,7 +467,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             if packed_ok:                                  # matrix-core cross-attention, 16 positions per launch
                 # (dperm: the head-dim slot order of the decode chain's fused fc_q + attention launch, so that teacher-forced
                 # logits and incremental decoding sum in the same order)
-                dperm = "wq_f" in L and hip.option("qproj_fusion")
+                dperm = "wq_f" in L
                 kp, vt = hip.attn_cross_pack(kv, bs, s_enc, d, nh, dperm=dperm)
                 return hip.attn_cross_prefill_packed(q, kp, vt, keymask, bs, seq, s_enc, d, nh, L["ea_scale"], dperm=dperm)
             return hip.attn_cross_prefill(q, kv, keymask, bs, seq, s_enc, d, nh, L["ea_scale"])

@@ -42,10 +42,9 @@ class CaptionPipeline:
         self.model, self.gen_kw, self.overlap, self.preprocess = model, gen_kw, overlap, preprocess
         self.dev = next(model.parameters()).device
         if overlap:
-            # (a high-priority decode stream -- DH_PIPE_PRIO=1 -- was measured: no gain, the encoder's workgroups hold the CUs
-            #  until they retire whatever the queue priority)
-            self.copy_s, self.enc_s = torch.cuda.Stream(device=self.dev), torch.cuda.Stream(device=self.dev)
-            self.dec_s = torch.cuda.Stream(device=self.dev, priority=-1 if hip.option("pipe_prio") else 0)
+            # (a high-priority decode stream was measured in round 4: no gain, the encoder's workgroups hold the CUs until they retire
+            #  whatever the queue priority)
+            self.copy_s, self.enc_s, self.dec_s = (torch.cuda.Stream(device=self.dev) for _ in range(3))
         else:
             self.copy_s = self.enc_s = self.dec_s = torch.cuda.current_stream(self.dev)
         # staging buffers, ONE per (slot, input) / output slot: a batch of another shape replaces the slot's buffer (a service fed

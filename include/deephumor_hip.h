@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 29
+#define DH_ABI_VERSION 30
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
@@ -289,36 +289,6 @@ int dh_linear_ln_wreg_supported(int N, int K, int with_residual_stats);
 double dh_linear_ln_wreg_occupancy(int M, int N, int K, int with_residual_stats);
 int dh_linear_ln_wreg(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
                       void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, int dtype, void* stream);
-/* dh_linear_ln_wreg whose launch carries n_pf (rounded up to 8) extra workgroups that pull the operands of the NEXT kernel on the stream
- * into L2 while the (latency-bound) GEMM computes: two arrays of tiles (tile_stride bytes apart, tile_bytes[a] used bytes of each tile, all
- * multiples of 16); the consumer's workgroup g reads tiles g * tiles_per_group .. and runs on XCD g % 8, which is where the prefetch
- * workgroups for group g run.  Used for fc_q (transformers.py:97 inside :364) in front of dh_attn_cross_decode_packed: Kp / Vt of the
- * (image, head) pairs.  Only the 4-wave K = 512 forms (64-column x 40-row blocks) carry them (others ignore pf); results as dh_linear_ln_wreg. */
-typedef struct dh_l2_prefetch {
-    const void* base[2]; uint32_t tile_stride; uint32_t tile_bytes[2]; int n_tiles; int tiles_per_group;
-    int part, parts;                 /* this launch takes part `part` of `parts` (every parts-th of an XCD's groups): several launches in
-                                      * front of the consumer can share the transfer */
-} dh_l2_prefetch_t;
-int dh_linear_ln_wreg_prefetch(const void* A, int lda, const void* w_packed, const float* bias, const void* residual, int ldres,
-                               void* C, int ldc, int M, int N, int K, int relu, const dh_ln_fold_t* ln, const dh_l2_prefetch_t* pf, int n_pf,
-                               int dtype, void* stream);
-
-/* Up to four DEPENDENT GEMMs of one decode position in ONE launch (round 5; csrc/linear_wreg.hip, decode_gemm_chain_kernel): the
- * deferred-LayerNorm chain of a DecoderLayer ends in (enc_)fc_o -> fc_1 -> fc_2 -> the next layer's fc_q|k|v (transformers.py:127 /
- * :364-375 / :162-163 / :97), each reading whole rows of its predecessor.  Step i = dh_linear_ln_wreg's arguments (either form); a
- * later step may read the C / o_stats an earlier one wrote.  The rows are cut into 8 groups, each worked on by the workgroups of ONE
- * XCD (hardware id) so that a step's outputs are read back through the L2 they were written to: no agent-scope fence between the
- * steps.  Bit-identical to the same steps as separate dh_linear_ln_wreg launches.  sync: 74 uint32 of device memory private to the
- * stream, zero before the first launch that uses them (the kernel leaves words 0..72 zero); sync[73] != 0 = a bounded wait timed out.
- * _supported: 1 when a step (N, K, residual form) is one the chain takes (K = 512; K = 2,048 with residual; N % 64 == 0). */
-typedef struct dh_chain_step {
-    const void* A; int lda; const void* w_packed; const float* bias; const void* residual; int ldres; void* C; int ldc;
-    int N, K, relu, _pad;
-    dh_ln_fold_t ln;
-} dh_chain_step_t;
-int dh_decode_gemm_chain_supported(int N, int K, int with_residual_stats);
-int dh_decode_gemm_chain(const dh_chain_step_t* steps, int n_steps, int M, uint32_t* sync, int dtype, void* stream);
-
 /* Vocabulary projection feeding beam search (bf16 operands): logits [M,V] fp32 = A*W^T + bias, and
  * group_max[m, g] = max(logits[m, 64g .. 64g+63]) for g < 2*ceil(V/128) (row stride gm_ld) -- the pre-filter
  * dh_beam_row_sample_groups uses to read only the ~top_k column groups that can hold a top-k logit.
@@ -373,17 +343,6 @@ int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, const int32
                         int row_mult, int rows_total, int t, int D, int n_heads, float scale,
                         int pad_index, int dtype, void* stream);
 
-/* The same self-attention WITH its QKV projection in one launch (16-bit dtypes; D = 64 * n_heads <= 512, t <= 39,
- * rows_per_img <= 6): x [rows, ldx] are the layer's input rows -- plain (a_stats == NULL: layer 0, the embedding) or
- * PRE-LayerNorm with partial statistics a_stats [rows][a_tiles][2] and wqkv / bqkv / colsum gamma- / beta-folded (dh_ln_fold_t
- * semantics).  Workgroup = 8 images x one head; the head's q / k / v weight slices stream through LDS, q|k|v of the position
- * never leave the chip except as the cache append.  Outputs (out, kcache, vcache) are bit-identical to dh_linear(_ln) into a
- * [rows, 3D] buffer followed by dh_attn_self_decode. */
-int dh_attn_self_qkv_decode(const void* x, int ldx, const float* a_stats, int a_tiles, float a_eps, const float* colsum,
-                            const void* wqkv, const float* bqkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
-                            const int32_t* tokens, int tok_ld, void* out, int n_img, int rows_per_img, int row_mult,
-                            int rows_total, int t, int D, int n_heads, float scale, int pad_index, int dtype, void* stream);
-
 /* Single-position multi-head attention over the S image patches (transformers.py:364 -> 97-127).
  *   q [rows, ldq] (first D columns used), kv [n_img*S, 2*D] = fc_k | fc_v of enc_out (computed once
  *   per image), keymask [n_img*S] uint8 (1 = masked: some element of that enc_out row == 0,
@@ -395,22 +354,13 @@ int dh_attn_cross_decode(const void* q, int ldq, const void* kv, const uint8_t* 
 /* The same attention on the matrix cores (16-bit dtypes, head dim 64, S <= 64, rows_per_img <= 16).  dh_attn_cross_pack
  * re-lays kv out ONCE per batch and layer as kp [n_img][n_heads][64 keys][64] and vt [n_img][n_heads][64][64 key slots]
  * (V transposed, key slots permuted into MFMA operand order, keys >= S zero) -- 16 KB per (image, head); dperm != 0
- * additionally permutes K's head-dim slots for dh_attn_cross_qproj_decode; _decode_packed / _prefill_packed take the same flag
- * and then read q in that slot order (same summation order as the fused kernel: prefill and decode agree bit for bit).  One wave then
+ * additionally permutes K's head-dim slots into the order of a 16 x 16 MFMA accumulator tile (the layout rounds 2-5's fused fc_q +
+ * attention launch needed; kept as the product's default so that every 16-bit summation order -- and token -- stays what it was);
+ * _decode_packed / _prefill_packed take the same flag and then read q in that slot order (prefill and decode agree bit for bit).  One wave then
  * handles one (image, head) straight from HBM: no LDS, no barrier, one memory round trip.  _prefill_packed: every
  * position of image n (rows n*n_pos + t), in chunks of 16 positions. */
 int dh_attn_cross_pack(const void* kv, void* kp, void* vt, int n_img, int S, int D, int n_heads, int dperm, int dtype, void* stream);
 
-/* enc_attn for one decode position WITH its query projection (transformers.py:364 -> 97-127: fc_q, energy, softmax, @v) in one
- * launch, on the deferred-LayerNorm chain: y [rows, ldy] are the PRE-LayerNorm rows with partial statistics `stats`
- * [rows][n_tiles][2] (dh_linear_ln's o_stats), wq_folded / bq_folded / colsum are fc_q with the LayerNorm's gamma / beta folded
- * in (dh_ln_fold_t semantics).  kp_dperm: dh_attn_cross_pack(..., dperm = 1) -- K's head-dim slots in the order the projection's
- * accumulators hold a q row, so q goes from the MFMA accumulators straight into the K q^T operand.  Workgroup = 8 images x one
- * head (the head's 64 weight rows staged once in LDS); out [rows, D].  D <= 512, head dim 64, S <= 64, rows_per_img <= 16. */
-int dh_attn_cross_qproj_decode(const void* y, int ldy, const float* stats, int n_tiles, float eps, const void* wq_folded,
-                               const float* bq_folded, const float* colsum, const void* kp_dperm, const void* vt,
-                               const uint8_t* keymask, void* out, int n_img, int rows_per_img, int S, int D, int n_heads,
-                               float scale, int dtype, void* stream);
 int dh_attn_cross_decode_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
                                 int n_img, int rows_per_img, int S, int D, int n_heads, float scale, int dperm, int dtype, void* stream);
 int dh_attn_cross_prefill_packed(const void* q, int ldq, const void* kp, const void* vt, const uint8_t* keymask, void* out,
@@ -522,20 +472,6 @@ int dh_beam_select(const int32_t* pick_idx, const float* pick_val, int32_t* toke
                    float temperature, int eos_index, const float* noise, uint64_t seed,
                    const uint64_t* seed_ptr, int img0, void* stream);
 
-/* One beam step in ONE launch (what dh_beam_row_sample_groups + dh_beam_select do in two): every row draws its picks, and the
- * workgroup that finishes an image's LAST row runs that image's candidate draw and state rewrite (hand-over through an
- * agent-scope release / acquire around an arrival counter: the rows of an image may run on different XCDs).  Arguments as in
- * the two entry points (`step` is also the select's step_index); row_noise / cand_noise NULL -> Philox.  arrive: int32
- * [n_img], zero before the first call; the kernel leaves it zero.  Returns DH_ERR_UNSUPPORTED when beam * (tok_ld + t) > 3072
- * (the image's token / ancestor rows do not fit the row kernel's LDS): use the two launches then.  Results are identical. */
-int dh_beam_step_groups(const float* logits, int ldl, int V, const float* group_max, int gm_ld, int n_groups,
-                        int group_cols, int rows, int rows_per_img, int beam, int top_k, float temperature,
-                        int unk_index, const float* row_noise, uint64_t seed, const uint64_t* seed_ptr, int img0,
-                        int step, int32_t* pick_idx, float* pick_val, int32_t* err, int32_t* tokens, int tok_ld,
-                        float* vals, uint8_t* ended, int32_t* src, int src_ld, int32_t* parent, int32_t* hparent,
-                        uint8_t* done, int32_t* end_step, int first, int first_sets_ended, int write_pos, int t,
-                        int eos_index, const float* cand_noise, int32_t* arrive, void* stream);
-
 /* ---- BeamSearchHelper's METHOD surface (deephumor/models/beam.py:32-108), for callers that drive the helper the way the
  * reference's own generate() loops do (rnn_models.py:87-128, transformers.py:532-569): one image, host-driven, tensors of the
  * reference's shapes and dtypes.  The batched engine (dh_beam_row_sample / dh_beam_select above) does not need them. */
@@ -634,8 +570,6 @@ typedef struct dh_tr_scratch {
     void *x, *qkv, *att, *o, *q, *ff;       /* [rows, D|3D|D|D|D|PF] */
     void* y2;                               /* [rows, D]      second pre-LayerNorm row buffer of the deferred chain (or NULL) */
     float *st0, *st1, *st2;                 /* [rows, D/64, 2] partial LayerNorm statistics of x / o / y2 (or NULL) */
-    uint32_t* chain_sync;                   /* optional: 74 zeroed uint32 private to the stream -- the layer's trailing GEMMs then run as ONE
-                                               launch (dh_decode_gemm_chain; option "decode_chain_fusion") */
 } dh_tr_scratch_t;
 
 /* Hidden state of position t for n_img*rows_per_img compact rows; x_out (optional, [rows,D]) receives the

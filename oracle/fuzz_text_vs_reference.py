@@ -62,4 +62,6 @@ for tk_name in ("WordPunctTokenizer", "CharTokenizer"):
                     except Exception as e: rb = ("exc", type(e).__name__)
                     if ra != rb:
                         bad += 1; print("split_caption differs", repr(d)[:60], nb, str(ra)[:80], str(rb)[:80])
-print(json.dumps({"docs": len(docs), "differences": bad}))
+print(json.dumps({"docs": len(docs), "differences": bad, "reference_inference_imported": rI is not None}))
+# a difference, or a reference module that did not import (its three checks were skipped), is a failure of this script
+sys.exit(1 if (bad or rI is None) else 0)

@@ -81,17 +81,16 @@ def test_option_table():
     value is read back, an unknown key is an argument error, and changing an option re-keys the models' weight plans."""
     from deephumor_amd import hip
     opts = hip.options()
-    assert len(opts) >= 30 and all(env.startswith("DH_") for _, env in opts.values())
-    for key in ("decode_wreg", "decode_wreg_min_rows", "qkv_fusion_max_rows", "cross_qproj", "lstm_wreg", "vocab_wreg", "f32_split",
-                "conv1x1_wreg", "deferred_ln", "fused_beam_step_max_rows", "dist_always"):
+    assert 10 <= len(opts) <= 20 and all(env == "DH_" + key.upper() for key, (_, env) in opts.items())
+    for key in ("decode_wreg", "decode_wreg_min_rows", "lstm_wreg", "vocab_wreg", "f32_split", "encoder_generic", "deferred_ln", "dist_always"):
         assert key in opts, key
     lib = hip.load()
     assert lib.dh_set_option(b"no_such_option", 1) == 1 and lib.dh_get_option(b"no_such_option", None) == 1
     epoch = hip.options_epoch
     old = hip.set_option("decode_wreg_min_rows", 123)
     assert hip.option("decode_wreg_min_rows") == 123 and hip.options_epoch == epoch + 1
-    with hip.option_scope(decode_wreg_min_rows=7, cross_qproj=0):
-        assert hip.option("decode_wreg_min_rows") == 7 and hip.option("cross_qproj") == 0
-    assert hip.option("decode_wreg_min_rows") == 123 and hip.option("cross_qproj") == opts["cross_qproj"][0]
+    with hip.option_scope(decode_wreg_min_rows=7, encoder_generic=2):
+        assert hip.option("decode_wreg_min_rows") == 7 and hip.option("encoder_generic") == 2
+    assert hip.option("decode_wreg_min_rows") == 123 and hip.option("encoder_generic") == opts["encoder_generic"][0]
     hip.set_option("decode_wreg_min_rows", old)
     assert hip.option("decode_wreg_min_rows") == opts["decode_wreg_min_rows"][0]

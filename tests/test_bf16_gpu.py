@@ -512,37 +512,6 @@ def test_direct_conv3x3(hip, n, h, w, c):
     np.testing.assert_allclose(got.float().cpu().numpy(), old.float().cpu().numpy(), **tol)
 
 
-@pytest.mark.parametrize("n_img,beam,top_k,v,src_len", [(7, 5, 50, 36541, 0), (33, 10, 50, 5000, 9), (3, 16, 20, 1500, 6), (64, 1, 2, 700, 0)])
-def test_fused_beam_step_equals_two_launches(hip, n_img, beam, top_k, v, src_len):
-    """dh_beam_step_groups (row draw + candidate draw in one launch; the workgroup that finishes an image's last row runs the
-    candidate draw) leaves exactly the state dh_beam_row_sample_groups + dh_beam_select leave, step after step, with Philox
-    noise and with an early <eos> in play."""
-    from deephumor_amd.models.beam import BeamSearchHelper
-    g = torch.Generator().manual_seed(n_img * 100 + beam)
-    max_len = 9
-    mk = lambda: BeamSearchHelper(1.1, beam, top_k, 1, 3, "cuda", n_img=n_img, max_len=max_len, src_len=src_len, seed=77, img0=5)
-    a, b = mk(), mk()
-    a.fused_step, b.fused_step = True, False              # (the model path opts in with option fused_beam_step = 1)
-    ng = hip.n_groups(v)
-    for step in range(5):
-        rows = n_img if step == 0 else n_img * beam
-        logits = torch.randn(rows, v, generator=g) * 3.0
-        logits[:, 3] += 4.0 if step >= 2 else -4.0                          # <eos> becomes likely from step 2 on
-        logits = logits.cuda()
-        pad = torch.full((rows, ng * 64 - v), float("-inf"), device="cuda")
-        gmax = torch.cat([logits, pad], 1).view(rows, ng, 64).max(-1).values.contiguous()
-        for h in (a, b):
-            h.step(logits, step == 0, step, step, step, first_sets_ended=True, group_max=gmax)
-        for name in ("tokens", "vals", "has_ended", "parent", "hparent", "done", "end_step", "pick_idx", "pick_val", "err", "src"):
-            x, y = getattr(a, name), getattr(b, name)
-            if x is not None:
-                if name.startswith("pick_"):
-                    x, y = x[:rows], y[:rows]                                   # the first step writes one row per image
-                assert torch.equal(x, y), (step, name)
-        assert int(a.arrive.abs().sum()) == 0
-    assert int(a.err.item()) == 0 and bool(a.has_ended.any())
-
-
 @pytest.mark.parametrize("n,h,w,c", [(2, 56, 56, 64), (3, 8, 56, 64), (2, 28, 28, 128), (5, 4, 28, 128), (1, 4, 28, 128), (3, 28, 28, 128)])
 def test_fused_bottleneck_tail(hip, n, h, w, c):
     """dh_bottleneck_tail_nhwc (3x3 conv2 + 1x1 conv3 + residual in one launch, the conv2 tile resident in LDS) against the
@@ -585,7 +554,7 @@ def test_encoder_16bit_other_image_sizes(h, w):
         assert float((emb16.float() - emb32).abs().max()) < tol * max(1.0, float(emb32.abs().max()))
         if (h, w) == (224, 224):
             from deephumor_amd import hip as H
-            with H.option_scope(s3_tail=0, fused_tail=0, direct_3x3=0):
+            with H.option_scope(encoder_generic=2):     # every bottleneck through the implicit-GEMM tile kernel
                 emb_g, sp_g = e16(x)
             assert torch.equal(emb_g, emb16) and torch.equal(sp_g, sp16)
 
@@ -642,89 +611,6 @@ def test_direct_stem_convolution(hip, n, h, w):
     w8[..., :3] = wgt.permute(0, 2, 3, 1)
     old = hip.conv2d_nhwc_bn_relu_maxpool(packed, w8.cuda(), sc.cuda(), sh.cuda(), stride=2, pad=3)
     np.testing.assert_allclose(got.float().cpu().numpy(), old.float().cpu().numpy(), atol=4e-2 if HALF == torch.bfloat16 else 6e-3, rtol=2e-2)
-
-
-@pytest.mark.parametrize("n_img,beam", [(3, 5), (8, 16), (11, 1), (17, 10), (256, 5)])
-def test_cross_attention_with_fused_query_projection(hip, n_img, beam):
-    """dh_attn_cross_qproj_decode (fc_q on the deferred-LayerNorm rows + attention, one launch, K head-dim slots permuted)
-    against the two-launch route (dh_linear_ln A-fold -> dh_attn_cross_decode_packed) and against fp32 math."""
-    d, h, s = 512, 8, 49
-    r = n_img * beam
-    g = torch.Generator().manual_seed(n_img * 31 + beam)
-    y = bf(torch.randn(r, d, generator=g) * 1.5 + 0.2)
-    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2
-    wq, bq = bf(torch.randn(d, d, generator=g) / d ** 0.5), torch.randn(d, generator=g) * 0.1
-    kv = bf(torch.randn(n_img * s, 2 * d, generator=g))
-    mask = torch.zeros(n_img * s, dtype=torch.uint8)
-    mask[7] = 1
-    t = y.float().view(r, -1, 64)
-    mean = t.mean(-1)
-    stats = torch.stack([mean, ((t - mean[..., None]) ** 2).sum(-1)], -1).contiguous()
-    wf = bf(wq.float() * gamma[None, :])
-    bfold = (bq + (wq.float() * beta[None, :]).sum(1)).contiguous()
-    colsum = wf.float().sum(1).contiguous()
-    kp1, vt = hip.attn_cross_pack(kv.cuda(), n_img, s, d, h, dperm=True)
-    out = torch.full((r, d), 3.0, device="cuda", dtype=HALF)
-    hip.attn_cross_qproj_decode(y.cuda(), stats.cuda(), 1e-5, wf.cuda(), bfold.cuda(), colsum.cuda(), kp1, vt, mask.cuda(), out,
-                                n_img, beam, s, d, h, 8.0)
-    q2 = hip.linear_ln(y.cuda(), wf.cuda(), bfold.cuda(), a_ln=(stats.cuda(), 1e-5, colsum.cuda()))
-    kp0, vt0 = hip.attn_cross_pack(kv.cuda(), n_img, s, d, h)
-    two = torch.empty_like(out)
-    hip.attn_cross_decode_packed(q2, kp0, vt0, mask.cuda(), two, n_img, beam, s, d, h, 8.0)
-    np.testing.assert_allclose(out.float().cpu().numpy(), two.float().cpu().numpy(), atol=3e-2, rtol=2e-2)
-    # ... and BIT FOR BIT against the two-launch route on the same (head-dim permuted) K tiles, through either GEMM kernel: the fused
-    # launch keeps the fp32 rounding of q (round 5: the compiler had turned its (f16)fma(...) into v_fma_mixlo_f16, one rounding
-    # instead of two -- 1 q element in ~15,000 differed in fp16, found by tools/fuzz_variants.py's option sweep)
-    for q_route in (q2, hip.linear_ln_wreg(y.cuda(), hip.pack_mfma_fragments(wf.cuda()), d, bfold.cuda(), a_ln=(stats.cuda(), 1e-5, colsum.cuda()))):
-        same = torch.empty_like(out)
-        hip.attn_cross_decode_packed(q_route, kp1, vt, mask.cuda(), same, n_img, beam, s, d, h, 8.0, dperm=True)
-        assert torch.equal(out, same)
-    q32 = F.linear(F.layer_norm(y.float(), (d,), gamma, beta, 1e-5), wq.float(), bq)
-    for row in range(0, r, max(1, r // 7)):
-        i = row // beam
-        keys = kv.float()[i * s:(i + 1) * s, :d].reshape(s, h, 64)
-        vals = kv.float()[i * s:(i + 1) * s, d:].reshape(s, h, 64)
-        energy = (torch.einsum("hd,lhd->hl", q32[row].view(h, 64), keys) / 8.0).masked_fill(mask[i * s:(i + 1) * s].bool()[None], -1e8)
-        ref = torch.einsum("hl,lhd->hd", torch.softmax(energy, -1), vals).reshape(-1)
-        np.testing.assert_allclose(out[row].float().cpu().numpy(), ref.numpy(), atol=6e-2 if HALF == torch.bfloat16 else 1.5e-2, rtol=2e-2)
-
-
-@pytest.mark.parametrize("n_img,beam,t,folded", [(3, 5, 0, False), (9, 5, 7, True), (8, 1, 3, True), (17, 6, 33, True), (2, 4, 39, False)])
-def test_self_attention_with_fused_qkv_projection(hip, n_img, beam, t, folded):
-    """dh_attn_self_qkv_decode (QKV projection + attention over the KV cache + cache append, one launch) against
-    dh_linear(_ln) -> dh_attn_self_decode: attention output and appended cache rows bit for bit."""
-    d, h, tmax = 512, 8, 40
-    r = n_img * beam
-    g = torch.Generator().manual_seed(n_img * 100 + t)
-    x = bf(torch.randn(r, d, generator=g) * 1.3 + 0.1)
-    w, b = bf(torch.randn(3 * d, d, generator=g) / d ** 0.5), torch.randn(3 * d, generator=g) * 0.1
-    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.2
-    kc, vc = bf(torch.randn(tmax + 1, r, d, generator=g)), bf(torch.randn(tmax + 1, r, d, generator=g))
-    src = (torch.arange(r)[:, None] // beam * beam + torch.randint(0, beam, (r, tmax + 1), generator=g)).int()
-    tokens = torch.randint(0, 4, (r, tmax), generator=g, dtype=torch.int32)
-    a_ln = None
-    if folded:
-        tt = x.float().view(r, -1, 64)
-        mean = tt.mean(-1)
-        stats = torch.stack([mean, ((tt - mean[..., None]) ** 2).sum(-1)], -1).contiguous().cuda()
-        wf = bf(w.float() * gamma[None, :]).cuda()
-        bfold = (b + (w.float() * beta[None, :]).sum(1)).contiguous().cuda()
-        colsum = wf.float().sum(1).contiguous()
-        a_ln = (stats, 1e-5, colsum)
-    else:
-        wf, bfold = w.cuda(), b.cuda()
-    outs = []
-    for fused in (False, True):
-        kcd, vcd = kc.cuda().clone(), vc.cuda().clone()
-        out = torch.full((r, d), 5.0, device="cuda", dtype=HALF)
-        if fused:
-            hip.attn_self_qkv_decode(x.cuda(), wf, bfold, kcd, vcd, src.cuda(), tokens.cuda(), out, n_img, beam, 1, r, t, d, h, 8.0, 0, a_ln=a_ln)
-        else:
-            qkv = hip.linear_ln(x.cuda(), wf, bfold, a_ln=a_ln)
-            hip.attn_self_decode(qkv, kcd, vcd, src.cuda(), tokens.cuda(), out, n_img, beam, 1, r, t, d, h, 8.0, 0)
-        outs.append((out.cpu(), kcd[t].cpu(), vcd[t].cpu(), kcd[t + 1 if t < tmax else 0].cpu()))
-    assert torch.equal(outs[0][0], outs[1][0])
-    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3])
 
 
 def test_round16_keep_nonzero_and_fp16_spatial_features(hip):
@@ -803,142 +689,11 @@ def test_decode_chain_wreg_equals_tile_chain(kind):
         t1, l1 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
         assert "wo_pk" in model.decoder._get_plan()["layers"][0]
         from deephumor_amd import hip as H
-        with H.option_scope(decode_wreg_plan=0):          # (a changed option re-keys the plan: it is rebuilt at the next call)
+        with H.option_scope(decode_wreg=0):               # (a changed option re-keys the plan: it is rebuilt at the next call)
             assert "wo_pk" not in model.decoder._get_plan()["layers"][0]
             t2, l2 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
         assert "wo_pk" in model.decoder._get_plan()["layers"][0]
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
-
-
-@pytest.mark.parametrize("m,cross", [(37, True), (380, True), (1280, True), (81, False), (640, False), (3000, True)])
-def test_decode_gemm_chain_equals_separate_launches(hip, m, cross):
-    """dh_decode_gemm_chain ((enc_)fc_o -> fc_1 -> fc_2 -> next qkv as ONE persistent launch, rows owned by XCDs, XCD-local hand-overs)
-    against the same four GEMMs as separate dh_linear_ln_wreg launches: every output and every statistics array bit for bit, three
-    launches in a row on the same counters (they must come back to zero), the error word clear.  ``cross = False`` is the
-    SelfAttentionDecoderLayer chain, where fc_2 re-writes the rows fc_o read (the phase behind it takes the L1-invalidate path)."""
-    d, pf = 512, 2048
-    g = torch.Generator().manual_seed(m + int(cross))
-    r = lambda *shape, sc=1.0: bf(torch.randn(*shape, generator=g) * sc).cuda()
-    f32 = lambda *shape, sc=1.0: (torch.randn(*shape, generator=g) * sc).cuda()
-    att, x_in = r(m, d), r(m, d)
-    w_o, w_1, w_2, w_q = r(d, d, sc=d ** -0.5), r(pf, d, sc=d ** -0.5), r(d, pf, sc=pf ** -0.5), r(3 * d, d, sc=d ** -0.5)
-    b_o, b_1, b_2, b_q = f32(d, sc=0.1), f32(pf, sc=0.1), f32(d, sc=0.1), f32(3 * d, sc=0.1)
-    cs_1, cs_q = w_1.float().sum(1).contiguous(), w_q.float().sum(1).contiguous()
-    gam = [(torch.rand(d, generator=g) + 0.5).cuda() for _ in range(2)]
-    bet = [f32(d, sc=0.2) for _ in range(2)]
-    t = x_in.float().view(m, -1, 64)
-    mean = t.mean(-1)
-    st_in = torch.stack([mean, ((t - mean[..., None]) ** 2).sum(-1)], -1).contiguous()
-    pk = {k: hip.pack_mfma_fragments(v) for k, v in (("o", w_o), ("1", w_1), ("2", w_2), ("q", w_q))}
-
-    def run(fused, x):
-        """x: the residual stream (pre-LayerNorm rows + st_x); returns every tensor the chain writes"""
-        st_x = st_in.clone()
-        o, ff, xq = torch.empty_like(x), torch.empty((m, pf), dtype=HALF, device="cuda"), torch.empty((m, 3 * d), dtype=HALF, device="cuda")
-        st_o = torch.empty((m, 8, 2), device="cuda")
-        xout, st_out = (torch.empty_like(x), torch.empty((m, 8, 2), device="cuda")) if cross else (x, st_x)   # no encoder attention: fc_2 re-writes x / st_x
-        steps = [dict(a=att, w_packed=pk["o"], n=d, bias=b_o, out=o, residual=x, r_ln=(st_x, 1e-5, gam[0], bet[0]), o_stats=st_o),
-                 dict(a=o, w_packed=pk["1"], n=pf, bias=b_1, out=ff, relu=True, a_ln=(st_o, 1e-5, cs_1)),
-                 dict(a=ff, w_packed=pk["2"], n=d, bias=b_2, out=xout, residual=o, r_ln=(st_o, 1e-5, gam[1], bet[1]), o_stats=st_out),
-                 dict(a=xout, w_packed=pk["q"], n=3 * d, bias=b_q, out=xq, a_ln=(st_out, 1e-5, cs_q))]
-        if fused:
-            sync = torch.zeros(80, dtype=torch.int32, device="cuda")
-            outs = []
-            for rep in range(3):
-                if not cross:
-                    x.copy_(x_in); st_x.copy_(st_in)
-                hip.decode_gemm_chain(steps, m, sync)
-                outs.append([v.clone() for v in (o, st_o, ff, xout, st_out, xq)])
-                assert int(sync[:73].abs().sum()) == 0 and int(sync[73]) == 0
-            for other in outs[1:]:
-                assert all(torch.equal(a, b) for a, b in zip(outs[0], other))
-            return outs[0]
-        for s_ in steps:
-            if s_.get("residual") is not None:
-                _, stats = hip.linear_ln_wreg(s_["a"], s_["w_packed"], s_["n"], s_["bias"], out=s_["out"], residual=s_["residual"], r_ln=s_["r_ln"])
-                s_["o_stats"].copy_(stats)
-            else:
-                hip.linear_ln_wreg(s_["a"], s_["w_packed"], s_["n"], s_["bias"], out=s_["out"], relu=bool(s_.get("relu")), a_ln=s_["a_ln"])
-        return [v.clone() for v in (o, st_o, ff, xout, st_out, xq)]
-    want = run(False, x_in.clone())
-    got = run(True, x_in.clone())
-    for name, a, b in zip(("o", "st_o", "ff", "x", "st_x", "qkv"), want, got):
-        assert torch.equal(a, b), name
-
-
-@pytest.mark.parametrize("kind", ["CaptioningTransformer", "CaptioningTransformerBase"])
-def test_decode_chain_fusion_equals_separate_launches(kind):
-    """Option decode_chain_fusion: the layer's trailing GEMMs + the next layer's qkv as one launch per layer -- same tokens, same lengths
-    as the chain of separate launches, at 3, 38 (x beam 10: the C5 shard's 380 rows) and 130 images, twice."""
-    import deephumor_amd.models as M
-    from deephumor_amd import hip as H
-    from deephumor_amd.synth import synth_state_dict
-    model = getattr(M, kind)(1000, hid_dim=512, n_layers=3).eval()
-    model.load_state_dict(synth_state_dict(model.state_dict(), seed=77))
-    model = model.to(HALF).cuda()
-    for n, beam in ((3, 5), (38, 10), (130, 5)):
-        imgs = synth_images(n, seed=21).cuda()
-        kw = dict(max_len=9, beam_size=beam, top_k=20, seed=3)
-        with torch.no_grad():
-            t1, l1 = model.generate_batch(imgs, **kw)
-            with H.option_scope(decode_chain_fusion=1):
-                for _ in range(2):
-                    t2, l2 = model.generate_batch(imgs, **kw)
-                    assert torch.equal(t1, t2) and torch.equal(l1, l2), (kind, n)
-
-
-def test_decode_chain_unfused_qproj_equals_fused():
-    """Option cross_qproj: 0 (default since round 5: fc_q as its own register-stationary GEMM in front of the packed cross-attention, K
-    packed in the fused launch's head-dim slot order) against 1 (fc_q inside the attention launch, dh_attn_cross_qproj_decode): same
-    tokens, same lengths, bit for bit -- the choice does not touch shard invariance."""
-    import deephumor_amd.models as M
-    from deephumor_amd import hip as H
-    from deephumor_amd.synth import synth_state_dict
-    model = M.CaptioningTransformer(1000, hid_dim=512, n_layers=2).eval()
-    model.load_state_dict(synth_state_dict(model.state_dict(), seed=99))
-    model = model.to(HALF).cuda()
-    for n in (7, 64):
-        imgs = synth_images(n, seed=13).cuda()
-        with torch.no_grad():
-            with H.option_scope(cross_qproj=1):
-                t1, l1 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
-            with H.option_scope(cross_qproj=0):
-                t2, l2 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
-        assert torch.equal(t1, t2) and torch.equal(l1, l2), n
-        # ... and with the K / V prefetch workgroups riding on the fc_q launch (dh_linear_ln_wreg_prefetch): they write nothing
-        with torch.no_grad(), H.option_scope(cross_qproj=0, cross_kv_prefetch=256):
-            t3, l3 = model.generate_batch(imgs, max_len=10, beam_size=5, top_k=20, seed=5)
-        assert torch.equal(t1, t3) and torch.equal(l1, l3), n
-
-
-@pytest.mark.parametrize("m,n_pf", [(40, 8), (200, 100), (1280, 256), (1280, 1024)])
-def test_linear_wreg_prefetch_workgroups_change_nothing(m, n_pf):
-    """dh_linear_ln_wreg_prefetch: the GEMM's outputs with prefetch workgroups in the launch equal the plain launch bit for bit, the
-    prefetched arrays are untouched (tile sizes as the packed cross-attention operands: 49 x 128 used bytes of 8 KB K tiles)."""
-    from deephumor_amd import hip as H
-    g = torch.Generator().manual_seed(m)
-    a = (torch.randn(m, 512, generator=g)).to(HALF).cuda()
-    w = (torch.randn(512, 512, generator=g) / 22.6).to(HALF).cuda()
-    bias = torch.randn(512, generator=g).cuda()
-    st = torch.stack([torch.randn(m, 8, generator=g) * 0.1, torch.rand(m, 8, generator=g) * 50 + 10], -1).contiguous().cuda()
-    cs = torch.randn(512, generator=g).cuda()
-    wp = H.pack_mfma_fragments(w)
-    n_tiles = 37 * 8
-    kp = torch.randn(n_tiles, 4096, generator=g).to(HALF).cuda()
-    vt = torch.randn(n_tiles, 4096, generator=g).to(HALF).cuda()
-    kp0, vt0 = kp.clone(), vt.clone()
-    want = H.linear_ln_wreg(a, wp, 512, bias, a_ln=(st, 1e-5, cs))
-    got = H.linear_ln_wreg(a, wp, 512, bias, a_ln=(st, 1e-5, cs), prefetch=(kp, vt, 8192, 49 * 128, 8192, n_tiles, 4, n_pf))
-    torch.cuda.synchronize()
-    assert torch.equal(got, want) and torch.equal(kp, kp0) and torch.equal(vt, vt0)
-    # the residual form (fc_o) carrying part 0 of 2
-    res = torch.randn(m, 512, generator=g).to(HALF).cuda()
-    gamma, beta = torch.randn(512, generator=g).cuda(), torch.randn(512, generator=g).cuda()
-    want, wst = H.linear_ln_wreg(a, wp, 512, bias, residual=res, r_ln=(st, 1e-5, gamma, beta))
-    got, gst = H.linear_ln_wreg(a, wp, 512, bias, residual=res, r_ln=(st, 1e-5, gamma, beta),
-                                prefetch=(kp, vt, 8192, 49 * 128, 8192, n_tiles, 4, n_pf, 0, 2))
-    torch.cuda.synchronize()
-    assert torch.equal(got, want) and torch.equal(gst, wst) and torch.equal(kp, kp0) and torch.equal(vt, vt0)
 
 
 @pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
@@ -958,7 +713,7 @@ def test_decode_with_vocab_wreg_equals_vocab_areg(kind):
         t1, l1 = model.generate_batch(imgs, max_len=9, beam_size=5, top_k=20, seed=6)
         s1 = model.generate_batch(imgs[:3], max_len=9, beam_size=5, top_k=20, seed=6)
         assert "cls_w_pk" in model.decoder._get_plan()
-        with H.option_scope(vocab_wreg_plan=0):
+        with H.option_scope(vocab_wreg=0):
             assert "cls_w_pk" not in model.decoder._get_plan()
             t2, l2 = model.generate_batch(imgs, max_len=9, beam_size=5, top_k=20, seed=6)
     assert torch.equal(t1, t2) and torch.equal(l1, l2)
@@ -1112,10 +867,9 @@ def test_encoder_round4_kernels_equal_the_kernels_they_replace(n):
     with torch.no_grad():
         emb, sp = enc(x)
         from deephumor_amd import hip as H
-        with H.option_scope(conv1x1_wreg=0, conv_s4=0, s2_tail=0, s1_conv1_fusion=0, s2_conv1_fusion=0):
+        with H.option_scope(encoder_generic=1):       # round 3's kernel set: tile GEMM 1x1 layers, ring tails, no conv1 fusion
             emb0, sp0 = enc(x)
-        # the stage-1 fusions alone on top of the tile / ring kernels, and the stage-2 strip tail without its fusion
-        with H.option_scope(conv1x1_wreg=0, conv_s4=0, s2_conv1_fusion=0):
+        with H.option_scope(encoder_generic=2):       # every bottleneck convolution through the implicit-GEMM tile kernel
             emb1, sp1 = enc(x)
     assert torch.equal(emb, emb0) and torch.equal(sp, sp0)
     assert torch.equal(emb, emb1) and torch.equal(sp, sp1)

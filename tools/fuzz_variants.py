@@ -1,9 +1,8 @@
 """Randomised equivalence sweep of the ways one batch can be decoded on the GPU box: ``generate_batch`` against the same call with
 ``streams`` = 2 / 3 (image sub-batches on concurrent HIP streams), ``early_stop_every`` (host-polled early exit), the captured-hipGraph
 replay (``generate_batch_graphed``, replayed with other images and seeds after capture), a 2-way split with ``img0``, a random
-combination of the run-time options that select between bit-identical kernels (``hip.option_scope``: fused / unfused cross-attention
-query projection, the K / V prefetch workgroups, the one-launch GEMM chain, tile instead of register-stationary GEMMs, the fused beam
-step, the fused QKV + self-attention launch, both classifiers), and a ``save`` / ``from_pretrained`` round trip of the model -- all five model classes, fp32 / bf16 / fp16, random batch sizes, decode
+combination of the run-time options that select between bit-identical kernels (``hip.option_scope``: tile instead of register-stationary GEMMs / LSTM steps,
+the three classifiers, the encoder's specialised kernels against the implicit-GEMM tile kernel), and a ``save`` / ``from_pretrained`` round trip of the model -- all five model classes, fp32 / bf16 / fp16, random batch sizes, decode
 settings, prefixes, EOS made likely so that images finish at different steps.  Everything must be bit-equal.  TEST INFRASTRUCTURE.
 
     python tools/fuzz_variants.py --trials 60 > gpurun_out/fuzz_var.jsonl
@@ -25,15 +24,12 @@ from deephumor_amd import hip                             # noqa: E402
 from deephumor_amd.synth import load_synthetic, synth_images           # noqa: E402
 
 # options whose every value must give the same tokens (each selects between kernels that are bit-identical by construction)
-OPTION_CHOICES = {"cross_qproj": (0, 1), "cross_kv_prefetch": (0, 64), "decode_chain_fusion": (0, 1), "decode_wreg_min_rows": (1, 100000),
-                  "vocab_wreg_transformer": (0, 1), "fused_beam_step": (0, 1), "qkv_fusion_max_rows": (0, 100000), "lstm_wreg_min_rows": (1, 256),
-                  "vocab_wreg": (0, 1),
-                  # kernel selection in the encoder / decoder plans (each replacement is bit-identical to the kernel it replaces; NOT in the list:
-                  # direct_stem -- the direct stem sums its 147 products in another order than the implicit GEMM, close but not bit-equal --
-                  # deferred_ln, packed_cross, qproj_fusion (other arithmetic by design) and f32_split)
-                  "conv1x1_wreg": (0, 1), "conv_s4": (0, 1), "direct_3x3": (0, 1), "stem_pool": (0, 1), "fused_tail": (0, 1),
-                  "s1_conv1_fusion": (0, 1), "s2_conv1_fusion": (0, 1), "s3_tail": (0, 1), "s2_tail": (0, 1), "vocab_wreg_plan": (0, 1),
-                  "decode_wreg_plan": (0, 1)}
+OPTION_CHOICES = {"decode_wreg_min_rows": (1, 100000), "decode_wreg": (0, 1), "vocab_wreg_transformer": (0, 1), "lstm_wreg_min_rows": (1, 256),
+                  "lstm_wreg": (0, 1), "vocab_wreg": (0, 1), "vocab_areg": (0, 1, 128),
+                  # kernel selection in the encoder plans: levels 1 / 2 replace the specialised kernels by the ones they are bit-identical to
+                  # (NOT in the list: encoder_generic 3 -- the direct stem sums its 147 products in another order than the implicit GEMM,
+                  # close but not bit-equal -- deferred_ln, packed_cross (other arithmetic by design) and f32_split)
+                  "encoder_generic": (0, 1, 2)}
 
 KINDS = ("CaptioningLSTM", "CaptioningLSTMWithLabels", "CaptioningTransformerBase", "CaptioningTransformer", "CaptioningTransformerWithLabels")
 
@@ -92,7 +88,7 @@ def main(argv=None):
                         for k, val in opts.items():
                             with hip.option_scope(**{k: val}):
                                 rec["options_culprits"][k] = not same(model.generate_batch(images, *extra, seed=seed, **kw))
-                        with hip.option_scope(**{k: (1 - val if val in (0, 1) else val) for k, val in opts.items() if k in ("cross_qproj", "vocab_wreg")}):
+                        with hip.option_scope(**{k: (1 - val if val in (0, 1) else val) for k, val in opts.items() if k in ("decode_wreg", "vocab_wreg")}):
                             rec["options_flipped_same"] = same(model.generate_batch(images, *extra, seed=seed, **kw))
                         rec["base_repeat_same"] = same(model.generate_batch(images, *extra, seed=seed, **kw))
                 if t % 3 == 0:

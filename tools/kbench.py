@@ -83,10 +83,8 @@ def main():
     res["cross:lds"] = timeit(lambda i: hip.attn_cross_decode(x[i % 6], kv[i % 6], mask, o, NIMG, BEAM, S, D, H, 8.0))
     res["cross:mfma"] = timeit(lambda i: hip.attn_cross_decode_packed(x[i % 6], packed[i % 6][0], packed[i % 6][1], mask, o, NIMG, BEAM, S, D, H, 8.0))
     packed_d = [hip.attn_cross_pack(t, NIMG, S, D, H, dperm=True) for t in kv]
-    wq = [rnd(D, D, scale=D ** -0.5) for _ in range(6)]
-    bq, csq = torch.zeros(D, device=dev), torch.zeros(D, device=dev)
-    res["cross:qproj+attn (fused)"] = timeit(lambda i: hip.attn_cross_qproj_decode(x[i % 6], st[i % 6], 1e-5, wq[i % 6], bq, csq, packed_d[i % 6][0],
-                                                                                  packed_d[i % 6][1], mask, o, NIMG, BEAM, S, D, H, 8.0))
+    res["cross:mfma (dperm slots)"] = timeit(lambda i: hip.attn_cross_decode_packed(x[i % 6], packed_d[i % 6][0], packed_d[i % 6][1], mask, o, NIMG, BEAM, S, D, H,
+                                                                                  8.0, dperm=True))
     # self attention at t = 16 and 31
     qkv = [rnd(R, 3 * D) for _ in range(6)]
     kc = [rnd(33, R, D) for _ in range(6)]

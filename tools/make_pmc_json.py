@@ -23,12 +23,10 @@ KEYS = [
     ("c3", "dh_attn_self_decode", "attn_decode_reg_kernel", 2048,
      "launch-weighted mean over the history depths of one sweep (2..22 keys per row)"),
     ("c3", "dh_attn_cross_decode", "attn_cross_mfma_kernel", 512,
-     "the packed cross-attention launch (option cross_qproj 0, the default since round 5: fc_q is its own GEMM in front of it)"),
-    ("c3", "dh_attn_cross_decode[qproj+attn]", "attn_cross_qproj_kernel", 256,
-     "the fused fc_q + cross-attention launch (option cross_qproj 1): includes the 8 x 64 KB fc_q weight slices every workgroup stages"),
-    ("c3", "dh_linear[ffn]{1280x512x2048}", "linear_wreg_kernelIDF16bLi4ELi1ELi40ELi4ELi1E", 256,
+     "the packed cross-attention launch (fc_q is its own GEMM in front of it)"),
+    ("c3", "dh_linear[ffn]{1280x512x2048}", "linear_wreg_kernelIDF16bLi4ELi40ELi4ELi1E", 256,
      "fc_2 of the feed-forward layer on the register-stationary kernel (64 columns x 40 rows per workgroup, K = 2,048)"),
-    ("c3", "dh_linear[ffn]{1280x2048x512}", "linear_wreg_kernelIDF16bLi8ELi1ELi80ELi1ELi0E", 256,
+    ("c3", "dh_linear[ffn]{1280x2048x512}", "linear_wreg_kernelIDF16bLi8ELi80ELi1ELi0E", 256,
      "fc_1 of the feed-forward layer on the register-stationary kernel (128 columns x 80 rows per workgroup)"),
 ]
 
@@ -44,8 +42,18 @@ def mean_kb(rs, frag, wgs):
     return (sum(float(r["total"]) for r in sel) / n, n) if n else (None, 0)
 
 
+def kernel_only_us(d, wl, frag, wgs):
+    """Launch-weighted mean duration of the same kernel in the rocprofv3 kernel trace of the same tree (`<wl>_bf16_kernel_stats.csv`)."""
+    try:
+        sel = [r for r in rows(d / f"{wl}_bf16_kernel_stats.csv") if frag in r["name"] and (wgs is None or int(r["workgroups"]) == wgs)]
+    except OSError:
+        return None, 0
+    n = sum(int(r["calls"]) for r in sel)
+    return (sum(float(r["total_ns"]) for r in sel) / n / 1e3, n) if n else (None, 0)
+
+
 def main():
-    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r5")
+    d = Path(sys.argv[1] if len(sys.argv) > 1 else "profiles/r6")
     commit = sys.argv[2] if len(sys.argv) > 2 else subprocess.run(
         ["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
     out = {"commit": commit,
@@ -59,6 +67,9 @@ def main():
         out.setdefault(wl, {})[key] = {
             "traffic_bytes_per_launch": (2 * f + w) * 1024, "fetch_size_kb_raw": f, "write_size_kb": w,
             "launches_fetch_pass": nf, "launches_write_pass": nw, "note": note}
+        us, n_us = kernel_only_us(d, wl, frag, wgs)
+        if us is not None:
+            out[wl][key].update(kernel_only_us=us, kernel_only_launches=n_us)
     json.dump(out, open(d / "pmc_hbm_traffic.json", "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -72,10 +72,8 @@ def main(argv=None):
         cap_pad = cap.clone()
         cap_pad[(torch.arange(cap.shape[1])[None, :] >= lengths[:, None]).cuda()] = 0          # (padding as pad_collate leaves it)
         tidx = torch.randint(0, n, (n,), generator=g)
-        # the opt-in kernels carry scratch of their own (chain counters, prefetch workgroups, the fused beam step's arrival counters)
-        opts = {k: 1 for k in ("decode_chain_fusion", "fused_beam_step", "cross_qproj", "vocab_wreg_transformer") if rng.random() < 0.3}
-        if rng.random() < 0.3:
-            opts["cross_kv_prefetch"] = 64
+        # the opt-in kernel selections
+        opts = {k: 1 for k in ("vocab_wreg_transformer", "encoder_generic") if rng.random() < 0.3}
         rec = dict(t=t, options=opts, kind=kind, dt=str(dt)[6:], V=v, N=n, **{k: x for k, x in kw.items()})
         try:
             outs = []
