@@ -447,7 +447,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
         for w in range(1, warmup):
             one_step(model, images, rank * n_local, n_total, seed=w, graph=graph)
         pipelined = args.schedule == "pipelined" and not graph
-        seq = None
+        seq = seq_rank_times = None
         # events only around the launches of the dominant key (a few dozen pairs per step)
         stride = max(1, breakdown[dominant]["calls"] // 32)
         watch = {dominant} if main_line and not graph else None
@@ -457,6 +457,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             # CUs with the next batch's encoder: its elapsed time there says nothing about the kernel) -- then the production schedule
             ts, _, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=watch, stride=stride)
             seq = {"value": n_total * steps / ts, "unit": "captions/s", "ms_per_step": ts / steps * 1e3}
+            seq_rank_times = list(RANK_TIMES)             # every rank's wall time of THIS region (the one `value` comes from)
             dt, lens, _ = timed_steps(model, images, rank, n_local, n_total, steps, barrier, pipelined=True)
         elif watch:
             dt, lens, summary = timed_steps(model, images, rank, n_local, n_total, steps, barrier, watch=watch, stride=stride)
@@ -501,7 +502,8 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                                    "at the dependent-launch floor (DESIGN section 12), so this fraction prices launch latency, not bandwidth -- the "
                                    "kernels north_star names are priced in roofline_self_attention / roofline_cross_attention / "
                                    "roofline_decoder_attention_combined")
-    res["per_rank_ms_per_step"] = {"min": min(RANK_TIMES) / steps * 1e3, "max": max(RANK_TIMES) / steps * 1e3, "ranks": len(RANK_TIMES)}
+    rt = seq_rank_times or list(RANK_TIMES)
+    res["per_rank_ms_per_step"] = {"min": min(rt) / steps * 1e3, "max": max(rt) / steps * 1e3, "ranks": len(rt), "skew_ms": (max(rt) - min(rt)) / steps * 1e3}
     res["encoder_layers"] = encoder_table(breakdown, dtype)
     if workload in ("c3", "c5"):
         for name, entry in (("roofline_self_attention", "dh_attn_self_decode"), ("roofline_cross_attention", "dh_attn_cross_decode")):
@@ -855,9 +857,15 @@ def stub_workload(args, rank, world, dev):
     """``--stub`` (tests/test_dist_cpu.py): the whole control flow of a multi-rank run -- launcher, process group, image shards,
     barrier / K steps / barrier, MAX over ranks, one all_gather per step, rank 0's line -- with the model replaced by a pure
     function of the GLOBAL image index, on CPU over gloo.  Its line says ``"data": "stub"``: it is never a measurement."""
-    from deephumor_amd.dist import gather_captions_async
-    n_local, n_total = args.batch, args.batch * world
-    idx = torch.arange(rank * n_local, (rank + 1) * n_local)
+    from deephumor_amd.dist import gather_captions_async, shard_range
+    if args.workload == "c5":
+        # BASELINE config 5's partitioning: 300 templates in contiguous, UNEVEN shards (8 ranks: 38 x 4 + 37 x 4), strong scaling
+        n_total = 300
+        lo, hi = shard_range(n_total, rank, world)
+    else:
+        n_local, n_total = args.batch, args.batch * world
+        lo, hi = rank * n_local, (rank + 1) * n_local
+    idx = torch.arange(lo, hi)
     calls = []
     pending = [None]
 
@@ -875,7 +883,10 @@ def stub_workload(args, rank, world, dev):
     dt, (toks, lens) = timed_region(step, args.steps, world, dev, drain=lambda: drain_pending(pending))
     want = (torch.arange(n_total)[:, None] * 10 + torch.arange(MAX_LEN)[None, :] + args.steps - 1) % 97
     return {"value": n_total * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "steps_run": calls,
-            "per_rank_ms_per_step": {"min": min(RANK_TIMES) / args.steps * 1e3, "max": max(RANK_TIMES) / args.steps * 1e3, "ranks": len(RANK_TIMES)},
+            "per_rank_ms_per_step": {"min": min(RANK_TIMES) / args.steps * 1e3, "max": max(RANK_TIMES) / args.steps * 1e3, "ranks": len(RANK_TIMES),
+                                     "skew_ms": (max(RANK_TIMES) - min(RANK_TIMES)) / args.steps * 1e3},
+            "shard": [lo, hi], "shard_sizes": [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
+            if args.workload == "c5" else [args.batch] * world,
             "gathered": int(toks.shape[0]), "gather_in_global_order": bool(torch.equal(toks, want)),
             "mean_caption_len": float(lens.float().mean())}
 
@@ -958,9 +969,11 @@ def main(argv=None):
 
     if args.stub:
         res = stub_workload(args, rank, world, dev)
-        return finish(dict(res, metric="captions/sec (224x224, 32-tok, beam=5)", unit="captions/s", n_gpus=world, steps=args.steps,
-                           warmup=args.warmup, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="none", data="stub",
-                           config={"workload": "STUB: control flow only, no model, CPU/gloo"}))
+        c5 = args.workload == "c5"
+        return finish(dict(res, metric="captions/sec (224x224, 32-tok, beam=10, 300-template sweep)" if c5 else "captions/sec (224x224, 32-tok, beam=5)",
+                           unit="captions/s", n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True,
+                           scaling="strong" if c5 else "weak", vs_baseline=None, dtype="none", data="stub",
+                           config={"workload": "STUB: control flow only, no model, CPU/gloo" + (" (C5 partitioning: 300 templates, uneven shards)" if c5 else "")}))
 
     if args.shard_of:
         if world != 1 or not 0 <= args.shard_rank < args.shard_of or args.workload.startswith("score-"):

@@ -141,6 +141,7 @@ SIGNATURES = {
     "dh_beam_gather": [_P, _I, _I, _P, _I, _P, _I, _P, _P],
     "dh_beam_expand": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "dh_split_f32x": [_P, _I, _P, _I, _I, _I, _P],
+    "dh_f32x_take_overflow": [_P, _P],
     "dh_linear_f32x": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv2d_nhwc_f32x": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],

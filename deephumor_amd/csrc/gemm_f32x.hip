@@ -33,7 +33,21 @@ struct F32xParams {
     int M, N, K, relu;
     int H, Wd, Cin, Ho, Wo, KS, stride, pad;           // conv loader (NHWC input)
     int tiles_m, tiles_n, n_fast;                      // n_fast: consecutive workgroups walk the N tiles of one M tile (small weights)
+    unsigned* range_flag;                              // sticky per-stream word: an activation outside the fp16 range was split (see below)
 };
+
+// Range guard of the ACTIVATIONS: the weights' range is checked when a plan is built, but an activation with |x| >= 65504
+// splits into hi = inf and the GEMM would silently return inf / NaN.  Every thread keeps the largest |x| it splits (one v_max3 per
+// pair) and a kernel that saw one out of range sets a sticky word -- one of 256, chosen by the launch stream -- that the Python layer
+// reads where it synchronises anyway (dh_f32x_take_overflow) and answers by repeating the call on the exact-fp32 kernels.
+// (Below 6.1e-5 an operand's hi part is an fp16 subnormal: its ABSOLUTE error stays <= 2^-36 after the lo part -- negligible next to
+// rows of ordinary magnitude -- but a tensor that is tiny THROUGHOUT keeps only ~1e-5 relative accuracy: documented, not guarded.)
+constexpr float kF16Max = 65504.0f;
+__device__ unsigned g_f32x_range_flags[256];
+__device__ __forceinline__ void track(float& amax, float a, float b) { amax = fmaxf(amax, fmaxf(fabsf(a), fabsf(b))); }
+__device__ __forceinline__ void report(const F32xParams& p, float amax) {
+    if (amax >= kF16Max) atomicOr(p.range_flag, 1u);
+}
 
 __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
     const f16_t ha = (f16_t)a, hb = (f16_t)b;
@@ -160,12 +174,14 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? 2 : 3) void gemm_f32x_k
             if (st_ci == p.Cin) { st_ci = 0; if (++st_kw == p.KS) { st_kw = 0; ++st_kh; } }
         }
     };
+    float amax = 0.f;                                  // largest |activation| this thread has split (range guard)
     auto store_a = [&](int buf) {
         unsigned char* ah = lds + buf * STAGE;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
             const int row = (tid >> 3) + it * 32;
             uint2 hi, lo;
+            track(amax, areg[it].x, areg[it].y); track(amax, areg[it].z, areg[it].w);
             split2(areg[it].x, areg[it].y, hi.x, lo.x);
             split2(areg[it].z, areg[it].w, hi.y, lo.y);
             const int off = row * 64 + swz(row, a_kc >> 1) * 16 + (a_kc & 1) * 8;
@@ -233,6 +249,7 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? 2 : 3) void gemm_f32x_k
         __syncthreads();
     }
 
+    report(p, amax);
     epilogue<TM, TN>(p, acc, cor, m0 + wm0, n0 + wn0, l15, lq);
 }
 
@@ -297,6 +314,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x_small_kernel(F32xParams p) {
 #pragma unroll
     for (int u = 0; u < NS - 1; ++u)
         if (u < nslab) stage(u);
+    float amax = 0.f;                                  // largest |activation| this thread has split (range guard)
     for (int t = 0; t < nslab; ++t) {
         // slab t has landed once at most min(NS - 2, slabs issued after t) newer slabs of this wave are outstanding
         const int newer = min(NS - 2, nslab - 1 - t);
@@ -319,6 +337,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x_small_kernel(F32xParams p) {
             const int r = wm0 + 16 * i + l15;
             const float4 x0 = *reinterpret_cast<const float4*>(st + r * 128 + (((2 * lq) ^ (r & 7)) << 4));
             const float4 x1 = *reinterpret_cast<const float4*>(st + r * 128 + (((2 * lq + 1) ^ (r & 7)) << 4));
+            track(amax, x0.x, x0.y); track(amax, x0.z, x0.w); track(amax, x1.x, x1.y); track(amax, x1.z, x1.w);
             split2(x0.x, x0.y, fa_h[i].x, fa_l[i].x); split2(x0.z, x0.w, fa_h[i].y, fa_l[i].y);
             split2(x1.x, x1.y, fa_h[i].z, fa_l[i].z); split2(x1.z, x1.w, fa_h[i].w, fa_l[i].w);
         }
@@ -336,6 +355,7 @@ __global__ __launch_bounds__(256, 1) void gemm_f32x_small_kernel(F32xParams p) {
             }
         }
     }
+    report(p, amax);
     epilogue<2, 2>(p, acc, cor, m0 + wm0, n0 + wn0, l15, lq);
 }
 
@@ -410,8 +430,21 @@ void launch_tile(F32xParams& p, int mode, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_f32x_kernel<2, BM, BN>), grid, block, 0, s, p);
 }
 
+// the sticky range word of a stream: one of 256 by a hash of the stream handle (two streams of one process sharing a word could at
+// worst make one of them repeat a call on the exact path without need)
+unsigned* range_flag_of(hipStream_t s) {
+    static unsigned* base = nullptr;
+    if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_f32x_range_flags)) != hipSuccess) return nullptr;
+    const uintptr_t h = (uintptr_t)s;
+    return base + (((h >> 4) ^ (h >> 12) ^ (h >> 20)) & 255u);
+}
+
+__global__ void take_flag_kernel(unsigned* flag, uint32_t* dst) { *dst = atomicExch(flag, 0u); }
+
 int launch(const F32xParams& p0, int mode, hipStream_t s) {
     F32xParams p = p0;
+    p.range_flag = range_flag_of(s);
+    if (!p.range_flag) return DH_ERR_LAUNCH;
     // weight planes of <= 4 MB stay in every XCD's L2: walk the N tiles of one M tile back to back (the activation tile comes
     // from HBM once instead of tiles_n times)
     p.n_fast = (double)p.N * p.Kp * 4.0 <= 4.0 * 1048576.0;
@@ -430,6 +463,16 @@ int launch(const F32xParams& p0, int mode, hipStream_t s) {
 }
 
 }  // namespace
+
+// *dst (device memory) = 1 when a dh_linear_f32x / dh_conv2d_nhwc_f32x launch on `stream` since the last call split an ACTIVATION
+// outside the fp16 range (|x| >= 65504: its results hold inf / NaN), else 0; resets the stream's word.
+extern "C" int dh_f32x_take_overflow(uint32_t* dst, void* stream) {
+    DH_REQUIRE(dst);
+    unsigned* flag = range_flag_of((hipStream_t)stream);
+    if (!flag) return DH_ERR_LAUNCH;
+    hipLaunchKernelGGL(take_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, dst);
+    DH_LAUNCH_CHECK();
+}
 
 extern "C" int dh_split_f32x(const float* w, int ldw, void* planes, int N, int K, int Kp, void* stream) {
     DH_REQUIRE(w && planes && N > 0 && K > 0 && ldw >= K && Kp >= K && (Kp % 32) == 0 && ((uintptr_t)planes % 16) == 0);

@@ -17,6 +17,15 @@ from .transformers import SelfAttentionTransformerDecoder, TransformerDecoder
 class _CaptioningBase(nn.Module):
     _GEN_KEYS = ("caption", "max_len", "temperature", "beam_size", "top_k", "eos_index")
 
+    def __init_subclass__(cls, **kw):
+        """Every model's ``forward`` / ``generate_batch`` is the OUTERMOST range-guarded call of the split-operand fp32 path
+        (``hip.f32x_guarded``: one host read of the stream's overflow word per call, with option ``f32_split`` only)."""
+        super().__init_subclass__(**kw)
+        from .. import hip
+        for name in ("forward", "generate_batch"):
+            if name in cls.__dict__:
+                setattr(cls, name, hip.f32x_guarded(cls.__dict__[name]))
+
     def save(self, ckpt_path):
         """Saves the model's state and hyperparameters (reference caption_models.py:76-81)."""
         torch.save({'model': self.state_dict(), 'hp': self._hp}, ckpt_path)
@@ -132,6 +141,11 @@ class _CaptioningBase(nn.Module):
             scap.copy_(caption)
         seed_t.fill_(int(seed))
         graph.replay()
+        from .. import hip
+        if next(self.parameters()).dtype == torch.float32 and hip.option("f32_split") and hip.f32x_take_overflow(inputs[0].device):
+            # an activation left the fp16 range of the split-operand path inside the replayed graph: this batch eagerly (the guarded
+            # generate_batch repeats itself on the exact-fp32 kernels)
+            return self.generate_batch(*inputs, caption=caption, seed=seed, **kw)
         try:
             BeamSearchHelper.raise_for(int(err.item()))
         except BeamOverflow:              # flat logits: the captured chain cannot switch samplers -- this batch (and, from now on, this

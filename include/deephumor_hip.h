@@ -640,7 +640,10 @@ int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, c
  * hi*lo, lo*hi; every fp16 product is exact in fp32) with fp32 accumulation -- fp32-class results (the dropped lo*lo term is
  * 2^-22 relative) at a multiple of the rate of v_mfma_f32_32x32x2_f32 / the vector ALUs.  Replaces the same torch call sites as
  * dh_linear (nn.Linear: encoders.py:61,67; rnn_models.py:45 + the LSTM gate products; transformers.py:97-99,127,162-163,489)
- * and dh_conv2d_bn_act (the torchvision trunk, encoders.py:56) for fp32 tensors.  |x| must stay below 65504.
+ * and dh_conv2d_bn_act (the torchvision trunk, encoders.py:56) for fp32 tensors.  Range: weights are checked when a plan is built;
+ * an ACTIVATION with |x| >= 65504 (hi = inf: the results would hold inf / NaN) sets a sticky per-stream word that
+ * dh_f32x_take_overflow hands over and resets -- the Python layer reads it where it synchronises anyway and repeats the call on the
+ * exact-fp32 kernels (dh_linear / dh_conv2d_bn_act with DH_F32).
  *   dh_split_f32x      w fp32 [N, ldw] -> planes [2][N][Kp] fp16 (hi plane, then lo * 2^11), Kp = K rounded up to 32, zero padded;
  *                      made once per weight version
  *   dh_linear_f32x     C [M, ldc] fp32 = act(((A W^T + bias) * scale + shift) + residual); A fp32 [M, lda] (lda % 4 == 0, K % 4 == 0),
@@ -648,9 +651,12 @@ int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, c
  *   dh_conv2d_nhwc_f32x  channels-last fp32 convolution + BatchNorm scale / shift (+ residual) (+ ReLU): x [N,H,W,Cin] (Cin % 4 == 0),
  *                      planes of w [Cout][KS][KS][Cin], y / residual [N,Ho,Wo,Cout]
  *   dh_nchw_to_nhwc_f32  [N,C,H,W] -> [N,H,W,Cp] (channels >= C zero): the stem's input
+ *   dh_f32x_take_overflow  *dst (device uint32) = 1 if a launch of the two kernels above on `stream` split an out-of-range activation
+ *                      since the last call, else 0; resets the stream's word
  *   dh_maxpool3x3s2_nhwc_f32, dh_avgpool_nhwc_f32   MaxPool2d(3, 2, 1) / AdaptiveAvgPool2d(1) on channels-last fp32 tensors
  * ------------------------------------------------------------------------------------------- */
 int dh_split_f32x(const float* w, int ldw, void* planes, int N, int K, int Kp, void* stream);
+int dh_f32x_take_overflow(uint32_t* dst, void* stream);
 int dh_linear_f32x(const float* A, int lda, const void* w_planes, int Kp, const float* bias, const float* scale, const float* shift,
                    const float* residual, int ldres, float* C, int ldc, int M, int N, int K, int relu, void* stream);
 int dh_conv2d_nhwc_f32x(const float* x, const void* w_planes, int Kp, const float* scale, const float* shift, const float* residual,

@@ -5,6 +5,7 @@ needed there: the fixtures it writes are committed.
     python oracle/make_golden.py            # rewrites tests/golden/
     python oracle/make_golden.py r3         # only the round-3 fixtures (g10 char-level, g11 demo decode settings)
     python oracle/make_golden.py r4         # only the round-4 fixtures (g14 V=36,541 logits, g15 bench-shape beam, g16 beam 24, g17 pad_index 1)
+    python oracle/make_golden.py r6         # only the round-6 fixture (g18: 16 images of the bench batch, greedy ids + step-0 logit samples)
 
 The reference imports torchvision (encoders.py:4), which is absent here, so
 ``oracle/_standin`` (our own ResNet-50 definition, torchvision naming) is put on ``sys.path``
@@ -280,6 +281,46 @@ def round4_goldens():
     np.savez_compressed(os.path.join(OUT, "g17_pad_index_1.npz"), **rec)
 
 
+G18_IMAGES = [17 * i for i in range(16)]          # 0, 17, ..., 255: sixteen images of the 256-image bench batch
+G18_COLS = 4096
+
+
+def round6_goldens():
+    """G18: the 16-bit gates at the BASELINE shape need more than three oracle rows, and the GPU run should not pay
+    for them -- recorded here from the REAL reference, V = 36,541, synthetic weights (seed 1234), images ``G18_IMAGES`` of
+    ``synth_images(256, seed=0)``: the greedy caption (32 tokens), the per-step top-1 / top-2 margin, and of the pre-filter logits of the
+    first decode step a fixed random sample of 4,096 columns + the top-8 (index, value) pairs + the row sum."""
+    torch.set_num_threads(8)
+    g = np.random.Generator(np.random.Philox(key=[SEED, 18]))
+    cols = np.sort(g.choice(V_WORD, size=G18_COLS, replace=False)).astype(np.int64)
+    for kind in ("CaptioningLSTM", "CaptioningTransformer"):
+        model = build(kind, V_WORD)
+        rec = {"images": np.array(G18_IMAGES, np.int64), "cols": cols}
+        for idx in G18_IMAGES:
+            img = synth_images(1, seed=0, first=idx)
+            tap = _LogitTap(model)
+            with torch.no_grad():
+                ids = model.generate(img, max_len=32, beam_size=1, top_k=1)
+            tap.close()
+            out = tap.rows[0]
+            row = (out[0] if out.dim() == 2 else out[0, 0]).float()
+            t8 = torch.topk(row, 8)
+            margins = []
+            for step, o in enumerate(tap.rows):
+                r = o[0] if o.dim() == 2 else o[0, step]
+                t2 = torch.topk(r, 2)
+                margins.append(float(t2.values[0] - t2.values[1]))
+            rec[f"greedy_{idx}"] = ids.reshape(-1).numpy().astype(np.int64)
+            rec[f"margins_{idx}"] = np.array(margins, np.float32)
+            rec[f"step0_cols_{idx}"] = row[torch.from_numpy(cols)].numpy()
+            rec[f"step0_top8_idx_{idx}"] = t8.indices.numpy().astype(np.int64)
+            rec[f"step0_top8_val_{idx}"] = t8.values.numpy()
+            rec[f"step0_rowsum_{idx}"] = np.float64(row.double().sum())
+            print(kind, "image", idx, "greedy", rec[f"greedy_{idx}"][:6], len(rec[f"greedy_{idx}"]), "min margin", min(margins), flush=True)
+        np.savez_compressed(os.path.join(OUT, f"g18_bench_rows_{kind}.npz"), **rec)
+
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -436,5 +477,7 @@ if __name__ == "__main__":
         round4_goldens()
     elif sys.argv[1:] == ["pad"]:
         pad_index_goldens()
+    elif sys.argv[1:] == ["r6"]:
+        round6_goldens()
     else:
         main()

@@ -203,6 +203,29 @@ def test_bench_gpus_n_launches_its_own_ranks(monkeypatch, capfd):
     assert pr["ranks"] == 2 and pr["max"] == pytest.approx(line["ms_per_step"]) and pr["min"] <= pr["max"]
 
 
+def test_bench_c5_stub_over_eight_ranks_with_uneven_shards(monkeypatch, capfd):
+    """BASELINE config 5's partitioning through the launcher path: ``bench.py --gpus 8 --workload c5 --stub`` -- 300
+    templates in the uneven shards 38 x 4 + 37 x 4, every step's all_gather issued asynchronously and waited for one step later, the
+    gathered batch in global order on rank 0, per-rank step times and their skew reported.  Eight gloo ranks on CPU; the model is stubbed,
+    the rendezvous / shard / exchange / timing code is what the 8-GPU run takes unchanged."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "DH_BENCH_LAUNCHED_BY"):
+        monkeypatch.delenv(k, raising=False)
+    rc = bench.main(["--gpus", "8", "--steps", "3", "--warmup", "1", "--workload", "c5", "--stub"])
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0, out
+    line = json.loads(out[-1])
+    assert line["n_gpus"] == 8 and line["n_ranks_seen"] == 8 and line["scaling"] == "strong" and line["data"] == "stub"
+    assert line["shard_sizes"] == [38, 38, 38, 38, 37, 37, 37, 37] and line["shard"] == [0, 38]
+    assert line["gathered"] == 300 and line["gather_in_global_order"] and line["steps_run"] == [0, 1, 2]
+    pr = line["per_rank_ms_per_step"]
+    assert pr["ranks"] == 8 and pr["max"] == pytest.approx(line["ms_per_step"]) and pr["skew_ms"] == pytest.approx(pr["max"] - pr["min"])
+    assert line["ms_per_step"] >= 80 - 5                                   # rank 7 sleeps 80 ms per step: MAX over ranks
+
+
 def test_bench_rejects_mismatched_world_size(monkeypatch, capfd):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -179,3 +179,60 @@ def test_c4_global_batch_as_eight_sequential_shards():
     res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
     assert res == {"backend": "nccl", "shape": [2048, 32], "spans": True, "fp32_rows_equal_oracle": True, "bf16_repeatable": True,
                    "bf16_shard_invariant": True, "bf16_valid": True, "bf16_shards_differ": True}
+
+
+C5_CHILD = r"""
+import sys, os, json, socket, datetime
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch, torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+with socket.socket() as _s:
+    _s.bind(("127.0.0.1", 0))
+    _port = _s.getsockname()[1]
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT") or str(_port))
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=300))
+import deephumor_amd.models as M
+from deephumor_amd import hip
+from deephumor_amd.dist import generate_micro_sharded, shard_range
+from deephumor_amd.synth import synth_images, synth_state_dict
+hip.set_option("dist_always", 1)                 # the one-rank group runs its all_gather per shard
+V, N, SH = 36541, 300, 8
+model = M.CaptioningTransformerWithLabels(V).eval()
+model.load_state_dict(synth_state_dict(model.state_dict(), seed=1234))
+model = model.to(dev).half()
+g = np.random.Generator(np.random.Philox(key=[1, 0]))
+labels = torch.from_numpy(g.integers(6, V, size=(N, 3)).astype(np.int64)).to(dev)
+images = synth_images(N, seed=2).to(dev)
+kw = dict(max_len=32, beam_size=10, top_k=50, temperature=1.0, seed=7)
+spans = []
+def fn(lo, hi):
+    spans.append((lo, hi))
+    return model.generate_batch(images[lo:hi], labels[lo:hi], img0=lo, **kw)
+res = {"backend": dist.get_backend()}
+with torch.no_grad():
+    toks, lens = generate_micro_sharded(fn, N, SH)
+    one, one_l = model.generate_batch(images, labels, **kw)            # the whole sweep as ONE batch on this GPU
+res["shape"] = list(toks.shape)
+res["spans"] = spans == [shard_range(N, r, SH) for r in range(SH)]
+res["shard_sizes"] = [b - a for a, b in spans]
+res["rows_0_150_299_equal_single_batch"] = all(bool(torch.equal(toks[i], one[i]) and int(lens[i]) == int(one_l[i])) for i in (0, 150, 299))
+res["all_rows_equal_single_batch"] = bool(torch.equal(toks, one) and torch.equal(lens, one_l))
+print("RESULT " + json.dumps(res))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_c5_sweep_as_eight_uneven_shards():
+    """BASELINE config C5 (ImageLabelEncoder + CaptioningTransformer, fp16, beam 10, 300 templates over 8 ranks) on the one GPU this
+    pool has: the eight UNEVEN shards (38 x 4 + 37 x 4, ``img0`` = the shard's first template) one after another
+    through ``generate_micro_sharded`` and the one-rank RCCL group's per-shard all_gather (padded to the largest shard) -- rows
+    {0, 150, 299}, and every other row, equal the 300-template single batch."""
+    p = subprocess.run([sys.executable, "-c", C5_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    res = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert res == {"backend": "nccl", "shape": [300, 32], "spans": True, "shard_sizes": [38, 38, 38, 38, 37, 37, 37, 37],
+                   "rows_0_150_299_equal_single_batch": True, "all_rows_equal_single_batch": True}

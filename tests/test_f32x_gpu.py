@@ -128,6 +128,90 @@ def test_full_batch_split(kind):
     TF.test_fp32_full_batch_sampled_beam_rows_equal_the_reference(kind)
 
 
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_all_bench_images_equal_the_exact_fp32_path(kind):
+    """bench.py's ``parity_grade_path.vs_exact_fp32_hip_all_images`` as an assertion: greedy captions of ALL 256 bench
+    images (V = 36,541, 32 tokens) on the split-operand path are identical to the exact-fp32 HIP path's -- which rows {0, 77, 255}
+    tie to the CPU oracle -- and the first-step logits agree to 1e-3 (north_star's fp32 tolerance; observed 1.5e-5 - 3.6e-5)."""
+    import bench
+    from deephumor_amd import hip
+    imgs = synth_images(256, seed=0).cuda()
+    with hip.option_scope(f32_split=0):
+        exact, _ = TF._model(kind, torch.float32)
+        ref = bench.greedy_all(exact, imgs)
+        del exact
+    torch.cuda.empty_cache()
+    model, _ = TF._model(kind, torch.float32)                 # (the autouse fixture has the option on)
+    cmp_ = bench.compare_greedy(ref, bench.greedy_all(model, imgs))
+    print(kind, cmp_)
+    assert cmp_["captions_identical"] == 1.0 and cmp_["token_match"] == 1.0, (kind, cmp_)
+    assert cmp_["step0_logit_max_abs_err"] < 1e-3, (kind, cmp_)
+
+
+def test_activation_range_guard_of_the_split_path():
+    """only the WEIGHTS of the split-operand path were range-checked (at plan time); an activation with |x| >= 65504 splits
+    into hi = inf and the GEMM silently returned inf / NaN.  Now such a launch sets the stream's sticky word
+    (``dh_f32x_take_overflow``): kernel level here, the models' answer (repeat on the exact-fp32 kernels) below.  Tiny operands: an
+    activation tensor that is ~1e-6 THROUGHOUT has fp16-subnormal hi parts and keeps ~1e-5 relative accuracy (documented limit;
+    ordinary tensors with some tiny entries are unaffected: the absolute error of such an entry is <= 2^-36)."""
+    from deephumor_amd import hip
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(96, 64, generator=g) * 0.3).cuda()
+    planes = hip.split_f32x(w)
+    hip.f32x_take_overflow()                                              # (whatever earlier tests of this process left)
+    a = (torch.randn(50, 64, generator=g) * 2.0).cuda()
+    ok = hip.linear_f32x(a, planes)
+    assert bool(torch.isfinite(ok).all()) and hip.f32x_take_overflow() is False
+    big = a.clone()
+    big[7, 3] = 1.0e5
+    out = hip.linear_f32x(big, planes)
+    assert not bool(torch.isfinite(out[7]).all())                         # what the kernel returns for that row ...
+    assert hip.f32x_take_overflow() is True and hip.f32x_take_overflow() is False     # ... is flagged once, then the word is clear
+    big[7, 3] = 6.0e4                                                     # the largest magnitudes the split represents: no flag, finite, fp32-class
+    out = hip.linear_f32x(big, planes)
+    assert hip.f32x_take_overflow() is False and _err_vs_f64(out, big.double(), w.double()) < 1.2e-6
+    x = (torch.randn(2, 9, 9, 32, generator=g)).cuda()
+    x[1, 4, 4, 5] = -7.0e4
+    wc = (torch.randn(16, 3, 3, 32, generator=g) * 0.1).cuda()
+    hip.conv2d_nhwc_f32x(x, hip.split_f32x(wc.reshape(16, -1).contiguous()), 3, torch.ones(16).cuda(), torch.zeros(16).cuda(), pad=1)
+    assert hip.f32x_take_overflow() is True
+    tiny = a * 1e-6
+    e = _err_vs_f64(hip.linear_f32x(tiny, planes), tiny.double(), w.double())
+    assert e < 4e-5 and hip.f32x_take_overflow() is False, e
+
+
+def test_models_repeat_an_out_of_range_call_on_the_exact_path():
+    """Images scaled by 3e5 drive the trunk's activations past the fp16 range: with option ``f32_split`` the guarded ``forward`` /
+    ``generate_batch`` notice (one host read of the stream's word), warn once and repeat the call on the exact-fp32 kernels -- the
+    caller gets the exact path's logits / tokens instead of inf / NaN or garbage ids."""
+    import warnings
+    from deephumor_amd import hip
+    model, _, _ = TM.build("CaptioningLSTM")
+    imgs = (synth_images(2, seed=0) * 3.0e5).cuda()
+    cap = torch.randint(6, 900, (2, 7)).cuda()
+    lengths = torch.tensor([8, 8]).cuda()
+    with hip.option_scope(f32_split=0), torch.no_grad():
+        want = model(imgs, cap, lengths)
+        want_t = model.generate_batch(imgs, max_len=6, beam_size=1, top_k=1)
+    hip.f32x_take_overflow()
+    hip._f32x_warned[0] = False
+    with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        got = model(imgs, cap, lengths)
+        got_t = model.generate_batch(imgs, max_len=6, beam_size=1, top_k=1)
+    assert any("fp16 range" in str(w.message) for w in rec)
+    assert bool(torch.isfinite(got).all()) and torch.equal(got, want)
+    assert torch.equal(got_t[0], want_t[0]) and torch.equal(got_t[1], want_t[1])
+    assert hip.option("f32_split") == 1                                   # the option is what the caller set again
+    with torch.no_grad():                                                 # ordinary images afterwards: the split path, no repeat
+        ok = synth_images(2, seed=0).cuda()
+        a = model(ok, cap, lengths)
+        assert hip.f32x_take_overflow() is False
+    with hip.option_scope(f32_split=0), torch.no_grad():
+        b = model(ok, cap, lengths)
+    assert float((a - b).abs().max()) < 1e-3
+
+
 def test_split_is_actually_selected_and_switchable():
     """The option reaches the kernels: with it on, the fp32 model's launches are dh_linear_f32x / dh_conv2d_nhwc_f32x; off, none are."""
     from deephumor_amd import hip

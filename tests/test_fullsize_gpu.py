@@ -47,32 +47,38 @@ def _oracle_greedy(kind, sd, hp, imgs, i):
     return _ORACLE_GREEDY[(kind, i)]
 
 
-# what the 16-bit paths must stay within of the fp32 CPU oracle at the BASELINE shape (observed by bench.py's precision_vs_fp32_hip,
-# round 4: bf16 0.21 max / 0.020 mean, fp16 0.022 / 0.0024 at step 0) -- gates with ~1.7x margin, fp16 about 8x tighter than bf16
-LOGIT_TOL = {torch.bfloat16: (0.36, 0.045), torch.float16: (0.045, 0.006)}
-# greedy token agreement of rows {0, 77, 255} with the oracle's captions (chaotic on synthetic weights: DESIGN section 10): floors set
-# below the values the committed kernels give (printed by the test), so a kernel that degrades precision turns the run red
-# (values of the round-5 tree on these three images: LSTM bf16 0.5625, fp16 1.0; Transformer bf16 0.9167, fp16 1.0)
-GREEDY_FLOOR = {("CaptioningLSTM", torch.bfloat16): 0.40, ("CaptioningLSTM", torch.float16): 0.80,
-                ("CaptioningTransformer", torch.bfloat16): 0.70, ("CaptioningTransformer", torch.float16): 0.80}
+# What the 16-bit paths must stay within of the REFERENCE at the BASELINE shape.  Round 6: sixteen images instead of
+# three, from golden G18 (recorded from the real reference by oracle/make_golden.py r6, so the GPU run does not pay for the rows), and
+# the bounds follow what the committed kernels give -- step-0 logits 1.25 x the worst observed over the sixteen images, greedy floors =
+# observed - 0.05 -- so a kernel that loses a further bit of precision turns the run red (checked with a deliberately degraded LSTM
+# step).  Observed on the round-6 tree (gpurun_out/oracle_gate_*.json of the run that set them):
+G18_OBSERVED = {  # (max |dlogit|, mean |dlogit|) at step 0 over 16 images x 4,096 sampled columns + top-8; greedy token match over 16 captions
+    ("CaptioningLSTM", torch.bfloat16): (0.2079, 0.02087, 0.5508), ("CaptioningLSTM", torch.float16): (0.0235, 0.00241, 0.9434),
+    ("CaptioningTransformer", torch.bfloat16): (0.1600, 0.01586, 0.8281), ("CaptioningTransformer", torch.float16): (0.0190, 0.00195, 0.9590)}
+LOGIT_MARGIN, GREEDY_SLACK = 1.25, 0.05
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
 def test_16bit_big_batch_kernels_against_the_oracle(kind, dtype):
     """The kernels only a BASELINE-size batch selects (256 images x beam 5 = 1,280 rows, V = 36,541: ``vocab_wreg`` / ``vocab_areg256``,
-    ``linear_wreg``, ``lstm_wreg``, the 256-workgroup encoder kernels) tied to the CPU ORACLE directly, not through bit-equality with
-    older kernels: (a) the logits the beam-5 decode itself computes at step 0 (256 rows) and step 1 (1,280 rows, each
-    row teacher-forced by the token the engine drew for it) for rows of images {0, 77, 255} against ``oracle.ref_path.model_forward``
-    within the type's tolerance, arg-max inside the oracle's near-top set; (b) greedy ids of those images at N = 256 against the
-    oracle's captions at or above the recorded floor."""
+    ``linear_wreg``, ``lstm_wreg``, the 256-workgroup encoder kernels) tied to the REFERENCE directly, not through bit-equality with
+    older kernels: (a) the step-0 logits the beam-5 decode itself computes (256 rows) for the sixteen G18 images against the logits
+    the real reference recorded (4,096 sampled columns + its top-8), within 1.25 x the worst error the committed kernels show, the
+    arg-max inside the reference's near-top set; (b) step 1 (1,280 rows, each row teacher-forced by the token the engine drew for it)
+    for three rows against ``oracle.ref_path.model_forward``; (c) greedy ids of the sixteen images at N = 256 against the reference's
+    captions at or above (observed - 0.05)."""
     import json
     import os
+    import numpy as np
     from oracle import ref_path as R
     from deephumor_amd.synth import synth_images
+    g18 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"g18_bench_rows_{kind}.npz"))
+    sel = [int(i) for i in g18["images"]]
+    cols = torch.from_numpy(g18["cols"])
     model, sd = _model(kind, dtype)
     imgs = synth_images(256, seed=0)
-    picks = {0: [0, 77, 255], 1: [0 * 5 + 0, 77 * 5 + 2, 255 * 5 + 4]}
+    picks = {0: sel, 1: [0 * 5 + 0, 77 * 5 + 2, 255 * 5 + 4]}
     cap = {}
 
     def hook(i, lg, tokens):
@@ -82,33 +88,78 @@ def test_16bit_big_batch_kernels_against_the_oracle(kind, dtype):
     hook.with_tokens = True
     with torch.no_grad():
         model.generate_batch(imgs.cuda(), max_len=32, beam_size=5, top_k=50, temperature=1.0, seed=42, logits_hook=hook)
-    tol_max, tol_mean = LOGIT_TOL[dtype]
+    obs_max, obs_mean, obs_greedy = G18_OBSERVED[(kind, dtype)]
+    tol_max, tol_mean = LOGIT_MARGIN * obs_max, LOGIT_MARGIN * obs_mean
+    if os.environ.get("DH_GATE_RECORD"):                              # (the run that sets G18_OBSERVED: record, do not judge)
+        tol_max = tol_mean = 1e9
+        obs_greedy = 0.0
     seen = {}
-    for step, rows in picks.items():
-        got, toks = cap[step]
-        for j, r in enumerate(rows):
-            img = r if step == 0 else r // 5
-            prefix = toks[j, :step].long()[None]                      # the row's own history: teacher forcing
-            want = R.model_forward(kind, sd, model._hp, imgs[img:img + 1], prefix)[0, step]
-            d = (got[j] - want).abs()
-            seen[f"step{step}_row{r}"] = [round(float(d.max()), 4), round(float(d.mean()), 5)]
-            assert float(d.max()) < tol_max and float(d.mean()) < tol_mean, (kind, dtype, step, r, float(d.max()), float(d.mean()))
-            assert float(want[int(got[j].argmax())]) >= float(want.max()) - 2 * tol_max, (kind, dtype, step, r)
+    # (a) step 0 against the recorded reference rows
+    got0 = cap[0][0]
+    worst_max = worst_mean = 0.0
+    for j, img in enumerate(sel):
+        want_cols = torch.from_numpy(g18[f"step0_cols_{img}"])
+        t8i, t8v = torch.from_numpy(g18[f"step0_top8_idx_{img}"]), torch.from_numpy(g18[f"step0_top8_val_{img}"])
+        d = torch.cat([(got0[j][cols] - want_cols).abs(), (got0[j][t8i] - t8v).abs()])
+        worst_max, worst_mean = max(worst_max, float(d.max())), max(worst_mean, float(d.mean()))
+        assert float(d.max()) < tol_max and float(d.mean()) < tol_mean, (kind, dtype, img, float(d.max()), float(d.mean()), tol_max, tol_mean)
+        # the engine's arg-max is one of the reference's near-top tokens (its top-8 reach further down than 2 x the tolerance)
+        am, band = int(got0[j].argmax()), float(t8v[0]) - 2 * tol_max
+        if float(t8v[7]) < band:                                      # (else the recorded top-8 do not reach below the band: undecidable)
+            assert am in t8i.tolist() and float(t8v[t8i.tolist().index(am)]) >= band, (kind, dtype, img, am)
+    seen["step0_worst_max_mean_16_images"] = [round(worst_max, 4), round(worst_mean, 5)]
+    # (b) step 1: 1,280 rows, teacher-forced by the engine's own draw
+    got, toks = cap[1]
+    for j, r in enumerate(picks[1]):
+        prefix = toks[j, :1].long()[None]
+        want = R.model_forward(kind, sd, model._hp, imgs[r // 5:r // 5 + 1], prefix)[0, 1]
+        d = (got[j] - want).abs()
+        seen[f"step1_row{r}"] = [round(float(d.max()), 4), round(float(d.mean()), 5)]
+        # (one more layer stack of rounding than step 0 and the whole vocabulary instead of a sample: 1.5 x step 0's bound)
+        assert float(d.max()) < 1.5 * tol_max and float(d.mean()) < 1.5 * tol_mean, (kind, dtype, r, float(d.max()), float(d.mean()))
+        assert float(want[int(got[j].argmax())]) >= float(want.max()) - 2 * tol_max, (kind, dtype, r)
+    # (c) greedy captions of the sixteen images inside the 256-image batch
     with torch.no_grad():
         toks, lens = model.generate_batch(imgs.cuda(), max_len=32, beam_size=1, top_k=1)
     same = total = 0
-    for i in (0, 77, 255):
-        want = _oracle_greedy(kind, sd, model._hp, imgs, i)
+    for i in sel:
+        want = g18[f"greedy_{i}"].tolist()
         g = toks[i, :int(lens[i])].cpu().tolist()
         total += max(len(want), len(g))
         same += sum(int(a == b) for a, b in zip(want, g))
-    seen["greedy_token_match_rows_0_77_255"] = round(same / total, 4)
+    seen["greedy_token_match_16_images"] = round(same / total, 4)
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    if os.path.isdir(out):                                            # (kept next to the run's other records; not asserted on)
+    if os.path.isdir(out):                                            # (kept next to the run's other records)
         with open(os.path.join(out, f"oracle_gate_{kind}_{str(dtype).split('.')[-1]}.json"), "w") as f:
             json.dump(seen, f)
     print(kind, dtype, seen)
-    assert same / total >= GREEDY_FLOOR[(kind, dtype)], (kind, dtype, seen)
+    assert same / total >= obs_greedy - GREEDY_SLACK, (kind, dtype, seen)
+
+
+# bench.py's precision_vs_fp32_hip as an assertion: greedy tokens of the 16-bit paths against the fp32 HIP path (which
+# is bit-exact vs the CPU oracle: the tests above) over ALL 256 bench images.  Floors: C2 / C3.
+MATCH_FLOOR = {("CaptioningLSTM", torch.bfloat16): 0.55, ("CaptioningTransformer", torch.bfloat16): 0.80,
+               ("CaptioningLSTM", torch.float16): 0.93, ("CaptioningTransformer", torch.float16): 0.95}
+
+
+@pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
+def test_16bit_greedy_token_match_against_the_fp32_path_over_all_bench_images(kind):
+    import bench
+    from deephumor_amd.synth import synth_images
+    imgs = synth_images(256, seed=0).cuda()
+    m32, _ = _model(kind, torch.float32)
+    ref = bench.greedy_all(m32, imgs)
+    del m32
+    torch.cuda.empty_cache()
+    for dtype in (torch.bfloat16, torch.float16):
+        model, _ = _model(kind, dtype)
+        cmp_ = bench.compare_greedy(ref, bench.greedy_all(model, imgs))
+        print(kind, dtype, cmp_)
+        assert cmp_["token_match"] >= MATCH_FLOOR[(kind, dtype)], (kind, dtype, cmp_)
+        # step-0 logits: the same bound as the oracle gate's maximum (all 256 images x the whole vocabulary instead of a sample)
+        assert cmp_["step0_logit_max_abs_err"] < 1.5 * LOGIT_MARGIN * G18_OBSERVED[(kind, dtype)][0], (kind, dtype, cmp_)
+        del model
+        torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])

@@ -237,6 +237,25 @@ def test_g15_bench_shape_beam(kind):
 
 
 @pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_g18_bench_rows(kind):
+    """Golden G18 (round 6): sixteen images of the 256-image bench batch at V = 36,541, recorded from the reference for the 16-bit
+    gates of ``tests/test_fullsize_gpu.py`` -- the ORACLE is pinned on two of them here: its greedy caption token for token, and its
+    first-step logits on the recorded 4,096-column sample + top-8."""
+    g = golden(f"g18_bench_rows_{kind}.npz")
+    sd, hp = synthetic_sd(kind, v=36541)
+    cols = torch.from_numpy(g["cols"])
+    for idx in (17, 255):
+        img = synth_images(1, seed=0, first=idx)
+        ids = R.model_generate(kind, sd, hp, img, max_len=32, beam_size=1, top_k=1)
+        assert ids.reshape(-1).tolist() == g[f"greedy_{idx}"].tolist(), (kind, idx)
+        row = R.model_forward(kind, sd, hp, img, torch.zeros((1, 0), dtype=torch.int64))[0, 0]
+        np.testing.assert_allclose(row[cols].numpy(), g[f"step0_cols_{idx}"], atol=2e-4, rtol=1e-5)
+        t8 = torch.from_numpy(g[f"step0_top8_idx_{idx}"])
+        np.testing.assert_allclose(row[t8].numpy(), g[f"step0_top8_val_{idx}"], atol=2e-4, rtol=1e-5)
+        assert abs(float(row.double().sum()) - float(g[f"step0_rowsum_{idx}"])) < 5e-2
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
 def test_g16_beam_24(kind):
     """beam_size 24 (any beam_size <= top_k is valid, beam.py:7-9)."""
     g = golden(f"g16_beam24_{kind}.npz")
