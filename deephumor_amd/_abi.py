@@ -21,7 +21,8 @@ class TrLayer(_c.Structure):
                 + [(n, _P) for n in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1", "kp", "vt")]
                 + [("kp_dperm", _I), ("_pad2", _I)]
                 + [(n, _P) for n in ("wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk")]
-                + [(n, _P) for n in ("wqkv_x", "wo_x", "w1_x", "w2_x", "wq_x", "weo_x")])
+                + [(n, _P) for n in ("wqkv_x", "wo_x", "w1_x", "w2_x", "wq_x", "weo_x")]
+                + [(n, _P) for n in ("wqkv_xp", "wo_xp", "w1_xp", "w2_xp", "wq_xp", "weo_xp")])
 
 
 class TrModel(_c.Structure):
@@ -41,7 +42,7 @@ class LnFold(_c.Structure):
 
 
 class LstmLayer(_c.Structure):
-    _fields_ = [("w", _P), ("b", _P), ("w_il", _P), ("b_il", _P), ("w_pk", _P), ("w_x", _P)]
+    _fields_ = [("w", _P), ("b", _P), ("w_il", _P), ("b_il", _P), ("w_pk", _P), ("w_x", _P), ("w_xp", _P)]
 
 
 class LstmModel(_c.Structure):
@@ -142,6 +143,8 @@ SIGNATURES = {
     "dh_beam_expand": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
     "dh_split_f32x": [_P, _I, _P, _I, _I, _I, _P],
     "dh_f32x_take_overflow": [_P, _P],
+    "dh_linear_f32x_wreg_supported": [_I, _I, _I],
+    "dh_linear_f32x_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_linear_f32x": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv2d_nhwc_f32x": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],

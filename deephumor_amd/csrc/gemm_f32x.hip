@@ -466,6 +466,8 @@ int launch(const F32xParams& p0, int mode, hipStream_t s) {
 
 // *dst (device memory) = 1 when a dh_linear_f32x / dh_conv2d_nhwc_f32x launch on `stream` since the last call split an ACTIVATION
 // outside the fp16 range (|x| >= 65504: its results hold inf / NaN), else 0; resets the stream's word.
+unsigned* dh_f32x_range_flag_of(hipStream_t s) { return range_flag_of(s); }      // (linear_f32x_wreg.hip)
+
 extern "C" int dh_f32x_take_overflow(uint32_t* dst, void* stream) {
     DH_REQUIRE(dst);
     unsigned* flag = range_flag_of((hipStream_t)stream);

@@ -49,10 +49,15 @@ static int chain_linear(const void* A, int lda, const void* W, const void* W_pk,
 
 // One dense layer of the plain (non-deferred) chains: fp32 models with split planes (option "f32_split") run it as three fp16
 // MFMAs on split operands (gemm_f32x.hip), everything else through dh_linear.
-static int plain_linear(const void* A, int lda, const void* W, const void* W_x, int ldw, const float* bias, void* C, int ldc, int rows, int N,
-                        int K, int relu, int dt, void* stream) {
-    if (dt == DH_F32 && W_x && dh_opt(DH_OPT_F32_SPLIT) && (lda % 4) == 0 && (K % 4) == 0 && ((uintptr_t)A % 16) == 0)
+static int plain_linear(const void* A, int lda, const void* W, const void* W_x, const void* W_xp, int ldw, const float* bias, void* C, int ldc,
+                        int rows, int N, int K, int relu, int dt, void* stream) {
+    if (dt == DH_F32 && W_x && dh_opt(DH_OPT_F32_SPLIT) && (lda % 4) == 0 && (K % 4) == 0 && ((uintptr_t)A % 16) == 0) {
+        // a decode position's rows: the weights stationary in registers (linear_f32x_wreg.hip; bit-identical to the tile kernels)
+        if (W_xp && bias && dh_opt(DH_OPT_DECODE_WREG) && (ldc % 4) == 0 && ((uintptr_t)C % 16) == 0 && ((uintptr_t)bias % 16) == 0 &&
+            dh_linear_f32x_wreg_supported(rows, N, K))
+            return dh_linear_f32x_wreg((const float*)A, lda, W_xp, bias, nullptr, 0, (float*)C, ldc, rows, N, K, relu, stream);
         return dh_linear_f32x((const float*)A, lda, W_x, (K + 31) / 32 * 32, bias, nullptr, nullptr, nullptr, 0, (float*)C, ldc, rows, N, K, relu, stream);
+    }
     return dh_linear(A, lda, W, ldw, bias, nullptr, nullptr, nullptr, 0, C, ldc, rows, N, K, relu, dt, stream);
 }
 
@@ -144,24 +149,24 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
     for (int l = 0; l < m->n_layers; ++l) {
         const dh_tr_layer_t& L = m->layers[l];
         dh_prof_set_tag("qkv");
-        DH_TRY(plain_linear(sc->x, D, L.wqkv, L.wqkv_x, D, L.bqkv, sc->qkv, 3 * D, rows, 3 * D, D, 0, dt, stream));
+        DH_TRY(plain_linear(sc->x, D, L.wqkv, L.wqkv_x, L.wqkv_xp, D, L.bqkv, sc->qkv, 3 * D, rows, 3 * D, D, 0, dt, stream));
         DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->att, n_img, rows_per_img,
                                    row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, dt, stream));
         dh_prof_set_tag("proj");
-        DH_TRY(plain_linear(sc->att, D, L.wo, L.wo_x, D, L.bo, sc->o, D, rows, D, D, 0, dt, stream));
+        DH_TRY(plain_linear(sc->att, D, L.wo, L.wo_x, L.wo_xp, D, L.bo, sc->o, D, rows, D, D, 0, dt, stream));
         DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln1_g, L.ln1_b, sc->x, rows, D, L.ln1_eps, dt, stream));
         if (m->cross) {
             dh_prof_set_tag("proj");
-            DH_TRY(plain_linear(sc->x, D, L.wq, L.wq_x, D, L.bq, sc->q, D, rows, D, D, 0, dt, stream));
+            DH_TRY(plain_linear(sc->x, D, L.wq, L.wq_x, L.wq_xp, D, L.bq, sc->q, D, rows, D, D, 0, dt, stream));
             DH_TRY(cross_attention(m, L, sc->q, sc->att, n_img, rows_per_img, dt, stream));
             dh_prof_set_tag("proj");
-            DH_TRY(plain_linear(sc->att, D, L.weo, L.weo_x, D, L.beo, sc->o, D, rows, D, D, 0, dt, stream));
+            DH_TRY(plain_linear(sc->att, D, L.weo, L.weo_x, L.weo_xp, D, L.beo, sc->o, D, rows, D, D, 0, dt, stream));
             DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln2_g, L.ln2_b, sc->x, rows, D, L.ln2_eps, dt, stream));
         }
         dh_prof_set_tag("ffn");
-        DH_TRY(plain_linear(sc->x, D, L.w1, L.w1_x, D, L.b1, sc->ff, m->pf_dim, rows, m->pf_dim, D, 1, dt, stream));
+        DH_TRY(plain_linear(sc->x, D, L.w1, L.w1_x, L.w1_xp, D, L.b1, sc->ff, m->pf_dim, rows, m->pf_dim, D, 1, dt, stream));
         dh_prof_set_tag("ffn");
-        DH_TRY(plain_linear(sc->ff, m->pf_dim, L.w2, L.w2_x, m->pf_dim, L.b2, sc->o, D, rows, D, m->pf_dim, 0, dt, stream));
+        DH_TRY(plain_linear(sc->ff, m->pf_dim, L.w2, L.w2_x, L.w2_xp, m->pf_dim, L.b2, sc->o, D, rows, D, m->pf_dim, 0, dt, stream));
         void* dst = (l == m->n_layers - 1 && x_out) ? x_out : sc->x;
         DH_TRY(dh_add_layernorm(sc->x, sc->o, L.ln3_g, L.ln3_b, dst, rows, D, L.ln3_eps, dt, stream));
     }
@@ -172,7 +177,7 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
     } else if (logits) {
         dh_prof_set_tag("vocab");
         if (dt == DH_F32) {
-            DH_TRY(plain_linear(x_out ? x_out : sc->x, D, m->cls_w, m->cls_w_x, D, m->cls_b, logits, ldl, rows, m->V, D, 0, dt, stream));
+            DH_TRY(plain_linear(x_out ? x_out : sc->x, D, m->cls_w, m->cls_w_x, nullptr, D, m->cls_b, logits, ldl, rows, m->V, D, 0, dt, stream));
         } else {
             DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows,
                              m->V, D, 0, dt == DH_F16 ? DH_F16_OUT_F32 : DH_BF16_OUT_F32, stream));
@@ -238,7 +243,7 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
         const int k = l == 0 ? E + Hh : 2 * Hh;
         dh_prof_set_tag("gates");
         if (dt == DH_F32) {
-            DH_TRY(plain_linear(a, k, m->layers[l].w, m->layers[l].w_x, k, m->layers[l].b, sc->gates, 4 * Hh, rows, 4 * Hh, k, 0, dt, stream));
+            DH_TRY(plain_linear(a, k, m->layers[l].w, m->layers[l].w_x, m->layers[l].w_xp, k, m->layers[l].b, sc->gates, 4 * Hh, rows, 4 * Hh, k, 0, dt, stream));
         } else {
             DH_TRY(dh_linear(a, k, m->layers[l].w, k, m->layers[l].b, nullptr, nullptr, nullptr, 0, sc->gates, 4 * Hh, rows,
                              4 * Hh, k, 0, gate_dt, stream));
@@ -253,7 +258,7 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
     } else if (logits) {
         dh_prof_set_tag("vocab");
         if (dt == DH_F32) {
-            DH_TRY(plain_linear(top, top_ld, m->cls_w, m->cls_w_x, Hh, m->cls_b, logits, ldl, rows, m->V, Hh, 0, dt, stream));
+            DH_TRY(plain_linear(top, top_ld, m->cls_w, m->cls_w_x, nullptr, Hh, m->cls_b, logits, ldl, rows, m->V, Hh, 0, dt, stream));
         } else {
             DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,
                              gate_dt, stream));

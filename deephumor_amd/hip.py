@@ -323,6 +323,33 @@ def split_f32x(w):
     return planes
 
 
+def pack_f32x_fragments(planes):
+    """The two planes of ``split_f32x`` (``[2, N, Kp]`` fp16), each through ``dh_pack_mfma_fragments`` -> ``[2, Kp / 32, N / 16, 64, 8]``:
+    the weight operand of ``linear_f32x_wreg`` (fragments loaded straight into registers).  None when the shape is not one it takes."""
+    _dev(planes)
+    two, n, kp = planes.shape
+    if two != 2 or n % 64 or not load().dh_linear_f32x_wreg_supported(1, n, kp):
+        return None
+    out = torch.empty((2, kp // 32, n // 16, 64, 8), dtype=torch.float16, device=planes.device)
+    for i in range(2):
+        _launch("dh_pack_mfma_fragments", _ptr(planes[i]), _ptr(out[i]), n, kp, _stream())
+    return out
+
+
+def linear_f32x_wreg(a, packed, bias, relu=False, residual=None, out=None, tag=None):
+    """``dh_linear_f32x_wreg``: ``linear_f32x`` for a decode position's rows with the split weights stationary in registers
+    (``packed = pack_f32x_fragments(split_f32x(w))``); bit-identical to ``linear_f32x``."""
+    _dev(a, packed, bias, residual, out)
+    m, k = a.shape
+    n = packed.shape[2] * 16
+    assert a.dtype == torch.float32 and a.stride(1) == 1 and packed.shape[1] * 32 == k
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _launch("dh_linear_f32x_wreg", _ptr(a), a.stride(0), _ptr(packed), _ptr(bias), _ptr(residual), residual.stride(0) if residual is not None else 0,
+            _ptr(out), out.stride(0), m, n, k, int(relu), _stream(), tag=tag)
+    return out
+
+
 def f32x_take_overflow(device=None):
     """``dh_f32x_take_overflow`` on the current stream -> bool (a host read: synchronises).  True when an f32x launch on this stream
     since the last call split an ACTIVATION outside the fp16 range: its results hold inf / NaN and the caller repeats on the exact

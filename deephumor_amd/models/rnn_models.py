@@ -51,7 +51,10 @@ class LSTMDecoder(_Planned, nn.Module):
                 w_pk = hip.pack_mfma_fragments(w_il) if hip.lstm_layer_wreg_supported(w.shape[1] - hh, hh) else None
             else:
                 w_il = b_il = w_pk = None
-            layers.append((w, b, w_il, b_il, w_pk, hip.split_f32x(w) if split else None))
+            w_x = hip.split_f32x(w) if split else None
+            # ... and the split planes in MFMA fragment order: the gate product of a decode step with the weights stationary in registers
+            w_xp = hip.pack_f32x_fragments(w_x) if (split and hip.option("decode_wreg")) else None
+            layers.append((w, b, w_il, b_il, w_pk, w_x, w_xp))
         plan = dict(layers=layers, emb=self.embedding.weight.detach(),
                     cls_w=self.classifier.weight.detach(), cls_b=self.classifier.bias.detach().float().contiguous(),
                     dtype=self.classifier.weight.dtype)
@@ -80,9 +83,11 @@ class LSTMDecoder(_Planned, nn.Module):
             self.started = 0                                                    # 0: zero state, then 1, 2, 1, 2, ...
             self._scratch = {}
             self.c_layers = (hip.LstmLayer * self.nl)()
-            for i, (w, b, w_il, b_il, w_pk, w_x) in enumerate(plan["layers"]):
+            for i, (w, b, w_il, b_il, w_pk, w_x, w_xp) in enumerate(plan["layers"]):
                 if w_x is not None:
                     self.c_layers[i].w_x = w_x.data_ptr()
+                if w_xp is not None:
+                    self.c_layers[i].w_xp = w_xp.data_ptr()
                 self.c_layers[i].w, self.c_layers[i].b = w.data_ptr(), b.data_ptr()
                 if w_il is not None:
                     self.c_layers[i].w_il, self.c_layers[i].b_il = w_il.data_ptr(), b_il.data_ptr()

@@ -225,6 +225,11 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 for name in ("wqkv", "wo", "w1", "w2", "wq", "weo", "wkv"):
                     if name in ent:
                         ent[name + "_x"] = hip.split_f32x(ent[name].contiguous())
+                        if name != "wkv" and hip.option("decode_wreg"):
+                            # the decode position's layers with the split weights stationary in registers (csrc/linear_f32x_wreg.hip)
+                            pk = hip.pack_f32x_fragments(ent[name + "_x"])
+                            if pk is not None:
+                                ent[name + "_xp"] = pk
             plan["cls_w_x"] = hip.split_f32x(plan["cls_w"].contiguous())
         if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and hip.option("vocab_wreg"):
             # the register-streamed classifier (csrc/vocab_wreg.hip; bit-identical).  The LSTM decoder uses it at every size; here it is
@@ -298,7 +303,8 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     if self.packed is not None:
                         c.kp, c.vt, c.kp_dperm = P(self.packed[i][0]), P(self.packed[i][1]), int(self.dperm)
                 for name in ("wqkv_f", "wq_f", "w1_f", "bqkv_f", "bq_f", "b1_f", "cs_qkv", "cs_q", "cs_1",
-                             "wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk", "wqkv_x", "wo_x", "w1_x", "w2_x", "wq_x", "weo_x"):
+                             "wqkv_pk", "wo_pk", "weo_pk", "w1_pk", "w2_pk", "wq_pk", "wqkv_x", "wo_x", "w1_x", "w2_x", "wq_x", "weo_x",
+                             "wqkv_xp", "wo_xp", "w1_xp", "w2_xp", "wq_xp", "weo_xp"):
                     if name in L:
                         setattr(c, name, P(L[name]))
                 c.kcache, c.vcache = self.kc[i].data_ptr(), self.vc[i].data_ptr()

@@ -553,6 +553,9 @@ typedef struct dh_tr_layer {
     /* optional (DH_F32 models, option "f32_split"): dh_split_f32x planes of wqkv, wo, w1, w2, wq, weo -- the dense layers of a
      * position then run as three fp16 MFMAs on split operands (dh_linear_f32x) instead of v_mfma_f32_32x32x2_f32; NULL = fp32 MFMA */
     const void *wqkv_x, *wo_x, *w1_x, *w2_x, *wq_x, *weo_x;
+    /* optional, next to the planes: both planes through dh_pack_mfma_fragments ([2][K / 32][N / 16][64] x 16 bytes) -- the dense layers of a
+     * decode position then run on dh_linear_f32x_wreg (weights stationary in registers; bit-identical to dh_linear_f32x) */
+    const void *wqkv_xp, *wo_xp, *w1_xp, *w2_xp, *wq_xp, *weo_xp;
 } dh_tr_layer_t;
 
 typedef struct dh_tr_model {
@@ -586,6 +589,7 @@ typedef struct dh_lstm_layer {
     const void* w_il; const float* b_il;    /* optional (bf16): the same, gate-interleaved: row 4u+g = gate g of unit u */
     const void* w_pk;                       /* optional: dh_pack_mfma_fragments(w_il) -- the register-stationary step (dh_lstm_layer_wreg) */
     const void* w_x;                        /* optional (DH_F32): dh_split_f32x planes of w -- the gate GEMM as dh_linear_f32x */
+    const void* w_xp;                       /* optional: those planes fragment-packed -- the gate GEMM as dh_linear_f32x_wreg */
 } dh_lstm_layer_t;
 
 typedef struct dh_lstm_model {
@@ -657,6 +661,13 @@ int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scratch_t* sc, c
  * ------------------------------------------------------------------------------------------- */
 int dh_split_f32x(const float* w, int ldw, void* planes, int N, int K, int Kp, void* stream);
 int dh_f32x_take_overflow(uint32_t* dst, void* stream);
+/* dh_linear_f32x for the rows of ONE decode position with the weights stationary in registers (csrc/linear_f32x_wreg.hip; the fp32
+ * counterpart of dh_linear_ln_wreg): w_packed = the hi plane, then the lo plane of dh_split_f32x(W [N, K]), each through
+ * dh_pack_mfma_fragments ([2][K / 32][N / 16][64] x 16 bytes).  C = act(A W^T + bias (+ residual)), bit-identical to dh_linear_f32x.
+ * _supported: N % 64 == 0, K % 512 == 0 or K % 384 == 0, M <= 8,192. */
+int dh_linear_f32x_wreg_supported(int M, int N, int K);
+int dh_linear_f32x_wreg(const float* A, int lda, const void* w_packed, const float* bias, const float* residual, int ldres,
+                        float* C, int ldc, int M, int N, int K, int relu, void* stream);
 int dh_linear_f32x(const float* A, int lda, const void* w_planes, int Kp, const float* bias, const float* scale, const float* shift,
                    const float* residual, int ldres, float* C, int ldc, int M, int N, int K, int relu, void* stream);
 int dh_conv2d_nhwc_f32x(const float* x, const void* w_planes, int Kp, const float* scale, const float* shift, const float* residual,

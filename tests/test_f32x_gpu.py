@@ -148,6 +148,36 @@ def test_all_bench_images_equal_the_exact_fp32_path(kind):
     assert cmp_["step0_logit_max_abs_err"] < 1e-3, (kind, cmp_)
 
 
+@pytest.mark.parametrize("n,k", [(512, 512), (1536, 512), (2048, 512), (512, 2048), (2048, 768), (2048, 1024), (64, 384)])
+@pytest.mark.parametrize("m", [37, 160, 1280, 3000])
+def test_linear_f32x_wreg_equals_linear_f32x(m, n, k):
+    """dh_linear_f32x_wreg (round 6: the decode position's dense layers with the split weights stationary in registers, the fp32 block
+    brought in by LDS-DMA and split in place) against dh_linear_f32x: the same three MFMA products per 32-k step in the same order ->
+    bit-identical; bias, ReLU, residual, a strided output; the activation range word."""
+    from deephumor_amd import hip
+    g = torch.Generator().manual_seed(m * 31 + n + k)
+    a = (torch.randn(m, k + 8, generator=g) * 1.5).cuda()[:, :k]             # (a row stride that is not K)
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    planes = hip.split_f32x(w)
+    packed = hip.pack_f32x_fragments(planes)
+    assert packed is not None and tuple(packed.shape) == (2, k // 32, n // 16, 64, 8)
+    hip.f32x_take_overflow()
+    for relu in (False, True):
+        want = hip.linear_f32x(a, planes, b, relu=relu)
+        got = hip.linear_f32x_wreg(a, packed, b, relu=relu)
+        assert torch.equal(got, want), (m, n, k, relu, float((got - want).abs().max()))
+    res = torch.randn(m, n, generator=g).cuda()
+    buf = torch.full((m, n + 12), 3.0, device="cuda")
+    hip.linear_f32x_wreg(a, packed, b, residual=res, out=buf[:, :n])
+    assert torch.equal(buf[:, :n], hip.linear_f32x(a, planes, b, residual=res)) and bool((buf[:, n:] == 3.0).all())
+    assert hip.f32x_take_overflow() is False
+    big = a.clone()
+    big[m // 2, k - 1] = -9.0e4
+    hip.linear_f32x_wreg(big, packed, b)
+    assert hip.f32x_take_overflow() is True
+
+
 def test_activation_range_guard_of_the_split_path():
     """only the WEIGHTS of the split-operand path were range-checked (at plan time); an activation with |x| >= 65504 splits
     into hi = inf and the GEMM silently returned inf / NaN.  Now such a launch sets the stream's sticky word
