@@ -178,11 +178,23 @@ int pick_xn(int tiles_m, int tiles_n) {
 }
 }  // namespace
 
+namespace {
+// 64-column x 40-row blocks (4 waves, 80 KB of LDS: two workgroups per CU) while they fit one residency round of 512; wider outputs
+// (fc_q|k|v, fc_1, the LSTM gates at 1,280 rows) as 128-column x 80-row blocks (8 waves, the whole 160 KB) up to two rounds of 256;
+// beyond that the tile kernels of gemm_f32x.hip are faster (measured, tools/f32x_kbench.py: 3,000 x 2,048 x 512 47 against 36 us)
+int fw_form(int M, int N) {
+    const long long narrow = (long long)dh_cdiv(M, 40) * (N / 64), wide = (long long)dh_cdiv(M, 80) * (N / 128);
+    if (narrow <= 512) return 1;
+    if ((N % 128) == 0 && wide <= 512) return 2;
+    return 0;
+}
+}  // namespace
+
 // 1 when dh_linear_f32x_wreg takes the shape: N a multiple of 64, K a multiple of 512 (the Transformer decoder's projections and
 // feed-forward layers) or of 384 (the LSTM gate product of the released models: E + Hh = 256 + 512), and few enough rows that the
-// launch stays within a few residency rounds (a decode position; teacher-forced batches keep the tile kernels)
+// launch stays within two residency rounds (a decode position; teacher-forced batches keep the tile kernels)
 extern "C" int dh_linear_f32x_wreg_supported(int M, int N, int K) {
-    return M > 0 && M <= 8192 && N > 0 && (N % 64) == 0 && K > 0 && ((K % 512) == 0 || (K % 384) == 0) && K <= 4096;
+    return M > 0 && N > 0 && (N % 64) == 0 && K > 0 && ((K % 512) == 0 || (K % 384) == 0) && K <= 4096 && fw_form(M, N) != 0;
 }
 
 // C [M, ldc] fp32 = act(A W^T + bias (+ residual)) as dh_linear_f32x computes it (bit-identical), with w_packed = the two planes of
@@ -201,10 +213,7 @@ extern "C" int dh_linear_f32x_wreg(const float* A, int lda, const void* w_packed
     dh_prof_set_dims(M, N, K);
     DhProfScope prof("dh_linear_f32x", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
     const bool k384 = (K % 512) != 0;
-    // 64-column x 40-row blocks (4 waves) while they fit ONE round of 256 workgroups (the N = 512 projections at 1,280 rows); wider
-    // outputs (fc_q|k|v, fc_1, the LSTM gates) as 128-column x 80-row blocks (8 waves, the whole 160 KB of LDS): 12 x 16 / 16 x 16
-    // workgroups at 1,280 rows
-    const bool wide = (N % 128) == 0 && (long long)dh_cdiv(M, 40) * (N / 64) > 256;
+    const bool wide = fw_form(M, N) == 2;
     p.tiles_n = N / (wide ? 128 : 64); p.tiles_m = dh_cdiv(M, wide ? 80 : 40);
     p.xn = pick_xn(p.tiles_m, p.tiles_n);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));

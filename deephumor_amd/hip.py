@@ -328,7 +328,7 @@ def pack_f32x_fragments(planes):
     the weight operand of ``linear_f32x_wreg`` (fragments loaded straight into registers).  None when the shape is not one it takes."""
     _dev(planes)
     two, n, kp = planes.shape
-    if two != 2 or n % 64 or not load().dh_linear_f32x_wreg_supported(1, n, kp):
+    if two != 2 or n % 64 or not load().dh_linear_f32x_wreg_supported(40, n, kp):
         return None
     out = torch.empty((2, kp // 32, n // 16, 64, 8), dtype=torch.float16, device=planes.device)
     for i in range(2):

@@ -155,6 +155,9 @@ def test_linear_f32x_wreg_equals_linear_f32x(m, n, k):
     brought in by LDS-DMA and split in place) against dh_linear_f32x: the same three MFMA products per 32-k step in the same order ->
     bit-identical; bias, ReLU, residual, a strided output; the activation range word."""
     from deephumor_amd import hip
+    if not hip.load().dh_linear_f32x_wreg_supported(m, n, k):
+        assert m == 3000 and n == 2048                                       # (more than two residency rounds: the tile kernels' job)
+        pytest.skip("shape left to the tile kernels")
     g = torch.Generator().manual_seed(m * 31 + n + k)
     a = (torch.randn(m, k + 8, generator=g) * 1.5).cuda()[:, :k]             # (a row stride that is not K)
     w = (torch.randn(n, k, generator=g) * k ** -0.5).cuda()
