@@ -28,7 +28,7 @@ class TrLayer(_c.Structure):
 class TrModel(_c.Structure):
     _fields_ = ([(n, _I) for n in ("n_layers", "D", "n_heads", "pf_dim", "V", "pad_index", "cross", "S", "dtype")]
                 + [("emb_scale", _F), ("layers", _c.POINTER(TrLayer))]
-                + [(n, _P) for n in ("tok_emb", "pos_emb", "cls_w", "cls_b", "keymask", "cls_w_pk", "cls_b_pad", "cls_w_x")])
+                + [(n, _P) for n in ("tok_emb", "pos_emb", "cls_w", "cls_b", "keymask", "cls_w_pk", "cls_b_pad", "cls_w_x", "layers_table", "layers_sync")])
 
 
 class TrScratch(_c.Structure):
@@ -119,6 +119,10 @@ SIGNATURES = {
     "dh_beam_row_sample_exact": [_P, _I, _I, _I, _I, _I, _I, _F, _I, _P, _U64, _P, _I, _I, _P, _P, _P, _P],
     "dh_beam_select": [_P, _P, _P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _P,
                        _U64, _P, _I, _P],
+    "dh_decode_layers_supported": [_c.POINTER(TrModel), _I, _I],
+    "dh_decode_layers_table_bytes": [_I],
+    "dh_decode_layers_table": [_c.POINTER(TrModel), _P, _P],
+    "dh_decode_layers": [_c.POINTER(TrModel), _c.POINTER(TrScratch), _P, _P, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "dh_transformer_decode_position": [_c.POINTER(TrModel), _c.POINTER(TrScratch), _P, _P, _I, _P, _I, _I, _I, _I, _I, _I,
                                        _P, _P, _I, _P, _I, _P],
     "dh_lstm_decode_step": [_c.POINTER(LstmModel), _c.POINTER(LstmScratch), _P, _P, _I, _I, _P, _I, _I, _I, _I, _I, _P,

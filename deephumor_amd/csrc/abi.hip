@@ -140,6 +140,7 @@ const OptDef g_opt_defs[DH_OPT_COUNT] = {
     {"vocab_wreg_transformer_max_rows", "DH_VOCAB_WREG_TRANSFORMER_MAX_ROWS", 640},
     {"decode_wreg", "DH_DECODE_WREG", 1},
     {"decode_wreg_min_rows", "DH_DECODE_WREG_MIN_ROWS", 1},
+    {"decode_layers", "DH_DECODE_LAYERS", 0},
     {"lstm_wreg", "DH_LSTM_WREG", 1},
     {"lstm_wreg_min_rows", "DH_LSTM_WREG_MIN_ROWS", 256},
     {"f32_split", "DH_F32_SPLIT", 0},

@@ -12,6 +12,7 @@ enum DhOption {
     DH_OPT_VOCAB_WREG_TRANSFORMER_MAX_ROWS,   // ... else up to this many rows per position
     DH_OPT_DECODE_WREG,              // register-stationary decode-chain GEMMs (linear_wreg.hip) and the plans that pack their weights
     DH_OPT_DECODE_WREG_MIN_ROWS,     // ... from this many rows per position
+    DH_OPT_DECODE_LAYERS,            // the decoder layers of a position as ONE persistent launch (decode_layers.hip)
     DH_OPT_LSTM_WREG,                // register-stationary LSTM step (lstm_wreg.hip)
     DH_OPT_LSTM_WREG_MIN_ROWS,       // ... from this many rows
     // ---- fp32 models: arithmetic of the dense layers ----

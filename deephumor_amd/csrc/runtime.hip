@@ -69,7 +69,14 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
                                     const int32_t* src, int src_ld, int n_img, int rows_per_img, int row_mult, int rows_total,
                                     int t, void* x_final, void* stream) {
     const int rows = n_img * rows_per_img, D = m->D, PF = m->pf_dim, dt = m->dtype, nt = D / 64;
-    for (int l = 0; l < m->n_layers; ++l) {
+    // Option "decode_layers": every layer of the position as ONE persistent launch (csrc/decode_layers.hip; clusters of 8 workgroups own
+    // 40 rows through all layers; bit-identical to the launches below)
+    const bool layers = dh_opt(DH_OPT_DECODE_LAYERS) && m->layers_table && m->layers_sync && dh_opt(DH_OPT_DECODE_WREG) &&
+                        dh_decode_layers_supported(m, rows_per_img, t);
+    if (layers) {
+        DH_TRY(dh_decode_layers(m, sc, m->layers_table, tokens, tok_ld, src, src_ld, n_img, rows_per_img, row_mult, rows_total, t, m->layers_sync, stream));
+    }
+    for (int l = 0; l < m->n_layers && !layers; ++l) {
         const dh_tr_layer_t& L = m->layers[l];
         const dh_tr_layer_t* P = l > 0 ? &m->layers[l - 1] : nullptr;       // its LN3 is pending on X
         dh_ln_fold_t f{};

@@ -1021,6 +1021,19 @@ def transformer_decode_position(model, scratch, start_emb, tokens, src, n_img, r
             group_max.stride(0) if group_max is not None else 0, _stream())
 
 
+def decode_layers_supported(model, rows_per_img, t):
+    """``dh_decode_layers_supported`` for a ``TrModel`` description."""
+    return bool(load().dh_decode_layers_supported(_c.byref(model), int(rows_per_img), int(t)))
+
+
+def decode_layers_table(model, device):
+    """The device-resident per-layer table of ``dh_decode_layers`` for this ``TrModel`` description (``dh_decode_layers_table``)."""
+    nbytes = load().dh_decode_layers_table_bytes(model.n_layers)
+    table = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    _launch("dh_decode_layers_table", _c.byref(model), _ptr(table), _stream())
+    return table
+
+
 def conv1x1_dual_nhwc(y, x, w_cat, shift, stride, relu=True):
     """relu(y (*) W3' + x[strided] (*) Wd' + shift): conv3 + downsample of a stage's first bottleneck as one GEMM
     (bf16, NHWC; ``w_cat`` [Cout, C1 + C2] has the BatchNorm scales folded in)."""

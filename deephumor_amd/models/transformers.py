@@ -320,6 +320,13 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 m.cls_w_pk, m.cls_b_pad = P(plan["cls_w_pk"]), P(plan["cls_b_pad"])
             if "cls_w_x" in plan:
                 m.cls_w_x = P(plan["cls_w_x"])
+            # the decoder layers of a position as ONE persistent launch (csrc/decode_layers.hip): a device-resident table of this run's
+            # per-layer pointers + the clusters' hand-over words (zero once; the kernel keeps them consistent from launch to launch)
+            self.layers_table = self.layers_sync = None
+            if hip.option("decode_layers") and self.dtype in hip.HALF_DTYPES and hip.decode_layers_supported(m, 1, 0):
+                self.layers_sync = torch.zeros((324,), device=dev, dtype=torch.int32)
+                self.layers_table = hip.decode_layers_table(m, dev)
+                m.layers_table, m.layers_sync = self.layers_table.data_ptr(), self.layers_sync.data_ptr()
 
         def scratch(self, rows):
             if rows not in self._scratch:
@@ -595,7 +602,13 @@ class _IncrementalDecoder(_Planned, nn.Module):
                 yield
                 if early_stop_every and (i - pos) % early_stop_every == 0 and bool(helper.done.all()):
                     break                                   # all_ended() break of the reference (transformers.py:585)
-            return helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index, defer_check=defer_check)
+            out = helper.finalize(len_bias_done=0, full_len=max_len, pad_index=self.pad_index, defer_check=defer_check)
+            if run.layers_sync is not None and not defer_check and int(run.layers_sync[320]) != 0:
+                # a hand-over of the persistent layer kernel timed out (fewer than 256 resident workgroups?): its results are undefined
+                hip.set_option("decode_layers", 0)
+                raise RuntimeError("deephumor_amd: the persistent decoder-layer kernel (option decode_layers) timed out waiting for its "
+                                   "workgroups; the option has been switched off for this process -- repeat the call")
+            return out
 
         exact = [bool(exact)]
         try:

@@ -567,6 +567,10 @@ typedef struct dh_tr_model {
     const uint8_t* keymask;                                 /* [n_img*S] or NULL */
     const void* cls_w_pk; const float* cls_b_pad;           /* optional: the operands of dh_vocab_logits_wreg (padded, fragment-packed classifier) */
     const void* cls_w_x;                                    /* optional (DH_F32): dh_split_f32x planes of cls_w */
+    const void* layers_table; uint32_t* layers_sync;        /* optional: dh_decode_layers' device-resident layer table (filled by
+                                                               dh_decode_layers_table for THIS description) and its 321 zeroed uint32 of
+                                                               hand-over words, private to the stream -- the decoder layers of a position
+                                                               then run as ONE persistent launch (option "decode_layers") */
 } dh_tr_model_t;
 
 typedef struct dh_tr_scratch {
@@ -574,6 +578,25 @@ typedef struct dh_tr_scratch {
     void* y2;                               /* [rows, D]      second pre-LayerNorm row buffer of the deferred chain (or NULL) */
     float *st0, *st1, *st2;                 /* [rows, D/64, 2] partial LayerNorm statistics of x / o / y2 (or NULL) */
 } dh_tr_scratch_t;
+
+/* All decoder layers of one decode position as ONE persistent launch (round 6; csrc/decode_layers.hip): DecoderLayer.forward
+ * (transformers.py:343-377) x n_layers on the rows of one position of generate's loop (:547-573), on the deferred-LayerNorm chain of
+ * the 16-bit types.  A cluster of 8 workgroups on one XCD owns 40 rows through all layers, member w = head w = column block w; six
+ * full-row hand-overs per layer through a counter in the cluster's L2 instead of eight kernel boundaries.  Bit-identical to the launch
+ * chain of dh_transformer_decode_position (every GEMM block is dh_linear_ln_wreg's, the attention arithmetic dh_attn_self_decode's /
+ * dh_attn_cross_decode_packed's).  Reads sc->x (the embedded rows), leaves sc->x / sc->st0 as the chain does (the final LayerNorm and
+ * the classifier follow), appends the position's K / V to the caches.
+ *   _supported      1 when the description / position is one it takes (16-bit, encoder attention on packed tiles, D = 512 = 8 x 64,
+ *                   feed-forward 2,048, folded + fragment-packed weights, 40 % rows_per_img == 0, t + 1 <= 40, S <= 64)
+ *   _table_bytes / _table   the device-resident per-layer table (weights, folded biases, caches, packed K / V^T), once per description
+ *   sync            321 uint32 of device memory private to the stream, zero before the first use; sync[320] != 0 afterwards = a bounded
+ *                   wait timed out (results undefined; zero the words again) */
+int dh_decode_layers_supported(const dh_tr_model_t* m, int rows_per_img, int t);
+int dh_decode_layers_table_bytes(int n_layers);
+int dh_decode_layers_table(const dh_tr_model_t* m, void* table, void* stream);
+int dh_decode_layers(const dh_tr_model_t* m, const dh_tr_scratch_t* sc, const void* table, const int32_t* tokens, int tok_ld,
+                     const int32_t* src, int src_ld, int n_img, int rows_per_img, int row_mult, int rows_total, int t,
+                     uint32_t* sync, void* stream);
 
 /* Hidden state of position t for n_img*rows_per_img compact rows; x_out (optional, [rows,D]) receives the
  * last layer's output instead of scratch->x; logits (optional, fp32 [rows,V], row stride ldl) = classifier(x); with

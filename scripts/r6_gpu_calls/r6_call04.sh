@@ -1,0 +1,14 @@
+#!/usr/bin/env bash
+# round 6, call 4: the persistent decoder-layer kernel: bit-identity against the launch chain, then the C3 step with / without it
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r6
+timeout 600 python -m pytest tests/test_decode_layers_gpu.py -x -q > gpurun_out/r6/call04_tests.txt 2>&1
+tail -15 gpurun_out/r6/call04_tests.txt
+for v in 0 1 0 1; do
+  DH_DECODE_LAYERS=$v timeout 300 python bench.py --workload c3 --steps 5 --warmup 2 --quick --schedule sequential 2> gpurun_out/r6/call04_c3_$v.err | tail -1 > gpurun_out/r6/call04_c3_$v.json
+  python - <<PY
+import json
+d = json.load(open("gpurun_out/r6/call04_c3_$v.json"))
+print("decode_layers=$v  C3 ms/step", round(d["ms_per_step"], 3), {k: v for k, v in list(d["kernel_breakdown_ms_per_step"].items())[:8]})
+PY
+done
