@@ -27,6 +27,7 @@
 // Placement: correctness does NOT depend on the dispatcher: every member publishes the XCD it runs on (HW_REG_XCC_ID); a cluster whose
 // members disagree (never observed) adds an agent-scope release (L2 write-back) to its barriers.  All 256 workgroups must become
 // resident (256 CUs, one workgroup each); waits are bounded (error word, checked by the host with the beam error word).
+#include <stdlib.h>
 #include "common.h"
 #include "prof.h"
 #include "attn_items.h"
@@ -51,7 +52,7 @@ struct DlParams {
     const DlLayer* layers; int n_layers;
     uint16_t *x, *qkv, *att, *o, *q, *ff, *y2; float2 *st0, *st1, *st2;
     const int32_t* tokens; int tok_ld; const int32_t* src; int src_ld; const uint8_t* keymask;
-    int rows, rows_per_img, row_mult, rows_total, t, S, pad_index, kp_dperm, n_rb, iters, PF_dim;
+    int rows, rows_per_img, row_mult, rows_total, t, S, pad_index, kp_dperm, n_rb, iters, dbg;
     unsigned* sync;                                     // [0, 32) cluster counters, [32, 64) their bases, [64, 320) XCD of every workgroup + 1, 320 error
 };
 
@@ -455,6 +456,9 @@ __device__ __forceinline__ void cross_attn_images(const DlParams& P, const DlLay
     }
 }
 
+// (debug, DH_DL_DEBUG & 2: workgroup 0 leaves s_memrealtime stamps (100 MHz) after every phase of layer 0 in sync[400 ...])
+#define DL_STAMP(k) do { if ((P.dbg & 2) && b == 0 && l == 0 && tid == 0) P.sync[400 + (k)] = (unsigned)__builtin_amdgcn_s_memrealtime(); } while (0)
+
 template <typename OT>
 __global__ __launch_bounds__(NT, 1) void decode_layers_kernel(DlParams P) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
@@ -485,6 +489,7 @@ __global__ __launch_bounds__(NT, 1) void decode_layers_kernel(DlParams P) {
             const DlLayer& Lp = P.layers[l > 0 ? l - 1 : 0];
             GemmP g{};
             g.M = P.rows;
+            DL_STAMP(0);
             if (work) {
                 // 1. q_w | k_w | v_w = LN3_prev(X) Wqkv^T + b (column blocks w, 8 + w, 16 + w), then head w's self-attention
                 g.A = P.x; g.lda = 512; g.wp = L.wqkv_pk; g.bias = L.bqkv; g.C = P.qkv; g.ldc = 1536; g.N = 1536; g.relu = 0;
@@ -493,10 +498,13 @@ __global__ __launch_bounds__(NT, 1) void decode_layers_kernel(DlParams P) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 asm volatile("buffer_inv sc1" ::: "memory");   // q / k / v of this position: written by this workgroup's other waves
-                if (P.t + 1 <= 16) self_attn_rows<OT, 2, 5>(P, L, m0, w);
+                DL_STAMP(1);
+                if (P.t + 1 <= 16 && !(P.dbg & 1)) self_attn_rows<OT, 2, 5>(P, L, m0, w);
                 else self_attn_rows<OT, 5, 4>(P, L, m0, w);
             }
+            DL_STAMP(2);
             cluster_barrier(C);
+            DL_STAMP(3);
             if (work) {
                 // 2. Y1_w = LN3_prev(X)_w + att Wo^T + bo, statistics -> st1
                 g = GemmP{}; g.M = P.rows;
@@ -505,7 +513,9 @@ __global__ __launch_bounds__(NT, 1) void decode_layers_kernel(DlParams P) {
                 g.o_stats = P.st1;
                 gemm_phase<OT, 1, 1, 1>(g, rb, w, 0, lds);
             }
+            DL_STAMP(4);
             cluster_barrier(C);
+            DL_STAMP(5);
             if (work) {
                 // 3. q_w = LN1(Y1) Wq^T + bq, then head w's attention over the images' patches
                 g = GemmP{}; g.M = P.rows;
@@ -515,9 +525,12 @@ __global__ __launch_bounds__(NT, 1) void decode_layers_kernel(DlParams P) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 asm volatile("buffer_inv sc1" ::: "memory");
+                DL_STAMP(14);
                 cross_attn_images<OT>(P, L, m0, w);
             }
+            DL_STAMP(6);
             cluster_barrier(C);
+            DL_STAMP(7);
             if (work) {
                 // 4. Y2_w = LN1(Y1)_w + att Weo^T + beo, statistics -> st2
                 g = GemmP{}; g.M = P.rows;
@@ -525,7 +538,9 @@ __global__ __launch_bounds__(NT, 1) void decode_layers_kernel(DlParams P) {
                 g.r_stats = P.st1; g.r_eps = L.ln1_eps; g.r_gamma = L.ln1_g; g.r_beta = L.ln1_b; g.o_stats = P.st2;
                 gemm_phase<OT, 1, 1, 1>(g, rb, w, 0, lds);
             }
+            DL_STAMP(8);
             cluster_barrier(C);
+            DL_STAMP(9);
             if (work) {
                 // 5. ff[:, 4w .. 4w + 3] = relu(LN2(Y2) W1^T + b1)
                 g = GemmP{}; g.M = P.rows;
@@ -533,7 +548,9 @@ __global__ __launch_bounds__(NT, 1) void decode_layers_kernel(DlParams P) {
                 g.a_stats = P.st2; g.a_eps = L.ln2_eps; g.a_colsum = L.cs_1;
                 gemm_phase<OT, 0, 4, 1>(g, rb, 4 * w, 1, lds);
             }
+            DL_STAMP(10);
             cluster_barrier(C);
+            DL_STAMP(11);
             if (work) {
                 // 6. X_w = LN2(Y2)_w + ff W2^T + b2, statistics -> st0  (LN3 of this layer now pending on X)
                 g = GemmP{}; g.M = P.rows;
@@ -541,13 +558,16 @@ __global__ __launch_bounds__(NT, 1) void decode_layers_kernel(DlParams P) {
                 g.r_stats = P.st2; g.r_eps = L.ln2_eps; g.r_gamma = L.ln2_g; g.r_beta = L.ln2_b; g.o_stats = P.st0;
                 gemm_phase<OT, 1, 1, 4>(g, rb, w, 0, lds);
             }
+            DL_STAMP(12);
             cluster_barrier(C);
+            DL_STAMP(13);
         }
     }
     // the counter's value for the next launch on this stream (every member has read the old one long ago)
     if (w == 0 && tid == 0) __hip_atomic_store(P.sync + 32 + cl, C.target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     (void)base0;
 }
+__global__ void set_layer_kernel(DlLayer* table, int l, DlLayer v) { table[l] = v; }
 }  // namespace
 
 // Bytes of the device-resident layer table of dh_decode_layers (one entry per decoder layer).
@@ -568,14 +588,12 @@ extern "C" int dh_decode_layers_supported(const dh_tr_model_t* m, int rows_per_i
 }
 
 // Fills the device-resident layer table (`table`: dh_decode_layers_table_bytes(n_layers) bytes of device memory) from the model
-// description -- once per run; the copy is stream-ordered (pageable source: staged by the runtime before the call returns).
+// description -- once per run, stream-ordered, one tiny launch per layer.
 extern "C" int dh_decode_layers_table(const dh_tr_model_t* m, void* table, void* stream) {
     DH_REQUIRE(m && table && dh_decode_layers_supported(m, 1, 0) && m->n_layers <= 64);
-    DlLayer host[64];
     for (int l = 0; l < m->n_layers; ++l) {
         const dh_tr_layer_t& L = m->layers[l];
-        DlLayer& d = host[l];
-        d = DlLayer{};
+        DlLayer d{};
         d.wqkv_pk = (const uint4*)L.wqkv_pk; d.wo_pk = (const uint4*)L.wo_pk; d.wq_pk = (const uint4*)L.wq_pk; d.weo_pk = (const uint4*)L.weo_pk;
         d.w1_pk = (const uint4*)L.w1_pk; d.w2_pk = (const uint4*)L.w2_pk;
         d.bqkv = l > 0 ? L.bqkv_f : L.bqkv; d.bo = L.bo; d.bq = L.bq_f; d.beo = L.beo; d.b1 = L.b1_f; d.b2 = L.b2;
@@ -583,8 +601,10 @@ extern "C" int dh_decode_layers_table(const dh_tr_model_t* m, void* table, void*
         d.ln1_g = L.ln1_g; d.ln1_b = L.ln1_b; d.ln2_g = L.ln2_g; d.ln2_b = L.ln2_b; d.ln3_g = L.ln3_g; d.ln3_b = L.ln3_b;
         d.ln1_eps = L.ln1_eps; d.ln2_eps = L.ln2_eps; d.ln3_eps = L.ln3_eps; d.sa_scale = L.sa_scale; d.ea_scale = L.ea_scale;
         d.kcache = (uint16_t*)L.kcache; d.vcache = (uint16_t*)L.vcache; d.kp = (const uint16_t*)L.kp; d.vt = (const uint16_t*)L.vt;
+        // (the entry travels as a kernel ARGUMENT: no host buffer has to outlive the call, and the launch can be captured in a hipGraph)
+        hipLaunchKernelGGL(set_layer_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (DlLayer*)table, l, d);
     }
-    return hipMemcpyAsync(table, host, sizeof(DlLayer) * m->n_layers, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+    DH_LAUNCH_CHECK();
 }
 
 // All decoder layers of one decode position in ONE launch: reads sc->x (the embedded rows), leaves sc->x / sc->st0 as the launch chain
@@ -604,6 +624,7 @@ extern "C" int dh_decode_layers(const dh_tr_model_t* m, const dh_tr_scratch_t* s
     P.rows = n_img * rows_per_img; P.rows_per_img = rows_per_img; P.row_mult = row_mult; P.rows_total = rows_total; P.t = t; P.S = m->S;
     P.pad_index = m->pad_index; P.kp_dperm = m->layers[0].kp_dperm; P.n_rb = dh_cdiv(P.rows, RL); P.iters = dh_cdiv(P.n_rb, 32);
     P.sync = sync;
+    { const char* e = getenv("DH_DL_DEBUG"); P.dbg = e ? atoi(e) : 0; }
     dh_prof_set_tag("layers");
     dh_prof_set_dims(P.rows, m->n_layers, t);
     DhProfScope prof("dh_decode_layers", 0.0, 0.0, stream);

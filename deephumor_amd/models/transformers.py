@@ -324,7 +324,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             # per-layer pointers + the clusters' hand-over words (zero once; the kernel keeps them consistent from launch to launch)
             self.layers_table = self.layers_sync = None
             if hip.option("decode_layers") and self.dtype in hip.HALF_DTYPES and hip.decode_layers_supported(m, 1, 0):
-                self.layers_sync = torch.zeros((324,), device=dev, dtype=torch.int32)
+                self.layers_sync = torch.zeros((512,), device=dev, dtype=torch.int32)
                 self.layers_table = hip.decode_layers_table(m, dev)
                 m.layers_table, m.layers_sync = self.layers_table.data_ptr(), self.layers_sync.data_ptr()
 

@@ -26,8 +26,8 @@ def _decode(model, images, extra, **kw):
     return toks, lens, logits
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("n_img,beam,max_len", [(3, 5, 8), (8, 5, 20), (37, 5, 12), (256, 5, 33), (40, 1, 10), (38, 10, 18), (300, 10, 6)])
+@pytest.mark.parametrize("n_img,beam,max_len,dtype", [(3, 5, 8, torch.bfloat16), (8, 5, 20, torch.float16), (256, 5, 33, torch.bfloat16),
+                                                    (40, 1, 10, torch.float16), (38, 10, 18, torch.float16), (300, 10, 6, torch.bfloat16)])
 def test_persistent_layers_equal_the_launch_chain(n_img, beam, max_len, dtype):
     from deephumor_amd import hip
     model = _model("CaptioningTransformer", dtype)
