@@ -317,6 +317,12 @@ def round6_goldens():
             rec[f"step0_top8_val_{idx}"] = t8.values.numpy()
             rec[f"step0_rowsum_{idx}"] = np.float64(row.double().sum())
             print(kind, "image", idx, "greedy", rec[f"greedy_{idx}"][:6], len(rec[f"greedy_{idx}"]), "min margin", min(margins), flush=True)
+        if kind == "CaptioningTransformer":
+            # BASELINE config C4's 2,048-image global batch: two images far outside the first 256 (tests/test_dist_gpu.py)
+            for idx in (1000, 2047):
+                with torch.no_grad():
+                    rec[f"greedy_far_{idx}"] = model.generate(synth_images(1, seed=0, first=idx), max_len=32, beam_size=1, top_k=1).reshape(-1).numpy().astype(np.int64)
+                print(kind, "C4 image", idx, rec[f"greedy_far_{idx}"][:6], flush=True)
         np.savez_compressed(os.path.join(OUT, f"g18_bench_rows_{kind}.npz"), **rec)
 
 

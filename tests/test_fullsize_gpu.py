@@ -38,6 +38,7 @@ def test_fp32_full_batch_greedy_rows_equal_the_oracle(kind):
 
 
 _ORACLE_GREEDY = {}
+_ORACLE_BEAM = {}
 
 
 def _oracle_greedy(kind, sd, hp, imgs, i):
@@ -253,10 +254,12 @@ def test_fp32_full_batch_sampled_beam_rows_equal_the_reference(kind):
     for i in (0, 255):
         got = toks[i, :int(lens[i])].cpu().tolist()
         assert got == g[f"beam_{i}"].tolist(), (kind, i, "vs the reference-recorded caption")
-    # (the oracle reproduces G15's image 255 in tests/test_oracle_golden.py; image 0 here, next to the HIP path)
-    torch.manual_seed(700)
-    want = R.model_generate(kind, sd, model._hp, imgs[:1], **kw).reshape(-1).tolist()
-    assert toks[0, :int(lens[0])].cpu().tolist() == want, (kind, "vs the oracle")
+    # (the oracle reproduces G15's image 255 in tests/test_oracle_golden.py; image 0 here, next to the HIP path -- once per process:
+    #  tests/test_f32x_gpu.py re-runs this test on the split-operand path against the same oracle caption)
+    if kind not in _ORACLE_BEAM:
+        torch.manual_seed(700)
+        _ORACLE_BEAM[kind] = R.model_generate(kind, sd, model._hp, imgs[:1], **kw).reshape(-1).tolist()
+    assert toks[0, :int(lens[0])].cpu().tolist() == _ORACLE_BEAM[kind], (kind, "vs the oracle")
     # the single-image reference call sequence: torch.manual_seed(s); model.generate(image, rng="torch")
     torch.manual_seed(700 + 255)
     with torch.no_grad():

@@ -253,6 +253,9 @@ def test_g18_bench_rows(kind):
         t8 = torch.from_numpy(g[f"step0_top8_idx_{idx}"])
         np.testing.assert_allclose(row[t8].numpy(), g[f"step0_top8_val_{idx}"], atol=2e-4, rtol=1e-5)
         assert abs(float(row.double().sum()) - float(g[f"step0_rowsum_{idx}"])) < 5e-2
+    if kind == "CaptioningTransformer":      # an image of BASELINE config C4's 2,048-image batch (what tests/test_dist_gpu.py compares the HIP path with)
+        ids = R.model_generate(kind, sd, hp, synth_images(1, seed=0, first=2047), max_len=32, beam_size=1, top_k=1)
+        assert ids.reshape(-1).tolist() == g["greedy_far_2047"].tolist()
 
 
 @pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))

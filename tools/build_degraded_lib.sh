@@ -1,6 +1,6 @@
 #!/usr/bin/env bash
 # A deliberately degraded library for the "the gates turn red" check: the register-stationary LSTM step rounds its
-# gate pre-activations to bf16 before the cell update (= a kernel that accumulated in 16 bits).  Built next to the product library;
+# accumulators to bf16 after every 32-k MFMA step (= a kernel that accumulates in 16 bits).  Built next to the product library;
 # tests select it with DEEPHUMOR_HIP_LIB.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
@@ -11,9 +11,10 @@ python3 - "$D/csrc/lstm_wreg.hip" <<'PY'
 import sys
 p = sys.argv[1]
 s = open(p).read()
-old = "const float gi = acc[i][0] + b4.x, gf = acc[i][1] + b4.y, gg = acc[i][2] + b4.z, go = acc[i][3] + b4.w;"
-new = ("const float gi = bf16_to_f32(f32_to_bf16(acc[i][0] + b4.x)), gf = bf16_to_f32(f32_to_bf16(acc[i][1] + b4.y)), "
-       "gg = bf16_to_f32(f32_to_bf16(acc[i][2] + b4.z)), go = bf16_to_f32(f32_to_bf16(acc[i][3] + b4.w));")
+# 16-bit ACCUMULATION: the accumulator is rounded to bf16 after every 32-k MFMA step
+old = "        acc[i] = Op16<OT>::mfma(wf[f], fa[t % (PF + 1)], acc[i]);"
+new = ("        acc[i] = Op16<OT>::mfma(wf[f], fa[t % (PF + 1)], acc[i]);\n"
+       "        for (int e_ = 0; e_ < 4; ++e_) acc[i][e_] = bf16_to_f32(f32_to_bf16(acc[i][e_]));")
 assert old in s
 open(p, "w").write(s.replace(old, new))
 PY

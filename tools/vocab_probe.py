@@ -1,5 +1,5 @@
 """Developer probe: the classifier GEMM at the decode shape (1280 rows x 36541 tokens x 512) with and without the logits
-store (dh_vocab_logits vs dh_vocab_logprob), for the tile size selected by DH_VOCAB_TILE / DH_LOGPROB_TILE."""
+store (dh_vocab_logits vs dh_vocab_logprob)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from deephumor_amd import hip
@@ -21,9 +21,9 @@ def timeit(fn, iters=40, warm=5):
         for i in range(iters): fn(i)
         torch.cuda.synchronize()
     return {k: round(v["ms"] / v["calls"] * 1e3, 1) for k, v in prof.summary().items()}
-print("logits ", os.environ.get("DH_VOCAB_TILE", "128"), timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, logits, gm)))
-print("gmax   ", os.environ.get("DH_VOCAB_GMAX_TILE", "256"), timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, None, gm)))
-print("logprob", os.environ.get("DH_LOGPROB_TILE", "auto"), timeit(lambda i: hip.vocab_logprob(a[i % 4], w, b, tg)))
+print("logits ", timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, logits, gm)))
+print("gmax   ", timeit(lambda i: hip.vocab_logits(a[i % 4], w, b, None, gm)))
+print("logprob", timeit(lambda i: hip.vocab_logprob(a[i % 4], w, b, tg)))
 vpad = (V + 255) // 256 * 256
 if K == 512 and hip.vocab_logits_wreg_supported(M, V, K, vpad, vpad // 64):      # round 4: weights streamed from L2 into registers
     wp, bp = hip.pack_vocab_weights(w, b)
