@@ -6,7 +6,6 @@ library cannot be loaded, importing a kernel raises ``RuntimeError``.
 """
 import ctypes
 import os
-import threading
 
 import torch
 
@@ -22,15 +21,6 @@ _P, _I, _F, _U64 = _c.c_void_p, _c.c_int, _c.c_float, _c.c_uint64
 _lib = None
 
 
-def lib_path():
-    return _build.LIB_PATH
-
-
-def _ab_override():
-    """Developer A/B switch: DEEPHUMOR_HIP_LIB=<other build of the same ABI> (kernel experiments in scratch/)."""
-    return os.environ.get("DEEPHUMOR_HIP_LIB")
-
-
 def load():
     """Loads the shared library.  A single-process run with a compiler present rebuilds it first when the sources are
     newer (developer convenience; the build itself is serialised by a file lock and replaces the library atomically).
@@ -39,7 +29,7 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    path = lib_path()
+    path = _build.LIB_PATH
     solo = int(os.environ.get("WORLD_SIZE", "1")) == 1 and int(os.environ.get("LOCAL_RANK", "0")) == 0
     if solo and os.path.exists(_build._hipcc()) and (not os.path.exists(path) or _build.needs_build()):
         try:
@@ -49,7 +39,7 @@ def load():
     if not os.path.exists(path):
         raise RuntimeError(f"deephumor_amd: HIP extension missing at {path}; run `python __graft_entry__.py build`. "
                            "There is no CPU fallback on the product path.")
-    lib = ctypes.CDLL(_ab_override() or path)
+    lib = ctypes.CDLL(os.environ.get("DEEPHUMOR_HIP_LIB") or path)      # (developer A/B switch: another build of the same ABI)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)             # AttributeError if the ABI lost a symbol
         fn.argtypes = argtypes
@@ -127,41 +117,7 @@ def _check(code, name):
         raise RuntimeError(f"{name} failed: {load().dh_error_string(code).decode()} (code {code})")
 
 
-class Profiler:
-    """Per-entry-point timing with HIP events recorded INSIDE the library on the launch stream
-    (``dh_prof_begin`` / ``dh_prof_end``), so launches made by the native step drivers are seen too.
-    ``with hip.profile(watch={...}) as prof`` ... ``prof.summary()`` -> {"entry[tag]": calls, ms, flops, bytes}
-    with the algorithmic flops/bytes the library attaches to each launch.  Off otherwise."""
-
-    def __init__(self, watch=None, stride=1):
-        self.watch = None if watch is None else sorted(watch)
-        self.stride = stride
-        self._summary = None
-
-    def __enter__(self):
-        global _prof
-        self._prev, _prof = _prof, self
-        _check(load().dh_prof_set_stride(self.stride), "dh_prof_set_stride")
-        _check(load().dh_prof_begin(",".join(self.watch).encode() if self.watch else None), "dh_prof_begin")
-        return self
-
-    def __exit__(self, *exc):
-        global _prof
-        _prof = self._prev
-        self.summary()
-
-    def summary(self):
-        if self._summary is None:
-            lib = load()
-            _check(lib.dh_prof_end(), "dh_prof_end")
-            out = {}
-            name = _c.create_string_buffer(96)
-            calls, ms, fl, by = _I(), _c.c_double(), _c.c_double(), _c.c_double()
-            for i in range(lib.dh_prof_num()):
-                _check(lib.dh_prof_get(i, name, 96, _c.byref(calls), _c.byref(ms), _c.byref(fl), _c.byref(by)), "dh_prof_get")
-                out[name.value.decode()] = dict(calls=calls.value, ms=ms.value, flops=fl.value, bytes=by.value)
-            self._summary = out
-        return self._summary
+from ._prof import Profiler  # noqa: E402  (the in-library event profiler; needs load / _check above)
 
 
 _prof = None
@@ -169,6 +125,7 @@ _fns = {}
 
 
 def profile(watch=None, stride=1):
+    """``with hip.profile(watch={...}) as prof: ...; prof.summary()`` -- per-launch-key timing from HIP events inside the library."""
     return Profiler(watch, stride)
 
 
@@ -357,44 +314,6 @@ def f32x_take_overflow(device=None):
     flag = torch.zeros((1,), dtype=torch.int32, device=device or torch.device("cuda", torch.cuda.current_device()))
     _launch("dh_f32x_take_overflow", _ptr(flag), _stream())
     return bool(int(flag.item()))
-
-
-_f32x_tls = threading.local()
-_f32x_warned = [False]
-
-
-def f32x_guarded(fn):
-    """Decorator of the models' ``forward`` / ``generate_batch``: with option ``f32_split`` on an fp32 CUDA model, the OUTERMOST guarded
-    call reads the stream's range word once it returns (one host read -- the opt-in path only) and, if an activation left the fp16
-    range, repeats the call with the option off: the exact-fp32 kernels, same RNG state.  ADVICE r5: the split silently returned
-    inf / NaN for |x| >= 65504."""
-    import functools
-    import warnings
-
-    @functools.wraps(fn)
-    def wrapped(self, *args, **kw):
-        par = next(self.parameters(), None)
-        if (getattr(_f32x_tls, "depth", 0) or par is None or par.dtype != torch.float32 or not par.is_cuda or not option("f32_split")
-                or torch.cuda.is_current_stream_capturing()):
-            return fn(self, *args, **kw)
-        _f32x_tls.depth = 1
-        rng = torch.get_rng_state()
-        try:
-            out = fn(self, *args, **kw)
-            with torch.cuda.device(par.device):
-                over = f32x_take_overflow(par.device)
-        finally:
-            _f32x_tls.depth = 0
-        if not over:
-            return out
-        if not _f32x_warned[0]:
-            _f32x_warned[0] = True
-            warnings.warn("deephumor_amd: an activation left the fp16 range of the split-operand fp32 path (option f32_split); this call "
-                          "is repeated on the exact-fp32 kernels", RuntimeWarning)
-        torch.set_rng_state(rng)
-        with option_scope(f32_split=0):
-            return fn(self, *args, **kw)
-    return wrapped
 
 
 def f32_split_ok(w):

@@ -19,12 +19,12 @@ class _CaptioningBase(nn.Module):
 
     def __init_subclass__(cls, **kw):
         """Every model's ``forward`` / ``generate_batch`` is the OUTERMOST range-guarded call of the split-operand fp32 path
-        (``hip.f32x_guarded``: one host read of the stream's overflow word per call, with option ``f32_split`` only)."""
+        (``_f32x_guard.f32x_guarded``: one host read of the stream's overflow word per call, with option ``f32_split`` only)."""
         super().__init_subclass__(**kw)
-        from .. import hip
+        from ._f32x_guard import f32x_guarded
         for name in ("forward", "generate_batch"):
             if name in cls.__dict__:
-                setattr(cls, name, hip.f32x_guarded(cls.__dict__[name]))
+                setattr(cls, name, f32x_guarded(cls.__dict__[name]))
 
     def save(self, ckpt_path):
         """Saves the model's state and hyperparameters (reference caption_models.py:76-81)."""

@@ -12,6 +12,7 @@ import torch
 from torch import nn
 
 from .. import hip
+from ._f32x_guard import f32x_guarded
 
 RESNET50_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
 
@@ -391,7 +392,7 @@ class ImageEncoder(_Planned, nn.Module):
             return conv(y, blk["c3"], residual=idt, nhwc=nhwc), None
         return step
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def forward(self, images):
         _require_eval(self, self.dropout.p)
         plan = self._get_plan()
@@ -464,7 +465,7 @@ class ImageLabelEncoder(nn.Module):
         self.label_encoder(labels, out=both[:, e:], checked=True)
         return hip.linear(both, self.linear.weight.detach(), self.linear.bias.detach().float())
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def forward(self, images, labels):
         _require_eval(self, self.dropout.p)
         self.label_encoder.check(labels)                    # host sync in front of the trunk's launches, not behind them
@@ -479,7 +480,7 @@ class SpatialImageLabelEncoder(ImageLabelEncoder):
         super().__init__(num_tokens, emb_dim, dropout)
         self.image_encoder.spatial_features = True
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def forward(self, images, labels):
         _require_eval(self, self.dropout.p)
         self.label_encoder.check(labels)

@@ -14,6 +14,7 @@ import torch
 from torch import nn
 
 from .. import hip
+from ._f32x_guard import f32x_guarded
 from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, check_ids, check_lengths, classifier_must_be_finite, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
@@ -132,7 +133,7 @@ class LSTMDecoder(_Planned, nn.Module):
         st.started = 2 if st.started == 1 else 1
         return hout if hout is not None else sc["hout"]
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def forward(self, image_emb, captions, lengths=None):
         """Teacher-forced logits ``[bs, max(lengths), num_tokens]`` (reference rnn_models.py:28-46).
         Rows past ``lengths[i]`` are the packed-sequence zeros, i.e. the classifier bias."""
@@ -165,7 +166,7 @@ class LSTMDecoder(_Planned, nn.Module):
         hs.mul_(valid[..., None])          # pad_packed_sequence zero rows (mask, not arithmetic on valid rows)
         return hs, bs, steps_out
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def generate_batch(self, image_emb, caption=None, max_len=25, temperature=1.0, beam_size=10, top_k=50,
                        eos_index=3, seed=None, img0=0, noise_source=None, logits_hook=None, streams=1, seed_tensor=None,
                        defer_check=False, early_stop_every=0, exact=False, rng=None):

@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from .. import hip
+from ._f32x_guard import f32x_guarded
 from .beam import BeamOverflow, BeamSearchHelper, call_logits_hook, check_ids, classifier_must_be_finite, make_noise_source, resolve_seed, run_interleaved, warn_overflow_retry
 from .encoders import _Planned
 
@@ -627,7 +628,7 @@ class TransformerDecoder(_IncrementalDecoder):
     _layer_cls = DecoderLayer
     _cross = True
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def forward(self, x, enc_out, start_emb=None, *, num_positions=None):
         """Teacher-forced logits ``[bs, max(len(x)+1, S), num_tokens]`` (transformers.py:432-490).  The reference pads
         the decoder input up to the number of image patches (:450), so a 32-token caption costs 49 positions;
@@ -635,7 +636,7 @@ class TransformerDecoder(_IncrementalDecoder):
         the mask is causal -- for callers such as the perplexity scorer that never look further."""
         return self._forward(x, enc_out, start_emb, num_positions)
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def generate_batch(self, start_emb, enc_out, caption=None, max_len=25, temperature=1.0, beam_size=10,
                        top_k=50, eos_index=3, **kw):
         """``start_emb [N, D]``, ``enc_out [N, S, D]`` -> ``(tokens [N, max_len], lengths [N])``."""
@@ -656,12 +657,12 @@ class SelfAttentionTransformerDecoder(_IncrementalDecoder):
     _layer_cls = SelfAttentionDecoderLayer
     _cross = False
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def forward(self, x, start_emb):
         """Teacher-forced logits ``[bs, len(x)+1, num_tokens]`` (transformers.py:694-738)."""
         return self._forward(x, None, start_emb)
 
-    @hip.f32x_guarded
+    @f32x_guarded
     def generate_batch(self, start_emb, caption=None, max_len=25, temperature=1.0, beam_size=10,
                        top_k=50, eos_index=3, **kw):
         return self._generate_batch(start_emb, None, caption, max_len, temperature, beam_size, top_k,

@@ -227,7 +227,8 @@ def test_models_repeat_an_out_of_range_call_on_the_exact_path():
         want = model(imgs, cap, lengths)
         want_t = model.generate_batch(imgs, max_len=6, beam_size=1, top_k=1)
     hip.f32x_take_overflow()
-    hip._f32x_warned[0] = False
+    from deephumor_amd.models import _f32x_guard
+    _f32x_guard._f32x_warned[0] = False
     with torch.no_grad(), warnings.catch_warnings(record=True) as rec:
         warnings.simplefilter("always")
         got = model(imgs, cap, lengths)
