@@ -5,7 +5,7 @@ import ctypes
 import torch
 
 F32, BF16, BF16_OUT_F32, F16, F16_OUT_F32 = 0, 1, 2, 3, 4
-ABI_VERSION = 30
+ABI_VERSION = 31
 HALF_DTYPES = (torch.bfloat16, torch.float16)       # the two 16-bit storage / MFMA operand types
 ERR_ALL_FILTERED, ERR_OVERFLOW, ERR_TOO_FEW, ERR_NONFINITE = 1, 2, 4, 8
 MAX_BEAMS = 64
@@ -32,7 +32,7 @@ class TrModel(_c.Structure):
 
 
 class TrScratch(_c.Structure):
-    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2")]
+    _fields_ = [(n, _P) for n in ("x", "qkv", "att", "o", "q", "ff", "y2", "st0", "st1", "st2", "xp", "attp", "ffp")]
 
 
 class LnFold(_c.Structure):
@@ -51,7 +51,7 @@ class LstmModel(_c.Structure):
 
 
 class LstmScratch(_c.Structure):
-    _fields_ = [(n, _P) for n in ("xcat0", "xcatl", "c_cur", "gates", "hout")]
+    _fields_ = [(n, _P) for n in ("xcat0", "xcatl", "c_cur", "gates", "hout", "topp")]
 
 
 # name -> argtypes, mirrors include/deephumor_hip.h line by line
@@ -149,9 +149,15 @@ SIGNATURES = {
     "dh_f32x_take_overflow": [_P, _P],
     "dh_linear_f32x_wreg_supported": [_I, _I, _I],
     "dh_linear_f32x_wreg": [_P, _I, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "dh_linear_f32xp_wreg": [_P, _P, _P, _P, _I, _P, _I, _P, _I, _I, _I, _I, _P],
+    "dh_add_layernorm_f32x": [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P],
     "dh_linear_f32x": [_P, _I, _P, _I, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _P],
     "dh_conv2d_nhwc_f32x": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_split_act_f32x": [_P, _I, _P, _I, _I, _I, _P],
+    "dh_linear_f32xp": [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],
+    "dh_conv2d_nhwc_f32xp": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P],
+    "dh_maxpool3x3s2_nhwc_f32xp": [_P, _P, _I, _I, _I, _I, _P],
     "dh_maxpool3x3s2_nhwc_f32": [_P, _P, _I, _I, _I, _I, _P],
     "dh_avgpool_nhwc_f32": [_P, _P, _I, _I, _I, _P],
     "dh_option_count": [],

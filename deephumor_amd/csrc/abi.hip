@@ -144,6 +144,7 @@ const OptDef g_opt_defs[DH_OPT_COUNT] = {
     {"lstm_wreg", "DH_LSTM_WREG", 1},
     {"lstm_wreg_min_rows", "DH_LSTM_WREG_MIN_ROWS", 256},
     {"f32_split", "DH_F32_SPLIT", 0},
+    {"f32_planes", "DH_F32_PLANES", 1},
     {"deferred_ln", "DH_DEFERRED_LN", 1},
     {"packed_cross", "DH_PACKED_CROSS", 1},
     {"encoder_generic", "DH_ENCODER_GENERIC", 0},

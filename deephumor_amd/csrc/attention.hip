@@ -13,6 +13,8 @@
 #include "prof.h"
 #include "attn_items.h"
 
+unsigned* dh_f32x_range_flag_of(hipStream_t s);      // gemm_f32x.hip
+
 template <typename T>
 struct AttnParams {
     const T* q; int ldq;                  // query rows (compact)
@@ -25,7 +27,47 @@ struct AttnParams {
     int rows_per_img, row_mult, rows_total, L, D, dh, lcap, pad_index;
     float scale;
     int row_si;                           // compact row of (image, w) = img * row_si + w (decode: rows_per_img; prefill chunks: n_pos)
+    // fp32 rows, dtype DH_F32_OUT_PLANES: the result is stored as the fp16 planes [2][rows][D] (hi, lo * 2^11) of the split-operand
+    // GEMM that consumes it (fc_o: csrc/linear_f32x_wreg.hip) instead of fp32 -- the same numbers that GEMM would split it into
+    uint16_t* outp; size_t out_plane; unsigned* range_flag;
 };
+
+template <typename T>
+__device__ __forceinline__ void out_store1(const AttnParams<T>& p, size_t off, float v) {
+    if constexpr (sizeof(T) == 4) {
+        if (p.outp) {
+            const f16_t h = (f16_t)v;
+            const f16_t l = (f16_t)((v - (float)h) * 2048.0f);
+            p.outp[off] = __builtin_bit_cast(uint16_t, h);
+            p.outp[p.out_plane + off] = __builtin_bit_cast(uint16_t, l);
+            if (fabsf(v) >= 65504.0f) atomicOr(p.range_flag, 1u);
+            return;
+        }
+    }
+    stf(p.out + off, v);
+}
+template <typename T>
+__device__ __forceinline__ void out_store8(const AttnParams<T>& p, size_t off, const float (&o)[8]) {
+    if constexpr (sizeof(T) == 4) {
+        if (p.outp) {
+            uint32_t h[4], l[4];
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const f16_t ha = (f16_t)o[j], hb = (f16_t)o[j + 1];
+                const f16_t la = (f16_t)((o[j] - (float)ha) * 2048.0f), lb = (f16_t)((o[j + 1] - (float)hb) * 2048.0f);
+                h[j / 2] = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+                l[j / 2] = (uint32_t)__builtin_bit_cast(uint16_t, la) | ((uint32_t)__builtin_bit_cast(uint16_t, lb) << 16);
+                amax = fmaxf(amax, fmaxf(fabsf(o[j]), fabsf(o[j + 1])));
+            }
+            *reinterpret_cast<uint4*>(p.outp + off) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4*>(p.outp + p.out_plane + off) = make_uint4(l[0], l[1], l[2], l[3]);
+            if (amax >= 65504.0f) atomicOr(p.range_flag, 1u);
+            return;
+        }
+    }
+    store8(p.out + off, o);
+}
 
 // Beam row of this wave: a workgroup holds DH_ATTN_RPB (= 16) waves = 16 rows of its image; images with more rows (beam_size > 16,
 // beam.py:7-9 allows any beam_size <= top_k) take blockIdx.z row blocks.  Waves past the image's last row compute a copy of
@@ -110,7 +152,7 @@ __global__ __launch_bounds__(1024) void attn_decode_kernel(AttnParams<T> p) {
             acc = fmaf(pj, ldf(vp + d), acc);
         }
         if (!w_ok) continue;
-        stf(p.out + (size_t)rc * D + h * dh + d, acc);
+        out_store1(p, (size_t)rc * D + h * dh + d, acc);
         if (!CROSS) {   // append this position to the cache at the row's own logical slot
             p.kc[((size_t)t * p.rows_total + rl) * D + h * dh + d] = p.knew[(size_t)rc * p.ldnew + h * dh + d];
             p.vc[((size_t)t * p.rows_total + rl) * D + h * dh + d] = p.vnew[(size_t)rc * p.ldnew + h * dh + d];
@@ -213,7 +255,7 @@ __global__ __launch_bounds__(1024) void attn_decode_fast_kernel(AttnParams<T> p)
             }
         }
     if (kg == 0 && w_ok) {
-        store8(p.out + (size_t)rc * D + h * DH + dc * 8, o);
+        out_store8(p, (size_t)rc * D + h * DH + dc * 8, o);
         if (!CROSS) {   // append this position to the cache at the row's own logical slot
             copy8(p.kc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.knew + (size_t)rc * p.ldnew + h * DH + dc * 8);
             copy8(p.vc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.vnew + (size_t)rc * p.ldnew + h * DH + dc * 8);
@@ -340,7 +382,7 @@ __global__ __launch_bounds__(1024) void attn_decode_reg_kernel(AttnParams<T> p) 
             }
         }
     if (kg == 0) {
-        store8(p.out + (size_t)rc * D + h * DH + dc * 8, o8);
+        out_store8(p, (size_t)rc * D + h * DH + dc * 8, o8);
         if (!CROSS) {
             copy8(p.kc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.knew + (size_t)rc * p.ldnew + h * DH + dc * 8);
             copy8(p.vc + ((size_t)t * p.rows_total + rl) * D + h * DH + dc * 8, p.vnew + (size_t)rc * p.ldnew + h * DH + dc * 8);
@@ -417,8 +459,8 @@ __global__ __launch_bounds__(1024) void attn_cross_lds_kernel(AttnParams<T> p) {
         o0 += __shfl_xor(o0, 32, 64);
         o1 += __shfl_xor(o1, 32, 64);
         if (par == 0 && w_ok) {
-            stf(p.out + (size_t)rc * D + (h0 + hh) * DH + d2, o0);
-            stf(p.out + (size_t)rc * D + (h0 + hh) * DH + d2 + 1, o1);
+            out_store1(p, (size_t)rc * D + (h0 + hh) * DH + d2, o0);
+            out_store1(p, (size_t)rc * D + (h0 + hh) * DH + d2 + 1, o1);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
@@ -445,8 +487,9 @@ static bool launch_fast(AttnParams<T>& p, int n_img, int n_heads, int rows_per_i
 template <typename T>
 static void launch_self(const void* qkv, void* kcache, void* vcache, const int32_t* src, int src_ld,
                         const int32_t* tokens, int tok_ld, void* out, int n_img, int rows_per_img, int row_mult,
-                        int rows_total, int t, int D, int n_heads, float scale, int pad_index, hipStream_t s) {
+                        int rows_total, int t, int D, int n_heads, float scale, int pad_index, hipStream_t s, bool planes = false) {
     AttnParams<T> p{};
+    if (planes) { p.outp = (uint16_t*)out; p.out_plane = (size_t)n_img * rows_per_img * D; p.range_flag = dh_f32x_range_flag_of(s); }
     p.q = (const T*)qkv; p.ldq = 3 * D;
     p.knew = (const T*)qkv + D; p.vnew = (const T*)qkv + 2 * D; p.ldnew = 3 * D;
     p.kc = (T*)kcache; p.vc = (T*)vcache; p.src = src; p.src_ld = src_ld;
@@ -469,6 +512,12 @@ extern "C" int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, 
     const double esz_ = dtype == DH_F32 ? 4.0 : 2.0;
     DhProfScope prof("dh_attn_self_decode", 4.0 * n_img * rows_per_img * (t + 1) * D,
                      esz_ * n_img * rows_per_img * ((t + 1) * 2.0 * D + 2.0 * D), stream);
+    if (dtype == DH_F32_OUT_PLANES) {     // fp32 rows, the result as split planes [2][rows][D] (see AttnParams)
+        DH_REQUIRE(((uintptr_t)out % 16) == 0 && dh_f32x_range_flag_of((hipStream_t)stream));
+        launch_self<float>(qkv, kcache, vcache, src, src_ld, tokens, tok_ld, out, n_img, rows_per_img, row_mult, rows_total, t, D, n_heads, scale,
+                           pad_index, (hipStream_t)stream, true);
+        DH_LAUNCH_CHECK();
+    }
     DH_DISPATCH_T(dtype, launch_self<T>(qkv, kcache, vcache, src, src_ld, tokens, tok_ld, out, n_img, rows_per_img,
                                         row_mult, rows_total, t, D, n_heads, scale, pad_index, (hipStream_t)stream));
     DH_LAUNCH_CHECK();
@@ -476,8 +525,9 @@ extern "C" int dh_attn_self_decode(const void* qkv, void* kcache, void* vcache, 
 
 template <typename T>
 static void launch_cross(const void* q, int ldq, const void* kv, const uint8_t* keymask, void* out, int n_img,
-                         int rows_per_img, int S, int D, int n_heads, float scale, hipStream_t s, int row_si = 0) {
+                         int rows_per_img, int S, int D, int n_heads, float scale, hipStream_t s, int row_si = 0, bool planes = false) {
     AttnParams<T> p{};
+    if (planes) { p.outp = (uint16_t*)out; p.out_plane = (size_t)n_img * rows_per_img * D; p.range_flag = dh_f32x_range_flag_of(s); }
     p.q = (const T*)q; p.ldq = ldq; p.kv = (const T*)kv; p.keymask = keymask; p.out = (T*)out;
     p.rows_per_img = rows_per_img; p.row_mult = 1; p.rows_total = 0; p.row_si = row_si > 0 ? row_si : rows_per_img;
     p.L = S; p.D = D; p.dh = D / n_heads; p.lcap = (S + 3) & ~3; p.pad_index = -1; p.scale = scale;
@@ -506,6 +556,11 @@ extern "C" int dh_attn_cross_decode(const void* q, int ldq, const void* kv, cons
     const double esz_ = dtype == DH_F32 ? 4.0 : 2.0;
     DhProfScope prof("dh_attn_cross_decode", 4.0 * n_img * rows_per_img * S * D,
                      esz_ * n_img * (S * 2.0 * D + rows_per_img * 2.0 * D), stream);
+    if (dtype == DH_F32_OUT_PLANES) {
+        DH_REQUIRE(((uintptr_t)out % 16) == 0 && dh_f32x_range_flag_of((hipStream_t)stream));
+        launch_cross<float>(q, ldq, kv, keymask, out, n_img, rows_per_img, S, D, n_heads, scale, (hipStream_t)stream, 0, true);
+        DH_LAUNCH_CHECK();
+    }
     DH_DISPATCH_T(dtype, launch_cross<T>(q, ldq, kv, keymask, out, n_img, rows_per_img, S, D, n_heads, scale,
                                          (hipStream_t)stream));
     DH_LAUNCH_CHECK();

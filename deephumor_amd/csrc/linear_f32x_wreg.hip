@@ -26,6 +26,8 @@ constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f, kF16Max = 65504.0f;
 
 struct FwParams {
     const float* A; int lda;
+    const uint16_t* Ap; unsigned a_plane_b;              // PIN: the activation as planes [2][M][lda] fp16 (hi, lo); bytes from hi to lo
+    uint16_t* Cp; size_t c_plane; int ldcp;              // optional: the result as planes [2][M][ldcp] (as well as / instead of C)
     const uint4* wh; const uint4* wl;                    // fragment-packed planes [K / 32][N / 16][64] x 16 bytes
     const float* bias; const float* res; int ldres;
     float* C; int ldc;
@@ -51,7 +53,9 @@ __device__ __forceinline__ void fw_dma16(const void* base, unsigned off, void* l
 // linear_wreg.hip).  The fp32 block comes in by LDS-DMA (no staging registers, every piece requested up front), then every 32-byte
 // piece (8 k values of one row: the two adjacent slots 2q ^ m, (2q + 1) ^ m) is split IN PLACE into its fp16 hi plane (first
 // slot) and lo plane (second slot): an MFMA fragment is then one ds_read_b128 per plane.
-template <int NW, int RL, int NS>
+// PIN: the activation arrives SPLIT (planes written by its producer: LayerNorm, attention, the ReLU layer in front): the hi / lo pieces go
+// by LDS-DMA straight into the slots the in-place split would fill -- no split pass, one barrier less, no VALU work before the MFMAs.
+template <int NW, int RL, int NS, bool PIN>
 __global__ __launch_bounds__(64 * NW, 1) void linear_f32x_wreg_kernel(FwParams p) {
     constexpr int NT = 64 * NW, KC = 32 * NS, KF = NS, TM = (RL + 15) / 16, RG = RL / 8, SLABB = RL * 128;
     constexpr int PIECES = RL * NS * 4;                  // 32-byte pieces of a chunk
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_f32x_wreg_kernel(FwParams p
     const unsigned rd_base = (unsigned)(l15 * 128 + (((2 * lq) ^ (l15 & 7)) << 4));
     const unsigned rd_last = PARTIAL ? (unsigned)((l15 & 7) * 128 + (((2 * lq) ^ (l15 & 7)) << 4)) : rd_base;
     // source byte offset of this lane's 16 bytes in row (8 g + lr) of the block: slot lpos of a row with (row & 7) == lr
-    const unsigned swz = (unsigned)((lpos ^ lr) << 4), ldb = (unsigned)p.lda * 4u;
+    const unsigned swz = (unsigned)((lpos ^ lr) << 4), ldb = (unsigned)p.lda * 4u, ldb2 = (unsigned)p.lda * 2u;
+    const unsigned pin_off = (unsigned)(((lpos ^ lr) >> 1) << 4) + (((lpos ^ lr) & 1) ? p.a_plane_b : 0u);
     float amax = 0.f;
     const size_t fstep = (size_t)(p.N / 16) * 64;
     const int nchunk = p.K / KC;
@@ -95,8 +100,12 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_f32x_wreg_kernel(FwParams p
                 const int s = wave + NW * sl;
                 if (s < NS) {
 #pragma unroll
-                    for (int g = 0; g < RG; ++g)
-                        fw_dma16(p.A, (unsigned)min(m0 + g * 8 + lr, p.M - 1) * ldb + swz + (unsigned)(kc * KC + 32 * s) * 4u, lds + s * SLABB + g * 1024);
+                    for (int g = 0; g < RG; ++g) {
+                        if (PIN)     // slot lpos of row (8 g + lr) holds logical slot lpos ^ lr = 2 q + plane: 8 k values of one plane
+                            fw_dma16(p.Ap, (unsigned)min(m0 + g * 8 + lr, p.M - 1) * ldb2 + pin_off + (unsigned)(kc * KC + 32 * s) * 2u, lds + s * SLABB + g * 1024);
+                        else
+                            fw_dma16(p.A, (unsigned)min(m0 + g * 8 + lr, p.M - 1) * ldb + swz + (unsigned)(kc * KC + 32 * s) * 4u, lds + s * SLABB + g * 1024);
+                    }
                 }
             }
         }
@@ -108,10 +117,10 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_f32x_wreg_kernel(FwParams p
             for (int f = 0; f < KF; ++f) { wfh[f] = p.wh[base + (size_t)f * fstep]; wfl[f] = p.wl[base + (size_t)f * fstep]; }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                 // the fp32 block is in LDS
+        __syncthreads();                                 // the block is in LDS
         // ---- split in place: piece pc = (slab, row, q): x0 = slot (2q) ^ m, x1 = its neighbour -> hi, lo -----------------------------------
 #pragma unroll 2
-        for (int it = 0; it < C_IT; ++it) {
+        for (int it = 0; it < (PIN ? 0 : C_IT); ++it) {
             const int pc = tid + it * NT;
             if (C_IT * NT == PIECES || pc < PIECES) {
                 const int q = pc & 3, row = (pc >> 2) % RL, s = (pc >> 2) / RL;
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_f32x_wreg_kernel(FwParams p
                 *reinterpret_cast<uint4*>(a1) = lo;
             }
         }
-        __syncthreads();
+        if (!PIN) __syncthreads();
         // ---- TM row tiles x KF k-steps: two fragment reads (PF groups ahead), three MFMAs in the tile kernels' order ---------------------
         uint4 fh[PF + 1], fl[PF + 1];
         auto rd = [&](int t) {                           // t = TM f + i
@@ -155,6 +164,7 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_f32x_wreg_kernel(FwParams p
     const int e15 = ln & 15, eq = ln >> 4;
     const int n = n0 + 16 * wave + 4 * eq;
     const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    float omax = 0.f;                                    // range guard of a result stored as planes
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int row = 16 * i + e15, m = m0 + row;
@@ -167,8 +177,16 @@ __global__ __launch_bounds__(64 * NW, 1) void linear_f32x_wreg_kernel(FwParams p
             v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
         if (p.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = v;
+        if (p.C) *reinterpret_cast<float4*>(p.C + (size_t)m * p.ldc + n) = v;
+        if (p.Cp) {
+            uint2 hi, lo;
+            split2(v.x, v.y, hi.x, lo.x); split2(v.z, v.w, hi.y, lo.y);
+            omax = fmaxf(omax, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+            *reinterpret_cast<uint2*>(p.Cp + (size_t)m * p.ldcp + n) = hi;
+            *reinterpret_cast<uint2*>(p.Cp + p.c_plane + (size_t)m * p.ldcp + n) = lo;
+        }
     }
+    if (omax >= kF16Max) atomicOr(p.range_flag, 1u);
 }
 
 int pick_xn(int tiles_m, int tiles_n) {
@@ -197,6 +215,27 @@ extern "C" int dh_linear_f32x_wreg_supported(int M, int N, int K) {
     return M > 0 && N > 0 && (N % 64) == 0 && K > 0 && ((K % 512) == 0 || (K % 384) == 0) && K <= 4096 && fw_form(M, N) != 0;
 }
 
+namespace {
+template <bool PIN>
+int fw_launch(FwParams& p, hipStream_t s) {
+    p.range_flag = dh_f32x_range_flag_of(s);
+    if (!p.range_flag) return DH_ERR_LAUNCH;
+    const bool k384 = (p.K % 512) != 0;
+    const bool wide = fw_form(p.M, p.N) == 2;
+    p.tiles_n = p.N / (wide ? 128 : 64); p.tiles_m = dh_cdiv(p.M, wide ? 80 : 40);
+    p.xn = pick_xn(p.tiles_m, p.tiles_n);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (wide) {
+        if (k384) hipLaunchKernelGGL((linear_f32x_wreg_kernel<8, 80, 12, PIN>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((linear_f32x_wreg_kernel<8, 80, 16, PIN>), grid, dim3(512), 0, s, p);
+    } else {
+        if (k384) hipLaunchKernelGGL((linear_f32x_wreg_kernel<4, 40, 12, PIN>), grid, dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((linear_f32x_wreg_kernel<4, 40, 16, PIN>), grid, dim3(256), 0, s, p);
+    }
+    return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
+}
+}  // namespace
+
 // C [M, ldc] fp32 = act(A W^T + bias (+ residual)) as dh_linear_f32x computes it (bit-identical), with w_packed = the two planes of
 // dh_split_f32x(W [N, K]) each through dh_pack_mfma_fragments: [2][K / 32][N / 16][64] x 16 bytes.
 extern "C" int dh_linear_f32x_wreg(const float* A, int lda, const void* w_packed, const float* bias, const float* residual, int ldres,
@@ -207,22 +246,27 @@ extern "C" int dh_linear_f32x_wreg(const float* A, int lda, const void* w_packed
     FwParams p{};
     p.A = A; p.lda = lda; p.wh = (const uint4*)w_packed; p.wl = p.wh + (size_t)(K / 32) * (N / 16) * 64;
     p.bias = bias; p.res = residual; p.ldres = ldres; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.relu = relu;
-    hipStream_t s = (hipStream_t)stream;
-    p.range_flag = dh_f32x_range_flag_of(s);
-    if (!p.range_flag) return DH_ERR_LAUNCH;
     dh_prof_set_dims(M, N, K);
     DhProfScope prof("dh_linear_f32x", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
-    const bool k384 = (K % 512) != 0;
-    const bool wide = fw_form(M, N) == 2;
-    p.tiles_n = N / (wide ? 128 : 64); p.tiles_m = dh_cdiv(M, wide ? 80 : 40);
-    p.xn = pick_xn(p.tiles_m, p.tiles_n);
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    if (wide) {
-        if (k384) hipLaunchKernelGGL((linear_f32x_wreg_kernel<8, 80, 12>), grid, dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((linear_f32x_wreg_kernel<8, 80, 16>), grid, dim3(512), 0, s, p);
-    } else {
-        if (k384) hipLaunchKernelGGL((linear_f32x_wreg_kernel<4, 40, 12>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((linear_f32x_wreg_kernel<4, 40, 16>), grid, dim3(256), 0, s, p);
-    }
-    DH_LAUNCH_CHECK();
+    return fw_launch<false>(p, (hipStream_t)stream);
+}
+
+// The same launch for an activation stored as planes (a_planes [2][M][K] fp16: hi, lo * 2^11 -- written by the producing kernel or
+// dh_split_act_f32x): no split pass in front of the MFMAs.  The result goes to C (fp32) and / or c_planes [2][M][N] (either may be NULL:
+// a layer whose only consumer is the next GEMM -- relu(fc_1) -- writes planes only).  Bit-identical to dh_linear_f32x on the same values.
+extern "C" int dh_linear_f32xp_wreg(const void* a_planes, const void* w_packed, const float* bias, const float* residual, int ldres,
+                                    float* C, int ldc, void* c_planes, int M, int N, int K, int relu, void* stream) {
+    DH_REQUIRE(a_planes && w_packed && bias && (C || c_planes) && dh_linear_f32x_wreg_supported(M, N, K) && (!C || ldc >= N));
+    DH_REQUIRE((!C || ((ldc % 4) == 0 && ((uintptr_t)C % 16) == 0)) && ((uintptr_t)a_planes % 16) == 0 && ((uintptr_t)w_packed % 16) == 0 &&
+               (!c_planes || ((uintptr_t)c_planes % 16) == 0) && ((uintptr_t)bias % 16) == 0 &&
+               (!residual || (ldres >= N && (ldres % 4) == 0 && ((uintptr_t)residual % 16) == 0)));
+    DH_REQUIRE((size_t)M * K * 2 < (1ull << 31));
+    FwParams p{};
+    p.Ap = (const uint16_t*)a_planes; p.a_plane_b = (unsigned)((size_t)M * K * 2); p.lda = K;
+    p.wh = (const uint4*)w_packed; p.wl = p.wh + (size_t)(K / 32) * (N / 16) * 64;
+    p.bias = bias; p.res = residual; p.ldres = ldres; p.C = C; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.relu = relu;
+    p.Cp = (uint16_t*)c_planes; p.c_plane = (size_t)M * N; p.ldcp = N;
+    dh_prof_set_dims(M, N, K);
+    DhProfScope prof("dh_linear_f32x", 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N), stream);
+    return fw_launch<true>(p, (hipStream_t)stream);
 }

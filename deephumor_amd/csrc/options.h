@@ -17,6 +17,7 @@ enum DhOption {
     DH_OPT_LSTM_WREG_MIN_ROWS,       // ... from this many rows
     // ---- fp32 models: arithmetic of the dense layers ----
     DH_OPT_F32_SPLIT,                // 1: fp32 GEMMs / convolutions as three fp16 MFMAs on split operands (gemm_f32x.hip)
+    DH_OPT_F32_PLANES,               // ... with the decode chain's GEMM operands stored split by their producers (gemm_f32xp.hip; 0: A/B)
     // ---- switches read by the Python layer (kernel selection in the plans) ----
     DH_OPT_DEFERRED_LN,              // deferred-LayerNorm decode chain (0: LayerNorm launches between the GEMMs)
     DH_OPT_PACKED_CROSS,             // matrix-core cross-attention on packed K / V^T tiles (0: the LDS kernel)

@@ -88,7 +88,8 @@ extern "C" int dh_embed_prefill(const void* tok_emb, const void* pos_emb, const 
 template <typename T, int NV>   // 16-byte vectors per lane kept in registers
 __global__ __launch_bounds__(256) void add_layernorm_kernel(
     const T* __restrict__ x, const T* __restrict__ y, const float* __restrict__ gamma,
-    const float* __restrict__ beta, T* __restrict__ out, int rows, int D, float eps) {
+    const float* __restrict__ beta, T* __restrict__ out, int rows, int D, float eps,
+    uint16_t* __restrict__ planes = nullptr, size_t plane = 0, unsigned* range_flag = nullptr) {
     constexpr int VN = Vec16<T>::N;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= rows) return;
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
     }
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
     T* o = out + (size_t)r * D;
+    float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         if (live[i]) {
@@ -138,8 +140,23 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(
 #pragma unroll
             for (int j = 0; j < VN; ++j) w[j] = (v[i][j] - mean) * rstd * gm[i][j] + bt[i][j];
             store16(o + (lane + i * 64) * VN, w);
+            if (VN == 4 && planes) {                     // (fp32 rows only) the same values as the split planes of the next GEMM operand
+                uint32_t h[2], l[2];
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {
+                    const f16_t ha = (f16_t)w[j], hb = (f16_t)w[j + 1];
+                    const f16_t la = (f16_t)((w[j] - (float)ha) * 2048.0f), lb = (f16_t)((w[j + 1] - (float)hb) * 2048.0f);
+                    h[j / 2] = (uint32_t)__builtin_bit_cast(uint16_t, ha) | ((uint32_t)__builtin_bit_cast(uint16_t, hb) << 16);
+                    l[j / 2] = (uint32_t)__builtin_bit_cast(uint16_t, la) | ((uint32_t)__builtin_bit_cast(uint16_t, lb) << 16);
+                    amax = fmaxf(amax, fmaxf(fabsf(w[j]), fabsf(w[j + 1])));
+                }
+                const size_t po = (size_t)r * D + (lane + i * 64) * 4;
+                *reinterpret_cast<uint2*>(planes + po) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2*>(planes + plane + po) = make_uint2(l[0], l[1]);
+            }
         }
     }
+    if (VN == 4 && planes && amax >= 65504.0f) atomicOr(range_flag, 1u);
 }
 
 extern "C" int dh_add_layernorm(const void* x, const void* y, const float* gamma, const float* beta,
@@ -150,12 +167,31 @@ extern "C" int dh_add_layernorm(const void* x, const void* y, const float* gamma
     const dim3 grid(dh_cdiv(rows, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define DH_LN(NV) hipLaunchKernelGGL((add_layernorm_kernel<T, NV>), grid, block, 0, s, (const T*)x, \
-                                     (const T*)y, gamma, beta, (T*)out, rows, D, eps)
+                                     (const T*)y, gamma, beta, (T*)out, rows, D, eps, (uint16_t*)nullptr, (size_t)0, (unsigned*)nullptr)
     DH_DISPATCH_T(dtype, {
         const int per_pass = 64 * Vec16<T>::N;
         if (D <= per_pass) DH_LN(1); else if (D <= 2 * per_pass) DH_LN(2); else if (D <= 4 * per_pass) DH_LN(4);
         else if (D <= 8 * per_pass) DH_LN(8); else DH_LN(16);
     });
+#undef DH_LN
+    DH_LAUNCH_CHECK();
+}
+
+// dh_add_layernorm on fp32 rows with the result ALSO stored as the fp16 planes [2][rows][D] of the split-operand GEMMs (hi, lo * 2^11):
+// the LayerNorm's output is the residual of the next sublayer (fp32) and the operand of its first GEMM (planes, csrc/linear_f32x_wreg.hip)
+unsigned* dh_f32x_range_flag_of(hipStream_t s);      // gemm_f32x.hip
+extern "C" int dh_add_layernorm_f32x(const float* x, const float* y, const float* gamma, const float* beta, float* out, void* out_planes,
+                                     int rows, int D, float eps, void* stream) {
+    DH_REQUIRE(x && gamma && beta && out && out_planes && rows > 0 && D > 0 && (D % 8) == 0 && D <= 4096);
+    DH_REQUIRE(((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && ((uintptr_t)out_planes % 16) == 0);
+    DhProfScope prof("dh_add_layernorm", 0.0, 0.0, stream);
+    const dim3 grid(dh_cdiv(rows, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned* flag = dh_f32x_range_flag_of(s);
+    if (!flag) return DH_ERR_LAUNCH;
+#define DH_LN(NV) hipLaunchKernelGGL((add_layernorm_kernel<float, NV>), grid, block, 0, s, x, y, gamma, beta, out, rows, D, eps, \
+                                     (uint16_t*)out_planes, (size_t)rows * D, flag)
+    if (D <= 256) DH_LN(1); else if (D <= 512) DH_LN(2); else if (D <= 1024) DH_LN(4); else if (D <= 2048) DH_LN(8); else DH_LN(16);
 #undef DH_LN
     DH_LAUNCH_CHECK();
 }

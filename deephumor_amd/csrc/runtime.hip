@@ -125,6 +125,66 @@ static int decode_position_deferred(const dh_tr_model_t* m, const dh_tr_scratch_
     return dh_add_layernorm(sc->x, nullptr, Z.ln3_g, Z.ln3_b, x_final, rows, D, Z.ln3_eps, dt, stream);
 }
 
+// The decode position of an fp32 model on the split-operand path with every GEMM operand STORED split (options "f32_split" +
+// "f32_planes"; round 6).  The producers -- LayerNorm, the two attentions, relu(fc_1) -- write the fp16 planes their consumer would make
+// of an fp32 tensor (the same numbers), so dh_linear_f32xp_wreg starts its MFMAs straight after the LDS-DMA: no split pass, and the
+// classifier (dh_linear_f32xp) hands the beam sampler its 64-column group maxima like the 16-bit paths.  Same arithmetic, same
+// results as the fp32-activation launches below it (tests/test_f32x_gpu.py).
+static bool f32xp_ready(const dh_tr_model_t* m, const dh_tr_scratch_t* sc, int rows) {
+    if (m->dtype != DH_F32 || !dh_opt(DH_OPT_F32_SPLIT) || !dh_opt(DH_OPT_F32_PLANES) || !dh_opt(DH_OPT_DECODE_WREG)) return false;
+    if (!sc->xp || !sc->attp || !sc->ffp || !m->cls_w_x || (m->D % 32) != 0) return false;
+    const int D = m->D, PF = m->pf_dim;
+    if (!dh_linear_f32x_wreg_supported(rows, 3 * D, D) || !dh_linear_f32x_wreg_supported(rows, D, D) ||
+        !dh_linear_f32x_wreg_supported(rows, PF, D) || !dh_linear_f32x_wreg_supported(rows, D, PF)) return false;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const dh_tr_layer_t& L = m->layers[l];
+        if (!L.wqkv_xp || !L.wo_xp || !L.w1_xp || !L.w2_xp || (m->cross && (!L.wq_xp || !L.weo_xp))) return false;
+    }
+    return true;
+}
+
+static int decode_position_f32xp(const dh_tr_model_t* m, const dh_tr_scratch_t* sc, const int32_t* tokens, int tok_ld, const int32_t* src,
+                                 int src_ld, int n_img, int rows_per_img, int row_mult, int rows_total, int t, void* x_out, float* logits,
+                                 int ldl, float* group_max, int gm_ld, void* stream) {
+    const int rows = n_img * rows_per_img, D = m->D, PF = m->pf_dim;
+    float *x = (float*)sc->x, *o = (float*)sc->o;
+    for (int l = 0; l < m->n_layers; ++l) {
+        const dh_tr_layer_t& L = m->layers[l];
+        dh_prof_set_tag("qkv");
+        if (l == 0) {      // the embedded rows are fp32 (dh_embed_rows): the one GEMM of the position that splits its operand itself
+            DH_TRY(dh_linear_f32x_wreg(x, D, L.wqkv_xp, L.bqkv, nullptr, 0, (float*)sc->qkv, 3 * D, rows, 3 * D, D, 0, stream));
+        } else {
+            DH_TRY(dh_linear_f32xp_wreg(sc->xp, L.wqkv_xp, L.bqkv, nullptr, 0, (float*)sc->qkv, 3 * D, nullptr, rows, 3 * D, D, 0, stream));
+        }
+        DH_TRY(dh_attn_self_decode(sc->qkv, L.kcache, L.vcache, src, src_ld, tokens, tok_ld, sc->attp, n_img, rows_per_img,
+                                   row_mult, rows_total, t, D, m->n_heads, L.sa_scale, m->pad_index, DH_F32_OUT_PLANES, stream));
+        dh_prof_set_tag("proj");
+        DH_TRY(dh_linear_f32xp_wreg(sc->attp, L.wo_xp, L.bo, nullptr, 0, o, D, nullptr, rows, D, D, 0, stream));
+        DH_TRY(dh_add_layernorm_f32x(x, o, L.ln1_g, L.ln1_b, x, sc->xp, rows, D, L.ln1_eps, stream));
+        if (m->cross) {
+            dh_prof_set_tag("proj");
+            DH_TRY(dh_linear_f32xp_wreg(sc->xp, L.wq_xp, L.bq, nullptr, 0, (float*)sc->q, D, nullptr, rows, D, D, 0, stream));
+            DH_TRY(dh_attn_cross_decode(sc->q, D, L.kv, m->keymask, sc->attp, n_img, rows_per_img, m->S, D, m->n_heads, L.ea_scale,
+                                        DH_F32_OUT_PLANES, stream));
+            dh_prof_set_tag("proj");
+            DH_TRY(dh_linear_f32xp_wreg(sc->attp, L.weo_xp, L.beo, nullptr, 0, o, D, nullptr, rows, D, D, 0, stream));
+            DH_TRY(dh_add_layernorm_f32x(x, o, L.ln2_g, L.ln2_b, x, sc->xp, rows, D, L.ln2_eps, stream));
+        }
+        dh_prof_set_tag("ffn");
+        DH_TRY(dh_linear_f32xp_wreg(sc->xp, L.w1_xp, L.b1, nullptr, 0, nullptr, 0, sc->ffp, rows, PF, D, 1, stream));   // relu(fc_1): planes only
+        dh_prof_set_tag("ffn");
+        DH_TRY(dh_linear_f32xp_wreg(sc->ffp, L.w2_xp, L.b2, nullptr, 0, o, D, nullptr, rows, D, PF, 0, stream));
+        float* dst = (l == m->n_layers - 1 && x_out) ? (float*)x_out : x;
+        DH_TRY(dh_add_layernorm_f32x(x, o, L.ln3_g, L.ln3_b, dst, sc->xp, rows, D, L.ln3_eps, stream));
+    }
+    if (logits) {
+        dh_prof_set_tag("vocab");
+        DH_TRY(dh_linear_f32xp(sc->xp, m->cls_w_x, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, nullptr, group_max, gm_ld, rows, m->V, 0,
+                               stream));
+    }
+    return DH_OK;
+}
+
 extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_tr_scratch_t* sc,
                                               const void* start_emb, const int32_t* tokens, int tok_ld,
                                               const int32_t* src, int src_ld, int n_img, int rows_per_img,
@@ -153,6 +213,9 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
         }
         return DH_OK;
     }
+    if (f32xp_ready(m, sc, rows))
+        return decode_position_f32xp(m, sc, tokens, tok_ld, src, src_ld, n_img, rows_per_img, row_mult, rows_total, t, x_out, logits, ldl,
+                                     group_max, gm_ld, stream);
     for (int l = 0; l < m->n_layers; ++l) {
         const dh_tr_layer_t& L = m->layers[l];
         dh_prof_set_tag("qkv");
@@ -183,7 +246,13 @@ extern "C" int dh_transformer_decode_position(const dh_tr_model_t* m, const dh_t
                                  m->V, D, dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
-        if (dt == DH_F32) {
+        if (dt == DH_F32 && group_max) {
+            // (a caller that wants group maxima from an fp32 model gets them from the planes classifier or an error, never stale memory)
+            if (!(m->cls_w_x && sc->xp && (D % 32) == 0)) return DH_ERR_UNSUPPORTED;
+            DH_TRY(dh_split_act_f32x((const float*)(x_out ? x_out : sc->x), D, sc->xp, rows, D, D, stream));
+            DH_TRY(dh_linear_f32xp(sc->xp, m->cls_w_x, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, nullptr, group_max, gm_ld, rows, m->V,
+                                   0, stream));
+        } else if (dt == DH_F32) {
             DH_TRY(plain_linear(x_out ? x_out : sc->x, D, m->cls_w, m->cls_w_x, nullptr, D, m->cls_b, logits, ldl, rows, m->V, D, 0, dt, stream));
         } else {
             DH_TRY(dh_linear(x_out ? x_out : sc->x, D, m->cls_w, D, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows,
@@ -264,7 +333,15 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
         DH_TRY(classifier_groups(top, top_ld, m->cls_w, m->cls_b, m->cls_w_pk, m->cls_b_pad, logits, ldl, group_max, gm_ld, rows, m->V, Hh, dt, stream));
     } else if (logits) {
         dh_prof_set_tag("vocab");
-        if (dt == DH_F32) {
+        if (dt == DH_F32 && group_max && !(m->cls_w_x && sc->topp && (Hh % 32) == 0 && (top_ld % 4) == 0)) return DH_ERR_UNSUPPORTED;
+        if (dt == DH_F32 && m->cls_w_x && sc->topp && (group_max || (dh_opt(DH_OPT_F32_SPLIT) && dh_opt(DH_OPT_F32_PLANES))) && (Hh % 32) == 0 &&
+            (top_ld % 4) == 0) {
+            // the classifier on a split top-layer state (csrc/gemm_f32xp.hip: both operands by LDS-DMA, three slabs deep) + the group
+            // maxima the beam sampler takes on the 16-bit paths; bit-identical logits
+            DH_TRY(dh_split_act_f32x((const float*)top, top_ld, sc->topp, rows, Hh, Hh, stream));
+            DH_TRY(dh_linear_f32xp(sc->topp, m->cls_w_x, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, nullptr, group_max, gm_ld, rows,
+                                   m->V, 0, stream));
+        } else if (dt == DH_F32) {
             DH_TRY(plain_linear(top, top_ld, m->cls_w, m->cls_w_x, nullptr, Hh, m->cls_b, logits, ldl, rows, m->V, Hh, 0, dt, stream));
         } else {
             DH_TRY(dh_linear(top, top_ld, m->cls_w, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, rows, m->V, Hh, 0,

@@ -61,6 +61,8 @@ class LSTMDecoder(_Planned, nn.Module):
                     dtype=self.classifier.weight.dtype)
         if split:
             plan["cls_w_x"] = hip.split_f32x(plan["cls_w"].contiguous())
+            # the classifier on a split top-layer state (csrc/gemm_f32xp.hip) fills the beam sampler's group maxima like the 16-bit paths
+            plan["f32_planes"] = bool(hip.option("f32_planes")) and self.lstm.hidden_size % 32 == 0
         if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and plan["cls_w"].shape[1] == 512 and hip.option("vocab_wreg"):
             # the beam-search classifier with the weights streamed from L2 into registers (csrc/vocab_wreg.hip): padded, fragment-packed copy
             plan["cls_w_pk"], plan["cls_b_pad"] = hip.pack_vocab_weights(plan["cls_w"], plan["cls_b"])
@@ -83,6 +85,7 @@ class LSTMDecoder(_Planned, nn.Module):
             self.c = torch.empty((self.nl, r, self.hh), device=dev)             # cell state always fp32
             self.started = 0                                                    # 0: zero state, then 1, 2, 1, 2, ...
             self._scratch = {}
+            self.planes = bool(plan.get("f32_planes"))
             self.c_layers = (hip.LstmLayer * self.nl)()
             for i, (w, b, w_il, b_il, w_pk, w_x, w_xp) in enumerate(plan["layers"]):
                 if w_x is not None:
@@ -117,6 +120,8 @@ class LSTMDecoder(_Planned, nn.Module):
                     c_cur=torch.empty((nl, rows, hh), device=dev),
                     gates=torch.empty((rows, 4 * hh), device=dev),              # gate pre-activations fp32
                     hout=torch.empty((rows, hh), device=dev, dtype=dt))
+                if self.planes:                        # fp32, split operands: the top layer's state as fp16 planes for the classifier
+                    bufs["topp"] = torch.empty((2, rows, hh), device=dev, dtype=torch.float16)
                 c = hip.LstmScratch()
                 for k, v in bufs.items():
                     setattr(c, k, v.data_ptr())
@@ -213,7 +218,7 @@ class LSTMDecoder(_Planned, nn.Module):
             # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
             logits = torch.empty((r, (self.num_tokens + 255) // 256 * 256), device=dev)[:, :self.num_tokens]   # whole 256-column chunks (vocab_wreg)
             gmax = (torch.empty((r, 4 * ((self.num_tokens + 255) // 256)), device=dev)[:, :hip.n_groups(self.num_tokens)]
-                    if plan["dtype"] in hip.HALF_DTYPES else None)                   # column-group maxima (16-bit paths)
+                    if plan["dtype"] in hip.HALF_DTYPES or plan.get("f32_planes") else None)    # column-group maxima (16-bit paths, f32x planes)
             gm = None if gmax is None else gmax[:n]
             # image slot, then the teacher-forced prefix: one row per image living at logical row img*beam
             lg = logits[:n]

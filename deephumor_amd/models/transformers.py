@@ -232,6 +232,9 @@ class _IncrementalDecoder(_Planned, nn.Module):
                             if pk is not None:
                                 ent[name + "_xp"] = pk
             plan["cls_w_x"] = hip.split_f32x(plan["cls_w"].contiguous())
+            # ... and the decode chain's GEMM operands stored split by their producers (csrc/gemm_f32xp.hip, runtime.hip): the scratch then
+            # carries plane buffers and the classifier fills the beam sampler's group maxima like the 16-bit paths
+            plan["f32_planes"] = bool(hip.option("f32_planes")) and self.hid_dim % 32 == 0
         if plan["dtype"] in hip.HALF_DTYPES and plan["cls_w"].is_cuda and self.hid_dim == 512 and hip.option("vocab_wreg"):
             # the register-streamed classifier (csrc/vocab_wreg.hip; bit-identical).  The LSTM decoder uses it at every size; here it is
             # selected per batch by row count (_Run): at <= "vocab_wreg_transformer_max_rows" rows per position (small shards, single
@@ -286,6 +289,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     self.dperm = "wq_f" in plan["layers"][0] and d <= 512
                     self.packed = [hip.attn_cross_pack(kv, n, s, d, dec.n_heads, dperm=self.dperm) for kv in self.kv]
             self._scratch = {}
+            self.planes = bool(plan.get("f32_planes"))
             self.pf = dec.layers[0].pf.fc_1.out_features
             self.d, self.dev = d, dev
             P = lambda t: 0 if t is None else t.data_ptr()
@@ -338,6 +342,9 @@ class _IncrementalDecoder(_Planned, nn.Module):
                     bufs["y2"] = e(rows, self.d)
                     for k in ("st0", "st1", "st2"):
                         bufs[k] = torch.empty((rows, self.d // 64, 2), device=self.dev, dtype=torch.float32)
+                if self.planes:                        # fp32, split operands: x / att / ff as fp16 planes (hi, lo)
+                    h = lambda w: torch.empty((2, rows, w), device=self.dev, dtype=torch.float16)
+                    bufs.update(xp=h(self.d), attp=h(self.d), ffp=h(self.pf))
                 c = hip.TrScratch()
                 for k, v in bufs.items():
                     setattr(c, k, v.data_ptr())
@@ -582,7 +589,7 @@ class _IncrementalDecoder(_Planned, nn.Module):
             # logits always fp32; row stride padded to 64 floats so rows are 16-byte aligned (vector stores)
             logits = torch.empty((r, (self.num_tokens + 255) // 256 * 256), device=dev)[:, :self.num_tokens]   # whole 256-column chunks (vocab_wreg)
             gmax = (torch.empty((r, 4 * ((self.num_tokens + 255) // 256)), device=dev)[:, :hip.n_groups(self.num_tokens)]
-                    if plan["dtype"] in hip.HALF_DTYPES else None)                   # column-group maxima (16-bit paths)
+                    if plan["dtype"] in hip.HALF_DTYPES or plan.get("f32_planes") else None)    # column-group maxima (16-bit paths, f32x planes)
             gm = None if gmax is None else gmax[:n]
             # positions 0..pos with ONE row per image (logical row img*beam), sampling at `pos`
             lg = logits[:n]

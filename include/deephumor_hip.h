@@ -25,13 +25,16 @@
 extern "C" {
 #endif
 
-#define DH_ABI_VERSION 30
+#define DH_ABI_VERSION 31
 
 enum { DH_OK = 0, DH_ERR_BAD_ARG = 1, DH_ERR_UNSUPPORTED = 2, DH_ERR_LAUNCH = 3 };
 enum { DH_F32 = 0, DH_BF16 = 1,          /* storage type of activations and weights */
        DH_BF16_OUT_F32 = 2,              /* dh_linear only: bf16 operands, fp32 output (logits) */
        DH_F16 = 3,                       /* IEEE half storage / v_mfma_f32_16x16x32_f16 operands (BASELINE config 5) */
-       DH_F16_OUT_F32 = 4 };             /* dh_linear only: fp16 operands, fp32 output */
+       DH_F16_OUT_F32 = 4,               /* dh_linear only: fp16 operands, fp32 output */
+       DH_F32_OUT_PLANES = 5 };          /* dh_attn_self_decode / dh_attn_cross_decode only: fp32 operands, `out` = the fp16 planes
+                                            [2][rows][D] (hi = fp16(x), lo = fp16((x - hi) * 2^11)) of the split-operand GEMM that
+                                            consumes the result (option "f32_split": dh_linear_f32xp_wreg) */
 
 /* device-side error bits OR-ed into the `err` word of the beam kernels */
 enum { DH_BEAM_ERR_ALL_FILTERED = 1,   /* every logit filtered (-inf): reference raises RuntimeError, beam.py:46 */
@@ -577,6 +580,9 @@ typedef struct dh_tr_scratch {
     void *x, *qkv, *att, *o, *q, *ff;       /* [rows, D|3D|D|D|D|PF] */
     void* y2;                               /* [rows, D]      second pre-LayerNorm row buffer of the deferred chain (or NULL) */
     float *st0, *st1, *st2;                 /* [rows, D/64, 2] partial LayerNorm statistics of x / o / y2 (or NULL) */
+    void *xp, *attp, *ffp;                  /* optional (DH_F32, options "f32_split" + "f32_planes"): fp16 planes [2][rows][D | D | PF] of x /
+                                               att / ff -- the GEMM operands of the position stored split by their producers; with them
+                                               (and the layers' *_xp weights) the position runs on dh_linear_f32xp_wreg / dh_linear_f32xp */
 } dh_tr_scratch_t;
 
 /* All decoder layers of one decode position as ONE persistent launch (round 6; csrc/decode_layers.hip): DecoderLayer.forward
@@ -627,7 +633,11 @@ typedef struct dh_lstm_model {
     const void* cls_w_x;                                    /* optional (DH_F32): dh_split_f32x planes of cls_w */
 } dh_lstm_model_t;
 
-typedef struct dh_lstm_scratch { void *xcat0, *xcatl; float *c_cur, *gates; void* hout; } dh_lstm_scratch_t;
+typedef struct dh_lstm_scratch {
+    void *xcat0, *xcatl; float *c_cur, *gates; void* hout;
+    void* topp;                             /* optional (DH_F32, option "f32_split"): fp16 planes [2][rows][Hh] of the top layer's state: the
+                                               classifier then runs on dh_linear_f32xp and fills group_max */
+} dh_lstm_scratch_t;
 
 /* One LSTM layer time step in one launch (bf16): gates = [x | h_prev[parent]] * w_il^T + b_il on the matrix cores,
  * cell update in the epilogue.  x row of compact row m: emb[tokens[m*row_mult*tok_ld + tok_pos]] if tokens, else
@@ -691,11 +701,36 @@ int dh_f32x_take_overflow(uint32_t* dst, void* stream);
 int dh_linear_f32x_wreg_supported(int M, int N, int K);
 int dh_linear_f32x_wreg(const float* A, int lda, const void* w_packed, const float* bias, const float* residual, int ldres,
                         float* C, int ldc, int M, int N, int K, int relu, void* stream);
+/* dh_linear_f32x_wreg for an activation stored as planes (a_planes [2][M][K], K = the row stride): no split pass in front of the MFMAs; the
+ * result as fp32 (C) and / or planes (c_planes [2][M][N]) -- either may be NULL.  dh_add_layernorm_f32x = dh_add_layernorm on fp32 rows
+ * with the result stored both ways (out fp32 = the next residual, out_planes = the next GEMM operand). */
+int dh_linear_f32xp_wreg(const void* a_planes, const void* w_packed, const float* bias, const float* residual, int ldres,
+                         float* C, int ldc, void* c_planes, int M, int N, int K, int relu, void* stream);
+int dh_add_layernorm_f32x(const float* x, const float* y, const float* gamma, const float* beta, float* out, void* out_planes,
+                          int rows, int D, float eps, void* stream);
 int dh_linear_f32x(const float* A, int lda, const void* w_planes, int Kp, const float* bias, const float* scale, const float* shift,
                    const float* residual, int ldres, float* C, int ldc, int M, int N, int K, int relu, void* stream);
 int dh_conv2d_nhwc_f32x(const float* x, const void* w_planes, int Kp, const float* scale, const float* shift, const float* residual,
                         float* y, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu, void* stream);
 int dh_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
+/* The same arithmetic on activations STORED split (csrc/gemm_f32xp.hip): a tensor whose only consumers are GEMM operands is kept as the
+ * two fp16 planes [2][rows][K] its consumer would make of it (4 bytes per element, the same numbers), so both operands go global ->
+ * LDS by DMA, three slabs deep, with no split work in the loop.  Bit-identical to dh_linear_f32x / dh_conv2d_nhwc_f32x on the same values.
+ *   dh_split_act_f32x        A fp32 [M, lda] -> planes [2][M][Kp] (zero padded to Kp = K rounded up to 32); range-guarded like the kernels
+ *   dh_linear_f32xp          a_planes [2][M][Kp] x w_planes [2][N][Kp] -> C fp32 [M, ldc] and / or c_planes [2][M][N] (N % 4 == 0), either
+ *                            NULL; group_max (optional) [M, gm_ld]: the maxima of the 64-column groups of the stored values -- what
+ *                            dh_vocab_logits hands dh_beam_row_sample_groups on the 16-bit paths
+ *   dh_conv2d_nhwc_f32xp     x_planes [2][N,H,W,Cin] (Cin % 32 == 0), w planes of [Cout][KS][KS][Cin] -> y fp32 and / or y_planes
+ *                            [2][N,Ho,Wo,Cout]; residual fp32
+ *   dh_maxpool3x3s2_nhwc_f32xp  MaxPool2d(3, 2, 1) of a channels-last fp32 tensor -> planes */
+int dh_split_act_f32x(const float* A, int lda, void* planes, int M, int K, int Kp, void* stream);
+int dh_linear_f32xp(const void* a_planes, const void* w_planes, int Kp, const float* bias, const float* scale, const float* shift,
+                    const float* residual, int ldres, float* C, int ldc, void* c_planes, float* group_max, int gm_ld, int M, int N,
+                    int relu, void* stream);
+int dh_conv2d_nhwc_f32xp(const void* x_planes, const void* w_planes, const float* scale, const float* shift, const float* residual,
+                         float* y, void* y_planes, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu,
+                         void* stream);
+int dh_maxpool3x3s2_nhwc_f32xp(const float* x, void* y_planes, int N, int H, int W, int C, void* stream);
 int dh_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int dh_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, void* stream);
 

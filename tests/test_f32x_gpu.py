@@ -181,6 +181,130 @@ def test_linear_f32x_wreg_equals_linear_f32x(m, n, k):
     assert hip.f32x_take_overflow() is True
 
 
+@pytest.mark.parametrize("m,v,k", [(1280, 36541, 512), (256, 4100, 512), (300, 1000, 96), (5, 7, 32), (513, 129, 2048)])
+def test_planes_linear_equals_linear_f32x(m, v, k):
+    """dh_linear_f32xp (round 6: the activation arrives as the fp16 planes its producer stored; both operands by LDS-DMA, three slabs deep)
+    against dh_linear_f32x on the same values: bit-identical logits, the 64-column group maxima the beam sampler takes, the planes output."""
+    from deephumor_amd import hip, f32xp
+    g = torch.Generator().manual_seed(m + v + k)
+    a = torch.randn(m, k, generator=g).cuda()
+    w = (torch.randn(v, k, generator=g) * k ** -0.5).cuda()
+    b = torch.randn(v, generator=g).cuda()
+    wp = hip.split_f32x(w)
+    ap = f32xp.split_act(a)
+    assert torch.equal(f32xp.join(ap)[:, :k].double(), (ap[0].double() + ap[1].double() / 2048.0)[:, :k])
+    want = hip.linear_f32x(a, wp, b)
+    ld = (v + 255) // 256 * 256
+    out = torch.full((m, ld), 7.0, device="cuda")
+    gm = torch.zeros(m, hip.n_groups(v), device="cuda")
+    f32xp.linear(ap, wp, b, out=out[:, :v], group_max=gm)
+    assert torch.equal(out[:, :v], want) and bool((out[:, v:] == 7.0).all())
+    pad = torch.full((m, gm.shape[1] * 64 - v), float("-inf"), device="cuda")
+    assert torch.equal(gm, torch.cat([want, pad], 1).view(m, -1, 64).amax(-1))
+    if v % 4 == 0:
+        res = torch.randn(m, v, generator=g).cuda()
+        o2, p2 = f32xp.linear(ap, wp, b, relu=True, residual=res, out_planes=True)
+        want2 = hip.linear_f32x(a, wp, b, relu=True, residual=res)
+        assert torch.equal(o2, want2) and torch.equal(p2, f32xp.split_act(want2)[:, :, :v])
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,ks,stride,pad,res", [(2, 14, 64, 64, 3, 1, 1, False), (2, 15, 64, 128, 3, 2, 1, False),
+                                                           (3, 9, 256, 64, 1, 1, 0, False), (2, 7, 128, 512, 1, 1, 0, True),
+                                                           (2, 16, 96, 192, 1, 2, 0, False), (70, 7, 512, 512, 3, 1, 1, True)])
+def test_planes_conv_equals_conv_f32x(n, hw, cin, cout, ks, stride, pad, res):
+    """dh_conv2d_nhwc_f32xp against dh_conv2d_nhwc_f32x: fp32 and planes outputs, residual, ReLU, stride 2, zero padding at the borders."""
+    from deephumor_amd import hip, f32xp
+    g = torch.Generator().manual_seed(hw * 7 + cin + cout)
+    x = torch.randn(n, hw, hw, cin, generator=g).cuda()
+    w = (torch.randn(cout, ks * ks * cin, generator=g) * (ks * ks * cin) ** -0.5).cuda()
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+    wp = hip.split_f32x(w)
+    xp = f32xp.split_act(x.view(-1, cin)).view(2, n, hw, hw, cin)
+    ho = (hw + 2 * pad - ks) // stride + 1
+    r = torch.randn(n, ho, ho, cout, generator=g).cuda() if res else None
+    want = hip.conv2d_nhwc_f32x(x, wp, ks, sc, sh, residual=r, stride=stride, pad=pad)
+    y, yp = f32xp.conv2d_nhwc(xp, wp, ks, sc, sh, residual=r, stride=stride, pad=pad, want="both")
+    assert torch.equal(y, want)
+    assert torch.equal(yp, f32xp.split_act(want.view(-1, cout)).view_as(yp))
+    assert torch.equal(f32xp.conv2d_nhwc(xp, wp, ks, sc, sh, residual=r, stride=stride, pad=pad, want="planes"), yp)
+    xm = torch.randn(n, 2 * hw, 2 * hw, 64, generator=g).cuda()
+    assert torch.equal(f32xp.maxpool3x3s2_nhwc(xm), f32xp.split_act(hip.maxpool3x3s2_nhwc_f32(xm).view(-1, 64)).view(2, n, hw, hw, 64))
+
+
+@pytest.mark.parametrize("n,k", [(512, 512), (1536, 512), (2048, 512), (512, 2048), (2048, 768), (2048, 1024)])
+@pytest.mark.parametrize("m", [37, 160, 1280])
+def test_planes_wreg_equals_linear_f32x(m, n, k):
+    """dh_linear_f32xp_wreg (planes in: no split pass in front of the MFMAs; fp32 and / or planes out) against dh_linear_f32x."""
+    from deephumor_amd import hip, f32xp
+    g = torch.Generator().manual_seed(m * 31 + n + k + 1)
+    a = (torch.randn(m, k, generator=g) * 1.5).cuda()
+    w = (torch.randn(n, k, generator=g) * k ** -0.5).cuda()
+    b = torch.randn(n, generator=g).cuda()
+    planes = hip.split_f32x(w)
+    packed = hip.pack_f32x_fragments(planes)
+    ap = f32xp.split_act(a)
+    hip.f32x_take_overflow()
+    res = torch.randn(m, n, generator=g).cuda()
+    for relu, r in ((False, None), (True, None), (False, res)):
+        want = hip.linear_f32x(a, planes, b, relu=relu, residual=r)
+        got, gp = f32xp.linear_wreg(ap, packed, b, relu=relu, residual=r, want="both")
+        assert torch.equal(got, want), (m, n, k, relu, float((got - want).abs().max()))
+        assert torch.equal(gp, f32xp.split_act(want))
+        assert torch.equal(f32xp.linear_wreg(ap, packed, b, relu=relu, residual=r, want="planes"), gp)
+    assert hip.f32x_take_overflow() is False
+
+
+def test_planes_producers_layernorm_and_attention():
+    """The producers of the planes chain: dh_add_layernorm_f32x (fp32 + planes) and the two fp32 decode attentions with dtype
+    DH_F32_OUT_PLANES store exactly the split of what their fp32 forms store."""
+    from deephumor_amd import hip, f32xp
+    g = torch.Generator().manual_seed(5)
+    for rows, d in ((1280, 512), (37, 256), (9, 1024)):
+        x, y = torch.randn(rows, d, generator=g).cuda(), torch.randn(rows, d, generator=g).cuda()
+        gam, bet = torch.randn(d, generator=g).cuda(), torch.randn(d, generator=g).cuda()
+        want = hip.add_layernorm(x, y, gam, bet)
+        out, pl = f32xp.add_layernorm(x, y, gam, bet)
+        assert torch.equal(out, want) and torch.equal(pl, f32xp.split_act(want))
+    n_img, beam, d, heads, s = 6, 5, 512, 8, 49
+    rows = n_img * beam
+    for t in (0, 3, 17, 41):
+        qkv = torch.randn(rows, 3 * d, generator=g).cuda()
+        kc, vc = torch.randn(t + 1, rows, d, generator=g).cuda(), torch.randn(t + 1, rows, d, generator=g).cuda()
+        src = torch.randint(0, rows, (rows, 64), generator=g, dtype=torch.int32).cuda()
+        toks = torch.randint(2, 50, (rows, 64), generator=g, dtype=torch.int32).cuda()
+        kc2, vc2 = kc.clone(), vc.clone()
+        want = hip.attn_self_decode(qkv, kc, vc, src, toks, torch.empty(rows, d, device="cuda"), n_img, beam, 1, rows, t, d, heads, 8.0, 0)
+        got = f32xp.attn_self_decode_planes(qkv, kc2, vc2, src, toks, n_img, beam, 1, rows, t, d, heads, 8.0, 0)
+        assert torch.equal(got, f32xp.split_act(want)) and torch.equal(kc, kc2) and torch.equal(vc, vc2)
+    q = torch.randn(rows, d, generator=g).cuda()
+    kv = torch.randn(n_img * s, 2 * d, generator=g).cuda()
+    km = (torch.rand(n_img * s, generator=g) < 0.1).to(torch.uint8).cuda()
+    want = hip.attn_cross_decode(q, kv, km, torch.empty(rows, d, device="cuda"), n_img, beam, s, d, heads, 8.0)
+    assert torch.equal(f32xp.attn_cross_decode_planes(q, kv, km, n_img, beam, s, d, heads, 8.0), f32xp.split_act(want))
+    assert hip.f32x_take_overflow() is False
+
+
+@pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
+def test_planes_chain_equals_the_fp32_activation_chain(kind, images):
+    """Option f32_planes (the decode chain's GEMM operands stored split by their producers, the classifier with group maxima) against the
+    fp32-activation launches of the same split-operand path: every step's logits and the sampled beam-5 captions are identical."""
+    from deephumor_amd import hip
+    imgs = synth_images(8, seed=3).cuda()
+    outs = {}
+    for planes in (0, 1):
+        with hip.option_scope(f32_planes=planes):
+            model, _ = TF._model(kind, torch.float32)
+            logs = []
+            toks, lens = model.generate_batch(imgs, max_len=20, beam_size=5, top_k=50, seed=11,
+                                              logits_hook=lambda i, lg: logs.append(lg.clone()))
+            outs[planes] = (toks.clone(), lens.clone(), logs)
+            del model
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert len(outs[0][2]) == len(outs[1][2]) > 0
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)
+
+
 def test_activation_range_guard_of_the_split_path():
     """only the WEIGHTS of the split-operand path were range-checked (at plan time); an activation with |x| >= 65504 splits
     into hi = inf and the GEMM silently returned inf / NaN.  Now such a launch sets the stream's sticky word
