@@ -56,9 +56,12 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     lo = (uint32_t)__builtin_bit_cast(uint16_t, la) | ((uint32_t)__builtin_bit_cast(uint16_t, lb) << 16);
 }
 
-// position of 16-byte chunk c (0..3) of row r inside the row's 64 bytes: rows r, r+4, r+8, r+12 of a 16-row fragment read
-// would otherwise hit the same banks
-__device__ __forceinline__ int swz(int r, int c) { return c ^ ((r >> 2) & 3); }
+// position of 16-byte chunk c (0..3) of row r inside the row's 64 bytes.  A 16-row fragment read is one ds_read_b128: lane = row +
+// 16 chunk, served in the four lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32) over a 256-byte bank row = four 64-byte
+// rows -- a group holds the row quartets (chunk 0: rows 0-3, 12-15; chunk 1: rows 4-11), so the XOR key g(row >> 2) must make
+// g(0), g(3), 1 ^ g(1), 1 ^ g(2) four different slots: g = 0, 3, 2, 1 (the key r >> 2 itself of rounds 4-5 left every read 2-way
+// conflicted: twice the LDS cycles)
+__device__ __forceinline__ int swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 3); }
 
 // acc[j][i][r] = C[m = mw + 16 i + l15][n = nw + 16 j + 4 lq + r]; main + 2^-11 * correction, then bias / scale + shift / residual / ReLU
 template <int TM, int TN>

@@ -1,9 +1,10 @@
-"""Python side of ``csrc/gemm_f32xp.hip``: the split-operand fp32 GEMM / convolution on activations STORED as their two fp16 planes.
+"""Python side of the split-operand fp32 kernels that take activations STORED as their two fp16 planes (``csrc/gemm_f32xp.hip``,
+``csrc/linear_f32x_wreg.hip``, the planes outputs of LayerNorm and the decode attentions).
 
-A planes tensor is ``[2, ...]`` fp16: index 0 = hi = fp16(x), index 1 = lo = fp16((x - hi) * 2^11) -- what ``dh_linear_f32x`` /
-``dh_conv2d_nhwc_f32x`` make of an fp32 operand in registers, here made ONCE by the producer's epilogue.  Same products, same sums:
-bit-identical results (``tests/test_f32x_gpu.py``).  Replaces the same reference call sites as ``hip.linear_f32x`` /
-``hip.conv2d_nhwc_f32x`` (encoders.py:56; rnn_models.py:45; transformers.py:489).
+A planes tensor is ``[2, ...]`` fp16: index 0 = hi = fp16(x), index 1 = lo = fp16((x - hi) * 2^11) -- what ``dh_linear_f32x`` makes of
+an fp32 operand in registers, here made ONCE by the producer.  Same products, same sums: bit-identical results
+(``tests/test_f32x_gpu.py``).  Replaces the same reference call sites as ``hip.linear_f32x`` / ``hip.linear_f32x_wreg``
+(rnn_models.py:45; transformers.py:97,127,162-163,489).
 """
 import torch
 
@@ -44,31 +45,6 @@ def linear(a_planes, w_planes, bias=None, scale=None, shift=None, relu=False, re
                 hip._ptr(residual), residual.stride(0) if residual is not None else 0, hip._ptr(out), out.stride(0) if out is not None else 0,
                 hip._ptr(cp), hip._ptr(group_max), group_max.stride(0) if group_max is not None else 0, m, n, int(relu), hip._stream(), tag=tag)
     return (out, cp) if out_planes is True else cp if out_planes else out
-
-
-def conv2d_nhwc(x_planes, w_planes, ks, scale, shift, residual=None, relu=True, stride=1, pad=0, want="f32"):
-    """``dh_conv2d_nhwc_f32xp``: ``x_planes [2, N, H, W, Cin]`` -> ``want`` = "f32" (fp32 ``[N, Ho, Wo, Cout]``), "planes", or "both"
-    (fp32, planes)."""
-    hip._dev(x_planes, w_planes, scale, shift, residual)
-    two, n, h, w, cin = x_planes.shape
-    cout, kp = w_planes.shape[1], w_planes.shape[2]
-    assert two == 2 and x_planes.is_contiguous() and kp == ks * ks * cin and cin % 32 == 0
-    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
-    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x_planes.device) if want != "planes" else None
-    yp = torch.empty((2, n, ho, wo, cout), dtype=torch.float16, device=x_planes.device) if want != "f32" else None
-    hip._launch("dh_conv2d_nhwc_f32xp", hip._ptr(x_planes), hip._ptr(w_planes), hip._ptr(scale), hip._ptr(shift), hip._ptr(residual),
-                hip._ptr(y), hip._ptr(yp), n, h, w, cin, cout, ks, stride, pad, int(relu), hip._stream())
-    return (y, yp) if want == "both" else yp if want == "planes" else y
-
-
-def maxpool3x3s2_nhwc(x):
-    """``dh_maxpool3x3s2_nhwc_f32xp``: fp32 ``[N, H, W, C]`` -> planes ``[2, N, Ho, Wo, C]``."""
-    hip._dev(x)
-    n, h, w, c = x.shape
-    assert x.dtype == torch.float32 and x.is_contiguous()
-    yp = torch.empty((2, n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c), dtype=torch.float16, device=x.device)
-    hip._launch("dh_maxpool3x3s2_nhwc_f32xp", hip._ptr(x), hip._ptr(yp), n, h, w, c, hip._stream())
-    return yp
 
 
 def linear_wreg(a_planes, packed, bias, relu=False, residual=None, out=None, want="f32", tag=None):

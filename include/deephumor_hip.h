@@ -715,22 +715,15 @@ int dh_conv2d_nhwc_f32x(const float* x, const void* w_planes, int Kp, const floa
 int dh_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
 /* The same arithmetic on activations STORED split (csrc/gemm_f32xp.hip): a tensor whose only consumers are GEMM operands is kept as the
  * two fp16 planes [2][rows][K] its consumer would make of it (4 bytes per element, the same numbers), so both operands go global ->
- * LDS by DMA, three slabs deep, with no split work in the loop.  Bit-identical to dh_linear_f32x / dh_conv2d_nhwc_f32x on the same values.
+ * LDS by DMA, three slabs deep, with no split work in the loop.  Bit-identical to dh_linear_f32x on the same values.
  *   dh_split_act_f32x        A fp32 [M, lda] -> planes [2][M][Kp] (zero padded to Kp = K rounded up to 32); range-guarded like the kernels
  *   dh_linear_f32xp          a_planes [2][M][Kp] x w_planes [2][N][Kp] -> C fp32 [M, ldc] and / or c_planes [2][M][N] (N % 4 == 0), either
  *                            NULL; group_max (optional) [M, gm_ld]: the maxima of the 64-column groups of the stored values -- what
- *                            dh_vocab_logits hands dh_beam_row_sample_groups on the 16-bit paths
- *   dh_conv2d_nhwc_f32xp     x_planes [2][N,H,W,Cin] (Cin % 32 == 0), w planes of [Cout][KS][KS][Cin] -> y fp32 and / or y_planes
- *                            [2][N,Ho,Wo,Cout]; residual fp32
- *   dh_maxpool3x3s2_nhwc_f32xp  MaxPool2d(3, 2, 1) of a channels-last fp32 tensor -> planes */
+ *                            dh_vocab_logits hands dh_beam_row_sample_groups on the 16-bit paths */
 int dh_split_act_f32x(const float* A, int lda, void* planes, int M, int K, int Kp, void* stream);
 int dh_linear_f32xp(const void* a_planes, const void* w_planes, int Kp, const float* bias, const float* scale, const float* shift,
                     const float* residual, int ldres, float* C, int ldc, void* c_planes, float* group_max, int gm_ld, int M, int N,
                     int relu, void* stream);
-int dh_conv2d_nhwc_f32xp(const void* x_planes, const void* w_planes, const float* scale, const float* shift, const float* residual,
-                         float* y, void* y_planes, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu,
-                         void* stream);
-int dh_maxpool3x3s2_nhwc_f32xp(const float* x, void* y_planes, int N, int H, int W, int C, void* stream);
 int dh_maxpool3x3s2_nhwc_f32(const float* x, float* y, int N, int H, int W, int C, void* stream);
 int dh_avgpool_nhwc_f32(const float* x, float* y, int N, int HW, int C, void* stream);
 

@@ -19,8 +19,9 @@ def main():
     out = {}
     imgs = synth_images(256, seed=0).to(dev)
     for wl in sys.argv[1:] or ["c2", "c3"]:
-        for split, wreg in ((0, 1), (1, 0), (1, 1)):     # exact fp32 | split operands on the tile kernels | + the register-stationary decode layers
-            with hip.option_scope(f32_split=split, decode_wreg=wreg), torch.no_grad():
+        # exact fp32 | split operands on the tile kernels | + the register-stationary decode layers | + the operands stored split (planes)
+        for split, wreg, planes in ((0, 1, 0), (1, 0, 0), (1, 1, 0), (1, 1, 1)):
+            with hip.option_scope(f32_split=split, decode_wreg=wreg, f32_planes=planes), torch.no_grad():
                 model = bench.build_model(wl, dev, "f32")[0]
                 bench.one_step(model, imgs, 0, 256, seed=0)
                 with hip.profile() as prof:
@@ -38,7 +39,7 @@ def main():
                     e[0] += v["calls"]; e[1] += v["ms"]
                 top = {k: [c, round(m, 2)] for k, (c, m) in sorted(by.items(), key=lambda kv: -kv[1][1])[:14]}
                 enc = bench.encoder_table(prof.summary(), "bf16" if split else "f32")[:12] if split else None
-                out[f"{wl}_split{split}" + ("" if wreg else "_tile_kernels")] = {"ms_per_step": round(ms, 2), "captions_per_s": round(256 / ms * 1e3, 1), "event_timed_ms": top, "encoder_rows": enc}
+                out[f"{wl}_split{split}" + ("" if wreg else "_tile_kernels") + ("_planes" if planes else "")] = {"ms_per_step": round(ms, 2), "captions_per_s": round(256 / ms * 1e3, 1), "event_timed_ms": top, "encoder_rows": enc}
                 del model
                 torch.cuda.empty_cache()
     print(json.dumps(out, indent=1))
