@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdeephumor_hip.so")
-SOURCES = ("abi.hip", "gemm.hip", "gemm_bf16.hip", "rowops.hip", "attention.hip", "lstm.hip", "lstm_fused.hip", "lstm_wreg.hip", "linear_wreg.hip", "decode_layers.hip", "conv1x1_wreg.hip", "vocab_wreg.hip", "beam.hip", "conv.hip", "stem.hip", "conv3x3.hip", "conv_s1.hip", "conv_s2.hip", "conv_s3.hip", "conv_s4.hip", "preproc.hip", "gemm_f32x.hip", "gemm_f32xp.hip", "linear_f32x_wreg.hip", "runtime.hip")
+SOURCES = ("abi.hip", "gemm.hip", "gemm_bf16.hip", "rowops.hip", "attention.hip", "lstm.hip", "lstm_fused.hip", "lstm_wreg.hip", "linear_wreg.hip", "decode_layers.hip", "conv1x1_wreg.hip", "vocab_wreg.hip", "beam.hip", "conv.hip", "stem.hip", "conv3x3.hip", "conv_s1.hip", "conv_s2.hip", "conv_s3.hip", "conv_s4.hip", "preproc.hip", "gemm_f32x.hip", "gemm_f32xp.hip", "conv1x1_f32x.hip", "linear_f32x_wreg.hip", "runtime.hip")
 ARCH = "gfx950"
 
 

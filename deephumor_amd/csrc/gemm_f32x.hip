@@ -19,6 +19,7 @@
 //   weights are the MFMA "A" operand: an accumulator quad is 4 consecutive output columns of one row -> 16-byte fp32 stores.
 #include "common.h"
 #include "prof.h"
+#include <cstdlib>
 
 namespace {
 
@@ -34,6 +35,7 @@ struct F32xParams {
     int H, Wd, Cin, Ho, Wo, KS, stride, pad;           // conv loader (NHWC input)
     int tiles_m, tiles_n, n_fast;                      // n_fast: consecutive workgroups walk the N tiles of one M tile (small weights)
     unsigned* range_flag;                              // sticky per-stream word: an activation outside the fp16 range was split (see below)
+    int diag;
 };
 
 // Range guard of the ACTIVATIONS: the weights' range is checked when a plan is built, but an activation with |x| >= 65504
@@ -88,11 +90,12 @@ __device__ __forceinline__ void epilogue(const F32xParams& p, const dh_f32x4 (&a
             for (int r = 0; r < 4; ++r) v[r] = fmaf(fmaf(cor[j][i][r], kLoInv, acc[j][i][r]) + bi[r], mu[r], ad[r]);
             float* dst = p.C + (size_t)m * p.ldc + n;
             if (vec && n + 3 < p.N) {
-                if (p.res) {
+                if (p.res && !(p.diag & 2)) {
                     const float4 rr = *reinterpret_cast<const float4*>(p.res + (size_t)m * p.ldres + n);
                     v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                 }
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                if (!(p.diag & 1) || v[0] == 12345.678f)
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? 2 : 3) void gemm_f32x_k
     constexpr int PLANE_A = BM * BK * 2, PLANE_W = BN * BK * 2;     // one fp16 plane of one operand
     constexpr int STAGE = 2 * PLANE_A + 2 * PLANE_W;     // A hi | A lo | W hi | W lo
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16, A_IT = BM / 32, W_PW = BN / 64;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE + 1024];     // + 1 KB: the sink of the residual prefetch below
 
     const int nblk = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
@@ -216,6 +219,20 @@ __global__ __launch_bounds__(256, BM * BN >= 128 * 128 ? 2 : 3) void gemm_f32x_k
         for (int i = 0; i < TM; ++i) { acc[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; cor[j][i] = dh_f32x4{0.f, 0.f, 0.f, 0.f}; }
 
     const int nslab = p.Kp / BK;
+    if (p.res && !(p.diag & 4) && (p.ldres & 3) == 0 && (p.N & 3) == 0 && (((uintptr_t)p.res) & 15) == 0) {
+        // The residual tile is read in the epilogue, after the reduction: measured (256 x 56 x 56 x 64 -> 256 with residual, 645 us) the
+        // reduction, the residual loads and the stores run one after the other -- 226 + 300 + 210 us -- because a CU holds two
+        // workgroups.  Touch the tile's cache lines NOW (one 16-byte LDS-DMA per 128-byte line into a sink nobody reads: no register,
+        // no wait of its own) so that the epilogue's loads find them in L2 / the Infinity Cache instead of in HBM.
+        constexpr int LPR = BN * 4 / 128;                // cache lines per residual row of the tile
+        constexpr int LINES = BM * LPR;
+#pragma unroll
+        for (int q = tid; q < LINES; q += 256) {
+            const int row = q / LPR, ln = q - row * LPR;
+            const int m = min(m0 + row, p.M - 1), n = min(n0 + ln * 32, p.N - 4);
+            dh_lds_dma16(p.res + (size_t)m * p.ldres + n, lds + 2 * STAGE);
+        }
+    }
     load_w(0, 0);
     load_a(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -448,6 +465,7 @@ int launch(const F32xParams& p0, int mode, hipStream_t s) {
     F32xParams p = p0;
     p.range_flag = range_flag_of(s);
     if (!p.range_flag) return DH_ERR_LAUNCH;
+    p.diag = getenv("DH_F32X_DIAG") ? atoi(getenv("DH_F32X_DIAG")) : 0;
     // weight planes of <= 4 MB stay in every XCD's L2: walk the N tiles of one M tile back to back (the activation tile comes
     // from HBM once instead of tiles_n times)
     p.n_fast = (double)p.N * p.Kp * 4.0 <= 4.0 * 1048576.0;

@@ -94,3 +94,33 @@ def attn_cross_decode_planes(q, kv, keymask, n_img, rows_per_img, s, d, n_heads,
     hip._launch("dh_attn_cross_decode", hip._ptr(q), q.stride(0), hip._ptr(kv), hip._ptr(keymask), hip._ptr(out), n_img, rows_per_img, s, d,
                 n_heads, float(scale), DH_F32_OUT_PLANES, hip._stream())
     return out
+
+
+def pack_conv1x1(w_planes):
+    """The planes of ``hip.split_f32x(w [Cout, Cin])`` in MFMA fragment order ``[2, Cin / 32, Cout / 16, 64, 8]`` for
+    ``conv1x1_stream``; None when the layer is not one the streaming kernel takes at any row count."""
+    hip._dev(w_planes)
+    two, n, kp = w_planes.shape
+    if two != 2 or not hip.load().dh_conv1x1_f32x_stream_supported(1 << 30, kp, n):
+        return None
+    out = torch.empty((2, kp // 32, n // 16, 64, 8), dtype=torch.float16, device=w_planes.device)
+    for i in range(2):
+        hip._launch("dh_pack_mfma_fragments", hip._ptr(w_planes[i]), hip._ptr(out[i]), n, kp, hip._stream())
+    return out
+
+
+def conv1x1_stream_supported(m, cin, cout):
+    return bool(hip.load().dh_conv1x1_f32x_stream_supported(m, cin, cout))
+
+
+def conv1x1_stream(x, packed, scale, shift, residual=None, relu=True):
+    """``dh_conv1x1_f32x_stream``: channels-last fp32 ``x [N, H, W, Cin]`` -> ``[N, H, W, Cout]``; bit-identical to
+    ``hip.conv2d_nhwc_f32x`` of the same 1 x 1 / stride 1 layer."""
+    hip._dev(x, packed, scale, shift, residual)
+    n, h, w, cin = x.shape
+    cout = packed.shape[2] * 16
+    assert x.dtype == torch.float32 and x.is_contiguous() and packed.shape[1] * 32 == cin and (residual is None or residual.is_contiguous())
+    y = torch.empty((n, h, w, cout), dtype=torch.float32, device=x.device)
+    hip._launch("dh_conv1x1_f32x_stream", hip._ptr(x), hip._ptr(packed), hip._ptr(scale), hip._ptr(shift), hip._ptr(residual), hip._ptr(y),
+                n * h * w, cin, cout, int(relu), hip._stream())
+    return y

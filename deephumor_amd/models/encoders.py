@@ -13,6 +13,7 @@ from torch import nn
 
 from .. import hip
 from ._f32x_guard import f32x_guarded
+from .. import f32xp
 
 RESNET50_STAGES = ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2))
 
@@ -145,8 +146,12 @@ class ImageEncoder(_Planned, nn.Module):
                     w4 = torch.zeros(tuple(wl.shape[:3]) + ((wl.shape[3] + 3) // 4 * 4,), dtype=w.dtype, device=w.device)
                     w4[..., :wl.shape[3]] = wl
                     wl = w4
-                return dict(w=w.contiguous(), wx=hip.split_f32x(wl.reshape(wl.shape[0], -1).contiguous()), ks=w.shape[2], cin=wl.shape[3],
-                            scale=s, shift=b, stride=c.stride[0], pad=c.padding[0], relu=relu, residual=residual)
+                ent = dict(w=w.contiguous(), wx=hip.split_f32x(wl.reshape(wl.shape[0], -1).contiguous()), ks=w.shape[2], cin=wl.shape[3],
+                           scale=s, shift=b, stride=c.stride[0], pad=c.padding[0], relu=relu, residual=residual)
+                if ent["ks"] == 1 and ent["stride"] == 1 and hip.option("f32_planes"):
+                    # the wide 1 x 1 layers (conv3, layer1's downsample) as a persistent streaming kernel (csrc/conv1x1_f32x.hip)
+                    ent["wxs"] = f32xp.pack_conv1x1(ent["wx"])
+                return ent
             if bf16 and stem:
                 # 3 input channels zero-padded to 8: the stem becomes a Cin=8 channels-last conv on the matrix cores
                 w8 = torch.zeros((w.shape[0], w.shape[2], w.shape[3], 8), dtype=w.dtype, device=w.device)
@@ -246,8 +251,11 @@ class ImageEncoder(_Planned, nn.Module):
 
     def _features_split(self, images, plan):
         """The trunk on channels-last fp32 tensors with split-operand MFMAs (plan["split"]) -> [N, H/32, W/32, 2048] fp32."""
-        cv = lambda x, c, residual=None: hip.conv2d_nhwc_f32x(x, c["wx"], c["ks"], c["scale"], c["shift"], residual=residual,
-                                                              relu=c["relu"], stride=c["stride"], pad=c["pad"])
+        def cv(x, c, residual=None):
+            if c.get("wxs") is not None and f32xp.conv1x1_stream_supported(x.shape[0] * x.shape[1] * x.shape[2], x.shape[3], c["wx"].shape[1]):
+                return f32xp.conv1x1_stream(x, c["wxs"], c["scale"], c["shift"], residual=residual, relu=c["relu"])
+            return hip.conv2d_nhwc_f32x(x, c["wx"], c["ks"], c["scale"], c["shift"], residual=residual, relu=c["relu"], stride=c["stride"],
+                                        pad=c["pad"])
         st = plan["stem"]
         x = hip.nchw_to_nhwc_f32(images.float().contiguous(), cp=st["cin"])
         x = hip.maxpool3x3s2_nhwc_f32(cv(x, st))

@@ -713,6 +713,14 @@ int dh_linear_f32x(const float* A, int lda, const void* w_planes, int Kp, const 
 int dh_conv2d_nhwc_f32x(const float* x, const void* w_planes, int Kp, const float* scale, const float* shift, const float* residual,
                         float* y, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu, void* stream);
 int dh_nchw_to_nhwc_f32(const float* x, float* y, int N, int C, int H, int W, int Cp, void* stream);
+/* The wide 1 x 1 / stride 1 layers of the fp32 trunk (Bottleneck.conv3 + bn3 + identity + relu, layer1's downsample; encoders.py:56) as a
+ * persistent streaming kernel (csrc/conv1x1_f32x.hip): weights stationary in registers (w_packed = both planes of dh_split_f32x(w [Cout,
+ * Cin]) through dh_pack_mfma_fragments), 32-row activation blocks double-buffered by LDS-DMA, the residual prefetched, the column
+ * groups of a row block on one XCD.  x [M, Cin], y / residual [M, Cout] channels-last fp32; bit-identical to dh_conv2d_nhwc_f32x.
+ * _supported: Cin = 64 / 128 / 256, Cout = 128 ... 1,024 in steps that divide an XCD's workgroups, M large enough for the grid. */
+int dh_conv1x1_f32x_stream_supported(int M, int Cin, int Cout);
+int dh_conv1x1_f32x_stream(const float* x, const void* w_packed, const float* scale, const float* shift, const float* residual,
+                           float* y, int M, int Cin, int Cout, int relu, void* stream);
 /* The same arithmetic on activations STORED split (csrc/gemm_f32xp.hip): a tensor whose only consumers are GEMM operands is kept as the
  * two fp16 planes [2][rows][K] its consumer would make of it (4 bytes per element, the same numbers), so both operands go global ->
  * LDS by DMA, three slabs deep, with no split work in the loop.  Bit-identical to dh_linear_f32x on the same values.

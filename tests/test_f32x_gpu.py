@@ -282,6 +282,33 @@ def test_planes_chain_equals_the_fp32_activation_chain(kind, images):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n,hw,cin,cout,res", [(44, 56, 64, 256, True), (43, 28, 128, 512, True), (45, 14, 256, 1024, True), (44, 56, 64, 256, False),
+                                               (90, 14, 256, 512, False), (90, 28, 128, 256, True)])
+def test_streaming_conv1x1_equals_conv_f32x(n, hw, cin, cout, res):
+    """dh_conv1x1_f32x_stream (round 6: the trunk's wide 1 x 1 layers as a persistent kernel -- weights in registers, activation blocks
+    double-buffered by LDS-DMA, residual prefetched) against dh_conv2d_nhwc_f32x: bit-identical, incl. a last row block that is not whole,
+    ReLU off, the activation range word; small batches are left to the tile kernel."""
+    from deephumor_amd import hip, f32xp
+    g = torch.Generator().manual_seed(hw + cin + cout)
+    x = torch.randn(n, hw, hw, cin, generator=g).cuda()
+    w = (torch.randn(cout, cin, generator=g) * cin ** -0.5).cuda()
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+    wp = hip.split_f32x(w)
+    pk = f32xp.pack_conv1x1(wp)
+    assert pk is not None and f32xp.conv1x1_stream_supported(n * hw * hw, cin, cout)
+    assert not f32xp.conv1x1_stream_supported(2 * hw * hw, cin, cout)
+    r = torch.randn(n, hw, hw, cout, generator=g).cuda() if res else None
+    hip.f32x_take_overflow()
+    for relu in (True, False):
+        want = hip.conv2d_nhwc_f32x(x, wp, 1, sc, sh, residual=r, relu=relu)
+        got = f32xp.conv1x1_stream(x, pk, sc, sh, residual=r, relu=relu)
+        assert torch.equal(got, want), (n, hw, cin, cout, relu, float((got - want).abs().max()))
+    assert hip.f32x_take_overflow() is False
+    x[n // 2, 1, 2, 3] = 7.0e4
+    f32xp.conv1x1_stream(x, pk, sc, sh, residual=r)
+    assert hip.f32x_take_overflow() is True
+
+
 def test_activation_range_guard_of_the_split_path():
     """only the WEIGHTS of the split-operand path were range-checked (at plan time); an activation with |x| >= 65504 splits
     into hi = inf and the GEMM silently returned inf / NaN.  Now such a launch sets the stream's sticky word
