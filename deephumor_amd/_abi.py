@@ -51,7 +51,7 @@ class LstmModel(_c.Structure):
 
 
 class LstmScratch(_c.Structure):
-    _fields_ = [(n, _P) for n in ("xcat0", "xcatl", "c_cur", "gates", "hout", "topp")]
+    _fields_ = [(n, _P) for n in ("xcat0", "xcatl", "c_cur", "gates", "hout", "topp", "xcat0p", "xcatlp")]
 
 
 # name -> argtypes, mirrors include/deephumor_hip.h line by line
@@ -109,6 +109,8 @@ SIGNATURES = {
     "dh_attn_masked": [_P, _I, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _F, _I, _P],
     "dh_lstm_prepare": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     "dh_lstm_cell": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dh_lstm_prepare_f32x": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dh_lstm_cell_f32x": [_P, _P, _P, _P, _P, _I, _P, _c.c_longlong, _I, _I, _I, _I, _P],
     "dh_embed_prefill": [_P, _P, _P, _P, _I, _P, _I, _I, _I, _F, _I, _P],
     "dh_attn_self_prefill": [_P, _P, _I, _P, _I, _I, _I, _I, _F, _I, _I, _P],
     "dh_attn_cross_prefill": [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P],

@@ -308,11 +308,40 @@ extern "C" int dh_lstm_decode_step(const dh_lstm_model_t* m, const dh_lstm_scrat
         }
         return DH_OK;
     }
+    void* top = h_out ? h_out : sc->hout;
+    const int top_ld = h_out ? ld_out : Hh;
+    // fp32 on the split-operand path with the GEMM operands stored split by the row kernels (options "f32_split" + "f32_planes"): the
+    // gate products run on dh_linear_f32xp_wreg (no split pass), the classifier on dh_linear_f32xp with group maxima
+    bool planes = dt == DH_F32 && dh_opt(DH_OPT_F32_SPLIT) && dh_opt(DH_OPT_F32_PLANES) && dh_opt(DH_OPT_DECODE_WREG) && sc->xcat0p && sc->topp &&
+                  (nl == 1 || sc->xcatlp) && m->cls_w_x && (Hh % 32) == 0 && (E % 32) == 0;
+    for (int l = 0; l < nl && planes; ++l)
+        planes = m->layers[l].w_xp && dh_linear_f32x_wreg_supported(rows, 4 * Hh, l == 0 ? E + Hh : 2 * Hh);
+    if (planes) {
+        DH_TRY(dh_lstm_prepare_f32x((const float*)m->emb, (const float*)img_emb, tokens, tok_ld, tok_pos, hparent, started ? (const float*)m->h : nullptr,
+                                    started ? m->c : nullptr, (float*)sc->xcat0, (float*)sc->xcatl, sc->c_cur, sc->xcat0p, sc->xcatlp, rows,
+                                    rows_per_img, row_mult, rows_total, nl, E, Hh, stream));
+        for (int l = 0; l < nl; ++l) {
+            const int k = l == 0 ? E + Hh : 2 * Hh;
+            const uint16_t* ap = l == 0 ? (const uint16_t*)sc->xcat0p : (const uint16_t*)sc->xcatlp + (size_t)(l - 1) * 2 * rows * 2 * Hh;
+            dh_prof_set_tag("gates");
+            DH_TRY(dh_linear_f32xp_wreg(ap, m->layers[l].w_xp, m->layers[l].b, nullptr, 0, sc->gates, 4 * Hh, nullptr, rows, 4 * Hh, k, 0, stream));
+            const bool last = l + 1 == nl;
+            float* dst = last ? (float*)top : (float*)sc->xcatl + (size_t)l * rows * 2 * Hh;
+            uint16_t* dp = last ? (uint16_t*)sc->topp : (uint16_t*)sc->xcatlp + (size_t)l * 2 * rows * 2 * Hh;
+            DH_TRY(dh_lstm_cell_f32x(sc->gates, sc->c_cur + (size_t)l * rows * Hh, (float*)m->h + (size_t)l * rows_total * Hh,
+                                     m->c + (size_t)l * rows_total * Hh, dst, last ? top_ld : 2 * Hh, dp,
+                                     (long long)rows * (last ? Hh : 2 * Hh), last ? Hh : 2 * Hh, rows, row_mult, Hh, stream));
+        }
+        if (logits) {
+            dh_prof_set_tag("vocab");
+            DH_TRY(dh_linear_f32xp(sc->topp, m->cls_w_x, Hh, m->cls_b, nullptr, nullptr, nullptr, 0, logits, ldl, nullptr, group_max, gm_ld, rows,
+                                   m->V, 0, stream));
+        }
+        return DH_OK;
+    }
     DH_TRY(dh_lstm_prepare(m->emb, img_emb, tokens, tok_ld, tok_pos, hparent, started ? m->h : nullptr,
                            started ? m->c : nullptr, sc->xcat0, sc->xcatl, sc->c_cur, rows, rows_per_img, row_mult,
                            rows_total, nl, E, Hh, dt, stream));
-    void* top = h_out ? h_out : sc->hout;
-    const int top_ld = h_out ? ld_out : Hh;
     const int gate_dt = dt == DH_F32 ? DH_F32 : (dt == DH_F16 ? DH_F16_OUT_F32 : DH_BF16_OUT_F32);
     for (int l = 0; l < nl; ++l) {
         const void* a = l == 0 ? sc->xcat0 : (const char*)sc->xcatl + (size_t)(l - 1) * rows * 2 * Hh * esz;

@@ -122,6 +122,8 @@ class LSTMDecoder(_Planned, nn.Module):
                     hout=torch.empty((rows, hh), device=dev, dtype=dt))
                 if self.planes:                        # fp32, split operands: the top layer's state as fp16 planes for the classifier
                     bufs["topp"] = torch.empty((2, rows, hh), device=dev, dtype=torch.float16)
+                    bufs["xcat0p"] = torch.empty((2, rows, e + hh), device=dev, dtype=torch.float16)       # ... and of the gate GEMMs' operands
+                    bufs["xcatlp"] = torch.empty((max(nl - 1, 1), 2, rows, 2 * hh), device=dev, dtype=torch.float16)
                 c = hip.LstmScratch()
                 for k, v in bufs.items():
                     setattr(c, k, v.data_ptr())

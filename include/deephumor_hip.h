@@ -412,6 +412,15 @@ int dh_lstm_prepare(const void* emb, const void* img_emb, const int32_t* tokens,
  * input slot or the classifier input). */
 int dh_lstm_cell(const float* gates, const float* c_cur, void* h_new, float* c_new, void* h_out,
                  int ld_out, int rows, int row_mult, int Hh, int dtype, void* stream);
+/* The same two row kernels for fp32 rows on the split-operand path with the gate GEMM's operand ALSO stored as fp16 planes (hi, lo * 2^11;
+ * options "f32_split" + "f32_planes"): xcat0_planes [2][rows][E + Hh], xcatl_planes [n_layers - 1][2][rows][2 Hh]; dh_lstm_cell_f32x
+ * stores the new hidden row into h_planes (hi at h_planes, lo `plane` elements further, row stride ld_planes). */
+int dh_lstm_prepare_f32x(const float* emb, const float* img_emb, const int32_t* tokens, int tok_ld, int tok_pos,
+                         const int32_t* hparent, const float* h_prev, const float* c_prev, float* xcat0, float* xcatl, float* c_cur,
+                         void* xcat0_planes, void* xcatl_planes, int rows, int rows_per_img, int row_mult, int rows_total,
+                         int n_layers, int E, int Hh, void* stream);
+int dh_lstm_cell_f32x(const float* gates, const float* c_cur, float* h_new, float* c_new, float* h_out, int ld_out,
+                      void* h_planes, long long plane, int ld_planes, int rows, int row_mult, int Hh, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Beam-search step (deephumor/models/beam.py:32-108; rnn_models.py:87-103,111-137;
@@ -637,6 +646,9 @@ typedef struct dh_lstm_scratch {
     void *xcat0, *xcatl; float *c_cur, *gates; void* hout;
     void* topp;                             /* optional (DH_F32, option "f32_split"): fp16 planes [2][rows][Hh] of the top layer's state: the
                                                classifier then runs on dh_linear_f32xp and fills group_max */
+    void *xcat0p, *xcatlp;                  /* optional, with topp: planes [2][rows][E + Hh] and [n_layers - 1][2][rows][2 Hh] of the gate
+                                               GEMMs' operands (option "f32_planes": dh_lstm_prepare_f32x / dh_lstm_cell_f32x write them,
+                                               dh_linear_f32xp_wreg reads them) */
 } dh_lstm_scratch_t;
 
 /* One LSTM layer time step in one launch (bf16): gates = [x | h_prev[parent]] * w_il^T + b_il on the matrix cores,
