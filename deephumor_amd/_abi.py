@@ -157,6 +157,8 @@ SIGNATURES = {
     "dh_conv2d_nhwc_f32x": [_P, _P, _I, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_nchw_to_nhwc_f32": [_P, _P, _I, _I, _I, _I, _I, _P],
     "dh_split_act_f32x": [_P, _I, _P, _I, _I, _I, _P],
+    "dh_conv2d_nhwc_f32x_planes_out": [_P, _P, _I, _P, _P, _P] + [_I] * 9 + [_P],
+    "dh_conv2d_nhwc_f32xp": [_P, _P, _P, _P, _P, _P, _P] + [_I] * 9 + [_P],
     "dh_conv1x1_f32x_stream_supported": [_I, _I, _I],
     "dh_conv1x1_f32x_stream": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dh_linear_f32xp": [_P, _P, _I, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P],

@@ -31,6 +31,7 @@ struct F32xParams {
     const float* bias; const float* scale; const float* shift;
     const float* res; int ldres;
     float* C; int ldc;
+    uint16_t* Cp; size_t c_plane;                      // optional: the result as fp16 planes [2][M][N] INSTEAD of C (its consumer is a GEMM operand)
     int M, N, K, relu;
     int H, Wd, Cin, Ho, Wo, KS, stride, pad;           // conv loader (NHWC input)
     int tiles_m, tiles_n, n_fast;                      // n_fast: consecutive workgroups walk the N tiles of one M tile (small weights)
@@ -69,7 +70,7 @@ __device__ __forceinline__ int swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue(const F32xParams& p, const dh_f32x4 (&acc)[TN][TM], const dh_f32x4 (&cor)[TN][TM], int mw, int nw, int l15,
                                          int lq) {
-    const bool vec = (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0));
+    const bool vec = p.Cp || ((p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0 && (!p.res || ((p.ldres & 3) == 0 && (((uintptr_t)p.res) & 15) == 0)));
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = nw + 16 * j + 4 * lq;
@@ -95,7 +96,13 @@ __device__ __forceinline__ void epilogue(const F32xParams& p, const dh_f32x4 (&a
                     v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
                 }
                 if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                if (!(p.diag & 1) || v[0] == 12345.678f)
+                if (p.Cp) {                              // (host: N % 4 == 0, no residual stride games: the planes are dense [M][N])
+                    uint2 hi, lo;
+                    split2(v[0], v[1], hi.x, lo.x); split2(v[2], v[3], hi.y, lo.y);
+                    if (fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))) >= kF16Max) atomicOr(p.range_flag, 1u);
+                    *reinterpret_cast<uint2*>(p.Cp + (size_t)m * p.N + n) = hi;
+                    *reinterpret_cast<uint2*>(p.Cp + p.c_plane + (size_t)m * p.N + n) = lo;
+                } else if (!(p.diag & 1) || v[0] == 12345.678f)
                 *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             } else {
 #pragma unroll
@@ -535,6 +542,29 @@ extern "C" int dh_conv2d_nhwc_f32x(const float* x, const void* w_planes, int Kp,
     dh_prof_set_dims(p.M, Cout, K);
     DhProfScope prof("dh_conv2d_nhwc_f32x", 2.0 * p.M * Cout * K,
                      4.0 * ((double)N * H * W * Cin + (double)Cout * K + (double)p.M * Cout * (residual ? 2 : 1)), stream);
+    return launch(p, (Cin % 32) == 0 && Kp == K ? 1 : 2, (hipStream_t)stream);
+}
+
+// dh_conv2d_nhwc_f32x with the result stored as fp16 planes [2][N, Ho, Wo, Cout] (hi, lo * 2^11) instead of fp32: Bottleneck.conv1 of
+// stages 2 - 4, whose only consumer is conv2 on dh_conv2d_nhwc_f32xp.  Cout % 4 == 0, no residual.
+extern "C" int dh_conv2d_nhwc_f32x_planes_out(const float* x, const void* w_planes, int Kp, const float* scale, const float* shift,
+                                              void* y_planes, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu,
+                                              void* stream) {
+    DH_REQUIRE(x && w_planes && y_planes && scale && shift && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KS > 0 && stride > 0 && pad >= 0);
+    const int K = KS * KS * Cin;
+    DH_REQUIRE((Cin % 4) == 0 && (Cout % 4) == 0 && Kp >= K && (Kp % 32) == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)w_planes % 16) == 0 &&
+               ((uintptr_t)y_planes % 16) == 0);
+    const int Ho = (H + 2 * pad - KS) / stride + 1, Wo = (W + 2 * pad - KS) / stride + 1;
+    DH_REQUIRE(Ho > 0 && Wo > 0 && (long long)N * Ho * Wo < (1ll << 31));
+    F32xParams p{};
+    p.A = x; p.Wp = (const uint16_t*)w_planes; p.Kp = Kp; p.plane = (size_t)Cout * Kp;
+    p.scale = scale; p.shift = shift; p.ldc = Cout;
+    p.M = N * Ho * Wo; p.N = Cout; p.K = K; p.relu = relu;
+    p.Cp = (uint16_t*)y_planes; p.c_plane = (size_t)p.M * Cout;
+    p.H = H; p.Wd = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KS = KS; p.stride = stride; p.pad = pad;
+    dh_prof_set_tag(KS == 1 ? "1x1" : KS == 3 ? "3x3" : "7x7");
+    dh_prof_set_dims(p.M, Cout, K);
+    DhProfScope prof("dh_conv2d_nhwc_f32x", 2.0 * p.M * Cout * K, 4.0 * ((double)N * H * W * Cin + (double)Cout * K + (double)p.M * Cout), stream);
     return launch(p, (Cin % 32) == 0 && Kp == K ? 1 : 2, (hipStream_t)stream);
 }
 

@@ -17,12 +17,12 @@
 //   of maxima + the candidate groups instead of 187 MB of logits, 20 instead of 61 us per position).
 // Measured (tools/f32xp_kbench.py, profiles/r6/f32xp_kbench_*.txt; 1,280 x 36,541 x 512): gemm_f32x_kernel 237 - 257 us, this kernel
 // 187 us with all waves in one phase, 176 us with the two groups = 818 TF of MFMA work (0.33 of the dense fp16 peak; the 16-bit
-// classifier's HBM-bound 61 us are out of reach at three MFMAs per product).  Also measured and NOT kept: the same kernel as the
-// encoder's convolution (activations stored split from layer to layer; bit-identical): 3 x 3 layers and 1 x 1 layers with Cin >= 1,024
-// 10 - 27 % faster, but the layers that write wide outputs (conv3 + residual: 1.5 - 1.6 x slower with one 8-wave workgroup per CU and
-// nothing to overlap its epilogue with) lose more than the others gain -- 4.35 against 3.65 ms over the 14 shapes of the trunk; 128 x 64
-// wave tiles at one wave per SIMD (fewer LDS bytes per MFMA): 20 % slower; the bank-conflict-free fragment swizzle: within noise
-// (kept).  The encoder stays on dh_conv2d_nhwc_f32x.
+// classifier's HBM-bound 61 us are out of reach at three MFMAs per product).  The same kernel with an implicit-GEMM loader (CONV) is the
+// trunk's 3 x 3 convolution of stages 2 - 4: conv1 writes its output as planes (dh_conv2d_nhwc_f32x_planes_out), this kernel reads them
+// -- 13 - 27 % faster than the tile kernel on those layers (l3 conv2 174 against 231 us, l4 conv2 160 against 222 us).  NOT used where
+// it loses: layers that write wide outputs (conv3 + residual: 1.5 x slower with one 8-wave workgroup per CU and nothing to overlap
+// its epilogue with -- those layers are csrc/conv1x1_f32x.hip's) and stage 1 (Cout = 64).  Also measured: 128 x 64 wave tiles at
+// one wave per SIMD (fewer LDS bytes per MFMA): 20 % slower; the bank-conflict-free fragment swizzle: within noise (kept).
 #include "common.h"
 #include "prof.h"
 
@@ -41,9 +41,12 @@ struct XpParams {
     uint16_t* Cp; size_t c_plane; int ldcp;            // planes output (optional)
     float* gmax; int gmax_ld;                          // per-row maxima of 64-column groups (optional)
     int M, N, relu;
+    int H, Wd, Cin, Ho, Wo, KS, stride, pad;           // convolution loader (CONV = 1)
     int tiles_m, tiles_n, n_fast;
     unsigned* range_flag;
 };
+
+__device__ uint4 g_xp_zero[1];                         // source of filter taps outside the image
 
 __device__ __forceinline__ int swz(int r, int c) { return c ^ ((0 - (r >> 2)) & 3); }
 
@@ -61,7 +64,8 @@ __device__ __forceinline__ void split4(const float (&v)[4], uint2& hi, uint2& lo
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
-template <int WMW, int WNW, int TM, int NS, bool PP>
+// CONV 0: dense A planes; 1: channels-last convolution, Cin % 32 == 0 (a slab lies inside one filter tap: the tap is wave-uniform)
+template <int CONV, int WMW, int WNW, int TM, int NS, bool PP>
 __global__ __launch_bounds__(64 * WMW * WNW, 1) void gemm_f32xp_kernel(XpParams p) {
     constexpr int NW = WMW * WNW, WTM = 16 * TM, BM = WTM * WMW, BN = 64 * WNW;
     constexpr int PLANE_A = BM * 64, PLANE_W = BN * 64, STAGE = 2 * PLANE_A + 2 * PLANE_W;
@@ -86,11 +90,20 @@ __global__ __launch_bounds__(64 * WMW * WNW, 1) void gemm_f32xp_kernel(XpParams 
 
     // ---- loaders: one wave instruction = 16 rows x 64 B of one plane -----------------------------------------------------------------
     const uint16_t* a_src[RPA];
+    int a_ih0[RPA], a_iw0[RPA];
 #pragma unroll
     for (int i = 0; i < RPA; ++i) {
         const int row = (wave * RPA + i) * 16 + (lane >> 2);
         const int m = min(m0 + row, p.M - 1);           // rows past M repeat the last one (their outputs are not stored)
-        a_src[i] = p.Ap + (size_t)m * p.lda + swz(row, lane & 3) * 8;
+        const int ch = swz(row, lane & 3) * 8;
+        if (CONV == 0) {
+            a_src[i] = p.Ap + (size_t)m * p.lda + ch;
+            a_ih0[i] = a_iw0[i] = 0;
+        } else {
+            const int hw = p.Ho * p.Wo, n = m / hw, r = m - n * hw, oh = r / p.Wo, ow = r - oh * p.Wo;
+            a_ih0[i] = oh * p.stride - p.pad; a_iw0[i] = ow * p.stride - p.pad;
+            a_src[i] = p.Ap + ((ptrdiff_t)((size_t)n * p.H + a_ih0[i]) * p.Wd + a_iw0[i]) * p.Cin + ch;
+        }
     }
     const uint16_t* w_src[RPW];
 #pragma unroll
@@ -99,17 +112,30 @@ __global__ __launch_bounds__(64 * WMW * WNW, 1) void gemm_f32xp_kernel(XpParams 
         const int n = min(n0 + row, p.N - 1);
         w_src[i] = p.Wp + (size_t)n * p.Kp + swz(row, lane & 3) * 8;
     }
+    int st_kh = 0, st_kw = 0, st_ci = 0;                // convolution: tap / channel offset of the NEXT slab to issue
     auto issue = [&](int buf, int k0) {
         unsigned char* st = lds + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < RPA; ++i) {
-            dh_lds_dma16(a_src[i] + k0, st + (wave * RPA + i) * 1024);
-            dh_lds_dma16(a_src[i] + p.a_plane + k0, st + PLANE_A + (wave * RPA + i) * 1024);
+            const uint16_t* src;
+            bool ok = true;
+            if (CONV == 0) src = a_src[i] + k0;
+            else {
+                ok = (unsigned)(a_ih0[i] + st_kh) < (unsigned)p.H && (unsigned)(a_iw0[i] + st_kw) < (unsigned)p.Wd;
+                src = a_src[i] + ((ptrdiff_t)st_kh * p.Wd + st_kw) * p.Cin + st_ci;
+            }
+            const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_xp_zero);
+            dh_lds_dma16(ok ? src : zero, st + (wave * RPA + i) * 1024);
+            dh_lds_dma16(ok ? src + p.a_plane : zero, st + PLANE_A + (wave * RPA + i) * 1024);
         }
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
             dh_lds_dma16(w_src[i] + k0, st + 2 * PLANE_A + (wave * RPW + i) * 1024);
             dh_lds_dma16(w_src[i] + p.w_plane + k0, st + 2 * PLANE_A + PLANE_W + (wave * RPW + i) * 1024);
+        }
+        if (CONV == 1) {
+            st_ci += 32;
+            if (st_ci == p.Cin) { st_ci = 0; if (++st_kw == p.KS) { st_kw = 0; ++st_kh; } }
         }
     };
 
@@ -295,17 +321,19 @@ __global__ __launch_bounds__(256) void split_act_kernel(const float* __restrict_
     if (amax >= kF16Max) atomicOr(range_flag, 1u);
 }
 
-int launch(XpParams& p, hipStream_t s) {
+int launch(XpParams& p, int conv, hipStream_t s) {
     p.range_flag = dh_f32x_range_flag_of(s);
     if (!p.range_flag) return DH_ERR_LAUNCH;
     p.n_fast = (double)p.N * p.Kp * 4.0 <= 4.0 * 1048576.0;
     p.tiles_m = dh_cdiv(p.M, 256);
-    if (p.N <= 64 && !p.gmax) {              // (group maxima: whole 128-column tiles, so that every group of the caller's table is written)
+    if (p.N <= 64 && !p.gmax && !conv) {     // (group maxima: whole 128-column tiles, so that every group of the caller's table is written)
         p.tiles_n = 1;
-        hipLaunchKernelGGL((gemm_f32xp_kernel<4, 1, 4, 3, false>), dim3((unsigned)p.tiles_m), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_f32xp_kernel<0, 4, 1, 4, 3, false>), dim3((unsigned)p.tiles_m), dim3(256), 0, s, p);
     } else {
         p.tiles_n = dh_cdiv(p.N, 128);
-        hipLaunchKernelGGL((gemm_f32xp_kernel<4, 2, 4, 3, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+        const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+        if (conv) hipLaunchKernelGGL((gemm_f32xp_kernel<1, 4, 2, 4, 3, true>), grid, dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((gemm_f32xp_kernel<0, 4, 2, 4, 3, true>), grid, dim3(512), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? DH_OK : DH_ERR_LAUNCH;
 }
@@ -342,5 +370,33 @@ extern "C" int dh_linear_f32xp(const void* a_planes, const void* w_planes, int K
     p.M = M; p.N = N; p.relu = relu;
     dh_prof_set_dims(M, N, Kp);
     DhProfScope prof("dh_linear_f32xp", 2.0 * M * N * Kp, 4.0 * ((double)M * Kp + (double)N * Kp + (double)M * N), stream);
-    return launch(p, (hipStream_t)stream);
+    return launch(p, 0, (hipStream_t)stream);
+}
+
+// Channels-last convolution + BatchNorm affine (+ fp32 residual) (+ ReLU) of an activation stored as planes [2][N, H, W, Cin]
+// (Cin % 32 == 0, Cout >= 128) -> fp32 [N, Ho, Wo, Cout] and / or planes; the arithmetic of dh_conv2d_nhwc_f32x (bit-identical).  The
+// trunk's 3 x 3 layers of stages 2 - 4 (Bottleneck.conv2, encoders.py:56): their input comes from conv1 as planes
+// (dh_conv2d_nhwc_f32x_planes_out), 13 - 27 % faster than the fp32-activation tile kernel (profiles/r6/f32xp_kbench_two_phase.txt).
+extern "C" int dh_conv2d_nhwc_f32xp(const void* x_planes, const void* w_planes, const float* scale, const float* shift, const float* residual,
+                                    float* y, void* y_planes, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu,
+                                    void* stream) {
+    DH_REQUIRE(x_planes && w_planes && (y || y_planes) && scale && shift && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && KS > 0 &&
+               stride > 0 && pad >= 0);
+    DH_REQUIRE((Cin % 32) == 0 && (Cout % 4) == 0 && ((uintptr_t)x_planes % 16) == 0 && ((uintptr_t)w_planes % 16) == 0);
+    DH_REQUIRE((!y || ((uintptr_t)y % 16) == 0) && (!y_planes || ((uintptr_t)y_planes % 16) == 0) && (!residual || ((uintptr_t)residual % 16) == 0));
+    const int Ho = (H + 2 * pad - KS) / stride + 1, Wo = (W + 2 * pad - KS) / stride + 1;
+    DH_REQUIRE(Ho > 0 && Wo > 0 && (long long)N * Ho * Wo < (1ll << 31));
+    XpParams p{};
+    p.Ap = (const uint16_t*)x_planes; p.a_plane = (size_t)N * H * W * Cin; p.lda = Cin;
+    p.Wp = (const uint16_t*)w_planes; p.Kp = KS * KS * Cin; p.w_plane = (size_t)Cout * p.Kp;
+    p.scale = scale; p.shift = shift; p.res = residual; p.ldres = Cout; p.C = y; p.ldc = Cout;
+    p.M = N * Ho * Wo; p.N = Cout; p.relu = relu;
+    p.Cp = (uint16_t*)y_planes; p.c_plane = (size_t)p.M * Cout; p.ldcp = Cout;
+    p.H = H; p.Wd = W; p.Cin = Cin; p.Ho = Ho; p.Wo = Wo; p.KS = KS; p.stride = stride; p.pad = pad;
+    dh_prof_set_tag(KS == 1 ? "1x1" : KS == 3 ? "3x3" : "7x7");
+    dh_prof_set_dims(p.M, Cout, p.Kp);
+    DhProfScope prof("dh_conv2d_nhwc_f32x", 2.0 * p.M * Cout * p.Kp,
+                     4.0 * ((double)N * H * W * Cin + (double)Cout * p.Kp + (double)p.M * Cout * ((residual ? 1 : 0) + (y ? 1 : 0) + (y_planes ? 1 : 0))),
+                     stream);
+    return launch(p, 1, (hipStream_t)stream);
 }

@@ -124,3 +124,31 @@ def conv1x1_stream(x, packed, scale, shift, residual=None, relu=True):
     hip._launch("dh_conv1x1_f32x_stream", hip._ptr(x), hip._ptr(packed), hip._ptr(scale), hip._ptr(shift), hip._ptr(residual), hip._ptr(y),
                 n * h * w, cin, cout, int(relu), hip._stream())
     return y
+
+
+def conv2d_nhwc_planes_out(x, w_planes, ks, scale, shift, relu=True, stride=1, pad=0):
+    """``dh_conv2d_nhwc_f32x_planes_out``: ``hip.conv2d_nhwc_f32x`` (fp32 ``x [N, H, W, Cin]``) with the result as planes
+    ``[2, N, Ho, Wo, Cout]``."""
+    hip._dev(x, w_planes, scale, shift)
+    n, h, w, cin = x.shape
+    cout, kp = w_planes.shape[1], w_planes.shape[2]
+    assert x.dtype == torch.float32 and x.is_contiguous() and kp == (ks * ks * cin + 31) // 32 * 32
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    yp = torch.empty((2, n, ho, wo, cout), dtype=torch.float16, device=x.device)
+    hip._launch("dh_conv2d_nhwc_f32x_planes_out", hip._ptr(x), hip._ptr(w_planes), kp, hip._ptr(scale), hip._ptr(shift), hip._ptr(yp), n, h, w,
+                cin, cout, ks, stride, pad, int(relu), hip._stream())
+    return yp
+
+
+def conv2d_nhwc(x_planes, w_planes, ks, scale, shift, residual=None, relu=True, stride=1, pad=0, want="f32"):
+    """``dh_conv2d_nhwc_f32xp``: ``x_planes [2, N, H, W, Cin]`` -> ``want`` = "f32" (fp32 ``[N, Ho, Wo, Cout]``), "planes", or "both"."""
+    hip._dev(x_planes, w_planes, scale, shift, residual)
+    two, n, h, w, cin = x_planes.shape
+    cout, kp = w_planes.shape[1], w_planes.shape[2]
+    assert two == 2 and x_planes.is_contiguous() and kp == ks * ks * cin and cin % 32 == 0
+    ho, wo = (h + 2 * pad - ks) // stride + 1, (w + 2 * pad - ks) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float32, device=x_planes.device) if want != "planes" else None
+    yp = torch.empty((2, n, ho, wo, cout), dtype=torch.float16, device=x_planes.device) if want != "f32" else None
+    hip._launch("dh_conv2d_nhwc_f32xp", hip._ptr(x_planes), hip._ptr(w_planes), hip._ptr(scale), hip._ptr(shift), hip._ptr(residual),
+                hip._ptr(y), hip._ptr(yp), n, h, w, cin, cout, ks, stride, pad, int(relu), hip._stream())
+    return (y, yp) if want == "both" else yp if want == "planes" else y

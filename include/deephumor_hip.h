@@ -741,6 +741,14 @@ int dh_conv1x1_f32x_stream(const float* x, const void* w_packed, const float* sc
  *                            NULL; group_max (optional) [M, gm_ld]: the maxima of the 64-column groups of the stored values -- what
  *                            dh_vocab_logits hands dh_beam_row_sample_groups on the 16-bit paths */
 int dh_split_act_f32x(const float* A, int lda, void* planes, int M, int K, int Kp, void* stream);
+/* The trunk's 3 x 3 layers of stages 2 - 4 on planes: dh_conv2d_nhwc_f32x_planes_out = dh_conv2d_nhwc_f32x (Bottleneck.conv1) with the result
+ * stored as planes [2][N,Ho,Wo,Cout] instead of fp32; dh_conv2d_nhwc_f32xp = the convolution (Bottleneck.conv2) of x_planes [2][N,H,W,Cin]
+ * (Cin % 32 == 0) through the planes kernel -> y fp32 and / or y_planes.  Bit-identical to dh_conv2d_nhwc_f32x on the same values. */
+int dh_conv2d_nhwc_f32x_planes_out(const float* x, const void* w_planes, int Kp, const float* scale, const float* shift, void* y_planes,
+                                   int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu, void* stream);
+int dh_conv2d_nhwc_f32xp(const void* x_planes, const void* w_planes, const float* scale, const float* shift, const float* residual,
+                         float* y, void* y_planes, int N, int H, int W, int Cin, int Cout, int KS, int stride, int pad, int relu,
+                         void* stream);
 int dh_linear_f32xp(const void* a_planes, const void* w_planes, int Kp, const float* bias, const float* scale, const float* shift,
                     const float* residual, int ldres, float* C, int ldc, void* c_planes, float* group_max, int gm_ld, int M, int N,
                     int relu, void* stream);

@@ -208,6 +208,31 @@ def test_planes_linear_equals_linear_f32x(m, v, k):
         assert torch.equal(o2, want2) and torch.equal(p2, f32xp.split_act(want2)[:, :, :v])
 
 
+@pytest.mark.parametrize("n,hw,cin,cout,ks,stride,pad,res", [(2, 14, 128, 128, 3, 1, 1, False), (2, 15, 128, 128, 3, 2, 1, False),
+                                                           (3, 9, 256, 256, 3, 1, 1, False), (2, 7, 128, 512, 1, 1, 0, True),
+                                                           (2, 16, 96, 192, 1, 2, 0, False), (70, 7, 512, 512, 3, 1, 1, True)])
+def test_planes_conv_equals_conv_f32x(n, hw, cin, cout, ks, stride, pad, res):
+    """dh_conv2d_nhwc_f32xp (the trunk's 3 x 3 layers of stages 2 - 4 on an input stored as planes) against dh_conv2d_nhwc_f32x: fp32 and planes
+    outputs, residual, stride 2, zero padding at the borders; and dh_conv2d_nhwc_f32x_planes_out (conv1 in front of it) against the split of
+    the fp32 form's output."""
+    from deephumor_amd import hip, f32xp
+    g = torch.Generator().manual_seed(hw * 7 + cin + cout)
+    x = torch.randn(n, hw, hw, cin, generator=g).cuda()
+    w = (torch.randn(cout, ks * ks * cin, generator=g) * (ks * ks * cin) ** -0.5).cuda()
+    sc, sh = (torch.rand(cout, generator=g) + 0.5).cuda(), (torch.randn(cout, generator=g) * 0.1).cuda()
+    wp = hip.split_f32x(w)
+    xp = f32xp.split_act(x.view(-1, cin)).view(2, n, hw, hw, cin)
+    ho = (hw + 2 * pad - ks) // stride + 1
+    r = torch.randn(n, ho, ho, cout, generator=g).cuda() if res else None
+    want = hip.conv2d_nhwc_f32x(x, wp, ks, sc, sh, residual=r, stride=stride, pad=pad)
+    y, yp = f32xp.conv2d_nhwc(xp, wp, ks, sc, sh, residual=r, stride=stride, pad=pad, want="both")
+    assert torch.equal(y, want)
+    assert torch.equal(yp, f32xp.split_act(want.view(-1, cout)).view_as(yp))
+    if not res:
+        assert torch.equal(f32xp.conv2d_nhwc_planes_out(x, wp, ks, sc, sh, stride=stride, pad=pad), yp)
+    assert hip.f32x_take_overflow() is False
+
+
 @pytest.mark.parametrize("n,k", [(512, 512), (1536, 512), (2048, 512), (512, 2048), (2048, 768), (2048, 1024)])
 @pytest.mark.parametrize("m", [37, 160, 1280])
 def test_planes_wreg_equals_linear_f32x(m, n, k):
