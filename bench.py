@@ -543,6 +543,19 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
             torch.cuda.synchronize()
             tp = time.perf_counter() - t0
             res["pipelined_device_resident"] = {"value": n_local * nb / tp, "unit": "captions/s", "ms_per_step": tp / nb * 1e3, "batches": nb}
+    if rank == 0 and with_cpu and dtype != "f32":
+        # the other 16-bit storage type, timed straight after the main legs (the same schedule as `value`; behind the fp32 legs below
+        # the same measurement read 24 - 37 k captions/s from run to run -- whatever state those long legs leave the part in)
+        other = "f16" if dtype == "bf16" else "bf16"
+        m16 = build_model(workload, dev, other)[0]
+        with torch.no_grad():
+            for w in range(3):
+                one_step(m16, images, 0, n_total, seed=w)
+            t16, _, _ = timed_steps(m16, images, 0, n_local, n_total, 10, barrier)
+        res[f"{other}_path"] = {"value": n_total * 10 / t16, "unit": "captions/s", "ms_per_step": t16 / 10 * 1e3, "steps": 10,
+                                "schedule": "sequential (as `value`)"}
+        del m16
+        torch.cuda.empty_cache()
     if rank == 0 and with_cpu:
         # the parity gate is the fp32 path: bit-exact greedy ids vs the CPU reference path -- timed here too
         if dtype == "f32":
@@ -589,13 +602,6 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                 res["precision_vs_fp32_hip"][dt] = compare_greedy(ref, greedy_all(model, images))
                 if dt == dtype:
                     res[f"greedy_token_match_{dtype}_vs_cpu_ref"] = greedy_match(workload, model, sd, hp, N_CHECK)
-                else:
-                    with torch.no_grad():
-                        for w in range(3):                  # (a fresh model after empty_cache: plans, allocator growth, first-touch of the weights)
-                            one_step(model, images, 0, n_total, seed=w)
-                        t16, _, _ = timed_steps(model, images, 0, n_local, n_total, 10, barrier)
-                    res[f"{dt}_path"] = {"value": n_total * 10 / t16, "unit": "captions/s", "ms_per_step": t16 / 10 * 1e3, "steps": 10,
-                                         "schedule": "sequential (as `value`)"}
                 del model
                 torch.cuda.empty_cache()
             del ref
