@@ -2,7 +2,7 @@
 // (torchvision Bottleneck.conv3 / bn3 + identity + relu and layer1's downsample: encoders.py:56 -- Cin = 64 ... 256, Cout = 4 Cin.)
 //
 // dh_conv2d_nhwc_f32x runs these layers as 128 x 128 tiles: a workgroup lives for two to eight 32-k slabs, then reads its residual
-// tile and stores 64 KB.  Measured on 256 x 56 x 56 x 64 -> 256 with residual (645 us; tools in profiles/r6/f32x_conv1x1_phases.txt):
+// tile and stores 64 KB.  Measured on 256 x 56 x 56 x 64 -> 256 with residual (645 us; tools/f32x_conv1x1_bench.py, profiles/r6/f32x_conv1x1_phases.txt):
 // without the stores 437 us, without the residual loads 347 us, without either 226 us -- the three phases run one after the other
 // (two workgroups per CU, each waiting on its own memory round trips): 2.9 TB/s of algorithmic traffic on an 8 TB/s part.  Here:
 //   * linear_f32x_wreg.hip's partition: a workgroup owns 64 output columns (4 waves x 16), a wave keeps the hi AND lo fp16 planes of
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void conv1x1_f32x_stream_kernel(CsParams p) {
     const int n = n0 + 16 * wave + 4 * lq;
     const float4 sc4 = *reinterpret_cast<const float4*>(p.scale + n), sh4 = *reinterpret_cast<const float4*>(p.shift + n);
     const unsigned rd_base = (unsigned)(l15 * 128 + (((2 * lq) ^ (l15 & 7)) << 4));
-    const unsigned swz = (unsigned)((lpos ^ lr) << 4), ldb = (unsigned)p.K * 4u;
+    const unsigned swz = (unsigned)((lpos ^ lr) << 4);
 
     auto issue = [&](int buf, int rb) {                  // the fp32 block rb -> LDS buffer buf; wave w moves pieces w PPW ...
         const int m0 = rb * RL;
@@ -81,7 +81,6 @@ __global__ __launch_bounds__(256) void conv1x1_f32x_stream_kernel(CsParams p) {
             dh_lds_dma16(reinterpret_cast<const unsigned char*>(src) + swz, lds + buf * BUF + s * SLABB + g * 1024);
         }
     };
-    (void)ldb;
 
     float amax = 0.f;
     int rb = stream;

@@ -472,7 +472,8 @@ int launch(const F32xParams& p0, int mode, hipStream_t s) {
     F32xParams p = p0;
     p.range_flag = range_flag_of(s);
     if (!p.range_flag) return DH_ERR_LAUNCH;
-    p.diag = getenv("DH_F32X_DIAG") ? atoi(getenv("DH_F32X_DIAG")) : 0;
+    static const int diag = getenv("DH_F32X_DIAG") ? atoi(getenv("DH_F32X_DIAG")) : 0;      // (tools/f32x_conv1x1_bench.py: phase timing, wrong results)
+    p.diag = diag;
     // weight planes of <= 4 MB stay in every XCD's L2: walk the N tiles of one M tile back to back (the activation tile comes
     // from HBM once instead of tiles_n times)
     p.n_fast = (double)p.N * p.Kp * 4.0 <= 4.0 * 1048576.0;
