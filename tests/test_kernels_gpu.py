@@ -112,7 +112,7 @@ def _attn_ref(q, keys, vals, masked, scale):
     return torch.einsum("hl,lhd->hd", torch.softmax(energy, -1), vals).reshape(-1)
 
 
-@pytest.mark.parametrize("t", [0, 1, 5, 32, 100])
+@pytest.mark.parametrize("t", [0, 1, 5, 15, 16, 20, 23, 24, 30, 31, 32, 39, 40, 100])
 def test_attn_self_decode(hip, t):
     n_img, beam, d, h, tmax = 3, 4, 512, 8, 128
     r = n_img * beam
