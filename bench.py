@@ -594,7 +594,7 @@ def run_workload(workload, args, rank, world, dev, steps, warmup, with_cpu, dtyp
                                         "note": "fp32 storage, dense layers + convolutions as split-operand fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 "
                                                 "accumulation): logits within 1e-3 and greedy ids bit-exact vs the reference in tests/test_f32x_gpu.py"}
             # what 16-bit storage costs in greedy tokens: both 16-bit paths against the fp32 HIP path (bit-exact vs the CPU
-            # oracle on the checked images above and on rows {0, 77, 255} in tests/test_fullsize_gpu.py) over ALL bench images
+            # oracle on the checked images above and vs the reference's captions on sixteen rows in tests/test_fullsize_gpu.py) over ALL bench images
             res["precision_vs_fp32_hip"] = {"reference": "fp32 HIP path, greedy (beam 1, top_k 1), all bench images",
                                             "table": "profiles/r3/precision_c2.json, precision_c3.json (which tensor's precision buys what; round 3)"}
             for dt in [dtype] + [d for d in ("bf16", "f16") if d != dtype]:

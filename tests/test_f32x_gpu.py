@@ -124,15 +124,15 @@ def test_word_vocab_split(kind, images):
 @pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
 def test_full_batch_split(kind):
     """N = 256, V = 36,541: sampled beam-5 rows == the reference's (golden G15) under rng="torch".  (The greedy rows: all 256 captions are
-    held equal to the exact-fp32 path's below, whose rows {0, 77, 255} tests/test_fullsize_gpu.py ties to the oracle.)"""
+    held equal to the exact-fp32 path's below, sixteen rows of which tests/test_fullsize_gpu.py ties to the reference's own captions.)"""
     TF.test_fp32_full_batch_sampled_beam_rows_equal_the_reference(kind)
 
 
 @pytest.mark.parametrize("kind", ("CaptioningLSTM", "CaptioningTransformer"))
 def test_all_bench_images_equal_the_exact_fp32_path(kind):
     """bench.py's ``parity_grade_path.vs_exact_fp32_hip_all_images`` as an assertion: greedy captions of ALL 256 bench
-    images (V = 36,541, 32 tokens) on the split-operand path are identical to the exact-fp32 HIP path's -- which rows {0, 77, 255}
-    tie to the CPU oracle -- and the first-step logits agree to 1e-3 (north_star's fp32 tolerance; observed 1.5e-5 - 3.6e-5)."""
+    images (V = 36,541, 32 tokens) on the split-operand path are identical to the exact-fp32 HIP path's -- sixteen rows of which (G18)
+    tie to the reference's own captions -- and the first-step logits agree to 1e-3 (north_star's fp32 tolerance; observed 1.5e-5 - 3.6e-5)."""
     import bench
     from deephumor_amd import hip
     imgs = synth_images(256, seed=0).cuda()

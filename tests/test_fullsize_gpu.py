@@ -1,5 +1,5 @@
 """BASELINE-size runs inside ``-m gpu``: the workloads bench.py times, checked -- not only timed.
-  * fp32, 256 images, V = 36,541, greedy: rows {0, 77, 255} of the batch equal the CPU oracle's ids
+  * fp32, 256 images, V = 36,541, greedy: sixteen rows of the batch equal the captions the reference produced for them (golden G18)
   * bf16 C2 / C3 at 256 images x beam 5: run-to-run equality and 128 + 128 split (``img0``) equality at the tile
     configurations the full batch selects (gemm_bf16.hip picks tiles by workgroup count)
   * the C5 shape: fp16, 300 templates x beam 10 with labels: run-to-run equality and a 150 + 150 split
@@ -25,27 +25,25 @@ def _model(kind, dtype):
 
 
 @pytest.mark.parametrize("kind", ["CaptioningLSTM", "CaptioningTransformer"])
-def test_fp32_full_batch_greedy_rows_equal_the_oracle(kind):
-    from oracle import ref_path as R
+def test_fp32_full_batch_greedy_rows_equal_the_reference(kind):
+    """N = 256, V = 36,541, fp32: the greedy captions of sixteen images inside the batch are, token for token, the captions the REFERENCE
+    produced for them (golden G18, recorded by oracle/make_golden.py from /root/reference; rounds 1 - 5 ran the CPU oracle on rows
+    {0, 77, 255} here: 20 s of host time for three rows)."""
+    import os
+    import numpy as np
     from deephumor_amd.synth import synth_images
+    g18 = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"g18_bench_rows_{kind}.npz"))
     model, sd = _model(kind, torch.float32)
     imgs = synth_images(256, seed=0)
     with torch.no_grad():
         toks, lens = model.generate_batch(imgs.cuda(), max_len=32, beam_size=1, top_k=1)
-    for i in (0, 77, 255):
-        want = _oracle_greedy(kind, sd, model._hp, imgs, i)
-        assert toks[i, :int(lens[i])].cpu().tolist() == want, (kind, i)
+    for i in (int(j) for j in g18["images"]):
+        assert toks[i, :int(lens[i])].cpu().tolist() == g18[f"greedy_{i}"].tolist(), (kind, i)
 
 
-_ORACLE_GREEDY = {}
 _ORACLE_BEAM = {}
 
 
-def _oracle_greedy(kind, sd, hp, imgs, i):
-    from oracle import ref_path as R
-    if (kind, i) not in _ORACLE_GREEDY:
-        _ORACLE_GREEDY[(kind, i)] = R.model_generate(kind, sd, hp, imgs[i:i + 1], max_len=32, beam_size=1, top_k=1).reshape(-1).tolist()
-    return _ORACLE_GREEDY[(kind, i)]
 
 
 # What the 16-bit paths must stay within of the REFERENCE at the BASELINE shape.  Round 6 (VERDICT r5 item 5): sixteen images instead of
